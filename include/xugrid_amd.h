@@ -1,0 +1,187 @@
+/*
+ * xugrid_amd.h -- C ABI of the MI355X-native regridding engine (libxugrid_amd.so).
+ *
+ * This is the drop-in boundary for ONE hot path of Deltares/xugrid 0.15.3: regridding weight
+ * construction + sparse weight x data apply.  xugrid has no FFI of its own;
+ * the path sits behind three Python seams, and every entry point below names the seam it
+ * replaces (paths relative to the reference tree):
+ *
+ *   seam 1  the tree object returned by Ugrid2d.celltree        xugrid/ugrid/ugrid2d.py:908-921
+ *           (external numba_celltree.CellTree2d) and its methods
+ *             .intersect_faces(vertices, faces, fill_value)     xugrid/regrid/unstructured.py:124-132
+ *             .locate_points(points, tolerance)                 xugrid/regrid/unstructured.py:139,189
+ *             .compute_barycentric_weights(points, tolerance)   xugrid/ugrid/ugrid2d.py:1078
+ *   seam 2  the apply callable  self._regrid(source(K,S), A, size)  xugrid/regrid/regridder.py:41-67,
+ *           looked up at :124-141, invoked at :187; COO variant :400-409
+ *   seam 3  MatrixCSR.from_triplet(target, source, w, n, m)     xugrid/regrid/regridder.py:433-435,
+ *           xugrid/core/sparse.py:61-78,119-127
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns an int
+ *     status: 0 = ok, < 0 = error (message via xr_last_error(), thread-local).  No exception or
+ *     abort crosses the boundary.
+ *   - Host arrays are caller-owned numpy-style buffers: float64 coordinates/weights, int64
+ *     indices (np.intp, xugrid/constants.py:10), fill value -1 after ingestion.
+ *     On the device the engine keeps int32 connectivity/indices and float64 geometry.
+ *   - Functions with the suffix _dev take DEVICE pointers (HBM addresses on the current device,
+ *     e.g. torch tensor .data_ptr()) and do no host transfer; they run on the engine stream and
+ *     synchronise it before returning unless stated otherwise.
+ *   - Handles (xr_mesh, xr_csr) own HBM; they are not tied to a host thread.  Calls are
+ *     serialised by one engine-wide mutex (dask may call the apply seam from several threads,
+ *     regridder.py:177).
+ *   - There is NO CPU fallback: without a HIP device every compute entry point fails with
+ *     XR_ERR_NO_DEVICE.
+ */
+#ifndef XUGRID_AMD_H
+#define XUGRID_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XR_OK 0
+#define XR_ERR_INVALID (-1)   /* bad argument (maps to ValueError/TypeError on the Python side) */
+#define XR_ERR_NO_DEVICE (-2) /* no HIP device / HIP runtime error at init */
+#define XR_ERR_HIP (-3)       /* HIP runtime error during a call */
+#define XR_ERR_LIMIT (-4)     /* size limit exceeded (int32 index range, max vertices per face) */
+
+/* Reducer ids.  Names and semantics: xugrid/regrid/reduce.py:16-272. */
+#define XR_MEAN 0
+#define XR_HARMONIC_MEAN 1
+#define XR_GEOMETRIC_MEAN 2
+#define XR_SUM 3
+#define XR_MINIMUM 4
+#define XR_MAXIMUM 5
+#define XR_MODE 6
+#define XR_PERCENTILE 7 /* + percentile argument; median = 50 */
+#define XR_FIRST_ORDER_CONSERVATIVE 8 /* = conductance */
+#define XR_MAX_OVERLAP 9
+
+/* Source data dtypes accepted by the apply seam (output is always float64, regridder.py:44). */
+#define XR_F64 0
+#define XR_F32 1
+
+#define XR_MAX_FACE_NODES 32 /* numba_celltree MAX_N_VERTEX */
+
+typedef struct xr_mesh xr_mesh; /* device-resident Ugrid2d face topology + spatial index */
+typedef struct xr_csr xr_csr;   /* device-resident MatrixCSR weights */
+
+/* ---- engine ---------------------------------------------------------------------------- */
+const char *xr_last_error(void);
+/* Number of HIP devices (0 if none / no runtime). */
+int xr_device_count(int *count);
+/* Bind the engine (this process) to one device; creates the engine stream.  One process per
+ * GPU is the multi-GPU model (torch.distributed ranks call this with LOCAL_RANK).  Calling any
+ * compute entry point before xr_init implies xr_init(0). */
+int xr_init(int device);
+int xr_current_device(int *device);
+/* Release cached HBM held by the engine's block pool. */
+int xr_trim_pool(void);
+int xr_version(void);
+
+/* ---- seam 1: mesh handle = CellTree2d(vertices, faces, fill_value) --------------------- */
+/* ugrid2d.py:915-921.  node_xy: float64[n_node,2] (node_coordinates, ugridbase.py:576-579);
+ * faces: int32 or int64 [n_face, n_max_node] dense face_node_connectivity with `fill_value`
+ * in unused slots (faces_itemsize = 4 or 8).  Uploads the raw arrays only; the derived state
+ * (CCW-normalised connectivity, per-face length/bbox/area, spatial index) is built on the
+ * device lazily by the first call that needs it, or explicitly by xr_mesh_prepare /
+ * xr_mesh_build_index. */
+int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int faces_itemsize,
+                   int64_t n_face, int64_t n_max_node, int64_t fill_value, xr_mesh **out);
+int xr_mesh_destroy(xr_mesh *mesh);
+int xr_mesh_info(const xr_mesh *mesh, int64_t *n_node, int64_t *n_face, int64_t *n_max_node);
+/* Per-face preparation on the device: fill->-1, polygon length, CCW normalisation, bbox, area. */
+int xr_mesh_prepare(xr_mesh *mesh);
+/* Spatial index over the faces of this mesh (the "tree" side): hierarchical uniform grid. */
+int xr_mesh_build_index(xr_mesh *mesh);
+/* Drop all derived state (prepare + index); used by benchmarks to time the whole path. */
+int xr_mesh_invalidate(xr_mesh *mesh);
+/* Face areas, connectivity.area (xugrid/ugrid/connectivity.py:615-633) -> float64[n_face]. */
+int xr_mesh_area(xr_mesh *mesh, double *area_out);
+/* Face centroids, connectivity.centroids (connectivity.py:636-664) -> float64[n_face,2]. */
+int xr_mesh_centroids(xr_mesh *mesh, double *centroids_out);
+/* CCW-normalised connectivity as held on the device -> int64[n_face, n_max_node]. */
+int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out);
+
+/* CellTree2d.intersect_faces (unstructured.py:124-132) + relative normalisation (:133-134)
+ * + MatrixCSR.from_triplet (regridder.py:433-435): all (query face, tree face) pairs with
+ * intersection area > 0, as a CSR matrix with one row per QUERY (= regridding target) face,
+ * columns = TREE (= source) faces sorted ascending within a row, data = overlap area, or
+ * area / tree-face area if relative != 0.  The result stays in HBM. */
+int xr_overlap(xr_mesh *tree, xr_mesh *query, int relative, xr_csr **out);
+/* Statistics of the last xr_overlap on this tree: bbox candidate pairs tested by the clipper. */
+int xr_overlap_stats(const xr_mesh *tree, int64_t *n_candidates);
+
+/* CellTree2d.locate_points(points, tolerance) (unstructured.py:139,189; ugridbase.py:1323).
+ * points float64[n,2] -> face index int64[n], -1 = not found.  tolerance < 0 selects the
+ * default 1e-12 x max bbox diagonal (ugridbase.py:1165-1170).  A point within tolerance of an
+ * edge shared by several faces is assigned to the LOWEST face index. */
+int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tolerance,
+                     int64_t *face_index_out);
+/* CellTree2d.compute_barycentric_weights(points, tolerance) (ugrid2d.py:1054-1078).
+ * -> face index int64[n] and float64[n, n_max_node] generalized barycentric weights
+ * (all zero, face -1 when outside). */
+int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolerance,
+                   int64_t *face_index_out, double *weights_out);
+
+/* ---- seam 3: MatrixCSR handle ----------------------------------------------------------- */
+int xr_csr_info(const xr_csr *csr, int64_t *n, int64_t *m, int64_t *nnz);
+/* Copy out as the reference's MatrixCSR fields (core/sparse.py:81-137): data float64[nnz],
+ * indices int64[nnz], indptr int64[n+1]. */
+int xr_csr_download(const xr_csr *csr, double *data, int64_t *indices, int64_t *indptr);
+/* Build a device CSR from host MatrixCSR fields (from_weights / from_dataset path,
+ * regridder.py:299-312,334-348). */
+int xr_csr_upload(const double *data, const int64_t *indices, const int64_t *indptr, int64_t n,
+                  int64_t m, int64_t nnz, xr_csr **out);
+/* MatrixCSR.from_triplet(row, col, data, n, m): rows must be non-decreasing
+ * (core/sparse.py:65); indptr = [0, cumsum(bincount(row, minlength=n))] computed on device. */
+int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *data, int64_t nnz,
+                        int64_t n, int64_t m, xr_csr **out);
+int xr_csr_destroy(xr_csr *csr);
+
+/* ---- seam 2: apply ---------------------------------------------------------------------- */
+/* make_regrid(func)._regrid(source, A, size), regridder.py:41-67.
+ * source: (K, S) row-major, S = csr.m, dtype XR_F64 / XR_F32; out: float64 (K, T), T = csr.n,
+ * NaN for empty rows.  `percentile` is used by XR_PERCENTILE only (0..100, reduce.py:241-243). */
+int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *source,
+                 int source_dtype, int64_t K, double *out);
+int xr_apply_csr_dev(const xr_csr *csr, int method, double percentile, const void *source_dev,
+                     int source_dtype, int64_t K, double *out_dev);
+/* CentroidLocatorRegridder._regrid, regridder.py:400-409: out[k,row[i]] = source[k,col[i]],
+ * NaN elsewhere.  rows must be unique (they are target indices of located centroids). */
+int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,
+                 const void *source, int source_dtype, int64_t K, int64_t S, double *out);
+
+/* Multi-GPU (source faces sharded over ranks).  For the sum-decomposable
+ * reducer `mean`: per-rank partial sums over this rank's columns,
+ *   numden_dev[0][k][t] = sum_j w_j v_j (v not NaN),  numden_dev[1][k][t] = sum_j w_j (v not NaN),
+ * laid out float64 [2, K, T]; the ranks then reduce-scatter (RCCL, sum) and finalise. */
+int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int source_dtype,
+                              int64_t K, double *numden_dev);
+/* out[i] = den[i] == 0 ? NaN : num[i] / den[i]  for i < count (mean's epilogue, reduce.py:24-27). */
+int xr_finalize_mean_dev(const double *num_dev, const double *den_dev, int64_t count,
+                         double *out_dev);
+
+/* ---- raw HBM helpers for hosts that do not bring their own allocator -------------------- */
+int xr_dev_alloc(int64_t bytes, void **ptr_out);
+int xr_dev_free(void *ptr);
+int xr_dev_upload(void *dst_dev, const void *src_host, int64_t bytes);
+int xr_dev_download(void *dst_host, const void *src_dev, int64_t bytes);
+int xr_dev_sync(void);
+
+/* ---- in-library kernel timing (HIP events on the engine stream) -------------------------- */
+/* When enabled every kernel launch is bracketed by hipEvents on the engine stream; durations
+ * are accumulated per kernel name. */
+int xr_prof_enable(int on);
+int xr_prof_reset(void);
+/* Number of distinct kernels recorded since the last reset. */
+int xr_prof_count(int *count);
+/* i-th record: name (copied, NUL-terminated, at most name_cap bytes), launches, total ms. */
+int xr_prof_get(int i, char *name, int name_cap, int64_t *launches, double *total_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XUGRID_AMD_H */

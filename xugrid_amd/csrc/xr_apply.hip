@@ -1,0 +1,635 @@
+// xr_apply.hip -- the sparse weight x data apply and the MatrixCSR handle.
+//
+// Replaces make_regrid(func)._regrid (xugrid/regrid/regridder.py:41-67) with one kernel
+// specialisation per reducer of xugrid/regrid/reduce.py, CentroidLocatorRegridder._regrid
+// (regridder.py:400-409) and MatrixCSR.from_triplet / MatrixCOO.to_csr
+// (xugrid/core/sparse.py:61-78,119-127).
+//
+// Reducer semantics are those of reduce.py line by line; entries of a
+// row are consumed in CSR order, one thread per (row, k-tile), so that results are
+// bit-identical to the reference loop on the same CSR (except exp/log in geometric_mean).
+//
+// HBM layout: source (K, S) row-major, out (K, T) row-major (regridder.py:163, :44);
+// CSR = indptr i32[T+1], indices i32[nnz], data f64[nnz].
+#include <vector>
+
+#include "xr_objects.h"
+
+namespace xr {
+
+static constexpr int AP_BLOCK = 256;
+static constexpr int KT = 8; // k-values per thread in the streaming kernel
+
+template <typename SRC> __device__ __forceinline__ double ld_src(const SRC *p, int64_t i) { return (double)p[i]; }
+
+// ---------------------------------------------------------------------------------------------
+// streaming reducers: constant-size state per (row, k), one pass over the row
+// ---------------------------------------------------------------------------------------------
+template <int METHOD> struct Red;
+
+template <> struct Red<XR_MEAN> { // reduce.py:16-27
+    double vsum = 0.0, wsum = 0.0;
+    __device__ void add(double v, double w, double) {
+        if (v != v) return;
+        vsum += w * v;
+        wsum += w;
+    }
+    __device__ double fin() const { return wsum == 0 ? NAN : vsum / wsum; }
+};
+template <> struct Red<XR_HARMONIC_MEAN> { // reduce.py:30-42
+    double v_agg = 0.0, w_sum = 0.0;
+    __device__ void add(double v, double w, double) {
+        if (v != v || v == 0) return;
+        if (w > 0) {
+            w_sum += w;
+            v_agg += w / v;
+        }
+    }
+    __device__ double fin() const { return (v_agg == 0 || w_sum == 0) ? NAN : w_sum / v_agg; }
+};
+template <> struct Red<XR_GEOMETRIC_MEAN> { // reduce.py:45-72; normsum = sum of ALL row weights
+    double v_agg = 0.0, w_sum = 0.0;
+    bool neg = false;
+    __device__ void add(double v, double w, double normsum) {
+        if (neg) return;
+        const double wn = w / normsum;
+        if (v > 0 && wn > 0) {
+            v_agg += wn * log(fabs(v));
+            w_sum += wn;
+        } else if (v < 0) {
+            neg = true;
+        }
+    }
+    __device__ double fin() const { return (neg || w_sum == 0) ? NAN : exp((1.0 / w_sum) * v_agg); }
+};
+template <> struct Red<XR_SUM> { // reduce.py:75-87
+    double v_sum = 0.0, w_sum = 0.0;
+    __device__ void add(double v, double w, double) {
+        if (v != v) return;
+        v_sum += v;
+        w_sum += w;
+    }
+    __device__ double fin() const { return w_sum == 0 ? NAN : v_sum; }
+};
+template <> struct Red<XR_MINIMUM> { // reduce.py:90-106
+    double v_min = INFINITY, w_max = 0.0;
+    __device__ void add(double v, double w, double) {
+        if (v != v) return;
+        if (v < v_min) v_min = v;
+        if (w > w_max) w_max = w;
+    }
+    __device__ double fin() const { return w_max == 0.0 ? NAN : v_min; }
+};
+template <> struct Red<XR_MAXIMUM> { // reduce.py:109-123
+    double v_max = -INFINITY, w_max = 0.0;
+    __device__ void add(double v, double w, double) {
+        if (v != v) return;
+        if (v > v_max) v_max = v;
+        if (w > w_max) w_max = w;
+    }
+    __device__ double fin() const { return w_max == 0.0 ? NAN : v_max; }
+};
+template <> struct Red<XR_FIRST_ORDER_CONSERVATIVE> { // reduce.py:206-222
+    double v_agg = 0.0, w_sum = 0.0;
+    __device__ void add(double v, double w, double) {
+        if (v != v) return;
+        v_agg += v * w;
+        w_sum += w;
+    }
+    __device__ double fin() const { return w_sum == 0 ? NAN : v_agg; }
+};
+template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238
+    double w_max = 0.0, v_max = -INFINITY;
+    __device__ void add(double v, double w, double) {
+        if (v != v) return;
+        if ((w > w_max) || (w == w_max && v > v_max)) {
+            w_max = w;
+            v_max = v;
+        }
+    }
+    __device__ double fin() const { return w_max == 0.0 ? NAN : v_max; }
+};
+
+template <int METHOD, typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+               const double *__restrict__ data, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+               double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
+    const int s = indptr[t], e = indptr[t + 1];
+    if (s == e) { // regridder.py:44,62: rows without entries stay NaN
+        for (int kk = 0; kk < kn; kk++) out[(k0 + kk) * T + t] = NAN;
+        return;
+    }
+    double normsum = 0.0;
+    if (METHOD == XR_GEOMETRIC_MEAN) {
+        for (int j = s; j < e; j++) normsum += data[j];
+    }
+    Red<METHOD> red[KT];
+    const SRC *src = source + k0 * S;
+    for (int j = s; j < e; j++) {
+        const int64_t col = indices[j];
+        const double w = data[j];
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++) {
+            if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; kk++) {
+        if (kk < kn) {
+            double r = red[kk].fin();
+            if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+            out[(k0 + kk) * T + t] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// workspace reducers: mode and percentile.  One thread per (row, k); per-row scratch lives in a
+// global workspace laid out like the CSR data (ws[k_local][nnz]).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool nan_le(double a, double b) { // nanpercentile.py:19-27
+    if (a != a) return false;
+    if (b != b) return true;
+    return a < b;
+}
+__device__ __forceinline__ void dswap(double *A, int i, int j) {
+    const double t = A[i];
+    A[i] = A[j];
+    A[j] = t;
+}
+__device__ int q_partition(double *A, int low, int high) { // nanpercentile.py:30-63
+    const int mid = (low + high) >> 1;
+    if (nan_le(A[mid], A[low])) dswap(A, low, mid);
+    if (nan_le(A[high], A[mid])) dswap(A, high, mid);
+    if (nan_le(A[mid], A[low])) dswap(A, low, mid);
+    const double pivot = A[mid];
+    dswap(A, high, mid);
+    int i = low, j = high - 1;
+    for (;;) {
+        while (i < high && nan_le(A[i], pivot)) i++;
+        while (j >= low && nan_le(pivot, A[j])) j--;
+        if (i >= j) break;
+        dswap(A, i, j);
+        i++;
+        j--;
+    }
+    dswap(A, i, high);
+    return i;
+}
+__device__ double q_select(double *A, int k, int low, int high) { // nanpercentile.py:66-77
+    int i = q_partition(A, low, high);
+    while (i != k) {
+        if (i < k) {
+            low = i + 1;
+            i = q_partition(A, low, high);
+        } else {
+            high = i - 1;
+            i = q_partition(A, low, high);
+        }
+    }
+    return A[k];
+}
+__device__ void q_select_two(double *A, int k, int low, int high, double &lo, double &hi) { // :80-102
+    for (;;) {
+        const int i = q_partition(A, low, high);
+        if (i < k) {
+            low = i + 1;
+        } else if (i > k + 1) {
+            high = i - 1;
+        } else if (i == k) {
+            q_select(A, k + 1, i + 1, high);
+            break;
+        } else {
+            q_select(A, k, low, i - 1);
+            break;
+        }
+    }
+    lo = A[k];
+    hi = A[k + 1];
+}
+
+template <int METHOD, typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_workspace(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                  const double *__restrict__ data, int64_t T, int64_t S, int64_t nnz,
+                  const SRC *__restrict__ source, int64_t k_base, double p, double *__restrict__ ws,
+                  double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const int64_t k = k_base + blockIdx.y;
+    const int s = indptr[t], e = indptr[t + 1], n = e - s;
+    double res = NAN;
+    if (n > 0) {
+        const SRC *src = source + k * S;
+        double *w_row = ws + (int64_t)blockIdx.y * nnz + s;
+        if (METHOD == XR_MODE) { // reduce.py:126-158
+            for (int i = 0; i < n; i++) w_row[i] = data[s + i];
+            int w_sum = 0;
+            double w_max = 0.0;
+            for (int i = 0; i < n; i++) {
+                const double v = ld_src(src, indices[s + i]);
+                if (v != v) continue;
+                const double w = data[s + i];
+                if (w > w_max) w_max = w;
+                w_sum += 1;
+                for (int j = 0; j < i; j++) {
+                    if (ld_src(src, indices[s + j]) == v) {
+                        w_row[j] += w;
+                        break;
+                    }
+                }
+            }
+            if (!(w_sum == 0 || w_max == 0.0)) {
+                w_max = 0;
+                double mode_value = ld_src(src, indices[s]);
+                for (int i = 0; i < n; i++) {
+                    const double v = ld_src(src, indices[s + i]);
+                    if (v == v) {
+                        const double wa = w_row[i];
+                        if ((wa > w_max) || (wa == w_max && v > mode_value)) {
+                            w_max = wa;
+                            mode_value = v;
+                        }
+                    }
+                }
+                res = mode_value;
+            }
+        } else { // percentile, reduce.py:161-203
+            double w_max = 0.0;
+            for (int i = 0; i < n; i++) {
+                const double w = data[s + i];
+                if (w > w_max) w_max = w;
+            }
+            if (w_max != 0.0) {
+                if (p == 0 || p == 100) {
+                    double v_ext = p == 0 ? INFINITY : -INFINITY, wm = 0.0;
+                    for (int i = 0; i < n; i++) {
+                        const double v = ld_src(src, indices[s + i]);
+                        if (v != v) continue;
+                        if (p == 0 ? (v < v_ext) : (v > v_ext)) v_ext = v;
+                        const double w = data[s + i];
+                        if (w > wm) wm = w;
+                    }
+                    res = wm == 0.0 ? NAN : v_ext;
+                } else {
+                    int m = 0;
+                    for (int i = 0; i < n; i++) {
+                        const double v = ld_src(src, indices[s + i]);
+                        if (v == v) w_row[m++] = v;
+                    }
+                    if (m == 1) {
+                        res = w_row[0];
+                    } else if (m > 1) {
+                        const double rank = 1 + (double)(m - 1) * p / 100.0;
+                        const double f = floor(rank);
+                        const double frac = rank - f;
+                        double lower, upper;
+                        q_select_two(w_row, (int)(f - 1), 0, m - 1, lower, upper);
+                        res = lower * (1 - frac) + upper * frac;
+                    }
+                }
+            }
+        }
+    }
+    out[k * T + t] = res;
+}
+
+// mean partials for source-sharded multi-GPU: num = sum w v, den = sum w over non-NaN v
+template <typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_partial_mean(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                     const double *__restrict__ data, int64_t T, int64_t S, const SRC *__restrict__ source,
+                     int64_t K, double *__restrict__ num, double *__restrict__ den) {
+    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
+    const int s = indptr[t], e = indptr[t + 1];
+    Red<XR_MEAN> red[KT];
+    const SRC *src = source + k0 * S;
+    for (int j = s; j < e; j++) {
+        const int64_t col = indices[j];
+        const double w = data[j];
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++)
+            if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, 0.0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; kk++) {
+        if (kk < kn) {
+            num[(k0 + kk) * T + t] = red[kk].vsum;
+            den[(k0 + kk) * T + t] = red[kk].wsum;
+        }
+    }
+}
+
+__global__ void k_finalize_mean(const double *__restrict__ num, const double *__restrict__ den, int64_t n,
+                                double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = den[i] == 0 ? NAN : num[i] / den[i];
+}
+
+template <typename SRC>
+__global__ void k_apply_coo(const int32_t *__restrict__ row, const int32_t *__restrict__ col, int64_t nnz, int64_t T,
+                            int64_t S, const SRC *__restrict__ source, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nnz) return;
+    const int64_t k = blockIdx.y;
+    out[k * T + row[i]] = ld_src(source + k * S, col[i]);
+}
+
+template <int METHOD, typename SRC>
+static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *out) {
+    dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
+    XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+              csr->indices.get(), csr->data.get(), csr->n, csr->m, src, K, out);
+}
+
+template <int METHOD, typename SRC>
+static void launch_workspace(const xr_csr *csr, const SRC *src, int64_t K, double p, double *out) {
+    // scratch budget: at most ~512 MB of per-(k,row) workspace at a time
+    int64_t kchunk = csr->nnz > 0 ? ((int64_t)64 << 20) / csr->nnz : K;
+    if (kchunk < 1) kchunk = 1;
+    if (kchunk > K) kchunk = K;
+    if (kchunk > 65535) kchunk = 65535;
+    DevBuf<double> ws((size_t)kchunk * (size_t)(csr->nnz > 0 ? csr->nnz : 1));
+    for (int64_t k0 = 0; k0 < K; k0 += kchunk) {
+        const int64_t kc = (K - k0) < kchunk ? (K - k0) : kchunk;
+        dim3 grid(div_up(csr->n, AP_BLOCK), (unsigned)kc);
+        XR_LAUNCH("apply_workspace", (k_apply_workspace<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), csr->n, csr->m, csr->nnz, src, k0, p, ws.get(), out);
+    }
+}
+
+template <typename SRC>
+static void apply_dispatch(const xr_csr *csr, int method, double p, const SRC *src, int64_t K, double *out) {
+    if (csr->n == 0 || K == 0) return;
+    switch (method) {
+    case XR_MEAN: launch_stream<XR_MEAN, SRC>(csr, src, K, out); break;
+    case XR_HARMONIC_MEAN: launch_stream<XR_HARMONIC_MEAN, SRC>(csr, src, K, out); break;
+    case XR_GEOMETRIC_MEAN: launch_stream<XR_GEOMETRIC_MEAN, SRC>(csr, src, K, out); break;
+    case XR_SUM: launch_stream<XR_SUM, SRC>(csr, src, K, out); break;
+    case XR_MINIMUM: launch_stream<XR_MINIMUM, SRC>(csr, src, K, out); break;
+    case XR_MAXIMUM: launch_stream<XR_MAXIMUM, SRC>(csr, src, K, out); break;
+    case XR_FIRST_ORDER_CONSERVATIVE: launch_stream<XR_FIRST_ORDER_CONSERVATIVE, SRC>(csr, src, K, out); break;
+    case XR_MAX_OVERLAP: launch_stream<XR_MAX_OVERLAP, SRC>(csr, src, K, out); break;
+    case XR_MODE: launch_workspace<XR_MODE, SRC>(csr, src, K, p, out); break;
+    case XR_PERCENTILE:
+        XR_REQUIRE(p >= 0.0 && p <= 100.0, XR_ERR_INVALID,
+                   "percentile must be in the range [0, 100], received: %g", p);
+        launch_workspace<XR_PERCENTILE, SRC>(csr, src, K, p, out);
+        break;
+    default: XR_REQUIRE(false, XR_ERR_INVALID, "unknown reducer id %d", method);
+    }
+}
+
+static void apply_dev(const xr_csr *csr, int method, double p, const void *src, int dtype, int64_t K, double *out) {
+    XR_REQUIRE(dtype == XR_F64 || dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", dtype);
+    if (dtype == XR_F64) apply_dispatch<double>(csr, method, p, static_cast<const double *>(src), K, out);
+    else apply_dispatch<float>(csr, method, p, static_cast<const float *>(src), K, out);
+}
+
+__global__ void k_narrow_i64(const int64_t *__restrict__ in, int32_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+__global__ void k_widen_i32(const int32_t *__restrict__ in, int64_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void k_bincount(const int32_t *__restrict__ row, int64_t nnz, int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < nnz) atomicAdd(&count[row[i]], 1);
+}
+
+static void upload_narrow(const int64_t *host, int64_t n, int32_t *dev) {
+    if (n <= 0) return;
+    DevBuf<int64_t> wide((size_t)n);
+    h2d(wide.get(), host, sizeof(int64_t) * (size_t)n);
+    XR_LAUNCH("narrow_i64", k_narrow_i64, dim3(div_up(n, 256)), dim3(256), 0, wide.get(), dev, n);
+}
+
+static void download_widen(const int32_t *dev, int64_t n, int64_t *host) {
+    if (n <= 0) return;
+    DevBuf<int64_t> wide((size_t)n);
+    XR_LAUNCH("widen_i32", k_widen_i32, dim3(div_up(n, 256)), dim3(256), 0, dev, wide.get(), n);
+    XR_HIP(hipMemcpyAsync(host, wide.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, engine().stream));
+    stream_sync();
+}
+
+} // namespace xr
+
+using namespace xr;
+
+extern "C" {
+
+int xr_csr_info(const xr_csr *csr, int64_t *n, int64_t *m, int64_t *nnz) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_info: NULL csr");
+    if (n) *n = csr->n;
+    if (m) *m = csr->m;
+    if (nnz) *nnz = csr->nnz;
+    XR_API_END
+}
+
+int xr_csr_download(const xr_csr *csr, double *data, int64_t *indices, int64_t *indptr) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_download: NULL csr");
+    if (data && csr->nnz > 0) {
+        XR_HIP(hipMemcpyAsync(data, csr->data.get(), sizeof(double) * (size_t)csr->nnz, hipMemcpyDeviceToHost,
+                              engine().stream));
+        stream_sync();
+    }
+    if (indices) download_widen(csr->indices.get(), csr->nnz, indices);
+    if (indptr) download_widen(csr->indptr.get(), csr->n + 1, indptr);
+    XR_API_END
+}
+
+int xr_csr_upload(const double *data, const int64_t *indices, const int64_t *indptr, int64_t n, int64_t m,
+                  int64_t nnz, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out && indptr && (nnz == 0 || (data && indices)), XR_ERR_INVALID, "xr_csr_upload: NULL argument");
+    XR_REQUIRE(n >= 0 && m >= 0 && nnz >= 0, XR_ERR_INVALID, "xr_csr_upload: negative sizes");
+    XR_REQUIRE(n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 31), XR_ERR_LIMIT,
+               "xr_csr_upload: matrix exceeds the int32 index range");
+    XR_REQUIRE(indptr[0] == 0 && indptr[n] == nnz, XR_ERR_INVALID, "xr_csr_upload: indptr does not span [0, nnz]");
+    int64_t max_row = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t d = indptr[i + 1] - indptr[i];
+        XR_REQUIRE(d >= 0, XR_ERR_INVALID, "xr_csr_upload: indptr is not non-decreasing at row %lld", (long long)i);
+        if (d > max_row) max_row = d;
+    }
+    for (int64_t i = 0; i < nnz; i++)
+        XR_REQUIRE(indices[i] >= 0 && indices[i] < m, XR_ERR_INVALID,
+                   "xr_csr_upload: column index %lld outside [0,%lld)", (long long)indices[i], (long long)m);
+    xr_csr *csr = new xr_csr();
+    try {
+        csr->n = n; csr->m = m; csr->nnz = nnz;
+        csr->max_row = (int32_t)max_row;
+        csr->indptr.alloc((size_t)n + 1);
+        csr->indices.alloc((size_t)nnz);
+        csr->data.alloc((size_t)nnz);
+        upload_narrow(indptr, n + 1, csr->indptr.get());
+        upload_narrow(indices, nnz, csr->indices.get());
+        h2d(csr->data.get(), data, sizeof(double) * (size_t)nnz);
+        stream_sync();
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *data, int64_t nnz, int64_t n,
+                        int64_t m, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out && (nnz == 0 || (row && col && data)), XR_ERR_INVALID, "xr_csr_from_triplet: NULL argument");
+    XR_REQUIRE(n >= 0 && m >= 0 && nnz >= 0, XR_ERR_INVALID, "xr_csr_from_triplet: negative sizes");
+    XR_REQUIRE(n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 31), XR_ERR_LIMIT,
+               "xr_csr_from_triplet: matrix exceeds the int32 index range");
+    for (int64_t i = 0; i < nnz; i++) {
+        XR_REQUIRE(row[i] >= 0 && row[i] < n && col[i] >= 0 && col[i] < m, XR_ERR_INVALID,
+                   "xr_csr_from_triplet: entry %lld outside the %lld x %lld matrix", (long long)i, (long long)n,
+                   (long long)m);
+        XR_REQUIRE(i == 0 || row[i] >= row[i - 1], XR_ERR_INVALID,
+                   "xr_csr_from_triplet: rows must be sorted (core/sparse.py:65)");
+    }
+    xr_csr *csr = new xr_csr();
+    try {
+        csr->n = n; csr->m = m; csr->nnz = nnz;
+        csr->indptr.alloc((size_t)n + 1);
+        csr->indices.alloc((size_t)nnz);
+        csr->data.alloc((size_t)nnz);
+        DevBuf<int32_t> row32((size_t)nnz), count((size_t)(n > 0 ? n : 1));
+        upload_narrow(row, nnz, row32.get());
+        upload_narrow(col, nnz, csr->indices.get());
+        h2d(csr->data.get(), data, sizeof(double) * (size_t)nnz);
+        XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)(n > 0 ? n : 1), engine().stream));
+        if (nnz > 0) XR_LAUNCH("bincount", k_bincount, dim3(div_up(nnz, 256)), dim3(256), 0, row32.get(), nnz, count.get());
+        exclusive_scan_i32(count.get(), csr->indptr.get(), n);
+        stream_sync();
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_csr_destroy(xr_csr *csr) {
+    XR_API_BEGIN
+    if (csr) {
+        stream_sync();
+        delete csr;
+    }
+    XR_API_END
+}
+
+int xr_apply_csr_dev(const xr_csr *csr, int method, double percentile, const void *source_dev, int source_dtype,
+                     int64_t K, double *out_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && (source_dev || csr->m == 0 || K == 0) && (out_dev || csr->n == 0 || K == 0), XR_ERR_INVALID,
+               "xr_apply_csr_dev: NULL argument");
+    XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_csr_dev: negative K");
+    apply_dev(csr, method, percentile, source_dev, source_dtype, K, out_dev);
+    stream_sync();
+    XR_API_END
+}
+
+int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *source, int source_dtype, int64_t K,
+                 double *out) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && (source || csr->m == 0 || K == 0) && (out || csr->n == 0 || K == 0), XR_ERR_INVALID,
+               "xr_apply_csr: NULL argument");
+    XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_csr: negative K");
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
+               source_dtype);
+    const size_t esz = source_dtype == XR_F64 ? 8 : 4;
+    const size_t n_src = (size_t)K * (size_t)csr->m, n_out = (size_t)K * (size_t)csr->n;
+    DevBuf<char> src(n_src * esz);
+    DevBuf<double> dst(n_out);
+    h2d(src.get(), source, n_src * esz);
+    apply_dev(csr, method, percentile, src.get(), source_dtype, K, dst.get());
+    if (n_out > 0) {
+        XR_HIP(hipMemcpyAsync(out, dst.get(), n_out * sizeof(double), hipMemcpyDeviceToHost, engine().stream));
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T, const void *source, int source_dtype,
+                 int64_t K, int64_t S, double *out) {
+    XR_API_BEGIN
+    XR_REQUIRE(nnz >= 0 && T >= 0 && K >= 0 && S >= 0, XR_ERR_INVALID, "xr_apply_coo: negative sizes");
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
+               source_dtype);
+    XR_REQUIRE(T < ((int64_t)1 << 31) && S < ((int64_t)1 << 31) && K < 65536, XR_ERR_LIMIT, "xr_apply_coo: too large");
+    for (int64_t i = 0; i < nnz; i++)
+        XR_REQUIRE(row[i] >= 0 && row[i] < T && col[i] >= 0 && col[i] < S, XR_ERR_INVALID,
+                   "xr_apply_coo: entry %lld out of range", (long long)i);
+    const size_t esz = source_dtype == XR_F64 ? 8 : 4;
+    const size_t n_src = (size_t)K * (size_t)S, n_out = (size_t)K * (size_t)T;
+    DevBuf<char> src(n_src * esz);
+    DevBuf<double> dst(n_out);
+    DevBuf<int32_t> r32((size_t)nnz), c32((size_t)nnz);
+    h2d(src.get(), source, n_src * esz);
+    upload_narrow(row, nnz, r32.get());
+    upload_narrow(col, nnz, c32.get());
+    fill_f64(dst.get(), NAN, (int64_t)n_out);
+    if (nnz > 0 && K > 0) {
+        dim3 grid(div_up(nnz, 256), (unsigned)K);
+        if (source_dtype == XR_F64)
+            XR_LAUNCH("apply_coo", k_apply_coo<double>, grid, dim3(256), 0, r32.get(), c32.get(), nnz, T, S,
+                      reinterpret_cast<const double *>(src.get()), dst.get());
+        else
+            XR_LAUNCH("apply_coo", k_apply_coo<float>, grid, dim3(256), 0, r32.get(), c32.get(), nnz, T, S,
+                      reinterpret_cast<const float *>(src.get()), dst.get());
+    }
+    if (n_out > 0) {
+        XR_HIP(hipMemcpyAsync(out, dst.get(), n_out * sizeof(double), hipMemcpyDeviceToHost, engine().stream));
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int source_dtype, int64_t K,
+                              double *numden_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && numden_dev, XR_ERR_INVALID, "xr_apply_partial_mean_dev: NULL argument");
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
+               source_dtype);
+    if (csr->n > 0 && K > 0) {
+        dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
+        double *num = numden_dev, *den = numden_dev + K * csr->n;
+        if (source_dtype == XR_F64)
+            XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<double>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), csr->n, csr->m, static_cast<const double *>(source_dev), K,
+                      num, den);
+        else
+            XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<float>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), csr->n, csr->m, static_cast<const float *>(source_dev), K,
+                      num, den);
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_finalize_mean_dev(const double *num_dev, const double *den_dev, int64_t count, double *out_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(count >= 0, XR_ERR_INVALID, "xr_finalize_mean_dev: negative count");
+    if (count > 0) {
+        XR_REQUIRE(num_dev && den_dev && out_dev, XR_ERR_INVALID, "xr_finalize_mean_dev: NULL argument");
+        XR_LAUNCH("finalize_mean", k_finalize_mean, dim3(div_up(count, 256)), dim3(256), 0, num_dev, den_dev, count,
+                  out_dev);
+    }
+    stream_sync();
+    XR_API_END
+}
+
+} // extern "C"

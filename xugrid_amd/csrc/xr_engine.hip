@@ -1,0 +1,295 @@
+// xr_engine.hip -- engine context, HBM block pool, error reporting, kernel timing, raw HBM helpers.
+#include <cstdarg>
+
+#include "xr_internal.h"
+
+namespace xr {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+std::recursive_mutex &engine_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
+static Engine g_engine;
+
+void engine_init(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); xugrid_amd has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        throw Failure{XR_ERR_NO_DEVICE};
+    }
+    XR_REQUIRE(device >= 0 && device < count, XR_ERR_INVALID, "device %d out of range [0,%d)", device, count);
+    if (g_engine.device == device && g_engine.stream) return;
+    XR_REQUIRE(g_engine.device < 0, XR_ERR_INVALID,
+               "engine already bound to device %d; one process per GPU", g_engine.device);
+    XR_HIP(hipSetDevice(device));
+    XR_HIP(hipStreamCreateWithFlags(&g_engine.stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    XR_HIP(hipGetDeviceProperties(&prop, device));
+    g_engine.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    XR_HIP(hipHostMalloc(&g_engine.pinned, 4096, hipHostMallocDefault));
+    g_engine.device = device;
+}
+
+Engine &engine() {
+    if (g_engine.device < 0) engine_init(0);
+    return g_engine;
+}
+
+// ---------------------------------------------------------------------------------------------
+// block pool: power-of-two-ish size classes (1/4-octave), free lists per class
+// ---------------------------------------------------------------------------------------------
+static std::map<void *, size_t> g_live;                  // ptr -> class size
+static std::multimap<size_t, void *> g_free;             // class size -> ptr
+
+static size_t size_class(size_t bytes) {
+    size_t b = bytes < 4096 ? 4096 : bytes;
+    size_t p = 4096;
+    while (p < b) p <<= 1;
+    // quarter-octave steps to limit internal waste to 25 %
+    size_t q = p >> 1;
+    for (int i = 1; i <= 3; i++) {
+        size_t c = q + (q >> 2) * i;
+        if (c >= b) return c;
+    }
+    return p;
+}
+
+void *pool_alloc(size_t bytes) {
+    engine();
+    size_t c = size_class(bytes);
+    auto it = g_free.find(c);
+    void *p = nullptr;
+    if (it != g_free.end()) {
+        p = it->second;
+        g_free.erase(it);
+    } else {
+        hipError_t e = hipMalloc(&p, c);
+        if (e != hipSuccess) {
+            // give cached blocks back and retry once
+            (void)hipGetLastError();
+            pool_trim();
+            XR_HIP(hipMalloc(&p, c));
+        }
+    }
+    g_live[p] = c;
+    return p;
+}
+
+void pool_free(void *p) {
+    if (!p) return;
+    auto it = g_live.find(p);
+    if (it == g_live.end()) return;
+    g_free.emplace(it->second, p);
+    g_live.erase(it);
+}
+
+void pool_trim() {
+    if (g_engine.stream) (void)hipStreamSynchronize(g_engine.stream);
+    for (auto &kv : g_free) (void)hipFree(kv.second);
+    g_free.clear();
+}
+
+void h2d(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, engine().stream));
+    XR_HIP(hipStreamSynchronize(engine().stream));
+}
+
+void d2h(void *dst, const void *src, size_t bytes) {
+    if (!bytes) return;
+    if (bytes <= 4096) {
+        // scalar read-backs go through the pinned page: no pageable staging, one sync
+        XR_HIP(hipMemcpyAsync(engine().pinned, src, bytes, hipMemcpyDeviceToHost, engine().stream));
+        XR_HIP(hipStreamSynchronize(engine().stream));
+        memcpy(dst, engine().pinned, bytes);
+        return;
+    }
+    XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, engine().stream));
+    XR_HIP(hipStreamSynchronize(engine().stream));
+}
+
+void stream_sync() { XR_HIP(hipStreamSynchronize(engine().stream)); }
+
+// ---------------------------------------------------------------------------------------------
+// kernel timing
+// ---------------------------------------------------------------------------------------------
+struct ProfRec {
+    int64_t launches = 0;
+    double ms = 0.0;
+};
+struct Pending {
+    const char *name;
+    hipEvent_t e0, e1;
+};
+static std::map<std::string, ProfRec> g_prof;
+static std::vector<std::string> g_prof_order;
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_event_pool;
+
+static hipEvent_t get_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    XR_HIP(hipEventCreate(&e));
+    return e;
+}
+
+ProfScope::ProfScope(const char *n) : name(n) {
+    if (!g_engine.prof) return;
+    e0 = get_event();
+    e1 = get_event();
+    (void)hipEventRecord(e0, engine().stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!e0) return;
+    (void)hipEventRecord(e1, g_engine.stream);
+    g_pending.push_back({name, e0, e1});
+}
+
+void prof_flush() {
+    if (g_pending.empty()) return;
+    (void)hipStreamSynchronize(g_engine.stream);
+    for (auto &p : g_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+            auto it = g_prof.find(p.name);
+            if (it == g_prof.end()) {
+                g_prof_order.push_back(p.name);
+                it = g_prof.emplace(p.name, ProfRec{}).first;
+            }
+            it->second.launches += 1;
+            it->second.ms += ms;
+        }
+        g_event_pool.push_back(p.e0);
+        g_event_pool.push_back(p.e1);
+    }
+    g_pending.clear();
+}
+
+} // namespace xr
+
+using namespace xr;
+
+extern "C" {
+
+const char *xr_last_error(void) { return g_err; }
+
+int xr_version(void) { return 100; }
+
+int xr_device_count(int *count) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    if (count) *count = c;
+    return XR_OK;
+}
+
+int xr_init(int device) {
+    XR_API_BEGIN
+    engine_init(device);
+    XR_API_END
+}
+
+int xr_current_device(int *device) {
+    XR_API_BEGIN
+    *device = engine().device;
+    XR_API_END
+}
+
+int xr_trim_pool(void) {
+    XR_API_BEGIN
+    pool_trim();
+    XR_API_END
+}
+
+int xr_dev_alloc(int64_t bytes, void **ptr_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(bytes >= 0 && ptr_out, XR_ERR_INVALID, "xr_dev_alloc: bad arguments");
+    *ptr_out = pool_alloc((size_t)bytes);
+    XR_API_END
+}
+
+int xr_dev_free(void *ptr) {
+    XR_API_BEGIN
+    pool_free(ptr);
+    XR_API_END
+}
+
+int xr_dev_upload(void *dst_dev, const void *src_host, int64_t bytes) {
+    XR_API_BEGIN
+    h2d(dst_dev, src_host, (size_t)bytes);
+    XR_API_END
+}
+
+int xr_dev_download(void *dst_host, const void *src_dev, int64_t bytes) {
+    XR_API_BEGIN
+    if (bytes > 0) {
+        XR_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, engine().stream));
+        XR_HIP(hipStreamSynchronize(engine().stream));
+    }
+    XR_API_END
+}
+
+int xr_dev_sync(void) {
+    XR_API_BEGIN
+    stream_sync();
+    XR_API_END
+}
+
+int xr_prof_enable(int on) {
+    XR_API_BEGIN
+    engine();
+    prof_flush();
+    engine().prof = on != 0;
+    XR_API_END
+}
+
+int xr_prof_reset(void) {
+    XR_API_BEGIN
+    prof_flush();
+    g_prof.clear();
+    g_prof_order.clear();
+    XR_API_END
+}
+
+int xr_prof_count(int *count) {
+    XR_API_BEGIN
+    prof_flush();
+    *count = (int)g_prof_order.size();
+    XR_API_END
+}
+
+int xr_prof_get(int i, char *name, int name_cap, int64_t *launches, double *total_ms) {
+    XR_API_BEGIN
+    prof_flush();
+    XR_REQUIRE(i >= 0 && i < (int)g_prof_order.size(), XR_ERR_INVALID, "xr_prof_get: index out of range");
+    const std::string &n = g_prof_order[i];
+    const ProfRec &r = g_prof[n];
+    if (name && name_cap > 0) {
+        snprintf(name, (size_t)name_cap, "%s", n.c_str());
+    }
+    if (launches) *launches = r.launches;
+    if (total_ms) *total_ms = r.ms;
+    XR_API_END
+}
+
+} // extern "C"

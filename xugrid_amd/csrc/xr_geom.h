@@ -1,0 +1,75 @@
+// xr_geom.h -- device-side geometry types shared by the mesh / overlap / locate kernels.
+//
+// HBM layout of a mesh (struct xr_mesh):
+//   node_xy   f64 [n_node][2]   interleaved: one 16-byte load per vertex
+//   faces     i32 [n_face][M]   CCW-normalised face_node_connectivity, -1 fill (dense, row = face;
+//                               the CSR offset of face f is the implicit f*M)
+//   len       u8  [n_face]      number of valid vertices (polygon_length)
+//   bbox      f64 [n_face][4]   xmin, xmax, ymin, ymax
+//   area      f64 [n_face]      connectivity.area on the caller's vertex order
+// Spatial index ("tree" side): hierarchical uniform grid, one insertion per face
+//   level l has square cells of size h0 * 2^l; a face lives on the lowest level whose cell
+//   size exceeds its bbox extent and is stored in the cell holding its bbox lower-left corner
+//   cell_start i32 [n_cell+1]   CSR offsets of the cell -> record lists, all levels concatenated
+//   rec_bb     f32 [n_face][4]  conservative (outward-rounded) bbox relative to the grid origin
+//   rec_face   i32 [n_face]     face id of each record
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace xr {
+
+struct P2 {
+    double x, y;
+};
+
+static constexpr int MAX_LEVELS = 24;
+
+struct GridParams {
+    double x0, y0;    // grid origin (domain lower-left)
+    double h0;        // level-0 cell size
+    double inv_h0;    // 1 / h0
+    int n_levels;
+    int n_cells;      // total over all levels
+    int base[MAX_LEVELS];
+    int nx[MAX_LEVELS];
+    int ny[MAX_LEVELS];
+};
+
+// level-l cell size and its inverse (exact power-of-two scalings of h0 / inv_h0)
+__host__ __device__ inline double level_h(const GridParams &g, int l) { return ldexp(g.h0, l); }
+__host__ __device__ inline double level_inv_h(const GridParams &g, int l) { return ldexp(g.inv_h0, -l); }
+
+// monotone non-decreasing in x: (x - x0) * inv_h, floor, clamp
+__host__ __device__ inline int cell_coord(double x, double origin, double inv_h, int n) {
+    double c = floor((x - origin) * inv_h);
+    if (!(c > 0.0)) return 0; // also catches NaN
+    if (c >= (double)(n - 1)) return n - 1;
+    return (int)c;
+}
+
+// lowest level whose cell size strictly dominates the extent (0.1 % slack covers every rounding)
+__host__ __device__ inline int level_of_extent(const GridParams &g, double e) {
+    int l = 0;
+    while (l < g.n_levels - 1 && !(e <= 0.999 * ldexp(g.h0, l))) l++;
+    return l;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ P2 load_p2(const double *__restrict__ xy, int i) {
+    const double2 v = reinterpret_cast<const double2 *>(xy)[i];
+    return P2{v.x, v.y};
+}
+
+// conservative float bounds: strictly below / above the double value
+__device__ __forceinline__ float f32_below(double v) {
+    return nextafterf(__double2float_rd(v), -INFINITY);
+}
+__device__ __forceinline__ float f32_above(double v) {
+    return nextafterf(__double2float_ru(v), INFINITY);
+}
+#endif
+
+} // namespace xr

@@ -1,0 +1,148 @@
+// xr_internal.h -- shared internals of libxugrid_amd.so (engine context, HBM block pool,
+// launch/profiling helpers, device scan).  gfx950 / wave64 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/xugrid_amd.h"
+
+namespace xr {
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+
+struct Failure {
+    int code;
+};
+
+#define XR_HIP(expr)                                                                            \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            xr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,      \
+                          __LINE__);                                                            \
+            throw xr::Failure{XR_ERR_HIP};                                                      \
+        }                                                                                       \
+    } while (0)
+
+#define XR_REQUIRE(cond, code, ...)                                                             \
+    do {                                                                                        \
+        if (!(cond)) {                                                                          \
+            xr::set_error(__VA_ARGS__);                                                         \
+            throw xr::Failure{code};                                                            \
+        }                                                                                       \
+    } while (0)
+
+// Every extern "C" entry point wraps its body:  XR_API_BEGIN ... XR_API_END
+#define XR_API_BEGIN                                                                            \
+    try {                                                                                       \
+        std::lock_guard<std::recursive_mutex> _guard(xr::engine_mutex());
+#define XR_API_END                                                                              \
+    return XR_OK;                                                                               \
+    }                                                                                           \
+    catch (const xr::Failure &f) {                                                              \
+        return f.code;                                                                          \
+    }                                                                                           \
+    catch (const std::exception &e) {                                                           \
+        xr::set_error("internal error: %s", e.what());                                          \
+        return XR_ERR_INVALID;                                                                  \
+    }
+
+std::recursive_mutex &engine_mutex();
+
+// ---------------------------------------------------------------------------------------------
+// engine context: one device + one stream per process
+// ---------------------------------------------------------------------------------------------
+struct Engine {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cu = 256;
+    void *pinned = nullptr; // small pinned staging buffer for scalar read-backs
+    bool prof = false;
+};
+Engine &engine();      // initialises device 0 on first use
+void engine_init(int device);
+
+// ---------------------------------------------------------------------------------------------
+// HBM block pool (size-bucketed cache so the timed path never calls hipMalloc/hipFree)
+// ---------------------------------------------------------------------------------------------
+void *pool_alloc(size_t bytes);
+void pool_free(void *p);
+void pool_trim();
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t count) { alloc(count); }
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept {
+        if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t count) {
+        release();
+        n = count;
+        p = static_cast<T *>(pool_alloc((count ? count : 1) * sizeof(T)));
+    }
+    void release() {
+        if (p) pool_free(p);
+        p = nullptr;
+        n = 0;
+    }
+    T *get() const { return p; }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+void h2d(void *dst, const void *src, size_t bytes);       // synchronous w.r.t. the host
+void d2h(void *dst, const void *src, size_t bytes);       // stream-ordered, then synchronised
+void stream_sync();
+template <typename T> T read_scalar(const T *dev) {
+    T v;
+    d2h(&v, dev, sizeof(T));
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch helper with optional hipEvent timing per kernel name
+// ---------------------------------------------------------------------------------------------
+struct ProfScope {
+    const char *name;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit ProfScope(const char *name);
+    ~ProfScope();
+};
+void prof_flush(); // resolve pending events into the per-name table
+
+#define XR_LAUNCH(name, kernel, grid, block, shmem, ...)                                        \
+    do {                                                                                        \
+        xr::ProfScope _ps(name);                                                                \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, xr::engine().stream, __VA_ARGS__);       \
+        XR_HIP(hipGetLastError());                                                              \
+    } while (0)
+
+inline unsigned div_up(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------
+// device primitives implemented in xr_scan.hip
+// ---------------------------------------------------------------------------------------------
+// out[0..n] = exclusive prefix sum of in[0..n-1] (out has n+1 entries; out[n] = total).
+// in and out may alias when out == in is NOT required; separate buffers expected.
+void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n);
+void fill_i32(int32_t *p, int32_t v, int64_t n);
+void fill_f64(double *p, double v, int64_t n);
+
+} // namespace xr

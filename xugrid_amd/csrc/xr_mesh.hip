@@ -1,0 +1,477 @@
+// xr_mesh.hip -- mesh handle: upload, per-face preparation (fill/length/CCW/bbox/area), the
+// hierarchical-grid spatial index, area / centroid kernels.
+//
+// Replaces, on the device, what the reference does when it constructs
+// numba_celltree.CellTree2d(node_coordinates, face_node_connectivity, -1)
+// (xugrid/ugrid/ugrid2d.py:908-921) and what intersect_faces does to the query mesh
+// (cast, counter-clockwise normalisation, bounding boxes).  The index is NOT a port of the
+// cell tree: a bounding-interval hierarchy is a pointer-chasing structure; on CDNA4 a
+// counting-sorted hierarchical grid gives contiguous, coalescable record runs per query row.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "xr_objects.h"
+
+namespace xr {
+
+static constexpr int PREP_BLOCK = 256;
+
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmin(v, __shfl_down(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = fmax(v, __shfl_down(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-face preparation.  MC > 0: compile-time vertices per face; MC == 0: runtime m <= 32.
+// ---------------------------------------------------------------------------------------------
+template <int MC>
+__global__ void __launch_bounds__(PREP_BLOCK)
+k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face,
+                int m_rt, int32_t *__restrict__ faces, uint8_t *__restrict__ len_out,
+                double *__restrict__ bbox, double *__restrict__ area, double *__restrict__ partials) {
+    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
+    const int m = MC > 0 ? MC : m_rt;
+    const int64_t f = (int64_t)blockIdx.x * PREP_BLOCK + threadIdx.x;
+
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, ext = 0.0, diag = 0.0;
+    if (f < n_face) {
+        int face[MA];
+#pragma unroll
+        for (int j = 0; j < MA; j++)
+            if (j < m) face[j] = faces_raw[f * m + j];
+
+        // connectivity.area on the caller's order (connectivity.py:372-382, 615-633):
+        // fill slots and the closing slot repeat node 0; everything relative to node 0.
+        {
+            const P2 p0 = load_p2(node_xy, face[0]);
+            double det = 0.0;
+#pragma unroll
+            for (int i = 0; i < MA; i++) {
+                if (i < m) {
+                    const int ia = face[i] < 0 ? face[0] : face[i];
+                    int ib = face[0];
+                    if (i + 1 < m) ib = face[i + 1] < 0 ? face[0] : face[i + 1];
+                    const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib);
+                    const double ax = a.x - p0.x, ay = a.y - p0.y;
+                    const double bx = b.x - p0.x, by = b.y - p0.y;
+                    det += ax * by - ay * bx;
+                }
+            }
+            area[f] = 0.5 * fabs(det);
+        }
+
+        // polygon_length: a minimal polygon is a triangle, stop at the first fill value
+        int n = m;
+#pragma unroll
+        for (int i = MA - 1; i >= 3; i--)
+            if (i < m && face[i] < 0) n = i;
+
+        // counter_clockwise: the first non-collinear vertex triple decides
+        bool flip = false;
+        for (int i = 0; i < n; i++) {
+            const int ia = face[(i + n - 2) % n], ib = face[(i + n - 1) % n], ic = face[i];
+            const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib), c = load_p2(node_xy, ic);
+            const double ux = b.x - a.x, uy = b.y - a.y, vx = c.x - a.x, vy = c.y - a.y;
+            const double prod = ux * vy - uy * vx;
+            if (prod == 0) continue;
+            flip = prod < 0;
+            break;
+        }
+#pragma unroll
+        for (int j = 0; j < MA; j++) {
+            if (j < m) {
+                int v = face[j];
+                if (flip && j < n) v = face[n - 1 - j];
+                faces[f * m + j] = v;
+            }
+        }
+        len_out[f] = (uint8_t)n;
+#pragma unroll
+        for (int j = 0; j < MA; j++) {
+            if (j < n) {
+                const P2 p = load_p2(node_xy, face[j]);
+                xmin = fmin(xmin, p.x);
+                xmax = fmax(xmax, p.x);
+                ymin = fmin(ymin, p.y);
+                ymax = fmax(ymax, p.y);
+            }
+        }
+        double4 *bb = reinterpret_cast<double4 *>(bbox);
+        bb[f] = make_double4(xmin, xmax, ymin, ymax);
+        ext = fmax(xmax - xmin, ymax - ymin);
+        const double dx = xmax - xmin, dy = ymax - ymin;
+        diag = sqrt(dx * dx + dy * dy);
+    }
+
+    // block partials: bounds, sum and max of the bbox extents (fixed order -> deterministic)
+    __shared__ double lds[7][PREP_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double r0 = wave_min(xmin), r1 = wave_max(xmax), r2 = wave_min(ymin), r3 = wave_max(ymax);
+    double r4 = wave_sum(ext), r5 = wave_max(ext), r6 = wave_max(diag);
+    if (lane == 0) {
+        lds[0][wave] = r0; lds[1][wave] = r1; lds[2][wave] = r2;
+        lds[3][wave] = r3; lds[4][wave] = r4; lds[5][wave] = r5; lds[6][wave] = r6;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = lds[0][0], a1 = lds[1][0], a2 = lds[2][0], a3 = lds[3][0], a4 = lds[4][0], a5 = lds[5][0], a6 = lds[6][0];
+        for (int w = 1; w < PREP_BLOCK / 64; w++) {
+            a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
+            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]);
+        }
+        double *p = partials + (int64_t)blockIdx.x * 7;
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__ partials, int64_t nb,
+                                                     double *__restrict__ stats) {
+    double a0 = INFINITY, a1 = -INFINITY, a2 = INFINITY, a3 = -INFINITY, a4 = 0.0, a5 = 0.0, a6 = 0.0;
+    for (int64_t i = threadIdx.x; i < nb; i += 256) {
+        const double *p = partials + i * 7;
+        a0 = fmin(a0, p[0]); a1 = fmax(a1, p[1]); a2 = fmin(a2, p[2]);
+        a3 = fmax(a3, p[3]); a4 += p[4]; a5 = fmax(a5, p[5]); a6 = fmax(a6, p[6]);
+    }
+    __shared__ double lds[7][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a0 = wave_min(a0); a1 = wave_max(a1); a2 = wave_min(a2); a3 = wave_max(a3); a4 = wave_sum(a4); a5 = wave_max(a5);
+    a6 = wave_max(a6);
+    if (lane == 0) {
+        lds[0][wave] = a0; lds[1][wave] = a1; lds[2][wave] = a2;
+        lds[3][wave] = a3; lds[4][wave] = a4; lds[5][wave] = a5; lds[6][wave] = a6;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
+            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]);
+        }
+        stats[0] = a0; stats[1] = a1; stats[2] = a2; stats[3] = a3; stats[4] = a4; stats[5] = a5; stats[6] = a6;
+    }
+}
+
+void mesh_prepare(xr_mesh *mesh) {
+    if (mesh->prepared) return;
+    const int64_t F = mesh->n_face;
+    const int m = mesh->m;
+    mesh->faces.alloc((size_t)F * m);
+    mesh->len.alloc((size_t)F);
+    mesh->bbox.alloc((size_t)F * 4);
+    mesh->area.alloc((size_t)F);
+    mesh->stats.alloc(7);
+    const int64_t nb = std::max<int64_t>(1, (F + PREP_BLOCK - 1) / PREP_BLOCK);
+    DevBuf<double> partials((size_t)nb * 7);
+    dim3 grid((unsigned)nb), block(PREP_BLOCK);
+    if (m == 3) {
+        XR_LAUNCH("prepare_faces", k_prepare_faces<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
+                  mesh->faces.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+    } else if (m == 4) {
+        XR_LAUNCH("prepare_faces", k_prepare_faces<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
+                  mesh->faces.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+    } else {
+        XR_LAUNCH("prepare_faces", k_prepare_faces<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
+                  mesh->faces.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+    }
+    XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get());
+    mesh->prepared = true;
+    mesh->stats_valid = false;
+}
+
+void mesh_read_stats(xr_mesh *mesh) {
+    mesh_prepare(mesh);
+    if (mesh->stats_valid) return;
+    d2h(mesh->h_stats, mesh->stats.get(), sizeof(double) * 7);
+    mesh->stats_valid = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// spatial index
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
+    const double e = fmax(bb.y - bb.x, bb.w - bb.z);
+    const int l = level_of_extent(g, e);
+    const double inv_h = level_inv_h(g, l);
+    const int cx = cell_coord(bb.x, g.x0, inv_h, g.nx[l]);
+    const int cy = cell_coord(bb.z, g.y0, inv_h, g.ny[l]);
+    return g.base[l] + cy * g.nx[l] + cx;
+}
+
+__global__ void __launch_bounds__(256) k_index_count(const double *__restrict__ bbox, int64_t n_face, GridParams g,
+                                                    int32_t *__restrict__ key, int32_t *__restrict__ cell_count) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    const int c = face_cell(g, bb);
+    key[f] = c;
+    atomicAdd(&cell_count[c], 1);
+}
+
+__global__ void __launch_bounds__(256) k_index_fill(const double *__restrict__ bbox, int64_t n_face, GridParams g,
+                                                   const int32_t *__restrict__ key,
+                                                   const int32_t *__restrict__ cell_start,
+                                                   int32_t *__restrict__ cell_fill, float *__restrict__ rec_bb,
+                                                   int32_t *__restrict__ rec_face) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    const int c = key[f];
+    const int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+    rec_face[pos] = (int32_t)f;
+    reinterpret_cast<float4 *>(rec_bb)[pos] = make_float4(f32_below(bb.x - g.x0), f32_above(bb.y - g.x0),
+                                                          f32_below(bb.z - g.y0), f32_above(bb.w - g.y0));
+}
+
+void mesh_build_index(xr_mesh *mesh) {
+    if (mesh->indexed) return;
+    mesh_read_stats(mesh);
+    const int64_t F = mesh->n_face;
+    XR_REQUIRE(F < (int64_t)1 << 31, XR_ERR_LIMIT, "mesh has too many faces for int32 indices");
+    const double xmin = mesh->h_stats[0], xmax = mesh->h_stats[1], ymin = mesh->h_stats[2], ymax = mesh->h_stats[3];
+    const double sum_ext = mesh->h_stats[4], max_ext = mesh->h_stats[5];
+    GridParams g{};
+    double W = F > 0 ? xmax - xmin : 1.0, H = F > 0 ? ymax - ymin : 1.0;
+    if (!(W > 0)) W = 1.0;
+    if (!(H > 0)) H = 1.0;
+    double h0 = F > 0 ? sum_ext / (double)F : 1.0;
+    if (!(h0 > 0)) h0 = std::max(W, H);
+    // bound the level-0 cell count by ~4 cells per face
+    const double max_cells0 = std::max(4.0 * (double)F, 1024.0);
+    while ((floor(W / h0) + 1.0) * (floor(H / h0) + 1.0) > max_cells0) h0 *= 2.0;
+    g.x0 = F > 0 ? xmin : 0.0;
+    g.y0 = F > 0 ? ymin : 0.0;
+    g.h0 = h0;
+    g.inv_h0 = 1.0 / h0;
+    int L = 1;
+    while (L < MAX_LEVELS && !(max_ext <= 0.999 * ldexp(h0, L - 1))) L++;
+    g.n_levels = L;
+    int64_t total = 0;
+    for (int l = 0; l < L; l++) {
+        const double inv_h = ldexp(g.inv_h0, -l);
+        const int64_t nx = (int64_t)floor(W * inv_h) + 1, ny = (int64_t)floor(H * inv_h) + 1;
+        XR_REQUIRE(total + nx * ny < ((int64_t)1 << 31), XR_ERR_LIMIT, "spatial index too large");
+        g.base[l] = (int)total;
+        g.nx[l] = (int)nx;
+        g.ny[l] = (int)ny;
+        total += nx * ny;
+    }
+    g.n_cells = (int)total;
+    mesh->grid = g;
+
+    mesh->cell_start.alloc((size_t)total + 1);
+    mesh->rec_bb.alloc((size_t)F * 4);
+    mesh->rec_face.alloc((size_t)F);
+    DevBuf<int32_t> key((size_t)F), count((size_t)total);
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)total, engine().stream));
+    if (F > 0) {
+        XR_LAUNCH("index_count", k_index_count, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, g, key.get(),
+                  count.get());
+    }
+    exclusive_scan_i32(count.get(), mesh->cell_start.get(), total);
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)total, engine().stream));
+    if (F > 0) {
+        XR_LAUNCH("index_fill", k_index_fill, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, g, key.get(),
+                  mesh->cell_start.get(), count.get(), mesh->rec_bb.get(), mesh->rec_face.get());
+    }
+    mesh->indexed = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// centroids -- connectivity.centroids (connectivity.py:636-664) on the caller's vertex order
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_centroids(const double *__restrict__ node_xy,
+                                                  const int32_t *__restrict__ faces_raw, int64_t n_face, int m,
+                                                  double *__restrict__ cxy) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    const int32_t *face = faces_raw + f * m;
+    if (m == 3) {
+        double sx = 0.0, sy = 0.0;
+        for (int i = 0; i < 3; i++) {
+            const P2 p = load_p2(node_xy, face[i]);
+            sx += p.x;
+            sy += p.y;
+        }
+        cxy[2 * f] = sx / 3.0;
+        cxy[2 * f + 1] = sy / 3.0;
+        return;
+    }
+    const int f0 = face[0];
+    const P2 p0 = load_p2(node_xy, f0);
+    double det = 0.0, sx = 0.0, sy = 0.0;
+    for (int i = 0; i < m; i++) {
+        const int ia = face[i] < 0 ? f0 : face[i];
+        int ib = f0;
+        if (i + 1 < m) ib = face[i + 1] < 0 ? f0 : face[i + 1];
+        const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib);
+        const double ax = a.x - p0.x, ay = a.y - p0.y, bx = b.x - p0.x, by = b.y - p0.y;
+        const double d = ax * by - ay * bx;
+        det += d;
+        sx += (ax + bx) * d;
+        sy += (ay + by) * d;
+    }
+    const double aw = 1.0 / (3.0 * det);
+    cxy[2 * f] = aw * sx + p0.x;
+    cxy[2 * f + 1] = aw * sy + p0.y;
+}
+
+__global__ void k_widen_faces(const int32_t *__restrict__ in, int64_t *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+
+} // namespace xr
+
+using namespace xr;
+
+extern "C" {
+
+int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int faces_itemsize, int64_t n_face,
+                   int64_t n_max_node, int64_t fill_value, xr_mesh **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out != nullptr, XR_ERR_INVALID, "xr_mesh_create: out is NULL");
+    XR_REQUIRE(n_node >= 0 && n_face >= 0, XR_ERR_INVALID, "xr_mesh_create: negative sizes");
+    XR_REQUIRE(n_max_node >= 3 && n_max_node <= XR_MAX_FACE_NODES, XR_ERR_LIMIT,
+               "xr_mesh_create: n_max_node_per_face must be in [3, %d], got %lld", XR_MAX_FACE_NODES,
+               (long long)n_max_node);
+    XR_REQUIRE(faces_itemsize == 4 || faces_itemsize == 8, XR_ERR_INVALID, "xr_mesh_create: faces_itemsize must be 4 or 8");
+    XR_REQUIRE(n_node < ((int64_t)1 << 31) && n_face * n_max_node < ((int64_t)1 << 31), XR_ERR_LIMIT,
+               "xr_mesh_create: mesh exceeds the int32 index range");
+    XR_REQUIRE((node_xy && faces) || n_face == 0, XR_ERR_INVALID, "xr_mesh_create: NULL arrays");
+    engine();
+    // ingest: fill -> -1, range check, narrow to int32 (host side; this is the H2D staging step)
+    const size_t cnt = (size_t)n_face * (size_t)n_max_node;
+    std::vector<int32_t> f32(cnt ? cnt : 1);
+    for (int64_t f = 0; f < n_face; f++) {
+        for (int64_t j = 0; j < n_max_node; j++) {
+            const size_t k = (size_t)f * n_max_node + j;
+            const int64_t v = faces_itemsize == 8 ? static_cast<const int64_t *>(faces)[k]
+                                                  : (int64_t) static_cast<const int32_t *>(faces)[k];
+            if (v == fill_value || v == -1) {
+                XR_REQUIRE(j >= 3, XR_ERR_INVALID, "xr_mesh_create: face %lld has fewer than 3 nodes", (long long)f);
+                f32[k] = -1;
+            } else {
+                XR_REQUIRE(v >= 0 && v < n_node, XR_ERR_INVALID,
+                           "xr_mesh_create: face %lld references node %lld outside [0,%lld)", (long long)f,
+                           (long long)v, (long long)n_node);
+                f32[k] = (int32_t)v;
+            }
+        }
+    }
+    xr_mesh *mesh = new xr_mesh();
+    try {
+        mesh->n_node = n_node;
+        mesh->n_face = n_face;
+        mesh->m = (int)n_max_node;
+        mesh->node_xy.alloc((size_t)n_node * 2);
+        mesh->faces_raw.alloc(cnt);
+        h2d(mesh->node_xy.get(), node_xy, sizeof(double) * 2 * (size_t)n_node);
+        h2d(mesh->faces_raw.get(), f32.data(), sizeof(int32_t) * cnt);
+    } catch (...) {
+        delete mesh;
+        throw;
+    }
+    *out = mesh;
+    XR_API_END
+}
+
+int xr_mesh_destroy(xr_mesh *mesh) {
+    XR_API_BEGIN
+    if (mesh) {
+        stream_sync();
+        delete mesh;
+    }
+    XR_API_END
+}
+
+int xr_mesh_info(const xr_mesh *mesh, int64_t *n_node, int64_t *n_face, int64_t *n_max_node) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_info: NULL mesh");
+    if (n_node) *n_node = mesh->n_node;
+    if (n_face) *n_face = mesh->n_face;
+    if (n_max_node) *n_max_node = mesh->m;
+    XR_API_END
+}
+
+int xr_mesh_prepare(xr_mesh *mesh) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_prepare: NULL mesh");
+    mesh_prepare(mesh);
+    stream_sync();
+    XR_API_END
+}
+
+int xr_mesh_build_index(xr_mesh *mesh) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_build_index: NULL mesh");
+    mesh_build_index(mesh);
+    stream_sync();
+    XR_API_END
+}
+
+int xr_mesh_invalidate(xr_mesh *mesh) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_invalidate: NULL mesh");
+    stream_sync();
+    mesh->prepared = false;
+    mesh->indexed = false;
+    mesh->stats_valid = false;
+    mesh->faces.release(); mesh->len.release(); mesh->bbox.release(); mesh->area.release(); mesh->stats.release();
+    mesh->cell_start.release(); mesh->rec_bb.release(); mesh->rec_face.release();
+    XR_API_END
+}
+
+int xr_mesh_area(xr_mesh *mesh, double *area_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh && area_out, XR_ERR_INVALID, "xr_mesh_area: NULL argument");
+    mesh_prepare(mesh);
+    if (mesh->n_face > 0) {
+        XR_HIP(hipMemcpyAsync(area_out, mesh->area.get(), sizeof(double) * (size_t)mesh->n_face,
+                              hipMemcpyDeviceToHost, engine().stream));
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_mesh_centroids(xr_mesh *mesh, double *centroids_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh && centroids_out, XR_ERR_INVALID, "xr_mesh_centroids: NULL argument");
+    const int64_t F = mesh->n_face;
+    if (F > 0) {
+        DevBuf<double> c((size_t)F * 2);
+        XR_LAUNCH("centroids", k_centroids, dim3(div_up(F, 256)), dim3(256), 0, mesh->node_xy.get(),
+                  mesh->faces_raw.get(), F, mesh->m, c.get());
+        XR_HIP(hipMemcpyAsync(centroids_out, c.get(), sizeof(double) * 2 * (size_t)F, hipMemcpyDeviceToHost,
+                              engine().stream));
+        stream_sync();
+    }
+    XR_API_END
+}
+
+int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh && faces_out, XR_ERR_INVALID, "xr_mesh_faces: NULL argument");
+    mesh_prepare(mesh);
+    const int64_t n = mesh->n_face * mesh->m;
+    if (n > 0) {
+        DevBuf<int64_t> wide((size_t)n);
+        XR_LAUNCH("widen_faces", k_widen_faces, dim3(div_up(n, 256)), dim3(256), 0, mesh->faces.get(), wide.get(), n);
+        XR_HIP(hipMemcpyAsync(faces_out, wide.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
+                              engine().stream));
+        stream_sync();
+    }
+    XR_API_END
+}
+
+} // extern "C"

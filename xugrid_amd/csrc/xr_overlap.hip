@@ -1,0 +1,578 @@
+// xr_overlap.hip -- OverlapRegridder weight construction on the device.
+//
+// Replaces numba_celltree.CellTree2d.intersect_faces as called from
+// UnstructuredGrid2d.overlap (xugrid/regrid/unstructured.py:109-135), the relative
+// normalisation (:133-134) and MatrixCSR.from_triplet (xugrid/regrid/regridder.py:433-435,
+// xugrid/core/sparse.py:61-78).
+//
+// Pipeline (all on the engine stream):
+//   search_count   one thread per query (target) face walks the tree mesh's hierarchical grid
+//                  and counts bbox-overlapping tree faces                    -> cand_count[T]
+//   scan           exclusive prefix sum                                     -> cand_off[T+1]
+//   search_fill    same walk, writes the candidate-pair queue               -> cand_tgt/src[C]
+//   clip           one thread per candidate pair: Sutherland-Hodgman clip of the query polygon
+//                  by the tree polygon, polygon buffers staged in LDS ([vertex][thread] layout,
+//                  conflict-free 16-byte accesses), fan area                 -> cand_area[C]
+//                  per-row counts of pairs with area > 0 by wave-aggregated atomics -> nnz_row[T]
+//   scan           -> indptr[T+1]
+//   row_fill       per query face: rank the surviving pairs by tree face id and write the CSR
+//                  row (indices, data); data /= tree face area if relative.  Rows with many
+//                  candidates go to one block each (LDS bitmap rank, k_row_fill_long).
+// Query faces whose bbox spans many grid rows/records are searched by one wave each
+// (k_search_big) instead of one thread.
+//
+// The clip arithmetic mirrors oracle/xr_oracle.c (clip_polygons / sh_polygon_area) operation
+// for operation; both are built with -ffp-contract=off, so areas agree bit for bit.
+#include "xr_objects.h"
+
+namespace xr {
+
+// ---------------------------------------------------------------------------------------------
+// candidate search
+// ---------------------------------------------------------------------------------------------
+// A query face is "big" when its bbox spans many grid rows or many records (hull slivers of a
+// Delaunay mesh, coarse target cells over a fine source): one thread would serialise thousands
+// of tests, so those faces are queued and handled by one wave each (k_search_big).
+static constexpr int BIG_VISITS = 768; // records visited by one thread before it gives up
+
+__device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy0, float qy1) {
+    return qx0 < b.y && b.x < qx1 && qy0 < b.w && b.z < qy1;
+}
+
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const int32_t *__restrict__ cell_start,
+         const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face,
+         const int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt,
+         int32_t *__restrict__ cand_src, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
+         int32_t *__restrict__ n_big) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_query) return;
+    if (FILL && is_big[t]) return;
+    const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
+    const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
+    const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
+    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+    int count = 0, visited = 0;
+    bool big = false;
+    int out = FILL ? cand_off[t] : 0;
+    if (!FILL) {
+        int n_rows = 0;
+        for (int l = 0; l < g.n_levels; l++) {
+            const double h = level_h(g, l), inv_h = level_inv_h(g, l);
+            n_rows += cell_coord(bb.w, g.y0, inv_h, g.ny[l]) - cell_coord(bb.z - h, g.y0, inv_h, g.ny[l]) + 1;
+        }
+        big = n_rows > 8 * g.n_levels + 8;
+    }
+    for (int l = 0; l < g.n_levels && !big; l++) {
+        const double h = level_h(g, l), inv_h = level_inv_h(g, l);
+        const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
+        const int cx0 = cell_coord(bb.x - h, g.x0, inv_h, nx), cx1 = cell_coord(bb.y, g.x0, inv_h, nx);
+        const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
+        for (int cy = cy0; cy <= cy1; cy++) {
+            const int r0 = cell_start[base + cy * nx + cx0];
+            const int r1 = cell_start[base + cy * nx + cx1 + 1];
+            if (!FILL) {
+                visited += r1 - r0;
+                if (visited > BIG_VISITS) {
+                    big = true;
+                    break;
+                }
+            }
+            for (int r = r0; r < r1; r++) {
+                if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
+                    if (FILL) {
+                        cand_tgt[out] = (int32_t)t;
+                        cand_src[out] = rec_face[r];
+                        out++;
+                    }
+                    count++;
+                }
+            }
+        }
+    }
+    if (!FILL) {
+        is_big[t] = big ? 1 : 0;
+        cand_count[t] = big ? 0 : count;
+        if (big) big_list[atomicAdd(n_big, 1)] = (int32_t)t;
+    }
+}
+
+// one wave per big query face; candidates are emitted in record order (ballot prefix), so the
+// result does not depend on which wave handles which face.
+template <bool FILL>
+__global__ void __launch_bounds__(256)
+k_search_big(const double *__restrict__ q_bbox, GridParams g, const int32_t *__restrict__ cell_start,
+             const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face,
+             const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big,
+             const int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt,
+             int32_t *__restrict__ cand_src) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+    const int nb = *n_big;
+    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+    const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    for (int bi = wave; bi < nb; bi += n_waves) {
+        const int t = big_list[bi];
+        const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
+        const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
+        const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
+        int total = 0;
+        int out = FILL ? cand_off[t] : 0;
+        for (int l = 0; l < g.n_levels; l++) {
+            const double h = level_h(g, l), inv_h = level_inv_h(g, l);
+            const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
+            const int cx0 = cell_coord(bb.x - h, g.x0, inv_h, nx), cx1 = cell_coord(bb.y, g.x0, inv_h, nx);
+            const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
+            for (int cy = cy0; cy <= cy1; cy++) {
+                const int r0 = cell_start[base + cy * nx + cx0];
+                const int r1 = cell_start[base + cy * nx + cx1 + 1];
+                for (int rb = r0; rb < r1; rb += 64) {
+                    const int r = rb + lane;
+                    const bool hit = r < r1 && rec_hit(rbb[r], qx0, qx1, qy0, qy1);
+                    const unsigned long long mask = __ballot(hit);
+                    if (FILL && hit) {
+                        const int slot = out + __popcll(mask & lt_mask);
+                        cand_tgt[slot] = t;
+                        cand_src[slot] = rec_face[r];
+                    }
+                    const int n = __popcll(mask);
+                    out += n;
+                    total += n;
+                }
+            }
+        }
+        if (!FILL && lane == 0) cand_count[t] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sutherland-Hodgman clip + fan area.  LDS: two polygon buffers per thread, [vertex][thread].
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool sh_inside(P2 p, P2 r, P2 U) { return U.x * (p.y - r.y) > U.y * (p.x - r.x); }
+
+__device__ __forceinline__ bool sh_intersection(P2 a, P2 V, P2 r, P2 N, P2 &out) {
+    const double wx = r.x - a.x, wy = r.y - a.y;
+    const double nw = N.x * wx + N.y * wy;
+    const double nv = N.x * V.x + N.y * V.y;
+    if (nv != 0) {
+        const double tt = nw / nv;
+        out.x = a.x + tt * V.x;
+        out.y = a.y + tt * V.y;
+        return true;
+    }
+    return false;
+}
+
+static constexpr double AREA_OVERFLOW = -1.0; // sentinel: polygon buffer too small, redo with MAXV=64
+
+template <int MAXV, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_clip(const double *__restrict__ q_xy, const int32_t *__restrict__ q_faces, const uint8_t *__restrict__ q_len,
+       int q_m, const double *__restrict__ s_xy, const int32_t *__restrict__ s_faces,
+       const uint8_t *__restrict__ s_len, int s_m, const int32_t *__restrict__ cand_tgt,
+       const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area, bool redo_only,
+       int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *sh = reinterpret_cast<double2 *>(smem);
+    const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = c < n_cand && !(redo_only && cand_area[c] != AREA_OVERFLOW);
+    int t = -1;
+    double area = 0.0;
+    if (active) {
+    t = cand_tgt[c];
+    const int s = cand_src[c];
+    const int nt = q_len[t], ns = s_len[s];
+    double2 *out = sh + threadIdx.x;                // out[j * BLOCK]
+    double2 *in = sh + MAXV * BLOCK + threadIdx.x;  // in[j * BLOCK]
+    const int32_t *tf = q_faces + (int64_t)t * q_m;
+    const int32_t *sf = s_faces + (int64_t)s * s_m;
+    for (int j = 0; j < nt; j++) out[j * BLOCK] = reinterpret_cast<const double2 *>(q_xy)[tf[j]];
+    int n_output = nt;
+    bool overflow = false;
+    P2 r = load_p2(s_xy, sf[ns - 1]);
+    bool empty = false;
+    for (int i = 0; i < ns; i++) {
+        const P2 sv = load_p2(s_xy, sf[i]);
+        const P2 U{sv.x - r.x, sv.y - r.y};
+        if (U.x == 0 && U.y == 0) continue;
+        const P2 N{-U.y, U.x};
+        const int length = n_output;
+        {
+            double2 *tmp = in;
+            in = out;
+            out = tmp;
+        }
+        n_output = 0;
+        const double2 a2 = in[(length - 1) * BLOCK];
+        P2 a{a2.x, a2.y};
+        bool a_inside = sh_inside(a, r, U);
+        for (int j = 0; j < length; j++) {
+            const double2 b2 = in[j * BLOCK];
+            const P2 b{b2.x, b2.y};
+            const P2 V{b.x - a.x, b.y - a.y};
+            if (V.x == 0 && V.y == 0) continue;
+            bool b_inside = sh_inside(b, r, U);
+            if (b_inside) {
+                if (!a_inside) {
+                    P2 pt;
+                    if (sh_intersection(a, V, r, N, pt)) {
+                        if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
+                        else overflow = true;
+                        n_output++;
+                    }
+                }
+                if (n_output < MAXV) out[n_output * BLOCK] = b2;
+                else overflow = true;
+                n_output++;
+            } else if (a_inside) {
+                P2 pt;
+                if (sh_intersection(a, V, r, N, pt)) {
+                    if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
+                    else overflow = true;
+                    n_output++;
+                } else {
+                    b_inside = true;
+                    if (n_output < MAXV) out[n_output * BLOCK] = b2;
+                    else overflow = true;
+                    n_output++;
+                }
+            }
+            a = b;
+            a_inside = b_inside;
+        }
+        if (overflow) break;
+        if (n_output < 3) {
+            empty = true;
+            break;
+        }
+        r = sv;
+    }
+    if (overflow) {
+        area = AREA_OVERFLOW;
+        atomicAdd(overflow_count, 1);
+    } else if (!empty) {
+        // fan area from the first clipped vertex (local origin)
+        const double2 a2 = out[0];
+        const double2 b2 = out[BLOCK];
+        double ux = b2.x - a2.x, uy = b2.y - a2.y;
+        for (int i = 2; i < n_output; i++) {
+            const double2 c2 = out[i * BLOCK];
+            const double vx = a2.x - c2.x, vy = a2.y - c2.y;
+            area += fabs(ux * vy - uy * vx);
+            ux = vx;
+            uy = vy;
+        }
+        area = 0.5 * area;
+    }
+    cand_area[c] = area;
+    } // active
+    // per-row survivor counts: candidates of one query face are contiguous, so a wave holds a
+    // few runs of equal t; the head lane of each run adds the run's survivor count.
+    {
+        const int lane = threadIdx.x & 63;
+        const int t_prev = __shfl_up(t, 1, 64);
+        const bool head = lane == 0 || t_prev != t;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long surv = __ballot(active && area > 0);
+        if (head && t >= 0) {
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+            unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
+            run &= ~((1ull << lane) - 1);
+            const int n = __popcll(surv & run);
+            if (n > 0) atomicAdd(&nnz_row[t], n);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSR assembly
+// ---------------------------------------------------------------------------------------------
+// recount of the survivors per row; only used after the rare clip-buffer overflow redo
+__global__ void __launch_bounds__(256) k_row_count(const int32_t *__restrict__ cand_off,
+                                                  const double *__restrict__ cand_area, int64_t n_query,
+                                                  int32_t *__restrict__ nnz_row) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_query) return;
+    int n = 0;
+    for (int c = cand_off[t]; c < cand_off[t + 1]; c++) n += cand_area[c] > 0 ? 1 : 0;
+    nnz_row[t] = n;
+}
+
+static constexpr int ROW_SHORT = 48; // rows with more candidates go to the block-per-row kernel
+
+__global__ void __launch_bounds__(256)
+k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
+           const double *__restrict__ cand_area, int64_t n_query, const int32_t *__restrict__ indptr,
+           const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
+           double *__restrict__ data, int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_query) return;
+    const int c0 = cand_off[t], c1 = cand_off[t + 1];
+    if (c1 - c0 > ROW_SHORT) {
+        long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
+        return;
+    }
+    const int base = indptr[t];
+    for (int i = c0; i < c1; i++) {
+        const double a = cand_area[i];
+        if (!(a > 0)) continue;
+        const int s = cand_src[i];
+        int rank = 0;
+        for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && cand_src[j] < s) ? 1 : 0;
+        indices[base + rank] = s;
+        data[base + rank] = relative ? a / src_area[s] : a;
+    }
+}
+
+// Long rows: one block per row ranks the survivors by tree face id with an LDS bitmap.
+// The id range is processed in chunks of BM_BITS ids: set one bit per survivor, build word
+// prefix popcounts, rank = (survivors in earlier chunks) + prefix[word] + popc(bits below).
+// O(n + S/32) per row instead of O(n^2); any row length, any number of tree faces.
+static constexpr int BM_WORDS = 16384;          // 64 KiB of bitmap
+static constexpr int BM_BITS = BM_WORDS * 32;   // ids per chunk
+static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread
+
+__global__ void __launch_bounds__(256)
+k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
+                const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
+                const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
+                double *__restrict__ data, const int32_t *__restrict__ long_rows,
+                const int32_t *__restrict__ n_long) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *bm = reinterpret_cast<uint32_t *>(smem);          // [BM_WORDS]
+    uint32_t *prefix = bm + BM_WORDS;                           // [BM_WORDS] exclusive, within thread segment
+    uint32_t *tbase = prefix + BM_WORDS;                        // [256] exclusive over thread segments
+    int32_t *red = reinterpret_cast<int32_t *>(tbase + 256);    // [8] scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = *n_long;
+    for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+        const int t = long_rows[li];
+        const int c0 = cand_off[t], c1 = cand_off[t + 1];
+        const int base = indptr[t];
+        // id range of the survivors
+        int lo = 0x7fffffff, hi = -1;
+        for (int i = c0 + tid; i < c1; i += 256) {
+            if (cand_area[i] > 0) {
+                const int s = cand_src[i];
+                lo = min(lo, s);
+                hi = max(hi, s);
+            }
+        }
+        for (int d = 32; d > 0; d >>= 1) {
+            lo = min(lo, __shfl_down(lo, d, 64));
+            hi = max(hi, __shfl_down(hi, d, 64));
+        }
+        __syncthreads();
+        if (lane == 0) {
+            red[wave] = lo;
+            red[4 + wave] = hi;
+        }
+        __syncthreads();
+        lo = min(min(red[0], red[1]), min(red[2], red[3]));
+        hi = max(max(red[4], red[5]), max(red[6], red[7]));
+        int running = 0;
+        if (hi >= 0) {
+            for (int cb = (lo / BM_BITS) * BM_BITS; cb <= hi; cb += BM_BITS) {
+                __syncthreads();
+                for (int w = tid; w < BM_WORDS; w += 256) bm[w] = 0u;
+                __syncthreads();
+                for (int i = c0 + tid; i < c1; i += 256) {
+                    if (cand_area[i] > 0) {
+                        const int s = cand_src[i] - cb;
+                        if (s >= 0 && s < BM_BITS) atomicOr(&bm[s >> 5], 1u << (s & 31));
+                    }
+                }
+                __syncthreads();
+                // exclusive popcount prefix inside each thread's segment of BM_SEG words
+                uint32_t acc = 0;
+                for (int k = 0; k < BM_SEG; k++) {
+                    const int w = tid * BM_SEG + k;
+                    prefix[w] = acc;
+                    acc += __popc(bm[w]);
+                }
+                // block exclusive scan of the per-thread totals
+                uint32_t incl = acc;
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t v = __shfl_up(incl, d, 64);
+                    if (lane >= d) incl += v;
+                }
+                if (lane == 63) red[wave] = (int32_t)incl;
+                __syncthreads();
+                uint32_t woff = 0, chunk_total = 0;
+                for (int w = 0; w < 4; w++) {
+                    if (w < wave) woff += (uint32_t)red[w];
+                    chunk_total += (uint32_t)red[w];
+                }
+                tbase[tid] = woff + incl - acc;
+                __syncthreads();
+                for (int i = c0 + tid; i < c1; i += 256) {
+                    const double a = cand_area[i];
+                    if (a > 0) {
+                        const int sid = cand_src[i];
+                        const int s = sid - cb;
+                        if (s >= 0 && s < BM_BITS) {
+                            const int w = s >> 5;
+                            const int rank = running + (int)(tbase[w / BM_SEG] + prefix[w]) +
+                                             __popc(bm[w] & ((1u << (s & 31)) - 1u));
+                            indices[base + rank] = sid;
+                            data[base + rank] = relative ? a / src_area[sid] : a;
+                        }
+                    }
+                }
+                running += (int)chunk_total;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MAXV, int BLOCK>
+static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
+                        int64_t C, double *cand_area, bool redo_only, int32_t *overflow_count, int32_t *nnz_row) {
+    const size_t shmem = (size_t)2 * MAXV * BLOCK * sizeof(double2);
+    static bool attr_set = false;
+    if (!attr_set) {
+        XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_clip<MAXV, BLOCK>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        attr_set = true;
+    }
+    XR_LAUNCH(MAXV == 8 ? "clip_v8" : (MAXV == 16 ? "clip_v16" : "clip_v64"), (k_clip<MAXV, BLOCK>),
+              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->node_xy.get(), query->faces.get(), query->len.get(),
+              query->m, tree->node_xy.get(), tree->faces.get(), tree->len.get(), tree->m, cand_tgt, cand_src, C,
+              cand_area, redo_only, overflow_count, nnz_row);
+}
+
+static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
+                            int64_t C, double *cand_area, int32_t *overflow_count, int32_t *nnz_row) {
+    const int vmax = query->m + tree->m;
+    if (vmax <= 8) launch_clip<8, 256>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
+    else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
+    else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
+}
+
+static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
+    mesh_prepare(tree);
+    mesh_prepare(query);
+    mesh_build_index(tree);
+    const int64_t T = query->n_face, S = tree->n_face;
+    XR_REQUIRE(T < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "too many query faces for int32 row offsets");
+    csr->n = T;
+    csr->m = S;
+    csr->nnz = 0;
+    csr->indptr.alloc((size_t)T + 1);
+    tree->last_candidates = 0;
+    if (T == 0 || S == 0) {
+        XR_HIP(hipMemsetAsync(csr->indptr.get(), 0, sizeof(int32_t) * ((size_t)T + 1), engine().stream));
+        csr->indices.alloc(0);
+        csr->data.alloc(0);
+        csr->max_row = 0;
+        return;
+    }
+    const GridParams &g = tree->grid;
+    hipStream_t st = engine().stream;
+    // counters: [0] clip overflow, [1] number of long rows, [2] number of big query faces
+    DevBuf<int32_t> counters(4);
+    XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 4, st));
+    // --- candidate search: count -> scan -> fill
+    DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
+    DevBuf<uint8_t> is_big((size_t)T);
+    const int big_grid = engine().num_cu * 2;
+    XR_LAUNCH("search_count", k_search<false>, dim3(div_up(T, 256)), dim3(256), 0, query->bbox.get(), T, g,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), (const int32_t *)nullptr,
+              cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr, is_big.get(), big_list.get(),
+              counters.get() + 2);
+    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->bbox.get(), g,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2,
+              (const int32_t *)nullptr, cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
+    exclusive_scan_i32(cand_count.get(), cand_off.get(), T);
+    const int32_t C32 = read_scalar(cand_off.get() + T);
+    XR_REQUIRE(C32 >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
+    const int64_t C = C32;
+    tree->last_candidates = C;
+    DevBuf<int32_t> cand_tgt((size_t)C), cand_src((size_t)C), nnz_row((size_t)T);
+    DevBuf<double> cand_area((size_t)C);
+    XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
+    if (C > 0) {
+        XR_LAUNCH("search_fill", k_search<true>, dim3(div_up(T, 256)), dim3(256), 0, query->bbox.get(), T, g,
+                  tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), cand_off.get(),
+                  (int32_t *)nullptr, cand_tgt.get(), cand_src.get(), is_big.get(), (int32_t *)nullptr,
+                  (int32_t *)nullptr);
+        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->bbox.get(), g,
+                  tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), big_list.get(),
+                  counters.get() + 2, cand_off.get(), (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
+        // --- clip (+ per-row survivor counts)
+        launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), counters.get(), nnz_row.get());
+    }
+    // --- rows
+    exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
+    // P is needed on the host anyway; the overflow counter travels in the same read-back
+    XR_HIP(hipMemcpyAsync(counters.get() + 3, csr->indptr.get() + T, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    int32_t tail[4];
+    d2h(tail, counters.get(), sizeof(int32_t) * 4);
+    if (tail[0] > 0) {
+        // polygon buffer overflow in the small-MAXV kernel (floating-point degenerate pairs):
+        // redo those pairs with the oracle's buffer size, then recount every row.
+        XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t), st));
+        XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
+        launch_clip<64, 64>(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), true, counters.get(),
+                            nnz_row.get());
+        XR_LAUNCH("row_recount", k_row_count, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_area.get(), T,
+                  nnz_row.get());
+        exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
+        tail[3] = read_scalar(csr->indptr.get() + T);
+    }
+    XR_REQUIRE(tail[3] >= 0, XR_ERR_LIMIT, "nnz exceeds the int32 range");
+    const int64_t P = tail[3];
+    csr->nnz = P;
+    csr->indices.alloc((size_t)P);
+    csr->data.alloc((size_t)P);
+    csr->max_row = -1;
+    if (P > 0) {
+        DevBuf<int32_t> long_rows((size_t)T);
+        XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_src.get(),
+                  cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative, csr->indices.get(),
+                  csr->data.get(), long_rows.get(), counters.get() + 1);
+        const size_t shmem = sizeof(uint32_t) * (2 * BM_WORDS + 256) + sizeof(int32_t) * 8;
+        static bool attr_set = false;
+        if (!attr_set) {
+            XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_fill_long),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+            attr_set = true;
+        }
+        XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
+                  cand_src.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, csr->indices.get(),
+                  csr->data.get(), long_rows.get(), counters.get() + 1);
+    }
+}
+
+} // namespace xr
+
+using namespace xr;
+
+extern "C" {
+
+int xr_overlap(xr_mesh *tree, xr_mesh *query, int relative, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && query && out, XR_ERR_INVALID, "xr_overlap: NULL argument");
+    xr_csr *csr = new xr_csr();
+    try {
+        overlap(tree, query, relative != 0, csr);
+        stream_sync();
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_overlap_stats(const xr_mesh *tree, int64_t *n_candidates) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && n_candidates, XR_ERR_INVALID, "xr_overlap_stats: NULL argument");
+    *n_candidates = tree->last_candidates;
+    XR_API_END
+}
+
+} // extern "C"

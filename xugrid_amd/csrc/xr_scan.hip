@@ -1,0 +1,125 @@
+// xr_scan.hip -- device exclusive prefix sum (int32) and fills.  wave64, 256-thread blocks.
+// Three-phase reduce / scan-of-partials / scan-with-offset; every element is read twice and
+// written once (HBM-bound, 12 B per element).
+#include "xr_internal.h"
+
+namespace xr {
+
+static constexpr int SCAN_BLOCK = 256;
+static constexpr int SCAN_ITEMS = 8; // per thread
+static constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, total via *total
+__device__ __forceinline__ int block_excl_scan(int v, int *total, int *lds /* >= 4 ints */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = wave_incl_scan(v);
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; w++) {
+        int s = lds[w];
+        if (w < wave) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - v;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const int32_t *__restrict__ in,
+                                                            int32_t *__restrict__ block_sums, int64_t n) {
+    __shared__ int lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        int64_t j = base + (int64_t)i * SCAN_BLOCK + threadIdx.x;
+        if (j < n) s += in[j];
+    }
+    int tot;
+    (void)block_excl_scan(s, &tot, lds);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// single block scans up to any number of partials sequentially by tiles
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partials(int32_t *__restrict__ sums, int64_t nb,
+                                                              int32_t *__restrict__ total_out) {
+    __shared__ int lds[4];
+    int carry = 0;
+    for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
+        int64_t j = base + threadIdx.x;
+        int v = j < nb ? sums[j] : 0;
+        int tot;
+        int ex = block_excl_scan(v, &tot, lds);
+        if (j < nb) sums[j] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const int32_t *__restrict__ in,
+                                                           const int32_t *__restrict__ block_off,
+                                                           int32_t *__restrict__ out, int64_t n) {
+    __shared__ int lds[4];
+    // thread owns SCAN_ITEMS consecutive elements so the scan order is the array order
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        int64_t j = base + i;
+        v[i] = j < n ? in[j] : 0;
+        s += v[i];
+    }
+    int tot;
+    int ex = block_excl_scan(s, &tot, lds) + block_off[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        int64_t j = base + i;
+        if (j < n) out[j] = ex;
+        ex += v[i];
+    }
+}
+
+__global__ void k_fill_i32(int32_t *p, int32_t v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_fill_f64(double *p, double v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n) {
+    if (n <= 0) {
+        fill_i32(out, 0, 1);
+        return;
+    }
+    const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    DevBuf<int32_t> sums((size_t)nb);
+    XR_LAUNCH("scan_reduce", k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), n);
+    XR_LAUNCH("scan_partials", k_scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, sums.get(), nb, out + n);
+    XR_LAUNCH("scan_apply", k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), out, n);
+}
+
+void fill_i32(int32_t *p, int32_t v, int64_t n) {
+    if (n <= 0) return;
+    XR_LAUNCH("fill_i32", k_fill_i32, dim3(div_up(n, 256)), dim3(256), 0, p, v, n);
+}
+void fill_f64(double *p, double v, int64_t n) {
+    if (n <= 0) return;
+    XR_LAUNCH("fill_f64", k_fill_f64, dim3(div_up(n, 256)), dim3(256), 0, p, v, n);
+}
+
+} // namespace xr

@@ -1,0 +1,295 @@
+"""
+Thin object layer over the C ABI: device-resident meshes and CSR weights.
+
+``DeviceMesh`` is the HBM counterpart of ``numba_celltree.CellTree2d(vertices, faces, fill)``
+(xugrid/ugrid/ugrid2d.py:908-921); ``DeviceCSR`` is the HBM counterpart of ``MatrixCSR``
+(xugrid/core/sparse.py:81-137).  Arrays in, arrays out: float64 / np.intp as in the reference
+(xugrid/constants.py:9-10).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import XR_F32, XR_F64, check
+
+IntDType = np.intp
+FloatDType = np.float64
+
+# reducer ids of include/xugrid_amd.h
+METHOD_IDS = {
+    "mean": 0,
+    "harmonic_mean": 1,
+    "geometric_mean": 2,
+    "sum": 3,
+    "minimum": 4,
+    "maximum": 5,
+    "mode": 6,
+    "percentile": 7,
+    "first_order_conservative": 8,
+    "conductance": 8,
+    "max_overlap": 9,
+}
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def init(device=0):
+    """Bind this process to one GPU (one process per GPU)."""
+    check(_lib.load().xr_init(int(device)))
+
+
+def _as_xy(vertices):
+    xy = np.ascontiguousarray(vertices, dtype=np.float64)
+    if xy.ndim != 2 or xy.shape[1] != 2:
+        raise ValueError(f"expected an (n, 2) array of coordinates, received shape {xy.shape}")
+    return xy
+
+
+def _as_faces(faces):
+    f = np.asarray(faces)
+    if f.ndim != 2:
+        raise ValueError(f"expected an (n_face, n_max_node) connectivity, received shape {f.shape}")
+    if not np.issubdtype(f.dtype, np.integer):
+        raise TypeError(f"face_node_connectivity must be integer, received {f.dtype}")
+    if f.dtype.itemsize not in (4, 8) or f.dtype.kind != "i":
+        f = f.astype(np.int64)
+    return np.ascontiguousarray(f)
+
+
+class DeviceMesh:
+    """Face topology resident in HBM (+ lazily built derived data and spatial index)."""
+
+    def __init__(self, vertices, faces, fill_value=-1):
+        lib = _lib.load()
+        xy = _as_xy(vertices)
+        f = _as_faces(faces)
+        self.n_node = xy.shape[0]
+        self.n_face, self.n_max_node = f.shape
+        handle = ctypes.c_void_p()
+        check(
+            lib.xr_mesh_create(
+                _ptr(xy), self.n_node, _ptr(f), f.dtype.itemsize, self.n_face, self.n_max_node,
+                int(fill_value), ctypes.byref(handle),
+            )
+        )
+        self._h = handle
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().xr_mesh_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def prepare(self):
+        check(_lib.load().xr_mesh_prepare(self._h))
+
+    def build_index(self):
+        check(_lib.load().xr_mesh_build_index(self._h))
+
+    def invalidate(self):
+        check(_lib.load().xr_mesh_invalidate(self._h))
+
+    def area(self):
+        out = np.empty(self.n_face, dtype=np.float64)
+        check(_lib.load().xr_mesh_area(self._h, _ptr(out)))
+        return out
+
+    def centroids(self):
+        out = np.empty((self.n_face, 2), dtype=np.float64)
+        check(_lib.load().xr_mesh_centroids(self._h, _ptr(out)))
+        return out
+
+    def faces_ccw(self):
+        out = np.empty((self.n_face, self.n_max_node), dtype=np.int64)
+        check(_lib.load().xr_mesh_faces(self._h, _ptr(out)))
+        return out
+
+    def overlap(self, query: "DeviceMesh", relative=False) -> "DeviceCSR":
+        """All (query face, self face) pairs with positive intersection area, as CSR rows=query."""
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_overlap(self._h, query._h, int(bool(relative)), ctypes.byref(handle)))
+        return DeviceCSR(handle)
+
+    def last_candidates(self):
+        n = ctypes.c_int64(0)
+        check(_lib.load().xr_overlap_stats(self._h, ctypes.byref(n)))
+        return n.value
+
+    def locate_points(self, points, tolerance=None):
+        pts = _as_xy(points)
+        out = np.empty(pts.shape[0], dtype=np.int64)
+        tol = -1.0 if tolerance is None else float(tolerance)
+        if tolerance is not None and tol < 0:
+            raise ValueError("tolerance must be non-negative")
+        check(_lib.load().xr_locate_points(self._h, _ptr(pts), pts.shape[0], tol, _ptr(out)))
+        return out.astype(IntDType, copy=False)
+
+    def compute_barycentric_weights(self, points, tolerance=None):
+        pts = _as_xy(points)
+        face = np.empty(pts.shape[0], dtype=np.int64)
+        w = np.empty((pts.shape[0], self.n_max_node), dtype=np.float64)
+        tol = -1.0 if tolerance is None else float(tolerance)
+        if tolerance is not None and tol < 0:
+            raise ValueError("tolerance must be non-negative")
+        check(_lib.load().xr_barycentric(self._h, _ptr(pts), pts.shape[0], tol, _ptr(face), _ptr(w)))
+        return face.astype(IntDType, copy=False), w
+
+
+def _source_2d(source):
+    """(K, S) C-contiguous float64/float32 view of the source block (regridder.py:152-163)."""
+    a = np.asarray(source)
+    if a.ndim != 2:
+        raise ValueError(f"source must be 2-D (n_extra, size), received shape {a.shape}")
+    if a.dtype == np.float32:
+        return np.ascontiguousarray(a), XR_F32
+    if a.dtype != np.float64:
+        # ints / bools / float16: the reference copies into a float64 workspace (regridder.py:49,57-58)
+        a = a.astype(np.float64)
+    return np.ascontiguousarray(a), XR_F64
+
+
+class DeviceCSR:
+    """MatrixCSR resident in HBM: rows = target faces, columns = source faces."""
+
+    def __init__(self, handle):
+        self._h = handle
+        n, m, nnz = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().xr_csr_info(handle, ctypes.byref(n), ctypes.byref(m), ctypes.byref(nnz)))
+        self.n, self.m, self.nnz = n.value, m.value, nnz.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().xr_csr_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    @classmethod
+    def from_arrays(cls, data, indices, indptr, n, m):
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        indices = np.ascontiguousarray(indices, dtype=np.int64)
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        if indptr.size != n + 1 or indices.size != data.size:
+            raise ValueError("inconsistent CSR arrays")
+        handle = ctypes.c_void_p()
+        check(
+            _lib.load().xr_csr_upload(
+                _ptr(data), _ptr(indices), _ptr(indptr), int(n), int(m), data.size, ctypes.byref(handle)
+            )
+        )
+        return cls(handle)
+
+    @classmethod
+    def from_triplet(cls, row, col, data, n, m):
+        row = np.ascontiguousarray(row, dtype=np.int64)
+        col = np.ascontiguousarray(col, dtype=np.int64)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        handle = ctypes.c_void_p()
+        check(
+            _lib.load().xr_csr_from_triplet(
+                _ptr(row), _ptr(col), _ptr(data), data.size, int(n), int(m), ctypes.byref(handle)
+            )
+        )
+        return cls(handle)
+
+    def download(self):
+        """-> (data float64[nnz], indices intp[nnz], indptr intp[n+1])"""
+        data = np.empty(self.nnz, dtype=np.float64)
+        indices = np.empty(self.nnz, dtype=np.int64)
+        indptr = np.empty(self.n + 1, dtype=np.int64)
+        check(_lib.load().xr_csr_download(self._h, _ptr(data), _ptr(indices), _ptr(indptr)))
+        return data, indices.astype(IntDType, copy=False), indptr.astype(IntDType, copy=False)
+
+    def apply(self, source, method_id=0, percentile=0.0):
+        """make_regrid(f)._regrid(source, A, size): (K, S) -> float64 (K, T)."""
+        src, dtype = _source_2d(source)
+        if src.shape[1] != self.m:
+            raise ValueError(f"source has {src.shape[1]} cells, weights expect {self.m}")
+        K = src.shape[0]
+        out = np.empty((K, self.n), dtype=np.float64)
+        check(_lib.load().xr_apply_csr(self._h, int(method_id), float(percentile), _ptr(src), dtype, K, _ptr(out)))
+        return out
+
+    def apply_dev(self, source_ptr, dtype, K, out_ptr, method_id=0, percentile=0.0):
+        """Device-pointer variant (e.g. torch tensor .data_ptr()); no host transfer."""
+        check(
+            _lib.load().xr_apply_csr_dev(
+                self._h, int(method_id), float(percentile), ctypes.c_void_p(source_ptr), int(dtype), int(K),
+                ctypes.c_void_p(out_ptr),
+            )
+        )
+
+    def partial_mean_dev(self, source_ptr, dtype, K, numden_ptr):
+        check(
+            _lib.load().xr_apply_partial_mean_dev(
+                self._h, ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(numden_ptr)
+            )
+        )
+
+
+def finalize_mean_dev(num_ptr, den_ptr, count, out_ptr):
+    check(
+        _lib.load().xr_finalize_mean_dev(
+            ctypes.c_void_p(num_ptr), ctypes.c_void_p(den_ptr), int(count), ctypes.c_void_p(out_ptr)
+        )
+    )
+
+
+def apply_coo(row, col, n_target, source):
+    """CentroidLocatorRegridder._regrid (regridder.py:400-409)."""
+    src, dtype = _source_2d(source)
+    row = np.ascontiguousarray(row, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int64)
+    K, S = src.shape
+    out = np.empty((K, n_target), dtype=np.float64)
+    check(_lib.load().xr_apply_coo(_ptr(row), _ptr(col), row.size, int(n_target), _ptr(src), dtype, K, S, _ptr(out)))
+    return out
+
+
+class KernelTimer:
+    """In-library hipEvent timing of every kernel launch on the engine stream."""
+
+    def __enter__(self):
+        lib = _lib.load()
+        check(lib.xr_prof_enable(1))
+        check(lib.xr_prof_reset())
+        return self
+
+    def __exit__(self, *exc):
+        self.records = kernel_times()
+        check(_lib.load().xr_prof_enable(0))
+        return False
+
+
+def kernel_times():
+    lib = _lib.load()
+    n = ctypes.c_int(0)
+    check(lib.xr_prof_count(ctypes.byref(n)))
+    out = {}
+    for i in range(n.value):
+        name = ctypes.create_string_buffer(128)
+        launches = ctypes.c_int64(0)
+        ms = ctypes.c_double(0.0)
+        check(lib.xr_prof_get(i, name, 128, ctypes.byref(launches), ctypes.byref(ms)))
+        out[name.value.decode()] = (launches.value, ms.value)
+    return out
+
+
+def prof_enable(on=True):
+    check(_lib.load().xr_prof_enable(int(bool(on))))
+
+
+def prof_reset():
+    check(_lib.load().xr_prof_reset())
+
+
+def dev_sync():
+    check(_lib.load().xr_dev_sync())

@@ -1,0 +1,90 @@
+"""
+Synthetic meshes for the benchmark and the parity tests:
+jittered-lattice points in the unit square, triangulated by scipy's Delaunay (qhull) when
+available, else by splitting every jittered lattice quad along its shorter diagonal.  The
+target meshes of the benchmark are the same generator with another seed, rotated 30 degrees
+about (0.5, 0.5) and scaled by 0.7 so that they lie inside the source hull.
+"""
+import math
+
+import numpy as np
+
+
+def jittered_lattice_points(n_points, seed, jitter=0.35):
+    """~n_points points: an m x m lattice on the unit square, jittered by U(-j, j) * h."""
+    m = max(2, int(round(math.sqrt(n_points))))
+    rng = np.random.default_rng(seed)
+    h = 1.0 / (m - 1)
+    gy, gx = np.meshgrid(np.arange(m) * h, np.arange(m) * h, indexing="ij")
+    x = gx + rng.uniform(-jitter, jitter, gx.shape) * h
+    y = gy + rng.uniform(-jitter, jitter, gy.shape) * h
+    return np.column_stack([x.ravel(), y.ravel()]), m
+
+
+def _split_lattice(points, m):
+    """2 (m-1)^2 CCW triangles: each lattice quad split along its shorter diagonal."""
+    idx = np.arange(m * m).reshape(m, m)
+    a = idx[:-1, :-1].ravel()  # lower-left
+    b = idx[:-1, 1:].ravel()  # lower-right
+    c = idx[1:, 1:].ravel()  # upper-right
+    d = idx[1:, :-1].ravel()  # upper-left
+    p = points
+    d_ac = ((p[a] - p[c]) ** 2).sum(axis=1)
+    d_bd = ((p[b] - p[d]) ** 2).sum(axis=1)
+    use_ac = d_ac <= d_bd
+    t1 = np.where(use_ac[:, None], np.column_stack([a, b, c]), np.column_stack([a, b, d]))
+    t2 = np.where(use_ac[:, None], np.column_stack([a, c, d]), np.column_stack([b, c, d]))
+    faces = np.empty((2 * a.size, 3), dtype=np.int64)
+    faces[0::2] = t1
+    faces[1::2] = t2
+    return faces
+
+
+def triangle_mesh(n_points, seed, rotate_deg=0.0, scale=1.0, delaunay=True):
+    """-> (node_xy float64[n,2], faces int64[F,3]); F ~ 2 n_points.  Faces are CCW."""
+    points, m = jittered_lattice_points(n_points, seed)
+    faces = None
+    if delaunay:
+        try:
+            from scipy.spatial import Delaunay
+
+            faces = Delaunay(points).simplices.astype(np.int64)
+            # qhull orientation is not guaranteed: make every triangle CCW
+            p = points
+            u = p[faces[:, 1]] - p[faces[:, 0]]
+            v = p[faces[:, 2]] - p[faces[:, 0]]
+            cw = (u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]) < 0
+            faces[cw] = faces[cw][:, ::-1]
+        except ImportError:
+            faces = None
+    if faces is None:
+        faces = _split_lattice(points, m)
+    if rotate_deg != 0.0 or scale != 1.0:
+        th = math.radians(rotate_deg)
+        rot = np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+        points = (points - 0.5) @ rot.T * scale + 0.5
+    return np.ascontiguousarray(points), np.ascontiguousarray(faces)
+
+
+def quad_mesh(x_edges, y_edges):
+    """Rectilinear quads: face id = row-major (y, x); CCW for ascending edges."""
+    xe = np.asarray(x_edges, dtype=np.float64)
+    ye = np.asarray(y_edges, dtype=np.float64)
+    nx, ny = xe.size - 1, ye.size - 1
+    yy, xx = np.meshgrid(ye, xe, indexing="ij")
+    xy = np.column_stack([xx.ravel(), yy.ravel()])
+    idx = np.arange((nx + 1) * (ny + 1)).reshape(ny + 1, nx + 1)
+    faces = np.column_stack(
+        [idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel(), idx[1:, 1:].ravel(), idx[1:, :-1].ravel()]
+    ).astype(np.int64)
+    return xy, faces
+
+
+def smooth_field(centroids, seed=0, nan_fraction=0.0):
+    """v = sin(6 pi x) cos(4 pi y) + 0.1 N(0,1) at the given points (BASELINE.md C2 data)."""
+    rng = np.random.default_rng(seed)
+    x, y = centroids[:, 0], centroids[:, 1]
+    v = np.sin(6 * np.pi * x) * np.cos(4 * np.pi * y) + 0.1 * rng.normal(size=x.size)
+    if nan_fraction > 0:
+        v[rng.random(x.size) < nan_fraction] = np.nan
+    return v
