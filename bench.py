@@ -1,0 +1,316 @@
+#!/usr/bin/env python
+"""
+Benchmark of the regridding hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): target cells regridded / s for an OverlapRegridder, area-weighted mean.
+Workload at N = 1: BASELINE config 2 -- a ~1M-triangle Delaunay source mesh (500k jittered-lattice
+points, seed 0) regridded to a ~1M-triangle target (seed 1, rotated 30 degrees, scaled 0.7).
+
+One "step" is one full pass of the hot path over the batch, starting from raw mesh arrays that are
+already resident in HBM (node coordinates f64, connectivity i32, source data f64):
+    per-face preparation of both meshes (fill, CCW, bbox, area)  ->  spatial index over the source
+    ->  candidate search  ->  polygon clip  ->  CSR assembly  ->  apply (mean) of one variable.
+Nothing is cached between steps (xr_mesh_invalidate); the scalar read-backs the path needs (number
+of candidate pairs, nnz) are inside the timed region.  value = T / time per step.
+
+N > 1 (weak scaling): the meshes grow with N (N x 500k points each); source faces are sharded
+over the ranks (Morton blocks), the target is replicated; each step additionally does the one
+exchange step of the path: a reduce-scatter (RCCL) of the per-target partial sums.  value = total
+target cells / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+"roofline" for the dominant kernel (algorithmic bytes / hipEvent-timed duration)
+and, at N = 1, "cpu_baseline" (the CPU oracle -- a port of the reference path -- timed on the host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def make_meshes(points_per_mesh, delaunay=True):
+    from xugrid_amd import meshgen
+
+    t0 = time.perf_counter()
+    sxy, sf = meshgen.triangle_mesh(points_per_mesh, 0, delaunay=delaunay)
+    txy, tf = meshgen.triangle_mesh(points_per_mesh, 1, 30.0, 0.7, delaunay=delaunay)
+    log(f"[bench] meshes: S={sf.shape[0]} T={tf.shape[0]} ({time.perf_counter() - t0:.1f}s)")
+    return sxy, sf, txy, tf
+
+
+def algorithmic_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
+    """Per-kernel algorithmic HBM bytes of one step: every array a kernel
+    must read or write once, int32 connectivity/indices, f64 coordinates/areas."""
+    b = {}
+    b["prepare_faces"] = 4 * (Ms * S + Mt * T) * 2 + 16 * (Ns + Nt) + (1 + 32 + 8) * (S + T)
+    b["index_count"] = 32 * S + 4 * S
+    b["index_fill"] = 32 * S + 4 * S + 4 * S + 20 * S
+    b["search_count"] = 32 * T + 20 * S + 4 * T
+    b["search_fill"] = 32 * T + 20 * S + 4 * T + 8 * C
+    b["clip_v8"] = 8 * C + 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + (S + T) + 8 * C + 4 * T
+    b["row_fill"] = 4 * T + 12 * C + 4 * T + 12 * P
+    b["apply_stream"] = 12 * P + 4 * (T + 1) + 8 * (S + T)
+    # whole weight construction, SURVEY.md 8(d): read both meshes once, write the CSR once
+    b["build_total"] = 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + 12 * P + 4 * (T + 1)
+    return b
+
+
+def cpu_baseline(sxy, sf, txy, tf, data):
+    """The CPU oracle (oracle/xr_oracle.c: cell tree + SAT + Sutherland-Hodgman + CSR + mean apply,
+    OpenMP over queries / candidate pairs, apply threaded over K only as numba's prange) timed once
+    on the full workload."""
+    from oracle import oracle as O
+
+    O.build()
+    cores = O.num_threads()
+    t0 = time.perf_counter()
+    tree = O.CellTree2d(sxy, sf)
+    q, s, a = tree.intersect_faces(txy, tf)
+    indptr = O.to_csr_indptr(q, tf.shape[0])
+    t1 = time.perf_counter()
+    out = O.regrid_csr("mean", data[None, :], a, s, indptr, tf.shape[0], parallel_rows=False)
+    t2 = time.perf_counter()
+    log(f"[bench] cpu oracle: weights {t1 - t0:.2f}s apply {t2 - t1:.3f}s on {cores} threads, nnz {a.size}")
+    return {
+        "value": tf.shape[0] / (t2 - t0),
+        "unit": "target cells/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"full workload once: S={sf.shape[0]} T={tf.shape[0]} K=1 (weights {t1 - t0:.2f}s + apply {t2 - t1:.3f}s)",
+    }, out[0]
+
+
+def run_single(args):
+    import ctypes
+
+    import xugrid_amd as xa
+    from xugrid_amd import _lib, engine as E
+
+    E.init(0)
+    lib = _lib.load()
+    sxy, sf, txy, tf = make_meshes(args.points, delaunay=not args.no_delaunay)
+    S, T, Ns, Nt = sf.shape[0], tf.shape[0], sxy.shape[0], txy.shape[0]
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    data = xa.meshgen.smooth_field(ms.centroids(), 0)
+    # source data and output resident in HBM
+    d_src, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.xr_dev_alloc(8 * S, ctypes.byref(d_src)))
+    _lib.check(lib.xr_dev_alloc(8 * T, ctypes.byref(d_out)))
+    _lib.check(lib.xr_dev_upload(d_src, data.ctypes.data_as(ctypes.c_void_p), 8 * S))
+
+    state = {}
+
+    def step():
+        ms.invalidate()
+        mt.invalidate()
+        csr = ms.overlap(mt)  # prepare x2 + index + search + clip + CSR
+        csr.apply_dev(d_src.value, E.XR_F64, 1, d_out.value, 0)
+        state["csr"] = csr
+
+    for _ in range(args.warmup):
+        step()
+    E.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    E.dev_sync()
+    elapsed = time.perf_counter() - t0
+    ms_per_step = 1e3 * elapsed / args.steps
+    csr = state["csr"]
+    C, P = ms.last_candidates(), csr.nnz
+
+    # weights-only and apply-only rates (reported in config, not the headline)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        csr.apply_dev(d_src.value, E.XR_F64, 1, d_out.value, 0)
+    E.dev_sync()
+    apply_ms = 1e3 * (time.perf_counter() - t0) / args.steps
+
+    # per-kernel durations: the same K steps with hipEvents around every launch (engine stream)
+    with E.KernelTimer() as kt:
+        for _ in range(args.steps):
+            step()
+    kernels = {k: (n, t / n) for k, (n, t) in kt.records.items()}  # name -> (launches, avg ms)
+    per_step = {k: n * avg / args.steps for k, (n, avg) in kernels.items()}
+    dominant = max(per_step, key=per_step.get)
+    ab = algorithmic_bytes(S, T, Ns, Nt, C, P)
+    dom_bytes = ab.get(dominant)
+    dom_ms = kernels[dominant][1]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_bytes else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant)
+        except Exception:
+            traffic = None
+    build_ms = sum(v for k, v in per_step.items() if k != "apply_stream")
+    roofline = {
+        "bound": "hbm",
+        "kernel": dominant,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS if achieved else None,
+        "traffic": traffic,
+        "algorithmic_bytes_per_launch": dom_bytes,
+        "avg_launch_ms": dom_ms,
+        "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+        "build_aggregate": {
+            "algorithmic_bytes": ab["build_total"],
+            "kernel_ms": build_ms,
+            "GBps": ab["build_total"] / (build_ms * 1e-3) / 1e9,
+            "frac": ab["build_total"] / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        },
+        "apply": {
+            "algorithmic_bytes": ab["apply_stream"],
+            "avg_launch_ms": kernels["apply_stream"][1],
+            "GBps": ab["apply_stream"] / (kernels["apply_stream"][1] * 1e-3) / 1e9,
+            "frac": ab["apply_stream"] / (kernels["apply_stream"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        },
+    }
+
+    out_gpu = np.empty(T)
+    _lib.check(lib.xr_dev_download(out_gpu.ctypes.data_as(ctypes.c_void_p), d_out, 8 * T))
+    cpu = None
+    if not args.no_cpu:
+        cpu, out_cpu = cpu_baseline(sxy, sf, txy, tf, data)
+        same = np.array_equal(out_gpu, out_cpu, equal_nan=True)
+        log(f"[bench] GPU result identical to the CPU oracle: {same}")
+        cpu["gpu_result_identical"] = bool(same)
+    result = {
+        "metric": "target cells regridded/s (OverlapRegridder 1M->1M tri, weights + mean apply)",
+        "value": T / (elapsed / args.steps),
+        "unit": "target cells/s",
+        "n_gpus": 1,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "BASELINE config 2: ~1M-triangle jittered-lattice Delaunay source -> ~1M-triangle target "
+            "(seed 1, rotated 30 deg, scaled 0.7), OverlapRegridder area-weighted mean, K=1",
+            "source_faces": S,
+            "target_faces": T,
+            "candidate_pairs": C,
+            "nnz": P,
+            "parallelism": "1 GPU",
+            "apply_only_ms": apply_ms,
+            "apply_only_cells_per_s": T / (apply_ms * 1e-3),
+        },
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+    }
+    print(json.dumps(result), flush=True)
+
+
+def run_multi(args):
+    import torch
+    import torch.distributed as dist
+
+    from xugrid_amd import meshgen
+    from xugrid_amd.distributed import HipBackend, ShardedOverlapRegridder, init_process_group_from_env
+
+    init_process_group_from_env("nccl")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    backend = HipBackend(local_rank)
+    # weak scaling: N x 500k points per mesh.  The lattice-split triangulation keeps the set-up of
+    # the N-times larger meshes to seconds on every rank (qhull on 4M points takes minutes).
+    sxy, sf, txy, tf = make_meshes(args.points * world, delaunay=False)
+    S, T = sf.shape[0], tf.shape[0]
+    rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition)
+    data = meshgen.smooth_field(sxy[sf].mean(axis=1), 0)
+    local = rg.local_source(data)
+
+    def step():
+        rg.rebuild()
+        return rg.regrid_local(local)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=backend.device)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+    nnz = torch.tensor([rg.weights.nnz], dtype=torch.int64, device=backend.device)
+    dist.all_reduce(nnz)
+    if rank == 0:
+        result = {
+            "metric": "target cells regridded/s (OverlapRegridder 1M->1M tri per GPU, weights + mean apply)",
+            "value": T / (elapsed / args.steps),
+            "unit": "target cells/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{world} x BASELINE config 2: ~{S} source -> ~{T} target triangles (lattice-split "
+                "triangulation), OverlapRegridder mean, K=1",
+                "source_faces": S,
+                "target_faces": T,
+                "nnz": int(nnz.item()),
+                "parallelism": f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
+                "RCCL reduce-scatter of per-target partial sums",
+            },
+            "roofline": None,
+            "cpu_baseline": None,
+        }
+        print(json.dumps(result), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=500_000, help="lattice points per mesh and per GPU (faces ~ 2x)")
+    ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--partition", default="morton", choices=["morton", "hash"])
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        run_multi(args)
+    else:
+        run_single(args)
+
+
+if __name__ == "__main__":
+    main()

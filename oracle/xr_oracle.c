@@ -973,8 +973,10 @@ double xo_default_tolerance(const xo_tree *t) {
 }
 
 /* point_in_polygon_or_on_edge: crossing-number test, plus "on edge" when the point is
- * within `tol` (distance) of an edge segment:  |cross(p-v0, p-v1)| <= tol*|v1-v0| and the
- * projection parameter lies in [0,1] (extended by tol at both ends). */
+ * strictly within `tol` (distance) of an edge's line, |cross(p-v0, v1-v0)| < tol*|v1-v0|, and its
+ * projection falls on the segment (0 <= t <= 1).  Pinned by tests/test_ugrid2d.py:724-730 (a point
+ * 0.01 outside is found with tolerance 0.011) and :771-791 (a point 0.01 beyond a corner along
+ * the edge direction, or exactly tol away, is NOT found with tolerance 0.01). */
 static int point_in_poly_or_on_edge(P2 p, const P2 *poly, int n, double tol) {
     int c = 0;
     P2 v0 = poly[n - 1];
@@ -986,9 +988,9 @@ static int point_in_poly_or_on_edge(P2 p, const P2 *poly, int n, double tol) {
             double ux = p.x - v0.x, uy = p.y - v0.y;
             double twice_area = fabs(wx * uy - wy * ux);
             double len = sqrt(len2);
-            if (twice_area <= tol * len) {
+            if (twice_area < tol * len) {
                 double tpar = ux * wx + uy * wy; /* = t * len2 */
-                if (tpar >= -tol * len && tpar <= len2 + tol * len) return 1;
+                if (tpar >= 0 && tpar <= len2) return 1;
             }
             if ((v0.y > p.y) != (v1.y > p.y)) {
                 double xint = wx * (p.y - v0.y) / wy + v0.x;
@@ -1056,9 +1058,9 @@ static void bary_weights(P2 p, const P2 *poly, int n, double tol, double *w /* n
         double len2 = wx * wx + wy * wy;
         if (len2 > 0) {
             double len = sqrt(len2);
-            if (fabs(a) <= tol * len) {
+            if (fabs(a) < tol * len) {
                 double tpar = ux * wx + uy * wy;
-                if (tpar >= -tol * len && tpar <= len2 + tol * len) {
+                if (tpar >= 0 && tpar <= len2) {
                     double tt = tpar / len2;
                     if (tt < 0) tt = 0;
                     if (tt > 1) tt = 1;

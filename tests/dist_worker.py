@@ -1,0 +1,77 @@
+"""Worker of the world_size-2 gloo tests: ShardedOverlapRegridder with an ORACLE-backed compute
+backend (tests only) -- exercises partitioning, padding, the reduce-scatter layout and the
+finalise step on CPU.  Launched by test_distributed_cpu.py via torch.distributed.run."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from xugrid_amd import meshgen  # noqa: E402
+from xugrid_amd.distributed import ShardedOverlapRegridder, init_process_group_from_env  # noqa: E402
+
+
+class OracleWeights:
+    def __init__(self, data, indices, indptr, n):
+        self.data, self.indices, self.indptr, self.n = data, indices, indptr, n
+
+
+class OracleBackend:
+    """Same three methods as xugrid_amd.distributed.HipBackend, computed by the CPU oracle."""
+
+    def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces):
+        q, s, a = O.CellTree2d(src_xy, src_faces).intersect_faces(tgt_xy, tgt_faces)
+        T = np.asarray(tgt_faces).shape[0]
+        return OracleWeights(a, s, O.to_csr_indptr(q, T), T)
+
+    def to_device(self, array):
+        return torch.as_tensor(np.ascontiguousarray(array))
+
+    def partial_mean(self, w, source):
+        src = source.numpy().astype(np.float64)
+        K = src.shape[0]
+        out = np.zeros((2, K, w.n))
+        rows = np.repeat(np.arange(w.n), np.diff(w.indptr))
+        for k in range(K):
+            v = src[k, w.indices]
+            ok = ~np.isnan(v)
+            out[0, k] = np.bincount(rows[ok], weights=(w.data * v)[ok], minlength=w.n)
+            out[1, k] = np.bincount(rows[ok], weights=w.data[ok], minlength=w.n)
+        return torch.as_tensor(out)
+
+    def finalize_mean(self, num, den):
+        n, d = num.numpy(), den.numpy()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return torch.as_tensor(np.where(d == 0, np.nan, n / d))
+
+
+def main():
+    out_dir = sys.argv[1]
+    dist_ = init_process_group_from_env("gloo")
+    rank, world = dist_.get_rank(), dist_.get_world_size()
+    sxy, sf = meshgen.triangle_mesh(1500, 0)
+    txy, tf = meshgen.triangle_mesh(1203, 1, 30.0, 0.7)  # T not divisible by the world size
+    data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
+    results = {}
+    for mode in ("morton", "hash"):
+        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition=mode)
+        owned = torch.zeros(sf.shape[0], dtype=torch.int64)
+        owned[torch.as_tensor(rg.local_faces)] = 1
+        dist.all_reduce(owned)
+        assert bool((owned == 1).all()), "every source face must be owned by exactly one rank"
+        results[mode] = rg.regrid(data)
+        results[mode + "_1d"] = rg.regrid(data[0])
+        results[mode + "_n_local"] = rg.local_faces.size
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "dist_out.npz"), world=world, **results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,345 @@
+"""
+GPU (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs, against the committed golden fixtures, and -- at BASELINE.json's full sizes -- through
+size-independent properties.  Bar: indices bit-exact, overlap areas bit-exact (identical
+operation order, no FMA contraction on either side), regridded values bit-exact except
+geometric_mean (device exp/log vs libm: rtol 1e-13; north_star tolerance is 1e-10).
+"""
+import numpy as np
+import pytest
+
+from conftest import same_or_nan
+from xugrid_amd import meshgen
+
+pytestmark = pytest.mark.gpu
+
+RTOL_GEOMETRIC = 1e-13
+
+
+def gpu_triplets(hip, sxy, sf, txy, tf, relative=False, fill=-1):
+    E = hip.engine
+    ms, mt = E.DeviceMesh(sxy, sf, fill), E.DeviceMesh(txy, tf, fill)
+    csr = ms.overlap(mt, relative)
+    data, idx, indptr = csr.download()
+    q = np.repeat(np.arange(csr.n), np.diff(indptr))
+    return csr, q, idx, data, indptr
+
+
+def assert_overlap_parity(hip, oracle, sxy, sf, txy, tf, relative=False, fill=-1):
+    tree = oracle.CellTree2d(sxy, sf, fill)
+    oq, os_, oa = tree.intersect_faces(txy, tf, fill)
+    if relative:
+        sf_norm = np.where(np.asarray(sf) == fill, -1, sf)
+        oa = oa / oracle.area(sxy, sf_norm)[os_]
+    csr, q, idx, data, indptr = gpu_triplets(hip, sxy, sf, txy, tf, relative, fill)
+    assert csr.n == np.asarray(tf).shape[0] and csr.m == np.asarray(sf).shape[0]
+    assert np.array_equal(q, oq), "target indices differ"
+    assert np.array_equal(idx, os_), "source indices differ"
+    assert np.array_equal(data, oa), "areas not bit-exact (max rel %.3g)" % (np.abs(data - oa) / oa).max()
+    # rows sorted by source index
+    for t in np.nonzero(np.diff(indptr) > 1)[0][:2000]:
+        row = idx[indptr[t]:indptr[t + 1]]
+        assert (np.diff(row) > 0).all()
+    return csr, (data, idx, indptr)
+
+
+def test_overlap_triangles_delaunay(hip, oracle):
+    sxy, sf = meshgen.triangle_mesh(3000, 0)
+    txy, tf = meshgen.triangle_mesh(3000, 1, 30.0, 0.7)
+    assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
+    assert_overlap_parity(hip, oracle, sxy, sf, txy, tf, relative=True)
+    assert_overlap_parity(hip, oracle, txy, tf, sxy, sf)  # fine target partly outside the source hull
+
+
+def test_overlap_clockwise_and_fill_values(hip, oracle):
+    sxy, sf = meshgen.triangle_mesh(800, 2)
+    txy, tf = meshgen.quad_mesh(np.linspace(0.05, 0.95, 23), np.linspace(0.1, 0.9, 17))
+    sf_cw = sf[:, ::-1].copy()
+    assert_overlap_parity(hip, oracle, sxy, sf_cw, txy, tf)
+    # triangles padded to 5 columns with a non-default fill value, quads padded likewise
+    sf5 = np.full((sf.shape[0], 5), -999, dtype=np.int64)
+    sf5[:, :3] = sf
+    tf5 = np.full((tf.shape[0], 5), -999, dtype=np.int64)
+    tf5[:, :4] = tf[:, ::-1]
+    assert_overlap_parity(hip, oracle, sxy, sf5, txy, tf5, fill=-999)
+    assert_overlap_parity(hip, oracle, sxy, sf5, txy, tf5, relative=True, fill=-999)
+
+
+def test_overlap_polygons_up_to_hexagons(hip, oracle):
+    """mixed 3..6-gons (voronoi cells of a Delaunay mesh) against triangles: MAXV = 16 clip kernel."""
+    from xugrid_amd import connectivity as C, voronoi
+
+    xy, faces = meshgen.triangle_mesh(400, 5)
+    cen = xy[faces].mean(axis=1)
+    nfc = C.invert_dense_to_sparse(faces, n_rows=len(xy))
+    v, cells, _, _ = voronoi.voronoi_topology(nfc, xy, cen)  # interior cells only, ragged
+    assert cells.shape[1] > 4
+    txy, tf = meshgen.triangle_mesh(500, 6, 10.0, 0.8)
+    assert_overlap_parity(hip, oracle, v, cells, txy, tf)
+    assert_overlap_parity(hip, oracle, txy, tf, v, cells)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_overlap_rectilinear_goldens(hip, golden, tag):
+    """HIP clip of quads == the reference's separable structured overlap (golden G4)."""
+    g = golden("g4_rectilinear.npz")
+    sxy, sf = meshgen.quad_mesh(g[tag + "_xe_s"], g[tag + "_ye_s"])
+    txy, tf = meshgen.quad_mesh(g[tag + "_xe_t"], g[tag + "_ye_t"])
+    _, q, idx, data, _ = gpu_triplets(hip, sxy, sf, txy, tf)
+    assert np.array_equal(q, g[tag + "_tgt"]) and np.array_equal(idx, g[tag + "_src"])
+    np.testing.assert_allclose(data, g[tag + "_w"], rtol=1e-12)
+
+
+def test_overlap_long_rows_and_big_queries(hip, oracle):
+    """coarse target over a fine source (rows of thousands of entries -> LDS bitmap rank kernel,
+    wave-per-face search) and the reverse (rows of 1-2 entries)."""
+    sxy, sf = meshgen.triangle_mesh(40000, 3)
+    txy, tf = meshgen.quad_mesh(np.linspace(-0.1, 1.1, 7), np.linspace(0.0, 1.0, 5))
+    csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
+    assert np.diff(indptr).max() > 2000
+    assert_overlap_parity(hip, oracle, txy, tf, sxy, sf, relative=True)
+
+
+def test_overlap_graded_mesh_many_levels(hip, oracle):
+    """face sizes spanning 4 orders of magnitude -> many grid levels."""
+    rng = np.random.default_rng(9)
+    r = 10.0 ** rng.uniform(-4, 0, 3000)
+    th = rng.uniform(0, 2 * np.pi, 3000)
+    pts = np.column_stack([r * np.cos(th), r * np.sin(th)])
+    from scipy.spatial import Delaunay
+
+    sf = Delaunay(pts).simplices.astype(np.int64)
+    txy, tf = meshgen.triangle_mesh(1500, 4, 15.0, 1.6)
+    txy = txy - 0.5
+    assert_overlap_parity(hip, oracle, pts, sf, txy, tf)
+    assert_overlap_parity(hip, oracle, txy, tf, pts, sf)
+
+
+def test_overlap_degenerate_inputs(hip, oracle):
+    sxy, sf = meshgen.triangle_mesh(100, 1)
+    # disjoint meshes -> empty matrix, apply gives NaN everywhere
+    csr, q, idx, data, indptr = gpu_triplets(hip, sxy, sf, sxy + 10.0, sf)
+    assert csr.nnz == 0 and np.array_equal(indptr, np.zeros(sf.shape[0] + 1, dtype=indptr.dtype))
+    out = csr.apply(np.ones((2, sf.shape[0])))
+    assert out.shape == (2, sf.shape[0]) and np.isnan(out).all()
+    # single face vs single face, identical -> one pair with the face area
+    one = np.array([[0, 1, 2]])
+    tri = np.array([[0.0, 0.0], [2.0, 0.0], [0.0, 1.0]])
+    csr, q, idx, data, _ = gpu_triplets(hip, tri, one, tri, one)
+    assert csr.nnz == 1 and data[0] == 1.0
+    # faces sharing only an edge / a vertex give no pair (area > 0 filter)
+    tri2 = np.array([[2.0, 0.0], [2.0, 1.0], [0.0, 1.0]])
+    csr, *_ = gpu_triplets(hip, tri, one, tri2, one)
+    assert csr.nnz == 0
+    # zero-area (collinear) face and repeated vertices
+    xy = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0], [1.0, 1.0]])
+    f = np.array([[0, 1, 2, -1], [0, 2, 3, -1], [0, 1, 1, 3]])
+    assert_overlap_parity(hip, oracle, xy, f, tri, one[:, [0, 1, 2]])
+    # empty query mesh
+    E = hip.engine
+    empty = E.DeviceMesh(sxy, np.zeros((0, 3), dtype=np.int64))
+    csr = E.DeviceMesh(sxy, sf).overlap(empty)
+    assert (csr.n, csr.m, csr.nnz) == (0, sf.shape[0], 0)
+    csr = empty.overlap(E.DeviceMesh(sxy, sf))
+    assert (csr.n, csr.m, csr.nnz) == (sf.shape[0], 0, 0)
+    with pytest.raises(ValueError):
+        E.DeviceMesh(sxy, np.array([[0, 1, 10**6]]))  # node index out of range
+    with pytest.raises(ValueError):
+        E.DeviceMesh(sxy, np.array([[0, 1, -1]]))  # fewer than 3 nodes
+    with pytest.raises(OverflowError):
+        E.DeviceMesh(sxy, np.zeros((1, 40), dtype=np.int64))  # more than 32 nodes per face
+
+
+def test_mesh_geometry_goldens(hip, golden):
+    """area / centroids kernels == connectivity.area / centroids of the reference, bit for bit."""
+    g = golden("g5_geometry.npz")
+    for t in ("tri", "quad", "mix"):
+        mesh = hip.engine.DeviceMesh(g[t + "_xy"], g[t + "_faces"])
+        assert np.array_equal(mesh.area(), g[t + "_area"])
+        assert np.array_equal(mesh.centroids(), g[t + "_centroids"])
+
+
+METHODS = [
+    ("mean", 0, 0.0), ("harmonic_mean", 1, 0.0), ("geometric_mean", 2, 0.0), ("sum", 3, 0.0),
+    ("minimum", 4, 0.0), ("maximum", 5, 0.0), ("mode", 6, 0.0), ("median", 7, 50.0), ("p5", 7, 5.0),
+    ("p10", 7, 10.0), ("p25", 7, 25.0), ("p50", 7, 50.0), ("p75", 7, 75.0), ("p90", 7, 90.0), ("p95", 7, 95.0),
+    ("p33.3", 7, 33.3), ("p0", 7, 0.0), ("p100", 7, 100.0), ("first_order_conservative", 8, 0.0),
+    ("conductance", 8, 0.0), ("max_overlap", 9, 0.0),
+]
+
+
+@pytest.mark.parametrize("name,mid,p", METHODS)
+def test_apply_golden_g2(hip, golden, name, mid, p):
+    """every reducer on the reference's own (inputs, outputs): make_regrid(f)._regrid, golden G2."""
+    g = golden("g2_apply.npz")
+    T, S = int(g["T"]), int(g["S"])
+    csr = hip.engine.DeviceCSR.from_arrays(g["data"], g["indices"], g["indptr"], T, S)
+    for tag in ("64", "32"):
+        got = csr.apply(g["src" + tag], mid, p)
+        exp = g[f"out{tag}_{name}"]
+        assert got.dtype == np.float64 and got.shape == exp.shape
+        if name == "geometric_mean":
+            np.testing.assert_allclose(got, exp, rtol=RTOL_GEOMETRIC, equal_nan=True)
+        else:
+            assert same_or_nan(got, exp).all(), "%d mismatches" % (~same_or_nan(got, exp)).sum()
+
+
+def test_apply_coo_golden(hip, golden):
+    g = golden("g2_apply.npz")
+    got = hip.engine.apply_coo(g["coo_row"], g["coo_col"], int(g["T"]), g["src64"])
+    assert same_or_nan(got, g["coo_out64"]).all()
+
+
+def test_csr_from_triplet_golden(hip, golden):
+    g = golden("g3_csr.npz")
+    csr = hip.engine.DeviceCSR.from_triplet(g["row"], g["col"], g["data"], int(g["n"]), int(g["m"]))
+    data, idx, indptr = csr.download()
+    assert np.array_equal(indptr, g["indptr"]) and np.array_equal(idx, g["indices"]) and np.array_equal(data, g["data"])
+    with pytest.raises(ValueError):  # rows must be sorted (core/sparse.py:65)
+        hip.engine.DeviceCSR.from_triplet(np.array([1, 0]), np.array([0, 0]), np.ones(2), 2, 1)
+
+
+def test_apply_vs_oracle_on_overlap_weights(hip, oracle):
+    sxy, sf = meshgen.triangle_mesh(2500, 0)
+    txy, tf = meshgen.triangle_mesh(2000, 1, 30.0, 0.7)
+    csr, _, idx, data, indptr = gpu_triplets(hip, sxy, sf, txy, tf)
+    v = meshgen.smooth_field(oracle.centroids(sxy, sf), 0, nan_fraction=0.05)
+    src = np.stack([v, np.abs(v) + 0.1, np.round(3 * v), -np.abs(v), np.zeros_like(v)])
+    for name, mid, p in METHODS:
+        m = ("percentile", p) if mid == 7 else name
+        for dtype in (np.float64, np.float32):
+            s_ = src.astype(dtype)
+            got = csr.apply(s_, mid, p)
+            exp = oracle.regrid_csr(m, s_.astype(np.float64), data, idx, indptr, csr.n)
+            if name == "geometric_mean":
+                np.testing.assert_allclose(got, exp, rtol=RTOL_GEOMETRIC, equal_nan=True)
+            else:
+                assert same_or_nan(got, exp).all(), (name, dtype)
+    # K not a multiple of the k-tile, and K = 1
+    for K in (1, 7, 9, 17):
+        s_ = np.random.default_rng(K).normal(size=(K, csr.m))
+        got = csr.apply(s_, 0)
+        assert same_or_nan(got, oracle.regrid_csr("mean", s_, data, idx, indptr, csr.n)).all()
+    with pytest.raises(ValueError):
+        csr.apply(np.ones((1, csr.m + 1)))
+    with pytest.raises(ValueError):
+        csr.apply(np.ones((1, csr.m)), 7, 101.0)
+    # integer input is promoted like the reference's float64 workspace
+    got = csr.apply(np.arange(csr.m)[None, :], 0)
+    exp = oracle.regrid_csr("mean", np.arange(csr.m, dtype=np.float64)[None, :], data, idx, indptr, csr.n)
+    assert same_or_nan(got, exp).all()
+
+
+def grid2d():
+    xy = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0], [0.0, 1.0], [1.0, 1.0], [2.0, 1.0], [1.0, 2.0]])
+    faces = np.array([[0, 1, 4, 3], [1, 2, 5, 4], [3, 4, 6, -1], [4, 5, 6, -1]])
+    return xy, faces
+
+
+def test_locate_and_barycentric_known_answers(hip):
+    xy, faces = grid2d()
+    mesh = hip.engine.DeviceMesh(xy, faces)
+    assert np.array_equal(mesh.locate_points(mesh.centroids()), [0, 1, 2, 3])
+    off = np.array([[-0.01, 1.0], [-0.01, 0.5]])
+    assert np.array_equal(mesh.locate_points(off, 0.011), [0, 0])  # tests/test_ugrid2d.py:724-730
+    pts = np.array([[0.0, 0.0], [0.5, 0.5], [1.5, 0.5], [0.5, 1.5], [2.0, 2.0]])
+    face, w = mesh.compute_barycentric_weights(pts)  # tests/test_ugrid2d.py:751-791
+    assert np.array_equal(face, [0, 0, 1, 2, -1])
+    expected = np.array([[1.0, 0, 0, 0], [0.25] * 4, [0.25] * 4, [0.5, 0.0, 0.5, 0.0], [0.0] * 4])
+    np.testing.assert_allclose(w, expected, atol=1e-15)
+    pts[:, 0] -= 0.01
+    face, w = mesh.compute_barycentric_weights(pts, tolerance=0.01)
+    assert np.array_equal(face, [-1, 0, 1, 2, -1])
+    expected[0] = 0.0
+    np.testing.assert_allclose(w, expected, atol=0.05)
+
+
+def test_locate_and_barycentric_vs_oracle(hip, oracle):
+    from xugrid_amd import connectivity as C, voronoi
+
+    xy, faces = meshgen.triangle_mesh(5000, 0)
+    rng = np.random.default_rng(5)
+    pts = rng.random((20000, 2)) * 1.1 - 0.05
+    # points exactly on vertices and edge midpoints (ties -> lowest face index)
+    pts[:500] = xy[rng.integers(0, len(xy), 500)]
+    e = faces[rng.integers(0, len(faces), 500)]
+    pts[500:1000] = 0.5 * (xy[e[:, 0]] + xy[e[:, 1]])
+    mesh, tree = hip.engine.DeviceMesh(xy, faces), oracle.CellTree2d(xy, faces)
+    for tol in (None, 0.0, 1e-3):
+        assert np.array_equal(mesh.locate_points(pts, tol), tree.locate_points(pts, tol))
+        fo, wo = tree.compute_barycentric_weights(pts, tol)
+        fg, wg = mesh.compute_barycentric_weights(pts, tol)
+        assert np.array_equal(fo, fg) and np.array_equal(wo, wg)
+    # polygons (voronoi cells incl. exterior) -> Wachspress branch
+    cen = oracle.centroids(xy, faces)
+    enc, fec = C.edge_connectivity(faces)
+    v, cells, _, _ = voronoi.voronoi_topology(C.invert_dense_to_sparse(faces, n_rows=len(xy)), xy, cen,
+                                              C.invert_dense(fec), enc, True, True, True)
+    mesh, tree = hip.engine.DeviceMesh(v, cells), oracle.CellTree2d(v, cells)
+    fo, wo = tree.compute_barycentric_weights(pts)
+    fg, wg = mesh.compute_barycentric_weights(pts)
+    assert np.array_equal(fo, fg) and np.array_equal(wo, wg)
+    inside = fo >= 0
+    np.testing.assert_allclose(wo[inside].sum(axis=1), 1.0, rtol=1e-12)
+
+
+def test_elevation_nl_config1(hip, oracle, golden):
+    """BASELINE config 1: elevation_nl (5248 triangles) -> 200 x 200 raster, mean."""
+    g = golden("g8_elevation_nl.npz")
+    xy = np.column_stack([g["node_x"], g["node_y"]])
+    faces = g["face_nodes"].astype(np.int64)
+    xmin, ymin, xmax, ymax = xy[:, 0].min(), xy[:, 1].min(), xy[:, 0].max(), xy[:, 1].max()
+    txy, tf = meshgen.quad_mesh(np.linspace(xmin, xmax, 201), np.linspace(ymin, ymax, 201))
+    csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, xy, faces, txy, tf)
+    elev = g["elevation"][None, :]
+    assert elev.dtype == np.float32
+    got = csr.apply(elev, 0)
+    exp = oracle.regrid_csr("mean", elev.astype(np.float64), data, idx, indptr, csr.n)
+    assert same_or_nan(got, exp).all()
+    total = oracle.area(xy, faces).sum()
+    assert abs(data.sum() / total - 1) < 1e-10
+    valid = ~np.isnan(got)
+    assert got[valid].min() >= -60.67 and got[valid].max() <= 252.74
+
+
+@pytest.mark.parametrize("n_points", [500_000])
+def test_full_size_properties(hip, n_points):
+    """BASELINE config 2 size (1M -> 1M triangles): size-independent properties of the result."""
+    sxy, sf = meshgen.triangle_mesh(n_points, 0, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(n_points, 1, 30.0, 0.7, delaunay=False)
+    E = hip.engine
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    csr = ms.overlap(mt)
+    data, idx, indptr = csr.download()
+    assert csr.n == tf.shape[0] and csr.m == sf.shape[0] and data.size == csr.nnz == indptr[-1]
+    assert (data > 0).all() and idx.min() >= 0 and idx.max() < csr.m
+    # rows strictly ascending in the source index
+    inner = np.ones(idx.size, dtype=bool)
+    inner[indptr[:-1][np.diff(indptr) > 0]] = False
+    assert (np.diff(idx)[inner[1:]] > 0).all()
+    # the target mesh lies inside the source hull: every target face is fully covered
+    t_area = mt.area()
+    row_sum = np.add.reduceat(data, indptr[:-1][np.diff(indptr) > 0])
+    full = np.diff(indptr) > 0
+    np.testing.assert_allclose(row_sum, t_area[full], rtol=1e-9)
+    assert full.all()
+    # column sums never exceed the source face area; total area is conserved
+    col_sum = np.bincount(idx, weights=data, minlength=csr.m)
+    assert (col_sum <= ms.area() * (1 + 1e-9)).all()
+    assert abs(data.sum() / t_area.sum() - 1) < 1e-10
+    # a constant field regrids to the same constant; linearity of mean in the data
+    one = csr.apply(np.full((1, csr.m), 3.25))
+    assert np.array_equal(one, np.full((1, csr.n), 3.25)) or np.allclose(one, 3.25, rtol=1e-14)
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(size=(1, csr.m)), rng.normal(size=(1, csr.m))
+    lhs = csr.apply(2.0 * a + b)
+    rhs = 2.0 * csr.apply(a) + csr.apply(b)
+    np.testing.assert_allclose(lhs, rhs, rtol=1e-10, atol=1e-12)
+    # determinism: rebuilding gives the identical matrix
+    ms.invalidate(); mt.invalidate()
+    d2, i2, p2 = ms.overlap(mt).download()
+    assert np.array_equal(d2, data) and np.array_equal(i2, idx) and np.array_equal(p2, indptr)
+    # relative weights: column sums == covered fraction <= 1; conservative regridding of ones
+    rel = ms.overlap(mt, relative=True)
+    rd, ri, rp = rel.download()
+    assert np.array_equal(ri, idx) and np.array_equal(rd, data / ms.area()[idx])

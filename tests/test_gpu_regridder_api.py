@@ -1,0 +1,204 @@
+"""
+GPU (-m gpu): the Regridder classes -- the reference's user API (xugrid/regrid/regridder.py) -- on
+the HIP engine.  Known answers are the numbers of the reference's own tests/fixtures
+(tests/fixtures/fixture_regridder.py, tests/test_regrid/test_regridder.py), transcribed.
+"""
+import numpy as np
+import pytest
+
+import xugrid_amd as xa
+from conftest import same_or_nan
+from xugrid_amd import meshgen
+
+pytestmark = pytest.mark.gpu
+
+
+def raster_a():  # grid_data_a: 3x3, 50 m cells, y descending
+    return xa.Raster(x=[50.0, 100.0, 150.0], y=[150.0, 100.0, 50.0], dx=50.0, dy=-50.0)
+
+
+def raster_b():  # grid_data_b: 4x4
+    return xa.Raster(x=[25.0, 75.0, 125.0, 175.0], y=[175.0, 125.0, 75.0, 25.0], dx=50.0, dy=-50.0)
+
+
+def disk_like(n=400, seed=3):
+    xy, faces = meshgen.triangle_mesh(n, seed)
+    return xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+
+
+EXPECTED_OVERLAP = np.array([0.0, 0.5, 1.5, 2.0, 1.5, 2.0, 3.0, 3.5, 4.5, 5.0, 6.0, 6.5, 6.0, 6.5, 7.5, 8.0]).reshape(4, 4)
+EXPECTED_CENTROID = np.full((4, 4), np.nan)
+EXPECTED_CENTROID[1:3, 1:3] = [[0, 1], [3, 4]]
+EXPECTED_LINEAR = np.full((4, 4), np.nan)
+EXPECTED_LINEAR[1:3, 1:3] = [[2.0, 3.0], [5.0, 6.0]]
+
+
+def test_overlap_regridder_structured_known_answer(hip):
+    """expected_results_overlap (fixture_regridder.py:294-322): 3x3 -> 4x4 mean."""
+    data = np.arange(9.0).reshape(3, 3)
+    rg = xa.OverlapRegridder(raster_a(), raster_b(), method="mean")
+    out = rg.regrid(data)
+    assert out.shape == (4, 4) and out.dtype == np.float64
+    np.testing.assert_allclose(out, EXPECTED_OVERLAP, rtol=1e-14)
+    # layered: shape (2, 3, 3) -> (2, 4, 4); each layer equals the 2-D result (test_regridder.py:230-239)
+    layered = np.arange(18.0).reshape(2, 3, 3)
+    out2 = rg.regrid(layered)
+    assert out2.shape == (2, 4, 4)
+    assert np.array_equal(out2[0], out)
+    np.testing.assert_allclose(out2[1], EXPECTED_OVERLAP + 9.0, rtol=1e-14)
+    # 36 pairs of 625 m2 (tests/test_regrid/test_structured.py:108-204)
+    df = rg.weights_as_dataframe()
+    assert list(df.columns) == ["target_index", "source_index", "weight"]
+    assert len(df) == 36 and (df["weight"] == 625.0).all()
+
+
+def test_centroid_locator_known_answer(hip):
+    """expected_results_centroid (fixture_regridder.py:240-291).  The inner 2x2 targets have their
+    centroid exactly on a corner shared by four source cells; the reference picks cells 0, 1, 3, 4
+    (= the lowest index, which is this engine's documented tie rule).  The outer ring's centroids
+    lie exactly ON the source boundary: the reference's separable structured search treats them as
+    outside (NaN); through the polygon path a boundary point is within tolerance of an edge, so the
+    touching source cell is used (as the reference's own unstructured path would, regridder.py:369-370)."""
+    data = np.arange(9.0).reshape(3, 3)
+    out = xa.CentroidLocatorRegridder(raster_a(), raster_b()).regrid(data)
+    assert np.array_equal(out[1:3, 1:3], EXPECTED_CENTROID[1:3, 1:3])
+    ring = np.ones((4, 4), dtype=bool)
+    ring[1:3, 1:3] = False
+    touching = np.array([[0, 0, 1, 2], [0, 0, 1, 2], [3, 3, 4, 5], [6, 6, 7, 8]], dtype=float)
+    assert (np.isnan(out[ring]) | (out[ring] == touching[ring])).all()
+    # strictly interior / exterior points behave as expected
+    shifted = xa.Raster(x=[30.0, 80.0, 130.0, 180.0], y=[170.0, 120.0, 70.0, 20.0], dx=50.0, dy=-50.0)
+    out = xa.CentroidLocatorRegridder(raster_a(), shifted).regrid(data)
+    expected = np.array([[0, 1, 2, np.nan], [3, 4, 5, np.nan], [6, 7, 8, np.nan], [np.nan] * 4])
+    assert same_or_nan(out, expected).all()
+
+
+def test_barycentric_structured_known_answer(hip):
+    """expected_results_linear (fixture_regridder.py:325-362); the reference asserts its structured
+    linear weights equal the unstructured barycentric ones (test_regridder.py:371-405)."""
+    data = np.arange(9.0).reshape(3, 3)
+    out = xa.BarycentricInterpolator(raster_a(), raster_b()).regrid(data)
+    np.testing.assert_allclose(out[1:3, 1:3], EXPECTED_LINEAR[1:3, 1:3], rtol=1e-12)
+    # ring: centroids exactly ON the source boundary (see test_centroid_locator_known_answer): NaN in the
+    # reference's separable structured path, edge-interpolated values through the polygon path
+    ring = np.ones((4, 4), dtype=bool)
+    ring[1:3, 1:3] = False
+    assert (np.isnan(out[ring]) | ((out[ring] >= 0.0) & (out[ring] <= 8.0))).all()
+    # a target strictly inside / outside: NaN exactly where the centroid is outside the source
+    shifted = xa.Raster(x=[60.0, 110.0, 160.0, 210.0], y=[140.0, 90.0, 40.0, -10.0], dx=50.0, dy=-50.0)
+    out = xa.BarycentricInterpolator(raster_a(), shifted).regrid(data)
+    assert np.isnan(out[:, 3]).all() and np.isnan(out[3, :]).all() and not np.isnan(out[:3, :3]).any()
+    # bilinear inside the centroid lattice: (60,140) sits 0.2 / 0.2 into the cell spanned by centroids 0,1,3,4
+    np.testing.assert_allclose(out[0, 0], 0.8 * 0.8 * 0 + 0.2 * 0.8 * 1 + 0.8 * 0.2 * 3 + 0.2 * 0.2 * 4, rtol=1e-12)
+
+
+def test_unstructured_identities(hip):
+    """tests/test_regrid/test_unstructured.py:32-59 on a seeded triangle mesh."""
+    grid = disk_like()
+    ug = xa.regrid.UnstructuredGrid2d(grid)
+    n = grid.n_face
+    for relative in (True, False):
+        source, target, weights = ug.overlap(ug, relative=relative)
+        valid = weights > 1.0e-5 * weights.max()
+        assert np.array_equal(source[valid], np.arange(n)) and np.array_equal(target[valid], np.arange(n))
+        np.testing.assert_allclose(weights[valid], np.ones(n) if relative else grid.area, rtol=1e-12)
+    source, target, weights = ug.locate_centroids(ug)
+    assert np.array_equal(source, np.arange(n)) and np.array_equal(target, np.arange(n)) and (weights == 1).all()
+    source, target, weights = ug.barycentric(ug)
+    keep = weights > 1e-9
+    assert np.array_equal(np.unique(target[keep]), np.arange(n))
+    big = weights > 0.999999
+    assert np.array_equal(source[big], target[big]) and big.sum() == n
+
+
+def test_regridders_unstructured_to_structured_and_back(hip):
+    """shapes and bounds as tests/test_regrid/test_regridder.py:137-201."""
+    grid = disk_like(900, 5)
+    z = meshgen.smooth_field(grid.centroids, 1)
+    x = np.arange(0.05, 1.0, 0.1)
+    target = xa.Raster(x=x, y=x[::-1].copy())
+    for cls in (xa.OverlapRegridder, xa.CentroidLocatorRegridder, xa.BarycentricInterpolator, xa.RelativeOverlapRegridder):
+        rg = cls(grid, target)
+        out = rg.regrid(z)
+        assert out.shape == (10, 10)
+        layered = np.stack([z, 2 * z, 3 * z, 4 * z, 5 * z])
+        out5 = rg.regrid(layered)
+        assert out5.shape == (5, 10, 10) and np.array_equal(out5[0], out, equal_nan=True)
+        if cls is not xa.RelativeOverlapRegridder:
+            assert np.nanmin(out) >= z.min() - 1e-12 and np.nanmax(out) <= z.max() + 1e-12
+        back = cls(target, grid).regrid(out)
+        assert back.shape == (grid.n_face,)
+
+
+def test_from_weights_and_from_dataset_round_trip(hip):
+    """round trips must be exactly equal (test_regridder.py:212-257)."""
+    grid = disk_like(600, 8)
+    target = disk_like(500, 9)
+    z = np.stack([meshgen.smooth_field(grid.centroids, k, 0.02) for k in range(3)])
+    for cls, kw in ((xa.OverlapRegridder, {"method": "median"}), (xa.RelativeOverlapRegridder, {}),
+                    (xa.BarycentricInterpolator, {}), (xa.CentroidLocatorRegridder, {})):
+        rg = cls(grid, target, **kw) if kw else cls(grid, target)
+        expected = rg.regrid(z)
+        ds = rg.to_dataset()
+        assert "__regrid_data" in ds and "__regrid_n" in ds and "__regrid_nnz" in ds
+        again = cls.from_weights(ds, target, **kw) if kw else cls.from_weights(ds, target)
+        assert np.array_equal(again.regrid(z), expected, equal_nan=True)
+        again = cls.from_dataset(ds)
+        if kw:
+            again._setup_regrid(kw["method"])
+        assert np.array_equal(again.regrid(z), expected, equal_nan=True)
+    # structured target survives the round trip too
+    rg = xa.OverlapRegridder(grid, raster_b())
+    ds = rg.weights
+    again = xa.OverlapRegridder.from_dataset(ds)
+    big = xa.Raster(x=[0.2, 0.6], y=[0.6, 0.2])
+    rg2 = xa.OverlapRegridder(grid, big)
+    assert np.array_equal(xa.OverlapRegridder.from_dataset(rg2.weights).regrid(z), rg2.regrid(z), equal_nan=True)
+    assert again.regrid(z).shape == (3, 4, 4)
+
+
+def test_methods_and_errors(hip):
+    grid = disk_like(300, 2)
+    target = disk_like(200, 4)
+    z = np.round(4 * meshgen.smooth_field(grid.centroids, 0))
+    base = xa.OverlapRegridder(grid, target)
+    ds = base.to_dataset()
+    for method in xa.OverlapRegridder._METHODS:
+        out = xa.OverlapRegridder.from_weights(ds, target, method=method).regrid(z)
+        assert out.shape == (target.n_face,)
+    p50 = xa.OverlapRegridder.create_percentile_method(50.0)
+    a = xa.OverlapRegridder.from_weights(ds, target, method=p50).regrid(z)
+    b = xa.OverlapRegridder.from_weights(ds, target, method="median").regrid(z)
+    assert np.array_equal(a, b, equal_nan=True)
+    with pytest.raises(ValueError):
+        xa.OverlapRegridder(grid, target, method="does_not_exist")
+    with pytest.raises(ValueError):
+        xa.OverlapRegridder.create_percentile_method(150.0)
+    with pytest.raises(TypeError):
+        xa.OverlapRegridder(grid, target, method=lambda v, w, ws: 0.0)  # needs a JIT CPU backend
+    with pytest.raises(TypeError):
+        xa.OverlapRegridder(1, target)
+    with pytest.raises(TypeError):
+        base.regrid("not an array")
+    with pytest.raises(ValueError):
+        base.regrid(np.zeros(grid.n_face + 1))
+    with pytest.raises(TypeError):
+        xa.regrid.UnstructuredGrid2d(1)
+    # create_percentile_method(50) on [0..4] -> 2 (test_regridder.py:282-293)
+    xy = np.array([[0.0, 0], [1, 0], [2, 0], [3, 0], [4, 0], [5, 0], [0, 1], [1, 1], [2, 1], [3, 1], [4, 1], [5, 1]])
+    quads = np.array([[i, i + 1, i + 7, i + 6] for i in range(5)])
+    src = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, quads)
+    tgt = xa.Ugrid2d(np.array([0.0, 5, 5, 0]), np.array([0.0, 0, 1, 1]), -1, np.array([[0, 1, 2, 3]]))
+    out = xa.OverlapRegridder(src, tgt, method=p50).regrid(np.arange(5.0))
+    assert out.shape == (1,) and out[0] == 2.0
+
+
+def test_celltree_adapter_matches_numba_celltree_call_shape(hip, oracle):
+    xy, faces = meshgen.triangle_mesh(500, 1)
+    txy, tf = meshgen.triangle_mesh(300, 2, 20.0, 0.8)
+    tree = xa.CellTree2d(xy, faces, -1)
+    i, j, a = tree.intersect_faces(vertices=txy, faces=tf, fill_value=-1)
+    oi, oj, oa = oracle.CellTree2d(xy, faces).intersect_faces(txy, tf)
+    assert i.dtype == np.intp and j.dtype == np.intp and a.dtype == np.float64
+    assert np.array_equal(i, oi) and np.array_equal(j, oj) and np.array_equal(a, oa)
+    assert (np.diff(i) >= 0).all()

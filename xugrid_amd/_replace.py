@@ -1,0 +1,46 @@
+"""
+``replace_interpolated_weights`` -- counterpart of xugrid/regrid/unstructured.py:17-57.
+
+Moves the barycentric weight of a synthetic exterior Voronoi vertex (vertex id >=
+``node_index_threshold``) onto its two projected neighbours by inverse distance.  Only points
+inside exterior Voronoi cells are affected (a thin boundary layer), so the affected (point, slot)
+entries are found vectorised and then processed in the reference's row-major order.
+"""
+import numpy as np
+
+
+def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_node_map, node_index_threshold):
+    n, m = weights.shape
+    if n == 0 or len(node_to_node_map) == 0:
+        return
+    valid = face_index >= 0
+    rows = np.nonzero(valid)[0]
+    if rows.size == 0:
+        return
+    face_rows = faces[face_index[rows]]  # (n_valid, m)
+    hit = (face_rows >= node_index_threshold) & (weights[rows] > 0)
+    ii, jj = np.nonzero(hit)
+    for i_local, j in zip(ii, jj):
+        i = rows[i_local]
+        face = face_rows[i_local]
+        p = face[j]
+        w = weights[i, j]
+        if w <= 0:  # may have been zeroed by an earlier slot of the same row
+            continue
+        q, r = node_to_node_map[p - node_index_threshold]
+        px, py = vertices[p]
+        qx, qy = vertices[q]
+        rx, ry = vertices[r]
+        p_q = np.sqrt((qx - px) ** 2 + (qy - py) ** 2)
+        p_r = np.sqrt((rx - px) ** 2 + (ry - py) ** 2)
+        total = p_q + p_r
+        weight_q = (p_r / total) * w
+        weight_r = (p_q / total) * w
+        weights[i, j] = 0.0
+        for k in range(m):
+            node = face[k]
+            if node == q:
+                weights[i, k] += weight_q
+            if node == r:
+                weights[i, k] += weight_r
+    return

@@ -23,9 +23,9 @@ __device__ bool point_in_face(const double *__restrict__ xy, const int32_t *__re
             const double ux = p.x - v0.x, uy = p.y - v0.y;
             const double twice_area = fabs(wx * uy - wy * ux);
             const double len = sqrt(len2);
-            if (twice_area <= tol * len) {
+            if (twice_area < tol * len) {
                 const double tpar = ux * wx + uy * wy;
-                if (tpar >= -tol * len && tpar <= len2 + tol * len) return true;
+                if (tpar >= 0 && tpar <= len2) return true;
             }
             if ((v0.y > p.y) != (v1.y > p.y)) {
                 const double xint = wx * (p.y - v0.y) / wy + v0.x;
@@ -91,9 +91,9 @@ __device__ void bary_weights(const double *__restrict__ xy, const int32_t *__res
         const double len2 = wx * wx + wy * wy;
         if (len2 > 0) {
             const double len = sqrt(len2);
-            if (fabs(a) <= tol * len) {
+            if (fabs(a) < tol * len) {
                 const double tpar = ux * wx + uy * wy;
-                if (tpar >= -tol * len && tpar <= len2 + tol * len) {
+                if (tpar >= 0 && tpar <= len2) {
                     double tt = tpar / len2;
                     if (tt < 0) tt = 0;
                     if (tt > 1) tt = 1;

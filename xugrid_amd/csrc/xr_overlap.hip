@@ -98,22 +98,50 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
     }
 }
 
-// one wave per big query face; candidates are emitted in record order (ballot prefix), so the
-// result does not depend on which wave handles which face.
+// One wave per big query face.  The face is scan-converted against the grid: for grid row cy of
+// level l only the cells under the polygon's x-extent inside the y-slab of that row are visited
+// (a thin hull sliver touches O(length) cells instead of the O(length^2) cells of its bbox).
+// Lanes take one grid row each (64 rows per batch); runs longer than LONG_RUN records are
+// processed by the whole wave in 64-record chunks.  Output order is a function of the index
+// only, so the result does not depend on which wave handles which face.
+//
+// Superset argument: a tree face s on level l with positive-area intersection has a point p in
+// both polygons; its record sits in the cell of (xmin_s, ymin_s) with p.x - h < xmin_s <= p.x and
+// p.y - h < ymin_s <= p.y (extent <= 0.999 h).  So for row cy the relevant points have
+// y in [Y(cy), Y(cy) + 2h) and the record's cell column lies in [cell(xlo - h), cell(xhi)], with
+// [xlo, xhi] the polygon's x-extent inside that slab (inflated by 1e-6 h against rounding).
+static constexpr int LONG_RUN = 128;
+
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += t;
+    }
+    return incl - v;
+}
+
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_search_big(const double *__restrict__ q_bbox, GridParams g, const int32_t *__restrict__ cell_start,
-             const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face,
-             const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big,
-             const int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt,
-             int32_t *__restrict__ cand_src) {
-    const int lane = threadIdx.x & 63;
+k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_xy,
+             const int32_t *__restrict__ q_faces, const uint8_t *__restrict__ q_len, int q_m, GridParams g,
+             const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+             const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
+             const int32_t *__restrict__ n_big, const int32_t *__restrict__ cand_off,
+             int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src) {
+    __shared__ double2 sh_poly[4][XR_MAX_FACE_NODES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
     const int nb = *n_big;
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    double2 *poly = sh_poly[wv];
     for (int bi = wave; bi < nb; bi += n_waves) {
         const int t = big_list[bi];
+        const int np = q_len[t];
+        if (lane < np) poly[lane] = reinterpret_cast<const double2 *>(q_xy)[q_faces[(int64_t)t * q_m + lane]];
+        __builtin_amdgcn_wave_barrier();
         const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
@@ -121,28 +149,88 @@ k_search_big(const double *__restrict__ q_bbox, GridParams g, const int32_t *__r
         int out = FILL ? cand_off[t] : 0;
         for (int l = 0; l < g.n_levels; l++) {
             const double h = level_h(g, l), inv_h = level_inv_h(g, l);
+            const double eps = 1e-6 * h;
             const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
-            const int cx0 = cell_coord(bb.x - h, g.x0, inv_h, nx), cx1 = cell_coord(bb.y, g.x0, inv_h, nx);
             const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
-            for (int cy = cy0; cy <= cy1; cy++) {
-                const int r0 = cell_start[base + cy * nx + cx0];
-                const int r1 = cell_start[base + cy * nx + cx1 + 1];
-                for (int rb = r0; rb < r1; rb += 64) {
-                    const int r = rb + lane;
-                    const bool hit = r < r1 && rec_hit(rbb[r], qx0, qx1, qy0, qy1);
-                    const unsigned long long mask = __ballot(hit);
-                    if (FILL && hit) {
-                        const int slot = out + __popcll(mask & lt_mask);
-                        cand_tgt[slot] = t;
-                        cand_src[slot] = rec_face[r];
+            for (int cyb = cy0; cyb <= cy1; cyb += 64) {
+                const int cy = cyb + lane;
+                int r0 = 0, r1 = 0;
+                if (cy <= cy1) {
+                    // polygon x-extent inside the slab [ya, yb] of this grid row
+                    const double ya = g.y0 + (double)cy * h - eps, yb = g.y0 + (double)(cy + 2) * h + eps;
+                    double xlo = INFINITY, xhi = -INFINITY;
+                    double2 p = poly[np - 1];
+                    for (int k = 0; k < np; k++) {
+                        const double2 q = poly[k];
+                        const double ylo = fmin(p.y, q.y), yhi = fmax(p.y, q.y);
+                        if (yhi >= ya && ylo <= yb) {
+                            double xa = p.x, xb = q.x;
+                            if (yhi > ylo) {
+                                // clip the edge to the slab (parameter along p -> q)
+                                const double inv = 1.0 / (q.y - p.y);
+                                double t0 = (ya - p.y) * inv, t1 = (yb - p.y) * inv;
+                                if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
+                                t0 = fmax(t0, 0.0);
+                                t1 = fmin(t1, 1.0);
+                                xa = p.x + t0 * (q.x - p.x);
+                                xb = p.x + t1 * (q.x - p.x);
+                            }
+                            xlo = fmin(xlo, fmin(xa, xb));
+                            xhi = fmax(xhi, fmax(xa, xb));
+                        }
+                        p = q;
                     }
-                    const int n = __popcll(mask);
-                    out += n;
-                    total += n;
+                    if (xhi >= xlo) {
+                        xlo = fmax(xlo - eps, bb.x);
+                        xhi = fmin(xhi + eps, bb.y);
+                        const int cx0 = cell_coord(xlo - h, g.x0, inv_h, nx), cx1 = cell_coord(xhi, g.x0, inv_h, nx);
+                        r0 = cell_start[base + cy * nx + cx0];
+                        r1 = cell_start[base + cy * nx + cx1 + 1];
+                    }
                 }
+                const int len = r1 - r0;
+                // (1) long runs: the whole wave, 64 records at a time, output in record order
+                unsigned long long long_mask = __ballot(len > LONG_RUN);
+                while (long_mask) {
+                    const int src_lane = __ffsll((long long)long_mask) - 1;
+                    long_mask &= long_mask - 1;
+                    const int R0 = __shfl(r0, src_lane, 64), R1 = __shfl(r1, src_lane, 64);
+                    for (int rb = R0; rb < R1; rb += 64) {
+                        const int r = rb + lane;
+                        const bool hit = r < R1 && rec_hit(rbb[r], qx0, qx1, qy0, qy1);
+                        const unsigned long long mask = __ballot(hit);
+                        if (FILL && hit) {
+                            const int slot = out + __popcll(mask & lt_mask);
+                            cand_tgt[slot] = t;
+                            cand_src[slot] = rec_face[r];
+                        }
+                        const int n = __popcll(mask);
+                        out += n;
+                        total += n;
+                    }
+                }
+                // (2) short runs: one lane per grid row
+                const int my_r1 = len > LONG_RUN ? r0 : r1;
+                int cnt = 0;
+                for (int r = r0; r < my_r1; r++) cnt += rec_hit(rbb[r], qx0, qx1, qy0, qy1) ? 1 : 0;
+                const int excl = wave_excl_scan_i32(cnt, lane);
+                const int batch = __shfl(excl + cnt, 63, 64);
+                if (FILL && cnt > 0) {
+                    int pos = out + excl;
+                    for (int r = r0; r < my_r1; r++) {
+                        if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
+                            cand_tgt[pos] = t;
+                            cand_src[pos] = rec_face[r];
+                            pos++;
+                        }
+                    }
+                }
+                out += batch;
+                total += batch;
             }
         }
         if (!FILL && lane == 0) cand_count[t] = total;
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -483,9 +571,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), (const int32_t *)nullptr,
               cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr, is_big.get(), big_list.get(),
               counters.get() + 2);
-    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->bbox.get(), g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2,
-              (const int32_t *)nullptr, cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
+    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->bbox.get(),
+              query->node_xy.get(), query->faces.get(), query->len.get(), query->m, g, tree->cell_start.get(),
+              tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, (const int32_t *)nullptr,
+              cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
     exclusive_scan_i32(cand_count.get(), cand_off.get(), T);
     const int32_t C32 = read_scalar(cand_off.get() + T);
     XR_REQUIRE(C32 >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
@@ -499,9 +588,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
                   tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), cand_off.get(),
                   (int32_t *)nullptr, cand_tgt.get(), cand_src.get(), is_big.get(), (int32_t *)nullptr,
                   (int32_t *)nullptr);
-        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->bbox.get(), g,
-                  tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), big_list.get(),
-                  counters.get() + 2, cand_off.get(), (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
+        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->bbox.get(),
+                  query->node_xy.get(), query->faces.get(), query->len.get(), query->m, g, tree->cell_start.get(),
+                  tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
+                  (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
         // --- clip (+ per-row survivor counts)
         launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), counters.get(), nnz_row.get());
     }

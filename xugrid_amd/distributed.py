@@ -1,0 +1,197 @@
+"""
+Multi-GPU regridding: one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI),
+SOURCE faces partitioned over the ranks, target mesh replicated (BASELINE north_star).
+
+    rank r:  faces_r = {s : part(s) == r}
+             W_r     = overlap(source[faces_r], target)              # HIP, no communication
+             num_r, den_r = sum_j w v, sum_j w  (v not NaN)          # HIP, per (k, target)
+    all:     reduce_scatter(sum) of [num ; den] over the target axis  # the ONE exchange step
+    rank r:  out[k, t] = num / den (NaN where den == 0)  for its slice of targets
+
+Only sum-decomposable reducers shard over sources; ``mean`` is implemented (it is the reducer of
+OverlapRegridder's default and of BarycentricInterpolator).  ``mode``, percentiles and
+``max_overlap`` need the whole row and would run as target-partitioned replicas instead.
+
+The compute backend is a parameter: the product uses ``HipBackend`` (C ABI, device pointers of
+torch tensors); the world_size-2 gloo tests on CPU inject an oracle-backed backend with the same
+three methods.  There is no CPU fallback in the product path.
+"""
+import os
+
+import numpy as np
+
+
+def partition_faces(centroids, world_size, mode="morton"):
+    """
+    Owner rank of every source face.
+
+    "morton": faces are ordered along a Z-order curve of their centroids and cut into
+    ``world_size`` contiguous blocks of equal size -- each rank's shard is spatially compact, so
+    the per-rank search touches ~T/world targets instead of all of them.
+    "hash":   ``face id mod world_size`` (BASELINE north_star wording); every rank sees every
+    target with ~1/world of its pairs.
+    """
+    n = centroids.shape[0]
+    if mode == "hash":
+        return (np.arange(n) % world_size).astype(np.int32)
+    if mode != "morton":
+        raise ValueError(f"unknown partition mode {mode!r}")
+    lo = centroids.min(axis=0)
+    span = np.maximum(centroids.max(axis=0) - lo, 1e-300)
+    q = np.minimum(((centroids - lo) / span * 65536.0).astype(np.uint64), 65535)
+
+    def spread(v):
+        v = (v | (v << 8)) & np.uint64(0x00FF00FF)
+        v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << 2)) & np.uint64(0x33333333)
+        v = (v | (v << 1)) & np.uint64(0x55555555)
+        return v
+
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
+    order = np.argsort(code, kind="stable")
+    owner = np.empty(n, dtype=np.int32)
+    owner[order] = (np.arange(n) * world_size // max(n, 1)).astype(np.int32)
+    return owner
+
+
+class HipBackend:
+    """Device compute through the C ABI; tensors are torch CUDA(HIP) tensors of this rank's GPU."""
+
+    def __init__(self, local_rank):
+        import torch
+
+        from . import engine
+
+        self.torch = torch
+        self.engine = engine
+        torch.cuda.set_device(local_rank)
+        engine.init(local_rank)
+        self.device = torch.device("cuda", local_rank)
+
+    def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces):
+        E = self.engine
+        self._src_mesh = E.DeviceMesh(src_xy, src_faces)
+        self._tgt_mesh = E.DeviceMesh(tgt_xy, tgt_faces)
+        return self._src_mesh.overlap(self._tgt_mesh, relative=False)
+
+    def rebuild_weights(self):
+        """Benchmark hook: redo prepare + index + overlap from the HBM-resident raw meshes."""
+        self._src_mesh.invalidate()
+        self._tgt_mesh.invalidate()
+        return self._src_mesh.overlap(self._tgt_mesh, relative=False)
+
+    def to_device(self, array):
+        return self.torch.as_tensor(np.ascontiguousarray(array), device=self.device)
+
+    def partial_mean(self, weights, source):
+        """source: (K, S_local) float64/float32 device tensor -> (2, K, T) float64 device tensor."""
+        torch = self.torch
+        K = source.shape[0]
+        out = torch.empty((2, K, weights.n), dtype=torch.float64, device=self.device)
+        dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
+        torch.cuda.current_stream().synchronize()  # inputs produced on torch's stream are ready
+        weights.partial_mean_dev(source.data_ptr(), dtype, K, out.data_ptr())
+        return out
+
+    def finalize_mean(self, num, den):
+        out = self.torch.empty_like(num)
+        self.torch.cuda.current_stream().synchronize()
+        self.engine.finalize_mean_dev(num.data_ptr(), den.data_ptr(), num.numel(), out.data_ptr())
+        return out
+
+
+def _reduce_scatter_sum(dist, tensor, world_size, group=None):
+    """tensor: (world, ...) contiguous -> this rank's (...) slice of the element-wise sum."""
+    import torch
+
+    out = torch.empty_like(tensor[0])
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(out, tensor, op=dist.ReduceOp.SUM, group=group)
+    else:  # gloo (CPU tests) has no reduce_scatter: all_reduce, then keep the own slice
+        full = tensor.clone()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        out.copy_(full[dist.get_rank(group)])
+    return out
+
+
+class ShardedOverlapRegridder:
+    """
+    ``OverlapRegridder(source, target, method="mean")`` with the source faces sharded over the
+    ranks of ``torch.distributed``.
+
+    source_xy/source_faces, target_xy/target_faces: the FULL meshes (every rank passes the same
+    arrays; each keeps only its shard of the source faces).
+    """
+
+    def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="morton", group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = backend
+        source_faces = np.asarray(source_faces)
+        self.n_source = source_faces.shape[0]
+        self.n_target = np.asarray(target_faces).shape[0]
+        valid = source_faces >= 0
+        cnt = valid.sum(axis=1)
+        xy = np.asarray(source_xy, dtype=np.float64)
+        safe = np.where(valid, source_faces, 0)
+        cen = (xy[safe] * valid[..., None]).sum(axis=1) / cnt[:, None]
+        owner = partition_faces(cen, self.world, partition)
+        self.local_faces = np.nonzero(owner == self.rank)[0]  # global ids of this rank's sources
+        # target rows are cut into `world` equal slices (padded): rank r finalises slice r
+        self.t_chunk = -(-self.n_target // self.world)
+        self.weights = backend.build_weights(xy, source_faces[self.local_faces], target_xy, target_faces)
+
+    def rebuild(self):
+        self.weights = self.backend.rebuild_weights()
+
+    def local_source(self, data):
+        """(K, S) global source data -> this rank's (K, S_local) columns, on the device."""
+        data = np.asarray(data)
+        if data.ndim == 1:
+            data = data[None, :]
+        return self.backend.to_device(data[:, self.local_faces])
+
+    def regrid_local(self, local_source):
+        """local (K, S_local) device tensor -> this rank's (K, t_chunk) slice of the result."""
+        import torch
+
+        nd = self.backend.partial_mean(self.weights, local_source)  # (2, K, T)
+        K = nd.shape[1]
+        pad = self.t_chunk * self.world - self.n_target
+        if pad:
+            nd = torch.nn.functional.pad(nd, (0, pad))
+        # (2, K, world, chunk) -> (world, 2, K, chunk): slice w of the target axis goes to rank w
+        send = nd.view(2, K, self.world, self.t_chunk).permute(2, 0, 1, 3).contiguous()
+        mine = _reduce_scatter_sum(self.dist, send, self.world, self.group)  # (2, K, chunk)
+        return self.backend.finalize_mean(mine[0].contiguous(), mine[1].contiguous())
+
+    def regrid(self, data, gather=True):
+        """(K, S) or (S,) global source data -> (K, T) float64 on every rank (gather=True)."""
+        import torch
+
+        squeeze = np.asarray(data).ndim == 1
+        local = self.regrid_local(self.local_source(data))  # (K, chunk)
+        if not gather:
+            return local
+        parts = [torch.empty_like(local) for _ in range(self.world)]
+        self.dist.all_gather(parts, local, group=self.group)
+        out = torch.cat(parts, dim=1)[:, : self.n_target].cpu().numpy()
+        return out[0] if squeeze else out
+
+
+def init_process_group_from_env(backend=None):
+    """RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as set by torch.distributed.run."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend=backend)
+    return dist

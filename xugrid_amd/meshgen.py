@@ -22,7 +22,8 @@ def jittered_lattice_points(n_points, seed, jitter=0.35):
 
 
 def _split_lattice(points, m):
-    """2 (m-1)^2 CCW triangles: each lattice quad split along its shorter diagonal."""
+    """2 (m-1)^2 CCW triangles: each lattice quad split along its shorter diagonal (along the
+    only valid diagonal where the jitter made the quad concave)."""
     idx = np.arange(m * m).reshape(m, m)
     a = idx[:-1, :-1].ravel()  # lower-left
     b = idx[:-1, 1:].ravel()  # lower-right
@@ -31,7 +32,14 @@ def _split_lattice(points, m):
     p = points
     d_ac = ((p[a] - p[c]) ** 2).sum(axis=1)
     d_bd = ((p[b] - p[d]) ** 2).sum(axis=1)
-    use_ac = d_ac <= d_bd
+
+    def ccw(i, j, k):
+        u, v = p[j] - p[i], p[k] - p[i]
+        return (u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]) > 0
+
+    ok_ac = ccw(a, b, c) & ccw(a, c, d)
+    ok_bd = ccw(a, b, d) & ccw(b, c, d)
+    use_ac = ok_ac & (~ok_bd | (d_ac <= d_bd))
     t1 = np.where(use_ac[:, None], np.column_stack([a, b, c]), np.column_stack([a, b, d]))
     t2 = np.where(use_ac[:, None], np.column_stack([a, c, d]), np.column_stack([b, c, d]))
     faces = np.empty((2 * a.size, 3), dtype=np.int64)

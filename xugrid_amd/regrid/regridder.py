@@ -1,0 +1,333 @@
+"""
+The regridder classes -- same names, constructor signatures, defaults, methods and error
+behaviour as xugrid/regrid/regridder.py (classes :99-659), with the two hot loops replaced by
+the HIP engine:
+
+  * weight construction  (``_compute_weights`` :386-398, :428-436, :624-638)  ->  device kernels
+    behind ``UnstructuredGrid2d.overlap_device / locate_centroids / barycentric``
+  * apply                (``make_regrid(f)._regrid`` :41-67, COO ``_regrid`` :400-409)  ->
+    ``DeviceCSR.apply`` / ``engine.apply_coo``
+
+Weights live in HBM (``self._device_weights``) and are only downloaded when somebody asks for them
+(``weights``, ``to_dataset``, ``weights_as_dataframe``).  Arrays in, arrays out: ``regrid`` takes
+a numpy array whose trailing axes are the source grid's (``(..., n_face)`` or ``(..., ny, nx)``,
+regridder.py:143-195) and returns float64 with the target's trailing shape.  xarray wrapping is
+left to the caller (xarray is optional and absent in this image).
+"""
+import abc
+from typing import Optional, Union
+
+import numpy as np
+
+from .. import engine
+from ..reduce import ABSOLUTE_OVERLAP_METHODS, RELATIVE_OVERLAP_METHODS, Method, create_percentile_method
+from ..sparse import MatrixCOO, MatrixCSR
+from ..ugrid2d import Ugrid2d
+from .structured import Raster, StructuredGrid2d
+from .unstructured import UnstructuredGrid2d
+
+
+def setup_grid(obj, **kwargs):
+    """regridder.py:72-80."""
+    if isinstance(obj, (UnstructuredGrid2d, StructuredGrid2d)):
+        return obj
+    if isinstance(obj, Ugrid2d) or (hasattr(obj, "grid") and isinstance(getattr(obj, "grid"), Ugrid2d)):
+        return UnstructuredGrid2d(obj)
+    if isinstance(obj, Raster):
+        return StructuredGrid2d(obj, name_y=kwargs.get("name_y", "y"), name_x=kwargs.get("name_x", "x"))
+    if _is_xarray(obj):
+        return StructuredGrid2d(obj, name_y=kwargs.get("name_y", "y"), name_x=kwargs.get("name_x", "x"))
+    raise TypeError(
+        f"Expected Ugrid2d, UgridDataArray-like or Raster/xarray.DataArray, received: {type(obj).__name__}"
+    )
+
+
+def _is_xarray(obj):
+    mod = type(obj).__module__ or ""
+    return mod.startswith("xarray") and hasattr(obj, "coords")
+
+
+def convert_to_match(source, target):
+    """regridder.py:83-96.  A structured pair is promoted to quads as well until the separable
+    structured fast path exists."""
+    return source.convert_to(UnstructuredGrid2d), target.convert_to(UnstructuredGrid2d)
+
+
+class BaseRegridder(abc.ABC):
+    _METHODS = {}
+
+    def __init__(self, source, target, tolerance: Optional[float] = None):
+        self._source = setup_grid(source)
+        self._target = setup_grid(target)
+        self._weights = None
+        self._device_weights = None
+        self._compute_weights(self._source, self._target, tolerance)
+
+    @abc.abstractmethod
+    def _compute_weights(self, source, target, tolerance: Optional[float] = None):
+        pass
+
+    # ---- method selection (regridder.py:124-141)
+    def _setup_regrid(self, func) -> None:
+        if isinstance(func, str):
+            try:
+                self._method = self._METHODS[func]
+            except KeyError as e:
+                raise ValueError(
+                    "Invalid regridding method. Available methods are: {}".format(self._METHODS.keys())
+                ) from e
+        elif isinstance(func, Method):
+            self._method = func
+        elif callable(func):
+            raise TypeError(
+                "custom Python reduction callables need a JIT CPU backend; the HIP engine only runs the "
+                f"built-in reducers {sorted(self._METHODS)} and create_percentile_method(p)"
+            )
+        else:
+            raise TypeError(f"method must be string or callable, received: {type(func).__name__}")
+
+    # ---- apply
+    def _regrid(self, source: np.ndarray, size: int) -> np.ndarray:
+        out = self._ensure_device_weights().apply(source, self._method.method_id, self._method.percentile)
+        assert out.shape[1] == size
+        return out
+
+    def _regrid_array(self, source):
+        """regridder.py:143-195 on plain ndarrays."""
+        if not isinstance(source, np.ndarray):
+            raise TypeError(f"Expected numpy.ndarray. Received: {type(source).__name__}")
+        source_grid = self._source
+        if source.ndim < source_grid.ndim or source.shape[source.ndim - source_grid.ndim:] != source_grid.shape:
+            raise ValueError(
+                f"data does not contain regridder source dimensions: trailing shape {source_grid.shape} expected, "
+                f"received {source.shape}"
+            )
+        first_dims_shape = source.shape[: source.ndim - source_grid.ndim]
+        if source.ndim == source_grid.ndim:
+            source = source[np.newaxis]
+        source = source.reshape((-1, source_grid.size))
+        size = self._target.size
+        out = self._regrid(source, size)
+        return out.reshape(first_dims_shape + self._target.shape)
+
+    def regrid(self, data):
+        """
+        Regrid ``data`` from the source topology to the target topology; additional leading
+        dimensions (time, layer ...) are regridded in one batched device call.
+
+        data: np.ndarray ``(..., n_face)`` / ``(..., ny, nx)``, or an object exposing ``.values``
+        (e.g. an xarray.DataArray, whose dims must end with the source dims).
+        """
+        if isinstance(data, np.ndarray):
+            return self._regrid_array(data)
+        if hasattr(data, "values") and hasattr(data, "dims"):
+            return self._regrid_array(np.asarray(data.values))
+        raise TypeError(f"Expected DataArray or UgridDataAray, received: {type(data).__name__}")
+
+    # ---- weights access / persistence (regridder.py:264-361)
+    def _ensure_host_weights(self):
+        if self._weights is None:
+            if self._device_weights is None:
+                raise ValueError("Weights have not been computed yet.")
+            data, indices, indptr = self._device_weights.download()
+            dw = self._device_weights
+            self._weights = MatrixCSR(data, indices, indptr, dw.n, dw.m, dw.nnz)
+        return self._weights
+
+    def _ensure_device_weights(self):
+        if self._device_weights is None:
+            w = self._weights
+            if w is None:
+                raise ValueError("Weights have not been computed yet.")
+            if isinstance(w, MatrixCOO):
+                w = w.to_csr()
+            self._device_weights = engine.DeviceCSR.from_arrays(w.data, w.indices, w.indptr, w.n, w.m)
+        return self._device_weights
+
+    def to_dataset(self) -> dict:
+        """Weights + source + target topology as a flat dict of arrays, with the variable names of
+        regridder.py:264-271 (``__regrid_data/indices/indptr/n/m/nnz`` or ``row/col`` for COO)."""
+        w = self._ensure_host_weights()
+        ds = {f"__regrid_{k}": v for k, v in zip(w._fields, w)}
+        ds.update(self._source.to_dataset("__source"))
+        ds.update(self._target.to_dataset("__target"))
+        return ds
+
+    @property
+    def weights(self):
+        return self.to_dataset()
+
+    def weights_as_dataframe(self):
+        """Three columns: target_index, source_index, weight (regridder.py:273-296)."""
+        import pandas as pd
+
+        matrix = self._ensure_host_weights()
+        if isinstance(matrix, MatrixCSR):
+            matrix = matrix.to_coo()
+        return pd.DataFrame({"target_index": matrix.row, "source_index": matrix.col, "weight": matrix.data})
+
+    @staticmethod
+    def _csr_from_dataset(dataset) -> MatrixCSR:
+        return MatrixCSR(
+            np.asarray(dataset["__regrid_data"]),
+            np.asarray(dataset["__regrid_indices"]),
+            np.asarray(dataset["__regrid_indptr"]),
+            int(np.asarray(dataset["__regrid_n"]).item()),
+            int(np.asarray(dataset["__regrid_m"]).item()),
+            int(np.asarray(dataset["__regrid_nnz"]).item()),
+        )
+
+    @staticmethod
+    def _coo_from_dataset(dataset) -> MatrixCOO:
+        return MatrixCOO(
+            np.asarray(dataset["__regrid_data"]),
+            np.asarray(dataset["__regrid_row"]),
+            np.asarray(dataset["__regrid_col"]),
+            int(np.asarray(dataset["__regrid_n"]).item()),
+            int(np.asarray(dataset["__regrid_m"]).item()),
+            int(np.asarray(dataset["__regrid_nnz"]).item()),
+        )
+
+    @classmethod
+    @abc.abstractmethod
+    def _weights_from_dataset(cls, dataset):
+        """Return either COO or CSR weights."""
+
+    @staticmethod
+    def _grid_from_dataset(dataset, name):
+        kind = dataset[name + "_type"]
+        kind = kind if isinstance(kind, str) else str(np.asarray(kind).item())
+        if kind == "UnstructuredGrid2d":
+            return setup_grid(Ugrid2d.from_dataset(dataset, name))
+        return StructuredGrid2d.from_dataset(dataset, name)
+
+    @classmethod
+    def from_weights(cls, weights, target):
+        instance = cls.__new__(cls)
+        instance._weights = cls._weights_from_dataset(weights)
+        instance._device_weights = None
+        instance._target = setup_grid(target)
+        instance._source = cls._grid_from_dataset(weights, "__source")
+        return instance
+
+    @classmethod
+    def from_dataset(cls, dataset):
+        """Reconstruct the regridder from ``to_dataset()`` output (regridder.py:350-361)."""
+        target = cls._grid_from_dataset(dataset, "__target")
+        return cls.from_weights(dataset, target)
+
+
+class CentroidLocatorRegridder(BaseRegridder):
+    """
+    Regrids by locating the centroids of the target faces in the source grid
+    (regridder.py:364-422).  If a centroid lies exactly on an edge between two faces the face with
+    the lowest index is used (the reference leaves the choice unspecified, :369-370).
+    """
+
+    def _compute_weights(self, source, target, tolerance: Optional[float] = None):
+        source, target = convert_to_match(source, target)
+        source_index, target_index, weight_values = source.locate_centroids(target, tolerance)
+        self._weights = MatrixCOO.from_triplet(target_index, source_index, weight_values, n=target.size, m=source.size)
+
+    def _regrid(self, source, size):
+        A = self._weights
+        return engine.apply_coo(A.row, A.col, size, source)
+
+    def _ensure_host_weights(self):
+        if self._weights is None:
+            raise ValueError("Weights have not been computed yet.")
+        return self._weights
+
+    @classmethod
+    def _weights_from_dataset(cls, dataset) -> MatrixCOO:
+        return cls._coo_from_dataset(dataset)
+
+
+class BaseOverlapRegridder(BaseRegridder, abc.ABC):
+    def _compute_overlap(self, source, target, relative: bool) -> None:
+        source, target = convert_to_match(source, target)
+        self._device_weights = source.overlap_device(target, relative=relative)
+        self._weights = None
+
+    @classmethod
+    def _weights_from_dataset(cls, dataset) -> MatrixCSR:
+        return cls._csr_from_dataset(dataset)
+
+
+class OverlapRegridder(BaseOverlapRegridder):
+    """
+    Area-weighted regridding from the overlap of target and source faces
+    (regridder.py:443-532).  Methods: ``mean, harmonic_mean, geometric_mean, sum, minimum,
+    maximum, mode, median, max_overlap, p5, p10, p25, p50, p75, p90, p95`` and any
+    ``OverlapRegridder.create_percentile_method(p)``.
+    """
+
+    _METHODS = ABSOLUTE_OVERLAP_METHODS
+
+    def __init__(self, source, target, method: Union[str, Method] = "mean"):
+        super().__init__(source=source, target=target)
+        self._setup_regrid(method)
+
+    def _compute_weights(self, source, target, tolerance: Optional[float] = None) -> None:
+        self._compute_overlap(source, target, relative=False)
+
+    @staticmethod
+    def create_percentile_method(percentile: float) -> Method:
+        return create_percentile_method(percentile)
+
+    @classmethod
+    def from_weights(cls, weights, target, method: Union[str, Method] = "mean"):
+        instance = super().from_weights(weights, target)
+        instance._setup_regrid(method)
+        return instance
+
+
+class RelativeOverlapRegridder(BaseOverlapRegridder):
+    """
+    As OverlapRegridder, but the overlap area is divided by the area of the source face
+    (regridder.py:535-586); methods ``first_order_conservative`` (default) and ``conductance``.
+    """
+
+    _METHODS = RELATIVE_OVERLAP_METHODS
+
+    def __init__(self, source, target, method: Union[str, Method] = "first_order_conservative"):
+        super().__init__(source=source, target=target, tolerance=None)
+        self._setup_regrid(method)
+
+    def _compute_weights(self, source, target, tolerance: Optional[float] = None) -> None:
+        self._compute_overlap(source, target, relative=True)
+
+    @classmethod
+    def from_weights(cls, weights, target, method: Union[str, Method] = "first_order_conservative"):
+        instance = super().from_weights(weights, target)
+        instance._setup_regrid(method)
+        return instance
+
+
+class BarycentricInterpolator(BaseRegridder):
+    """
+    Interpolates with barycentric weights in the centroidal Voronoi tessellation of the source
+    grid, evaluated at the target face centroids (regridder.py:589-659).  The weights of a target
+    sum to one, so the reducer is fixed to ``mean`` (NaN-aware renormalisation).
+    """
+
+    _METHODS = {"mean": ABSOLUTE_OVERLAP_METHODS["mean"]}
+
+    def __init__(self, source, target, tolerance: Optional[float] = None):
+        super().__init__(source, target, tolerance)
+        self._setup_regrid("mean")
+
+    def _compute_weights(self, source, target, tolerance: Optional[float] = None):
+        source, target = convert_to_match(source, target)
+        source_index, target_index, weights = source.barycentric(target, tolerance)
+        self._weights = MatrixCSR.from_triplet(target_index, source_index, weights, n=target.size, m=source.size)
+
+    @classmethod
+    def from_weights(cls, weights, target):
+        instance = super().from_weights(weights, target)
+        instance._setup_regrid("mean")
+        return instance
+
+    @classmethod
+    def _weights_from_dataset(cls, dataset) -> MatrixCSR:
+        return cls._csr_from_dataset(dataset)

@@ -1,0 +1,119 @@
+"""
+``UnstructuredGrid2d``: the regridder-side adapter of a ``Ugrid2d`` -- counterpart of
+xugrid/regrid/unstructured.py:60-220.  The three weight constructions
+(``overlap`` :109-135, ``locate_centroids`` :137-144, ``barycentric`` :146-201) call the HIP
+kernels through the grid's ``celltree``.
+"""
+from typing import Optional
+
+import numpy as np
+
+from ..engine import FloatDType, IntDType
+from ..ugrid2d import Ugrid2d
+
+
+class UnstructuredGrid2d:
+    """Stores only the grid topology (face -> face regridding)."""
+
+    def __init__(self, obj):
+        if isinstance(obj, Ugrid2d):
+            self.ugrid_topology = obj
+        elif hasattr(obj, "grid") and isinstance(obj.grid, Ugrid2d):
+            self.ugrid_topology = obj.grid  # UgridDataArray-like wrapper
+        else:
+            options = {"Ugrid2d", "UgridDataArray", "UgridDataset"}
+            raise TypeError(f"Expected one of {options}, received: {type(obj).__name__}")
+
+    @property
+    def ndim(self):
+        return 1
+
+    @property
+    def dims(self):
+        return (self.ugrid_topology.face_dimension,)
+
+    @property
+    def shape(self):
+        return (self.ugrid_topology.n_face,)
+
+    @property
+    def size(self):
+        return self.ugrid_topology.n_face
+
+    @property
+    def area(self):
+        return self.ugrid_topology.area
+
+    @property
+    def coords(self):
+        return {}
+
+    def convert_to(self, matched_type):
+        if isinstance(self, matched_type):
+            return self
+        # the reference builds this TypeError without raising it (unstructured.py:107); raise it
+        raise TypeError(f"Cannot convert UnstructuredGrid2d to {matched_type.__name__}")
+
+    def overlap_device(self, other: "UnstructuredGrid2d", relative: bool):
+        """Weights as a device-resident CSR (rows = faces of ``other``); nothing is downloaded."""
+        return self.ugrid_topology.device_mesh.overlap(other.ugrid_topology.device_mesh, relative=relative)
+
+    def overlap(self, other: "UnstructuredGrid2d", relative: bool):
+        """-> (source_index, target_index, weights), as unstructured.py:109-135."""
+        target_index, source_index, weights = self.ugrid_topology.celltree.intersect_mesh(
+            other.ugrid_topology.device_mesh, relative=relative
+        )
+        return source_index, target_index, weights
+
+    def locate_centroids(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
+        tree = self.ugrid_topology.celltree
+        source_index = tree.locate_points(other.ugrid_topology.centroids, tolerance)
+        inside = source_index != -1
+        source_index = source_index[inside]
+        target_index = np.arange(other.size, dtype=IntDType)[inside]
+        weight_values = np.ones_like(source_index, dtype=FloatDType)
+        return source_index, target_index, weight_values
+
+    def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
+        from .. import voronoi
+        from .._replace import replace_interpolated_weights
+
+        points = other.ugrid_topology.centroids
+        grid = self.ugrid_topology
+        vertices, faces, node_to_face_index, node_to_node_map = voronoi.voronoi_topology(
+            grid.node_face_connectivity,
+            grid.node_coordinates,
+            grid.centroids,
+            edge_face_connectivity=grid.edge_face_connectivity,
+            edge_node_connectivity=grid.edge_node_connectivity,
+            add_exterior=True,
+            add_vertices=True,
+            skip_concave=True,
+        )
+        voronoi_grid = Ugrid2d(vertices[:, 0], vertices[:, 1], -1, faces)
+        face_index, weights = voronoi_grid.compute_barycentric_weights(points, tolerance)
+        replace_interpolated_weights(
+            vertices=vertices,
+            faces=faces,
+            face_index=face_index,
+            weights=weights,
+            node_to_node_map=node_to_node_map,
+            node_index_threshold=len(vertices) - len(node_to_node_map),
+        )
+        # discard zero weights and points outside of the source grid (unstructured.py:188-198)
+        outside = grid.locate_points(points) == -1
+        weights[outside] = 0
+        keep = weights.ravel() > 0
+        source_index = node_to_face_index[voronoi_grid.face_node_connectivity[face_index]].ravel()[keep]
+        n_points, n_max_node = weights.shape
+        target_index = np.repeat(np.arange(n_points, dtype=IntDType), n_max_node)[keep]
+        weights = weights.ravel()[keep]
+        # target_index is already non-decreasing; a stable sort keeps the reference's intent
+        # (its own argsort is non-stable)
+        order = np.argsort(target_index, kind="stable")
+        return source_index[order], target_index[order], weights[order]
+
+    def to_dataset(self, name: str):
+        ds = self.ugrid_topology.to_dataset(name)
+        ds[name + "_type"] = "UnstructuredGrid2d"
+        return ds
