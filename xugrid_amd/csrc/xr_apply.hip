@@ -6,7 +6,7 @@
 // (xugrid/core/sparse.py:61-78,119-127).
 //
 // Reducer semantics are those of reduce.py line by line; entries of a
-// row are consumed in CSR order, one thread per (row, k-tile), so that results are
+// row are consumed in CSR order by one thread per (row, k-tile), so that results are
 // bit-identical to the reference loop on the same CSR (except exp/log in geometric_mean).
 //
 // HBM layout: source (K, S) row-major, out (K, T) row-major (regridder.py:163, :44);
@@ -110,40 +110,72 @@ template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238
     __device__ double fin() const { return w_max == 0.0 ? NAN : v_max; }
 };
 
-template <int METHOD, typename SRC>
+// One block = AP_BLOCK consecutive rows.  The block's CSR segment [indptr[row0], indptr[row0+B)) is
+// contiguous: it is streamed through LDS in chunks of CH entries -- column index and weight are
+// loaded coalesced (one entry per thread), the source values are gathered by the same thread and
+// parked next to the weight -- then every thread reduces ITS row's entries of the chunk from LDS,
+// sequentially in CSR order (bit-identical to the reference loop).  Reducer state lives in
+// registers across chunks.  KTILE source variables are reduced per pass so the CSR is re-read only
+// K / KTILE times.
+template <int METHOD, typename SRC, int KTILE, int CH>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                const double *__restrict__ data, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
                double *__restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
-    if (t >= T) return;
-    const int64_t k0 = (int64_t)blockIdx.y * KT;
-    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
-    const int s = indptr[t], e = indptr[t + 1];
-    if (s == e) { // regridder.py:44,62: rows without entries stay NaN
-        for (int kk = 0; kk < kn; kk++) out[(k0 + kk) * T + t] = NAN;
-        return;
+    __shared__ double sh_w[CH];
+    __shared__ double sh_v[KTILE][CH];
+    const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
+    const int64_t t = row0 + threadIdx.x;
+    const int64_t row_end = (row0 + AP_BLOCK < T) ? row0 + AP_BLOCK : T;
+    const int64_t k0 = (int64_t)blockIdx.y * KTILE;
+    const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+    const int seg0 = indptr[row0], seg1 = indptr[row_end];
+    int s = 0, e = 0;
+    if (t < T) {
+        s = indptr[t];
+        e = indptr[t + 1];
     }
+    const SRC *src = source + k0 * S;
     double normsum = 0.0;
     if (METHOD == XR_GEOMETRIC_MEAN) {
-        for (int j = s; j < e; j++) normsum += data[j];
-    }
-    Red<METHOD> red[KT];
-    const SRC *src = source + k0 * S;
-    for (int j = s; j < e; j++) {
-        const int64_t col = indices[j];
-        const double w = data[j];
-#pragma unroll
-        for (int kk = 0; kk < KT; kk++) {
-            if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
+        for (int c0 = seg0; c0 < seg1; c0 += CH) {
+            __syncthreads();
+            for (int j = c0 + threadIdx.x; j < c0 + CH && j < seg1; j += AP_BLOCK) sh_w[j - c0] = data[j];
+            __syncthreads();
+            const int a = s > c0 ? s : c0, b = e < c0 + CH ? e : c0 + CH;
+            for (int j = a; j < b; j++) normsum += sh_w[j - c0];
         }
     }
+    Red<METHOD> red[KTILE];
+    for (int c0 = seg0; c0 < seg1; c0 += CH) {
+        __syncthreads();
+        for (int j = c0 + threadIdx.x; j < c0 + CH && j < seg1; j += AP_BLOCK) {
+            const int64_t col = indices[j];
+            sh_w[j - c0] = data[j];
 #pragma unroll
-    for (int kk = 0; kk < KT; kk++) {
-        if (kk < kn) {
-            double r = red[kk].fin();
-            if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
-            out[(k0 + kk) * T + t] = r;
+            for (int kk = 0; kk < KTILE; kk++)
+                if (kk < kn) sh_v[kk][j - c0] = ld_src(src, (int64_t)kk * S + col);
+        }
+        __syncthreads();
+        const int a = s > c0 ? s : c0, b = e < c0 + CH ? e : c0 + CH;
+        for (int j = a; j < b; j++) {
+            const double w = sh_w[j - c0];
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++)
+                if (kk < kn) red[kk].add(sh_v[kk][j - c0], w, normsum);
+        }
+    }
+    if (t < T) {
+#pragma unroll
+        for (int kk = 0; kk < KTILE; kk++) {
+            if (kk < kn) {
+                double r = NAN; // regridder.py:44,62: rows without entries stay NaN
+                if (e > s) {
+                    r = red[kk].fin();
+                    if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+                }
+                out[(k0 + kk) * T + t] = r;
+            }
         }
     }
 }
@@ -345,9 +377,15 @@ __global__ void k_apply_coo(const int32_t *__restrict__ row, const int32_t *__re
 
 template <int METHOD, typename SRC>
 static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *out) {
-    dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
-    XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-              csr->indices.get(), csr->data.get(), csr->n, csr->m, src, K, out);
+    if (K == 1) {
+        dim3 grid(div_up(csr->n, AP_BLOCK), 1);
+        XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), csr->n, csr->m, src, K, out);
+    } else {
+        dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
+        XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, KT, 768>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), csr->n, csr->m, src, K, out);
+    }
 }
 
 template <int METHOD, typename SRC>

@@ -390,12 +390,29 @@ __global__ void __launch_bounds__(256) k_row_count(const int32_t *__restrict__ c
 
 static constexpr int ROW_SHORT = 48; // rows with more candidates go to the block-per-row kernel
 
+static constexpr int ROW_LDS = 4096; // candidate entries one block can stage in LDS
+
+// One block = 256 consecutive query faces; their candidate segment is contiguous and is staged
+// in LDS once (coalesced), then every thread ranks the survivors of its own row from LDS.
 __global__ void __launch_bounds__(256)
 k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
            const double *__restrict__ cand_area, int64_t n_query, const int32_t *__restrict__ indptr,
            const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
            double *__restrict__ data, int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    __shared__ int32_t sh_src[ROW_LDS];
+    __shared__ double sh_area[ROW_LDS];
+    const int64_t t0 = (int64_t)blockIdx.x * 256;
+    const int64_t t = t0 + threadIdx.x;
+    const int64_t t_end = t0 + 256 < n_query ? t0 + 256 : n_query;
+    const int seg0 = cand_off[t0], seg1 = cand_off[t_end];
+    const bool staged = seg1 - seg0 <= ROW_LDS;
+    if (staged) {
+        for (int j = seg0 + threadIdx.x; j < seg1; j += 256) {
+            sh_src[j - seg0] = cand_src[j];
+            sh_area[j - seg0] = cand_area[j];
+        }
+    }
+    __syncthreads();
     if (t >= n_query) return;
     const int c0 = cand_off[t], c1 = cand_off[t + 1];
     if (c1 - c0 > ROW_SHORT) {
@@ -403,14 +420,26 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
         return;
     }
     const int base = indptr[t];
-    for (int i = c0; i < c1; i++) {
-        const double a = cand_area[i];
-        if (!(a > 0)) continue;
-        const int s = cand_src[i];
-        int rank = 0;
-        for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && cand_src[j] < s) ? 1 : 0;
-        indices[base + rank] = s;
-        data[base + rank] = relative ? a / src_area[s] : a;
+    if (staged) {
+        for (int i = c0 - seg0; i < c1 - seg0; i++) {
+            const double a = sh_area[i];
+            if (!(a > 0)) continue;
+            const int s = sh_src[i];
+            int rank = 0;
+            for (int j = c0 - seg0; j < c1 - seg0; j++) rank += (sh_area[j] > 0 && sh_src[j] < s) ? 1 : 0;
+            indices[base + rank] = s;
+            data[base + rank] = relative ? a / src_area[s] : a;
+        }
+    } else {
+        for (int i = c0; i < c1; i++) {
+            const double a = cand_area[i];
+            if (!(a > 0)) continue;
+            const int s = cand_src[i];
+            int rank = 0;
+            for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && cand_src[j] < s) ? 1 : 0;
+            indices[base + rank] = s;
+            data[base + rank] = relative ? a / src_area[s] : a;
+        }
     }
 }
 
