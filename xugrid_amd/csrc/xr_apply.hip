@@ -496,19 +496,15 @@ int xr_csr_upload(const double *data, const int64_t *indices, const int64_t *ind
     XR_REQUIRE(n < ((int64_t)1 << 31) - 1 && m < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 31), XR_ERR_LIMIT,
                "xr_csr_upload: matrix exceeds the int32 index range");
     XR_REQUIRE(indptr[0] == 0 && indptr[n] == nnz, XR_ERR_INVALID, "xr_csr_upload: indptr does not span [0, nnz]");
-    int64_t max_row = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const int64_t d = indptr[i + 1] - indptr[i];
-        XR_REQUIRE(d >= 0, XR_ERR_INVALID, "xr_csr_upload: indptr is not non-decreasing at row %lld", (long long)i);
-        if (d > max_row) max_row = d;
-    }
+    for (int64_t i = 0; i < n; i++)
+        XR_REQUIRE(indptr[i + 1] >= indptr[i], XR_ERR_INVALID,
+                   "xr_csr_upload: indptr is not non-decreasing at row %lld", (long long)i);
     for (int64_t i = 0; i < nnz; i++)
         XR_REQUIRE(indices[i] >= 0 && indices[i] < m, XR_ERR_INVALID,
                    "xr_csr_upload: column index %lld outside [0,%lld)", (long long)indices[i], (long long)m);
     xr_csr *csr = new xr_csr();
     try {
         csr->n = n; csr->m = m; csr->nnz = nnz;
-        csr->max_row = (int32_t)max_row;
         csr->indptr.alloc((size_t)n + 1);
         csr->indices.alloc((size_t)nnz);
         csr->data.alloc((size_t)nnz);

@@ -1,18 +1,24 @@
 // xr_geom.h -- device-side geometry types shared by the mesh / overlap / locate kernels.
 //
-// HBM layout of a mesh (struct xr_mesh):
-//   node_xy   f64 [n_node][2]   interleaved: one 16-byte load per vertex
-//   faces     i32 [n_face][M]   CCW-normalised face_node_connectivity, -1 fill (dense, row = face;
-//                               the CSR offset of face f is the implicit f*M)
-//   len       u8  [n_face]      number of valid vertices (polygon_length)
-//   bbox      f64 [n_face][4]   xmin, xmax, ymin, ymax
-//   area      f64 [n_face]      connectivity.area on the caller's vertex order
-// Spatial index ("tree" side): hierarchical uniform grid, one insertion per face
-//   level l has square cells of size h0 * 2^l; a face lives on the lowest level whose cell
-//   size exceeds its bbox extent and is stored in the cell holding its bbox lower-left corner
-//   cell_start i32 [n_cell+1]   CSR offsets of the cell -> record lists, all levels concatenated
-//   rec_bb     f32 [n_face][4]  conservative (outward-rounded) bbox relative to the grid origin
-//   rec_face   i32 [n_face]     face id of each record
+// HBM layout of a mesh (struct xr_mesh), all face-major so that no hot kernel chases
+// connectivity -> node indirections:
+//   fxy   f64 [n_face][M][2]  CCW-normalised vertex coordinates of every face (M = n_max_node;
+//                             48 B per triangle); slots >= len are never read
+//   len   u8  [n_face]        number of valid vertices (polygon_length)
+//   bbox  f64 [n_face][4]     xmin, xmax, ymin, ymax
+//   area  f64 [n_face]        connectivity.area on the caller's vertex order
+// The raw upload (node_xy f64[N][2], faces_raw i32[F][M], the CSR-style flat connectivity with the
+// implicit offset f*M) is only read once, by the prepare kernel.
+// Two spatially sorted copies exist (counting sort, xr_mesh.hip):
+//   query order  q_perm/q_fxy/q_len/q_bbox: faces grouped by the Morton code of a coarse cell, so a
+//                256-face block is a compact 2-D patch (search/clip/row kernels walk this order)
+//   tree index   hierarchical uniform grid, one insertion per face: level l has square cells of
+//                size h0 * 2^l; a face lives on the lowest level whose cell size exceeds its bbox
+//                extent, in the cell holding its bbox lower-left corner
+//     cell_start i32 [n_cell+1]  CSR offsets cell -> record run, all levels concatenated
+//     rec_bb     f32 [n_face][4] conservative (outward-rounded) bbox relative to the grid origin
+//     rec_face   i32 [n_face]    caller's face id of each record
+//     rec_fxy / rec_len          the face arrays in record order (clip reads them contiguously)
 #pragma once
 
 #include <hip/hip_runtime.h>

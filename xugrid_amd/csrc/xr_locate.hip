@@ -10,13 +10,12 @@
 
 namespace xr {
 
-// crossing-number test + "within tol of an edge segment"
-__device__ bool point_in_face(const double *__restrict__ xy, const int32_t *__restrict__ face, int n, P2 p,
-                              double tol) {
+// crossing-number test + "strictly within tol of an edge's line, projection on the segment"
+__device__ bool point_in_face(const double *__restrict__ poly, int n, P2 p, double tol) {
     bool c = false;
-    P2 v0 = load_p2(xy, face[n - 1]);
+    P2 v0 = load_p2(poly, n - 1);
     for (int i = 0; i < n; i++) {
-        const P2 v1 = load_p2(xy, face[i]);
+        const P2 v1 = load_p2(poly, i);
         const double wx = v1.x - v0.x, wy = v1.y - v0.y;
         const double len2 = wx * wx + wy * wy;
         if (len2 > 0) {
@@ -37,14 +36,14 @@ __device__ bool point_in_face(const double *__restrict__ xy, const int32_t *__re
     return c;
 }
 
-__device__ int locate_point(const double *__restrict__ xy, const int32_t *__restrict__ faces,
-                            const uint8_t *__restrict__ len, int m, const double *__restrict__ bbox,
+// -> record index of the matching face with the LOWEST caller face id, or -1
+__device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m,
                             const GridParams &g, const int32_t *__restrict__ cell_start,
                             const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, P2 p, double tol) {
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const float qx0 = f32_below(p.x - tol - g.x0), qx1 = f32_above(p.x + tol - g.x0);
     const float qy0 = f32_below(p.y - tol - g.y0), qy1 = f32_above(p.y + tol - g.y0);
-    int best = -1;
+    int best = -1, best_rec = -1;
     for (int l = 0; l < g.n_levels; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
@@ -58,33 +57,47 @@ __device__ int locate_point(const double *__restrict__ xy, const int32_t *__rest
                 if (!(qx0 <= b.y && b.x <= qx1 && qy0 <= b.w && b.z <= qy1)) continue;
                 const int f = rec_face[r];
                 if (best >= 0 && f > best) continue;
-                const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
-                if (p.x < bb.x - tol || p.x > bb.y + tol || p.y < bb.z - tol || p.y > bb.w + tol) continue;
-                if (point_in_face(xy, faces + (int64_t)f * m, len[f], p, tol)) best = f;
+                const double *poly = rec_fxy + (int64_t)r * m * 2;
+                const int n = rec_len[r];
+                // exact bbox of the face (the same min/max the prepare kernel stored)
+                double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+                for (int j = 0; j < n; j++) {
+                    const P2 v = load_p2(poly, j);
+                    xmin = fmin(xmin, v.x);
+                    xmax = fmax(xmax, v.x);
+                    ymin = fmin(ymin, v.y);
+                    ymax = fmax(ymax, v.y);
+                }
+                if (p.x < xmin - tol || p.x > xmax + tol || p.y < ymin - tol || p.y > ymax + tol) continue;
+                if (point_in_face(poly, n, p, tol)) {
+                    best = f;
+                    best_rec = r;
+                }
             }
         }
     }
-    return best;
+    return best_rec;
 }
 
 __global__ void __launch_bounds__(256)
-k_locate(const double *__restrict__ xy, const int32_t *__restrict__ faces, const uint8_t *__restrict__ len, int m,
-         const double *__restrict__ bbox, GridParams g, const int32_t *__restrict__ cell_start,
-         const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, const double *__restrict__ pts,
-         int64_t n, double tol, int64_t *__restrict__ out) {
+k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+         const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+         const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+         int64_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    out[i] = locate_point(xy, faces, len, m, bbox, g, cell_start, rec_bb, rec_face, p, tol);
+    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    out[i] = r >= 0 ? rec_face[r] : -1;
 }
 
 // Wachspress coordinates with the on-edge special case; triangles use plain area coordinates.
-// w points at this point's row of the (n, m) weight table (global memory, zero-initialised).
-__device__ void bary_weights(const double *__restrict__ xy, const int32_t *__restrict__ face, int n, P2 p, double tol,
-                             double *__restrict__ w) {
+// w points at this point's row of the (n, m) weight table (global memory, zero-initialised);
+// weights are aligned with the CCW-normalised vertex order of the face (as numba_celltree's).
+__device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, double tol, double *__restrict__ w) {
     // pass 1: on-edge detection
     for (int i = 0; i < n; i++) {
-        const P2 v0 = load_p2(xy, face[i]), v1 = load_p2(xy, face[(i + 1) % n]);
+        const P2 v0 = load_p2(poly, i), v1 = load_p2(poly, (i + 1) % n);
         const double wx = v1.x - v0.x, wy = v1.y - v0.y;
         const double ux = p.x - v0.x, uy = p.y - v0.y;
         const double a = wx * uy - wy * ux;
@@ -97,7 +110,6 @@ __device__ void bary_weights(const double *__restrict__ xy, const int32_t *__res
                     double tt = tpar / len2;
                     if (tt < 0) tt = 0;
                     if (tt > 1) tt = 1;
-                    // (zeroing first keeps the semantics of "w[i] = 1-t; w[i+1] = t" when n == 1 wraps)
                     w[i] = 1.0 - tt;
                     w[(i + 1) % n] = tt;
                     return;
@@ -106,7 +118,7 @@ __device__ void bary_weights(const double *__restrict__ xy, const int32_t *__res
         }
     }
     auto A = [&](int i) { // cross(v_i - p, v_{i+1} - p) in the oracle's form
-        const P2 v0 = load_p2(xy, face[i]), v1 = load_p2(xy, face[(i + 1) % n]);
+        const P2 v0 = load_p2(poly, i), v1 = load_p2(poly, (i + 1) % n);
         const double wx = v1.x - v0.x, wy = v1.y - v0.y;
         const double ux = p.x - v0.x, uy = p.y - v0.y;
         return wx * uy - wy * ux;
@@ -122,7 +134,7 @@ __device__ void bary_weights(const double *__restrict__ xy, const int32_t *__res
     double wsum = 0.0;
     for (int i = 0; i < n; i++) {
         const int ip = (i + n - 1) % n, in = (i + 1) % n;
-        const P2 vp = load_p2(xy, face[ip]), vi = load_p2(xy, face[i]), vn = load_p2(xy, face[in]);
+        const P2 vp = load_p2(poly, ip), vi = load_p2(poly, i), vn = load_p2(poly, in);
         const double cx = (vi.x - vp.x) * (vn.y - vi.y) - (vi.y - vp.y) * (vn.x - vi.x);
         const double wi = cx / (A(ip) * A(i));
         w[i] = wi;
@@ -132,18 +144,18 @@ __device__ void bary_weights(const double *__restrict__ xy, const int32_t *__res
 }
 
 __global__ void __launch_bounds__(256)
-k_barycentric(const double *__restrict__ xy, const int32_t *__restrict__ faces, const uint8_t *__restrict__ len, int m,
-              const double *__restrict__ bbox, GridParams g, const int32_t *__restrict__ cell_start,
-              const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, const double *__restrict__ pts,
-              int64_t n, double tol, int64_t *__restrict__ face_out, double *__restrict__ weights) {
+k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+              const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+              int64_t *__restrict__ face_out, double *__restrict__ weights) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    const int f = locate_point(xy, faces, len, m, bbox, g, cell_start, rec_bb, rec_face, p, tol);
-    face_out[i] = f;
+    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    face_out[i] = r >= 0 ? rec_face[r] : -1;
     double *w = weights + i * m;
     for (int j = 0; j < m; j++) w[j] = 0.0;
-    if (f >= 0) bary_weights(xy, faces + (int64_t)f * m, len[f], p, tol, w);
+    if (r >= 0) bary_weights(rec_fxy + (int64_t)r * m * 2, rec_len[r], p, tol, w);
 }
 
 static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
@@ -171,9 +183,9 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
         DevBuf<int64_t> out((size_t)n);
         h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
         if (mesh->n_face > 0) {
-            XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->node_xy.get(),
-                      mesh->faces.get(), mesh->len.get(), mesh->m, mesh->bbox.get(), mesh->grid,
-                      mesh->cell_start.get(), mesh->rec_bb.get(), mesh->rec_face.get(), pts.get(), n, tol, out.get());
+            XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
+                      mesh->rec_len.get(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
+                      mesh->rec_face.get(), pts.get(), n, tol, out.get());
             XR_HIP(hipMemcpyAsync(face_index_out, out.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
                                   engine().stream));
             stream_sync();
@@ -199,9 +211,9 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
             DevBuf<double> pts((size_t)n * 2), w((size_t)n * m);
             DevBuf<int64_t> out((size_t)n);
             h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
-            XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, mesh->node_xy.get(),
-                      mesh->faces.get(), mesh->len.get(), m, mesh->bbox.get(), mesh->grid, mesh->cell_start.get(),
-                      mesh->rec_bb.get(), mesh->rec_face.get(), pts.get(), n, tol, out.get(), w.get());
+            XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
+                      mesh->rec_len.get(), m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
+                      mesh->rec_face.get(), pts.get(), n, tol, out.get(), w.get());
             XR_HIP(hipMemcpyAsync(face_index_out, out.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
                                   engine().stream));
             XR_HIP(hipMemcpyAsync(weights_out, w.get(), sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost,

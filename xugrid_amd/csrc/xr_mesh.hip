@@ -1,5 +1,6 @@
-// xr_mesh.hip -- mesh handle: upload, per-face preparation (fill/length/CCW/bbox/area), the
-// hierarchical-grid spatial index, area / centroid kernels.
+// xr_mesh.hip -- mesh handle: upload, per-face preparation (fill/length/CCW/bbox/area/vertex
+// gather), the two spatial orderings (query order, hierarchical-grid tree index), area / centroid
+// kernels.
 //
 // Replaces, on the device, what the reference does when it constructs
 // numba_celltree.CellTree2d(node_coordinates, face_node_connectivity, -1)
@@ -36,11 +37,32 @@ __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------
 // per-face preparation.  MC > 0: compile-time vertices per face; MC == 0: runtime m <= 32.
 // ---------------------------------------------------------------------------------------------
+// polygon_length (a minimal polygon is a triangle; stop at the first fill value) and
+// counter_clockwise (the first non-collinear vertex triple decides) of one face
+template <int MA>
+__device__ __forceinline__ void face_shape(const double *__restrict__ node_xy, const int (&face)[MA], int m, int &n,
+                                           bool &flip) {
+    n = m;
+#pragma unroll
+    for (int i = MA - 1; i >= 3; i--)
+        if (i < m && face[i] < 0) n = i;
+    flip = false;
+    for (int i = 0; i < n; i++) {
+        const int ia = face[(i + n - 2) % n], ib = face[(i + n - 1) % n], ic = face[i];
+        const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib), c = load_p2(node_xy, ic);
+        const double ux = b.x - a.x, uy = b.y - a.y, vx = c.x - a.x, vy = c.y - a.y;
+        const double prod = ux * vy - uy * vx;
+        if (prod == 0) continue;
+        flip = prod < 0;
+        break;
+    }
+}
+
 template <int MC>
 __global__ void __launch_bounds__(PREP_BLOCK)
 k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face,
-                int m_rt, int32_t *__restrict__ faces, uint8_t *__restrict__ len_out,
-                double *__restrict__ bbox, double *__restrict__ area, double *__restrict__ partials) {
+                int m_rt, double *__restrict__ fxy, uint8_t *__restrict__ len_out, double *__restrict__ bbox,
+                double *__restrict__ area, double *__restrict__ partials) {
     constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * PREP_BLOCK + threadIdx.x;
@@ -71,33 +93,11 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
             }
             area[f] = 0.5 * fabs(det);
         }
-
-        // polygon_length: a minimal polygon is a triangle, stop at the first fill value
-        int n = m;
-#pragma unroll
-        for (int i = MA - 1; i >= 3; i--)
-            if (i < m && face[i] < 0) n = i;
-
-        // counter_clockwise: the first non-collinear vertex triple decides
-        bool flip = false;
-        for (int i = 0; i < n; i++) {
-            const int ia = face[(i + n - 2) % n], ib = face[(i + n - 1) % n], ic = face[i];
-            const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib), c = load_p2(node_xy, ic);
-            const double ux = b.x - a.x, uy = b.y - a.y, vx = c.x - a.x, vy = c.y - a.y;
-            const double prod = ux * vy - uy * vx;
-            if (prod == 0) continue;
-            flip = prod < 0;
-            break;
-        }
-#pragma unroll
-        for (int j = 0; j < MA; j++) {
-            if (j < m) {
-                int v = face[j];
-                if (flip && j < n) v = face[n - 1 - j];
-                faces[f * m + j] = v;
-            }
-        }
+        int n;
+        bool flip;
+        face_shape<MA>(node_xy, face, m, n, flip);
         len_out[f] = (uint8_t)n;
+        double2 *fx = reinterpret_cast<double2 *>(fxy) + f * m;
 #pragma unroll
         for (int j = 0; j < MA; j++) {
             if (j < n) {
@@ -106,6 +106,7 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
                 xmax = fmax(xmax, p.x);
                 ymin = fmin(ymin, p.y);
                 ymax = fmax(ymax, p.y);
+                fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
             }
         }
         double4 *bb = reinterpret_cast<double4 *>(bbox);
@@ -134,6 +135,20 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
         double *p = partials + (int64_t)blockIdx.x * 7;
         p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6;
     }
+}
+
+// CCW-normalised connectivity (xr_mesh_faces; not on the hot path)
+__global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ node_xy,
+                                                  const int32_t *__restrict__ faces_raw, int64_t n_face, int m,
+                                                  int64_t *__restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    int face[XR_MAX_FACE_NODES];
+    for (int j = 0; j < m; j++) face[j] = faces_raw[f * m + j];
+    int n;
+    bool flip;
+    face_shape<XR_MAX_FACE_NODES>(node_xy, face, m, n, flip);
+    for (int j = 0; j < m; j++) out[f * m + j] = (flip && j < n) ? face[n - 1 - j] : face[j];
 }
 
 __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__ partials, int64_t nb,
@@ -166,7 +181,7 @@ void mesh_prepare(xr_mesh *mesh) {
     if (mesh->prepared) return;
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
-    mesh->faces.alloc((size_t)F * m);
+    mesh->fxy.alloc((size_t)F * m * 2);
     mesh->len.alloc((size_t)F);
     mesh->bbox.alloc((size_t)F * 4);
     mesh->area.alloc((size_t)F);
@@ -176,13 +191,13 @@ void mesh_prepare(xr_mesh *mesh) {
     dim3 grid((unsigned)nb), block(PREP_BLOCK);
     if (m == 3) {
         XR_LAUNCH("prepare_faces", k_prepare_faces<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  mesh->faces.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
     } else if (m == 4) {
         XR_LAUNCH("prepare_faces", k_prepare_faces<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  mesh->faces.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
     } else {
         XR_LAUNCH("prepare_faces", k_prepare_faces<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  mesh->faces.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
     }
     XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get());
     mesh->prepared = true;
@@ -197,7 +212,109 @@ void mesh_read_stats(xr_mesh *mesh) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// spatial index
+// counting sort of element ids by an integer key (the ONLY sort the engine needs: spatial keys
+// are small integers).  Order inside a bucket follows the atomics, i.e. is unspecified -- every
+// consumer is written so that final results do not depend on it.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_key_count(const int32_t *__restrict__ key, int64_t n,
+                                                  int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&count[key[i]], 1);
+}
+
+__global__ void __launch_bounds__(256) k_key_fill(const int32_t *__restrict__ key, int64_t n,
+                                                 const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
+                                                 int32_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = key[i];
+    perm[start[k] + atomicAdd(&cursor[k], 1)] = (int32_t)i;
+}
+
+void counting_sort_perm(const int32_t *key, int64_t n, int64_t n_buckets, int32_t *perm, int32_t *bucket_start) {
+    DevBuf<int32_t> count((size_t)n_buckets);
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
+    if (n > 0) XR_LAUNCH("sort_count", k_key_count, dim3(div_up(n, 256)), dim3(256), 0, key, n, count.get());
+    exclusive_scan_i32(count.get(), bucket_start, n_buckets);
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
+    if (n > 0)
+        XR_LAUNCH("sort_fill", k_key_fill, dim3(div_up(n, 256)), dim3(256), 0, key, n, bucket_start, count.get(), perm);
+}
+
+// permute the per-face arrays: out[r] = in[perm[r]]; optionally emit the conservative f32 record bbox
+__global__ void __launch_bounds__(256)
+k_gather_faces(const int32_t *__restrict__ perm, int64_t n, int m, const double *__restrict__ fxy,
+               const uint8_t *__restrict__ len, const double *__restrict__ bbox, double *__restrict__ o_fxy,
+               uint8_t *__restrict__ o_len, double *__restrict__ o_bbox, float *__restrict__ o_recbb, double x0,
+               double y0) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int64_t f = perm[r];
+    const int nl = len[f];
+    o_len[r] = (uint8_t)nl;
+    const double2 *src = reinterpret_cast<const double2 *>(fxy) + f * m;
+    double2 *dst = reinterpret_cast<double2 *>(o_fxy) + r * m;
+    for (int j = 0; j < nl; j++) dst[j] = src[j];
+    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    if (o_bbox) reinterpret_cast<double4 *>(o_bbox)[r] = bb;
+    if (o_recbb)
+        reinterpret_cast<float4 *>(o_recbb)[r] =
+            make_float4(f32_below(bb.x - x0), f32_above(bb.y - x0), f32_below(bb.z - y0), f32_above(bb.w - y0));
+}
+
+// ---------------------------------------------------------------------------------------------
+// query order: faces grouped by the Morton code of the coarse cell holding their bbox centre
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread_bits16(uint32_t v) {
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_morton_keys(const double *__restrict__ bbox, int64_t n, double x0, double y0,
+                                                    double inv_h, int n_side, int32_t *__restrict__ key) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    const int cx = cell_coord(0.5 * (bb.x + bb.y), x0, inv_h, n_side);
+    const int cy = cell_coord(0.5 * (bb.z + bb.w), y0, inv_h, n_side);
+    key[f] = (int32_t)(spread_bits16((uint32_t)cx) | (spread_bits16((uint32_t)cy) << 1));
+}
+
+void mesh_query_order(xr_mesh *mesh) {
+    if (mesh->query_ready) return;
+    mesh_read_stats(mesh);
+    const int64_t F = mesh->n_face;
+    const int m = mesh->m;
+    mesh->q_perm.alloc((size_t)F);
+    mesh->q_fxy.alloc((size_t)F * m * 2);
+    mesh->q_len.alloc((size_t)F);
+    mesh->q_bbox.alloc((size_t)F * 4);
+    if (F > 0) {
+        const double xmin = mesh->h_stats[0], xmax = mesh->h_stats[1], ymin = mesh->h_stats[2], ymax = mesh->h_stats[3];
+        double span = std::max(xmax - xmin, ymax - ymin);
+        if (!(span > 0)) span = 1.0;
+        double h = 2.0 * mesh->h_stats[4] / (double)F; // two mean extents per coarse cell
+        if (!(h > 0)) h = span;
+        int bits = 1;
+        while (bits < 10 && ldexp(h, bits) < span) bits++;
+        const int n_side = 1 << bits;
+        const double inv_h = (double)n_side / (span * (1.0 + 1e-9));
+        DevBuf<int32_t> key((size_t)F), start(((size_t)1 << (2 * bits)) + 1);
+        XR_LAUNCH("morton_keys", k_morton_keys, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, xmin, ymin,
+                  inv_h, n_side, key.get());
+        counting_sort_perm(key.get(), F, (int64_t)1 << (2 * bits), mesh->q_perm.get(), start.get());
+        XR_LAUNCH("gather_query", k_gather_faces, dim3(div_up(F, 256)), dim3(256), 0, mesh->q_perm.get(), F, m,
+                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->q_fxy.get(), mesh->q_len.get(),
+                  mesh->q_bbox.get(), (float *)nullptr, 0.0, 0.0);
+    }
+    mesh->query_ready = true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tree index
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
     const double e = fmax(bb.y - bb.x, bb.w - bb.z);
@@ -208,35 +325,18 @@ __device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
     return g.base[l] + cy * g.nx[l] + cx;
 }
 
-__global__ void __launch_bounds__(256) k_index_count(const double *__restrict__ bbox, int64_t n_face, GridParams g,
-                                                    int32_t *__restrict__ key, int32_t *__restrict__ cell_count) {
+__global__ void __launch_bounds__(256) k_index_keys(const double *__restrict__ bbox, int64_t n_face, GridParams g,
+                                                   int32_t *__restrict__ key) {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n_face) return;
-    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
-    const int c = face_cell(g, bb);
-    key[f] = c;
-    atomicAdd(&cell_count[c], 1);
-}
-
-__global__ void __launch_bounds__(256) k_index_fill(const double *__restrict__ bbox, int64_t n_face, GridParams g,
-                                                   const int32_t *__restrict__ key,
-                                                   const int32_t *__restrict__ cell_start,
-                                                   int32_t *__restrict__ cell_fill, float *__restrict__ rec_bb,
-                                                   int32_t *__restrict__ rec_face) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_face) return;
-    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
-    const int c = key[f];
-    const int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
-    rec_face[pos] = (int32_t)f;
-    reinterpret_cast<float4 *>(rec_bb)[pos] = make_float4(f32_below(bb.x - g.x0), f32_above(bb.y - g.x0),
-                                                          f32_below(bb.z - g.y0), f32_above(bb.w - g.y0));
+    key[f] = face_cell(g, reinterpret_cast<const double4 *>(bbox)[f]);
 }
 
 void mesh_build_index(xr_mesh *mesh) {
     if (mesh->indexed) return;
     mesh_read_stats(mesh);
     const int64_t F = mesh->n_face;
+    const int m = mesh->m;
     XR_REQUIRE(F < (int64_t)1 << 31, XR_ERR_LIMIT, "mesh has too many faces for int32 indices");
     const double xmin = mesh->h_stats[0], xmax = mesh->h_stats[1], ymin = mesh->h_stats[2], ymax = mesh->h_stats[3];
     const double sum_ext = mesh->h_stats[4], max_ext = mesh->h_stats[5];
@@ -272,18 +372,16 @@ void mesh_build_index(xr_mesh *mesh) {
     mesh->cell_start.alloc((size_t)total + 1);
     mesh->rec_bb.alloc((size_t)F * 4);
     mesh->rec_face.alloc((size_t)F);
-    DevBuf<int32_t> key((size_t)F), count((size_t)total);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)total, engine().stream));
-    if (F > 0) {
-        XR_LAUNCH("index_count", k_index_count, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, g, key.get(),
-                  count.get());
-    }
-    exclusive_scan_i32(count.get(), mesh->cell_start.get(), total);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)total, engine().stream));
-    if (F > 0) {
-        XR_LAUNCH("index_fill", k_index_fill, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, g, key.get(),
-                  mesh->cell_start.get(), count.get(), mesh->rec_bb.get(), mesh->rec_face.get());
-    }
+    mesh->rec_fxy.alloc((size_t)F * m * 2);
+    mesh->rec_len.alloc((size_t)F);
+    DevBuf<int32_t> key((size_t)F);
+    if (F > 0)
+        XR_LAUNCH("index_keys", k_index_keys, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, g, key.get());
+    counting_sort_perm(key.get(), F, total, mesh->rec_face.get(), mesh->cell_start.get());
+    if (F > 0)
+        XR_LAUNCH("gather_index", k_gather_faces, dim3(div_up(F, 256)), dim3(256), 0, mesh->rec_face.get(), F, m,
+                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->rec_fxy.get(), mesh->rec_len.get(),
+                  (double *)nullptr, mesh->rec_bb.get(), g.x0, g.y0);
     mesh->indexed = true;
 }
 
@@ -324,11 +422,6 @@ __global__ void __launch_bounds__(256) k_centroids(const double *__restrict__ no
     const double aw = 1.0 / (3.0 * det);
     cxy[2 * f] = aw * sx + p0.x;
     cxy[2 * f + 1] = aw * sy + p0.y;
-}
-
-__global__ void k_widen_faces(const int32_t *__restrict__ in, int64_t *__restrict__ out, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = in[i];
 }
 
 } // namespace xr
@@ -425,10 +518,13 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_invalidate: NULL mesh");
     stream_sync();
     mesh->prepared = false;
+    mesh->query_ready = false;
     mesh->indexed = false;
     mesh->stats_valid = false;
-    mesh->faces.release(); mesh->len.release(); mesh->bbox.release(); mesh->area.release(); mesh->stats.release();
-    mesh->cell_start.release(); mesh->rec_bb.release(); mesh->rec_face.release();
+    mesh->fxy.release(); mesh->len.release(); mesh->bbox.release(); mesh->area.release(); mesh->stats.release();
+    mesh->q_perm.release(); mesh->q_fxy.release(); mesh->q_len.release(); mesh->q_bbox.release();
+    mesh->cell_start.release(); mesh->rec_bb.release(); mesh->rec_face.release(); mesh->rec_fxy.release();
+    mesh->rec_len.release();
     XR_API_END
 }
 
@@ -462,11 +558,11 @@ int xr_mesh_centroids(xr_mesh *mesh, double *centroids_out) {
 int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out) {
     XR_API_BEGIN
     XR_REQUIRE(mesh && faces_out, XR_ERR_INVALID, "xr_mesh_faces: NULL argument");
-    mesh_prepare(mesh);
     const int64_t n = mesh->n_face * mesh->m;
     if (n > 0) {
         DevBuf<int64_t> wide((size_t)n);
-        XR_LAUNCH("widen_faces", k_widen_faces, dim3(div_up(n, 256)), dim3(256), 0, mesh->faces.get(), wide.get(), n);
+        XR_LAUNCH("faces_ccw", k_faces_ccw, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
+                  mesh->faces_raw.get(), mesh->n_face, mesh->m, wide.get());
         XR_HIP(hipMemcpyAsync(faces_out, wide.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
                               engine().stream));
         stream_sync();

@@ -4,7 +4,13 @@
 #include "xr_geom.h"
 #include "xr_internal.h"
 
-// Device-resident face topology + derived per-face data + spatial index.  Layout: xr_geom.h.
+// Device-resident face topology + derived per-face data, in three stages (layout: xr_geom.h):
+//   raw      what the caller uploaded (node_xy, faces_raw)
+//   prepared per-face arrays in the CALLER's face order (fxy, len, bbox, area, stats)
+//   query    the same arrays permuted into a spatially coherent order (Morton order of coarse
+//            cells) -- used when the mesh is the QUERY (regridding target) side
+//   index    the same arrays permuted into grid-cell order + cell_start -- used when the mesh is
+//            the TREE (regridding source) side
 struct xr_mesh {
     int64_t n_node = 0, n_face = 0;
     int m = 0; // n_max_node_per_face
@@ -12,22 +18,31 @@ struct xr_mesh {
     xr::DevBuf<double> node_xy;    // [n_node*2]
     xr::DevBuf<int32_t> faces_raw; // [n_face*m] caller's vertex order, fill -> -1
 
-    // derived by xr_mesh_prepare
+    // ---- prepared (caller's face order)
     bool prepared = false;
-    xr::DevBuf<int32_t> faces; // [n_face*m] CCW
-    xr::DevBuf<uint8_t> len;   // [n_face]
-    xr::DevBuf<double> bbox;   // [n_face*4] xmin,xmax,ymin,ymax
-    xr::DevBuf<double> area;   // [n_face]
-    xr::DevBuf<double> stats;  // [7] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal (device)
+    xr::DevBuf<double> fxy;   // [n_face*m*2] CCW-normalised vertex coordinates per face
+    xr::DevBuf<uint8_t> len;  // [n_face]
+    xr::DevBuf<double> bbox;  // [n_face*4] xmin,xmax,ymin,ymax
+    xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order
+    xr::DevBuf<double> stats; // [7] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal (device)
     bool stats_valid = false;
     double h_stats[7] = {0, 0, 0, 0, 0, 0, 0};
 
-    // derived by xr_mesh_build_index
+    // ---- query order
+    bool query_ready = false;
+    xr::DevBuf<int32_t> q_perm; // [n_face] position -> caller's face id
+    xr::DevBuf<double> q_fxy;   // [n_face*m*2]
+    xr::DevBuf<uint8_t> q_len;  // [n_face]
+    xr::DevBuf<double> q_bbox;  // [n_face*4]
+
+    // ---- tree index (records in grid-cell order)
     bool indexed = false;
     xr::GridParams grid{};
     xr::DevBuf<int32_t> cell_start; // [n_cells+1]
-    xr::DevBuf<float> rec_bb;       // [n_face*4]
-    xr::DevBuf<int32_t> rec_face;   // [n_face]
+    xr::DevBuf<float> rec_bb;       // [n_face*4] conservative f32 bbox relative to the grid origin
+    xr::DevBuf<int32_t> rec_face;   // [n_face]   record -> caller's face id
+    xr::DevBuf<double> rec_fxy;     // [n_face*m*2]
+    xr::DevBuf<uint8_t> rec_len;    // [n_face]
 
     int64_t last_candidates = 0;
 };
@@ -35,14 +50,19 @@ struct xr_mesh {
 // Device-resident MatrixCSR (xugrid/core/sparse.py:81-137), int32 structure + float64 data.
 struct xr_csr {
     int64_t n = 0, m = 0, nnz = 0;
-    xr::DevBuf<int32_t> indptr;  // [n+1]
-    xr::DevBuf<int32_t> indices; // [nnz]
-    xr::DevBuf<double> data;     // [nnz]
-    int32_t max_row = -1;        // longest row (np.diff(indptr).max(), regridder.py:48); -1 = unknown
+    xr::DevBuf<int32_t> indptr;    // [n+1]
+    xr::DevBuf<int32_t> indices;   // [nnz]
+    xr::DevBuf<double> data;       // [nnz]
+    xr::DevBuf<int32_t> row_order; // [n] optional: spatially coherent processing order of the rows
+    bool has_row_order = false;
 };
 
 namespace xr {
 void mesh_prepare(xr_mesh *mesh);
+void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
 void mesh_read_stats(xr_mesh *mesh);
+// perm[i] = element ids grouped by ascending key (order inside a bucket unspecified);
+// bucket_start (n_buckets + 1) receives the bucket offsets.
+void counting_sort_perm(const int32_t *key, int64_t n, int64_t n_buckets, int32_t *perm, int32_t *bucket_start);
 } // namespace xr

@@ -83,7 +83,7 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
                 if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
                     if (FILL) {
                         cand_tgt[out] = (int32_t)t;
-                        cand_src[out] = rec_face[r];
+                        cand_src[out] = r;
                         out++;
                     }
                     count++;
@@ -124,8 +124,8 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
 
 template <bool FILL>
 __global__ void __launch_bounds__(256)
-k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_xy,
-             const int32_t *__restrict__ q_faces, const uint8_t *__restrict__ q_len, int q_m, GridParams g,
+k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy,
+             const uint8_t *__restrict__ q_len, int q_m, GridParams g,
              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
              const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
              const int32_t *__restrict__ n_big, const int32_t *__restrict__ cand_off,
@@ -140,7 +140,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_xy,
     for (int bi = wave; bi < nb; bi += n_waves) {
         const int t = big_list[bi];
         const int np = q_len[t];
-        if (lane < np) poly[lane] = reinterpret_cast<const double2 *>(q_xy)[q_faces[(int64_t)t * q_m + lane]];
+        if (lane < np) poly[lane] = reinterpret_cast<const double2 *>(q_fxy)[(int64_t)t * q_m + lane];
         __builtin_amdgcn_wave_barrier();
         const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
@@ -202,7 +202,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_xy,
                         if (FILL && hit) {
                             const int slot = out + __popcll(mask & lt_mask);
                             cand_tgt[slot] = t;
-                            cand_src[slot] = rec_face[r];
+                            cand_src[slot] = r;
                         }
                         const int n = __popcll(mask);
                         out += n;
@@ -220,7 +220,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_xy,
                     for (int r = r0; r < my_r1; r++) {
                         if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
                             cand_tgt[pos] = t;
-                            cand_src[pos] = rec_face[r];
+                            cand_src[pos] = r;
                             pos++;
                         }
                     }
@@ -256,11 +256,11 @@ static constexpr double AREA_OVERFLOW = -1.0; // sentinel: polygon buffer too sm
 
 template <int MAXV, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-k_clip(const double *__restrict__ q_xy, const int32_t *__restrict__ q_faces, const uint8_t *__restrict__ q_len,
-       int q_m, const double *__restrict__ s_xy, const int32_t *__restrict__ s_faces,
-       const uint8_t *__restrict__ s_len, int s_m, const int32_t *__restrict__ cand_tgt,
-       const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area, bool redo_only,
-       int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
+k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int q_m,
+       const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy, const uint8_t *__restrict__ s_len,
+       int s_m, const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
+       double *__restrict__ cand_area, bool redo_only, int32_t *__restrict__ overflow_count,
+       int32_t *__restrict__ nnz_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *sh = reinterpret_cast<double2 *>(smem);
     const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -273,15 +273,15 @@ k_clip(const double *__restrict__ q_xy, const int32_t *__restrict__ q_faces, con
     const int nt = q_len[t], ns = s_len[s];
     double2 *out = sh + threadIdx.x;                // out[j * BLOCK]
     double2 *in = sh + MAXV * BLOCK + threadIdx.x;  // in[j * BLOCK]
-    const int32_t *tf = q_faces + (int64_t)t * q_m;
-    const int32_t *sf = s_faces + (int64_t)s * s_m;
-    for (int j = 0; j < nt; j++) out[j * BLOCK] = reinterpret_cast<const double2 *>(q_xy)[tf[j]];
+    const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
+    const double *sf = s_fxy + (int64_t)s * s_m * 2;
+    for (int j = 0; j < nt; j++) out[j * BLOCK] = tf[j];
     int n_output = nt;
     bool overflow = false;
-    P2 r = load_p2(s_xy, sf[ns - 1]);
+    P2 r = load_p2(sf, ns - 1);
     bool empty = false;
     for (int i = 0; i < ns; i++) {
-        const P2 sv = load_p2(s_xy, sf[i]);
+        const P2 sv = load_p2(sf, i);
         const P2 U{sv.x - r.x, sv.y - r.y};
         if (U.x == 0 && U.y == 0) continue;
         const P2 N{-U.y, U.x};
@@ -369,7 +369,143 @@ k_clip(const double *__restrict__ q_xy, const int32_t *__restrict__ q_faces, con
             unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
             run &= ~((1ull << lane) - 1);
             const int n = __popcll(surv & run);
-            if (n > 0) atomicAdd(&nnz_row[t], n);
+            if (n > 0) atomicAdd(&nnz_row[q_perm[t]], n);
+        }
+    }
+}
+
+// Small-polygon variant (query + tree vertices <= MAXV, i.e. triangles / quads): the subject
+// polygon lives in REGISTERS (statically indexed, loops fully unrolled and predicated on the
+// current length); only the output polygon, whose write index is data dependent, is staged in
+// LDS ([vertex][thread]).  Half the LDS of the generic kernel -> twice the resident waves.
+// The arithmetic and its order are those of k_clip / the oracle.
+template <int MAXV, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int q_m,
+             const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy,
+             const uint8_t *__restrict__ s_len, int s_m, const int32_t *__restrict__ cand_tgt,
+             const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area,
+             int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *out = reinterpret_cast<double2 *>(smem) + threadIdx.x; // out[j * BLOCK]
+    const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool active = c < n_cand;
+    int t = -1;
+    double area = 0.0;
+    if (active) {
+        t = cand_tgt[c];
+        const int s = cand_src[c];
+        const int nt = q_len[t], ns = s_len[s];
+        const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
+        const double *sf = s_fxy + (int64_t)s * s_m * 2;
+        P2 in[MAXV];
+        P2 last{0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < MAXV; j++) {
+            if (j < nt) {
+                const double2 v = tf[j];
+                in[j] = P2{v.x, v.y};
+                last = in[j];
+            }
+        }
+        int length = nt;
+        bool overflow = false, empty = false;
+        P2 r = load_p2(sf, ns - 1);
+        for (int i = 0; i < ns; i++) {
+            const P2 sv = load_p2(sf, i);
+            const P2 U{sv.x - r.x, sv.y - r.y};
+            if (U.x == 0 && U.y == 0) continue;
+            const P2 N{-U.y, U.x};
+            int n_output = 0;
+            P2 a = last;
+            bool a_inside = sh_inside(a, r, U);
+#pragma unroll
+            for (int j = 0; j < MAXV; j++) {
+                if (j < length) {
+                    const P2 b = in[j];
+                    const P2 V{b.x - a.x, b.y - a.y};
+                    if (!(V.x == 0 && V.y == 0)) {
+                        bool b_inside = sh_inside(b, r, U);
+                        if (b_inside) {
+                            if (!a_inside) {
+                                P2 pt;
+                                if (sh_intersection(a, V, r, N, pt)) {
+                                    if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
+                                    else overflow = true;
+                                    n_output++;
+                                }
+                            }
+                            if (n_output < MAXV) out[n_output * BLOCK] = make_double2(b.x, b.y);
+                            else overflow = true;
+                            n_output++;
+                            last = b;
+                        } else if (a_inside) {
+                            P2 pt;
+                            if (sh_intersection(a, V, r, N, pt)) {
+                                if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
+                                else overflow = true;
+                                n_output++;
+                                last = pt;
+                            } else {
+                                b_inside = true;
+                                if (n_output < MAXV) out[n_output * BLOCK] = make_double2(b.x, b.y);
+                                else overflow = true;
+                                n_output++;
+                                last = b;
+                            }
+                        }
+                        a = b;
+                        a_inside = b_inside;
+                    }
+                }
+            }
+            if (overflow) break;
+            if (n_output < 3) {
+                empty = true;
+                break;
+            }
+            length = n_output;
+#pragma unroll
+            for (int j = 0; j < MAXV; j++) {
+                if (j < length) {
+                    const double2 v = out[j * BLOCK];
+                    in[j] = P2{v.x, v.y};
+                }
+            }
+            r = sv;
+        }
+        if (overflow) {
+            area = AREA_OVERFLOW;
+            atomicAdd(overflow_count, 1);
+        } else if (!empty) {
+            const P2 a0 = in[0];
+            double ux = in[1].x - a0.x, uy = in[1].y - a0.y;
+#pragma unroll
+            for (int i = 2; i < MAXV; i++) {
+                if (i < length) {
+                    const double vx = a0.x - in[i].x, vy = a0.y - in[i].y;
+                    area += fabs(ux * vy - uy * vx);
+                    ux = vx;
+                    uy = vy;
+                }
+            }
+            area = 0.5 * area;
+        }
+        cand_area[c] = area;
+    }
+    {
+        const int lane = threadIdx.x & 63;
+        const int t_prev = __shfl_up(t, 1, 64);
+        const bool head = lane == 0 || t_prev != t;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long surv = __ballot(active && area > 0);
+        if (head && t >= 0) {
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+            unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
+            run &= ~((1ull << lane) - 1);
+            const int n = __popcll(surv & run);
+            if (n > 0) atomicAdd(&nnz_row[q_perm[t]], n);
         }
     }
 }
@@ -380,23 +516,27 @@ k_clip(const double *__restrict__ q_xy, const int32_t *__restrict__ q_faces, con
 // recount of the survivors per row; only used after the rare clip-buffer overflow redo
 __global__ void __launch_bounds__(256) k_row_count(const int32_t *__restrict__ cand_off,
                                                   const double *__restrict__ cand_area, int64_t n_query,
+                                                  const int32_t *__restrict__ q_perm,
                                                   int32_t *__restrict__ nnz_row) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_query) return;
     int n = 0;
     for (int c = cand_off[t]; c < cand_off[t + 1]; c++) n += cand_area[c] > 0 ? 1 : 0;
-    nnz_row[t] = n;
+    nnz_row[q_perm[t]] = n;
 }
 
 static constexpr int ROW_SHORT = 48; // rows with more candidates go to the block-per-row kernel
 
 static constexpr int ROW_LDS = 4096; // candidate entries one block can stage in LDS
 
-// One block = 256 consecutive query faces; their candidate segment is contiguous and is staged
-// in LDS once (coalesced), then every thread ranks the survivors of its own row from LDS.
+// One block = 256 consecutive query faces (query order); their candidate segment is contiguous
+// and is staged in LDS once (coalesced; record index -> caller's tree face id resolved while
+// staging), then every thread ranks the survivors of its own row from LDS and writes the CSR row
+// of the caller's face id q_perm[r].
 __global__ void __launch_bounds__(256)
 k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
-           const double *__restrict__ cand_area, int64_t n_query, const int32_t *__restrict__ indptr,
+           const double *__restrict__ cand_area, int64_t n_query, const int32_t *__restrict__ q_perm,
+           const int32_t *__restrict__ rec_face, const int32_t *__restrict__ indptr,
            const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
            double *__restrict__ data, int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long) {
     __shared__ int32_t sh_src[ROW_LDS];
@@ -408,7 +548,7 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
     const bool staged = seg1 - seg0 <= ROW_LDS;
     if (staged) {
         for (int j = seg0 + threadIdx.x; j < seg1; j += 256) {
-            sh_src[j - seg0] = cand_src[j];
+            sh_src[j - seg0] = rec_face[cand_src[j]];
             sh_area[j - seg0] = cand_area[j];
         }
     }
@@ -419,7 +559,7 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
         long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
         return;
     }
-    const int base = indptr[t];
+    const int base = indptr[q_perm[t]];
     if (staged) {
         for (int i = c0 - seg0; i < c1 - seg0; i++) {
             const double a = sh_area[i];
@@ -434,9 +574,9 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
         for (int i = c0; i < c1; i++) {
             const double a = cand_area[i];
             if (!(a > 0)) continue;
-            const int s = cand_src[i];
+            const int s = rec_face[cand_src[i]];
             int rank = 0;
-            for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && cand_src[j] < s) ? 1 : 0;
+            for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && rec_face[cand_src[j]] < s) ? 1 : 0;
             indices[base + rank] = s;
             data[base + rank] = relative ? a / src_area[s] : a;
         }
@@ -453,7 +593,8 @@ static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread
 
 __global__ void __launch_bounds__(256)
 k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
-                const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
+                const double *__restrict__ cand_area, const int32_t *__restrict__ q_perm,
+                const int32_t *__restrict__ rec_face, const int32_t *__restrict__ indptr,
                 const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
                 const int32_t *__restrict__ n_long) {
@@ -467,12 +608,12 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
         const int c0 = cand_off[t], c1 = cand_off[t + 1];
-        const int base = indptr[t];
+        const int base = indptr[q_perm[t]];
         // id range of the survivors
         int lo = 0x7fffffff, hi = -1;
         for (int i = c0 + tid; i < c1; i += 256) {
             if (cand_area[i] > 0) {
-                const int s = cand_src[i];
+                const int s = rec_face[cand_src[i]];
                 lo = min(lo, s);
                 hi = max(hi, s);
             }
@@ -497,7 +638,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 __syncthreads();
                 for (int i = c0 + tid; i < c1; i += 256) {
                     if (cand_area[i] > 0) {
-                        const int s = cand_src[i] - cb;
+                        const int s = rec_face[cand_src[i]] - cb;
                         if (s >= 0 && s < BM_BITS) atomicOr(&bm[s >> 5], 1u << (s & 31));
                     }
                 }
@@ -527,7 +668,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 for (int i = c0 + tid; i < c1; i += 256) {
                     const double a = cand_area[i];
                     if (a > 0) {
-                        const int sid = cand_src[i];
+                        const int sid = rec_face[cand_src[i]];
                         const int s = sid - cb;
                         if (s >= 0 && s < BM_BITS) {
                             const int w = s >> 5;
@@ -556,15 +697,21 @@ static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t
         attr_set = true;
     }
     XR_LAUNCH(MAXV == 8 ? "clip_v8" : (MAXV == 16 ? "clip_v16" : "clip_v64"), (k_clip<MAXV, BLOCK>),
-              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->node_xy.get(), query->faces.get(), query->len.get(),
-              query->m, tree->node_xy.get(), tree->faces.get(), tree->len.get(), tree->m, cand_tgt, cand_src, C,
-              cand_area, redo_only, overflow_count, nnz_row);
+              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->q_fxy.get(), query->q_len.get(), query->m,
+              query->q_perm.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area,
+              redo_only, overflow_count, nnz_row);
 }
 
 static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
                             int64_t C, double *cand_area, int32_t *overflow_count, int32_t *nnz_row) {
     const int vmax = query->m + tree->m;
-    if (vmax <= 8) launch_clip<8, 256>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
+    if (vmax <= 8) {
+        constexpr int MAXV = 8, BLOCK = 256;
+        const size_t shmem = (size_t)MAXV * BLOCK * sizeof(double2);
+        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
+                  query->q_fxy.get(), query->q_len.get(), query->m, query->q_perm.get(), tree->rec_fxy.get(),
+                  tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, overflow_count, nnz_row);
+    }
     else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
     else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
 }
@@ -573,6 +720,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     mesh_prepare(tree);
     mesh_prepare(query);
     mesh_build_index(tree);
+    mesh_query_order(query);
     const int64_t T = query->n_face, S = tree->n_face;
     XR_REQUIRE(T < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "too many query faces for int32 row offsets");
     csr->n = T;
@@ -584,7 +732,6 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         XR_HIP(hipMemsetAsync(csr->indptr.get(), 0, sizeof(int32_t) * ((size_t)T + 1), engine().stream));
         csr->indices.alloc(0);
         csr->data.alloc(0);
-        csr->max_row = 0;
         return;
     }
     const GridParams &g = tree->grid;
@@ -596,12 +743,12 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
     DevBuf<uint8_t> is_big((size_t)T);
     const int big_grid = engine().num_cu * 2;
-    XR_LAUNCH("search_count", k_search<false>, dim3(div_up(T, 256)), dim3(256), 0, query->bbox.get(), T, g,
+    XR_LAUNCH("search_count", k_search<false>, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), (const int32_t *)nullptr,
               cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr, is_big.get(), big_list.get(),
               counters.get() + 2);
-    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->bbox.get(),
-              query->node_xy.get(), query->faces.get(), query->len.get(), query->m, g, tree->cell_start.get(),
+    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->q_bbox.get(),
+              query->q_fxy.get(), query->q_len.get(), query->m, g, tree->cell_start.get(),
               tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, (const int32_t *)nullptr,
               cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
     exclusive_scan_i32(cand_count.get(), cand_off.get(), T);
@@ -613,12 +760,12 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     DevBuf<double> cand_area((size_t)C);
     XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
     if (C > 0) {
-        XR_LAUNCH("search_fill", k_search<true>, dim3(div_up(T, 256)), dim3(256), 0, query->bbox.get(), T, g,
+        XR_LAUNCH("search_fill", k_search<true>, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
                   tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), cand_off.get(),
                   (int32_t *)nullptr, cand_tgt.get(), cand_src.get(), is_big.get(), (int32_t *)nullptr,
                   (int32_t *)nullptr);
-        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->bbox.get(),
-                  query->node_xy.get(), query->faces.get(), query->len.get(), query->m, g, tree->cell_start.get(),
+        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->q_bbox.get(),
+                  query->q_fxy.get(), query->q_len.get(), query->m, g, tree->cell_start.get(),
                   tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
                   (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
         // --- clip (+ per-row survivor counts)
@@ -638,7 +785,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         launch_clip<64, 64>(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), true, counters.get(),
                             nnz_row.get());
         XR_LAUNCH("row_recount", k_row_count, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_area.get(), T,
-                  nnz_row.get());
+                  query->q_perm.get(), nnz_row.get());
         exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
         tail[3] = read_scalar(csr->indptr.get() + T);
     }
@@ -647,12 +794,16 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     csr->nnz = P;
     csr->indices.alloc((size_t)P);
     csr->data.alloc((size_t)P);
-    csr->max_row = -1;
+    // rows are best processed in the query mesh's spatial order (apply kernels)
+    csr->row_order.alloc((size_t)T);
+    XR_HIP(hipMemcpyAsync(csr->row_order.get(), query->q_perm.get(), sizeof(int32_t) * (size_t)T,
+                          hipMemcpyDeviceToDevice, st));
+    csr->has_row_order = true;
     if (P > 0) {
         DevBuf<int32_t> long_rows((size_t)T);
         XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_src.get(),
-                  cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative, csr->indices.get(),
-                  csr->data.get(), long_rows.get(), counters.get() + 1);
+                  cand_area.get(), T, query->q_perm.get(), tree->rec_face.get(), csr->indptr.get(), tree->area.get(),
+                  relative, csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
         const size_t shmem = sizeof(uint32_t) * (2 * BM_WORDS + 256) + sizeof(int32_t) * 8;
         static bool attr_set = false;
         if (!attr_set) {
@@ -661,8 +812,9 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
             attr_set = true;
         }
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
-                  cand_src.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, csr->indices.get(),
-                  csr->data.get(), long_rows.get(), counters.get() + 1);
+                  cand_src.get(), cand_area.get(), query->q_perm.get(), tree->rec_face.get(), csr->indptr.get(),
+                  tree->area.get(), relative, csr->indices.get(), csr->data.get(), long_rows.get(),
+                  counters.get() + 1);
     }
 }
 
