@@ -120,8 +120,8 @@ template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238
 template <int METHOD, typename SRC, int KTILE, int CH>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-               const double *__restrict__ data, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
-               double *__restrict__ out) {
+               const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
+               const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
     __shared__ double sh_w[CH];
     __shared__ double sh_v[KTILE][CH];
     const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
@@ -149,12 +149,24 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
     Red<METHOD> red[KTILE];
     for (int c0 = seg0; c0 < seg1; c0 += CH) {
         __syncthreads();
-        for (int j = c0 + threadIdx.x; j < c0 + CH && j < seg1; j += AP_BLOCK) {
-            const int64_t col = indices[j];
-            sh_w[j - c0] = data[j];
+        {
+            constexpr int PER = CH / AP_BLOCK;
+            int col[PER];
 #pragma unroll
-            for (int kk = 0; kk < KTILE; kk++)
-                if (kk < kn) sh_v[kk][j - c0] = ld_src(src, (int64_t)kk * S + col);
+            for (int u = 0; u < PER; u++) {
+                const int j = c0 + u * AP_BLOCK + threadIdx.x;
+                col[u] = j < seg1 ? indices[j] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int j = c0 + u * AP_BLOCK + threadIdx.x;
+                if (col[u] >= 0) {
+                    sh_w[j - c0] = data[j];
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++)
+                        if (kk < kn) sh_v[kk][j - c0] = ld_src(src, (int64_t)kk * S + col[u]);
+                }
+            }
         }
         __syncthreads();
         const int a = s > c0 ? s : c0, b = e < c0 + CH ? e : c0 + CH;
@@ -166,6 +178,7 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
         }
     }
     if (t < T) {
+        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
 #pragma unroll
         for (int kk = 0; kk < KTILE; kk++) {
             if (kk < kn) {
@@ -174,7 +187,7 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
                     r = red[kk].fin();
                     if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
                 }
-                out[(k0 + kk) * T + t] = r;
+                out[(k0 + kk) * T + t_out] = r;
             }
         }
     }
@@ -248,7 +261,8 @@ __device__ void q_select_two(double *A, int k, int low, int high, double &lo, do
 template <int METHOD, typename SRC>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_workspace(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                  const double *__restrict__ data, int64_t T, int64_t S, int64_t nnz,
+                  const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
+                  int64_t nnz,
                   const SRC *__restrict__ source, int64_t k_base, double p, double *__restrict__ ws,
                   double *__restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
@@ -328,14 +342,15 @@ k_apply_workspace(const int32_t *__restrict__ indptr, const int32_t *__restrict_
             }
         }
     }
-    out[k * T + t] = res;
+    out[k * T + (row_order ? (int64_t)row_order[t] : t)] = res;
 }
 
 // mean partials for source-sharded multi-GPU: num = sum w v, den = sum w over non-NaN v
 template <typename SRC>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_partial_mean(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                     const double *__restrict__ data, int64_t T, int64_t S, const SRC *__restrict__ source,
+                     const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
+                     const SRC *__restrict__ source,
                      int64_t K, double *__restrict__ num, double *__restrict__ den) {
     const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
     if (t >= T) return;
@@ -351,11 +366,12 @@ k_apply_partial_mean(const int32_t *__restrict__ indptr, const int32_t *__restri
         for (int kk = 0; kk < KT; kk++)
             if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, 0.0);
     }
+    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
 #pragma unroll
     for (int kk = 0; kk < KT; kk++) {
         if (kk < kn) {
-            num[(k0 + kk) * T + t] = red[kk].vsum;
-            den[(k0 + kk) * T + t] = red[kk].wsum;
+            num[(k0 + kk) * T + t_out] = red[kk].vsum;
+            den[(k0 + kk) * T + t_out] = red[kk].wsum;
         }
     }
 }
@@ -375,16 +391,20 @@ __global__ void k_apply_coo(const int32_t *__restrict__ row, const int32_t *__re
     out[k * T + row[i]] = ld_src(source + k * S, col[i]);
 }
 
+static inline const int32_t *row_order_of(const xr_csr *csr) {
+    return csr->has_row_order ? csr->row_order.get() : nullptr;
+}
+
 template <int METHOD, typename SRC>
 static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *out) {
     if (K == 1) {
         dim3 grid(div_up(csr->n, AP_BLOCK), 1);
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), csr->n, csr->m, src, K, out);
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m, src, K, out);
     } else {
         dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, KT, 768>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), csr->n, csr->m, src, K, out);
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m, src, K, out);
     }
 }
 
@@ -400,7 +420,8 @@ static void launch_workspace(const xr_csr *csr, const SRC *src, int64_t K, doubl
         const int64_t kc = (K - k0) < kchunk ? (K - k0) : kchunk;
         dim3 grid(div_up(csr->n, AP_BLOCK), (unsigned)kc);
         XR_LAUNCH("apply_workspace", (k_apply_workspace<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), csr->n, csr->m, csr->nnz, src, k0, p, ws.get(), out);
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m, csr->nnz, src, k0, p,
+                  ws.get(), out);
     }
 }
 
@@ -445,6 +466,27 @@ __global__ void k_bincount(const int32_t *__restrict__ row, int64_t nnz, int32_t
     if (i < nnz) atomicAdd(&count[row[i]], 1);
 }
 
+// stored row r -> caller row row_order[r]
+__global__ void k_unpermute_len(const int32_t *__restrict__ indptr, const int32_t *__restrict__ row_order, int64_t n,
+                                int32_t *__restrict__ len) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < n) len[row_order[r]] = indptr[r + 1] - indptr[r];
+}
+// one wave per stored row
+__global__ void k_unpermute_rows(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                 const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t n,
+                                 const int32_t *__restrict__ c_indptr, int32_t *__restrict__ c_indices,
+                                 double *__restrict__ c_data) {
+    const int64_t r = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (r >= n) return;
+    const int s = indptr[r], e = indptr[r + 1], d = c_indptr[row_order[r]];
+    for (int j = s + lane; j < e; j += 64) {
+        c_indices[d + (j - s)] = indices[j];
+        c_data[d + (j - s)] = data[j];
+    }
+}
+
 static void upload_narrow(const int64_t *host, int64_t n, int32_t *dev) {
     if (n <= 0) return;
     DevBuf<int64_t> wide((size_t)n);
@@ -478,13 +520,34 @@ int xr_csr_info(const xr_csr *csr, int64_t *n, int64_t *m, int64_t *nnz) {
 int xr_csr_download(const xr_csr *csr, double *data, int64_t *indices, int64_t *indptr) {
     XR_API_BEGIN
     XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_download: NULL csr");
+    const int32_t *d_indptr = csr->indptr.get(), *d_indices = csr->indices.get();
+    const double *d_data = csr->data.get();
+    DevBuf<int32_t> c_indptr, c_indices;
+    DevBuf<double> c_data;
+    if (csr->has_row_order && csr->n > 0) {
+        // rows are stored in query order: rebuild the caller's row order on the device
+        DevBuf<int32_t> len((size_t)csr->n);
+        c_indptr.alloc((size_t)csr->n + 1);
+        c_indices.alloc((size_t)csr->nnz);
+        c_data.alloc((size_t)csr->nnz);
+        XR_LAUNCH("unpermute_len", k_unpermute_len, dim3(div_up(csr->n, 256)), dim3(256), 0, csr->indptr.get(),
+                  csr->row_order.get(), csr->n, len.get());
+        exclusive_scan_i32(len.get(), c_indptr.get(), csr->n);
+        XR_LAUNCH("unpermute_rows", k_unpermute_rows, dim3(div_up(csr->n * 64, 256)), dim3(256), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), csr->row_order.get(), csr->n, c_indptr.get(), c_indices.get(),
+                  c_data.get());
+        d_indptr = c_indptr.get();
+        d_indices = c_indices.get();
+        d_data = c_data.get();
+    }
     if (data && csr->nnz > 0) {
-        XR_HIP(hipMemcpyAsync(data, csr->data.get(), sizeof(double) * (size_t)csr->nnz, hipMemcpyDeviceToHost,
+        XR_HIP(hipMemcpyAsync(data, d_data, sizeof(double) * (size_t)csr->nnz, hipMemcpyDeviceToHost,
                               engine().stream));
         stream_sync();
     }
-    if (indices) download_widen(csr->indices.get(), csr->nnz, indices);
-    if (indptr) download_widen(csr->indptr.get(), csr->n + 1, indptr);
+    if (indices) download_widen(d_indices, csr->nnz, indices);
+    if (indptr) download_widen(d_indptr, csr->n + 1, indptr);
+    stream_sync();
     XR_API_END
 }
 
@@ -643,12 +706,12 @@ int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int sou
         double *num = numden_dev, *den = numden_dev + K * csr->n;
         if (source_dtype == XR_F64)
             XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<double>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                      csr->indices.get(), csr->data.get(), csr->n, csr->m, static_cast<const double *>(source_dev), K,
-                      num, den);
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                      static_cast<const double *>(source_dev), K, num, den);
         else
             XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<float>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                      csr->indices.get(), csr->data.get(), csr->n, csr->m, static_cast<const float *>(source_dev), K,
-                      num, den);
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                      static_cast<const float *>(source_dev), K, num, den);
     }
     stream_sync();
     XR_API_END

@@ -53,7 +53,10 @@ struct xr_csr {
     xr::DevBuf<int32_t> indptr;    // [n+1]
     xr::DevBuf<int32_t> indices;   // [nnz]
     xr::DevBuf<double> data;       // [nnz]
-    xr::DevBuf<int32_t> row_order; // [n] optional: spatially coherent processing order of the rows
+    // Rows may be STORED in a spatially coherent order instead of the caller's: stored row r is the
+    // caller's row row_order[r] (weights built by xr_overlap: the query mesh's query order).  The
+    // apply kernels scatter their outputs through it; xr_csr_download un-permutes.
+    xr::DevBuf<int32_t> row_order; // [n]
     bool has_row_order = false;
 };
 

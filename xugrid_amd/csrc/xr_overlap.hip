@@ -6,10 +6,10 @@
 // xugrid/core/sparse.py:61-78).
 //
 // Pipeline (all on the engine stream):
-//   search_count   one thread per query (target) face walks the tree mesh's hierarchical grid
-//                  and counts bbox-overlapping tree faces                    -> cand_count[T]
+//   search         one thread per query (target) face walks the tree mesh's hierarchical grid,
+//                  parks the bbox-overlapping tree records in a 16-slot row  -> cand_count[T]
 //   scan           exclusive prefix sum                                     -> cand_off[T+1]
-//   search_fill    same walk, writes the candidate-pair queue               -> cand_tgt/src[C]
+//   compact        slot rows -> dense candidate-pair queue                   -> cand_tgt/src[C]
 //   clip           one thread per candidate pair: Sutherland-Hodgman clip of the query polygon
 //                  by the tree polygon, polygon buffers staged in LDS ([vertex][thread] layout,
 //                  conflict-free 16-byte accesses), fan area                 -> cand_area[C]
@@ -39,62 +39,113 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
     return qx0 < b.y && b.x < qx1 && qy0 < b.w && b.z < qy1;
 }
 
-template <bool FILL>
+// One traversal per query face: hits are parked in a fixed-capacity slot row (SLOTS record ids,
+// one 64-byte line per face) and counted; after the scan of the counts a compaction kernel moves
+// them into the dense candidate queue.  Faces with more than SLOTS hits, too many grid rows or too
+// many visited records are "big" and go to the wave-per-face kernels instead.
+static constexpr int SLOTS = 16;
+
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const int32_t *__restrict__ cell_start,
-         const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face,
-         const int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt,
-         int32_t *__restrict__ cand_src, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
-         int32_t *__restrict__ n_big) {
+         const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ slots,
+         uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list, int32_t *__restrict__ n_big) {
+    __shared__ int32_t sh_slots[SLOTS][256]; // [slot][thread]: conflict-free, written out as whole lines
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_query) return;
-    if (FILL && is_big[t]) return;
-    const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
-    const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
-    const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
-    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-    int count = 0, visited = 0;
+    int count = 0;
     bool big = false;
-    int out = FILL ? cand_off[t] : 0;
-    if (!FILL) {
-        int n_rows = 0;
+    if (t < n_query) {
+        const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
+        const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
+        const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
+        const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+        int visited = 0, n_rows = 0;
         for (int l = 0; l < g.n_levels; l++) {
             const double h = level_h(g, l), inv_h = level_inv_h(g, l);
             n_rows += cell_coord(bb.w, g.y0, inv_h, g.ny[l]) - cell_coord(bb.z - h, g.y0, inv_h, g.ny[l]) + 1;
         }
         big = n_rows > 8 * g.n_levels + 8;
-    }
-    for (int l = 0; l < g.n_levels && !big; l++) {
-        const double h = level_h(g, l), inv_h = level_inv_h(g, l);
-        const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
-        const int cx0 = cell_coord(bb.x - h, g.x0, inv_h, nx), cx1 = cell_coord(bb.y, g.x0, inv_h, nx);
-        const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
-        for (int cy = cy0; cy <= cy1; cy++) {
-            const int r0 = cell_start[base + cy * nx + cx0];
-            const int r1 = cell_start[base + cy * nx + cx1 + 1];
-            if (!FILL) {
-                visited += r1 - r0;
-                if (visited > BIG_VISITS) {
-                    big = true;
-                    break;
+        for (int l = 0; l < g.n_levels && !big; l++) {
+            const double h = level_h(g, l), inv_h = level_inv_h(g, l);
+            const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
+            const int cx0 = cell_coord(bb.x - h, g.x0, inv_h, nx), cx1 = cell_coord(bb.y, g.x0, inv_h, nx);
+            const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
+            for (int cyb = cy0; cyb <= cy1 && !big; cyb += 4) {
+                // fetch the record runs of up to four grid rows before walking them
+                int r0[4], r1[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int cy = cyb + k <= cy1 ? cyb + k : cy1;
+                    r0[k] = cell_start[base + cy * nx + cx0];
+                    r1[k] = cyb + k <= cy1 ? cell_start[base + cy * nx + cx1 + 1] : r0[k];
                 }
-            }
-            for (int r = r0; r < r1; r++) {
-                if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
-                    if (FILL) {
-                        cand_tgt[out] = (int32_t)t;
-                        cand_src[out] = r;
-                        out++;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    visited += r1[k] - r0[k];
+                    if (visited > BIG_VISITS) big = true;
+                    if (!big) {
+                        for (int r = r0[k]; r < r1[k]; r += 4) {
+                            // four independent 16-byte loads in flight per step
+                            const int last = r1[k] - 1;
+                            const float4 b0 = rbb[r];
+                            const float4 b1 = rbb[r + 1 <= last ? r + 1 : last];
+                            const float4 b2 = rbb[r + 2 <= last ? r + 2 : last];
+                            const float4 b3 = rbb[r + 3 <= last ? r + 3 : last];
+                            if (rec_hit(b0, qx0, qx1, qy0, qy1)) {
+                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r;
+                                count++;
+                            }
+                            if (r + 1 <= last && rec_hit(b1, qx0, qx1, qy0, qy1)) {
+                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r + 1;
+                                count++;
+                            }
+                            if (r + 2 <= last && rec_hit(b2, qx0, qx1, qy0, qy1)) {
+                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r + 2;
+                                count++;
+                            }
+                            if (r + 3 <= last && rec_hit(b3, qx0, qx1, qy0, qy1)) {
+                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r + 3;
+                                count++;
+                            }
+                        }
                     }
-                    count++;
                 }
             }
         }
-    }
-    if (!FILL) {
+        if (count > SLOTS) big = true;
         is_big[t] = big ? 1 : 0;
         cand_count[t] = big ? 0 : count;
         if (big) big_list[atomicAdd(n_big, 1)] = (int32_t)t;
+    }
+    // every thread writes its own 64-byte slot row
+    if (t < n_query && !big && count > 0) {
+        int4 *row = reinterpret_cast<int4 *>(slots + t * SLOTS);
+#pragma unroll
+        for (int q = 0; q < SLOTS / 4; q++) {
+            if (q * 4 < count)
+                row[q] = make_int4(sh_slots[q * 4][threadIdx.x], sh_slots[q * 4 + 1][threadIdx.x],
+                                   sh_slots[q * 4 + 2][threadIdx.x], sh_slots[q * 4 + 3][threadIdx.x]);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_compact(const int32_t *__restrict__ slots, const int32_t *__restrict__ cand_off, const uint8_t *__restrict__ is_big,
+          int64_t n_query, int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_query || is_big[t]) return;
+    const int c0 = cand_off[t], n = cand_off[t + 1] - c0;
+    const int4 *row = reinterpret_cast<const int4 *>(slots + t * SLOTS);
+#pragma unroll
+    for (int q = 0; q < SLOTS / 4; q++) {
+        if (q * 4 < n) {
+            const int4 v = row[q];
+            const int k = q * 4;
+            cand_tgt[c0 + k] = (int32_t)t;
+            cand_src[c0 + k] = v.x;
+            if (k + 1 < n) { cand_tgt[c0 + k + 1] = (int32_t)t; cand_src[c0 + k + 1] = v.y; }
+            if (k + 2 < n) { cand_tgt[c0 + k + 2] = (int32_t)t; cand_src[c0 + k + 2] = v.z; }
+            if (k + 3 < n) { cand_tgt[c0 + k + 3] = (int32_t)t; cand_src[c0 + k + 3] = v.w; }
+        }
     }
 }
 
@@ -259,8 +310,8 @@ __global__ void __launch_bounds__(BLOCK)
 k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int q_m,
        const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy, const uint8_t *__restrict__ s_len,
        int s_m, const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
-       double *__restrict__ cand_area, bool redo_only, int32_t *__restrict__ overflow_count,
-       int32_t *__restrict__ nnz_row) {
+       double *__restrict__ cand_area, bool redo_only, const int32_t *__restrict__ rec_face,
+       int32_t *__restrict__ cand_sid, int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *sh = reinterpret_cast<double2 *>(smem);
     const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -270,6 +321,7 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int 
     if (active) {
     t = cand_tgt[c];
     const int s = cand_src[c];
+    cand_sid[c] = rec_face[s];
     const int nt = q_len[t], ns = s_len[s];
     double2 *out = sh + threadIdx.x;                // out[j * BLOCK]
     double2 *in = sh + MAXV * BLOCK + threadIdx.x;  // in[j * BLOCK]
@@ -369,7 +421,7 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int 
             unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
             run &= ~((1ull << lane) - 1);
             const int n = __popcll(surv & run);
-            if (n > 0) atomicAdd(&nnz_row[q_perm[t]], n);
+            if (n > 0) atomicAdd(&nnz_row[t], n);
         }
     }
 }
@@ -385,6 +437,7 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
              const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy,
              const uint8_t *__restrict__ s_len, int s_m, const int32_t *__restrict__ cand_tgt,
              const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area,
+             const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
              int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *out = reinterpret_cast<double2 *>(smem) + threadIdx.x; // out[j * BLOCK]
@@ -395,6 +448,7 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
     if (active) {
         t = cand_tgt[c];
         const int s = cand_src[c];
+        cand_sid[c] = rec_face[s];
         const int nt = q_len[t], ns = s_len[s];
         const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
         const double *sf = s_fxy + (int64_t)s * s_m * 2;
@@ -505,7 +559,7 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
             unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
             run &= ~((1ull << lane) - 1);
             const int n = __popcll(surv & run);
-            if (n > 0) atomicAdd(&nnz_row[q_perm[t]], n);
+            if (n > 0) atomicAdd(&nnz_row[t], n);
         }
     }
 }
@@ -522,61 +576,82 @@ __global__ void __launch_bounds__(256) k_row_count(const int32_t *__restrict__ c
     if (t >= n_query) return;
     int n = 0;
     for (int c = cand_off[t]; c < cand_off[t + 1]; c++) n += cand_area[c] > 0 ? 1 : 0;
-    nnz_row[q_perm[t]] = n;
+    nnz_row[t] = n;
 }
 
 static constexpr int ROW_SHORT = 48; // rows with more candidates go to the block-per-row kernel
 
-static constexpr int ROW_LDS = 4096; // candidate entries one block can stage in LDS
+static constexpr int ROW_LDS = 2560; // candidate entries one block can stage in LDS
 
-// One block = 256 consecutive query faces (query order); their candidate segment is contiguous
-// and is staged in LDS once (coalesced; record index -> caller's tree face id resolved while
-// staging), then every thread ranks the survivors of its own row from LDS and writes the CSR row
-// of the caller's face id q_perm[r].
+// One block = 256 consecutive query faces (query order).  Their candidate segment is contiguous:
+// it is staged in LDS once, coalesced (record index -> caller's tree face id resolved while
+// staging), then the block works ENTRY-parallel: each thread takes candidate entries, ranks a
+// survivor among the survivors of its row (entries of a row are adjacent in LDS) and writes it to
+// its final CSR position.  The block's output segment is contiguous as well.  Rows are stored in
+// QUERY order (row r belongs to the caller's face q_perm[r], xr_csr::row_order).
 __global__ void __launch_bounds__(256)
-k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
-           const double *__restrict__ cand_area, int64_t n_query, const int32_t *__restrict__ q_perm,
-           const int32_t *__restrict__ rec_face, const int32_t *__restrict__ indptr,
+k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_tgt,
+           const int32_t *__restrict__ cand_sid, const double *__restrict__ cand_area, int64_t n_query,
+           const int32_t *__restrict__ indptr,
            const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
            double *__restrict__ data, int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long) {
     __shared__ int32_t sh_src[ROW_LDS];
     __shared__ double sh_area[ROW_LDS];
+    __shared__ uint16_t sh_row[ROW_LDS];
+    __shared__ int32_t sh_off[257], sh_ptr[257];
     const int64_t t0 = (int64_t)blockIdx.x * 256;
     const int64_t t = t0 + threadIdx.x;
     const int64_t t_end = t0 + 256 < n_query ? t0 + 256 : n_query;
+    const int n_rows = (int)(t_end - t0);
     const int seg0 = cand_off[t0], seg1 = cand_off[t_end];
+    if (threadIdx.x <= n_rows) {
+        sh_off[threadIdx.x] = cand_off[t0 + threadIdx.x] - seg0;
+        sh_ptr[threadIdx.x] = indptr[t0 + threadIdx.x];
+    }
+    if (threadIdx.x == 0 && n_rows == 256) {
+        sh_off[256] = seg1 - seg0;
+        sh_ptr[256] = indptr[t_end];
+    }
     const bool staged = seg1 - seg0 <= ROW_LDS;
     if (staged) {
-        for (int j = seg0 + threadIdx.x; j < seg1; j += 256) {
-            sh_src[j - seg0] = rec_face[cand_src[j]];
-            sh_area[j - seg0] = cand_area[j];
+#pragma unroll
+        for (int k = 0; k < ROW_LDS / 256; k++) {
+            const int j = seg0 + k * 256 + threadIdx.x;
+            if (j < seg1) {
+                sh_src[j - seg0] = cand_sid[j];
+                sh_area[j - seg0] = cand_area[j];
+                sh_row[j - seg0] = (uint16_t)(cand_tgt[j] - t0);
+            }
         }
     }
     __syncthreads();
-    if (t >= n_query) return;
-    const int c0 = cand_off[t], c1 = cand_off[t + 1];
-    if (c1 - c0 > ROW_SHORT) {
+    // rows with many candidates are ranked by the block-per-row kernel
+    if (t < n_query && sh_off[threadIdx.x + 1] - sh_off[threadIdx.x] > ROW_SHORT)
         long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
-        return;
-    }
-    const int base = indptr[q_perm[t]];
     if (staged) {
-        for (int i = c0 - seg0; i < c1 - seg0; i++) {
-            const double a = sh_area[i];
+        for (int j = threadIdx.x; j < seg1 - seg0; j += 256) {
+            const double a = sh_area[j];
             if (!(a > 0)) continue;
-            const int s = sh_src[i];
+            const int row = sh_row[j];
+            const int c0 = sh_off[row], c1 = sh_off[row + 1];
+            if (c1 - c0 > ROW_SHORT) continue;
+            const int s = sh_src[j];
             int rank = 0;
-            for (int j = c0 - seg0; j < c1 - seg0; j++) rank += (sh_area[j] > 0 && sh_src[j] < s) ? 1 : 0;
-            indices[base + rank] = s;
-            data[base + rank] = relative ? a / src_area[s] : a;
+            for (int i = c0; i < c1; i++) rank += (sh_area[i] > 0 && sh_src[i] < s) ? 1 : 0;
+            const int pos = sh_ptr[row] + rank;
+            indices[pos] = s;
+            data[pos] = relative ? a / src_area[s] : a;
         }
-    } else {
+    } else if (t < n_query) {
+        const int c0 = cand_off[t], c1 = cand_off[t + 1];
+        if (c1 - c0 > ROW_SHORT) return;
+        const int base = indptr[t];
         for (int i = c0; i < c1; i++) {
             const double a = cand_area[i];
             if (!(a > 0)) continue;
-            const int s = rec_face[cand_src[i]];
+            const int s = cand_sid[i];
             int rank = 0;
-            for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && rec_face[cand_src[j]] < s) ? 1 : 0;
+            for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && cand_sid[j] < s) ? 1 : 0;
             indices[base + rank] = s;
             data[base + rank] = relative ? a / src_area[s] : a;
         }
@@ -592,9 +667,8 @@ static constexpr int BM_BITS = BM_WORDS * 32;   // ids per chunk
 static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread
 
 __global__ void __launch_bounds__(256)
-k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_src,
-                const double *__restrict__ cand_area, const int32_t *__restrict__ q_perm,
-                const int32_t *__restrict__ rec_face, const int32_t *__restrict__ indptr,
+k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_sid,
+                const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
                 const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
                 const int32_t *__restrict__ n_long) {
@@ -608,12 +682,12 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
         const int c0 = cand_off[t], c1 = cand_off[t + 1];
-        const int base = indptr[q_perm[t]];
+        const int base = indptr[t];
         // id range of the survivors
         int lo = 0x7fffffff, hi = -1;
         for (int i = c0 + tid; i < c1; i += 256) {
             if (cand_area[i] > 0) {
-                const int s = rec_face[cand_src[i]];
+                const int s = cand_sid[i];
                 lo = min(lo, s);
                 hi = max(hi, s);
             }
@@ -638,7 +712,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 __syncthreads();
                 for (int i = c0 + tid; i < c1; i += 256) {
                     if (cand_area[i] > 0) {
-                        const int s = rec_face[cand_src[i]] - cb;
+                        const int s = cand_sid[i] - cb;
                         if (s >= 0 && s < BM_BITS) atomicOr(&bm[s >> 5], 1u << (s & 31));
                     }
                 }
@@ -668,7 +742,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 for (int i = c0 + tid; i < c1; i += 256) {
                     const double a = cand_area[i];
                     if (a > 0) {
-                        const int sid = rec_face[cand_src[i]];
+                        const int sid = cand_sid[i];
                         const int s = sid - cb;
                         if (s >= 0 && s < BM_BITS) {
                             const int w = s >> 5;
@@ -688,7 +762,8 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
 
 template <int MAXV, int BLOCK>
 static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
-                        int64_t C, double *cand_area, bool redo_only, int32_t *overflow_count, int32_t *nnz_row) {
+                        int64_t C, double *cand_area, bool redo_only, int32_t *cand_sid, int32_t *overflow_count,
+                        int32_t *nnz_row) {
     const size_t shmem = (size_t)2 * MAXV * BLOCK * sizeof(double2);
     static bool attr_set = false;
     if (!attr_set) {
@@ -699,21 +774,23 @@ static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t
     XR_LAUNCH(MAXV == 8 ? "clip_v8" : (MAXV == 16 ? "clip_v16" : "clip_v64"), (k_clip<MAXV, BLOCK>),
               dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->q_fxy.get(), query->q_len.get(), query->m,
               query->q_perm.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area,
-              redo_only, overflow_count, nnz_row);
+              redo_only, tree->rec_face.get(), cand_sid, overflow_count, nnz_row);
 }
 
 static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
-                            int64_t C, double *cand_area, int32_t *overflow_count, int32_t *nnz_row) {
+                            int64_t C, double *cand_area, int32_t *cand_sid, int32_t *overflow_count,
+                            int32_t *nnz_row) {
     const int vmax = query->m + tree->m;
     if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)MAXV * BLOCK * sizeof(double2);
         XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
                   query->q_fxy.get(), query->q_len.get(), query->m, query->q_perm.get(), tree->rec_fxy.get(),
-                  tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, overflow_count, nnz_row);
+                  tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
+                  overflow_count, nnz_row);
     }
-    else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
-    else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, overflow_count, nnz_row);
+    else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
+    else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
 }
 
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
@@ -743,9 +820,9 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
     DevBuf<uint8_t> is_big((size_t)T);
     const int big_grid = engine().num_cu * 2;
-    XR_LAUNCH("search_count", k_search<false>, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), (const int32_t *)nullptr,
-              cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr, is_big.get(), big_list.get(),
+    DevBuf<int32_t> slots((size_t)T * SLOTS);
+    XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
+              tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), slots.get(), is_big.get(), big_list.get(),
               counters.get() + 2);
     XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->q_bbox.get(),
               query->q_fxy.get(), query->q_len.get(), query->m, g, tree->cell_start.get(),
@@ -756,20 +833,19 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     XR_REQUIRE(C32 >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
     const int64_t C = C32;
     tree->last_candidates = C;
-    DevBuf<int32_t> cand_tgt((size_t)C), cand_src((size_t)C), nnz_row((size_t)T);
+    DevBuf<int32_t> cand_tgt((size_t)C), cand_src((size_t)C), cand_sid((size_t)C), nnz_row((size_t)T);
     DevBuf<double> cand_area((size_t)C);
     XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
     if (C > 0) {
-        XR_LAUNCH("search_fill", k_search<true>, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
-                  tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(), cand_off.get(),
-                  (int32_t *)nullptr, cand_tgt.get(), cand_src.get(), is_big.get(), (int32_t *)nullptr,
-                  (int32_t *)nullptr);
+        XR_LAUNCH("compact", k_compact, dim3(div_up(T, 256)), dim3(256), 0, slots.get(), cand_off.get(), is_big.get(),
+                  T, cand_tgt.get(), cand_src.get());
         XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->q_bbox.get(),
                   query->q_fxy.get(), query->q_len.get(), query->m, g, tree->cell_start.get(),
                   tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
                   (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
         // --- clip (+ per-row survivor counts)
-        launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), counters.get(), nnz_row.get());
+        launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), cand_sid.get(), counters.get(),
+                        nnz_row.get());
     }
     // --- rows
     exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
@@ -782,8 +858,8 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         // redo those pairs with the oracle's buffer size, then recount every row.
         XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t), st));
         XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
-        launch_clip<64, 64>(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), true, counters.get(),
-                            nnz_row.get());
+        launch_clip<64, 64>(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), true, cand_sid.get(),
+                            counters.get(), nnz_row.get());
         XR_LAUNCH("row_recount", k_row_count, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_area.get(), T,
                   query->q_perm.get(), nnz_row.get());
         exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
@@ -801,9 +877,9 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     csr->has_row_order = true;
     if (P > 0) {
         DevBuf<int32_t> long_rows((size_t)T);
-        XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_src.get(),
-                  cand_area.get(), T, query->q_perm.get(), tree->rec_face.get(), csr->indptr.get(), tree->area.get(),
-                  relative, csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
+        XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_tgt.get(),
+                  cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
+                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
         const size_t shmem = sizeof(uint32_t) * (2 * BM_WORDS + 256) + sizeof(int32_t) * 8;
         static bool attr_set = false;
         if (!attr_set) {
@@ -812,9 +888,8 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
             attr_set = true;
         }
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
-                  cand_src.get(), cand_area.get(), query->q_perm.get(), tree->rec_face.get(), csr->indptr.get(),
-                  tree->area.get(), relative, csr->indices.get(), csr->data.get(), long_rows.get(),
-                  counters.get() + 1);
+                  cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative,
+                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
     }
 }
 
