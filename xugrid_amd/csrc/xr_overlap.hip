@@ -579,79 +579,93 @@ __global__ void __launch_bounds__(256) k_row_count(const int32_t *__restrict__ c
     nnz_row[t] = n;
 }
 
-static constexpr int ROW_SHORT = 48; // rows with more candidates go to the block-per-row kernel
+static constexpr int ROW_SHORT = 24; // rows with more candidates go to the block-per-row kernel
 
-static constexpr int ROW_LDS = 2560; // candidate entries one block can stage in LDS
+static constexpr int ROW_LDS = 3072; // short-row candidate entries one block can stage in LDS
 
-// One block = 256 consecutive query faces (query order).  Their candidate segment is contiguous:
-// it is staged in LDS once, coalesced (record index -> caller's tree face id resolved while
-// staging), then the block works ENTRY-parallel: each thread takes candidate entries, ranks a
-// survivor among the survivors of its row (entries of a row are adjacent in LDS) and writes it to
-// its final CSR position.  The block's output segment is contiguous as well.  Rows are stored in
-// QUERY order (row r belongs to the caller's face q_perm[r], xr_csr::row_order).
+// One block = 256 consecutive query faces (query order).  The candidate entries of the block's
+// SHORT rows (<= ROW_SHORT candidates; long rows go to k_row_fill_long) are packed into LDS -- the
+// block's candidate segment is contiguous, so the loads are coalesced -- then the block works
+// ENTRY-parallel: each thread takes entries, ranks a survivor among the survivors of its row
+// (adjacent in LDS) and writes it to its final CSR position.  Rows are stored in QUERY order
+// (row r belongs to the caller's face q_perm[r], xr_csr::row_order).
 __global__ void __launch_bounds__(256)
 k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_tgt,
            const int32_t *__restrict__ cand_sid, const double *__restrict__ cand_area, int64_t n_query,
-           const int32_t *__restrict__ indptr,
-           const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
-           double *__restrict__ data, int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long) {
+           const int32_t *__restrict__ indptr, const double *__restrict__ src_area, bool relative,
+           int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ long_rows,
+           int32_t *__restrict__ n_long) {
     __shared__ int32_t sh_src[ROW_LDS];
     __shared__ double sh_area[ROW_LDS];
     __shared__ uint16_t sh_row[ROW_LDS];
-    __shared__ int32_t sh_off[257], sh_ptr[257];
+    __shared__ int32_t sh_c0[256];   // first candidate of the row (global index)
+    __shared__ int32_t sh_lds[257];  // LDS offset of the row (short rows only), [256] = total
+    __shared__ int32_t sh_ptr[256];  // CSR offset of the row
+    __shared__ int32_t sh_wave[4];
     const int64_t t0 = (int64_t)blockIdx.x * 256;
     const int64_t t = t0 + threadIdx.x;
     const int64_t t_end = t0 + 256 < n_query ? t0 + 256 : n_query;
-    const int n_rows = (int)(t_end - t0);
     const int seg0 = cand_off[t0], seg1 = cand_off[t_end];
-    if (threadIdx.x <= n_rows) {
-        sh_off[threadIdx.x] = cand_off[t0 + threadIdx.x] - seg0;
-        sh_ptr[threadIdx.x] = indptr[t0 + threadIdx.x];
+    int c0 = 0, len = 0;
+    if (t < n_query) {
+        c0 = cand_off[t];
+        len = cand_off[t + 1] - c0;
+        sh_ptr[threadIdx.x] = indptr[t];
+        if (len > ROW_SHORT) long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
     }
-    if (threadIdx.x == 0 && n_rows == 256) {
-        sh_off[256] = seg1 - seg0;
-        sh_ptr[256] = indptr[t_end];
-    }
-    const bool staged = seg1 - seg0 <= ROW_LDS;
-    if (staged) {
+    const int slen = len > ROW_SHORT ? 0 : len;
+    sh_c0[threadIdx.x] = len > ROW_SHORT ? -1 : c0;
+    // block exclusive scan of the short-row lengths
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = slen;
 #pragma unroll
-        for (int k = 0; k < ROW_LDS / 256; k++) {
-            const int j = seg0 + k * 256 + threadIdx.x;
-            if (j < seg1) {
-                sh_src[j - seg0] = cand_sid[j];
-                sh_area[j - seg0] = cand_area[j];
-                sh_row[j - seg0] = (uint16_t)(cand_tgt[j] - t0);
-            }
-        }
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
     }
+    if (lane == 63) sh_wave[wave] = incl;
     __syncthreads();
-    // rows with many candidates are ranked by the block-per-row kernel
-    if (t < n_query && sh_off[threadIdx.x + 1] - sh_off[threadIdx.x] > ROW_SHORT)
-        long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
-    if (staged) {
-        for (int j = threadIdx.x; j < seg1 - seg0; j += 256) {
-            const double a = sh_area[j];
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) woff += sh_wave[w];
+        total += sh_wave[w];
+    }
+    sh_lds[threadIdx.x] = woff + incl - slen;
+    if (threadIdx.x == 0) sh_lds[256] = total;
+    __syncthreads();
+    if (total <= ROW_LDS) {
+        for (int j = seg0 + threadIdx.x; j < seg1; j += 256) {
+            const int row = cand_tgt[j] - (int)t0;
+            const int rc0 = sh_c0[row];
+            if (rc0 < 0) continue; // entry of a long row
+            const int k = sh_lds[row] + (j - rc0);
+            sh_src[k] = cand_sid[j];
+            sh_area[k] = cand_area[j];
+            sh_row[k] = (uint16_t)row;
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < total; k += 256) {
+            const double a = sh_area[k];
             if (!(a > 0)) continue;
-            const int row = sh_row[j];
-            const int c0 = sh_off[row], c1 = sh_off[row + 1];
-            if (c1 - c0 > ROW_SHORT) continue;
-            const int s = sh_src[j];
+            const int row = sh_row[k];
+            const int a0 = sh_lds[row], a1 = row == 255 ? total : sh_lds[row + 1];
+            const int s = sh_src[k];
             int rank = 0;
-            for (int i = c0; i < c1; i++) rank += (sh_area[i] > 0 && sh_src[i] < s) ? 1 : 0;
+            for (int i = a0; i < a1; i++) rank += (sh_area[i] > 0 && sh_src[i] < s) ? 1 : 0;
             const int pos = sh_ptr[row] + rank;
             indices[pos] = s;
             data[pos] = relative ? a / src_area[s] : a;
         }
-    } else if (t < n_query) {
-        const int c0 = cand_off[t], c1 = cand_off[t + 1];
-        if (c1 - c0 > ROW_SHORT) return;
+    } else if (t < n_query && len <= ROW_SHORT) {
+        // cannot happen with ROW_LDS >= 256 * ROW_SHORT; kept as a safe slow path
         const int base = indptr[t];
-        for (int i = c0; i < c1; i++) {
+        for (int i = c0; i < c0 + len; i++) {
             const double a = cand_area[i];
             if (!(a > 0)) continue;
             const int s = cand_sid[i];
             int rank = 0;
-            for (int j = c0; j < c1; j++) rank += (cand_area[j] > 0 && cand_sid[j] < s) ? 1 : 0;
+            for (int j = c0; j < c0 + len; j++) rank += (cand_area[j] > 0 && cand_sid[j] < s) ? 1 : 0;
             indices[base + rank] = s;
             data[base + rank] = relative ? a / src_area[s] : a;
         }
