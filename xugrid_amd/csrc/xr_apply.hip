@@ -25,90 +25,177 @@ template <typename SRC> __device__ __forceinline__ double ld_src(const SRC *p, i
 // ---------------------------------------------------------------------------------------------
 // streaming reducers: constant-size state per (row, k), one pass over the row
 // ---------------------------------------------------------------------------------------------
+// State = up to three doubles (a, b, c) so that partial states can be shuffled between lanes and
+// merged (long rows are reduced by a whole block, see k_apply_long).
 template <int METHOD> struct Red;
 
-template <> struct Red<XR_MEAN> { // reduce.py:16-27
-    double vsum = 0.0, wsum = 0.0;
+template <> struct Red<XR_MEAN> { // reduce.py:16-27   a = sum w v, b = sum w
+    double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v) return;
-        vsum += w * v;
-        wsum += w;
+        a += w * v;
+        b += w;
     }
-    __device__ double fin() const { return wsum == 0 ? NAN : vsum / wsum; }
+    __device__ void merge(const Red &o) { a += o.a; b += o.b; }
+    __device__ double fin() const { return b == 0 ? NAN : a / b; }
 };
-template <> struct Red<XR_HARMONIC_MEAN> { // reduce.py:30-42
-    double v_agg = 0.0, w_sum = 0.0;
+template <> struct Red<XR_HARMONIC_MEAN> { // reduce.py:30-42   a = sum w / v, b = sum w
+    double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v || v == 0) return;
         if (w > 0) {
-            w_sum += w;
-            v_agg += w / v;
+            b += w;
+            a += w / v;
         }
     }
-    __device__ double fin() const { return (v_agg == 0 || w_sum == 0) ? NAN : w_sum / v_agg; }
+    __device__ void merge(const Red &o) { a += o.a; b += o.b; }
+    __device__ double fin() const { return (a == 0 || b == 0) ? NAN : b / a; }
 };
 template <> struct Red<XR_GEOMETRIC_MEAN> { // reduce.py:45-72; normsum = sum of ALL row weights
-    double v_agg = 0.0, w_sum = 0.0;
-    bool neg = false;
+    double a = 0.0, b = 0.0, c = 0.0;        // a = sum wn ln v, b = sum wn, c = 1 if a negative value was seen
     __device__ void add(double v, double w, double normsum) {
-        if (neg) return;
+        if (c != 0.0) return;
         const double wn = w / normsum;
         if (v > 0 && wn > 0) {
-            v_agg += wn * log(fabs(v));
-            w_sum += wn;
+            a += wn * log(fabs(v));
+            b += wn;
         } else if (v < 0) {
-            neg = true;
+            c = 1.0;
         }
     }
-    __device__ double fin() const { return (neg || w_sum == 0) ? NAN : exp((1.0 / w_sum) * v_agg); }
+    __device__ void merge(const Red &o) { a += o.a; b += o.b; if (o.c != 0.0) c = 1.0; }
+    __device__ double fin() const { return (c != 0.0 || b == 0) ? NAN : exp((1.0 / b) * a); }
 };
-template <> struct Red<XR_SUM> { // reduce.py:75-87
-    double v_sum = 0.0, w_sum = 0.0;
+template <> struct Red<XR_SUM> { // reduce.py:75-87   a = sum v, b = sum w
+    double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v) return;
-        v_sum += v;
-        w_sum += w;
+        a += v;
+        b += w;
     }
-    __device__ double fin() const { return w_sum == 0 ? NAN : v_sum; }
+    __device__ void merge(const Red &o) { a += o.a; b += o.b; }
+    __device__ double fin() const { return b == 0 ? NAN : a; }
 };
-template <> struct Red<XR_MINIMUM> { // reduce.py:90-106
-    double v_min = INFINITY, w_max = 0.0;
+template <> struct Red<XR_MINIMUM> { // reduce.py:90-106   a = min v, b = max w
+    double a = INFINITY, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v) return;
-        if (v < v_min) v_min = v;
-        if (w > w_max) w_max = w;
+        if (v < a) a = v;
+        if (w > b) b = w;
     }
-    __device__ double fin() const { return w_max == 0.0 ? NAN : v_min; }
+    __device__ void merge(const Red &o) { if (o.a < a) a = o.a; if (o.b > b) b = o.b; }
+    __device__ double fin() const { return b == 0.0 ? NAN : a; }
 };
-template <> struct Red<XR_MAXIMUM> { // reduce.py:109-123
-    double v_max = -INFINITY, w_max = 0.0;
+template <> struct Red<XR_MAXIMUM> { // reduce.py:109-123   a = max v, b = max w
+    double a = -INFINITY, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v) return;
-        if (v > v_max) v_max = v;
-        if (w > w_max) w_max = w;
+        if (v > a) a = v;
+        if (w > b) b = w;
     }
-    __device__ double fin() const { return w_max == 0.0 ? NAN : v_max; }
+    __device__ void merge(const Red &o) { if (o.a > a) a = o.a; if (o.b > b) b = o.b; }
+    __device__ double fin() const { return b == 0.0 ? NAN : a; }
 };
-template <> struct Red<XR_FIRST_ORDER_CONSERVATIVE> { // reduce.py:206-222
-    double v_agg = 0.0, w_sum = 0.0;
+template <> struct Red<XR_FIRST_ORDER_CONSERVATIVE> { // reduce.py:206-222   a = sum v w, b = sum w
+    double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v) return;
-        v_agg += v * w;
-        w_sum += w;
+        a += v * w;
+        b += w;
     }
-    __device__ double fin() const { return w_sum == 0 ? NAN : v_agg; }
+    __device__ void merge(const Red &o) { a += o.a; b += o.b; }
+    __device__ double fin() const { return b == 0 ? NAN : a; }
 };
-template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238
-    double w_max = 0.0, v_max = -INFINITY;
+template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238   a = value of the largest weight b
+    double a = -INFINITY, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
         if (v != v) return;
-        if ((w > w_max) || (w == w_max && v > v_max)) {
-            w_max = w;
-            v_max = v;
+        if ((w > b) || (w == b && v > a)) {
+            b = w;
+            a = v;
         }
     }
-    __device__ double fin() const { return w_max == 0.0 ? NAN : v_max; }
+    __device__ void merge(const Red &o) {
+        if ((o.b > b) || (o.b == b && o.a > a)) {
+            b = o.b;
+            a = o.a;
+        }
+    }
+    __device__ double fin() const { return b == 0.0 ? NAN : a; }
 };
+
+// Rows longer than APPLY_LONG entries are not reduced by one thread (a coarse target cell over a
+// fine source has thousands of entries) but by a whole block: strided per-thread partial states,
+// merged in a fixed butterfly order -> deterministic, but the summation order differs from the
+// reference's sequential loop (agreement ~1e-15 relative instead of bit-exact).
+static constexpr int APPLY_LONG = XR_APPLY_LONG_ROW;
+
+template <int METHOD> __device__ __forceinline__ void block_merge(Red<METHOD> &r, double (*lds)[3]) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        Red<METHOD> o;
+        o.a = __shfl_xor(r.a, d, 64);
+        o.b = __shfl_xor(r.b, d, 64);
+        o.c = __shfl_xor(r.c, d, 64);
+        // merge in a lane-independent order so that every lane holds the same value
+        if ((threadIdx.x & d) == 0) {
+            r.merge(o);
+        } else {
+            o.merge(r);
+            r = o;
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        lds[wave][0] = r.a;
+        lds[wave][1] = r.b;
+        lds[wave][2] = r.c;
+    }
+    __syncthreads();
+    Red<METHOD> t;
+    t.a = lds[0][0]; t.b = lds[0][1]; t.c = lds[0][2];
+#pragma unroll
+    for (int w = 1; w < AP_BLOCK / 64; w++) {
+        Red<METHOD> o;
+        o.a = lds[w][0]; o.b = lds[w][1]; o.c = lds[w][2];
+        t.merge(o);
+    }
+    r = t;
+}
+
+template <int METHOD, typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_long(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+             const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+             const int32_t *__restrict__ n_long, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+             double *__restrict__ out) {
+    __shared__ double lds[AP_BLOCK / 64][3];
+    const int nl = *n_long;
+    for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+        const int t = long_rows[li];
+        const int s = indptr[t], e = indptr[t + 1];
+        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+        double normsum = 0.0;
+        if (METHOD == XR_GEOMETRIC_MEAN) {
+            Red<XR_SUM> ws; // b accumulates the weights
+            for (int j = s + threadIdx.x; j < e; j += AP_BLOCK) ws.b += data[j];
+            block_merge<XR_SUM>(ws, lds);
+            normsum = ws.b;
+        }
+        for (int64_t k = blockIdx.y; k < K; k += gridDim.y) {
+            const SRC *src = source + k * S;
+            Red<METHOD> r;
+            for (int j = s + threadIdx.x; j < e; j += AP_BLOCK) r.add(ld_src(src, indices[j]), data[j], normsum);
+            block_merge<METHOD>(r, lds);
+            if (threadIdx.x == 0) {
+                double v = r.fin();
+                if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) v = NAN;
+                out[k * T + t_out] = v;
+            }
+        }
+    }
+}
 
 // One block = AP_BLOCK consecutive rows.  The block's CSR segment [indptr[row0], indptr[row0+B)) is
 // contiguous: it is streamed through LDS in chunks of CH entries -- column index and weight are
@@ -120,8 +207,8 @@ template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238
 template <int METHOD, typename SRC, int KTILE, int CH>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-               const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
-               const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
+               const double *__restrict__ data, const int32_t *__restrict__ row_order, bool skip_long, int64_t T,
+               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
     __shared__ double sh_w[CH];
     __shared__ double sh_v[KTILE][CH];
     const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
@@ -135,6 +222,8 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
         s = indptr[t];
         e = indptr[t + 1];
     }
+    const bool is_long = skip_long && (e - s > APPLY_LONG); // reduced by k_apply_long instead
+    if (is_long) e = s;
     const SRC *src = source + k0 * S;
     double normsum = 0.0;
     if (METHOD == XR_GEOMETRIC_MEAN) {
@@ -177,7 +266,7 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
                 if (kk < kn) red[kk].add(sh_v[kk][j - c0], w, normsum);
         }
     }
-    if (t < T) {
+    if (t < T && !is_long) {
         const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
 #pragma unroll
         for (int kk = 0; kk < KTILE; kk++) {
@@ -370,8 +459,8 @@ k_apply_partial_mean(const int32_t *__restrict__ indptr, const int32_t *__restri
 #pragma unroll
     for (int kk = 0; kk < KT; kk++) {
         if (kk < kn) {
-            num[(k0 + kk) * T + t_out] = red[kk].vsum;
-            den[(k0 + kk) * T + t_out] = red[kk].wsum;
+            num[(k0 + kk) * T + t_out] = red[kk].a;
+            den[(k0 + kk) * T + t_out] = red[kk].b;
         }
     }
 }
@@ -400,11 +489,17 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
     if (K == 1) {
         dim3 grid(div_up(csr->n, AP_BLOCK), 1);
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m, src, K, out);
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
     } else {
         dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, KT, 768>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m, src, K, out);
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
+    }
+    if (csr->has_long) {
+        dim3 grid((unsigned)engine().num_cu, (unsigned)(K < 8 ? K : 8));
+        XR_LAUNCH("apply_long", (k_apply_long<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                  csr->n, csr->m, src, K, out);
     }
 }
 
@@ -485,6 +580,16 @@ __global__ void k_unpermute_rows(const int32_t *__restrict__ indptr, const int32
         c_indices[d + (j - s)] = indices[j];
         c_data[d + (j - s)] = data[j];
     }
+}
+
+static void set_long_rows(xr_csr *csr, const std::vector<int32_t> &longs) {
+    csr->has_long = !longs.empty();
+    if (!csr->has_long) return;
+    const int32_t count = (int32_t)longs.size();
+    csr->long_rows.alloc(longs.size());
+    csr->n_long.alloc(1);
+    h2d(csr->long_rows.get(), longs.data(), sizeof(int32_t) * longs.size());
+    h2d(csr->n_long.get(), &count, sizeof(int32_t));
 }
 
 static void upload_narrow(const int64_t *host, int64_t n, int32_t *dev) {
@@ -574,6 +679,10 @@ int xr_csr_upload(const double *data, const int64_t *indices, const int64_t *ind
         upload_narrow(indptr, n + 1, csr->indptr.get());
         upload_narrow(indices, nnz, csr->indices.get());
         h2d(csr->data.get(), data, sizeof(double) * (size_t)nnz);
+        std::vector<int32_t> longs;
+        for (int64_t i = 0; i < n; i++)
+            if (indptr[i + 1] - indptr[i] > APPLY_LONG) longs.push_back((int32_t)i);
+        set_long_rows(csr, longs);
         stream_sync();
     } catch (...) {
         delete csr;
@@ -610,6 +719,12 @@ int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *da
         XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)(n > 0 ? n : 1), engine().stream));
         if (nnz > 0) XR_LAUNCH("bincount", k_bincount, dim3(div_up(nnz, 256)), dim3(256), 0, row32.get(), nnz, count.get());
         exclusive_scan_i32(count.get(), csr->indptr.get(), n);
+        std::vector<int32_t> longs;
+        for (int64_t i = 0, j = 0; i < nnz; i = j) { // rows are sorted: run lengths
+            while (j < nnz && row[j] == row[i]) j++;
+            if (j - i > APPLY_LONG) longs.push_back((int32_t)row[i]);
+        }
+        set_long_rows(csr, longs);
         stream_sync();
     } catch (...) {
         delete csr;

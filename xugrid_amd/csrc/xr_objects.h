@@ -47,6 +47,9 @@ struct xr_mesh {
     int64_t last_candidates = 0;
 };
 
+// rows with more entries than this are reduced by a whole block in the apply kernels
+static constexpr int XR_APPLY_LONG_ROW = 256;
+
 // Device-resident MatrixCSR (xugrid/core/sparse.py:81-137), int32 structure + float64 data.
 struct xr_csr {
     int64_t n = 0, m = 0, nnz = 0;
@@ -58,6 +61,10 @@ struct xr_csr {
     // apply kernels scatter their outputs through it; xr_csr_download un-permutes.
     xr::DevBuf<int32_t> row_order; // [n]
     bool has_row_order = false;
+    // stored rows with more than APPLY_LONG entries (reduced by one block each in the apply)
+    xr::DevBuf<int32_t> long_rows; // [<= n]
+    xr::DevBuf<int32_t> n_long;    // [1] device-side count
+    bool has_long = false;
 };
 
 namespace xr {

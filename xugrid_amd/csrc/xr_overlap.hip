@@ -33,7 +33,7 @@ namespace xr {
 // A query face is "big" when its bbox spans many grid rows or many records (hull slivers of a
 // Delaunay mesh, coarse target cells over a fine source): one thread would serialise thousands
 // of tests, so those faces are queued and handled by one wave each (k_search_big).
-static constexpr int BIG_VISITS = 768; // records visited by one thread before it gives up
+static constexpr int BIG_VISITS = 160; // records visited by one thread before it gives up
 
 __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy0, float qy1) {
     return qx0 < b.y && b.x < qx1 && qy0 < b.w && b.z < qy1;
@@ -594,7 +594,8 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
            const int32_t *__restrict__ cand_sid, const double *__restrict__ cand_area, int64_t n_query,
            const int32_t *__restrict__ indptr, const double *__restrict__ src_area, bool relative,
            int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ long_rows,
-           int32_t *__restrict__ n_long) {
+           int32_t *__restrict__ n_long, int32_t *__restrict__ apply_long_rows,
+           int32_t *__restrict__ n_apply_long) {
     __shared__ int32_t sh_src[ROW_LDS];
     __shared__ double sh_area[ROW_LDS];
     __shared__ uint16_t sh_row[ROW_LDS];
@@ -612,6 +613,7 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
         len = cand_off[t + 1] - c0;
         sh_ptr[threadIdx.x] = indptr[t];
         if (len > ROW_SHORT) long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
+        if (indptr[t + 1] - indptr[t] > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(n_apply_long, 1)] = (int32_t)t;
     }
     const int slen = len > ROW_SHORT ? 0 : len;
     sh_c0[threadIdx.x] = len > ROW_SHORT ? -1 : c0;
@@ -891,9 +893,14 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     csr->has_row_order = true;
     if (P > 0) {
         DevBuf<int32_t> long_rows((size_t)T);
+        csr->long_rows.alloc((size_t)(P / XR_APPLY_LONG_ROW + 1));
+        csr->n_long.alloc(1);
+        csr->has_long = true;
+        XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), st));
         XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_tgt.get(),
                   cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
-                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
+                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, csr->long_rows.get(),
+                  csr->n_long.get());
         const size_t shmem = sizeof(uint32_t) * (2 * BM_WORDS + 256) + sizeof(int32_t) * 8;
         static bool attr_set = false;
         if (!attr_set) {
