@@ -480,22 +480,23 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
                     const P2 V{b.x - a.x, b.y - a.y};
                     if (!(V.x == 0 && V.y == 0)) {
                         bool b_inside = sh_inside(b, r, U);
+                        // one intersection per boundary crossing, computed in ONE place for both
+                        // crossing directions (same operands and arithmetic as the two S-H branches)
+                        P2 pt{0.0, 0.0};
+                        bool have_pt = false;
+                        if (b_inside != a_inside) have_pt = sh_intersection(a, V, r, N, pt);
                         if (b_inside) {
-                            if (!a_inside) {
-                                P2 pt;
-                                if (sh_intersection(a, V, r, N, pt)) {
-                                    if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
-                                    else overflow = true;
-                                    n_output++;
-                                }
+                            if (have_pt) {
+                                if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
+                                else overflow = true;
+                                n_output++;
                             }
                             if (n_output < MAXV) out[n_output * BLOCK] = make_double2(b.x, b.y);
                             else overflow = true;
                             n_output++;
                             last = b;
                         } else if (a_inside) {
-                            P2 pt;
-                            if (sh_intersection(a, V, r, N, pt)) {
+                            if (have_pt) {
                                 if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
                                 else overflow = true;
                                 n_output++;
