@@ -212,58 +212,16 @@ void mesh_read_stats(xr_mesh *mesh) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// counting sort of element ids by an integer key (the ONLY sort the engine needs: spatial keys
-// are small integers).  Order inside a bucket follows the atomics, i.e. is unspecified -- every
-// consumer is written so that final results do not depend on it.
-// ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_key_count(const int32_t *__restrict__ key, int64_t n,
-                                                  int32_t *__restrict__ count) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&count[key[i]], 1);
-}
-
-__global__ void __launch_bounds__(256) k_key_fill(const int32_t *__restrict__ key, int64_t n,
-                                                 const int32_t *__restrict__ start, int32_t *__restrict__ cursor,
-                                                 int32_t *__restrict__ perm) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int k = key[i];
-    perm[start[k] + atomicAdd(&cursor[k], 1)] = (int32_t)i;
-}
-
-void counting_sort_perm(const int32_t *key, int64_t n, int64_t n_buckets, int32_t *perm, int32_t *bucket_start) {
-    DevBuf<int32_t> count((size_t)n_buckets);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
-    if (n > 0) XR_LAUNCH("sort_count", k_key_count, dim3(div_up(n, 256)), dim3(256), 0, key, n, count.get());
-    exclusive_scan_i32(count.get(), bucket_start, n_buckets);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
-    if (n > 0)
-        XR_LAUNCH("sort_fill", k_key_fill, dim3(div_up(n, 256)), dim3(256), 0, key, n, bucket_start, count.get(), perm);
-}
-
-// permute the per-face arrays: out[r] = in[perm[r]]; optionally emit the conservative f32 record bbox
-__global__ void __launch_bounds__(256)
-k_gather_faces(const int32_t *__restrict__ perm, int64_t n, int m, const double *__restrict__ fxy,
-               const uint8_t *__restrict__ len, const double *__restrict__ bbox, double *__restrict__ o_fxy,
-               uint8_t *__restrict__ o_len, double *__restrict__ o_bbox, float *__restrict__ o_recbb, double x0,
-               double y0) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    const int64_t f = perm[r];
-    const int nl = len[f];
-    o_len[r] = (uint8_t)nl;
-    const double2 *src = reinterpret_cast<const double2 *>(fxy) + f * m;
-    double2 *dst = reinterpret_cast<double2 *>(o_fxy) + r * m;
-    for (int j = 0; j < nl; j++) dst[j] = src[j];
-    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
-    if (o_bbox) reinterpret_cast<double4 *>(o_bbox)[r] = bb;
-    if (o_recbb)
-        reinterpret_cast<float4 *>(o_recbb)[r] =
-            make_float4(f32_below(bb.x - x0), f32_above(bb.y - x0), f32_below(bb.z - y0), f32_above(bb.w - y0));
-}
-
-// ---------------------------------------------------------------------------------------------
-// query order: faces grouped by the Morton code of the coarse cell holding their bbox centre
+// spatial ordering = counting sort of the faces by a small integer key (the ONLY sort the engine
+// needs), fused with the permutation of the per-face arrays:
+//   pass 1 (k_spatial_count)   key of every face (Morton code of a coarse cell / grid cell of the
+//                              tree index) + bucket histogram (global atomics)
+//   scan                       bucket offsets (= cell_start for the tree index)
+//   pass 2 (k_spatial_scatter) slot = offset + atomic cursor; the face's vertex block, length,
+//                              bbox (f64, or the conservative f32 record bbox) are read
+//                              coalesced in the caller's order and written to the slot
+// Order inside a bucket follows the atomics, i.e. is unspecified -- every consumer is written
+// so that final results do not depend on it.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t spread_bits16(uint32_t v) {
     v = (v | (v << 8)) & 0x00FF00FFu;
@@ -273,14 +231,80 @@ __device__ __forceinline__ uint32_t spread_bits16(uint32_t v) {
     return v;
 }
 
-__global__ void __launch_bounds__(256) k_morton_keys(const double *__restrict__ bbox, int64_t n, double x0, double y0,
-                                                    double inv_h, int n_side, int32_t *__restrict__ key) {
+struct MortonParams {
+    double x0, y0, inv_h;
+    int n_side;
+};
+
+__device__ __forceinline__ int morton_key(const MortonParams &mp, double4 bb) {
+    const int cx = cell_coord(0.5 * (bb.x + bb.y), mp.x0, mp.inv_h, mp.n_side);
+    const int cy = cell_coord(0.5 * (bb.z + bb.w), mp.y0, mp.inv_h, mp.n_side);
+    return (int)(spread_bits16((uint32_t)cx) | (spread_bits16((uint32_t)cy) << 1));
+}
+
+__device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
+    const double e = fmax(bb.y - bb.x, bb.w - bb.z);
+    const int l = level_of_extent(g, e);
+    const double inv_h = level_inv_h(g, l);
+    const int cx = cell_coord(bb.x, g.x0, inv_h, g.nx[l]);
+    const int cy = cell_coord(bb.z, g.y0, inv_h, g.ny[l]);
+    return g.base[l] + cy * g.nx[l] + cx;
+}
+
+template <bool INDEX>
+__global__ void __launch_bounds__(256) k_spatial_count(const double *__restrict__ bbox, int64_t n, GridParams g,
+                                                      MortonParams mp, int32_t *__restrict__ key,
+                                                      int32_t *__restrict__ count) {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n) return;
     const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
-    const int cx = cell_coord(0.5 * (bb.x + bb.y), x0, inv_h, n_side);
-    const int cy = cell_coord(0.5 * (bb.z + bb.w), y0, inv_h, n_side);
-    key[f] = (int32_t)(spread_bits16((uint32_t)cx) | (spread_bits16((uint32_t)cy) << 1));
+    const int k = INDEX ? face_cell(g, bb) : morton_key(mp, bb);
+    key[f] = k;
+    atomicAdd(&count[k], 1);
+}
+
+template <bool INDEX>
+__global__ void __launch_bounds__(256)
+k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m, const int32_t *__restrict__ start,
+                  int32_t *__restrict__ cursor, const double *__restrict__ fxy, const uint8_t *__restrict__ len,
+                  const double *__restrict__ bbox, int32_t *__restrict__ perm, double *__restrict__ o_fxy,
+                  uint8_t *__restrict__ o_len, double *__restrict__ o_bbox, float *__restrict__ o_recbb, double x0,
+                  double y0) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    const int k = key[f];
+    const int64_t r = start[k] + atomicAdd(&cursor[k], 1);
+    perm[r] = (int32_t)f;
+    const int nl = len[f];
+    o_len[r] = (uint8_t)nl;
+    const double2 *src = reinterpret_cast<const double2 *>(fxy) + f * m;
+    double2 *dst = reinterpret_cast<double2 *>(o_fxy) + r * m;
+    for (int j = 0; j < nl; j++) dst[j] = src[j];
+    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    if (INDEX) {
+        reinterpret_cast<float4 *>(o_recbb)[r] =
+            make_float4(f32_below(bb.x - x0), f32_above(bb.y - x0), f32_below(bb.z - y0), f32_above(bb.w - y0));
+    } else {
+        reinterpret_cast<double4 *>(o_bbox)[r] = bb;
+    }
+}
+
+template <bool INDEX>
+static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams &mp, int64_t n_buckets,
+                         int32_t *bucket_start, int32_t *perm, double *o_fxy, uint8_t *o_len, double *o_bbox,
+                         float *o_recbb) {
+    const int64_t F = mesh->n_face;
+    DevBuf<int32_t> key((size_t)F), count((size_t)n_buckets);
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
+    if (F > 0)
+        XR_LAUNCH(INDEX ? "index_count" : "order_count", k_spatial_count<INDEX>, dim3(div_up(F, 256)), dim3(256), 0,
+                  mesh->bbox.get(), F, g, mp, key.get(), count.get());
+    exclusive_scan_i32(count.get(), bucket_start, n_buckets);
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
+    if (F > 0)
+        XR_LAUNCH(INDEX ? "index_scatter" : "order_scatter", k_spatial_scatter<INDEX>, dim3(div_up(F, 256)), dim3(256),
+                  0, key.get(), F, mesh->m, bucket_start, count.get(), mesh->fxy.get(), mesh->len.get(),
+                  mesh->bbox.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
 }
 
 void mesh_query_order(xr_mesh *mesh) {
@@ -300,36 +324,13 @@ void mesh_query_order(xr_mesh *mesh) {
         if (!(h > 0)) h = span;
         int bits = 1;
         while (bits < 10 && ldexp(h, bits) < span) bits++;
-        const int n_side = 1 << bits;
-        const double inv_h = (double)n_side / (span * (1.0 + 1e-9));
-        DevBuf<int32_t> key((size_t)F), start(((size_t)1 << (2 * bits)) + 1);
-        XR_LAUNCH("morton_keys", k_morton_keys, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, xmin, ymin,
-                  inv_h, n_side, key.get());
-        counting_sort_perm(key.get(), F, (int64_t)1 << (2 * bits), mesh->q_perm.get(), start.get());
-        XR_LAUNCH("gather_query", k_gather_faces, dim3(div_up(F, 256)), dim3(256), 0, mesh->q_perm.get(), F, m,
-                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->q_fxy.get(), mesh->q_len.get(),
-                  mesh->q_bbox.get(), (float *)nullptr, 0.0, 0.0);
+        MortonParams mp{xmin, ymin, (double)(1 << bits) / (span * (1.0 + 1e-9)), 1 << bits};
+        GridParams g{};
+        DevBuf<int32_t> start(((size_t)1 << (2 * bits)) + 1);
+        spatial_sort<false>(mesh, g, mp, (int64_t)1 << (2 * bits), start.get(), mesh->q_perm.get(), mesh->q_fxy.get(),
+                            mesh->q_len.get(), mesh->q_bbox.get(), nullptr);
     }
     mesh->query_ready = true;
-}
-
-// ---------------------------------------------------------------------------------------------
-// tree index
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
-    const double e = fmax(bb.y - bb.x, bb.w - bb.z);
-    const int l = level_of_extent(g, e);
-    const double inv_h = level_inv_h(g, l);
-    const int cx = cell_coord(bb.x, g.x0, inv_h, g.nx[l]);
-    const int cy = cell_coord(bb.z, g.y0, inv_h, g.ny[l]);
-    return g.base[l] + cy * g.nx[l] + cx;
-}
-
-__global__ void __launch_bounds__(256) k_index_keys(const double *__restrict__ bbox, int64_t n_face, GridParams g,
-                                                   int32_t *__restrict__ key) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_face) return;
-    key[f] = face_cell(g, reinterpret_cast<const double4 *>(bbox)[f]);
 }
 
 void mesh_build_index(xr_mesh *mesh) {
@@ -374,14 +375,9 @@ void mesh_build_index(xr_mesh *mesh) {
     mesh->rec_face.alloc((size_t)F);
     mesh->rec_fxy.alloc((size_t)F * m * 2);
     mesh->rec_len.alloc((size_t)F);
-    DevBuf<int32_t> key((size_t)F);
-    if (F > 0)
-        XR_LAUNCH("index_keys", k_index_keys, dim3(div_up(F, 256)), dim3(256), 0, mesh->bbox.get(), F, g, key.get());
-    counting_sort_perm(key.get(), F, total, mesh->rec_face.get(), mesh->cell_start.get());
-    if (F > 0)
-        XR_LAUNCH("gather_index", k_gather_faces, dim3(div_up(F, 256)), dim3(256), 0, mesh->rec_face.get(), F, m,
-                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->rec_fxy.get(), mesh->rec_len.get(),
-                  (double *)nullptr, mesh->rec_bb.get(), g.x0, g.y0);
+    MortonParams mp{};
+    spatial_sort<true>(mesh, g, mp, total, mesh->cell_start.get(), mesh->rec_face.get(), mesh->rec_fxy.get(),
+                       mesh->rec_len.get(), nullptr, mesh->rec_bb.get());
     mesh->indexed = true;
 }
 

@@ -72,7 +72,4 @@ void mesh_prepare(xr_mesh *mesh);
 void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
 void mesh_read_stats(xr_mesh *mesh);
-// perm[i] = element ids grouped by ascending key (order inside a bucket unspecified);
-// bucket_start (n_buckets + 1) receives the bucket offsets.
-void counting_sort_perm(const int32_t *key, int64_t n, int64_t n_buckets, int32_t *perm, int32_t *bucket_start);
 } // namespace xr
