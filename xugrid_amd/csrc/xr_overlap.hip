@@ -149,12 +149,11 @@ k_compact(const int32_t *__restrict__ slots, const int32_t *__restrict__ cand_of
     }
 }
 
-// One wave per big query face.  The face is scan-converted against the grid: for grid row cy of
+// One block per big query face.  The face is scan-converted against the grid: for grid row cy of
 // level l only the cells under the polygon's x-extent inside the y-slab of that row are visited
 // (a thin hull sliver touches O(length) cells instead of the O(length^2) cells of its bbox).
-// Lanes take one grid row each (64 rows per batch); runs longer than LONG_RUN records are
-// processed by the whole wave in 64-record chunks.  Output order is a function of the index
-// only, so the result does not depend on which wave handles which face.
+// Lanes take one grid row each (64 rows per batch, batches dealt round-robin to the block's four
+// waves); runs longer than LONG_RUN records are processed by the whole wave in 64-record chunks.
 //
 // Superset argument: a tree face s on level l with positive-area intersection has a point p in
 // both polygons; its record sits in the cell of (xmin_s, ymin_s) with p.x - h < xmin_s <= p.x and
@@ -181,29 +180,36 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
              const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
              const int32_t *__restrict__ n_big, const int32_t *__restrict__ cand_off,
              int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src) {
-    __shared__ double2 sh_poly[4][XR_MAX_FACE_NODES];
+    // one BLOCK per big face: its four waves take the 64-row batches round-robin; candidates are
+    // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
+    // ranked by tree face id afterwards)
+    __shared__ double2 sh_poly[XR_MAX_FACE_NODES];
+    __shared__ int sh_cursor;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
     const int nb = *n_big;
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-    double2 *poly = sh_poly[wv];
-    for (int bi = wave; bi < nb; bi += n_waves) {
+    for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
         const int t = big_list[bi];
         const int np = q_len[t];
-        if (lane < np) poly[lane] = reinterpret_cast<const double2 *>(q_fxy)[(int64_t)t * q_m + lane];
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        if (threadIdx.x < np) sh_poly[threadIdx.x] = reinterpret_cast<const double2 *>(q_fxy)[(int64_t)t * q_m + threadIdx.x];
+        if (threadIdx.x == 0) sh_cursor = 0;
+        __syncthreads();
+        const double2 *poly = sh_poly;
         const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
+        const int out0 = FILL ? cand_off[t] : 0;
         int total = 0;
-        int out = FILL ? cand_off[t] : 0;
+        int batch_id = 0;
         for (int l = 0; l < g.n_levels; l++) {
             const double h = level_h(g, l), inv_h = level_inv_h(g, l);
             const double eps = 1e-6 * h;
             const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
             const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
-            for (int cyb = cy0; cyb <= cy1; cyb += 64) {
+            for (int cyb = cy0; cyb <= cy1; cyb += 64, batch_id++) {
+                if ((batch_id & 3) != wv) continue;
                 const int cy = cyb + lane;
                 int r0 = 0, r1 = 0;
                 if (cy <= cy1) {
@@ -240,7 +246,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                     }
                 }
                 const int len = r1 - r0;
-                // (1) long runs: the whole wave, 64 records at a time, output in record order
+                // (1) long runs: the whole wave, 64 records at a time
                 unsigned long long long_mask = __ballot(len > LONG_RUN);
                 while (long_mask) {
                     const int src_lane = __ffsll((long long)long_mask) - 1;
@@ -250,13 +256,17 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                         const int r = rb + lane;
                         const bool hit = r < R1 && rec_hit(rbb[r], qx0, qx1, qy0, qy1);
                         const unsigned long long mask = __ballot(hit);
-                        if (FILL && hit) {
-                            const int slot = out + __popcll(mask & lt_mask);
-                            cand_tgt[slot] = t;
-                            cand_src[slot] = r;
-                        }
                         const int n = __popcll(mask);
-                        out += n;
+                        if (FILL && n > 0) {
+                            int slot0 = 0;
+                            if (lane == 0) slot0 = atomicAdd(&sh_cursor, n);
+                            slot0 = __shfl(slot0, 0, 64);
+                            if (hit) {
+                                const int slot = out0 + slot0 + __popcll(mask & lt_mask);
+                                cand_tgt[slot] = t;
+                                cand_src[slot] = r;
+                            }
+                        }
                         total += n;
                     }
                 }
@@ -266,8 +276,11 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                 for (int r = r0; r < my_r1; r++) cnt += rec_hit(rbb[r], qx0, qx1, qy0, qy1) ? 1 : 0;
                 const int excl = wave_excl_scan_i32(cnt, lane);
                 const int batch = __shfl(excl + cnt, 63, 64);
-                if (FILL && cnt > 0) {
-                    int pos = out + excl;
+                if (FILL && batch > 0) {
+                    int slot0 = 0;
+                    if (lane == 0) slot0 = atomicAdd(&sh_cursor, batch);
+                    slot0 = __shfl(slot0, 0, 64);
+                    int pos = out0 + slot0 + excl;
                     for (int r = r0; r < my_r1; r++) {
                         if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
                             cand_tgt[pos] = t;
@@ -276,12 +289,15 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                         }
                     }
                 }
-                out += batch;
                 total += batch;
             }
         }
-        if (!FILL && lane == 0) cand_count[t] = total;
-        __builtin_amdgcn_wave_barrier();
+        if (!FILL) {
+            // block total (every lane of a wave holds the wave's total)
+            if (lane == 0) atomicAdd(&sh_cursor, total);
+            __syncthreads();
+            if (threadIdx.x == 0) cand_count[t] = sh_cursor;
+        }
     }
 }
 
@@ -836,7 +852,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     // --- candidate search: count -> scan -> fill
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
     DevBuf<uint8_t> is_big((size_t)T);
-    const int big_grid = engine().num_cu * 2;
+    const int big_grid = engine().num_cu * 8;
     DevBuf<int32_t> slots((size_t)T * SLOTS);
     XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), slots.get(), is_big.get(), big_list.get(),
