@@ -56,17 +56,21 @@ def make_meshes(points_per_mesh, delaunay=True):
 
 
 def algorithmic_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
-    """Per-kernel algorithmic HBM bytes of one step: every array a kernel
-    must read or write once, int32 connectivity/indices, f64 coordinates/areas."""
+    """Per-kernel algorithmic HBM bytes of one step: every array a kernel has
+    to read or write once -- int32 connectivity / indices, f64 coordinates / areas, the face-major
+    vertex blocks (16 M bytes per face) and 16-byte f32 record boxes the engine keeps in HBM."""
+    vs, vt = 16 * Ms, 16 * Mt  # face-major vertex block bytes
     b = {}
-    b["prepare_faces"] = 4 * (Ms * S + Mt * T) * 2 + 16 * (Ns + Nt) + (1 + 32 + 8) * (S + T)
+    b["prepare_faces"] = 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + (vs + 1 + 32 + 8) * S + (vt + 1 + 32 + 8) * T
     b["index_count"] = 32 * S + 4 * S
-    b["index_fill"] = 32 * S + 4 * S + 4 * S + 20 * S
-    b["search_count"] = 32 * T + 20 * S + 4 * T
-    b["search_fill"] = 32 * T + 20 * S + 4 * T + 8 * C
-    b["clip_v8"] = 8 * C + 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + (S + T) + 8 * C + 4 * T
-    b["row_fill"] = 4 * T + 12 * C + 4 * T + 12 * P
-    b["apply_stream"] = 12 * P + 4 * (T + 1) + 8 * (S + T)
+    b["order_count"] = 32 * T + 4 * T
+    b["index_scatter"] = (4 + vs + 1 + 32) * S + (4 + vs + 1 + 16) * S
+    b["order_scatter"] = (4 + vt + 1 + 32) * T + (4 + vt + 1 + 32) * T
+    b["search"] = 32 * T + 16 * S + 4 * T + 4 * C  # query boxes, record boxes once, counts, slot rows
+    b["compact"] = 4 * C + 4 * T + 8 * C
+    b["clip_small"] = 8 * C + vt * T + vs * S + (S + T) + 4 * S + 12 * C + 4 * T  # queue, vertex blocks, area + face id out
+    b["row_fill"] = 4 * T + 16 * C + 4 * T + 12 * P
+    b["apply_stream"] = 12 * P + 4 * (T + 1) + 4 * T + 8 * (S + T)
     # whole weight construction, SURVEY.md 8(d): read both meshes once, write the CSR once
     b["build_total"] = 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + 12 * P + 4 * (T + 1)
     return b
@@ -161,7 +165,7 @@ def run_single(args):
             traffic = json.load(open(tpath)).get(dominant)
         except Exception:
             traffic = None
-    build_ms = sum(v for k, v in per_step.items() if k != "apply_stream")
+    build_ms = sum(v for k, v in per_step.items() if not k.startswith("apply"))
     roofline = {
         "bound": "hbm",
         "kernel": dominant,
@@ -309,9 +313,10 @@ def main():
     ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--partition", default="morton", choices=["morton", "hash"])
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         run_multi(args)
     else:
         run_single(args)

@@ -11,6 +11,7 @@
 //
 // HBM layout: source (K, S) row-major, out (K, T) row-major (regridder.py:163, :44);
 // CSR = indptr i32[T+1], indices i32[nnz], data f64[nnz].
+#include <cstdlib>
 #include <vector>
 
 #include "xr_objects.h"
@@ -18,7 +19,7 @@
 namespace xr {
 
 static constexpr int AP_BLOCK = 256;
-static constexpr int KT = 8; // k-values per thread in the streaming kernel
+static constexpr int KT = 16; // source variables reduced per pass over the CSR (K >= 2)
 
 template <typename SRC> __device__ __forceinline__ double ld_src(const SRC *p, int64_t i) { return (double)p[i]; }
 
@@ -282,6 +283,216 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
     }
 }
 
+// Many source variables (K >= 2): one thread per row keeps KTILE reducer states in registers and
+// walks its row once per k-tile; no LDS, so occupancy is limited by registers only and every
+// thread has KTILE independent gathers in flight per entry.  Rows are visited in stored (spatial)
+// order, so the gathers of neighbouring threads hit the same cache lines.
+template <int METHOD, typename SRC, int KTILE>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_direct(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+               const double *__restrict__ data, const int32_t *__restrict__ row_order, bool skip_long, int64_t T,
+               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const int64_t k0 = (int64_t)blockIdx.y * KTILE;
+    const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+    const int s = indptr[t], e = indptr[t + 1];
+    if (skip_long && e - s > APPLY_LONG) return; // reduced by k_apply_long
+    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+    const SRC *src = source + k0 * S;
+    double normsum = 0.0;
+    if (METHOD == XR_GEOMETRIC_MEAN)
+        for (int j = s; j < e; j++) normsum += data[j];
+    Red<METHOD> red[KTILE];
+    for (int j = s; j < e; j++) {
+        const int64_t col = indices[j];
+        const double w = data[j];
+        double v[KTILE];
+#pragma unroll
+        for (int kk = 0; kk < KTILE; kk++) v[kk] = kk < kn ? ld_src(src, (int64_t)kk * S + col) : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KTILE; kk++)
+            if (kk < kn) red[kk].add(v[kk], w, normsum);
+    }
+#pragma unroll
+    for (int kk = 0; kk < KTILE; kk++) {
+        if (kk < kn) {
+            double r = NAN;
+            if (e > s) {
+                r = red[kk].fin();
+                if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+            }
+            out[(k0 + kk) * T + t_out] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// apply plan: blocked CSR with per-block distinct-column lists.
+// A block of 256 spatially adjacent rows references ~5x fewer DISTINCT source faces than it has
+// entries.  With many source variables the gathers dominate, so each distinct source value is
+// loaded ONCE per (block, variable) -- lanes run over the ascending column list, neighbours share
+// cache lines -- into LDS, and the rows are reduced from LDS through 16-bit local indices.
+// ---------------------------------------------------------------------------------------------
+static constexpr int PLAN_LMAX = 4096; // entries of a block the builder can sort in LDS
+static constexpr int PLAN_UMAX = 512;  // distinct columns per block kept in the plan
+static constexpr int PLAN_KT = 8;      // source variables per pass (LDS: PLAN_KT * PLAN_UMAX doubles)
+
+__global__ void __launch_bounds__(AP_BLOCK)
+k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
+             int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc) {
+    __shared__ int32_t keys[PLAN_LMAX];
+    __shared__ int32_t uniq[PLAN_UMAX];
+    __shared__ int32_t sh_wave[4];
+    __shared__ int32_t sh_total;
+    const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
+    const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
+    const int seg0 = indptr[row0], seg1 = indptr[row_end];
+    const int n = seg1 - seg0;
+    if (n > PLAN_LMAX) {
+        if (threadIdx.x == 0) nuniq[blockIdx.x] = -1;
+        return;
+    }
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += AP_BLOCK) keys[i] = i < n ? indices[seg0 + i] : 0x7fffffff;
+    __syncthreads();
+    // bitonic sort, ascending
+    for (int k = 2; k <= np2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += AP_BLOCK) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // unique: each thread owns a contiguous slice of the sorted keys
+    const int per = (n + AP_BLOCK - 1) / AP_BLOCK;
+    const int a0 = threadIdx.x * per, a1 = a0 + per < n ? a0 + per : n;
+    int cnt = 0;
+    for (int i = a0; i < a1; i++) cnt += (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) sh_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) woff += sh_wave[w];
+        total += sh_wave[w];
+    }
+    if (threadIdx.x == 0) sh_total = total;
+    if (total > PLAN_UMAX) {
+        if (threadIdx.x == 0) nuniq[blockIdx.x] = -1;
+        return;
+    }
+    int pos = woff + incl - cnt;
+    for (int i = a0; i < a1; i++) {
+        if (i == 0 || keys[i] != keys[i - 1]) uniq[pos++] = keys[i];
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < total; u += AP_BLOCK) ucol[(int64_t)blockIdx.x * PLAN_UMAX + u] = uniq[u];
+    if (threadIdx.x == 0) nuniq[blockIdx.x] = total;
+    // local index of every entry: binary search in the distinct list
+    for (int i = threadIdx.x; i < n; i += AP_BLOCK) {
+        const int c = indices[seg0 + i];
+        int lo = 0, hi = total - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uniq[mid] < c) lo = mid + 1;
+            else hi = mid;
+        }
+        loc[seg0 + i] = (uint16_t)lo;
+    }
+}
+
+template <int METHOD, typename SRC, int KTILE>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+             const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
+             const int32_t *__restrict__ row_order, bool skip_long, int64_t T, int64_t S,
+             const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
+    __shared__ double vals[KTILE][PLAN_UMAX];
+    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.y * KTILE;
+    const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+    const SRC *src = source + k0 * S;
+    const int nu = nuniq[blockIdx.x];
+    if (nu >= 0) {
+        // each distinct source value once per variable; lanes walk the ascending column list
+        const int32_t *uc = ucol + (int64_t)blockIdx.x * PLAN_UMAX;
+        for (int u = threadIdx.x; u < nu; u += AP_BLOCK) {
+            const int64_t col = uc[u];
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++)
+                if (kk < kn) vals[kk][u] = ld_src(src, (int64_t)kk * S + col);
+        }
+    }
+    __syncthreads();
+    if (t >= T) return;
+    const int s = indptr[t], e = indptr[t + 1];
+    if (skip_long && e - s > APPLY_LONG) return; // reduced by k_apply_long
+    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+    double normsum = 0.0;
+    if (METHOD == XR_GEOMETRIC_MEAN)
+        for (int j = s; j < e; j++) normsum += data[j];
+    Red<METHOD> red[KTILE];
+    if (nu >= 0) {
+        for (int j = s; j < e; j++) {
+            const int l = loc[j];
+            const double w = data[j];
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++)
+                if (kk < kn) red[kk].add(vals[kk][l], w, normsum);
+        }
+    } else {
+        for (int j = s; j < e; j++) {
+            const int64_t col = indices[j];
+            const double w = data[j];
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++)
+                if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
+        }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KTILE; kk++) {
+        if (kk < kn) {
+            double r = NAN;
+            if (e > s) {
+                r = red[kk].fin();
+                if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+            }
+            out[(k0 + kk) * T + t_out] = r;
+        }
+    }
+}
+
+static void ensure_plan(const xr_csr *ccsr) {
+    xr_csr *csr = const_cast<xr_csr *>(ccsr); // the plan is a cache attached to the weights
+    if (csr->plan_ready) return;
+    const int64_t nb = (csr->n + AP_BLOCK - 1) / AP_BLOCK;
+    csr->plan_ucol.alloc((size_t)nb * PLAN_UMAX);
+    csr->plan_nuniq.alloc((size_t)nb);
+    csr->plan_loc.alloc((size_t)csr->nnz);
+    if (nb > 0)
+        XR_LAUNCH("plan_build", k_plan_build, dim3((unsigned)nb), dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get());
+    csr->plan_ready = true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // workspace reducers: mode and percentile.  One thread per (row, k); per-row scratch lives in a
 // global workspace laid out like the CSR data (ws[k_local][nnz]).
@@ -491,9 +702,21 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
     } else {
-        dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
-        XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, KT, 768>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
+        static const bool no_plan = getenv("XR_APPLY_NO_PLAN") != nullptr;
+        if (K >= PLAN_KT && !no_plan) {
+            // many variables: blocked CSR with per-block distinct-column lists (built once per matrix)
+            ensure_plan(csr);
+            dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, PLAN_KT));
+            XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),
+                      csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
+        } else {
+            // a few variables: register-resident k-tiles, direct gathers, no LDS
+            dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
+            XR_LAUNCH("apply_direct", (k_apply_direct<METHOD, SRC, KT>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K,
+                      out);
+        }
     }
     if (csr->has_long) {
         dim3 grid((unsigned)engine().num_cu, (unsigned)(K < 8 ? K : 8));

@@ -65,6 +65,12 @@ struct xr_csr {
     xr::DevBuf<int32_t> long_rows; // [<= n]
     xr::DevBuf<int32_t> n_long;    // [1] device-side count
     bool has_long = false;
+    // "apply plan" for many source variables (built lazily, xr_apply.hip): per block of 256 stored
+    // rows the sorted list of DISTINCT column ids and, per entry, its 16-bit position in that list
+    bool plan_ready = false;
+    xr::DevBuf<int32_t> plan_ucol;   // [n_blocks * PLAN_UMAX]
+    xr::DevBuf<int32_t> plan_nuniq;  // [n_blocks], -1 = block not planned (falls back to direct gathers)
+    xr::DevBuf<uint16_t> plan_loc;   // [nnz]
 };
 
 namespace xr {
