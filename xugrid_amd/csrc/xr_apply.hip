@@ -33,9 +33,10 @@ template <int METHOD> struct Red;
 template <> struct Red<XR_MEAN> { // reduce.py:16-27   a = sum w v, b = sum w
     double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
-        if (v != v) return;
-        a += w * v;
-        b += w;
+        const bool ok = v == v; // select instead of branch: lanes stay converged
+        const double na = a + w * v, nb = b + w;
+        a = ok ? na : a;
+        b = ok ? nb : b;
     }
     __device__ void merge(const Red &o) { a += o.a; b += o.b; }
     __device__ double fin() const { return b == 0 ? NAN : a / b; }
@@ -70,9 +71,10 @@ template <> struct Red<XR_GEOMETRIC_MEAN> { // reduce.py:45-72; normsum = sum of
 template <> struct Red<XR_SUM> { // reduce.py:75-87   a = sum v, b = sum w
     double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
-        if (v != v) return;
-        a += v;
-        b += w;
+        const bool ok = v == v;
+        const double na = a + v, nb = b + w;
+        a = ok ? na : a;
+        b = ok ? nb : b;
     }
     __device__ void merge(const Red &o) { a += o.a; b += o.b; }
     __device__ double fin() const { return b == 0 ? NAN : a; }
@@ -80,9 +82,9 @@ template <> struct Red<XR_SUM> { // reduce.py:75-87   a = sum v, b = sum w
 template <> struct Red<XR_MINIMUM> { // reduce.py:90-106   a = min v, b = max w
     double a = INFINITY, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
-        if (v != v) return;
-        if (v < a) a = v;
-        if (w > b) b = w;
+        const bool ok = v == v;
+        a = (ok && v < a) ? v : a;
+        b = (ok && w > b) ? w : b;
     }
     __device__ void merge(const Red &o) { if (o.a < a) a = o.a; if (o.b > b) b = o.b; }
     __device__ double fin() const { return b == 0.0 ? NAN : a; }
@@ -90,9 +92,9 @@ template <> struct Red<XR_MINIMUM> { // reduce.py:90-106   a = min v, b = max w
 template <> struct Red<XR_MAXIMUM> { // reduce.py:109-123   a = max v, b = max w
     double a = -INFINITY, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
-        if (v != v) return;
-        if (v > a) a = v;
-        if (w > b) b = w;
+        const bool ok = v == v;
+        a = (ok && v > a) ? v : a;
+        b = (ok && w > b) ? w : b;
     }
     __device__ void merge(const Red &o) { if (o.a > a) a = o.a; if (o.b > b) b = o.b; }
     __device__ double fin() const { return b == 0.0 ? NAN : a; }
@@ -100,9 +102,10 @@ template <> struct Red<XR_MAXIMUM> { // reduce.py:109-123   a = max v, b = max w
 template <> struct Red<XR_FIRST_ORDER_CONSERVATIVE> { // reduce.py:206-222   a = sum v w, b = sum w
     double a = 0.0, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
-        if (v != v) return;
-        a += v * w;
-        b += w;
+        const bool ok = v == v;
+        const double na = a + v * w, nb = b + w;
+        a = ok ? na : a;
+        b = ok ? nb : b;
     }
     __device__ void merge(const Red &o) { a += o.a; b += o.b; }
     __device__ double fin() const { return b == 0 ? NAN : a; }
@@ -110,11 +113,9 @@ template <> struct Red<XR_FIRST_ORDER_CONSERVATIVE> { // reduce.py:206-222   a =
 template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238   a = value of the largest weight b
     double a = -INFINITY, b = 0.0, c = 0.0;
     __device__ void add(double v, double w, double) {
-        if (v != v) return;
-        if ((w > b) || (w == b && v > a)) {
-            b = w;
-            a = v;
-        }
+        const bool take = (v == v) && ((w > b) || (w == b && v > a));
+        b = take ? w : b;
+        a = take ? v : a;
     }
     __device__ void merge(const Red &o) {
         if ((o.b > b) || (o.b == b && o.a > a)) {
@@ -336,7 +337,7 @@ k_apply_direct(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
 // ---------------------------------------------------------------------------------------------
 static constexpr int PLAN_LMAX = 4096; // entries of a block the builder can sort in LDS
 static constexpr int PLAN_UMAX = 512;  // distinct columns per block kept in the plan
-static constexpr int PLAN_KT = 8;      // source variables per pass (LDS: PLAN_KT * PLAN_UMAX doubles)
+static constexpr int PLAN_KT = 8;      // source variables per pipeline stage (LDS: PLAN_KT * PLAN_UMAX doubles)
 
 __global__ void __launch_bounds__(AP_BLOCK)
 k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
@@ -419,63 +420,182 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
 }
 
+// One block = 256 stored rows, ALL variables: the block's CSR entries (weight + 16-bit local column)
+// are staged in LDS once, then the block walks the variables in tiles of KTILE.  Software pipeline
+// (global -> registers -> LDS): the distinct source values of tile i+1 are requested into registers
+// before tile i is reduced, and written to LDS after it -- HBM latency overlaps the reduction, so one
+// resident block per CU is enough to keep its share of the memory system busy.
 template <int METHOD, typename SRC, int KTILE>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
              const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
              const int32_t *__restrict__ row_order, bool skip_long, int64_t T, int64_t S,
              const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
-    __shared__ double vals[KTILE][PLAN_UMAX];
-    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
-    const int64_t k0 = (int64_t)blockIdx.y * KTILE;
-    const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
-    const SRC *src = source + k0 * S;
-    const int nu = nuniq[blockIdx.x];
-    if (nu >= 0) {
-        // each distinct source value once per variable; lanes walk the ascending column list
-        const int32_t *uc = ucol + (int64_t)blockIdx.x * PLAN_UMAX;
-        for (int u = threadIdx.x; u < nu; u += AP_BLOCK) {
-            const int64_t col = uc[u];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][PLAN_UMAX]
+    double *sh_w = vals + KTILE * PLAN_UMAX;                              // [PLAN_LMAX]
+    uint16_t *sh_loc = reinterpret_cast<uint16_t *>(sh_w + PLAN_LMAX);    // [PLAN_LMAX]
+    constexpr int UPT = PLAN_UMAX / AP_BLOCK;                             // distinct columns per thread
+    // XCD-aware block order: hardware block b runs on XCD b % 8; give every XCD a CONTIGUOUS range of
+    // row blocks (= one spatial region), so that lines shared by neighbouring blocks stay in one L2
+    const int64_t n_blocks = (T + AP_BLOCK - 1) / AP_BLOCK;
+    const int64_t per_xcd = (n_blocks + 7) / 8;
+    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (lb >= n_blocks) return;
+    const int64_t row0 = lb * AP_BLOCK;
+    const int64_t t = row0 + threadIdx.x;
+    const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
+    const int nu = nuniq[lb];
+    int s = 0, e = 0;
+    if (t < T) {
+        s = indptr[t];
+        e = indptr[t + 1];
+    }
+    const bool is_long = skip_long && (e - s > APPLY_LONG); // reduced by k_apply_long
+    const int64_t t_out = (t < T && row_order) ? (int64_t)row_order[t] : t;
+    if (nu < 0) {
+        // unplanned block (too many entries / distinct columns): direct gathers
+        if (t >= T || is_long) return;
+        double normsum = 0.0;
+        if (METHOD == XR_GEOMETRIC_MEAN)
+            for (int j = s; j < e; j++) normsum += data[j];
+        for (int64_t k0 = 0; k0 < K; k0 += KTILE) {
+            const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+            const SRC *src = source + k0 * S;
+            Red<METHOD> red[KTILE];
+            for (int j = s; j < e; j++) {
+                const int64_t col = indices[j];
+                const double w = data[j];
 #pragma unroll
-            for (int kk = 0; kk < KTILE; kk++)
-                if (kk < kn) vals[kk][u] = ld_src(src, (int64_t)kk * S + col);
+                for (int kk = 0; kk < KTILE; kk++)
+                    if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++) {
+                if (kk < kn) {
+                    double r = NAN;
+                    if (e > s) {
+                        r = red[kk].fin();
+                        if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+                    }
+                    out[(k0 + kk) * T + t_out] = r;
+                }
+            }
         }
+        return;
+    }
+    // stage the block's entries once
+    const int seg0 = indptr[row0], seg1 = indptr[row_end];
+    for (int j = seg0 + threadIdx.x; j < seg1; j += AP_BLOCK) {
+        sh_w[j - seg0] = data[j];
+        sh_loc[j - seg0] = loc[j];
+    }
+    // this thread's distinct columns
+    int64_t mycol[UPT];
+#pragma unroll
+    for (int q = 0; q < UPT; q++) {
+        const int u = q * AP_BLOCK + threadIdx.x;
+        mycol[q] = u < nu ? (int64_t)ucol[lb * PLAN_UMAX + u] : -1;
     }
     __syncthreads();
-    if (t >= T) return;
-    const int s = indptr[t], e = indptr[t + 1];
-    if (skip_long && e - s > APPLY_LONG) return; // reduced by k_apply_long
-    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
     double normsum = 0.0;
-    if (METHOD == XR_GEOMETRIC_MEAN)
-        for (int j = s; j < e; j++) normsum += data[j];
-    Red<METHOD> red[KTILE];
-    if (nu >= 0) {
-        for (int j = s; j < e; j++) {
-            const int l = loc[j];
-            const double w = data[j];
+    if (METHOD == XR_GEOMETRIC_MEAN && !is_long)
+        for (int j = s; j < e; j++) normsum += sh_w[j - seg0];
+    double wsum_row = 0.0; // sum of the row's weights in entry order (= Red::b when no value is NaN)
+    if (!is_long)
+        for (int j = s; j < e; j++) wsum_row += sh_w[j - seg0];
+    // prologue: request tile 0
+    double stage[UPT][KTILE];
+    {
+        const int kn = (int)(K < KTILE ? K : KTILE);
+#pragma unroll
+        for (int q = 0; q < UPT; q++)
 #pragma unroll
             for (int kk = 0; kk < KTILE; kk++)
-                if (kk < kn) red[kk].add(vals[kk][l], w, normsum);
-        }
-    } else {
-        for (int j = s; j < e; j++) {
-            const int64_t col = indices[j];
-            const double w = data[j];
-#pragma unroll
-            for (int kk = 0; kk < KTILE; kk++)
-                if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
-        }
+                stage[q][kk] = (mycol[q] >= 0 && kk < kn) ? ld_src(source, (int64_t)kk * S + mycol[q]) : 0.0;
     }
+    for (int64_t k0 = 0; k0 < K; k0 += KTILE) {
+        const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+        __syncthreads(); // everybody finished reading the previous tile
+        int my_nan = 0;
 #pragma unroll
-    for (int kk = 0; kk < KTILE; kk++) {
-        if (kk < kn) {
-            double r = NAN;
-            if (e > s) {
-                r = red[kk].fin();
-                if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+        for (int q = 0; q < UPT; q++) {
+            const int u = q * AP_BLOCK + threadIdx.x;
+            if (u < nu) {
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++) {
+                    vals[kk * PLAN_UMAX + u] = stage[q][kk];
+                    my_nan |= (stage[q][kk] != stage[q][kk]) ? 1 : 0;
+                }
             }
-            out[(k0 + kk) * T + t_out] = r;
+        }
+        // block-uniform: does this tile hold any NaN?  (NaN-free tiles take the short path below)
+        const bool tile_has_nan = __syncthreads_or(my_nan) != 0;
+        // request the next tile while this one is reduced
+        const int64_t k1 = k0 + KTILE;
+        if (k1 < K) {
+            const int kn1 = (int)((K - k1) < KTILE ? (K - k1) : KTILE);
+            const SRC *src1 = source + k1 * S;
+#pragma unroll
+            for (int q = 0; q < UPT; q++)
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++)
+                    stage[q][kk] = (mycol[q] >= 0 && kk < kn1) ? ld_src(src1, (int64_t)kk * S + mycol[q]) : 0.0;
+        }
+        constexpr bool LINEAR = METHOD == XR_MEAN || METHOD == XR_SUM || METHOD == XR_FIRST_ORDER_CONSERVATIVE;
+        if (LINEAR && !tile_has_nan) {
+            // no NaN anywhere in the tile: the weight sum of a row is the same for every variable
+            // (computed once, wsum_row) and the value sums need no per-entry test.  Same additions
+            // in the same order as the general path -> bit-identical results.
+            if (t < T && !is_long) {
+                double acc[KTILE];
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++) acc[kk] = 0.0;
+                for (int j = s - seg0; j < e - seg0; j++) {
+                    const int l = sh_loc[j];
+                    const double w = sh_w[j];
+                    double v[KTILE];
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * PLAN_UMAX + l];
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++) {
+                        if (METHOD == XR_MEAN) acc[kk] += w * v[kk];
+                        else if (METHOD == XR_SUM) acc[kk] += v[kk];
+                        else acc[kk] += v[kk] * w;
+                    }
+                }
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++) {
+                    if (kk < kn) {
+                        double r = NAN;
+                        if (e > s && wsum_row != 0) r = METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk];
+                        out[(k0 + kk) * T + t_out] = r;
+                    }
+                }
+            }
+        } else if (t < T && !is_long) {
+            Red<METHOD> red[KTILE];
+            for (int j = s - seg0; j < e - seg0; j++) {
+                const int l = sh_loc[j];
+                const double w = sh_w[j];
+                double v[KTILE];
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * PLAN_UMAX + l];
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++)
+                    if (kk < kn) red[kk].add(v[kk], w, normsum);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++) {
+                if (kk < kn) {
+                    double r = NAN;
+                    if (e > s) {
+                        r = red[kk].fin();
+                        if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+                    }
+                    out[(k0 + kk) * T + t_out] = r;
+                }
+            }
         }
     }
 }
@@ -706,10 +826,17 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         if (K >= PLAN_KT && !no_plan) {
             // many variables: blocked CSR with per-block distinct-column lists (built once per matrix)
             ensure_plan(csr);
-            dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, PLAN_KT));
-            XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                      csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),
-                      csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
+            const size_t shmem = sizeof(double) * (PLAN_KT * PLAN_UMAX + PLAN_LMAX) + sizeof(uint16_t) * PLAN_LMAX;
+            static bool attr_set = false;
+            if (!attr_set) {
+                XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                attr_set = true;
+            }
+            XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), dim3((div_up(csr->n, AP_BLOCK) + 7) / 8 * 8), dim3(AP_BLOCK),
+                      shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(),
+                      csr->plan_nuniq.get(), csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src,
+                      K, out);
         } else {
             // a few variables: register-resident k-tiles, direct gathers, no LDS
             dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
