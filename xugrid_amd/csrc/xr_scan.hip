@@ -101,6 +101,41 @@ __global__ void k_fill_f64(double *p, double v, int64_t n) {
     if (i < n) p[i] = v;
 }
 
+// two-kernel variant for up to SCAN_FUSED_TILES tiles: every block of the apply pass first scans the
+// (few) tile sums itself in LDS instead of waiting for a separate single-block kernel
+static constexpr int SCAN_FUSED_TILES = 8192;
+
+__global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply_fused(const int32_t *__restrict__ in,
+                                                                 const int32_t *__restrict__ tile_sums, int64_t nb,
+                                                                 int32_t *__restrict__ out, int64_t n) {
+    __shared__ int lds[4];
+    __shared__ int sh_base;
+    // offset of this tile = sum of the tile sums before it (strided partial sums + block reduce)
+    int part = 0;
+    for (int64_t i = threadIdx.x; i < blockIdx.x; i += SCAN_BLOCK) part += tile_sums[i];
+    int tot;
+    (void)block_excl_scan(part, &tot, lds);
+    if (threadIdx.x == 0) sh_base = tot;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const int64_t j = base + i;
+        v[i] = j < n ? in[j] : 0;
+        s += v[i];
+    }
+    int ex = block_excl_scan(s, &tot, lds) + sh_base;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const int64_t j = base + i;
+        if (j < n) out[j] = ex;
+        ex += v[i];
+    }
+    if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = sh_base + tot; // grand total
+}
+
 void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n) {
     if (n <= 0) {
         fill_i32(out, 0, 1);
@@ -109,6 +144,10 @@ void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n) {
     const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     DevBuf<int32_t> sums((size_t)nb);
     XR_LAUNCH("scan_reduce", k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), n);
+    if (nb <= SCAN_FUSED_TILES) {
+        XR_LAUNCH("scan_apply", k_scan_apply_fused, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), nb, out, n);
+        return;
+    }
     XR_LAUNCH("scan_partials", k_scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, sums.get(), nb, out + n);
     XR_LAUNCH("scan_apply", k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), out, n);
 }
