@@ -691,6 +691,42 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
     }
 }
 
+// Medium rows (ROW_SHORT < candidates <= ROW_MEDIUM): one WAVE per row.  The row's tree face ids
+// are staged in LDS (non-survivors as INT_MAX), every lane ranks its survivors against the whole
+// row with broadcast LDS reads: O(n^2 / 64) per row, no 64 KiB bitmap to clear.
+static constexpr int ROW_MEDIUM = 128;
+
+__global__ void __launch_bounds__(256)
+k_row_fill_medium(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_sid,
+                  const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
+                  const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
+                  double *__restrict__ data, const int32_t *__restrict__ long_rows,
+                  const int32_t *__restrict__ n_long) {
+    __shared__ int32_t sh_sid[4][ROW_MEDIUM];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
+    const int nl = *n_long;
+    int32_t *sid = sh_sid[wv];
+    for (int li = wave; li < nl; li += n_waves) {
+        const int t = long_rows[li];
+        const int c0 = cand_off[t], n = cand_off[t + 1] - c0;
+        if (n > ROW_MEDIUM) continue; // bitmap kernel
+        const int base = indptr[t];
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += 64) sid[i] = cand_area[c0 + i] > 0 ? cand_sid[c0 + i] : 0x7fffffff;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n; i += 64) {
+            const int s = sid[i];
+            if (s == 0x7fffffff) continue;
+            int rank = 0;
+            for (int j = 0; j < n; j++) rank += sid[j] < s ? 1 : 0;
+            const double a = cand_area[c0 + i];
+            indices[base + rank] = s;
+            data[base + rank] = relative ? a / src_area[s] : a;
+        }
+    }
+}
+
 // Long rows: one block per row ranks the survivors by tree face id with an LDS bitmap.
 // The id range is processed in chunks of BM_BITS ids: set one bit per survivor, build word
 // prefix popcounts, rank = (survivors in earlier chunks) + prefix[word] + popc(bits below).
@@ -715,6 +751,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
         const int c0 = cand_off[t], c1 = cand_off[t + 1];
+        if (c1 - c0 <= ROW_MEDIUM) continue; // wave-per-row kernel
         const int base = indptr[t];
         // id range of the survivors
         int lo = 0x7fffffff, hi = -1;
@@ -925,6 +962,9 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             attr_set = true;
         }
+        XR_LAUNCH("row_fill_medium", k_row_fill_medium, dim3(engine().num_cu * 4), dim3(256), 0, cand_off.get(),
+                  cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative,
+                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
                   cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
