@@ -67,6 +67,7 @@ def main():
         results[mode] = rg.regrid(data)
         results[mode + "_1d"] = rg.regrid(data[0])
         results[mode + "_n_local"] = rg.local_faces.size
+        results[mode + "_n_local_targets"] = rg.local_targets.size
     if rank == 0:
         np.savez(os.path.join(out_dir, "dist_out.npz"), world=world, **results)
     dist.barrier()

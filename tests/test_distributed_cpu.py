@@ -58,3 +58,6 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
         np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True)  # summation order differs across shards
         np.testing.assert_allclose(out[mode + "_1d"], exp[0], rtol=1e-12, equal_nan=True)
         assert abs(int(out[mode + "_n_local"]) - sf.shape[0] / 2) <= 1
+    # spatially compact shards only look at the targets near them; hash shards see (almost) all
+    assert int(out["morton_n_local_targets"]) < 0.8 * tf.shape[0]
+    assert int(out["hash_n_local_targets"]) > 0.95 * tf.shape[0]

@@ -2,11 +2,15 @@
 Multi-GPU regridding: one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI),
 SOURCE faces partitioned over the ranks, target mesh replicated (BASELINE north_star).
 
-    rank r:  faces_r = {s : part(s) == r}
-             W_r     = overlap(source[faces_r], target)              # HIP, no communication
-             num_r, den_r = sum_j w v, sum_j w  (v not NaN)          # HIP, per (k, target)
+    rank r:  faces_r = {s : part(s) == r}                            # Morton blocks (or s mod N)
+             targets_r = {t : bbox(t) overlaps bbox(faces_r)}         # only these can get weight from r
+             W_r     = overlap(source[faces_r], target[targets_r])    # HIP, no communication
+             num_r, den_r = sum_j w v, sum_j w  (v not NaN)          # HIP, per (k, target in targets_r)
     all:     reduce_scatter(sum) of [num ; den] over the target axis  # the ONE exchange step
     rank r:  out[k, t] = num / den (NaN where den == 0)  for its slice of targets
+
+With spatially compact shards the per-rank work is ~(S + T) / N plus a boundary layer; only the
+exchange buffer is O(T) per rank (dense reduce-scatter, as the north star specifies).
 
 Only sum-decomposable reducers shard over sources; ``mean`` is implemented (it is the reducer of
 OverlapRegridder's default and of BarycentricInterpolator).  ``mode``, percentiles and
@@ -100,6 +104,50 @@ class HipBackend:
         return out
 
 
+def _face_boxes(xy, faces):
+    valid = faces >= 0
+    safe = np.where(valid, faces, 0)
+    px = np.where(valid, xy[safe, 0], np.nan)
+    py = np.where(valid, xy[safe, 1], np.nan)
+    return np.nanmin(px, axis=1), np.nanmax(px, axis=1), np.nanmin(py, axis=1), np.nanmax(py, axis=1)
+
+
+def _targets_near_shard(src_xy, src_faces, tgt_xy, tgt_faces, n_grid=128):
+    """
+    ids of the target faces that can overlap the given source shard: a coarse occupancy raster of
+    the shard's face bboxes (2-D difference array + cumulative sums), queried with the target face
+    bboxes through an integral image.  Conservative (cell granularity), and -- unlike one bbox per
+    shard -- not spoiled by a few long hull slivers.
+    """
+    n_t = tgt_faces.shape[0]
+    if src_faces.shape[0] == 0 or n_t == 0:
+        return np.zeros(0, dtype=np.int64)
+    sx0, sx1, sy0, sy1 = _face_boxes(src_xy, src_faces)
+    tx0, tx1, ty0, ty1 = _face_boxes(tgt_xy, tgt_faces)
+    x_lo, y_lo = min(sx0.min(), tx0.min()), min(sy0.min(), ty0.min())
+    x_hi, y_hi = max(sx1.max(), tx1.max()), max(sy1.max(), ty1.max())
+    fx = n_grid / max(x_hi - x_lo, 1e-300)
+    fy = n_grid / max(y_hi - y_lo, 1e-300)
+
+    def cells(v, lo, f):
+        return np.clip(np.floor((v - lo) * f).astype(np.int64), 0, n_grid - 1)
+
+    cx0, cx1 = cells(sx0, x_lo, fx), cells(sx1, x_lo, fx)
+    cy0, cy1 = cells(sy0, y_lo, fy), cells(sy1, y_lo, fy)
+    diff = np.zeros((n_grid + 1, n_grid + 1), dtype=np.int64)
+    np.add.at(diff, (cy0, cx0), 1)
+    np.add.at(diff, (cy0, cx1 + 1), -1)
+    np.add.at(diff, (cy1 + 1, cx0), -1)
+    np.add.at(diff, (cy1 + 1, cx1 + 1), 1)
+    occupied = (diff.cumsum(axis=0).cumsum(axis=1)[:n_grid, :n_grid] > 0).astype(np.int64)
+    integral = np.zeros((n_grid + 1, n_grid + 1), dtype=np.int64)
+    integral[1:, 1:] = occupied.cumsum(axis=0).cumsum(axis=1)
+    qx0, qx1 = cells(tx0, x_lo, fx), cells(tx1, x_lo, fx) + 1
+    qy0, qy1 = cells(ty0, y_lo, fy), cells(ty1, y_lo, fy) + 1
+    hits = integral[qy1, qx1] - integral[qy0, qx1] - integral[qy1, qx0] + integral[qy0, qx0]
+    return np.nonzero(hits > 0)[0]
+
+
 def _reduce_scatter_sum(dist, tensor, world_size, group=None):
     """tensor: (world, ...) contiguous -> this rank's (...) slice of the element-wise sum."""
     import torch
@@ -141,9 +189,16 @@ class ShardedOverlapRegridder:
         cen = (xy[safe] * valid[..., None]).sum(axis=1) / cnt[:, None]
         owner = partition_faces(cen, self.world, partition)
         self.local_faces = np.nonzero(owner == self.rank)[0]  # global ids of this rank's sources
+        # only targets whose bbox overlaps the bbox of this rank's source shard can receive weight
+        target_faces = np.asarray(target_faces)
+        txy = np.asarray(target_xy, dtype=np.float64)
+        self.local_targets = _targets_near_shard(xy, source_faces[self.local_faces], txy, target_faces)
         # target rows are cut into `world` equal slices (padded): rank r finalises slice r
         self.t_chunk = -(-self.n_target // self.world)
-        self.weights = backend.build_weights(xy, source_faces[self.local_faces], target_xy, target_faces)
+        self.weights = backend.build_weights(
+            xy, source_faces[self.local_faces], txy, target_faces[self.local_targets]
+        )
+        self._local_targets_dev = backend.to_device(self.local_targets.astype(np.int64))
 
     def rebuild(self):
         self.weights = self.backend.rebuild_weights()
@@ -159,11 +214,11 @@ class ShardedOverlapRegridder:
         """local (K, S_local) device tensor -> this rank's (K, t_chunk) slice of the result."""
         import torch
 
-        nd = self.backend.partial_mean(self.weights, local_source)  # (2, K, T)
-        K = nd.shape[1]
-        pad = self.t_chunk * self.world - self.n_target
-        if pad:
-            nd = torch.nn.functional.pad(nd, (0, pad))
+        part = self.backend.partial_mean(self.weights, local_source)  # (2, K, T_local)
+        K = part.shape[1]
+        t_pad = self.t_chunk * self.world
+        nd = torch.zeros((2, K, t_pad), dtype=part.dtype, device=part.device)
+        nd.index_copy_(2, self._local_targets_dev, part)  # dense exchange buffer, zeros elsewhere
         # (2, K, world, chunk) -> (world, 2, K, chunk): slice w of the target axis goes to rank w
         send = nd.view(2, K, self.world, self.t_chunk).permute(2, 0, 1, 3).contiguous()
         mine = _reduce_scatter_sum(self.dist, send, self.world, self.group)  # (2, K, chunk)
