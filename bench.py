@@ -249,7 +249,7 @@ def run_multi(args):
     # the N-times larger meshes to seconds on every rank (qhull on 4M points takes minutes).
     sxy, sf, txy, tf = make_meshes(args.points * world, delaunay=False)
     S, T = sf.shape[0], tf.shape[0]
-    rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition)
+    rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=args.exchange)
     data = meshgen.smooth_field(sxy[sf].mean(axis=1), 0)
     local = rg.local_source(data)
 
@@ -294,7 +294,8 @@ def run_multi(args):
                 "target_faces": T,
                 "nnz": int(nnz.item()),
                 "parallelism": f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
-                "RCCL reduce-scatter of per-target partial sums",
+                + ("RCCL sparse all-to-all (reduce-scatter restricted to the touched targets) of per-target partial sums"
+                   if args.exchange == "sparse" else "RCCL reduce-scatter of per-target partial sums"),
             },
             "roofline": None,
             "cpu_baseline": None,
@@ -313,6 +314,8 @@ def main():
     ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--partition", default="morton", choices=["morton", "hash"])
+    ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
+                    help="sparse all-to-all of the touched targets (default) or dense reduce-scatter")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))

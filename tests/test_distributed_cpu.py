@@ -51,13 +51,15 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
     q, s, a = oracle.CellTree2d(sxy, sf).intersect_faces(txy, tf)
     exp = oracle.regrid_csr("mean", data, a, s, oracle.to_csr_indptr(q, tf.shape[0]), tf.shape[0])
-    for mode in ("morton", "hash"):
+    for mode in ("morton", "hash", "morton_dense"):
         got = out[mode]
         assert got.shape == exp.shape
         assert np.array_equal(np.isnan(got), np.isnan(exp))
         np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True)  # summation order differs across shards
         np.testing.assert_allclose(out[mode + "_1d"], exp[0], rtol=1e-12, equal_nan=True)
         assert abs(int(out[mode + "_n_local"]) - sf.shape[0] / 2) <= 1
+    # the sparse all-to-all exchange and the dense reduce-scatter agree to the last bit on 2 ranks
+    assert np.array_equal(out["morton"], out["morton_dense"], equal_nan=True)
     # spatially compact shards only look at the targets near them; hash shards see (almost) all
     assert int(out["morton_n_local_targets"]) < 0.8 * tf.shape[0]
     assert int(out["hash_n_local_targets"]) > 0.95 * tf.shape[0]

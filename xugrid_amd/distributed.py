@@ -9,8 +9,14 @@ SOURCE faces partitioned over the ranks, target mesh replicated (SURVEY.md 8e, B
     all:     reduce_scatter(sum) of [num ; den] over the target axis  # the ONE exchange step
     rank r:  out[k, t] = num / den (NaN where den == 0)  for its slice of targets
 
-With spatially compact shards the per-rank work is ~(S + T) / N plus a boundary layer; only the
-exchange buffer is O(T) per rank (dense reduce-scatter, as the north star specifies).
+With spatially compact shards the per-rank work is ~(S + T) / N plus a boundary layer.  The
+exchange step comes in two forms:
+  "dense"   reduce_scatter_tensor over the whole target axis, as worded in the north star: every
+            rank contributes a [2, K, T] buffer (zeros where it has no weight) -- O(T) bytes per rank;
+  "sparse"  (default) the same reduction restricted to the entries that exist: each rank sends, to
+            the owner of every target it touched, that target's (num, den) -- an
+            all_to_all_single of ~T/N rows per rank; the owner adds the contributions sender by
+            sender (deterministic order).  Index lists are exchanged once at set-up.
 
 Only sum-decomposable reducers shard over sources; ``mean`` is implemented (it is the reducer of
 OverlapRegridder's default and of BarycentricInterpolator).  ``mode``, percentiles and
@@ -171,9 +177,13 @@ class ShardedOverlapRegridder:
     arrays; each keeps only its shard of the source faces).
     """
 
-    def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="morton", group=None):
+    def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="morton", group=None,
+                 exchange="sparse"):
         import torch.distributed as dist
 
+        if exchange not in ("sparse", "dense"):
+            raise ValueError(f"unknown exchange mode {exchange!r}")
+        self.exchange = exchange
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
@@ -199,6 +209,28 @@ class ShardedOverlapRegridder:
             xy, source_faces[self.local_faces], txy, target_faces[self.local_targets]
         )
         self._local_targets_dev = backend.to_device(self.local_targets.astype(np.int64))
+        self._setup_sparse_exchange()
+
+    def _setup_sparse_exchange(self):
+        """Who gets which of my partial rows: exchanged once (the weights are fixed)."""
+        import torch
+
+        dist, W = self.dist, self.world
+        owner = self.local_targets // self.t_chunk  # local_targets is ascending -> grouped by owner
+        send_counts = np.bincount(owner, minlength=W).astype(np.int64)
+        cnt_in = torch.as_tensor(send_counts)
+        cnt_out = torch.empty(W, dtype=torch.int64)
+        dev = self._local_targets_dev.device
+        if dist.get_backend(self.group) == "nccl":
+            cnt_in, cnt_out = cnt_in.to(dev), cnt_out.to(dev)
+        dist.all_to_all_single(cnt_out, cnt_in, group=self.group)
+        self._send_counts = [int(c) for c in send_counts]
+        self._recv_counts = [int(c) for c in cnt_out.cpu()]
+        ids_in = self.backend.to_device((self.local_targets - owner * self.t_chunk).astype(np.int64))
+        ids_out = torch.empty(sum(self._recv_counts), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(ids_out, ids_in, output_split_sizes=self._recv_counts,
+                               input_split_sizes=self._send_counts, group=self.group)
+        self._recv_ids = ids_out  # positions inside my slice, grouped by sender
 
     def rebuild(self):
         self.weights = self.backend.rebuild_weights()
@@ -216,6 +248,22 @@ class ShardedOverlapRegridder:
 
         part = self.backend.partial_mean(self.weights, local_source)  # (2, K, T_local)
         K = part.shape[1]
+        if self.exchange == "sparse":
+            # one row of 2K values per touched target, rows grouped by owner rank
+            send = part.permute(2, 0, 1).reshape(part.shape[2], 2 * K).contiguous()
+            recv = torch.empty((sum(self._recv_counts), 2 * K), dtype=part.dtype, device=part.device)
+            self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
+                                        input_split_sizes=self._send_counts, group=self.group)
+            acc = torch.zeros((self.t_chunk, 2 * K), dtype=part.dtype, device=part.device)
+            start = 0
+            for cnt in self._recv_counts:  # sender by sender: ids are unique within a sender
+                if cnt:
+                    ids = self._recv_ids[start:start + cnt]
+                    acc[ids] += recv[start:start + cnt]
+                start += cnt
+            num = acc[:, :K].t().contiguous()
+            den = acc[:, K:].t().contiguous()
+            return self.backend.finalize_mean(num, den)
         t_pad = self.t_chunk * self.world
         nd = torch.zeros((2, K, t_pad), dtype=part.dtype, device=part.device)
         nd.index_copy_(2, self._local_targets_dev, part)  # dense exchange buffer, zeros elsewhere
