@@ -163,6 +163,18 @@ int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int sou
 /* out[i] = den[i] == 0 ? NaN : num[i] / den[i]  for i < count (mean's epilogue, reduce.py:24-27). */
 int xr_finalize_mean_dev(const double *num_dev, const double *den_dev, int64_t count,
                          double *out_dev);
+/* Row layout of the same partial sums, for the sparse exchange (one message row per target):
+ *   rows_dev[t][0..K) = num[k][t],  rows_dev[t][K..2K) = den[k][t]      float64 [T, 2K]
+ * t runs over the CALLER's row order of the matrix. */
+int xr_apply_partial_mean_rows_dev(const xr_csr *csr, const void *source_dev, int source_dtype,
+                                   int64_t K, double *rows_dev);
+/* acc_dev[ids_dev[i]][:] += rows_dev[i][:]  for i < n, rows of `width` float64; the ids of one call
+ * must be distinct (one sender's contribution), so the addition order is deterministic. */
+int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double *rows_dev,
+                           int64_t n, int64_t width);
+/* out_dev[k][t] = acc[t][K+k] == 0 ? NaN : acc[t][k] / acc[t][K+k]   (acc float64 [n_rows, 2K],
+ * out float64 [K, n_rows]). */
+int xr_finalize_mean_rows_dev(const double *acc_dev, int64_t n_rows, int64_t K, double *out_dev);
 
 /* ---- raw HBM helpers for hosts that do not bring their own allocator -------------------- */
 int xr_dev_alloc(int64_t bytes, void **ptr_out);

@@ -44,6 +44,16 @@ class OracleBackend:
             out[1, k] = np.bincount(rows[ok], weights=w.data[ok], minlength=w.n)
         return torch.as_tensor(out)
 
+    def partial_mean_rows(self, w, source):
+        nd = self.partial_mean(w, source)  # (2, K, T)
+        return nd.permute(2, 0, 1).reshape(nd.shape[2], -1).contiguous()
+
+    def accumulate_rows(self, acc, ids, rows):
+        acc[ids] += rows
+
+    def finalize_mean_rows(self, acc, K):
+        return self.finalize_mean(acc[:, :K].t().contiguous(), acc[:, K:].t().contiguous())
+
     def finalize_mean(self, num, den):
         n, d = num.numpy(), den.numpy()
         with np.errstate(invalid="ignore", divide="ignore"):

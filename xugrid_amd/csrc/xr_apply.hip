@@ -796,6 +796,54 @@ k_apply_partial_mean(const int32_t *__restrict__ indptr, const int32_t *__restri
     }
 }
 
+// row layout of the partial sums (sparse multi-GPU exchange): rows[t_out][0..K) = num, [K..2K) = den
+template <typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_partial_mean_rows(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                          const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T,
+                          int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ rows) {
+    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    if (t >= T) return;
+    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
+    const int s = indptr[t], e = indptr[t + 1];
+    Red<XR_MEAN> red[KT];
+    const SRC *src = source + k0 * S;
+    for (int j = s; j < e; j++) {
+        const int64_t col = indices[j];
+        const double w = data[j];
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++)
+            if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, 0.0);
+    }
+    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+    double *row = rows + t_out * 2 * K;
+#pragma unroll
+    for (int kk = 0; kk < KT; kk++) {
+        if (kk < kn) {
+            row[k0 + kk] = red[kk].a;
+            row[K + k0 + kk] = red[kk].b;
+        }
+    }
+}
+
+__global__ void k_accumulate_rows(double *__restrict__ acc, const int64_t *__restrict__ ids,
+                                  const double *__restrict__ rows, int64_t n, int64_t width) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * width) return;
+    const int64_t r = i / width, c = i - r * width;
+    acc[ids[r] * width + c] += rows[i];
+}
+
+__global__ void k_finalize_mean_rows(const double *__restrict__ acc, int64_t n_rows, int64_t K,
+                                     double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * K) return;
+    const int64_t k = i / n_rows, t = i - k * n_rows;
+    const double num = acc[t * 2 * K + k], den = acc[t * 2 * K + K + k];
+    out[i] = den == 0 ? NAN : num / den;
+}
+
 __global__ void k_finalize_mean(const double *__restrict__ num, const double *__restrict__ den, int64_t n,
                                 double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1177,6 +1225,51 @@ int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int sou
             XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<float>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                       static_cast<const float *>(source_dev), K, num, den);
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_apply_partial_mean_rows_dev(const xr_csr *csr, const void *source_dev, int source_dtype, int64_t K,
+                                   double *rows_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && rows_dev, XR_ERR_INVALID, "xr_apply_partial_mean_rows_dev: NULL argument");
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
+               source_dtype);
+    if (csr->n > 0 && K > 0) {
+        dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
+        if (source_dtype == XR_F64)
+            XR_LAUNCH("apply_partial_mean_rows", k_apply_partial_mean_rows<double>, grid, dim3(AP_BLOCK), 0,
+                      csr->indptr.get(), csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                      static_cast<const double *>(source_dev), K, rows_dev);
+        else
+            XR_LAUNCH("apply_partial_mean_rows", k_apply_partial_mean_rows<float>, grid, dim3(AP_BLOCK), 0,
+                      csr->indptr.get(), csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                      static_cast<const float *>(source_dev), K, rows_dev);
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double *rows_dev, int64_t n, int64_t width) {
+    XR_API_BEGIN
+    XR_REQUIRE(n >= 0 && width >= 0, XR_ERR_INVALID, "xr_accumulate_rows_dev: negative size");
+    if (n > 0 && width > 0) {
+        XR_REQUIRE(acc_dev && ids_dev && rows_dev, XR_ERR_INVALID, "xr_accumulate_rows_dev: NULL argument");
+        XR_LAUNCH("accumulate_rows", k_accumulate_rows, dim3(div_up(n * width, 256)), dim3(256), 0, acc_dev, ids_dev,
+                  rows_dev, n, width);
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_finalize_mean_rows_dev(const double *acc_dev, int64_t n_rows, int64_t K, double *out_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(n_rows >= 0 && K >= 0, XR_ERR_INVALID, "xr_finalize_mean_rows_dev: negative size");
+    if (n_rows > 0 && K > 0) {
+        XR_REQUIRE(acc_dev && out_dev, XR_ERR_INVALID, "xr_finalize_mean_rows_dev: NULL argument");
+        XR_LAUNCH("finalize_mean_rows", k_finalize_mean_rows, dim3(div_up(n_rows * K, 256)), dim3(256), 0, acc_dev,
+                  n_rows, K, out_dev);
     }
     stream_sync();
     XR_API_END

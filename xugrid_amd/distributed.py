@@ -109,6 +109,29 @@ class HipBackend:
         self.engine.finalize_mean_dev(num.data_ptr(), den.data_ptr(), num.numel(), out.data_ptr())
         return out
 
+    # ---- row layout used by the sparse exchange
+    def partial_mean_rows(self, weights, source):
+        """-> (T_local, 2K) float64: [num_0..num_K-1, den_0..den_K-1] per target."""
+        torch = self.torch
+        K = source.shape[0]
+        rows = torch.empty((weights.n, 2 * K), dtype=torch.float64, device=self.device)
+        dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
+        torch.cuda.current_stream().synchronize()
+        weights.partial_mean_rows_dev(source.data_ptr(), dtype, K, rows.data_ptr())
+        return rows
+
+    def accumulate_rows(self, acc, ids, rows):
+        """acc[ids] += rows (ids distinct)."""
+        self.torch.cuda.current_stream().synchronize()
+        self.engine.accumulate_rows_dev(acc.data_ptr(), ids.data_ptr(), rows.data_ptr(), rows.shape[0], rows.shape[1])
+
+    def finalize_mean_rows(self, acc, K):
+        """(chunk, 2K) -> (K, chunk)."""
+        out = self.torch.empty((K, acc.shape[0]), dtype=self.torch.float64, device=self.device)
+        self.torch.cuda.current_stream().synchronize()
+        self.engine.finalize_mean_rows_dev(acc.data_ptr(), acc.shape[0], K, out.data_ptr())
+        return out
+
 
 def _face_boxes(xy, faces):
     valid = faces >= 0
@@ -246,24 +269,21 @@ class ShardedOverlapRegridder:
         """local (K, S_local) device tensor -> this rank's (K, t_chunk) slice of the result."""
         import torch
 
-        part = self.backend.partial_mean(self.weights, local_source)  # (2, K, T_local)
-        K = part.shape[1]
+        K = local_source.shape[0]
         if self.exchange == "sparse":
             # one row of 2K values per touched target, rows grouped by owner rank
-            send = part.permute(2, 0, 1).reshape(part.shape[2], 2 * K).contiguous()
-            recv = torch.empty((sum(self._recv_counts), 2 * K), dtype=part.dtype, device=part.device)
+            send = self.backend.partial_mean_rows(self.weights, local_source)  # (T_local, 2K)
+            recv = torch.empty((sum(self._recv_counts), 2 * K), dtype=send.dtype, device=send.device)
             self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
                                         input_split_sizes=self._send_counts, group=self.group)
-            acc = torch.zeros((self.t_chunk, 2 * K), dtype=part.dtype, device=part.device)
+            acc = torch.zeros((self.t_chunk, 2 * K), dtype=send.dtype, device=send.device)
             start = 0
             for cnt in self._recv_counts:  # sender by sender: ids are unique within a sender
                 if cnt:
-                    ids = self._recv_ids[start:start + cnt]
-                    acc[ids] += recv[start:start + cnt]
+                    self.backend.accumulate_rows(acc, self._recv_ids[start:start + cnt], recv[start:start + cnt])
                 start += cnt
-            num = acc[:, :K].t().contiguous()
-            den = acc[:, K:].t().contiguous()
-            return self.backend.finalize_mean(num, den)
+            return self.backend.finalize_mean_rows(acc, K)
+        part = self.backend.partial_mean(self.weights, local_source)  # (2, K, T_local)
         t_pad = self.t_chunk * self.world
         nd = torch.zeros((2, K, t_pad), dtype=part.dtype, device=part.device)
         nd.index_copy_(2, self._local_targets_dev, part)  # dense exchange buffer, zeros elsewhere

@@ -227,12 +227,31 @@ class DeviceCSR:
             )
         )
 
+    def partial_mean_rows_dev(self, source_ptr, dtype, K, rows_ptr):
+        check(
+            _lib.load().xr_apply_partial_mean_rows_dev(
+                self._h, ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(rows_ptr)
+            )
+        )
+
     def partial_mean_dev(self, source_ptr, dtype, K, numden_ptr):
         check(
             _lib.load().xr_apply_partial_mean_dev(
                 self._h, ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(numden_ptr)
             )
         )
+
+
+def accumulate_rows_dev(acc_ptr, ids_ptr, rows_ptr, n, width):
+    check(
+        _lib.load().xr_accumulate_rows_dev(
+            ctypes.c_void_p(acc_ptr), ctypes.c_void_p(ids_ptr), ctypes.c_void_p(rows_ptr), int(n), int(width)
+        )
+    )
+
+
+def finalize_mean_rows_dev(acc_ptr, n_rows, K, out_ptr):
+    check(_lib.load().xr_finalize_mean_rows_dev(ctypes.c_void_p(acc_ptr), int(n_rows), int(K), ctypes.c_void_p(out_ptr)))
 
 
 def finalize_mean_dev(num_ptr, den_ptr, count, out_ptr):
