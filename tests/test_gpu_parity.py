@@ -62,6 +62,19 @@ def test_overlap_triangles_delaunay(hip, oracle):
     assert_overlap_parity(hip, oracle, txy, tf, sxy, sf)  # fine target partly outside the source hull
 
 
+def test_overlap_random_face_numbering(hip, oracle):
+    """Shuffled face numbering on both sides: the engine sorts the target into its spatial query
+    order internally (coherent numberings skip that step) -- results are in the caller's numbering."""
+    rng = np.random.default_rng(42)
+    sxy, sf = meshgen.triangle_mesh(3000, 0)
+    txy, tf = meshgen.triangle_mesh(3000, 1, 30.0, 0.7)
+    sf, tf = sf[rng.permutation(sf.shape[0])], tf[rng.permutation(tf.shape[0])]
+    csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
+    v = meshgen.smooth_field(oracle.centroids(sxy, sf), 3, nan_fraction=0.03)[None, :]
+    assert_apply_equal(csr.apply(v, 0), oracle.regrid_csr("mean", v, data, idx, indptr, csr.n), indptr)
+    assert_overlap_parity(hip, oracle, sxy, sf, txy, tf, relative=True)
+
+
 def test_overlap_clockwise_and_fill_values(hip, oracle):
     sxy, sf = meshgen.triangle_mesh(800, 2)
     txy, tf = meshgen.quad_mesh(np.linspace(0.05, 0.95, 23), np.linspace(0.1, 0.9, 17))

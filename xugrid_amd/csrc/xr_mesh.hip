@@ -10,6 +10,7 @@
 // counting-sorted hierarchical grid gives contiguous, coalescable record runs per query row.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "xr_objects.h"
@@ -67,7 +68,7 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * PREP_BLOCK + threadIdx.x;
 
-    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, ext = 0.0, diag = 0.0;
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY, ext = 0.0, diag = 0.0, jump = 0.0;
     if (f < n_face) {
         int face[MA];
 #pragma unroll
@@ -116,24 +117,30 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
         diag = sqrt(dx * dx + dy * dy);
     }
 
-    // block partials: bounds, sum and max of the bbox extents (fixed order -> deterministic)
-    __shared__ double lds[7][PREP_BLOCK / 64];
+    // numbering coherence: distance between the bbox centres of consecutive faces (within a wave)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const double cx = 0.5 * (xmin + xmax), cy = 0.5 * (ymin + ymax);
+        const double px = __shfl_up(cx, 1, 64), py = __shfl_up(cy, 1, 64);
+        if (lane > 0 && f < n_face) jump = fmax(fabs(cx - px), fabs(cy - py));
+    }
+    // block partials: bounds, sum and max of the bbox extents (fixed order -> deterministic)
+    __shared__ double lds[8][PREP_BLOCK / 64];
     double r0 = wave_min(xmin), r1 = wave_max(xmax), r2 = wave_min(ymin), r3 = wave_max(ymax);
-    double r4 = wave_sum(ext), r5 = wave_max(ext), r6 = wave_max(diag);
+    double r4 = wave_sum(ext), r5 = wave_max(ext), r6 = wave_max(diag), r7 = wave_sum(jump);
     if (lane == 0) {
         lds[0][wave] = r0; lds[1][wave] = r1; lds[2][wave] = r2;
-        lds[3][wave] = r3; lds[4][wave] = r4; lds[5][wave] = r5; lds[6][wave] = r6;
+        lds[3][wave] = r3; lds[4][wave] = r4; lds[5][wave] = r5; lds[6][wave] = r6; lds[7][wave] = r7;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a0 = lds[0][0], a1 = lds[1][0], a2 = lds[2][0], a3 = lds[3][0], a4 = lds[4][0], a5 = lds[5][0], a6 = lds[6][0];
+        double a0 = lds[0][0], a1 = lds[1][0], a2 = lds[2][0], a3 = lds[3][0], a4 = lds[4][0], a5 = lds[5][0], a6 = lds[6][0], a7 = lds[7][0];
         for (int w = 1; w < PREP_BLOCK / 64; w++) {
             a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
-            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]);
+            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]); a7 += lds[7][w];
         }
-        double *p = partials + (int64_t)blockIdx.x * 7;
-        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6;
+        double *p = partials + (int64_t)blockIdx.x * 8;
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6; p[7] = a7;
     }
 }
 
@@ -153,27 +160,29 @@ __global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ no
 
 __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__ partials, int64_t nb,
                                                      double *__restrict__ stats) {
-    double a0 = INFINITY, a1 = -INFINITY, a2 = INFINITY, a3 = -INFINITY, a4 = 0.0, a5 = 0.0, a6 = 0.0;
+    double a0 = INFINITY, a1 = -INFINITY, a2 = INFINITY, a3 = -INFINITY, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     for (int64_t i = threadIdx.x; i < nb; i += 256) {
-        const double *p = partials + i * 7;
+        const double *p = partials + i * 8;
         a0 = fmin(a0, p[0]); a1 = fmax(a1, p[1]); a2 = fmin(a2, p[2]);
-        a3 = fmax(a3, p[3]); a4 += p[4]; a5 = fmax(a5, p[5]); a6 = fmax(a6, p[6]);
+        a3 = fmax(a3, p[3]); a4 += p[4]; a5 = fmax(a5, p[5]); a6 = fmax(a6, p[6]); a7 += p[7];
     }
-    __shared__ double lds[7][4];
+    __shared__ double lds[8][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     a0 = wave_min(a0); a1 = wave_max(a1); a2 = wave_min(a2); a3 = wave_max(a3); a4 = wave_sum(a4); a5 = wave_max(a5);
     a6 = wave_max(a6);
+    a7 = wave_sum(a7);
     if (lane == 0) {
         lds[0][wave] = a0; lds[1][wave] = a1; lds[2][wave] = a2;
-        lds[3][wave] = a3; lds[4][wave] = a4; lds[5][wave] = a5; lds[6][wave] = a6;
+        lds[3][wave] = a3; lds[4][wave] = a4; lds[5][wave] = a5; lds[6][wave] = a6; lds[7][wave] = a7;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) {
             a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
-            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]);
+            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]); a7 += lds[7][w];
         }
         stats[0] = a0; stats[1] = a1; stats[2] = a2; stats[3] = a3; stats[4] = a4; stats[5] = a5; stats[6] = a6;
+        stats[7] = a7;
     }
 }
 
@@ -185,9 +194,9 @@ void mesh_prepare(xr_mesh *mesh) {
     mesh->len.alloc((size_t)F);
     mesh->bbox.alloc((size_t)F * 4);
     mesh->area.alloc((size_t)F);
-    mesh->stats.alloc(7);
+    mesh->stats.alloc(8);
     const int64_t nb = std::max<int64_t>(1, (F + PREP_BLOCK - 1) / PREP_BLOCK);
-    DevBuf<double> partials((size_t)nb * 7);
+    DevBuf<double> partials((size_t)nb * 8);
     dim3 grid((unsigned)nb), block(PREP_BLOCK);
     if (m == 3) {
         XR_LAUNCH("prepare_faces", k_prepare_faces<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
@@ -207,7 +216,7 @@ void mesh_prepare(xr_mesh *mesh) {
 void mesh_read_stats(xr_mesh *mesh) {
     mesh_prepare(mesh);
     if (mesh->stats_valid) return;
-    d2h(mesh->h_stats, mesh->stats.get(), sizeof(double) * 7);
+    d2h(mesh->h_stats, mesh->stats.get(), sizeof(double) * 8);
     mesh->stats_valid = true;
 }
 
@@ -312,6 +321,16 @@ void mesh_query_order(xr_mesh *mesh) {
     mesh_read_stats(mesh);
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
+    // coherent numbering (consecutive faces are, on average, within a few face extents of each
+    // other -- typical for mesh generators, not for qhull output): keep the caller's order
+    static const bool force_sort = getenv("XR_FORCE_QUERY_SORT") != nullptr;
+    const double mean_ext = F > 0 ? mesh->h_stats[4] / (double)F : 0.0;
+    const double mean_jump = F > 0 ? mesh->h_stats[7] / ((double)F * 63.0 / 64.0) : 0.0;
+    mesh->query_identity = !force_sort && (F == 0 || mean_jump <= 4.0 * mean_ext);
+    if (mesh->query_identity) {
+        mesh->query_ready = true;
+        return;
+    }
     mesh->q_perm.alloc((size_t)F);
     mesh->q_fxy.alloc((size_t)F * m * 2);
     mesh->q_len.alloc((size_t)F);
@@ -515,6 +534,7 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     stream_sync();
     mesh->prepared = false;
     mesh->query_ready = false;
+    mesh->query_identity = false;
     mesh->indexed = false;
     mesh->stats_valid = false;
     mesh->fxy.release(); mesh->len.release(); mesh->bbox.release(); mesh->area.release(); mesh->stats.release();

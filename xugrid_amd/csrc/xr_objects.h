@@ -24,12 +24,15 @@ struct xr_mesh {
     xr::DevBuf<uint8_t> len;  // [n_face]
     xr::DevBuf<double> bbox;  // [n_face*4] xmin,xmax,ymin,ymax
     xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order
-    xr::DevBuf<double> stats; // [7] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal (device)
+    xr::DevBuf<double> stats; // [8] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal,sum_jump (device)
     bool stats_valid = false;
-    double h_stats[7] = {0, 0, 0, 0, 0, 0, 0};
+    double h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    // ---- query order
+    // ---- query order.  If the caller's face numbering is already spatially coherent (mean distance
+    // between consecutive faces <= a few face extents) the caller's order IS the query order:
+    // no permutation, no copies (query_identity); the accessors below hide the difference.
     bool query_ready = false;
+    bool query_identity = false;
     xr::DevBuf<int32_t> q_perm; // [n_face] position -> caller's face id
     xr::DevBuf<double> q_fxy;   // [n_face*m*2]
     xr::DevBuf<uint8_t> q_len;  // [n_face]
@@ -45,6 +48,11 @@ struct xr_mesh {
     xr::DevBuf<uint8_t> rec_len;    // [n_face]
 
     int64_t last_candidates = 0;
+
+    const double *qo_fxy() const { return query_identity ? fxy.get() : q_fxy.get(); }
+    const uint8_t *qo_len() const { return query_identity ? len.get() : q_len.get(); }
+    const double *qo_bbox() const { return query_identity ? bbox.get() : q_bbox.get(); }
+    const int32_t *qo_perm() const { return query_identity ? nullptr : q_perm.get(); } // nullptr = identity
 };
 
 // rows with more entries than this are reduced by a whole block in the apply kernels

@@ -842,8 +842,8 @@ static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t
         attr_set = true;
     }
     XR_LAUNCH(MAXV == 8 ? "clip_v8" : (MAXV == 16 ? "clip_v16" : "clip_v64"), (k_clip<MAXV, BLOCK>),
-              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->q_fxy.get(), query->q_len.get(), query->m,
-              query->q_perm.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area,
+              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->qo_fxy(), query->qo_len(), query->m,
+              query->qo_perm(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area,
               redo_only, tree->rec_face.get(), cand_sid, overflow_count, nnz_row);
 }
 
@@ -855,7 +855,7 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)MAXV * BLOCK * sizeof(double2);
         XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
-                  query->q_fxy.get(), query->q_len.get(), query->m, query->q_perm.get(), tree->rec_fxy.get(),
+                  query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
                   overflow_count, nnz_row);
     }
@@ -891,11 +891,11 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     DevBuf<uint8_t> is_big((size_t)T);
     const int big_grid = engine().num_cu * 8;
     DevBuf<int32_t> slots((size_t)T * SLOTS);
-    XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->q_bbox.get(), T, g,
+    XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->qo_bbox(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), slots.get(), is_big.get(), big_list.get(),
               counters.get() + 2);
-    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->q_bbox.get(),
-              query->q_fxy.get(), query->q_len.get(), query->m, g, tree->cell_start.get(),
+    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
+              query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
               tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, (const int32_t *)nullptr,
               cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
     exclusive_scan_i32(cand_count.get(), cand_off.get(), T);
@@ -909,8 +909,8 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     if (C > 0) {
         XR_LAUNCH("compact", k_compact, dim3(div_up(T, 256)), dim3(256), 0, slots.get(), cand_off.get(), is_big.get(),
                   T, cand_tgt.get(), cand_src.get());
-        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->q_bbox.get(),
-                  query->q_fxy.get(), query->q_len.get(), query->m, g, tree->cell_start.get(),
+        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
+                  query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
                   tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
                   (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
         // --- clip (+ per-row survivor counts)
@@ -931,7 +931,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         launch_clip<64, 64>(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), true, cand_sid.get(),
                             counters.get(), nnz_row.get());
         XR_LAUNCH("row_recount", k_row_count, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_area.get(), T,
-                  query->q_perm.get(), nnz_row.get());
+                  query->qo_perm(), nnz_row.get());
         exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
         tail[3] = read_scalar(csr->indptr.get() + T);
     }
@@ -941,10 +941,12 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     csr->indices.alloc((size_t)P);
     csr->data.alloc((size_t)P);
     // rows are best processed in the query mesh's spatial order (apply kernels)
-    csr->row_order.alloc((size_t)T);
-    XR_HIP(hipMemcpyAsync(csr->row_order.get(), query->q_perm.get(), sizeof(int32_t) * (size_t)T,
-                          hipMemcpyDeviceToDevice, st));
-    csr->has_row_order = true;
+    if (query->qo_perm()) {
+        csr->row_order.alloc((size_t)T);
+        XR_HIP(hipMemcpyAsync(csr->row_order.get(), query->qo_perm(), sizeof(int32_t) * (size_t)T,
+                              hipMemcpyDeviceToDevice, st));
+        csr->has_row_order = true;
+    }
     if (P > 0) {
         DevBuf<int32_t> long_rows((size_t)T);
         csr->long_rows.alloc((size_t)(P / XR_APPLY_LONG_ROW + 1));
