@@ -162,7 +162,9 @@ def run_single(args):
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dominant)
+            entry = json.load(open(tpath)).get(dominant)
+            # HBM-side bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)
+            traffic = entry["hbm_bytes_corrected"] if entry else None
         except Exception:
             traffic = None
     build_ms = sum(v for k, v in per_step.items() if not k.startswith("apply"))
