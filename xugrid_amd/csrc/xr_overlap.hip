@@ -492,44 +492,36 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
 #pragma unroll
             for (int j = 0; j < MAXV; j++) {
                 if (j < length) {
+                    // flat body: the only nested divergent region is the division of a crossing
                     const P2 b = in[j];
                     const P2 V{b.x - a.x, b.y - a.y};
-                    if (!(V.x == 0 && V.y == 0)) {
-                        bool b_inside = sh_inside(b, r, U);
-                        // one intersection per boundary crossing, computed in ONE place for both
-                        // crossing directions (same operands and arithmetic as the two S-H branches)
-                        P2 pt{0.0, 0.0};
-                        bool have_pt = false;
-                        if (b_inside != a_inside) have_pt = sh_intersection(a, V, r, N, pt);
-                        if (b_inside) {
-                            if (have_pt) {
-                                if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
-                                else overflow = true;
-                                n_output++;
-                            }
-                            if (n_output < MAXV) out[n_output * BLOCK] = make_double2(b.x, b.y);
-                            else overflow = true;
-                            n_output++;
-                            last = b;
-                        } else if (a_inside) {
-                            if (have_pt) {
-                                if (n_output < MAXV) out[n_output * BLOCK] = make_double2(pt.x, pt.y);
-                                else overflow = true;
-                                n_output++;
-                                last = pt;
-                            } else {
-                                b_inside = true;
-                                if (n_output < MAXV) out[n_output * BLOCK] = make_double2(b.x, b.y);
-                                else overflow = true;
-                                n_output++;
-                                last = b;
-                            }
-                        }
+                    const bool live = !(V.x == 0 && V.y == 0);
+                    bool b_inside = sh_inside(b, r, U);
+                    const bool cross = live && (b_inside != a_inside);
+                    P2 pt{0.0, 0.0};
+                    bool have_pt = false;
+                    if (cross) have_pt = sh_intersection(a, V, r, N, pt);
+                    // S-H emission: entering -> [pt] b ; inside -> b ; leaving -> pt, or (parallel-edge
+                    // quirk) b, which then counts as inside
+                    const bool quirk = cross && !b_inside && !have_pt;
+                    if (cross && have_pt) {
+                        out[(n_output < MAXV ? n_output : MAXV) * BLOCK] = make_double2(pt.x, pt.y);
+                        n_output++;
+                        last = pt;
+                    }
+                    b_inside = b_inside || quirk;
+                    if (live && b_inside) {
+                        out[(n_output < MAXV ? n_output : MAXV) * BLOCK] = make_double2(b.x, b.y);
+                        n_output++;
+                        last = b;
+                    }
+                    if (live) {
                         a = b;
                         a_inside = b_inside;
                     }
                 }
             }
+            overflow = n_output > MAXV;
             if (overflow) break;
             if (n_output < 3) {
                 empty = true;
@@ -853,7 +845,7 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
     const int vmax = query->m + tree->m;
     if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
-        const size_t shmem = (size_t)MAXV * BLOCK * sizeof(double2);
+        const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
         XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
                   query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
