@@ -843,7 +843,15 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
                             int64_t C, double *cand_area, int32_t *cand_sid, int32_t *overflow_count,
                             int32_t *nnz_row) {
     const int vmax = query->m + tree->m;
-    if (vmax <= 8) {
+    if (vmax <= 6) {
+        // triangle x triangle: the clipped polygon never has more than 6 vertices
+        constexpr int MAXV = 6, BLOCK = 256;
+        const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
+        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
+                  query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
+                  tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
+                  overflow_count, nnz_row);
+    } else if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
         XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
