@@ -447,7 +447,7 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int 
 // current length); only the output polygon, whose write index is data dependent, is staged in
 // LDS ([vertex][thread]).  Half the LDS of the generic kernel -> twice the resident waves.
 // The arithmetic and its order are those of k_clip / the oracle.
-template <int MAXV, int BLOCK>
+template <int MAXV, int BLOCK, bool TRI>
 __global__ void __launch_bounds__(BLOCK)
 k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int q_m,
              const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy,
@@ -465,7 +465,8 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
         t = cand_tgt[c];
         const int s = cand_src[c];
         cand_sid[c] = rec_face[s];
-        const int nt = q_len[t], ns = s_len[s];
+        // TRI: both meshes are pure triangle meshes -> vertex counts are compile-time constants
+        const int nt = TRI ? 3 : q_len[t], ns = TRI ? 3 : s_len[s];
         const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
         const double *sf = s_fxy + (int64_t)s * s_m * 2;
         P2 in[MAXV];
@@ -480,9 +481,17 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
         }
         int length = nt;
         bool overflow = false, empty = false;
-        P2 r = load_p2(sf, ns - 1);
-        for (int i = 0; i < ns; i++) {
-            const P2 sv = load_p2(sf, i);
+        // all clipper vertices up front (three independent 16-byte loads for triangles)
+        P2 sv_all[TRI ? 3 : 1];
+        if (TRI) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) sv_all[i] = load_p2(sf, i);
+        }
+        P2 r = TRI ? sv_all[2] : load_p2(sf, ns - 1);
+#pragma unroll
+        for (int i = 0; i < (TRI ? 3 : XR_MAX_FACE_NODES); i++) {
+            if (!TRI && i >= ns) break;
+            const P2 sv = TRI ? sv_all[i] : load_p2(sf, i);
             const P2 U{sv.x - r.x, sv.y - r.y};
             if (U.x == 0 && U.y == 0) continue;
             const P2 N{-U.y, U.x};
@@ -847,14 +856,14 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
         // triangle x triangle: the clipped polygon never has more than 6 vertices
         constexpr int MAXV = 6, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
-        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
+        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
                   query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
                   overflow_count, nnz_row);
     } else if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
-        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
+        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, false>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
                   query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
                   overflow_count, nnz_row);
