@@ -614,8 +614,7 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
            int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ long_rows,
            int32_t *__restrict__ n_long, int32_t *__restrict__ apply_long_rows,
            int32_t *__restrict__ n_apply_long) {
-    __shared__ int32_t sh_src[ROW_LDS];
-    __shared__ double sh_area[ROW_LDS];
+    __shared__ int32_t sh_src[ROW_LDS];  // tree face id of a survivor, INT_MAX for area <= 0
     __shared__ uint16_t sh_row[ROW_LDS];
     __shared__ int32_t sh_c0[256];   // first candidate of the row (global index)
     __shared__ int32_t sh_lds[257];  // LDS offset of the row (short rows only), [256] = total
@@ -660,19 +659,18 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
             const int rc0 = sh_c0[row];
             if (rc0 < 0) continue; // entry of a long row
             const int k = sh_lds[row] + (j - rc0);
-            sh_src[k] = cand_sid[j];
-            sh_area[k] = cand_area[j];
+            sh_src[k] = cand_area[j] > 0 ? cand_sid[j] : 0x7fffffff;
             sh_row[k] = (uint16_t)row;
         }
         __syncthreads();
         for (int k = threadIdx.x; k < total; k += 256) {
-            const double a = sh_area[k];
-            if (!(a > 0)) continue;
+            const int s = sh_src[k];
+            if (s == 0x7fffffff) continue;
             const int row = sh_row[k];
             const int a0 = sh_lds[row], a1 = row == 255 ? total : sh_lds[row + 1];
-            const int s = sh_src[k];
             int rank = 0;
-            for (int i = a0; i < a1; i++) rank += (sh_area[i] > 0 && sh_src[i] < s) ? 1 : 0;
+            for (int i = a0; i < a1; i++) rank += sh_src[i] < s ? 1 : 0;
+            const double a = cand_area[sh_c0[row] + (k - a0)];
             const int pos = sh_ptr[row] + rank;
             indices[pos] = s;
             data[pos] = relative ? a / src_area[s] : a;
