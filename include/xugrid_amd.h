@@ -139,6 +139,17 @@ int xr_csr_upload(const double *data, const int64_t *indices, const int64_t *ind
  * (core/sparse.py:65); indptr = [0, cumsum(bincount(row, minlength=n))] computed on device. */
 int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *data, int64_t nnz,
                         int64_t n, int64_t m, xr_csr **out);
+/* Separable (rectilinear) weights: StructuredGrid2d.broadcast_sorted (xugrid/regrid/structured.py:503-531 =
+ * utils.broadcast, regrid/utils.py:17-36, followed by an argsort on the target index) for the per-axis
+ * triplets of StructuredGrid1d.overlap / linear_weights (structured.py:335-356, :379-403).  Each axis is a
+ * small sparse matrix in CSR form: indptr int64[n_target+1], source index int64[nnz] (ascending within a
+ * row) and weight float64[nnz].  The result is the CSR of their outer product: row jt * n_target_x + it holds
+ * the entries (source_y * n_source_x + source_x, weight_y * weight_x), ordered by column id, assembled on the
+ * device without a sort. */
+int xr_csr_from_outer(const int64_t *indptr_y, const int64_t *source_y, const double *weight_y,
+                      int64_t n_target_y, int64_t n_source_y, const int64_t *indptr_x,
+                      const int64_t *source_x, const double *weight_x, int64_t n_target_x,
+                      int64_t n_source_x, xr_csr **out);
 int xr_csr_destroy(xr_csr *csr);
 
 /* ---- seam 2: apply ---------------------------------------------------------------------- */

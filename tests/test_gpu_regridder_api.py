@@ -53,14 +53,16 @@ def test_overlap_regridder_structured_known_answer(hip):
 
 
 def test_centroid_locator_known_answer(hip):
-    """expected_results_centroid (fixture_regridder.py:240-291).  The inner 2x2 targets have their
-    centroid exactly on a corner shared by four source cells; the reference picks cells 0, 1, 3, 4
-    (= the lowest index, which is this engine's documented tie rule).  The outer ring's centroids
-    lie exactly ON the source boundary: the reference's separable structured search treats them as
-    outside (NaN); through the polygon path a boundary point is within tolerance of an edge, so the
-    touching source cell is used (as the reference's own unstructured path would, regridder.py:369-370)."""
+    """expected_results_centroid (fixture_regridder.py:240-291): a structured pair goes through the separable
+    search, where the outer ring's centroids -- exactly ON the source boundary -- are outside (NaN) and the
+    inner 2x2 targets, whose centroid is a corner shared by four source cells, get cells 0, 1, 3, 4."""
     data = np.arange(9.0).reshape(3, 3)
     out = xa.CentroidLocatorRegridder(raster_a(), raster_b()).regrid(data)
+    assert same_or_nan(out, EXPECTED_CENTROID).all()
+    # the same targets as quads through the polygon path (source promoted too, regridder.py:83-96): a boundary
+    # point is within tolerance of an edge, so the touching source cell is used; ties -> lowest index
+    quads = xa.regrid.StructuredGrid2d(raster_b()).convert_to(xa.regrid.UnstructuredGrid2d).ugrid_topology
+    out = xa.CentroidLocatorRegridder(raster_a(), quads).regrid(data).reshape(4, 4)
     assert np.array_equal(out[1:3, 1:3], EXPECTED_CENTROID[1:3, 1:3])
     ring = np.ones((4, 4), dtype=bool)
     ring[1:3, 1:3] = False
@@ -68,8 +70,11 @@ def test_centroid_locator_known_answer(hip):
     assert (np.isnan(out[ring]) | (out[ring] == touching[ring])).all()
     # strictly interior / exterior points behave as expected
     shifted = xa.Raster(x=[30.0, 80.0, 130.0, 180.0], y=[170.0, 120.0, 70.0, 20.0], dx=50.0, dy=-50.0)
-    out = xa.CentroidLocatorRegridder(raster_a(), shifted).regrid(data)
     expected = np.array([[0, 1, 2, np.nan], [3, 4, 5, np.nan], [6, 7, 8, np.nan], [np.nan] * 4])
+    out = xa.CentroidLocatorRegridder(raster_a(), shifted).regrid(data)
+    assert same_or_nan(out, expected).all()
+    quads = xa.regrid.StructuredGrid2d(shifted).convert_to(xa.regrid.UnstructuredGrid2d).ugrid_topology
+    out = xa.CentroidLocatorRegridder(raster_a(), quads).regrid(data).reshape(4, 4)
     assert same_or_nan(out, expected).all()
 
 
@@ -78,18 +83,28 @@ def test_barycentric_structured_known_answer(hip):
     linear weights equal the unstructured barycentric ones (test_regridder.py:371-405)."""
     data = np.arange(9.0).reshape(3, 3)
     out = xa.BarycentricInterpolator(raster_a(), raster_b()).regrid(data)
+    assert same_or_nan(out, EXPECTED_LINEAR).all()
+    # structured == unstructured on the interior (the ring is ON the boundary: NaN in the separable path,
+    # edge-interpolated values through the polygon path)
+    quads = xa.regrid.StructuredGrid2d(raster_b()).convert_to(xa.regrid.UnstructuredGrid2d).ugrid_topology
+    out = xa.BarycentricInterpolator(raster_a(), quads).regrid(data).reshape(4, 4)
     np.testing.assert_allclose(out[1:3, 1:3], EXPECTED_LINEAR[1:3, 1:3], rtol=1e-12)
-    # ring: centroids exactly ON the source boundary (see test_centroid_locator_known_answer): NaN in the
-    # reference's separable structured path, edge-interpolated values through the polygon path
     ring = np.ones((4, 4), dtype=bool)
     ring[1:3, 1:3] = False
     assert (np.isnan(out[ring]) | ((out[ring] >= 0.0) & (out[ring] <= 8.0))).all()
     # a target strictly inside / outside: NaN exactly where the centroid is outside the source
     shifted = xa.Raster(x=[60.0, 110.0, 160.0, 210.0], y=[140.0, 90.0, 40.0, -10.0], dx=50.0, dy=-50.0)
+    bilinear = 0.8 * 0.8 * 0 + 0.2 * 0.8 * 1 + 0.8 * 0.2 * 3 + 0.2 * 0.2 * 4
     out = xa.BarycentricInterpolator(raster_a(), shifted).regrid(data)
     assert np.isnan(out[:, 3]).all() and np.isnan(out[3, :]).all() and not np.isnan(out[:3, :3]).any()
     # bilinear inside the centroid lattice: (60,140) sits 0.2 / 0.2 into the cell spanned by centroids 0,1,3,4
-    np.testing.assert_allclose(out[0, 0], 0.8 * 0.8 * 0 + 0.2 * 0.8 * 1 + 0.8 * 0.2 * 3 + 0.2 * 0.2 * 4, rtol=1e-12)
+    np.testing.assert_allclose(out[0, 0], bilinear, rtol=1e-12)
+    quads = xa.regrid.StructuredGrid2d(shifted).convert_to(xa.regrid.UnstructuredGrid2d).ugrid_topology
+    out_u = xa.BarycentricInterpolator(raster_a(), quads).regrid(data).reshape(4, 4)
+    assert np.isnan(out_u[:, 3]).all() and np.isnan(out_u[3, :]).all()
+    np.testing.assert_allclose(out_u[0, 0], bilinear, rtol=1e-12)
+    # inside the lattice of source midpoints both paths are the same bilinear interpolation
+    np.testing.assert_allclose(out_u[:2, :2], out[:2, :2], rtol=1e-12)
 
 
 def test_unstructured_identities(hip):

@@ -990,6 +990,47 @@ static void set_long_rows(xr_csr *csr, const std::vector<int32_t> &longs) {
     h2d(csr->n_long.get(), &count, sizeof(int32_t));
 }
 
+// ---- separable (rectilinear) weights: CSR of the outer product of two per-axis sparse matrices.
+// Row (jt, it) of the product holds cy(jt) * cx(it) entries, y-major / x-minor, i.e. ascending in the
+// column id sy * n_source_x + sx when both axis rows are ascending.  The entries of one jt form a
+// contiguous slab of cy * Px entries (Px = nnz of the x axis) that starts at indptr_y[jt] * Px, and
+// entry e of the slab belongs to the x-target that owns x-entry floor(e / cy): offsets have a closed
+// form, so there is no sort and no scan (the reference argsorts the broadcast triplets,
+// xugrid/regrid/structured.py:527).
+__global__ __launch_bounds__(256) void
+k_outer_indptr(const int32_t *__restrict__ ipy, const int32_t *__restrict__ ipx, int64_t nty, int64_t ntx, int64_t Px,
+               int64_t nnz, int32_t *__restrict__ indptr, int32_t *__restrict__ long_rows,
+               int32_t *__restrict__ n_long) {
+    const int64_t T = nty * ntx;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0) indptr[T] = (int32_t)nnz;
+    if (t >= T) return;
+    const int64_t jt = t / ntx, it = t - jt * ntx;
+    const int64_t cy = ipy[jt + 1] - ipy[jt], cx = ipx[it + 1] - ipx[it];
+    indptr[t] = (int32_t)((int64_t)ipy[jt] * Px + cy * ipx[it]);
+    if (cy * cx > XR_APPLY_LONG_ROW) long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
+}
+
+__global__ __launch_bounds__(256) void
+k_outer_fill(const int32_t *__restrict__ ipy, const int32_t *__restrict__ sy, const double *__restrict__ wy,
+             const int32_t *__restrict__ ipx, const int32_t *__restrict__ sx, const double *__restrict__ wx,
+             const int32_t *__restrict__ tx_of_entry, int64_t nty, int64_t nsx, int64_t Px,
+             int32_t *__restrict__ indices, double *__restrict__ data) {
+    for (int64_t jt = blockIdx.y; jt < nty; jt += gridDim.y) {
+        const int y0 = ipy[jt], cy = ipy[jt + 1] - y0;
+        if (cy == 0) continue;
+        const int64_t slab = (int64_t)y0 * Px, n = (int64_t)cy * Px;
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+            const int it = tx_of_entry[e / cy];
+            const int x0 = ipx[it], cx = ipx[it + 1] - x0;
+            const int r = (int)(e - (int64_t)cy * x0);
+            const int a = r / cx, b = r - a * cx;
+            indices[slab + e] = (int32_t)((int64_t)sy[y0 + a] * nsx + sx[x0 + b]);
+            data[slab + e] = wy[y0 + a] * wx[x0 + b];
+        }
+    }
+}
+
 static void upload_narrow(const int64_t *host, int64_t n, int32_t *dev) {
     if (n <= 0) return;
     DevBuf<int64_t> wide((size_t)n);
@@ -1124,6 +1165,83 @@ int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *da
         }
         set_long_rows(csr, longs);
         stream_sync();
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+static void check_axis(const char *name, const int64_t *indptr, const int64_t *source, const double *weight,
+                       int64_t n_target, int64_t n_source) {
+    XR_REQUIRE(indptr, XR_ERR_INVALID, "xr_csr_from_outer: NULL indptr (%s axis)", name);
+    XR_REQUIRE(n_target >= 0 && n_source >= 0, XR_ERR_INVALID, "xr_csr_from_outer: negative size (%s axis)", name);
+    XR_REQUIRE(indptr[0] == 0, XR_ERR_INVALID, "xr_csr_from_outer: indptr[0] != 0 (%s axis)", name);
+    for (int64_t i = 0; i < n_target; i++)
+        XR_REQUIRE(indptr[i + 1] >= indptr[i], XR_ERR_INVALID, "xr_csr_from_outer: indptr decreases at %lld (%s axis)",
+                   (long long)i, name);
+    const int64_t nnz = indptr[n_target];
+    XR_REQUIRE(nnz == 0 || (source && weight), XR_ERR_INVALID, "xr_csr_from_outer: NULL entries (%s axis)", name);
+    for (int64_t i = 0; i < nnz; i++)
+        XR_REQUIRE(source[i] >= 0 && source[i] < n_source, XR_ERR_INVALID,
+                   "xr_csr_from_outer: source index %lld outside [0,%lld) (%s axis)", (long long)source[i],
+                   (long long)n_source, name);
+}
+
+int xr_csr_from_outer(const int64_t *indptr_y, const int64_t *source_y, const double *weight_y, int64_t n_target_y,
+                      int64_t n_source_y, const int64_t *indptr_x, const int64_t *source_x, const double *weight_x,
+                      int64_t n_target_x, int64_t n_source_x, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out, XR_ERR_INVALID, "xr_csr_from_outer: NULL argument");
+    check_axis("y", indptr_y, source_y, weight_y, n_target_y, n_source_y);
+    check_axis("x", indptr_x, source_x, weight_x, n_target_x, n_source_x);
+    const int64_t Py = indptr_y[n_target_y], Px = indptr_x[n_target_x];
+    const int64_t lim = ((int64_t)1 << 31) - 1;
+    XR_REQUIRE(n_target_y == 0 || n_target_x < lim / n_target_y, XR_ERR_LIMIT,
+               "xr_csr_from_outer: target grid exceeds the int32 index range");
+    XR_REQUIRE(n_source_y == 0 || n_source_x <= lim / n_source_y, XR_ERR_LIMIT,
+               "xr_csr_from_outer: source grid exceeds the int32 index range");
+    XR_REQUIRE(Py == 0 || Px < lim / Py, XR_ERR_LIMIT, "xr_csr_from_outer: %lld x %lld entries exceed the int32 range",
+               (long long)Py, (long long)Px);
+    const int64_t n = n_target_y * n_target_x, m = n_source_y * n_source_x, nnz = Py * Px;
+    xr_csr *csr = new xr_csr();
+    try {
+        csr->n = n; csr->m = m; csr->nnz = nnz;
+        csr->indptr.alloc((size_t)n + 1);
+        csr->indices.alloc((size_t)nnz);
+        csr->data.alloc((size_t)nnz);
+        DevBuf<int32_t> ipy((size_t)n_target_y + 1), ipx((size_t)n_target_x + 1), sy((size_t)Py), sx((size_t)Px),
+            tx((size_t)Px);
+        DevBuf<double> wy((size_t)Py), wx((size_t)Px);
+        upload_narrow(indptr_y, n_target_y + 1, ipy.get());
+        upload_narrow(indptr_x, n_target_x + 1, ipx.get());
+        upload_narrow(source_y, Py, sy.get());
+        upload_narrow(source_x, Px, sx.get());
+        h2d(wy.get(), weight_y, sizeof(double) * (size_t)Py);
+        h2d(wx.get(), weight_x, sizeof(double) * (size_t)Px);
+        std::vector<int32_t> owner((size_t)Px);
+        for (int64_t it = 0; it < n_target_x; it++)
+            for (int64_t q = indptr_x[it]; q < indptr_x[it + 1]; q++) owner[(size_t)q] = (int32_t)it;
+        h2d(tx.get(), owner.data(), sizeof(int32_t) * (size_t)Px);
+        csr->long_rows.alloc((size_t)(nnz / XR_APPLY_LONG_ROW + 1));
+        csr->n_long.alloc(1);
+        XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), engine().stream));
+        XR_LAUNCH("outer_indptr", k_outer_indptr, dim3(div_up(n + 1, 256)), dim3(256), 0, ipy.get(), ipx.get(), n_target_y,
+                  n_target_x, Px, nnz, csr->indptr.get(), csr->long_rows.get(), csr->n_long.get());
+        if (nnz > 0) {
+            int64_t max_cy = 0;
+            for (int64_t j = 0; j < n_target_y; j++) max_cy = std::max(max_cy, indptr_y[j + 1] - indptr_y[j]);
+            const int64_t gx = std::min<int64_t>(div_up(max_cy * Px, 256), 1 << 16);
+            const int64_t gy = std::min<int64_t>(n_target_y, 32768);
+            XR_LAUNCH("outer_fill", k_outer_fill, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ipy.get(), sy.get(),
+                      wy.get(), ipx.get(), sx.get(), wx.get(), tx.get(), n_target_y, n_source_x, Px, csr->indices.get(),
+                      csr->data.get());
+        }
+        int32_t nl = 0;
+        XR_HIP(hipMemcpyAsync(&nl, csr->n_long.get(), sizeof(int32_t), hipMemcpyDeviceToHost, engine().stream));
+        stream_sync();
+        csr->has_long = nl > 0;
     } catch (...) {
         delete csr;
         throw;

@@ -200,6 +200,32 @@ class DeviceCSR:
         )
         return cls(handle)
 
+    @classmethod
+    def from_outer(cls, axis_y, n_source_y, axis_x, n_source_x):
+        """
+        CSR of the outer product of two per-axis sparse matrices, each ``(indptr, source, weight)`` with
+        the source indices ascending within a row (StructuredGrid2d.broadcast_sorted, structured.py:503-531).
+        """
+        arrays = []
+        for indptr, source, weight in (axis_y, axis_x):
+            indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+            source = np.ascontiguousarray(source, dtype=np.int64)
+            weight = np.ascontiguousarray(weight, dtype=np.float64)
+            if indptr.ndim != 1 or indptr.size < 1 or source.shape != weight.shape or source.ndim != 1:
+                raise ValueError("inconsistent axis arrays")
+            if indptr[-1] != source.size:
+                raise ValueError("axis indptr does not span its entries")
+            arrays.append((indptr, source, weight))
+        (ipy, sy, wy), (ipx, sx, wx) = arrays
+        handle = ctypes.c_void_p()
+        check(
+            _lib.load().xr_csr_from_outer(
+                _ptr(ipy), _ptr(sy), _ptr(wy), ipy.size - 1, int(n_source_y),
+                _ptr(ipx), _ptr(sx), _ptr(wx), ipx.size - 1, int(n_source_x), ctypes.byref(handle),
+            )
+        )
+        return cls(handle)
+
     def download(self):
         """-> (data float64[nnz], indices intp[nnz], indptr intp[n+1])"""
         data = np.empty(self.nnz, dtype=np.float64)

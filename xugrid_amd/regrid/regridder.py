@@ -48,8 +48,10 @@ def _is_xarray(obj):
 
 
 def convert_to_match(source, target):
-    """regridder.py:83-96.  A structured pair is promoted to quads as well until the separable
-    structured fast path exists."""
+    """regridder.py:83-96: a structured pair stays structured (separable weights); any pair with an
+    unstructured member is promoted to UnstructuredGrid2d (rasters become quads)."""
+    if isinstance(source, StructuredGrid2d) and isinstance(target, StructuredGrid2d):
+        return source, target
     return source.convert_to(UnstructuredGrid2d), target.convert_to(UnstructuredGrid2d)
 
 
@@ -319,6 +321,11 @@ class BarycentricInterpolator(BaseRegridder):
 
     def _compute_weights(self, source, target, tolerance: Optional[float] = None):
         source, target = convert_to_match(source, target)
+        if isinstance(source, StructuredGrid2d):
+            # regridder.py:628-630: linear interpolation between cell midpoints, per axis
+            self._device_weights = source.linear_weights_device(target)
+            self._weights = None
+            return
         source_index, target_index, weights = source.barycentric(target, tolerance)
         self._weights = MatrixCSR.from_triplet(target_index, source_index, weights, n=target.size, m=source.size)
 

@@ -1,10 +1,15 @@
 """
-Rectilinear grids on the regridder boundary: the part of xugrid/regrid/structured.py the
-unstructured hot path needs -- bounds inference of ``StructuredGrid1d``
-(:33-83), ``directional_bounds`` (:110-116), ``coords``/``shape``/``dims`` (:85-108, :454-483) and
-``StructuredGrid2d.convert_to(UnstructuredGrid2d)`` (:489-501).  The separable structured ->
-structured fast paths (:503-601) are SURVEY 8(f) rank 1 ("next"); until they exist a structured
-pair is promoted to quads and goes through the polygon clip like everything else.
+Rectilinear grids on the regridder boundary -- counterpart of xugrid/regrid/structured.py:
+
+  * bounds inference of ``StructuredGrid1d`` (:33-83), ``directional_bounds`` (:110-116),
+    ``coords``/``shape``/``dims`` (:85-108, :454-483) and ``StructuredGrid2d.convert_to(UnstructuredGrid2d)``
+    (:489-501), which is how a raster enters the polygon hot path when the other grid is unstructured;
+  * the separable structured -> structured constructions: per axis ``overlap`` (:335-356,
+    through regrid/overlap_1d.py:162-257), ``locate_centroids`` (:358-377, :118-156) and ``linear_weights``
+    (:379-403, :201-315) are O(n) host numpy exactly as in the reference; what is O(n_y * n_x) -- the outer
+    product of the two axes and its ordering by target cell (``broadcast_sorted`` :503-531, regrid/utils.py:17-36)
+    -- is assembled straight into a device CSR by ``xr_csr_from_outer`` (no argsort: the CSR offsets of an
+    outer product have a closed form).
 
 xarray is optional (absent in this image): a raster is described by ``Raster`` -- the coordinates
 an ``xr.DataArray`` would carry -- or by a real DataArray/Dataset when xarray is importable.
@@ -13,8 +18,61 @@ from typing import Optional
 
 import numpy as np
 
+from .. import engine
 from ..ugrid2d import Ugrid2d
 from .unstructured import UnstructuredGrid2d
+
+IntDType = engine.IntDType
+
+
+def _clipped_search(a, v, side, add):
+    """
+    overlap_1d.py:77-101 for one pair of 1-D arrays: a binary search of ``v`` in the NaN-free part of
+    ``a`` that never looks at its last element (``n = jj - 1``), mapped back to positions of ``a`` and
+    shifted by ``add``, clipped to [0, a.size]; -1 where ``v`` is NaN.
+    """
+    keep = np.flatnonzero(~np.isnan(a))
+    if keep.size == 0:
+        raise ValueError("bounds contain no valid values")
+    packed = a[keep]
+    pos = np.searchsorted(packed[:-1], v, side=side)
+    out = np.clip(keep[pos] + add, 0, a.size)
+    out[np.isnan(v)] = -1
+    return out
+
+
+def _overlap_1d(source_bounds, target_bounds):
+    """
+    overlap_1d.py:246-257: all (source, target) interval pairs with a positive overlap length, target-major,
+    source ascending.  Candidates per target are the sources from the one containing its lower bound to the
+    one containing its upper bound (binary searches as in the reference, :213-218).
+    """
+    sl, su = source_bounds[:, 0], source_bounds[:, 1]
+    tl, tu = target_bounds[:, 0], target_bounds[:, 1]
+    first = _clipped_search(sl, tl, "right", -1)
+    last = _clipped_search(su, tu, "left", 1)
+    count = np.maximum(last - first, 0)
+    total = int(count.sum())
+    t_idx = np.repeat(np.arange(tl.size, dtype=IntDType), count)
+    run_start = np.cumsum(count) - count
+    s_idx = (np.arange(total, dtype=IntDType) - np.repeat(run_start, count) + np.repeat(first, count)).astype(IntDType)
+    length = np.maximum(0.0, np.minimum(su[s_idx], tu[t_idx]) - np.maximum(sl[s_idx], tl[t_idx]))
+    keep = length > 0.0
+    return s_idx[keep], t_idx[keep], length[keep]
+
+
+def _by_target_then_source(source_index, target_index, weights):
+    """Rows of the weight matrix are target cells; within a row we order by source index (the reference's
+    own within-row order is whatever its non-stable argsort leaves, structured.py:333)."""
+    order = np.lexsort((weights, source_index, target_index))
+    return source_index[order], target_index[order], weights[order]
+
+
+def _axis_csr(source_index, target_index, weights, n_target):
+    """(indptr, source, weight) of one axis; entries already ordered by (target, source)."""
+    indptr = np.zeros(n_target + 1, dtype=np.int64)
+    np.cumsum(np.bincount(target_index, minlength=n_target), out=indptr[1:])
+    return indptr, np.ascontiguousarray(source_index, dtype=np.int64), np.ascontiguousarray(weights, dtype=np.float64)
 
 
 class Raster:
@@ -117,6 +175,65 @@ class StructuredGrid1d:
     def directional_bounds(self):
         return self.bounds[::-1, :].copy() if self.flipped else self.bounds
 
+    def flip_if_needed(self, index):
+        return self.size - index - 1 if self.flipped else index
+
+    # ---- structured -> structured, one axis (all return triplets ordered by target, then source)
+    def overlap(self, other: "StructuredGrid1d", relative: bool):
+        """Overlap length of every (source, target) cell pair (structured.py:183-206, :335-356)."""
+        source_index, target_index, weights = _overlap_1d(self.bounds, other.bounds)
+        source_index = self.flip_if_needed(source_index)
+        target_index = other.flip_if_needed(target_index)
+        if relative:
+            # as the reference: ``length`` is in ascending-coordinate order, the index already flipped (:354-355)
+            weights = weights / self.length[source_index]
+        return _by_target_then_source(source_index, target_index, weights)
+
+    def valid_nodes_within_bounds(self, other: "StructuredGrid1d"):
+        """Source cell containing each target midpoint (structured.py:118-156)."""
+        start = np.searchsorted(self.bounds[:, 0], other.midpoints, side=self.side)
+        end = np.searchsorted(self.bounds[:, 1], other.midpoints, side=self.side)
+        valid = (start == (end + 1)) & (other.midpoints > self.bounds[0, 0]) & (other.midpoints < self.bounds[-1, 1])
+        valid_other_index = np.arange(other.size, dtype=IntDType)[valid]
+        valid_self_index = end[valid].astype(IntDType)
+        return self.flip_if_needed(valid_self_index), other.flip_if_needed(valid_other_index)
+
+    def locate_centroids(self, other: "StructuredGrid1d"):
+        """structured.py:358-377."""
+        source_index, target_index = self.valid_nodes_within_bounds(other)
+        weights = np.ones(source_index.size, dtype=float)
+        return _by_target_then_source(source_index, target_index, weights)
+
+    def linear_weights(self, other: "StructuredGrid1d"):
+        """
+        Two-point linear interpolation between source midpoints (structured.py:379-403, :201-315): each
+        located target gets (source, w) and (neighbour, 1 - w); outside the outermost midpoints the
+        neighbour collapses onto the source cell itself (weights 0 and 1).
+        """
+        if self.midpoints.size < 2:
+            raise ValueError(
+                f"Coordinate {self.name} has size: {self.midpoints.size}. "
+                "At least two points are required for interpolation."
+            )
+        source_index, target_index = self.valid_nodes_within_bounds(other)
+        src_mid = self.flip_if_needed(source_index)  # position in the ascending midpoints
+        tgt_mid = other.flip_if_needed(target_index)
+        step = np.where(other.midpoints[tgt_mid] <= self.midpoints[src_mid], -1, 1)
+        neighbour_mid = np.clip(src_mid + step, 0, self.midpoints.size - 1)
+        step = neighbour_mid - src_mid
+        length = other.midpoints[tgt_mid] - self.midpoints[src_mid]
+        total_length = self.midpoints[neighbour_mid] - self.midpoints[src_mid]
+        total_length[total_length == 0] = 1
+        weights = 1 - (length / total_length)
+        weights[step == 0] = 0.0
+        if self.flipped:
+            step = -step
+        pair_source = np.column_stack((source_index, source_index + step)).ravel()
+        pair_target = np.repeat(target_index, 2)
+        pair_weights = np.column_stack((weights, 1.0 - weights)).ravel()
+        valid = (pair_source <= self.size - 1) & (pair_source >= 0)
+        return _by_target_then_source(pair_source[valid], pair_target[valid], pair_weights[valid])
+
 
 class StructuredGrid2d:
     """Raster topology; face id of cell (iy, ix) = iy * nx + ix in the raster's own order."""
@@ -161,6 +278,50 @@ class StructuredGrid2d:
                 self._unstructured = UnstructuredGrid2d(ugrid2d)
             return self._unstructured
         raise TypeError(f"Cannot convert StructuredGrid2d to {matched_type.__name__}")
+
+    # ---- structured -> structured (structured.py:503-601)
+    def _axes(self, other: "StructuredGrid2d", kind: str, relative: bool = False):
+        if kind == "overlap":
+            return self.ybounds.overlap(other.ybounds, relative), self.xbounds.overlap(other.xbounds, relative)
+        if kind == "locate_centroids":
+            return self.ybounds.locate_centroids(other.ybounds), self.xbounds.locate_centroids(other.xbounds)
+        if kind == "linear_weights":
+            return self.ybounds.linear_weights(other.ybounds), self.xbounds.linear_weights(other.xbounds)
+        raise ValueError(kind)
+
+    def _outer_host(self, other, axes):
+        """broadcast_sorted (structured.py:503-531) on the host: (source_index, target_index, weights) ordered
+        by target cell, then source cell.  O(P) numpy; the regridders use ``_outer_device`` instead."""
+        (sy, ty, wy), (sx, tx, wx) = axes
+        iy, ix = np.meshgrid(np.arange(sy.size), np.arange(sx.size), indexing="ij")
+        iy, ix = iy.ravel(), ix.ravel()
+        source_index = (sy[iy] * self.xbounds.size + sx[ix]).astype(IntDType)
+        target_index = (ty[iy] * other.xbounds.size + tx[ix]).astype(IntDType)
+        weights = wy[iy] * wx[ix]
+        return _by_target_then_source(source_index, target_index, weights)
+
+    def _outer_device(self, other, axes) -> "engine.DeviceCSR":
+        (sy, ty, wy), (sx, tx, wx) = axes
+        return engine.DeviceCSR.from_outer(
+            _axis_csr(sy, ty, wy, other.ybounds.size), self.ybounds.size,
+            _axis_csr(sx, tx, wx, other.xbounds.size), self.xbounds.size,
+        )
+
+    def overlap(self, other: "StructuredGrid2d", relative: bool):
+        return self._outer_host(other, self._axes(other, "overlap", relative))
+
+    def overlap_device(self, other: "StructuredGrid2d", relative: bool):
+        """The (relative) overlap weights as a device CSR: rows = target cells (row-major y, x)."""
+        return self._outer_device(other, self._axes(other, "overlap", relative))
+
+    def locate_centroids(self, other: "StructuredGrid2d", tolerance=None):
+        return self._outer_host(other, self._axes(other, "locate_centroids"))
+
+    def linear_weights(self, other: "StructuredGrid2d"):
+        return self._outer_host(other, self._axes(other, "linear_weights"))
+
+    def linear_weights_device(self, other: "StructuredGrid2d"):
+        return self._outer_device(other, self._axes(other, "linear_weights"))
 
     def to_dataset(self, name: str):
         return {
