@@ -188,7 +188,20 @@ k_apply_long(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         for (int64_t k = blockIdx.y; k < K; k += gridDim.y) {
             const SRC *src = source + k * S;
             Red<METHOD> r;
-            for (int j = s + threadIdx.x; j < e; j += AP_BLOCK) r.add(ld_src(src, indices[j]), data[j], normsum);
+            int j = s + threadIdx.x;
+            // four entries in flight per thread; the additions keep their sequential order
+            for (; j + 3 * AP_BLOCK < e; j += 4 * AP_BLOCK) {
+                const int c0 = indices[j], c1 = indices[j + AP_BLOCK], c2 = indices[j + 2 * AP_BLOCK],
+                          c3 = indices[j + 3 * AP_BLOCK];
+                const double w0 = data[j], w1 = data[j + AP_BLOCK], w2 = data[j + 2 * AP_BLOCK],
+                             w3 = data[j + 3 * AP_BLOCK];
+                const double v0 = ld_src(src, c0), v1 = ld_src(src, c1), v2 = ld_src(src, c2), v3 = ld_src(src, c3);
+                r.add(v0, w0, normsum);
+                r.add(v1, w1, normsum);
+                r.add(v2, w2, normsum);
+                r.add(v3, w3, normsum);
+            }
+            for (; j < e; j += AP_BLOCK) r.add(ld_src(src, indices[j]), data[j], normsum);
             block_merge<METHOD>(r, lds);
             if (threadIdx.x == 0) {
                 double v = r.fin();
@@ -226,11 +239,34 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
     }
     const bool is_long = skip_long && (e - s > APPLY_LONG); // reduced by k_apply_long instead
     if (is_long) e = s;
+    // A block that holds long rows must not stream their entries: the chunk loop then jumps to the
+    // first entry of the next row that still has work (block-wide minimum), skipping whole long rows.
+    __shared__ int sh_next;
+    const bool jumpy = skip_long && __syncthreads_or(is_long);
+    auto next_chunk = [&](int c0) -> int {
+        if (!jumpy) {
+            __syncthreads();
+            return c0;
+        }
+        int mine = (e > s && e > c0) ? (s > c0 ? s : c0) : INT_MAX;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(mine, o);
+            mine = other < mine ? other : mine;
+        }
+        __syncthreads(); // readers of the previous chunk (and of sh_next) are done
+        if (threadIdx.x == 0) sh_next = INT_MAX;
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0 && mine != INT_MAX) atomicMin(&sh_next, mine);
+        __syncthreads();
+        return sh_next;
+    };
     const SRC *src = source + k0 * S;
     double normsum = 0.0;
     if (METHOD == XR_GEOMETRIC_MEAN) {
         for (int c0 = seg0; c0 < seg1; c0 += CH) {
-            __syncthreads();
+            c0 = next_chunk(c0);
+            if (c0 >= seg1) break;
             for (int j = c0 + threadIdx.x; j < c0 + CH && j < seg1; j += AP_BLOCK) sh_w[j - c0] = data[j];
             __syncthreads();
             const int a = s > c0 ? s : c0, b = e < c0 + CH ? e : c0 + CH;
@@ -239,7 +275,8 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
     }
     Red<METHOD> red[KTILE];
     for (int c0 = seg0; c0 < seg1; c0 += CH) {
-        __syncthreads();
+        c0 = next_chunk(c0);
+        if (c0 >= seg1) break;
         {
             constexpr int PER = CH / AP_BLOCK;
             int col[PER];
@@ -894,7 +931,8 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         }
     }
     if (csr->has_long) {
-        dim3 grid((unsigned)engine().num_cu, (unsigned)(K < 8 ? K : 8));
+        const unsigned gy = (unsigned)(K < 8 ? K : 8);
+        dim3 grid((unsigned)engine().num_cu * (8 / gy), gy); // 8 blocks per CU; blocks past n_long exit at once
         XR_LAUNCH("apply_long", (k_apply_long<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
                   csr->n, csr->m, src, K, out);
