@@ -126,6 +126,19 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
 int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolerance,
                    int64_t *face_index_out, double *weights_out);
 
+/* The whole of UnstructuredGrid2d.barycentric after the Voronoi pre-step (xugrid/regrid/unstructured.py:166-201),
+ * assembled on the device: compute_barycentric_weights of the query points in the centroidal Voronoi mesh
+ * `voronoi` (ugrid2d.py:1054-1078), replace_interpolated_weights (unstructured.py:17-57) for the synthetic exterior
+ * vertices (the last n_extra Voronoi vertices; node_to_node_map int64[n_extra, 2]), zero rows for points outside
+ * `source` (locate_points == -1 with the default tolerance, :188-190), weights > 0 only (:191-198), Voronoi
+ * vertices mapped to source faces through vertex_face int64[n_vertex] (node_to_face_index).  The query points are
+ * either `points` float64[n, 2] (query == NULL) or the face centroids of the mesh `query` (points == NULL; computed
+ * on the device, nothing crosses PCIe).  Result: MatrixCSR.from_triplet(target, source, weights) (regridder.py:634-636)
+ * with n rows (points) and source->n_face columns, entries of a row in Voronoi-vertex slot order. */
+int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points,
+                       int64_t n, double tolerance, const int64_t *vertex_face,
+                       const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
+
 /* ---- seam 3: MatrixCSR handle ----------------------------------------------------------- */
 int xr_csr_info(const xr_csr *csr, int64_t *n, int64_t *m, int64_t *nnz);
 /* Copy out as the reference's MatrixCSR fields (core/sparse.py:81-137): data float64[nnz],

@@ -217,3 +217,71 @@ def test_celltree_adapter_matches_numba_celltree_call_shape(hip, oracle):
     assert i.dtype == np.intp and j.dtype == np.intp and a.dtype == np.float64
     assert np.array_equal(i, oi) and np.array_equal(j, oj) and np.array_equal(a, oa)
     assert (np.diff(i) >= 0).all()
+
+
+def _oracle_barycentric_triplets(oracle, grid, points, tolerance=None):
+    """unstructured.py:146-201 step by step with the CPU oracle (Voronoi pre-step: xugrid_amd.voronoi, pinned by G6)."""
+    from xugrid_amd import voronoi
+
+    xy = grid.node_coordinates
+    faces = grid.face_node_connectivity
+    vertices, vfaces, node_to_face_index, n2n = voronoi.voronoi_topology(
+        grid.node_face_connectivity, xy, oracle.centroids(xy, faces),
+        edge_face_connectivity=grid.edge_face_connectivity, edge_node_connectivity=grid.edge_node_connectivity,
+        add_exterior=True, add_vertices=True, skip_concave=True,
+    )
+    vtree = oracle.CellTree2d(vertices, vfaces, -1)
+    face_index, weights = vtree.compute_barycentric_weights(points, tolerance)
+    oracle.replace_interpolated_weights(vertices, vtree.faces, face_index, weights, n2n, len(vertices) - len(n2n))
+    outside = oracle.CellTree2d(xy, faces, -1).locate_points(points) == -1
+    weights[outside] = 0
+    keep = weights.ravel() > 0
+    source_index = node_to_face_index[vtree.faces[face_index]].ravel()[keep]
+    n, m = weights.shape
+    target_index = np.repeat(np.arange(n), m)[keep]
+    return source_index, target_index, weights.ravel()[keep]
+
+
+@pytest.mark.parametrize("kind", ["tri", "quad"])
+def test_barycentric_device_pipeline(hip, oracle, kind):
+    """The device-assembled CSR (xr_barycentric_csr) == the step-by-step host path == the oracle, bit for bit;
+    the target sticks out of the source so that exterior Voronoi cells, replaced weights and outside points occur."""
+    if kind == "tri":
+        sxy, sf = meshgen.triangle_mesh(1500, 21)
+    else:
+        rng = np.random.default_rng(4)
+        sxy, sf = meshgen.quad_mesh(np.cumsum(rng.uniform(0.5, 1.5, 31)), np.cumsum(rng.uniform(0.5, 1.5, 27)))
+    txy, tf = meshgen.triangle_mesh(2500, 22)
+    lo, hi = sxy.min(axis=0), sxy.max(axis=0)
+    txy = lo + (hi - lo) * (0.5 + 1.12 * ((txy - txy.min(axis=0)) / (txy.max(axis=0) - txy.min(axis=0)) - 0.5))
+    src = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    us, ut = xa.regrid.UnstructuredGrid2d(src), xa.regrid.UnstructuredGrid2d(tgt)
+    for tol in (None, 1e-9):
+        dcsr = us.barycentric_device(ut, tol)
+        data, indices, indptr = dcsr.download()
+        rows = np.repeat(np.arange(dcsr.n), np.diff(indptr))
+        hs, ht, hw = us.barycentric(ut, tol)
+        assert (dcsr.n, dcsr.m) == (tgt.n_face, src.n_face)
+        assert np.array_equal(indices, hs) and np.array_equal(rows, ht) and np.array_equal(data, hw)
+        os_, ot, ow = _oracle_barycentric_triplets(oracle, src, tgt.centroids, tol)
+        assert np.array_equal(indices, os_) and np.array_equal(rows, ot) and np.array_equal(data, ow)
+        outside_rows = np.diff(indptr) == 0
+        assert 0 < outside_rows.sum() < tgt.n_face
+        sums = np.bincount(rows, weights=data, minlength=dcsr.n)
+        # rows sum to one, except in (concave) exterior Voronoi cells where negative Wachspress weights are
+        # dropped by the weights > 0 filter (unstructured.py:191) -- a thin boundary layer
+        assert (np.abs(sums[~outside_rows] - 1.0) < 1e-12).mean() > 0.9
+    rg = xa.BarycentricInterpolator(src, tgt)
+    z = 2.0 * src.centroids[:, 0] - 3.0 * src.centroids[:, 1] + 1.0
+    out = rg.regrid(z)
+    assert np.array_equal(np.isnan(out), outside_rows)
+    # the regridder agrees with the oracle apply on the oracle's weights
+    expected = oracle.regrid_csr("mean", z[None], ow, os_, oracle.to_csr_indptr(ot, tgt.n_face), tgt.n_face)[0]
+    assert same_or_nan(out, expected).all()
+    # explicit points instead of a query mesh
+    from xugrid_amd import engine
+    vg, _, _, v2f, n2n = us._voronoi()
+    c2 = engine.barycentric_csr(vg.device_mesh, src.device_mesh, v2f, n2n, points=tgt.centroids)
+    d2, i2, p2 = c2.download()
+    assert np.array_equal(d2, data) and np.array_equal(i2, indices) and np.array_equal(p2, indptr)

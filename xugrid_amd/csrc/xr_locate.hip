@@ -158,6 +158,83 @@ k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
     if (r >= 0) bary_weights(rec_fxy + (int64_t)r * m * 2, rec_len[r], p, tol, w);
 }
 
+// ---- BarycentricInterpolator weights assembled on the device (xr_barycentric_csr) ----------------
+
+__global__ void __launch_bounds__(256)
+k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+              const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+              uint8_t *__restrict__ inside) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const P2 p = load_p2(pts, (int)i);
+    inside[i] = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol) >= 0;
+}
+
+// replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) on the point's own row, then the
+// masking of unstructured.py:188-191 (points outside the source grid; weights > 0), counted per point.
+// Same statement order as oracle/xr_oracle.c:xo_replace_interpolated_weights.
+__global__ void __launch_bounds__(256)
+k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__ weights, int m,
+                 const int64_t *__restrict__ faces_ccw, const double *__restrict__ vxy,
+                 const int64_t *__restrict__ node_to_node_map, int64_t threshold,
+                 const uint8_t *__restrict__ inside, int64_t n, int32_t *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t f = face_of_point[i];
+    int c = 0;
+    if (f >= 0) {
+        double *w = weights + i * m;
+        if (!inside[i]) {
+            for (int j = 0; j < m; j++) w[j] = 0.0;
+        } else {
+            const int64_t *face = faces_ccw + f * m;
+            for (int j = 0; j < m; j++) {
+                const int64_t pidx = face[j];
+                const double wj = w[j];
+                if (pidx < threshold || wj <= 0) continue;
+                const int64_t index = pidx - threshold;
+                const int64_t q = node_to_node_map[2 * index], r = node_to_node_map[2 * index + 1];
+                const double px = vxy[2 * pidx], py = vxy[2 * pidx + 1];
+                const double qx = vxy[2 * q], qy = vxy[2 * q + 1];
+                const double rx = vxy[2 * r], ry = vxy[2 * r + 1];
+                const double p_q = sqrt((qx - px) * (qx - px) + (qy - py) * (qy - py));
+                const double p_r = sqrt((rx - px) * (rx - px) + (ry - py) * (ry - py));
+                const double total = p_q + p_r;
+                const double weight_q = (p_r / total) * wj;
+                const double weight_r = (p_q / total) * wj;
+                w[j] = 0.0;
+                for (int jj = 0; jj < m; jj++) {
+                    if (face[jj] == q) w[jj] += weight_q;
+                    if (face[jj] == r) w[jj] += weight_r;
+                }
+            }
+            for (int j = 0; j < m; j++) c += w[j] > 0;
+        }
+    }
+    count[i] = c;
+}
+
+__global__ void __launch_bounds__(256)
+k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict__ weights, int m,
+            const int64_t *__restrict__ faces_ccw, const int64_t *__restrict__ vertex_face,
+            const int32_t *__restrict__ indptr, int64_t n, int32_t *__restrict__ indices,
+            double *__restrict__ data) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int pos = indptr[i];
+    if (indptr[i + 1] == pos) return;
+    const int64_t *face = faces_ccw + face_of_point[i] * m;
+    const double *w = weights + i * m;
+    for (int j = 0; j < m; j++) {
+        if (w[j] > 0) {
+            indices[pos] = (int32_t)vertex_face[face[j]];
+            data[pos] = w[j];
+            pos++;
+        }
+    }
+}
+
 static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
     if (tolerance >= 0) return tolerance;
     mesh_read_stats(mesh);
@@ -224,6 +301,75 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
             for (int64_t i = 0; i < n * m; i++) weights_out[i] = 0.0;
         }
     }
+    XR_API_END
+}
+
+int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
+                       double tolerance, const int64_t *vertex_face, const int64_t *node_to_node_map, int64_t n_extra,
+                       xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(voronoi && source && out && vertex_face, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
+    XR_REQUIRE((query != nullptr) != (points != nullptr), XR_ERR_INVALID,
+               "xr_barycentric_csr: give either a query mesh (its face centroids are the points) or points");
+    if (query) n = query->n_face;
+    XR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "xr_barycentric_csr: too many points");
+    XR_REQUIRE(n_extra >= 0 && n_extra <= voronoi->n_node && (n_extra == 0 || node_to_node_map), XR_ERR_INVALID,
+               "xr_barycentric_csr: bad node_to_node_map");
+    const int64_t nv = voronoi->n_node;
+    for (int64_t i = 0; i < 2 * n_extra; i++)
+        XR_REQUIRE(node_to_node_map[i] >= 0 && node_to_node_map[i] < nv, XR_ERR_INVALID,
+                   "xr_barycentric_csr: node_to_node_map entry %lld outside [0,%lld)", (long long)i, (long long)nv);
+    for (int64_t i = 0; i < nv - n_extra; i++)
+        XR_REQUIRE(vertex_face[i] >= 0 && vertex_face[i] < source->n_face, XR_ERR_INVALID,
+                   "xr_barycentric_csr: vertex_face[%lld] outside the source grid", (long long)i);
+    const int m = voronoi->m;
+    xr_csr *csr = new xr_csr();
+    try {
+        csr->n = n; csr->m = source->n_face; csr->nnz = 0;
+        csr->indptr.alloc((size_t)n + 1);
+        if (n == 0 || voronoi->n_face == 0 || source->n_face == 0) {
+            fill_i32(csr->indptr.get(), 0, n + 1);
+            csr->indices.alloc(0);
+            csr->data.alloc(0);
+            stream_sync();
+        } else {
+            mesh_prepare(voronoi); mesh_build_index(voronoi);
+            mesh_prepare(source); mesh_build_index(source);
+            const double tol = resolve_tolerance(voronoi, tolerance);
+            const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
+            DevBuf<double> pts((size_t)n * 2), w((size_t)n * m);
+            if (query) mesh_centroids_dev(query, pts.get());
+            else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)voronoi->n_face * m), vface((size_t)nv),
+                n2n((size_t)(n_extra > 0 ? 2 * n_extra : 1));
+            DevBuf<uint8_t> inside((size_t)n);
+            DevBuf<int32_t> count((size_t)n);
+            h2d(vface.get(), vertex_face, sizeof(int64_t) * (size_t)nv);
+            if (n_extra > 0) h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_extra);
+            mesh_faces_ccw_dev(voronoi, faces_ccw.get());
+            XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
+                      voronoi->rec_len.get(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
+                      voronoi->rec_face.get(), pts.get(), n, tol, face.get(), w.get());
+            XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
+                      source->rec_len.get(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
+                      source->rec_face.get(), pts.get(), n, tol_source, inside.get());
+            XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                      faces_ccw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
+            exclusive_scan_i32(count.get(), csr->indptr.get(), n);
+            const int64_t nnz = read_scalar(csr->indptr.get() + n);
+            csr->nnz = nnz;
+            csr->indices.alloc((size_t)nnz);
+            csr->data.alloc((size_t)nnz);
+            if (nnz > 0)
+                XR_LAUNCH("bary_fill", k_bary_fill, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                          faces_ccw.get(), vface.get(), csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+            stream_sync();
+        }
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
     XR_API_END
 }
 

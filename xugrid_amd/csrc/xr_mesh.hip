@@ -441,6 +441,19 @@ __global__ void __launch_bounds__(256) k_centroids(const double *__restrict__ no
     cxy[2 * f + 1] = aw * sy + p0.y;
 }
 
+// device-resident variants used by other translation units (no host copy)
+void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev) {
+    if (mesh->n_face > 0)
+        XR_LAUNCH("centroids", k_centroids, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
+                  mesh->faces_raw.get(), mesh->n_face, mesh->m, cxy_dev);
+}
+
+void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev) {
+    if (mesh->n_face > 0)
+        XR_LAUNCH("faces_ccw", k_faces_ccw, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
+                  mesh->faces_raw.get(), mesh->n_face, mesh->m, faces_dev);
+}
+
 } // namespace xr
 
 using namespace xr;

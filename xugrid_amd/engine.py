@@ -141,6 +141,35 @@ class DeviceMesh:
         return face.astype(IntDType, copy=False), w
 
 
+def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,
+                    points=None, tolerance=None) -> "DeviceCSR":
+    """UnstructuredGrid2d.barycentric after the Voronoi pre-step, on the device (see include/xugrid_amd.h)."""
+    vertex_face = np.ascontiguousarray(vertex_face, dtype=np.int64)
+    if vertex_face.shape != (voronoi.n_node,):
+        raise ValueError("vertex_face must have one entry per Voronoi vertex")
+    if node_to_node_map is None:
+        n2n = np.zeros((0, 2), dtype=np.int64)
+    else:
+        n2n = np.ascontiguousarray(node_to_node_map, dtype=np.int64).reshape(-1, 2)
+    tol = -1.0 if tolerance is None else float(tolerance)
+    if tolerance is not None and tol < 0:
+        raise ValueError("tolerance must be non-negative")
+    if (query is None) == (points is None):
+        raise ValueError("give either a query mesh or points")
+    if points is not None:
+        pts = _as_xy(points)
+        p_arg, n, q_arg = _ptr(pts), pts.shape[0], None
+    else:
+        p_arg, n, q_arg = None, query.n_face, query._h
+    handle = ctypes.c_void_p()
+    check(
+        _lib.load().xr_barycentric_csr(
+            voronoi._h, source._h, q_arg, p_arg, n, tol, _ptr(vertex_face), _ptr(n2n), n2n.shape[0], ctypes.byref(handle)
+        )
+    )
+    return DeviceCSR(handle)
+
+
 def _source_2d(source):
     """(K, S) C-contiguous float64/float32 view of the source block (regridder.py:152-163)."""
     a = np.asarray(source)

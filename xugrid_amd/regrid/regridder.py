@@ -326,8 +326,8 @@ class BarycentricInterpolator(BaseRegridder):
             self._device_weights = source.linear_weights_device(target)
             self._weights = None
             return
-        source_index, target_index, weights = source.barycentric(target, tolerance)
-        self._weights = MatrixCSR.from_triplet(target_index, source_index, weights, n=target.size, m=source.size)
+        self._device_weights = source.barycentric_device(target, tolerance)
+        self._weights = None
 
     @classmethod
     def from_weights(cls, weights, target):

@@ -74,11 +74,11 @@ class UnstructuredGrid2d:
         weight_values = np.ones_like(source_index, dtype=FloatDType)
         return source_index, target_index, weight_values
 
-    def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
+    def _voronoi(self):
+        """Centroidal Voronoi tessellation of this grid (unstructured.py:151-166) as a Ugrid2d, plus
+        vertex -> source face (node_to_face_index) and the exterior interpolation map."""
         from .. import voronoi
-        from .._replace import replace_interpolated_weights
 
-        points = other.ugrid_topology.centroids
         grid = self.ugrid_topology
         vertices, faces, node_to_face_index, node_to_node_map = voronoi.voronoi_topology(
             grid.node_face_connectivity,
@@ -91,7 +91,36 @@ class UnstructuredGrid2d:
             skip_concave=True,
         )
         voronoi_grid = Ugrid2d(vertices[:, 0], vertices[:, 1], -1, faces)
+        return voronoi_grid, vertices, faces, node_to_face_index, node_to_node_map
+
+    def barycentric_device(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
+        """The barycentric weights as a device CSR (rows = faces of ``other``): everything after the Voronoi
+        pre-step -- locate + weights, exterior-vertex replacement, masking, compaction -- runs in HBM."""
+        from .. import engine
+
+        voronoi_grid, _, _, node_to_face_index, node_to_node_map = self._voronoi()
+        return engine.barycentric_csr(
+            voronoi_grid.device_mesh,
+            self.ugrid_topology.device_mesh,
+            node_to_face_index,
+            node_to_node_map,
+            query=other.ugrid_topology.device_mesh,
+            tolerance=tolerance,
+        )
+
+    def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
+        """-> (source_index, target_index, weights) on the host, step by step as unstructured.py:146-201."""
+        from .._replace import replace_interpolated_weights
+
+        points = other.ugrid_topology.centroids
+        grid = self.ugrid_topology
+        voronoi_grid, vertices, faces, node_to_face_index, node_to_node_map = self._voronoi()
         face_index, weights = voronoi_grid.compute_barycentric_weights(points, tolerance)
+        # The weights are aligned with the tree's own vertex order of each cell (numba_celltree normalises
+        # its copy of the faces to counter-clockwise: the first non-collinear vertex triple decides, which
+        # reverses a concave cell that starts at a reflex corner).  The reference indexes with the caller's
+        # order (unstructured.py:175,193), which misaligns exactly those cells; here the tree's order is used.
+        faces = voronoi_grid.device_mesh.faces_ccw()
         replace_interpolated_weights(
             vertices=vertices,
             faces=faces,
@@ -104,7 +133,7 @@ class UnstructuredGrid2d:
         outside = grid.locate_points(points) == -1
         weights[outside] = 0
         keep = weights.ravel() > 0
-        source_index = node_to_face_index[voronoi_grid.face_node_connectivity[face_index]].ravel()[keep]
+        source_index = node_to_face_index[faces[face_index]].ravel()[keep]
         n_points, n_max_node = weights.shape
         target_index = np.repeat(np.arange(n_points, dtype=IntDType), n_max_node)[keep]
         weights = weights.ravel()[keep]
