@@ -104,6 +104,10 @@ int xr_mesh_area(xr_mesh *mesh, double *area_out);
 int xr_mesh_centroids(xr_mesh *mesh, double *centroids_out);
 /* CCW-normalised connectivity as held on the device -> int64[n_face, n_max_node]. */
 int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out);
+/* The arrays the handle was created from: node_xy float64[n_node, 2] and the connectivity int64[n_face, m] in
+ * the caller's vertex order, fill -1 (either pointer may be NULL).  Mainly for meshes that were built on the
+ * device (xr_voronoi_mesh). */
+int xr_mesh_download(xr_mesh *mesh, double *node_xy_out, int64_t *faces_out);
 
 /* CellTree2d.intersect_faces (unstructured.py:124-132) + relative normalisation (:133-134)
  * + MatrixCSR.from_triplet (regridder.py:433-435): all (query face, tree face) pairs with
@@ -138,6 +142,32 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points,
                        int64_t n, double tolerance, const int64_t *vertex_face,
                        const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
+
+/* ---- Voronoi pre-step of BarycentricInterpolator (xugrid/ugrid/voronoi.py:330-458 as called from
+ * xugrid/regrid/unstructured.py:151-165: add_exterior, add_vertices, skip_concave) ---------------------
+ * xr_voronoi_create does the O(n) part on the device: the node -> face inversion
+ * (ugrid2d.py:700-713, connectivity.py:247-259), the exterior edges (the only part of edge_node_connectivity /
+ * edge_face_connectivity the Voronoi step reads, voronoi.py:77-97; ugrid2d.py:497-509, :661-677) and the cells
+ * of all nodes that touch no exterior edge: the centroids of the surrounding faces ordered counter-clockwise
+ * about the node (voronoi.py:355-372).  The cells of boundary nodes are O(boundary) host work
+ * (xugrid_amd/voronoi.py) that needs what xr_voronoi_download returns and hands its result to
+ * xr_voronoi_mesh, which assembles the Voronoi tessellation as a device-resident mesh:
+ *   vertices = [face centroids ; extra_xy]      cells = [interior nodes ascending ; boundary_cells]. */
+typedef struct xr_voronoi xr_voronoi;
+int xr_voronoi_create(xr_mesh *mesh, xr_voronoi **out); /* `mesh` must outlive the handle */
+int xr_voronoi_info(const xr_voronoi *v, int64_t *n_node, int64_t *nnz, int64_t *n_exterior_edge,
+                    int64_t *n_interior_cell, int64_t *max_interior_degree);
+/* node_face_connectivity as CSR (indptr int64[n_node+1], indices int64[nnz], faces ascending per node), the
+ * exterior edges in lexicographic order (edge_nodes int64[n_edge, 2] = (lower, higher node id), edge_face
+ * int64[n_edge]) and, optionally, the face centroids float64[n_face, 2]. */
+int xr_voronoi_download(const xr_voronoi *v, int64_t *indptr, int64_t *indices, int64_t *edge_nodes,
+                        int64_t *edge_face, double *centroids);
+/* extra_xy float64[n_extra_vertex, 2]: projections and substitute vertices (ids n_face ...);
+ * boundary_cells int64[n_boundary_cell, n_max_boundary], -1 padded, counter-clockwise. */
+int xr_voronoi_mesh(const xr_voronoi *v, const double *extra_xy, int64_t n_extra_vertex,
+                    const int64_t *boundary_cells, int64_t n_boundary_cell, int64_t n_max_boundary,
+                    xr_mesh **out);
+int xr_voronoi_destroy(xr_voronoi *v);
 
 /* ---- seam 3: MatrixCSR handle ----------------------------------------------------------- */
 int xr_csr_info(const xr_csr *csr, int64_t *n, int64_t *m, int64_t *nnz);

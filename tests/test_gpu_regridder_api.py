@@ -285,3 +285,63 @@ def test_barycentric_device_pipeline(hip, oracle, kind):
     c2 = engine.barycentric_csr(vg.device_mesh, src.device_mesh, v2f, n2n, points=tgt.centroids)
     d2, i2, p2 = c2.download()
     assert np.array_equal(d2, data) and np.array_equal(i2, indices) and np.array_equal(p2, indptr)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_voronoi_device_matches_reference_goldens(hip, golden, tag):
+    """G6: voronoi_topology of the reference on seeded Delaunay meshes (50 / 500 / 5000 points).  The device
+    pre-step (xr_voronoi_*) + host boundary cells must give the same tessellation, array for array."""
+    from xugrid_amd import engine, voronoi
+
+    g = golden("g6_voronoi.npz")
+    xy, faces = g[tag + "_xy"], g[tag + "_faces"]
+    grid = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+    # the device's node -> face inversion and exterior edges == the host connectivities
+    b = engine.DeviceVoronoi(grid.device_mesh)
+    indptr, indices, edge_nodes, edge_face, cen = b.download()
+    nfc = grid.node_face_connectivity.tocsr()
+    assert np.array_equal(indptr, nfc.indptr) and np.array_equal(indices, nfc.indices)
+    enc, efc = g[tag + "_enc"], g[tag + "_efc"]
+    ext = efc[:, 1] == -1
+    assert np.array_equal(edge_nodes, enc[ext]) and np.array_equal(edge_face, efc[ext, 0])
+    assert np.array_equal(cen, grid.centroids)
+    np.testing.assert_allclose(cen, g[tag + "_centroids"], rtol=1e-15)
+    mesh, face_i, nmap = voronoi.voronoi_topology_device(grid)
+    v, f = mesh.download()
+    # vertices: the reference's centroids are numpy nanmean, ours the device kernel's (sum / 3): last-ulp apart
+    np.testing.assert_allclose(v, g[tag + "_vor_vertices"], rtol=1e-14, atol=1e-16)
+    gf = g[tag + "_vor_faces"]
+    assert f.shape[1] <= gf.shape[1] or (f[:, gf.shape[1]:] == -1).all()
+    k = min(f.shape[1], gf.shape[1])
+    assert np.array_equal(f[:, :k], gf[:, :k]) and (gf[:, k:] == -1).all()
+    assert np.array_equal(face_i, g[tag + "_vor_face_i"])
+    assert np.array_equal(np.sort(nmap, axis=1), np.sort(g[tag + "_vor_nmap"], axis=1))
+    # and it is exactly what the all-host function produces from the same (device) centroids
+    hv, hf, hfi, hnm = voronoi.voronoi_topology(
+        grid.node_face_connectivity, grid.node_coordinates, grid.centroids, grid.edge_face_connectivity,
+        grid.edge_node_connectivity, add_exterior=True, add_vertices=True, skip_concave=True,
+    )
+    assert np.array_equal(v, hv) and np.array_equal(f, hf) and np.array_equal(face_i, hfi) and np.array_equal(nmap, hnm)
+
+
+def test_voronoi_device_mixed_and_large(hip):
+    """quads (+ a mixed tri/quad mesh) and a 200k-face lattice mesh: device tessellation == host tessellation."""
+    from xugrid_amd import voronoi
+
+    rng = np.random.default_rng(8)
+    qxy, qf = meshgen.quad_mesh(np.cumsum(rng.uniform(0.5, 1.5, 40)), np.cumsum(rng.uniform(0.5, 1.5, 33)))
+    # mixed: split the first 300 quads into triangles, pad with -1
+    tri_a = np.column_stack([qf[:300, 0], qf[:300, 1], qf[:300, 2], np.full(300, -1)])
+    tri_b = np.column_stack([qf[:300, 0], qf[:300, 2], qf[:300, 3], np.full(300, -1)])
+    mixed = np.vstack([tri_a, tri_b, qf[300:]])
+    lxy, lf = meshgen.triangle_mesh(100_000, 5, delaunay=False)
+    for xy, faces in ((qxy, qf), (qxy, mixed), (lxy, lf)):
+        grid = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+        mesh, face_i, nmap = voronoi.voronoi_topology_device(grid)
+        v, f = mesh.download()
+        hv, hf, hfi, hnm = voronoi.voronoi_topology(
+            grid.node_face_connectivity, grid.node_coordinates, grid.centroids, grid.edge_face_connectivity,
+            grid.edge_node_connectivity, add_exterior=True, add_vertices=True, skip_concave=True,
+        )
+        assert np.array_equal(v, hv) and np.array_equal(f, hf)
+        assert np.array_equal(face_i, hfi) and np.array_equal(nmap, hnm)

@@ -52,6 +52,12 @@ SIGNATURES = {
     "xr_mesh_area": (c_int, [vp, vp]),
     "xr_mesh_centroids": (c_int, [vp, vp]),
     "xr_mesh_faces": (c_int, [vp, vp]),
+    "xr_mesh_download": (c_int, [vp, vp, vp]),
+    "xr_voronoi_create": (c_int, [vp, p_vp]),
+    "xr_voronoi_info": (c_int, [vp, p_i64, p_i64, p_i64, p_i64, p_i64]),
+    "xr_voronoi_download": (c_int, [vp, vp, vp, vp, vp, vp]),
+    "xr_voronoi_mesh": (c_int, [vp, vp, c_i64, vp, c_i64, c_i64, p_vp]),
+    "xr_voronoi_destroy": (c_int, [vp]),
     "xr_overlap": (c_int, [vp, vp, c_int, p_vp]),
     "xr_overlap_stats": (c_int, [vp, p_i64]),
     "xr_locate_points": (c_int, [vp, vp, c_i64, c_f64, vp]),

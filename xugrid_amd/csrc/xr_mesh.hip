@@ -601,4 +601,17 @@ int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out) {
     XR_API_END
 }
 
+int xr_mesh_download(xr_mesh *mesh, double *node_xy_out, int64_t *faces_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_download: NULL handle");
+    if (node_xy_out && mesh->n_node > 0) d2h(node_xy_out, mesh->node_xy.get(), sizeof(double) * 2 * (size_t)mesh->n_node);
+    const int64_t n = mesh->n_face * mesh->m;
+    if (faces_out && n > 0) {
+        std::vector<int32_t> raw((size_t)n);
+        d2h(raw.data(), mesh->faces_raw.get(), sizeof(int32_t) * (size_t)n);
+        for (int64_t i = 0; i < n; i++) faces_out[i] = raw[(size_t)i];
+    }
+    XR_API_END
+}
+
 } // extern "C"

@@ -62,6 +62,23 @@ def _as_faces(faces):
 class DeviceMesh:
     """Face topology resident in HBM (+ lazily built derived data and spatial index)."""
 
+    @classmethod
+    def _from_handle(cls, handle):
+        """Wrap a mesh that was built on the device (xr_voronoi_mesh)."""
+        self = cls.__new__(cls)
+        self._h = handle
+        n_node, n_face, m = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().xr_mesh_info(handle, ctypes.byref(n_node), ctypes.byref(n_face), ctypes.byref(m)))
+        self.n_node, self.n_face, self.n_max_node = n_node.value, n_face.value, m.value
+        return self
+
+    def download(self):
+        """-> (node_xy float64[n_node, 2], faces int64[n_face, n_max_node]) as uploaded / assembled."""
+        xy = np.empty((self.n_node, 2), dtype=np.float64)
+        faces = np.empty((self.n_face, self.n_max_node), dtype=np.int64)
+        check(_lib.load().xr_mesh_download(self._h, _ptr(xy), _ptr(faces)))
+        return xy, faces
+
     def __init__(self, vertices, faces, fill_value=-1):
         lib = _lib.load()
         xy = _as_xy(vertices)
@@ -139,6 +156,55 @@ class DeviceMesh:
             raise ValueError("tolerance must be non-negative")
         check(_lib.load().xr_barycentric(self._h, _ptr(pts), pts.shape[0], tol, _ptr(face), _ptr(w)))
         return face.astype(IntDType, copy=False), w
+
+
+class DeviceVoronoi:
+    """Device part of the centroidal Voronoi pre-step of a mesh (see include/xugrid_amd.h, xr_voronoi_*)."""
+
+    def __init__(self, mesh: DeviceMesh):
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_voronoi_create(mesh._h, ctypes.byref(handle)))
+        self._h = handle
+        self._mesh = mesh  # keep the source alive
+        vals = [ctypes.c_int64() for _ in range(5)]
+        check(_lib.load().xr_voronoi_info(handle, *[ctypes.byref(v) for v in vals]))
+        self.n_node, self.nnz, self.n_exterior_edge, self.n_interior_cell, self.max_interior_degree = (v.value for v in vals)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().xr_voronoi_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def download(self):
+        """-> (indptr, indices) of node_face_connectivity, exterior edge_nodes (n, 2), edge_face (n,), centroids."""
+        indptr = np.empty(self.n_node + 1, dtype=np.int64)
+        indices = np.empty(self.nnz, dtype=np.int64)
+        edge_nodes = np.empty((self.n_exterior_edge, 2), dtype=np.int64)
+        edge_face = np.empty(self.n_exterior_edge, dtype=np.int64)
+        centroids = np.empty((self._mesh.n_face, 2), dtype=np.float64)
+        check(
+            _lib.load().xr_voronoi_download(
+                self._h, _ptr(indptr), _ptr(indices), _ptr(edge_nodes), _ptr(edge_face), _ptr(centroids)
+            )
+        )
+        return indptr, indices, edge_nodes, edge_face, centroids
+
+    def assemble(self, extra_xy, boundary_cells) -> DeviceMesh:
+        extra_xy = np.ascontiguousarray(extra_xy, dtype=np.float64).reshape(-1, 2)
+        cells = np.ascontiguousarray(boundary_cells, dtype=np.int64)
+        if cells.ndim != 2:
+            raise ValueError("boundary_cells must be 2-D")
+        handle = ctypes.c_void_p()
+        check(
+            _lib.load().xr_voronoi_mesh(
+                self._h, _ptr(extra_xy), extra_xy.shape[0], _ptr(cells), cells.shape[0], cells.shape[1], ctypes.byref(handle)
+            )
+        )
+        return DeviceMesh._from_handle(handle)
 
 
 def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,

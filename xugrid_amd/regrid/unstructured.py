@@ -96,11 +96,11 @@ class UnstructuredGrid2d:
     def barycentric_device(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
         """The barycentric weights as a device CSR (rows = faces of ``other``): everything after the Voronoi
         pre-step -- locate + weights, exterior-vertex replacement, masking, compaction -- runs in HBM."""
-        from .. import engine
+        from .. import engine, voronoi
 
-        voronoi_grid, _, _, node_to_face_index, node_to_node_map = self._voronoi()
+        voronoi_mesh, node_to_face_index, node_to_node_map = voronoi.voronoi_topology_device(self.ugrid_topology)
         return engine.barycentric_csr(
-            voronoi_grid.device_mesh,
+            voronoi_mesh,
             self.ugrid_topology.device_mesh,
             node_to_face_index,
             node_to_node_map,

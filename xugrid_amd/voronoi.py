@@ -63,13 +63,11 @@ def _ccw_sort(keys, corner_ids, corner_xy, pivot_x, pivot_y):
     return keys[order], corner_ids[order]
 
 
-def _boundary_records(nfc, node_xy, centroids, efc, enc, add_vertices, skip_concave):
-    """Cells of the boundary nodes.  -> (vertex table, keys, corner ids, face_index, interp map)"""
+def _boundary_records(nfc, node_xy, centroids, edge_nodes, edge_face, add_vertices, skip_concave):
+    """Cells of the boundary nodes from the exterior edges (edge_nodes (n_be, 2), edge_face (n_be,)).
+    -> (vertex table, keys, corner ids, face_index, interp map)"""
     n_face = nfc.shape[1]
     per_node = np.diff(nfc.indptr)
-    ext_edge = efc[:, 1] == FILL_VALUE
-    edge_nodes = enc[ext_edge]                      # (n_be, 2)
-    edge_face = efc[ext_edge, 0]
 
     # -- corners that are face centroids
     bnodes = np.unique(edge_nodes.ravel())
@@ -184,7 +182,8 @@ def voronoi_topology(
 
     if add_exterior:
         table, bkeys, bids, face_index, interp_map = _boundary_records(
-            nfc, vertices, centroids, edge_face_connectivity, edge_node_connectivity, add_vertices, skip_concave
+            nfc, vertices, centroids, edge_node_connectivity[ext_edge], edge_face_connectivity[ext_edge, 0],
+            add_vertices, skip_concave,
         )
         shift = int(keys.max()) + 1 if keys.size else 0
         keys = np.concatenate([keys, bkeys + shift])
@@ -197,3 +196,36 @@ def voronoi_topology(
         ids = np.searchsorted(used, ids)
     cells = _pack_rows(keys, ids)
     return table, cells, face_index, interp_map
+
+
+def voronoi_topology_device(grid):
+    """
+    ``voronoi_topology(..., add_exterior=True, add_vertices=True, skip_concave=True)`` of a Ugrid2d with the
+    O(n) part on the device (node -> face inversion, exterior edges, counter-clockwise interior cells, assembly;
+    xugrid_amd/csrc/xr_voronoi.hip) and only the cells of the boundary nodes on the host.
+
+    Returns (DeviceMesh of the tessellation, face_index, interpolation_map): the mesh has the same vertices and
+    cells, in the same order, as the host function returns as arrays.
+    """
+    import scipy.sparse
+
+    from . import engine
+
+    builder = engine.DeviceVoronoi(grid.device_mesh)
+    indptr, indices, edge_nodes, edge_face, centroids = builder.download()
+    n_face = grid.n_face
+    nfc = scipy.sparse.csr_matrix(
+        (np.ones(indices.size, dtype=np.int8), indices, indptr), shape=(builder.n_node, n_face)
+    )
+    if edge_face.size:
+        table, bkeys, bids, face_index, interp_map = _boundary_records(
+            nfc, grid.node_coordinates, centroids, edge_nodes, edge_face, True, True
+        )
+        cells = _pack_rows(bkeys, bids)
+        extra = table[n_face:]
+    else:  # closed surface: nothing to add
+        cells = np.zeros((0, 3), dtype=IntDType)
+        extra = np.zeros((0, 2))
+        face_index, interp_map = np.arange(n_face), np.zeros((0, 2), dtype=IntDType)
+    mesh = builder.assemble(extra, cells)
+    return mesh, face_index, interp_map
