@@ -58,6 +58,10 @@ extern "C" {
 #define XR_PERCENTILE 7 /* + percentile argument; median = 50 */
 #define XR_FIRST_ORDER_CONSERVATIVE 8 /* = conductance */
 #define XR_MAX_OVERLAP 9
+/* Not a reduce.py reducer: the value of the row's LAST entry, NaN included, weights ignored -- the COO scatter
+ * of CentroidLocatorRegridder._regrid (xugrid/regrid/regridder.py:400-409: out[k, row] = source[k, col], later
+ * entries overwrite earlier ones) expressed on CSR rows, so that locator weights stay in HBM too. */
+#define XR_SELECT 10
 
 /* Source data dtypes accepted by the apply seam (output is always float64, regridder.py:44). */
 #define XR_F64 0
@@ -129,6 +133,13 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
  * (all zero, face -1 when outside). */
 int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolerance,
                    int64_t *face_index_out, double *weights_out);
+
+/* UnstructuredGrid2d.locate_centroids (xugrid/regrid/unstructured.py:137-144) + MatrixCOO.from_triplet
+ * (regridder.py:386-398) without leaving the device: one row per query point holding (face containing it, 1.0),
+ * no entry when the point is in no face.  Query points: `points` float64[n, 2] (query == NULL) or the face
+ * centroids of the mesh `query` (points == NULL).  Apply with XR_SELECT. */
+int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n, double tolerance,
+                  xr_csr **out);
 
 /* The whole of UnstructuredGrid2d.barycentric after the Voronoi pre-step (xugrid/regrid/unstructured.py:166-201),
  * assembled on the device: compute_barycentric_weights of the query points in the centroidal Voronoi mesh

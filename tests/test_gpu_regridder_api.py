@@ -345,3 +345,49 @@ def test_voronoi_device_mixed_and_large(hip):
         )
         assert np.array_equal(v, hv) and np.array_equal(f, hf)
         assert np.array_equal(face_i, hfi) and np.array_equal(nmap, hnm)
+
+
+def test_centroid_locator_device_pipeline(hip, oracle):
+    """xr_locate_csr + the select apply == locate_points + the COO scatter of the oracle (regridder.py:386-409)."""
+    sxy, sf = meshgen.triangle_mesh(2000, 31)
+    txy, tf = meshgen.triangle_mesh(3000, 32)
+    txy = 0.5 + 1.1 * (txy - 0.5)  # part of the target lies outside the source
+    src = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    rg = xa.CentroidLocatorRegridder(src, tgt)
+    tree = oracle.CellTree2d(sxy, sf, -1)
+    located = tree.locate_points(oracle.centroids(txy, tf))
+    row = np.nonzero(located >= 0)[0]
+    col = located[row]
+    assert 0 < row.size < tgt.n_face
+    df = rg.weights_as_dataframe()
+    assert np.array_equal(df["target_index"], row) and np.array_equal(df["source_index"], col)
+    assert (df["weight"] == 1.0).all()
+    rng = np.random.default_rng(0)
+    data = rng.normal(size=(5, src.n_face))
+    data[1, ::7] = np.nan  # NaN is copied, not skipped
+    data[2, ::5] = -0.0    # and so is the sign of zero
+    data32 = data.astype(np.float32)
+    for d in (data, data32):
+        out = rg.regrid(d)
+        expected = oracle.regrid_coo(d, row, col, tgt.n_face)
+        assert out.dtype == np.float64 and same_or_nan(out, expected).all()
+        assert np.array_equal(np.signbit(out), np.signbit(expected))
+    # many variables take the planned apply kernels
+    many = rng.normal(size=(40, src.n_face))
+    assert same_or_nan(rg.regrid(many), oracle.regrid_coo(many, row, col, tgt.n_face)).all()
+    # weights round trip (MatrixCOO fields) and unsorted external COO weights
+    rg2 = xa.CentroidLocatorRegridder.from_dataset(rg.to_dataset())
+    assert same_or_nan(rg2.regrid(data), rg.regrid(data)).all()
+    ds = rg.to_dataset()
+    perm = rng.permutation(row.size)
+    for key in ("__regrid_data", "__regrid_row", "__regrid_col"):
+        ds[key] = np.asarray(ds[key])[perm]
+    rg3 = xa.CentroidLocatorRegridder.from_weights(ds, tgt)
+    assert same_or_nan(rg3.regrid(data), rg.regrid(data)).all()
+    # explicit points
+    from xugrid_amd import engine
+    c = engine.locate_csr(src.device_mesh, points=tgt.centroids)
+    d1, i1, p1 = c.download()
+    d0, i0, p0 = rg._device_weights.download()
+    assert np.array_equal(i1, i0) and np.array_equal(p1, p0) and np.array_equal(d1, d0)

@@ -62,6 +62,7 @@ SIGNATURES = {
     "xr_overlap_stats": (c_int, [vp, p_i64]),
     "xr_locate_points": (c_int, [vp, vp, c_i64, c_f64, vp]),
     "xr_barycentric": (c_int, [vp, vp, c_i64, c_f64, vp, vp]),
+    "xr_locate_csr": (c_int, [vp, vp, vp, c_i64, c_f64, p_vp]),
     "xr_barycentric_csr": (c_int, [vp, vp, vp, vp, c_i64, c_f64, vp, vp, c_i64, p_vp]),
     "xr_csr_info": (c_int, [vp, p_i64, p_i64, p_i64]),
     "xr_csr_download": (c_int, [vp, vp, vp, vp]),

@@ -126,6 +126,21 @@ template <> struct Red<XR_MAX_OVERLAP> { // reduce.py:225-238   a = value of the
     __device__ double fin() const { return b == 0.0 ? NAN : a; }
 };
 
+template <> struct Red<XR_SELECT> { // regridder.py:400-409 on CSR rows: the last entry wins, NaN included
+    double a = NAN, b = 0.0, c = 0.0;
+    __device__ void add(double v, double, double) {
+        a = v;
+        b = 1.0;
+    }
+    __device__ void merge(const Red &o) {
+        if (o.b != 0.0) {
+            a = o.a;
+            b = 1.0;
+        }
+    }
+    __device__ double fin() const { return a; }
+};
+
 // Rows longer than APPLY_LONG entries are not reduced by one thread (a coarse target cell over a
 // fine source has thousands of entries) but by a whole block: strided per-thread partial states,
 // merged in a fixed butterfly order -> deterministic, but the summation order differs from the
@@ -968,6 +983,7 @@ static void apply_dispatch(const xr_csr *csr, int method, double p, const SRC *s
     case XR_MAXIMUM: launch_stream<XR_MAXIMUM, SRC>(csr, src, K, out); break;
     case XR_FIRST_ORDER_CONSERVATIVE: launch_stream<XR_FIRST_ORDER_CONSERVATIVE, SRC>(csr, src, K, out); break;
     case XR_MAX_OVERLAP: launch_stream<XR_MAX_OVERLAP, SRC>(csr, src, K, out); break;
+    case XR_SELECT: launch_stream<XR_SELECT, SRC>(csr, src, K, out); break;
     case XR_MODE: launch_workspace<XR_MODE, SRC>(csr, src, K, p, out); break;
     case XR_PERCENTILE:
         XR_REQUIRE(p >= 0.0 && p <= 100.0, XR_ERR_INVALID,

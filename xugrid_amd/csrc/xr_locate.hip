@@ -235,6 +235,29 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
     }
 }
 
+// ---- locator weights as CSR (xr_locate_csr) -------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_locate_col(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+             const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+             const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+             int32_t *__restrict__ col, int32_t *__restrict__ found) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const P2 p = load_p2(pts, (int)i);
+    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    col[i] = r >= 0 ? rec_face[r] : -1;
+    found[i] = r >= 0;
+}
+
+__global__ void __launch_bounds__(256)
+k_locate_fill(const int32_t *__restrict__ col, const int32_t *__restrict__ indptr, int64_t n,
+              int32_t *__restrict__ indices, double *__restrict__ data) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || col[i] < 0) return;
+    indices[indptr[i]] = col[i];
+    data[indptr[i]] = 1.0;
+}
+
 static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
     if (tolerance >= 0) return tolerance;
     mesh_read_stats(mesh);
@@ -363,6 +386,50 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
             if (nnz > 0)
                 XR_LAUNCH("bary_fill", k_bary_fill, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                           faces_ccw.get(), vface.get(), csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+            stream_sync();
+        }
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n, double tolerance, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && out, XR_ERR_INVALID, "xr_locate_csr: NULL argument");
+    XR_REQUIRE((query != nullptr) != (points != nullptr) || (n == 0 && !query), XR_ERR_INVALID,
+               "xr_locate_csr: give either a query mesh (its face centroids are the points) or points");
+    if (query) n = query->n_face;
+    XR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "xr_locate_csr: too many points");
+    xr_csr *csr = new xr_csr();
+    try {
+        csr->n = n; csr->m = tree->n_face; csr->nnz = 0;
+        csr->indptr.alloc((size_t)n + 1);
+        if (n == 0 || tree->n_face == 0) {
+            fill_i32(csr->indptr.get(), 0, n + 1);
+            csr->indices.alloc(0);
+            csr->data.alloc(0);
+            stream_sync();
+        } else {
+            mesh_prepare(tree);
+            mesh_build_index(tree);
+            const double tol = resolve_tolerance(tree, tolerance);
+            DevBuf<double> pts((size_t)n * 2);
+            if (query) mesh_centroids_dev(query, pts.get());
+            else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            DevBuf<int32_t> col((size_t)n), found((size_t)n);
+            XR_LAUNCH("locate_col", k_locate_col, dim3(div_up(n, 256)), dim3(256), 0, tree->rec_fxy.get(),
+                      tree->rec_len.get(), tree->m, tree->grid, tree->cell_start.get(), tree->rec_bb.get(),
+                      tree->rec_face.get(), pts.get(), n, tol, col.get(), found.get());
+            exclusive_scan_i32(found.get(), csr->indptr.get(), n);
+            csr->nnz = read_scalar(csr->indptr.get() + n);
+            csr->indices.alloc((size_t)csr->nnz);
+            csr->data.alloc((size_t)csr->nnz);
+            if (csr->nnz > 0)
+                XR_LAUNCH("locate_fill", k_locate_fill, dim3(div_up(n, 256)), dim3(256), 0, col.get(), csr->indptr.get(), n,
+                          csr->indices.get(), csr->data.get());
             stream_sync();
         }
     } catch (...) {

@@ -29,6 +29,7 @@ METHOD_IDS = {
     "first_order_conservative": 8,
     "conductance": 8,
     "max_overlap": 9,
+    "select": 10,  # CentroidLocatorRegridder: value of the row's last entry (include/xugrid_amd.h XR_SELECT)
 }
 
 
@@ -205,6 +206,23 @@ class DeviceVoronoi:
             )
         )
         return DeviceMesh._from_handle(handle)
+
+
+def locate_csr(tree: DeviceMesh, query: DeviceMesh = None, points=None, tolerance=None) -> "DeviceCSR":
+    """locate_centroids + MatrixCOO.from_triplet on the device: one (face, 1.0) entry per located point."""
+    tol = -1.0 if tolerance is None else float(tolerance)
+    if tolerance is not None and tol < 0:
+        raise ValueError("tolerance must be non-negative")
+    if (query is None) == (points is None):
+        raise ValueError("give either a query mesh or points")
+    if points is not None:
+        pts = _as_xy(points)
+        p_arg, n, q_arg = _ptr(pts), pts.shape[0], None
+    else:
+        p_arg, n, q_arg = None, query.n_face, query._h
+    handle = ctypes.c_void_p()
+    check(_lib.load().xr_locate_csr(tree._h, q_arg, p_arg, n, tol, ctypes.byref(handle)))
+    return DeviceCSR(handle)
 
 
 def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,

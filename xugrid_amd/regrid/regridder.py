@@ -224,21 +224,43 @@ class CentroidLocatorRegridder(BaseRegridder):
     Regrids by locating the centroids of the target faces in the source grid
     (regridder.py:364-422).  If a centroid lies exactly on an edge between two faces the face with
     the lowest index is used (the reference leaves the choice unspecified, :369-370).
+
+    The weights are the reference's MatrixCOO (one (target, source, 1.0) triplet per located centroid); on
+    the device they live as CSR rows with at most one entry and are applied with the ``select`` kernel
+    (= the COO scatter ``out[k, row] = source[k, col]``, NaN included).
     """
 
     def _compute_weights(self, source, target, tolerance: Optional[float] = None):
         source, target = convert_to_match(source, target)
-        source_index, target_index, weight_values = source.locate_centroids(target, tolerance)
-        self._weights = MatrixCOO.from_triplet(target_index, source_index, weight_values, n=target.size, m=source.size)
+        self._device_weights = source.locate_centroids_device(target, tolerance)
+        self._weights = None
 
     def _regrid(self, source, size):
         A = self._weights
-        return engine.apply_coo(A.row, A.col, size, source)
+        if self._device_weights is None and A is not None and A.row.size and (np.diff(A.row) < 0).any():
+            # externally supplied, unsorted COO weights: plain scatter (regridder.py:400-409)
+            return engine.apply_coo(A.row, A.col, size, source)
+        out = self._ensure_device_weights().apply(source, engine.METHOD_IDS["select"], 0.0)
+        assert out.shape[1] == size
+        return out
 
     def _ensure_host_weights(self):
         if self._weights is None:
-            raise ValueError("Weights have not been computed yet.")
+            if self._device_weights is None:
+                raise ValueError("Weights have not been computed yet.")
+            dw = self._device_weights
+            data, indices, indptr = dw.download()
+            row = np.repeat(np.arange(dw.n, dtype=indices.dtype), np.diff(indptr))
+            self._weights = MatrixCOO(data, row, indices, dw.n, dw.m, dw.nnz)
         return self._weights
+
+    def _ensure_device_weights(self):
+        if self._device_weights is None:
+            w = self._weights
+            if w is None:
+                raise ValueError("Weights have not been computed yet.")
+            self._device_weights = engine.DeviceCSR.from_triplet(w.row, w.col, w.data, w.n, w.m)
+        return self._device_weights
 
     @classmethod
     def _weights_from_dataset(cls, dataset) -> MatrixCOO:

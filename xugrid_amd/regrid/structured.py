@@ -317,6 +317,9 @@ class StructuredGrid2d:
     def locate_centroids(self, other: "StructuredGrid2d", tolerance=None):
         return self._outer_host(other, self._axes(other, "locate_centroids"))
 
+    def locate_centroids_device(self, other: "StructuredGrid2d", tolerance=None):
+        return self._outer_device(other, self._axes(other, "locate_centroids"))
+
     def linear_weights(self, other: "StructuredGrid2d"):
         return self._outer_host(other, self._axes(other, "linear_weights"))
 

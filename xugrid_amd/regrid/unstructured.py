@@ -65,6 +65,14 @@ class UnstructuredGrid2d:
         )
         return source_index, target_index, weights
 
+    def locate_centroids_device(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
+        """The locator weights as a device CSR: row t holds (face containing centroid t, 1.0) or nothing."""
+        from .. import engine
+
+        return engine.locate_csr(
+            self.ugrid_topology.device_mesh, query=other.ugrid_topology.device_mesh, tolerance=tolerance
+        )
+
     def locate_centroids(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
         tree = self.ugrid_topology.celltree
         source_index = tree.locate_points(other.ugrid_topology.centroids, tolerance)
