@@ -122,6 +122,11 @@ def test_overlap_long_rows_and_big_queries(hip, oracle):
     csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
     assert np.diff(indptr).max() > 2000
     assert_overlap_parity(hip, oracle, txy, tf, sxy, sf, relative=True)
+    # rows of a few hundred to ~2000 candidates: block-per-row all-pairs rank kernel
+    for nx, ny in ((21, 17), (12, 9)):
+        txy, tf = meshgen.quad_mesh(np.linspace(-0.05, 1.05, nx), np.linspace(0.02, 0.97, ny))
+        csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf, relative=(nx == 12))
+        assert 128 < np.diff(indptr).max() < 2048
 
 
 def test_overlap_graded_mesh_many_levels(hip, oracle):

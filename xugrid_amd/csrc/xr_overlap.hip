@@ -690,140 +690,147 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
     }
 }
 
-// Medium rows (ROW_SHORT < candidates <= ROW_MEDIUM): one WAVE per row.  The row's tree face ids
-// are staged in LDS (non-survivors as INT_MAX), every lane ranks its survivors against the whole
-// row with broadcast LDS reads: O(n^2 / 64) per row, no 64 KiB bitmap to clear.
-static constexpr int ROW_MEDIUM = 128;
-
-__global__ void __launch_bounds__(256)
-k_row_fill_medium(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_sid,
-                  const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
-                  const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
-                  double *__restrict__ data, const int32_t *__restrict__ long_rows,
-                  const int32_t *__restrict__ n_long) {
-    __shared__ int32_t sh_sid[4][ROW_MEDIUM];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = gridDim.x * 4;
-    const int nl = *n_long;
-    int32_t *sid = sh_sid[wv];
-    for (int li = wave; li < nl; li += n_waves) {
-        const int t = long_rows[li];
-        const int c0 = cand_off[t], n = cand_off[t + 1] - c0;
-        if (n > ROW_MEDIUM) continue; // bitmap kernel
-        const int base = indptr[t];
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < n; i += 64) sid[i] = cand_area[c0 + i] > 0 ? cand_sid[c0 + i] : 0x7fffffff;
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < n; i += 64) {
-            const int s = sid[i];
-            if (s == 0x7fffffff) continue;
-            int rank = 0;
-            for (int j = 0; j < n; j++) rank += sid[j] < s ? 1 : 0;
-            const double a = cand_area[c0 + i];
-            indices[base + rank] = s;
-            data[base + rank] = relative ? a / src_area[s] : a;
-        }
-    }
-}
+// Rows that do not fit the packed short-row path (candidates > ROW_SHORT) are listed by k_row_fill and
+// finished by ONE kernel, one block per row: up to ROW_BLOCK candidates by an all-pairs rank (ids staged in
+// LDS, 16-byte broadcast reads: a few microseconds), longer rows by the bitmap rank below.  (Separate
+// wave-per-row / block-per-row / bitmap kernels were each pure latency on a few hundred rows: 14 + 21 + 26 us
+// back to back.)
+static constexpr int ROW_BLOCK = 512;
 
 // Long rows: one block per row ranks the survivors by tree face id with an LDS bitmap.
-// The id range is processed in chunks of BM_BITS ids: set one bit per survivor, build word
-// prefix popcounts, rank = (survivors in earlier chunks) + prefix[word] + popc(bits below).
-// O(n + S/32) per row instead of O(n^2); any row length, any number of tree faces.
-static constexpr int BM_WORDS = 16384;          // 64 KiB of bitmap
+// The id space [0, S) is processed in chunks of BM_BITS ids (one chunk covers a million tree faces): set one
+// bit per survivor, count the bits of each thread's segment of BM_SEG words (rotated start -> bank-conflict
+// free), scan the 256 segment totals, rank = (survivors in earlier chunks) + segment base + popcounts of
+// the segment's words below + popc(bits below).  O(n + S/32) per row instead of O(n^2); any row length,
+// any number of tree faces.  The row is read from HBM once, four candidates in flight per thread, and
+// parked in LDS (survivor id or -1) for the later passes: the kernel is a chain of dependent phases on a
+// handful of rows, i.e. pure latency.
+static constexpr int BM_WORDS = 32768;          // 128 KiB of bitmap
 static constexpr int BM_BITS = BM_WORDS * 32;   // ids per chunk
-static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread
+static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread segment
+static constexpr int BM_STAGE = 4096;           // candidates parked in LDS (16 KiB); longer rows re-read HBM
 
 __global__ void __launch_bounds__(256)
 k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_sid,
                 const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
-                const double *__restrict__ src_area, bool relative, int32_t *__restrict__ indices,
+                const double *__restrict__ src_area, bool relative, int64_t n_tree, int32_t *__restrict__ indices,
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
                 const int32_t *__restrict__ n_long) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);          // [BM_WORDS]
-    uint32_t *prefix = bm + BM_WORDS;                           // [BM_WORDS] exclusive, within thread segment
-    uint32_t *tbase = prefix + BM_WORDS;                        // [256] exclusive over thread segments
+    uint32_t *tbase = bm + BM_WORDS;                            // [256] exclusive over thread segments
     int32_t *red = reinterpret_cast<int32_t *>(tbase + 256);    // [8] scratch
+    int32_t *stage = red + 8;                                   // [BM_STAGE]
+    uint16_t *gcnt = reinterpret_cast<uint16_t *>(stage + BM_STAGE); // [BM_WORDS / 8] bits per 8 words -> prefix in segment
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nl = *n_long;
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
-        const int c0 = cand_off[t], c1 = cand_off[t + 1];
-        if (c1 - c0 <= ROW_MEDIUM) continue; // wave-per-row kernel
+        const int c0 = cand_off[t], n = cand_off[t + 1] - c0;
         const int base = indptr[t];
-        // id range of the survivors
-        int lo = 0x7fffffff, hi = -1;
-        for (int i = c0 + tid; i < c1; i += 256) {
-            if (cand_area[i] > 0) {
-                const int s = cand_sid[i];
-                lo = min(lo, s);
-                hi = max(hi, s);
+        __syncthreads();
+        // park the row: survivor id or -1 (four independent pairs of loads per thread and trip)
+        for (int i0 = tid; i0 < n && i0 < BM_STAGE; i0 += 4 * 256) {
+            double a[4];
+            int sd[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 256;
+                const bool in = i < n && i < BM_STAGE;
+                a[u] = in ? cand_area[c0 + i] : 0.0;
+                sd[u] = in ? cand_sid[c0 + i] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * 256;
+                if (i < n && i < BM_STAGE) stage[i] = a[u] > 0 ? sd[u] : -1;
             }
         }
-        for (int d = 32; d > 0; d >>= 1) {
-            lo = min(lo, __shfl_down(lo, d, 64));
-            hi = max(hi, __shfl_down(hi, d, 64));
+        if (n <= ROW_BLOCK) { // all-pairs rank; dead candidates compare as +inf
+            __syncthreads();
+            const int n4 = (n + 3) & ~3;
+            if (tid < n4 - n) stage[n + tid] = -1;
+            __syncthreads();
+            const int4 *quad = reinterpret_cast<const int4 *>(stage);
+            for (int i = tid; i < n; i += 256) {
+                const int sd = stage[i];
+                if (sd < 0) continue;
+                int rank = 0;
+                for (int j = 0; j < n4 / 4; j++) {
+                    const int4 q = quad[j];
+                    rank += ((unsigned)q.x < (unsigned)sd) + ((unsigned)q.y < (unsigned)sd) + ((unsigned)q.z < (unsigned)sd) +
+                            ((unsigned)q.w < (unsigned)sd);
+                }
+                const double a = cand_area[c0 + i];
+                indices[base + rank] = sd;
+                data[base + rank] = relative ? a / src_area[sd] : a;
+            }
+            continue;
         }
-        __syncthreads();
-        if (lane == 0) {
-            red[wave] = lo;
-            red[4 + wave] = hi;
-        }
-        __syncthreads();
-        lo = min(min(red[0], red[1]), min(red[2], red[3]));
-        hi = max(max(red[4], red[5]), max(red[6], red[7]));
+        auto survivor = [&](int i) -> int { // tree face id of candidate i of the row, -1 if its area is not positive
+            if (i < BM_STAGE) return stage[i];
+            return cand_area[c0 + i] > 0 ? cand_sid[c0 + i] : -1;
+        };
         int running = 0;
-        if (hi >= 0) {
-            for (int cb = (lo / BM_BITS) * BM_BITS; cb <= hi; cb += BM_BITS) {
-                __syncthreads();
-                for (int w = tid; w < BM_WORDS; w += 256) bm[w] = 0u;
-                __syncthreads();
-                for (int i = c0 + tid; i < c1; i += 256) {
-                    if (cand_area[i] > 0) {
-                        const int s = cand_sid[i] - cb;
-                        if (s >= 0 && s < BM_BITS) atomicOr(&bm[s >> 5], 1u << (s & 31));
-                    }
-                }
-                __syncthreads();
-                // exclusive popcount prefix inside each thread's segment of BM_SEG words
-                uint32_t acc = 0;
-                for (int k = 0; k < BM_SEG; k++) {
-                    const int w = tid * BM_SEG + k;
-                    prefix[w] = acc;
-                    acc += __popc(bm[w]);
-                }
-                // block exclusive scan of the per-thread totals
-                uint32_t incl = acc;
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t v = __shfl_up(incl, d, 64);
-                    if (lane >= d) incl += v;
-                }
-                if (lane == 63) red[wave] = (int32_t)incl;
-                __syncthreads();
-                uint32_t woff = 0, chunk_total = 0;
-                for (int w = 0; w < 4; w++) {
-                    if (w < wave) woff += (uint32_t)red[w];
-                    chunk_total += (uint32_t)red[w];
-                }
-                tbase[tid] = woff + incl - acc;
-                __syncthreads();
-                for (int i = c0 + tid; i < c1; i += 256) {
-                    const double a = cand_area[i];
-                    if (a > 0) {
-                        const int sid = cand_sid[i];
-                        const int s = sid - cb;
-                        if (s >= 0 && s < BM_BITS) {
-                            const int w = s >> 5;
-                            const int rank = running + (int)(tbase[w / BM_SEG] + prefix[w]) +
-                                             __popc(bm[w] & ((1u << (s & 31)) - 1u));
-                            indices[base + rank] = sid;
-                            data[base + rank] = relative ? a / src_area[sid] : a;
-                        }
-                    }
-                }
-                running += (int)chunk_total;
+        for (int64_t cb64 = 0; cb64 < n_tree; cb64 += BM_BITS) {
+            const int cb = (int)cb64;
+            __syncthreads();
+            {
+                uint4 *bm4 = reinterpret_cast<uint4 *>(bm);
+                for (int w = tid; w < BM_WORDS / 4; w += 256) bm4[w] = make_uint4(0u, 0u, 0u, 0u);
             }
+            __syncthreads();
+            for (int i = tid; i < n; i += 256) {
+                const int s = survivor(i) - cb;
+                if (s >= 0 && s < BM_BITS) atomicOr(&bm[s >> 5], 1u << (s & 31));
+            }
+            __syncthreads();
+            // bits per group of 8 words (coalesced 32-byte reads), then an exclusive prefix over the 16 groups
+            // of each thread's segment
+            for (int g = tid; g < BM_WORDS / 8; g += 256) {
+                const uint4 x = reinterpret_cast<const uint4 *>(bm)[2 * g], y = reinterpret_cast<const uint4 *>(bm)[2 * g + 1];
+                gcnt[g] = (uint16_t)(__popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w) + __popc(y.x) + __popc(y.y) +
+                                     __popc(y.z) + __popc(y.w));
+            }
+            __syncthreads();
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < BM_SEG / 8; k++) {
+                const uint32_t c = gcnt[tid * (BM_SEG / 8) + k];
+                gcnt[tid * (BM_SEG / 8) + k] = (uint16_t)acc;
+                acc += c;
+            }
+            // block exclusive scan of the per-thread totals
+            uint32_t incl = acc;
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t v = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += v;
+            }
+            if (lane == 63) red[wave] = (int32_t)incl;
+            __syncthreads();
+            uint32_t woff = 0, chunk_total = 0;
+            for (int w = 0; w < 4; w++) {
+                if (w < wave) woff += (uint32_t)red[w];
+                chunk_total += (uint32_t)red[w];
+            }
+            tbase[tid] = woff + incl - acc;
+            __syncthreads();
+            if (chunk_total != 0) {
+                for (int i = tid; i < n; i += 256) {
+                    const int sid = survivor(i);
+                    const int s = sid - cb;
+                    if (sid >= 0 && s >= 0 && s < BM_BITS) {
+                        const int w = s >> 5;
+                        int rank = running + (int)tbase[w / BM_SEG] + (int)gcnt[w >> 3] +
+                                   __popc(bm[w] & ((1u << (s & 31)) - 1u));
+                        for (int k = w & ~7; k < w; k++) rank += __popc(bm[k]);
+                        const double a = cand_area[c0 + i];
+                        indices[base + rank] = sid;
+                        data[base + rank] = relative ? a / src_area[sid] : a;
+                    }
+                }
+            }
+            running += (int)chunk_total;
         }
         __syncthreads();
     }
@@ -964,18 +971,15 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
                   cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, csr->long_rows.get(),
                   csr->n_long.get());
-        const size_t shmem = sizeof(uint32_t) * (2 * BM_WORDS + 256) + sizeof(int32_t) * 8;
+        const size_t shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
         static bool attr_set = false;
         if (!attr_set) {
             XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_fill_long),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
             attr_set = true;
         }
-        XR_LAUNCH("row_fill_medium", k_row_fill_medium, dim3(engine().num_cu * 4), dim3(256), 0, cand_off.get(),
-                  cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative,
-                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
-                  cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative,
+                  cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, tree->n_face,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
     }
 }
