@@ -204,6 +204,12 @@ int xr_csr_from_outer(const int64_t *indptr_y, const int64_t *source_y, const do
                       int64_t n_target_y, int64_t n_source_y, const int64_t *indptr_x,
                       const int64_t *source_x, const double *weight_x, int64_t n_target_x,
                       int64_t n_source_x, xr_csr **out);
+/* Optional locality hint for matrices that were uploaded (xr_csr_upload / xr_csr_from_triplet, i.e. the
+ * from_weights path): one small integer per row such that rows with equal keys are spatial neighbours (e.g. the
+ * Morton code of a coarse cell holding the target face's centroid).  With many source variables (K >= 8) the apply
+ * regroups the STORED rows by key once -- results and xr_csr_download are unaffected.  xr_overlap attaches such
+ * keys itself. */
+int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range);
 int xr_csr_destroy(xr_csr *csr);
 
 /* ---- seam 2: apply ---------------------------------------------------------------------- */

@@ -396,3 +396,43 @@ def test_full_size_properties(hip, n_points):
     rel = ms.overlap(mt, relative=True)
     rd, ri, rp = rel.download()
     assert np.array_equal(ri, idx) and np.array_equal(rd, data / ms.area()[idx])
+
+
+def test_apply_many_variables_row_tiling(hip, oracle):
+    """K >= 8 applies regroup the stored rows into 2-D tiles once (keys from xr_overlap, or from
+    xr_csr_set_row_keys for uploaded weights): results, downloads and later K = 1 applies are unchanged."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.triangle_mesh(20000, 3, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(24000, 4, 30.0, 0.8, delaunay=False)
+    tree = oracle.CellTree2d(sxy, sf, -1)
+    oq, os_, oa = tree.intersect_faces(txy, tf, -1)
+    indptr = oracle.to_csr_indptr(oq, tf.shape[0])
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(24, sf.shape[0]))
+    v[3, ::11] = np.nan
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    csr = ms.overlap(mt)
+    before = csr.download()
+    out1 = csr.apply(v[:1], 0)
+    for method, mid in (("mean", 0), ("maximum", 5), ("sum", 3)):
+        got = csr.apply(v, mid)  # first call re-tiles the rows
+        exp = oracle.regrid_csr(method, v, oa, os_, indptr, csr.n)
+        assert_apply_equal(got, exp, indptr, method)
+    after = csr.download()
+    for a, b in zip(before, after):
+        assert np.array_equal(a, b)
+    assert same_or_nan(csr.apply(v[:1], 0), out1).all()
+    assert_apply_equal(csr.apply(v, 7, 50.0), oracle.regrid_csr("median", v, oa, os_, indptr, csr.n), indptr, "median")
+    # uploaded weights + explicit keys
+    up = E.DeviceCSR.from_arrays(oa, os_, indptr, csr.n, csr.m)
+    keys, key_range = E.morton_row_keys(oracle.centroids(txy, tf), faces_per_tile=64)
+    assert key_range > 1
+    up.set_row_keys(keys, key_range)
+    assert_apply_equal(up.apply(v, 0), oracle.regrid_csr("mean", v, oa, os_, indptr, csr.n), indptr, "uploaded")
+    d, i, p = up.download()
+    assert np.array_equal(d, oa) and np.array_equal(i, os_) and np.array_equal(p, indptr)
+    with pytest.raises(ValueError):
+        up.set_row_keys(keys, key_range)  # rows are already stored in a spatial order
+    with pytest.raises(ValueError):
+        E.DeviceCSR.from_arrays(oa, os_, indptr, csr.n, csr.m).set_row_keys(keys + key_range, key_range)

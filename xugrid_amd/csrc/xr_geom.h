@@ -78,4 +78,26 @@ __device__ __forceinline__ float f32_above(double v) {
 }
 #endif
 
+// Morton (Z-order) key of the coarse cell that holds a bbox centre: spatial orderings of faces / matrix rows
+__device__ __forceinline__ uint32_t spread_bits16(uint32_t v) {
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+struct MortonParams {
+    double x0, y0, inv_h;
+    int n_side;
+    int n_run = 1;
+};
+
+__device__ __forceinline__ int morton_key(const MortonParams &mp, double4 bb) {
+    const int cx = cell_coord(0.5 * (bb.x + bb.y), mp.x0, mp.inv_h, mp.n_side);
+    const int cy = cell_coord(0.5 * (bb.z + bb.w), mp.y0, mp.inv_h, mp.n_side);
+    return (int)(spread_bits16((uint32_t)cx) | (spread_bits16((uint32_t)cy) << 1));
+}
+
+
 } // namespace xr

@@ -232,24 +232,6 @@ void mesh_read_stats(xr_mesh *mesh) {
 // Order inside a bucket follows the atomics, i.e. is unspecified -- every consumer is written
 // so that final results do not depend on it.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t spread_bits16(uint32_t v) {
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
-}
-
-struct MortonParams {
-    double x0, y0, inv_h;
-    int n_side;
-};
-
-__device__ __forceinline__ int morton_key(const MortonParams &mp, double4 bb) {
-    const int cx = cell_coord(0.5 * (bb.x + bb.y), mp.x0, mp.inv_h, mp.n_side);
-    const int cy = cell_coord(0.5 * (bb.z + bb.w), mp.y0, mp.inv_h, mp.n_side);
-    return (int)(spread_bits16((uint32_t)cx) | (spread_bits16((uint32_t)cy) << 1));
-}
 
 __device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
     const double e = fmax(bb.y - bb.x, bb.w - bb.z);

@@ -73,6 +73,12 @@ struct xr_csr {
     xr::DevBuf<int32_t> long_rows; // [<= n]
     xr::DevBuf<int32_t> n_long;    // [1] device-side count
     bool has_long = false;
+    // Coarse Morton key per STORED row (tile of ~12 target extents).  Set by xr_overlap when the rows are kept
+    // in the caller's order, or by xr_csr_set_row_keys; consumed once by the many-variable apply, which regroups
+    // the stored rows into compact 2-D tiles (xr_apply.hip: ensure_tiled) and then drops the keys.
+    xr::DevBuf<int32_t> tile_key; // [n]
+    bool has_tile_key = false;
+    int64_t tile_key_range = 0;   // keys are in [0, tile_key_range)
     // "apply plan" for many source variables (built lazily, xr_apply.hip): per block of 256 stored
     // rows the sorted list of DISTINCT column ids and, per entry, its 16-bit position in that list
     bool plan_ready = false;

@@ -44,17 +44,25 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
 // them into the dense candidate queue.  Faces with more than SLOTS hits, too many grid rows or too
 // many visited records are "big" and go to the wave-per-face kernels instead.
 static constexpr int SLOTS = 16;
+static constexpr int TILE_RUN = 64; // rows per run in the tiling hint (512-byte output stores per variable)
 
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const int32_t *__restrict__ cell_start,
          const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ slots,
-         uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list, int32_t *__restrict__ n_big) {
+         uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, MortonParams tile,
+         int32_t *__restrict__ tile_key) {
     __shared__ int32_t sh_slots[SLOTS][256]; // [slot][thread]: conflict-free, written out as whole lines
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int count = 0;
     bool big = false;
     if (t < n_query) {
         const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
+        if (tile_key) {
+            // row tiling hint for the many-variable apply: all rows of a run of TILE_RUN consecutive ids share the
+            // key of the run's middle row, so runs stay contiguous (long output stores) and neighbouring runs meet
+            const int64_t mid = (t & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
+            tile_key[t] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
+        }
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
         const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
@@ -905,9 +913,28 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     DevBuf<uint8_t> is_big((size_t)T);
     const int big_grid = engine().num_cu * 8;
     DevBuf<int32_t> slots((size_t)T * SLOTS);
+    // Rows kept in the caller's (coherent, but typically strip-like) numbering get a coarse Morton key each:
+    // tiles of 12-24 mean target extents, runs of TILE_RUN consecutive rows kept together.  A Morton-sorted query order is tiled already.
+    MortonParams tile{};
+    csr->has_tile_key = false;
+    if (query->query_identity) {
+        const double *hs = query->h_stats;
+        double span = std::max(hs[1] - hs[0], hs[3] - hs[2]);
+        if (!(span > 0)) span = 1.0;
+        // tile edge <= 24 mean extents (the side count is a power of two); measured flat between 8 and 32
+        double h = 24.0 * hs[4] / (double)T;
+        if (!(h > 0)) h = span;
+        int bits = 0;
+        while (bits < 10 && ldexp(h, bits) < span) bits++;
+        tile = MortonParams{hs[0], hs[2], (double)(1 << bits) / (span * (1.0 + 1e-9)), 1 << bits};
+        tile.n_run = TILE_RUN;
+        csr->tile_key.alloc((size_t)T);
+        csr->tile_key_range = (int64_t)1 << (2 * bits);
+        csr->has_tile_key = bits > 0;
+    }
     XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->qo_bbox(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), slots.get(), is_big.get(), big_list.get(),
-              counters.get() + 2);
+              counters.get() + 2, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr);
     XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
               query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
               tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, (const int32_t *)nullptr,

@@ -208,6 +208,31 @@ class DeviceVoronoi:
         return DeviceMesh._from_handle(handle)
 
 
+def morton_row_keys(xy, faces_per_tile=144):
+    """Coarse Morton keys of points (row locality hint): tiles holding about ``faces_per_tile`` points each.
+    -> (keys int64[n], key_range)"""
+    xy = np.asarray(xy, dtype=np.float64)
+    n = xy.shape[0]
+    if n == 0:
+        return np.zeros(0, dtype=np.int64), 1
+    lo = np.nanmin(xy, axis=0)
+    span = float(np.nanmax(np.nanmax(xy, axis=0) - lo))
+    if not span > 0:
+        return np.zeros(n, dtype=np.int64), 1
+    bits = int(np.clip(np.floor(0.5 * np.log2(max(n / faces_per_tile, 1.0))), 0, 10))
+    side = 1 << bits
+    cell = np.clip(np.nan_to_num((xy - lo) * (side / (span * (1 + 1e-9)))).astype(np.int64), 0, side - 1)
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        v = (v | (v << 1)) & 0x55555555
+        return v
+
+    return spread(cell[:, 0]) | (spread(cell[:, 1]) << 1), 1 << (2 * bits)
+
+
 def locate_csr(tree: DeviceMesh, query: DeviceMesh = None, points=None, tolerance=None) -> "DeviceCSR":
     """locate_centroids + MatrixCOO.from_triplet on the device: one (face, 1.0) entry per located point."""
     tol = -1.0 if tolerance is None else float(tolerance)
@@ -338,6 +363,13 @@ class DeviceCSR:
             )
         )
         return cls(handle)
+
+    def set_row_keys(self, keys, key_range):
+        """Locality hint for uploaded weights (see include/xugrid_amd.h: xr_csr_set_row_keys)."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        if keys.shape != (self.n,):
+            raise ValueError("one key per row expected")
+        check(_lib.load().xr_csr_set_row_keys(self._h, _ptr(keys), int(key_range)))
 
     def download(self):
         """-> (data float64[nnz], indices intp[nnz], indptr intp[n+1])"""

@@ -144,7 +144,24 @@ class BaseRegridder(abc.ABC):
             if isinstance(w, MatrixCOO):
                 w = w.to_csr()
             self._device_weights = engine.DeviceCSR.from_arrays(w.data, w.indices, w.indptr, w.n, w.m)
+            self._attach_row_keys(self._device_weights)
         return self._device_weights
+
+    def _attach_row_keys(self, device_weights):
+        """Uploaded (cached) weights carry no geometry: hand the engine a coarse Morton key per target cell so
+        that applies of many variables can regroup the rows into compact tiles (pure locality hint)."""
+        target = self._target
+        try:
+            if isinstance(target, StructuredGrid2d):
+                yy, xx = np.meshgrid(target.ybounds.index, target.xbounds.index, indexing="ij")
+                centres = np.column_stack([xx.ravel(), yy.ravel()])
+            else:
+                centres = target.ugrid_topology.centroids
+        except Exception:
+            return
+        if centres.shape[0] == device_weights.n and device_weights.n >= 4096:
+            keys, key_range = engine.morton_row_keys(centres)
+            device_weights.set_row_keys(keys, key_range)
 
     def to_dataset(self) -> dict:
         """Weights + source + target topology as a flat dict of arrays, with the variable names of
