@@ -39,6 +39,10 @@ void engine_init(int device) {
     XR_HIP(hipGetDeviceProperties(&prop, device));
     g_engine.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     XR_HIP(hipHostMalloc(&g_engine.pinned, 4096, hipHostMallocDefault));
+    void *mail = nullptr;
+    XR_HIP(hipHostMalloc(&mail, 4096, hipHostMallocCoherent));
+    g_engine.mailbox = static_cast<volatile int32_t *>(mail);
+    XR_HIP(hipEventCreateWithFlags(&g_engine.mail_event, hipEventDisableTiming | hipEventReleaseToSystem));
     g_engine.device = device;
 }
 
@@ -121,6 +125,11 @@ void d2h(void *dst, const void *src, size_t bytes) {
 }
 
 void stream_sync() { XR_HIP(hipStreamSynchronize(engine().stream)); }
+
+void mailbox_wait() {
+    XR_HIP(hipEventRecord(engine().mail_event, engine().stream));
+    XR_HIP(hipEventSynchronize(engine().mail_event));
+}
 
 // ---------------------------------------------------------------------------------------------
 // kernel timing

@@ -68,8 +68,14 @@ struct Engine {
     hipStream_t stream = nullptr;
     int num_cu = 256;
     void *pinned = nullptr; // small pinned staging buffer for scalar read-backs
+    // "mailbox": pinned host memory that kernels write the few scalars the host is waiting for into
+    // (candidate count, nnz, overflow flag).  The host then waits on an event instead of issuing a
+    // device-to-host blit + stream synchronisation per scalar.
+    volatile int32_t *mailbox = nullptr; // [1024]
+    hipEvent_t mail_event = nullptr;
     bool prof = false;
 };
+void mailbox_wait(); // everything enqueued so far has executed and its mailbox writes are visible
 Engine &engine();      // initialises device 0 on first use
 void engine_init(int device);
 
@@ -141,7 +147,10 @@ inline unsigned div_up(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b
 // ---------------------------------------------------------------------------------------------
 // out[0..n] = exclusive prefix sum of in[0..n-1] (out has n+1 entries; out[n] = total).
 // in and out may alias when out == in is NOT required; separate buffers expected.
-void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n);
+// Optionally the grand total (and one extra device word, e.g. an overflow counter) is also deposited in host
+// memory (engine().mailbox) by the kernel that writes out[n].
+void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *host_total = nullptr,
+                        const int32_t *extra_src = nullptr, int32_t *extra_host = nullptr);
 void fill_i32(int32_t *p, int32_t v, int64_t n);
 void fill_f64(double *p, double v, int64_t n);
 

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ no
 }
 
 __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__ partials, int64_t nb,
-                                                     double *__restrict__ stats) {
+                                                     double *__restrict__ stats, double *stats_host) {
     double a0 = INFINITY, a1 = -INFINITY, a2 = INFINITY, a3 = -INFINITY, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     for (int64_t i = threadIdx.x; i < nb; i += 256) {
         const double *p = partials + i * 8;
@@ -183,6 +183,8 @@ __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__
         }
         stats[0] = a0; stats[1] = a1; stats[2] = a2; stats[3] = a3; stats[4] = a4; stats[5] = a5; stats[6] = a6;
         stats[7] = a7;
+        stats_host[0] = a0; stats_host[1] = a1; stats_host[2] = a2; stats_host[3] = a3; stats_host[4] = a4;
+        stats_host[5] = a5; stats_host[6] = a6; stats_host[7] = a7;
     }
 }
 
@@ -208,7 +210,15 @@ void mesh_prepare(xr_mesh *mesh) {
         XR_LAUNCH("prepare_faces", k_prepare_faces<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
                   mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
     }
-    XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get());
+    if (!mesh->stats_host) {
+        void *p = nullptr;
+        XR_HIP(hipHostMalloc(&p, sizeof(double) * 8, hipHostMallocCoherent));
+        mesh->stats_host = static_cast<double *>(p);
+        XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
+    }
+    XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
+              mesh->stats_host);
+    XR_HIP(hipEventRecord(mesh->stats_event, engine().stream));
     mesh->prepared = true;
     mesh->stats_valid = false;
 }
@@ -216,7 +226,8 @@ void mesh_prepare(xr_mesh *mesh) {
 void mesh_read_stats(xr_mesh *mesh) {
     mesh_prepare(mesh);
     if (mesh->stats_valid) return;
-    d2h(mesh->h_stats, mesh->stats.get(), sizeof(double) * 8);
+    XR_HIP(hipEventSynchronize(mesh->stats_event));
+    for (int i = 0; i < 8; i++) mesh->h_stats[i] = mesh->stats_host[i];
     mesh->stats_valid = true;
 }
 

@@ -27,6 +27,17 @@ struct xr_mesh {
     xr::DevBuf<double> stats; // [8] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal,sum_jump (device)
     bool stats_valid = false;
     double h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // the reduction kernel also deposits the statistics in pinned host memory; the host waits on an event
+    // recorded right behind it, so kernels queued later (the other mesh's prepare) keep the GPU busy meanwhile
+    double *stats_host = nullptr; // [8] pinned
+    hipEvent_t stats_event = nullptr;
+    xr_mesh() = default;
+    xr_mesh(const xr_mesh &) = delete;
+    xr_mesh &operator=(const xr_mesh &) = delete;
+    ~xr_mesh() {
+        if (stats_host) (void)hipHostFree(stats_host);
+        if (stats_event) (void)hipEventDestroy(stats_event);
+    }
 
     // ---- query order.  If the caller's face numbering is already spatially coherent (mean distance
     // between consecutive faces <= a few face extents) the caller's order IS the query order:

@@ -939,8 +939,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
               query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
               tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, (const int32_t *)nullptr,
               cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
-    exclusive_scan_i32(cand_count.get(), cand_off.get(), T);
-    const int32_t C32 = read_scalar(cand_off.get() + T);
+    int32_t *mail = const_cast<int32_t *>(engine().mailbox);
+    exclusive_scan_i32(cand_count.get(), cand_off.get(), T, mail + 0);
+    mailbox_wait();
+    const int32_t C32 = mail[0];
     XR_REQUIRE(C32 >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
     const int64_t C = C32;
     tree->last_candidates = C;
@@ -959,11 +961,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
                         nnz_row.get());
     }
     // --- rows
-    exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
-    // P is needed on the host anyway; the overflow counter travels in the same read-back
-    XR_HIP(hipMemcpyAsync(counters.get() + 3, csr->indptr.get() + T, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    int32_t tail[4];
-    d2h(tail, counters.get(), sizeof(int32_t) * 4);
+    // P is needed on the host anyway; the overflow counter travels in the same mailbox round trip
+    exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T, mail + 1, counters.get(), mail + 2);
+    mailbox_wait();
+    int32_t tail[4] = {mail[2], 0, 0, mail[1]};
     if (tail[0] > 0) {
         // polygon buffer overflow in the small-MAXV kernel (floating-point degenerate pairs):
         // redo those pairs with the oracle's buffer size, then recount every row.

@@ -54,7 +54,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const int32_t *__res
 
 // single block scans up to any number of partials sequentially by tiles
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partials(int32_t *__restrict__ sums, int64_t nb,
-                                                              int32_t *__restrict__ total_out) {
+                                                              int32_t *__restrict__ total_out, int32_t *host_total,
+                                                              const int32_t *extra_src, int32_t *extra_host) {
     __shared__ int lds[4];
     int carry = 0;
     for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
@@ -66,6 +67,8 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_partials(int32_t *__restric
         carry += tot;
     }
     if (threadIdx.x == 0 && total_out) *total_out = carry;
+    if (threadIdx.x == 0 && host_total) *host_total = carry;
+    if (threadIdx.x == 0 && extra_host) *extra_host = *extra_src;
 }
 
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const int32_t *__restrict__ in,
@@ -107,7 +110,8 @@ static constexpr int SCAN_FUSED_TILES = 8192;
 
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply_fused(const int32_t *__restrict__ in,
                                                                  const int32_t *__restrict__ tile_sums, int64_t nb,
-                                                                 int32_t *__restrict__ out, int64_t n) {
+                                                                 int32_t *__restrict__ out, int64_t n, int32_t *host_total,
+                                                                 const int32_t *extra_src, int32_t *extra_host) {
     __shared__ int lds[4];
     __shared__ int sh_base;
     // offset of this tile = sum of the tile sums before it (strided partial sums + block reduce)
@@ -133,22 +137,34 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply_fused(const int32_t *
         if (j < n) out[j] = ex;
         ex += v[i];
     }
-    if (blockIdx.x == nb - 1 && threadIdx.x == 0) out[n] = sh_base + tot; // grand total
+    if (blockIdx.x == nb - 1 && threadIdx.x == 0) {
+        out[n] = sh_base + tot; // grand total
+        if (host_total) *host_total = sh_base + tot;
+        if (extra_host) *extra_host = *extra_src;
+    }
 }
 
-void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n) {
+void exclusive_scan_i32(const int32_t *in, int32_t *out, int64_t n, int32_t *host_total, const int32_t *extra_src,
+                        int32_t *extra_host) {
     if (n <= 0) {
         fill_i32(out, 0, 1);
+        if (host_total) {
+            stream_sync();
+            *host_total = 0;
+            if (extra_host) d2h(extra_host, extra_src, sizeof(int32_t));
+        }
         return;
     }
     const int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
     DevBuf<int32_t> sums((size_t)nb);
     XR_LAUNCH("scan_reduce", k_scan_reduce, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), n);
     if (nb <= SCAN_FUSED_TILES) {
-        XR_LAUNCH("scan_apply", k_scan_apply_fused, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), nb, out, n);
+        XR_LAUNCH("scan_apply", k_scan_apply_fused, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), nb, out, n,
+                  host_total, extra_src, extra_host);
         return;
     }
-    XR_LAUNCH("scan_partials", k_scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, sums.get(), nb, out + n);
+    XR_LAUNCH("scan_partials", k_scan_partials, dim3(1), dim3(SCAN_BLOCK), 0, sums.get(), nb, out + n, host_total, extra_src,
+              extra_host);
     XR_LAUNCH("scan_apply", k_scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, in, sums.get(), out, n);
 }
 
