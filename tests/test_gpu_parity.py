@@ -436,3 +436,41 @@ def test_apply_many_variables_row_tiling(hip, oracle):
         up.set_row_keys(keys, key_range)  # rows are already stored in a spatial order
     with pytest.raises(ValueError):
         E.DeviceCSR.from_arrays(oa, os_, indptr, csr.n, csr.m).set_row_keys(keys + key_range, key_range)
+
+
+def test_overlap_projected_coordinates(hip, oracle):
+    """UTM-like coordinates (offsets of 5e5 / 6e6 m, 10-50 m cells): the f32 record bboxes are stored relative
+    to the grid origin and rounded outwards, so nothing is lost against the f64 oracle."""
+    sxy, sf = meshgen.triangle_mesh(4000, 11)
+    txy, tf = meshgen.triangle_mesh(5000, 12, 20.0, 0.9)
+    off = np.array([512_345.678, 6_123_456.789])
+    sxy, txy = off + 3000.0 * sxy, off + 3000.0 * txy
+    assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
+    assert_overlap_parity(hip, oracle, sxy, sf, txy, tf, relative=True)
+    E = hip.engine
+    pts = off + 3000.0 * np.random.default_rng(0).random((20000, 2)) * 1.1 - 100.0
+    tree = oracle.CellTree2d(sxy, sf, -1)
+    assert np.array_equal(E.DeviceMesh(sxy, sf).locate_points(pts), tree.locate_points(pts))
+    fo, wo = tree.compute_barycentric_weights(pts)
+    fg, wg = E.DeviceMesh(sxy, sf).compute_barycentric_weights(pts)
+    assert np.array_equal(fg, fo) and np.array_equal(wg, wo)
+
+
+def test_device_pipelines_with_empty_sides(hip):
+    """locate / barycentric CSR builders with an empty query or an empty tree."""
+    E = hip.engine
+    sxy, sf = meshgen.triangle_mesh(300, 2)
+    src = E.DeviceMesh(sxy, sf)
+    empty = E.DeviceMesh(sxy, np.zeros((0, 3), dtype=np.int64))
+    c = E.locate_csr(src, query=empty)
+    assert (c.n, c.m, c.nnz) == (0, sf.shape[0], 0)
+    c = E.locate_csr(empty, query=src)
+    assert (c.n, c.m, c.nnz) == (sf.shape[0], 0, 0)
+    assert np.isnan(c.apply(np.zeros((2, 0)), E.METHOD_IDS["select"])).all()
+    c = E.locate_csr(src, points=np.zeros((0, 2)))
+    assert (c.n, c.nnz) == (0, 0)
+    # all points outside
+    c = E.locate_csr(src, points=np.full((5, 2), 99.0))
+    assert (c.n, c.nnz) == (5, 0)
+    out = c.apply(np.ones((1, sf.shape[0])), E.METHOD_IDS["select"])
+    assert out.shape == (1, 5) and np.isnan(out).all()
