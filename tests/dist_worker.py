@@ -13,7 +13,11 @@ sys.path.insert(0, ROOT)
 
 from oracle import oracle as O  # noqa: E402
 from xugrid_amd import meshgen  # noqa: E402
-from xugrid_amd.distributed import ShardedOverlapRegridder, init_process_group_from_env  # noqa: E402
+from xugrid_amd.distributed import (  # noqa: E402
+    ShardedOverlapRegridder,
+    TargetPartitionedRegridder,
+    init_process_group_from_env,
+)
 
 
 class OracleWeights:
@@ -31,6 +35,12 @@ class OracleBackend:
 
     def to_device(self, array):
         return torch.as_tensor(np.ascontiguousarray(array))
+
+    def apply(self, w, source, method_id, percentile=0.0):
+        names = {0: "mean", 1: "harmonic_mean", 2: "geometric_mean", 3: "sum", 4: "minimum", 5: "maximum", 6: "mode",
+                 8: "first_order_conservative", 9: "max_overlap"}
+        method = ("percentile", percentile) if method_id == 7 else names[method_id]
+        return torch.as_tensor(O.regrid_csr(method, source.numpy(), w.data, w.indices, w.indptr, w.n))
 
     def partial_mean(self, w, source):
         src = source.numpy().astype(np.float64)
@@ -78,6 +88,10 @@ def main():
         results[mode + "_1d"] = rg.regrid(data[0])
         results[mode + "_n_local"] = rg.local_faces.size
         results[mode + "_n_local_targets"] = rg.local_targets.size
+    for method in ("mode", "median", "max_overlap", "minimum", "sum", "mean"):
+        tp = TargetPartitionedRegridder(sxy, sf, txy, tf, OracleBackend(), method=method)
+        results["tp_" + method] = tp.regrid(data)
+        results["tp_n_local_sources"] = tp.local_faces.size
     if rank == 0:
         np.savez(os.path.join(out_dir, "dist_out.npz"), world=world, **results)
     dist.barrier()

@@ -1,0 +1,46 @@
+"""Worker of the GPU distributed test: the product's HipBackend (C ABI through torch device pointers) inside a
+torch.distributed process group over RCCL ("nccl").  The GPU box has one device, so the group has one rank; the
+collectives still run through RCCL.  Results go to an .npz that the test compares with the oracle."""
+import os
+import sys
+
+import numpy as np
+import torch  # noqa: F401  (initialised before the engine binds the device)
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from xugrid_amd import meshgen  # noqa: E402
+from xugrid_amd.distributed import (  # noqa: E402
+    HipBackend,
+    ShardedOverlapRegridder,
+    TargetPartitionedRegridder,
+    init_process_group_from_env,
+)
+
+
+def main():
+    out_dir = sys.argv[1]
+    init_process_group_from_env("nccl")
+    rank = dist.get_rank()
+    backend = HipBackend(int(os.environ.get("LOCAL_RANK", rank)))
+    sxy, sf = meshgen.triangle_mesh(3000, 0)
+    txy, tf = meshgen.triangle_mesh(2501, 1, 30.0, 0.7)
+    data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
+    results = {}
+    for exchange in ("sparse", "dense"):
+        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, exchange=exchange)
+        results["mean_" + exchange] = rg.regrid(data)
+        rg.rebuild()
+        results["mean_rebuilt_" + exchange] = rg.regrid(data.astype(np.float32))
+    for method in ("mode", "median", "max_overlap", "minimum"):
+        results["tp_" + method] = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method=method).regrid(data)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "dist_gpu_out.npz"), **results)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

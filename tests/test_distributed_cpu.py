@@ -63,3 +63,9 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     # spatially compact shards only look at the targets near them; hash shards see (almost) all
     assert int(out["morton_n_local_targets"]) < 0.8 * tf.shape[0]
     assert int(out["hash_n_local_targets"]) > 0.95 * tf.shape[0]
+    # target-partitioned replicas (row-wise reducers): exactly the single-process result, no collective
+    indptr = oracle.to_csr_indptr(q, tf.shape[0])
+    for method in ("mode", "median", "max_overlap", "minimum", "sum", "mean"):
+        single = oracle.regrid_csr(method, data, a, s, indptr, tf.shape[0])
+        assert np.array_equal(out["tp_" + method], single, equal_nan=True), method
+    assert int(out["tp_n_local_sources"]) < 0.85 * sf.shape[0]

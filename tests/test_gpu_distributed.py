@@ -1,0 +1,43 @@
+"""
+GPU (-m gpu): the multi-GPU code path with the product's HIP backend, run as a one-rank RCCL process group
+(the GPU box has a single device; world_size 2 is covered on CPU over gloo in test_distributed_cpu.py).
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from xugrid_amd import meshgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sharded_and_target_partitioned_regridders_rccl(hip, oracle, tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker_gpu.py"), str(tmp_path)]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    out = np.load(tmp_path / "dist_gpu_out.npz")
+    sxy, sf = meshgen.triangle_mesh(3000, 0)
+    txy, tf = meshgen.triangle_mesh(2501, 1, 30.0, 0.7)
+    data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
+    q, s_, a = oracle.CellTree2d(sxy, sf).intersect_faces(txy, tf)
+    indptr = oracle.to_csr_indptr(q, tf.shape[0])
+    exp = oracle.regrid_csr("mean", data, a, s_, indptr, tf.shape[0])
+    exp32 = oracle.regrid_csr("mean", data.astype(np.float32), a, s_, indptr, tf.shape[0])
+    for exchange in ("sparse", "dense"):
+        # partial sums + finalise: same additions as the sequential loop on one rank
+        np.testing.assert_allclose(out["mean_" + exchange], exp, rtol=1e-13, equal_nan=True)
+        np.testing.assert_allclose(out["mean_rebuilt_" + exchange], exp32, rtol=1e-13, equal_nan=True)
+    assert np.array_equal(out["mean_sparse"], out["mean_dense"], equal_nan=True)
+    for method in ("mode", "median", "max_overlap", "minimum"):
+        single = oracle.regrid_csr(method, data, a, s_, indptr, tf.shape[0])
+        assert np.array_equal(out["tp_" + method], single, equal_nan=True), method

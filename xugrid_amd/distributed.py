@@ -18,9 +18,12 @@ exchange step comes in two forms:
             all_to_all_single of ~T/N rows per rank; the owner adds the contributions sender by
             sender (deterministic order).  Index lists are exchanged once at set-up.
 
-Only sum-decomposable reducers shard over sources; ``mean`` is implemented (it is the reducer of
-OverlapRegridder's default and of BarycentricInterpolator).  ``mode``, percentiles and
-``max_overlap`` need the whole row and would run as target-partitioned replicas instead.
+Only sum-decomposable reducers shard over sources; ``mean`` is implemented that way (it is the reducer
+of OverlapRegridder's default and of BarycentricInterpolator).  Every other reducer -- ``mode``, percentiles,
+``max_overlap``, ``minimum`` ... -- needs the whole row of a target: ``TargetPartitionedRegridder`` gives each
+rank a contiguous slice of the TARGETS plus the sources near them (the same occupancy-raster filter, the other
+way round), so a rank holds complete rows, applies any reducer locally, bit-identically to one GPU, and the only
+communication is the optional gather of the output slices (SURVEY.md 8e "not shardable over sources").
 
 The compute backend is a parameter: the product uses ``HipBackend`` (C ABI, device pointers of
 torch tensors); the world_size-2 gloo tests on CPU inject an oracle-backed backend with the same
@@ -92,6 +95,17 @@ class HipBackend:
 
     def to_device(self, array):
         return self.torch.as_tensor(np.ascontiguousarray(array), device=self.device)
+
+    def apply(self, weights, source, method_id, percentile=0.0):
+        """Any reducer on complete rows: (K, S_local) device tensor -> (K, T_local) float64 device tensor."""
+        torch = self.torch
+        K = source.shape[0]
+        out = torch.empty((K, weights.n), dtype=torch.float64, device=self.device)
+        dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
+        torch.cuda.current_stream().synchronize()
+        weights.apply_dev(source.data_ptr(), dtype, K, out.data_ptr(), method_id, percentile)
+        self.engine.dev_sync()
+        return out
 
     def partial_mean(self, weights, source):
         """source: (K, S_local) float64/float32 device tensor -> (2, K, T) float64 device tensor."""
@@ -302,6 +316,70 @@ class ShardedOverlapRegridder:
             return local
         parts = [torch.empty_like(local) for _ in range(self.world)]
         self.dist.all_gather(parts, local, group=self.group)
+        out = torch.cat(parts, dim=1)[:, : self.n_target].cpu().numpy()
+        return out[0] if squeeze else out
+
+
+class TargetPartitionedRegridder:
+    """
+    ``OverlapRegridder(source, target, method)`` for reducers that need whole rows: rank r owns the targets
+    ``[r * chunk, (r + 1) * chunk)`` and the source faces that can overlap them.  No data-path collective; results
+    are exactly those of a single GPU.  ``method``: a name of reduce.ABSOLUTE_OVERLAP_METHODS /
+    RELATIVE_OVERLAP_METHODS or a ``Method`` from ``create_percentile_method``.
+    """
+
+    def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, method="mean", group=None):
+        import torch.distributed as dist
+
+        from .reduce import ABSOLUTE_OVERLAP_METHODS, RELATIVE_OVERLAP_METHODS, Method
+
+        if isinstance(method, Method):
+            self.method = method
+        else:
+            table = {**ABSOLUTE_OVERLAP_METHODS, **RELATIVE_OVERLAP_METHODS}
+            if method not in table:
+                raise ValueError("Invalid regridding method. Available methods are: {}".format(table.keys()))
+            self.method = table[method]
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.backend = backend
+        source_faces = np.asarray(source_faces)
+        target_faces = np.asarray(target_faces)
+        sxy = np.asarray(source_xy, dtype=np.float64)
+        txy = np.asarray(target_xy, dtype=np.float64)
+        self.n_source, self.n_target = source_faces.shape[0], target_faces.shape[0]
+        self.t_chunk = -(-self.n_target // self.world)
+        lo = min(self.rank * self.t_chunk, self.n_target)
+        hi = min(lo + self.t_chunk, self.n_target)
+        self.local_targets = np.arange(lo, hi)
+        # sources that can overlap the owned targets (conservative filter; complete rows guaranteed)
+        self.local_faces = _targets_near_shard(txy, target_faces[lo:hi], sxy, source_faces)
+        self.weights = backend.build_weights(sxy, source_faces[self.local_faces], txy, target_faces[lo:hi])
+
+    def local_source(self, data):
+        data = np.asarray(data)
+        if data.ndim == 1:
+            data = data[None, :]
+        return self.backend.to_device(data[:, self.local_faces])
+
+    def regrid_local(self, local_source):
+        """local (K, S_local) device tensor -> this rank's (K, owned targets) slice."""
+        return self.backend.apply(self.weights, local_source, self.method.method_id, self.method.percentile)
+
+    def regrid(self, data, gather=True):
+        import torch
+
+        squeeze = np.asarray(data).ndim == 1
+        local = self.regrid_local(self.local_source(data))
+        if not gather:
+            return local
+        K = local.shape[0]
+        padded = torch.full((K, self.t_chunk), float("nan"), dtype=local.dtype, device=local.device)
+        padded[:, : local.shape[1]] = local
+        parts = [torch.empty_like(padded) for _ in range(self.world)]
+        self.dist.all_gather(parts, padded, group=self.group)
         out = torch.cat(parts, dim=1)[:, : self.n_target].cpu().numpy()
         return out[0] if squeeze else out
 
