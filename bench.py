@@ -167,6 +167,28 @@ def run_single(args):
             traffic = entry["hbm_bytes_corrected"] if entry else None
         except Exception:
             traffic = None
+    # The dominant kernel (the clip) is FP64-VALU work, not HBM traffic: next to the HBM fraction the contract asks
+    # for, report how close it runs to the VALU issue limit.  Instruction count from the committed PMC pass
+    # (SQ_INSTS_VALU, wave-instructions per launch); a wave64 FP64 instruction occupies its SIMD for 4 cycles
+    # (78.6 TFLOP/s FP64 vector peak = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz), a 32-bit one for 2.
+    valu = None
+    ppath = os.path.join(ROOT, "profiles", "r01e_pmc_per_launch.json")
+    pmc_names = {"clip_small": "k_clip_small<6, 256, true>", "search": "k_search"}
+    if os.path.exists(ppath) and dominant in pmc_names:
+        try:
+            insts = json.load(open(ppath))[pmc_names[dominant]]["SQ_INSTS_VALU"]
+            n_simd, clock = 256 * 4, 2.4e9
+            floor_fp64_ms = insts * 4 / n_simd / clock * 1e3
+            floor_mixed_ms = insts * 3 / n_simd / clock * 1e3
+            valu = {
+                "wave_instructions_per_launch": insts,
+                "issue_floor_ms_all_fp64": floor_fp64_ms,
+                "issue_floor_ms_half_fp64": floor_mixed_ms,
+                "frac_of_issue_limit": [floor_mixed_ms / dom_ms, floor_fp64_ms / dom_ms],
+                "source": "profiles/r01e_pmc_per_launch.json",
+            }
+        except Exception:
+            valu = None
     build_ms = sum(v for k, v in per_step.items() if not k.startswith("apply"))
     roofline = {
         "bound": "hbm",
@@ -178,6 +200,7 @@ def run_single(args):
         "traffic": traffic,
         "algorithmic_bytes_per_launch": dom_bytes,
         "avg_launch_ms": dom_ms,
+        "valu_issue": valu,
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
         "build_aggregate": {
             "algorithmic_bytes": ab["build_total"],
