@@ -66,8 +66,7 @@ def algorithmic_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
     b["order_count"] = 32 * T + 4 * T
     b["index_scatter"] = (4 + vs + 1 + 32) * S + (4 + vs + 1 + 16) * S
     b["order_scatter"] = (4 + vt + 1 + 32) * T + (4 + vt + 1 + 32) * T
-    b["search"] = 32 * T + 16 * S + 4 * T + 4 * C  # query boxes, record boxes once, counts, slot rows
-    b["compact"] = 4 * C + 4 * T + 8 * C
+    b["search"] = 32 * T + 16 * S + 8 * T + 8 * C  # query boxes, record boxes once, count + offset, pair queue out
     b["clip_small"] = 8 * C + vt * T + vs * S + (S + T) + 4 * S + 12 * C + 4 * T  # queue, vertex blocks, area + face id out
     b["row_fill"] = 4 * T + 16 * C + 4 * T + 12 * P
     b["apply_stream"] = 12 * P + 4 * (T + 1) + 4 * T + 8 * (S + T)

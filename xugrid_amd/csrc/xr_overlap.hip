@@ -6,10 +6,11 @@
 // xugrid/core/sparse.py:61-78).
 //
 // Pipeline (all on the engine stream):
-//   search         one thread per query (target) face walks the tree mesh's hierarchical grid,
-//                  parks the bbox-overlapping tree records in a 16-slot row  -> cand_count[T]
-//   scan           exclusive prefix sum                                     -> cand_off[T+1]
-//   compact        slot rows -> dense candidate-pair queue                   -> cand_tgt/src[C]
+//   search         one thread per query (target) face walks the tree mesh's hierarchical grid and
+//                  parks the bbox-overlapping tree records in 16 LDS slots; the block reserves its
+//                  stretch of the candidate-pair queue with one atomic and writes it compacted
+//                                               -> cand_off/cand_count[T], cand_tgt/src[C]
+//   search_big     faces with too many rows / records / hits: block per face, count -> reserve -> fill
 //   clip           one thread per candidate pair: Sutherland-Hodgman clip of the query polygon
 //                  by the tree polygon, polygon buffers staged in LDS ([vertex][thread] layout,
 //                  conflict-free 16-byte accesses), fan area                 -> cand_area[C]
@@ -48,10 +49,14 @@ static constexpr int TILE_RUN = 64; // rows per run in the tiling hint (512-byte
 
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const int32_t *__restrict__ cell_start,
-         const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ slots,
-         uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, MortonParams tile,
-         int32_t *__restrict__ tile_key) {
-    __shared__ int32_t sh_slots[SLOTS][256]; // [slot][thread]: conflict-free, written out as whole lines
+         const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_off,
+         int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
+         int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
+         int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key) {
+    __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS][256]; // [slot][thread]: conflict-free
+    __shared__ uint8_t sh_owner[SLOTS * 256];
+    __shared__ int32_t sh_wave[4];
+    __shared__ int32_t sh_base;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int count = 0;
     bool big = false;
@@ -121,40 +126,58 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
         }
         if (count > SLOTS) big = true;
         is_big[t] = big ? 1 : 0;
-        cand_count[t] = big ? 0 : count;
         if (big) big_list[atomicAdd(n_big, 1)] = (int32_t)t;
     }
-    // every thread writes its own 64-byte slot row
-    if (t < n_query && !big && count > 0) {
-        int4 *row = reinterpret_cast<int4 *>(slots + t * SLOTS);
+    // The block's candidates go straight into the pair queue: block-level exclusive scan of the counts, ONE
+    // atomic reservation per block, then the entries -- compacted in LDS -- are written as whole lines.  No
+    // slot array, no global scan, no compaction pass; blocks land in the queue in arbitrary order (nothing
+    // downstream depends on it: rows are re-ranked by tree face id), the rows of one block stay contiguous.
+    const int mine = (t < n_query && !big) ? count : 0;
+    int own[SLOTS];
 #pragma unroll
-        for (int q = 0; q < SLOTS / 4; q++) {
-            if (q * 4 < count)
-                row[q] = make_int4(sh_slots[q * 4][threadIdx.x], sh_slots[q * 4 + 1][threadIdx.x],
-                                   sh_slots[q * 4 + 2][threadIdx.x], sh_slots[q * 4 + 3][threadIdx.x]);
+    for (int j = 0; j < SLOTS; j++) own[j] = j < mine ? sh_slots[j][threadIdx.x] : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    if (lane == 63) sh_wave[wave] = incl;
+    __syncthreads(); // (also: every thread has read its slots)
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w < wave) woff += sh_wave[w];
+        total += sh_wave[w];
+    }
+    const int lo = woff + incl - mine;
+    if (threadIdx.x == 0) sh_base = total > 0 ? atomicAdd(queue_cursor, total) : 0;
+    int32_t *flat = &sh_slots[0][0];
+#pragma unroll
+    for (int j = 0; j < SLOTS; j++) {
+        if (j < mine) {
+            flat[lo + j] = own[j];
+            sh_owner[lo + j] = (uint8_t)threadIdx.x;
         }
+    }
+    __syncthreads();
+    const int base = sh_base;
+    if (t < n_query && !big) { // big faces get their offset and count from k_search_big<false>
+        cand_off[t] = base + lo;
+        cand_count[t] = mine;
+    }
+    if (threadIdx.x == 0) block_seg[blockIdx.x] = make_int2(base, total);
+    const int32_t t0 = (int32_t)((int64_t)blockIdx.x * 256);
+    for (int i = threadIdx.x; i < total; i += 256) {
+        cand_tgt[base + i] = t0 + sh_owner[i];
+        cand_src[base + i] = flat[i];
     }
 }
 
-__global__ void __launch_bounds__(256)
-k_compact(const int32_t *__restrict__ slots, const int32_t *__restrict__ cand_off, const uint8_t *__restrict__ is_big,
-          int64_t n_query, int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= n_query || is_big[t]) return;
-    const int c0 = cand_off[t], n = cand_off[t + 1] - c0;
-    const int4 *row = reinterpret_cast<const int4 *>(slots + t * SLOTS);
-#pragma unroll
-    for (int q = 0; q < SLOTS / 4; q++) {
-        if (q * 4 < n) {
-            const int4 v = row[q];
-            const int k = q * 4;
-            cand_tgt[c0 + k] = (int32_t)t;
-            cand_src[c0 + k] = v.x;
-            if (k + 1 < n) { cand_tgt[c0 + k + 1] = (int32_t)t; cand_src[c0 + k + 1] = v.y; }
-            if (k + 2 < n) { cand_tgt[c0 + k + 2] = (int32_t)t; cand_src[c0 + k + 2] = v.z; }
-            if (k + 3 < n) { cand_tgt[c0 + k + 3] = (int32_t)t; cand_src[c0 + k + 3] = v.w; }
-        }
-    }
+// deposit one device word in the host mailbox (pinned memory)
+__global__ void k_publish(const int32_t *__restrict__ src, int32_t *dst) {
+    if (threadIdx.x == 0) *dst = *src;
 }
 
 // One block per big query face.  The face is scan-converted against the grid: for grid row cy of
@@ -186,8 +209,8 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
              const uint8_t *__restrict__ q_len, int q_m, GridParams g,
              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
              const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
-             const int32_t *__restrict__ n_big, const int32_t *__restrict__ cand_off,
-             int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src) {
+             const int32_t *__restrict__ n_big, int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count,
+             int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor) {
     // one BLOCK per big face: its four waves take the 64-row batches round-robin; candidates are
     // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
     // ranked by tree face id afterwards)
@@ -304,7 +327,10 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
             // block total (every lane of a wave holds the wave's total)
             if (lane == 0) atomicAdd(&sh_cursor, total);
             __syncthreads();
-            if (threadIdx.x == 0) cand_count[t] = sh_cursor;
+            if (threadIdx.x == 0) { // reserve the face's stretch of the pair queue
+                cand_count[t] = sh_cursor;
+                cand_off[t] = atomicAdd(queue_cursor, sh_cursor);
+            }
         }
     }
 }
@@ -595,13 +621,14 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
 // ---------------------------------------------------------------------------------------------
 // recount of the survivors per row; only used after the rare clip-buffer overflow redo
 __global__ void __launch_bounds__(256) k_row_count(const int32_t *__restrict__ cand_off,
+                                                  const int32_t *__restrict__ cand_count,
                                                   const double *__restrict__ cand_area, int64_t n_query,
                                                   const int32_t *__restrict__ q_perm,
                                                   int32_t *__restrict__ nnz_row) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_query) return;
     int n = 0;
-    for (int c = cand_off[t]; c < cand_off[t + 1]; c++) n += cand_area[c] > 0 ? 1 : 0;
+    for (int c = cand_off[t]; c < cand_off[t] + cand_count[t]; c++) n += cand_area[c] > 0 ? 1 : 0;
     nnz_row[t] = n;
 }
 
@@ -616,8 +643,10 @@ static constexpr int ROW_LDS = 3072; // short-row candidate entries one block ca
 // (adjacent in LDS) and writes it to its final CSR position.  Rows are stored in QUERY order
 // (row r belongs to the caller's face q_perm[r], xr_csr::row_order).
 __global__ void __launch_bounds__(256)
-k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_tgt,
-           const int32_t *__restrict__ cand_sid, const double *__restrict__ cand_area, int64_t n_query,
+k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_count,
+           const int2 *__restrict__ block_seg, const uint8_t *__restrict__ is_big,
+           const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_sid,
+           const double *__restrict__ cand_area, int64_t n_query,
            const int32_t *__restrict__ indptr, const double *__restrict__ src_area, bool relative,
            int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ long_rows,
            int32_t *__restrict__ n_long, int32_t *__restrict__ apply_long_rows,
@@ -630,18 +659,22 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
     __shared__ int32_t sh_wave[4];
     const int64_t t0 = (int64_t)blockIdx.x * 256;
     const int64_t t = t0 + threadIdx.x;
-    const int64_t t_end = t0 + 256 < n_query ? t0 + 256 : n_query;
-    const int seg0 = cand_off[t0], seg1 = cand_off[t_end];
+    // the candidates of the block's rows that k_search wrote itself (all but its "big" faces) are one stretch
+    const int2 seg = block_seg[blockIdx.x];
+    const int seg0 = seg.x, seg1 = seg.x + seg.y;
     int c0 = 0, len = 0;
+    bool is_short = true; // packed here; everything else (long rows, and the "big" faces of the search, whose
+                          // candidates live elsewhere in the queue) goes to the block-per-row kernel
     if (t < n_query) {
         c0 = cand_off[t];
-        len = cand_off[t + 1] - c0;
+        len = cand_count[t];
+        is_short = len <= ROW_SHORT && !is_big[t];
         sh_ptr[threadIdx.x] = indptr[t];
-        if (len > ROW_SHORT) long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
+        if (!is_short) long_rows[atomicAdd(n_long, 1)] = (int32_t)t;
         if (indptr[t + 1] - indptr[t] > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(n_apply_long, 1)] = (int32_t)t;
     }
-    const int slen = len > ROW_SHORT ? 0 : len;
-    sh_c0[threadIdx.x] = len > ROW_SHORT ? -1 : c0;
+    const int slen = is_short ? len : 0;
+    sh_c0[threadIdx.x] = is_short ? c0 : -1;
     // block exclusive scan of the short-row lengths
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int incl = slen;
@@ -683,8 +716,8 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
             indices[pos] = s;
             data[pos] = relative ? a / src_area[s] : a;
         }
-    } else if (t < n_query && len <= ROW_SHORT) {
-        // cannot happen with ROW_LDS >= 256 * ROW_SHORT; kept as a safe slow path
+    } else if (t < n_query && is_short) {
+        // more short-row candidates than the LDS stage holds: rank straight from memory
         const int base = indptr[t];
         for (int i = c0; i < c0 + len; i++) {
             const double a = cand_area[i];
@@ -719,7 +752,8 @@ static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread segment
 static constexpr int BM_STAGE = 4096;           // candidates parked in LDS (16 KiB); longer rows re-read HBM
 
 __global__ void __launch_bounds__(256)
-k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_sid,
+k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_count,
+                const int32_t *__restrict__ cand_sid,
                 const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
                 const double *__restrict__ src_area, bool relative, int64_t n_tree, int32_t *__restrict__ indices,
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
@@ -734,7 +768,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     const int nl = *n_long;
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
-        const int c0 = cand_off[t], n = cand_off[t + 1] - c0;
+        const int c0 = cand_off[t], n = cand_count[t];
         const int base = indptr[t];
         __syncthreads();
         // park the row: survivor id or -1 (four independent pairs of loads per thread and trip)
@@ -905,14 +939,21 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     }
     const GridParams &g = tree->grid;
     hipStream_t st = engine().stream;
-    // counters: [0] clip overflow, [1] number of long rows, [2] number of big query faces
+    // counters: [0] clip overflow, [1] number of long rows, [2] number of big query faces, [3] pair-queue cursor
     DevBuf<int32_t> counters(4);
     XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 4, st));
-    // --- candidate search: count -> scan -> fill
+    // --- candidate search.  k_search appends the candidates of its 256 faces to the pair queue itself (one
+    // atomic reservation per block); the few "big" faces are counted, reserve their stretch, and are filled by
+    // the block-per-face kernels.  The queue is sized for the regular faces (at most SLOTS candidates each) plus
+    // a margin for the big ones; if the big faces need more, it is regrown before they are filled (rare).
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
     DevBuf<uint8_t> is_big((size_t)T);
     const int big_grid = engine().num_cu * 8;
-    DevBuf<int32_t> slots((size_t)T * SLOTS);
+    const int64_t n_blocks = div_up(T, 256);
+    DevBuf<int2> block_seg((size_t)n_blocks);
+    int64_t capacity = T * SLOTS + ((int64_t)4 << 20);
+    XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
+    DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity);
     // Rows kept in the caller's (coherent, but typically strip-like) numbering get a coarse Morton key each:
     // tiles of 12-24 mean target extents, runs of TILE_RUN consecutive rows kept together.  A Morton-sorted query order is tiled already.
     MortonParams tile{};
@@ -933,29 +974,39 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->has_tile_key = bits > 0;
     }
     XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->qo_bbox(), T, g,
-              tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), slots.get(), is_big.get(), big_list.get(),
-              counters.get() + 2, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr);
+              tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
+              cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
+              csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr);
     XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
               query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
-              tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, (const int32_t *)nullptr,
-              cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr);
+              tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
+              cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr, counters.get() + 3);
+    // queue length -> host
     int32_t *mail = const_cast<int32_t *>(engine().mailbox);
-    exclusive_scan_i32(cand_count.get(), cand_off.get(), T, mail + 0);
+    XR_LAUNCH("publish", k_publish, dim3(1), dim3(64), 0, counters.get() + 3, mail + 0);
     mailbox_wait();
     const int32_t C32 = mail[0];
     XR_REQUIRE(C32 >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
     const int64_t C = C32;
     tree->last_candidates = C;
-    DevBuf<int32_t> cand_tgt((size_t)C), cand_src((size_t)C), cand_sid((size_t)C), nnz_row((size_t)T);
+    if (C > capacity) {
+        // the big faces need more room than the margin: move the regular part to a larger queue
+        DevBuf<int32_t> bigger_tgt((size_t)C), bigger_src((size_t)C);
+        XR_HIP(hipMemcpyAsync(bigger_tgt.get(), cand_tgt.get(), sizeof(int32_t) * (size_t)capacity, hipMemcpyDeviceToDevice, st));
+        XR_HIP(hipMemcpyAsync(bigger_src.get(), cand_src.get(), sizeof(int32_t) * (size_t)capacity, hipMemcpyDeviceToDevice, st));
+        stream_sync();
+        cand_tgt = std::move(bigger_tgt);
+        cand_src = std::move(bigger_src);
+        capacity = C;
+    }
+    DevBuf<int32_t> cand_sid((size_t)C), nnz_row((size_t)T);
     DevBuf<double> cand_area((size_t)C);
     XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
     if (C > 0) {
-        XR_LAUNCH("compact", k_compact, dim3(div_up(T, 256)), dim3(256), 0, slots.get(), cand_off.get(), is_big.get(),
-                  T, cand_tgt.get(), cand_src.get());
         XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
                   query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
                   tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
-                  (int32_t *)nullptr, cand_tgt.get(), cand_src.get());
+                  (int32_t *)nullptr, cand_tgt.get(), cand_src.get(), (int32_t *)nullptr);
         // --- clip (+ per-row survivor counts)
         launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), cand_sid.get(), counters.get(),
                         nnz_row.get());
@@ -972,7 +1023,8 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
         launch_clip<64, 64>(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), true, cand_sid.get(),
                             counters.get(), nnz_row.get());
-        XR_LAUNCH("row_recount", k_row_count, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_area.get(), T,
+        XR_LAUNCH("row_recount", k_row_count, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_count.get(),
+                  cand_area.get(), T,
                   query->qo_perm(), nnz_row.get());
         exclusive_scan_i32(nnz_row.get(), csr->indptr.get(), T);
         tail[3] = read_scalar(csr->indptr.get() + T);
@@ -995,8 +1047,8 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->n_long.alloc(1);
         csr->has_long = true;
         XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), st));
-        XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_tgt.get(),
-                  cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
+        XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_count.get(),
+                  block_seg.get(), is_big.get(), cand_tgt.get(), cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, csr->long_rows.get(),
                   csr->n_long.get());
         const size_t shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
@@ -1007,7 +1059,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
             attr_set = true;
         }
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
-                  cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, tree->n_face,
+                  cand_count.get(), cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, tree->n_face,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
     }
 }
