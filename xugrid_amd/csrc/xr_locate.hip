@@ -276,7 +276,7 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
                "xr_locate_points: bad arguments");
     XR_REQUIRE(n < ((int64_t)1 << 31), XR_ERR_LIMIT, "xr_locate_points: too many points");
     if (n > 0) {
-        mesh_prepare(mesh);
+        mesh_prepare(mesh, false);
         mesh_build_index(mesh);
         const double tol = resolve_tolerance(mesh, tolerance);
         DevBuf<double> pts((size_t)n * 2);
@@ -303,7 +303,7 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
                "xr_barycentric: bad arguments");
     XR_REQUIRE(n < ((int64_t)1 << 31), XR_ERR_LIMIT, "xr_barycentric: too many points");
     if (n > 0) {
-        mesh_prepare(mesh);
+        mesh_prepare(mesh, false);
         mesh_build_index(mesh);
         const double tol = resolve_tolerance(mesh, tolerance);
         const int m = mesh->m;
@@ -356,8 +356,8 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
             csr->data.alloc(0);
             stream_sync();
         } else {
-            mesh_prepare(voronoi); mesh_build_index(voronoi);
-            mesh_prepare(source); mesh_build_index(source);
+            mesh_prepare(voronoi, false); mesh_build_index(voronoi);
+            mesh_prepare(source, false); mesh_build_index(source);
             const double tol = resolve_tolerance(voronoi, tolerance);
             const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
             DevBuf<double> pts((size_t)n * 2), w((size_t)n * m);
@@ -413,7 +413,7 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
             csr->data.alloc(0);
             stream_sync();
         } else {
-            mesh_prepare(tree);
+            mesh_prepare(tree, false);
             mesh_build_index(tree);
             const double tol = resolve_tolerance(tree, tolerance);
             DevBuf<double> pts((size_t)n * 2);

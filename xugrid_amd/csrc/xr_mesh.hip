@@ -107,7 +107,7 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
                 xmax = fmax(xmax, p.x);
                 ymin = fmin(ymin, p.y);
                 ymax = fmax(ymax, p.y);
-                fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
+                if (fxy) fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y); // (tree-only meshes skip this array)
             }
         }
         double4 *bb = reinterpret_cast<double4 *>(bbox);
@@ -188,11 +188,60 @@ __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__
     }
 }
 
-void mesh_prepare(xr_mesh *mesh) {
+// caller-order vertex blocks for a mesh that was prepared without them (tree-only so far) and now becomes a
+// query kept in its own numbering
+template <int MC>
+__global__ void __launch_bounds__(256)
+k_face_coords(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face, int m_rt,
+              double *__restrict__ fxy) {
+    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
+    const int m = MC > 0 ? MC : m_rt;
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    int face[MA];
+#pragma unroll
+    for (int j = 0; j < MA; j++)
+        if (j < m) face[j] = faces_raw[f * m + j];
+    int n;
+    bool flip;
+    face_shape<MA>(node_xy, face, m, n, flip);
+    double2 *fx = reinterpret_cast<double2 *>(fxy) + f * m;
+#pragma unroll
+    for (int j = 0; j < MA; j++) {
+        if (j < n) {
+            const P2 p = load_p2(node_xy, face[j]);
+            fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
+        }
+    }
+}
+
+void mesh_face_coords(xr_mesh *mesh) {
+    mesh_prepare(mesh, true);
+    if (mesh->fxy_valid) return;
+    const int64_t F = mesh->n_face;
+    mesh->fxy.alloc((size_t)F * mesh->m * 2);
+    if (F > 0) {
+        const dim3 grid(div_up(F, 256)), block(256);
+        if (mesh->m == 3)
+            XR_LAUNCH("face_coords", k_face_coords<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
+                      mesh->fxy.get());
+        else if (mesh->m == 4)
+            XR_LAUNCH("face_coords", k_face_coords<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
+                      mesh->fxy.get());
+        else
+            XR_LAUNCH("face_coords", k_face_coords<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
+                      mesh->fxy.get());
+    }
+    mesh->fxy_valid = true;
+}
+
+void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
     if (mesh->prepared) return;
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
-    mesh->fxy.alloc((size_t)F * m * 2);
+    if (want_fxy) mesh->fxy.alloc((size_t)F * m * 2);
+    else mesh->fxy.release();
+    mesh->fxy_valid = want_fxy;
     mesh->len.alloc((size_t)F);
     mesh->bbox.alloc((size_t)F * 4);
     mesh->area.alloc((size_t)F);
@@ -202,13 +251,16 @@ void mesh_prepare(xr_mesh *mesh) {
     dim3 grid((unsigned)nb), block(PREP_BLOCK);
     if (m == 3) {
         XR_LAUNCH("prepare_faces", k_prepare_faces<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+                  want_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(), mesh->bbox.get(), mesh->area.get(),
+                  partials.get());
     } else if (m == 4) {
         XR_LAUNCH("prepare_faces", k_prepare_faces<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+                  want_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(), mesh->bbox.get(), mesh->area.get(),
+                  partials.get());
     } else {
         XR_LAUNCH("prepare_faces", k_prepare_faces<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), mesh->area.get(), partials.get());
+                  want_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(), mesh->bbox.get(), mesh->area.get(),
+                  partials.get());
     }
     if (!mesh->stats_host) {
         void *p = nullptr;
@@ -265,29 +317,49 @@ __global__ void __launch_bounds__(256) k_spatial_count(const double *__restrict_
     atomicAdd(&count[k], 1);
 }
 
-template <bool INDEX>
+// The face's CCW-normalised vertex block and its bbox are recomputed from the raw mesh (node gathers hit the
+// L2-resident node array) instead of being copied from the caller-order arrays: a mesh that is only ever the
+// TREE never materialises `fxy`, and the scatter reads 17 bytes per face instead of 97.
+template <bool INDEX, int MC>
 __global__ void __launch_bounds__(256)
-k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m, const int32_t *__restrict__ start,
-                  int32_t *__restrict__ cursor, const double *__restrict__ fxy, const uint8_t *__restrict__ len,
-                  const double *__restrict__ bbox, int32_t *__restrict__ perm, double *__restrict__ o_fxy,
+k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m_rt, const int32_t *__restrict__ start,
+                  int32_t *__restrict__ cursor, const double *__restrict__ node_xy,
+                  const int32_t *__restrict__ faces_raw, int32_t *__restrict__ perm, double *__restrict__ o_fxy,
                   uint8_t *__restrict__ o_len, double *__restrict__ o_bbox, float *__restrict__ o_recbb, double x0,
                   double y0) {
+    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
+    const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n) return;
     const int k = key[f];
     const int64_t r = start[k] + atomicAdd(&cursor[k], 1);
     perm[r] = (int32_t)f;
-    const int nl = len[f];
+    int face[MA];
+#pragma unroll
+    for (int j = 0; j < MA; j++)
+        if (j < m) face[j] = faces_raw[f * m + j];
+    int nl;
+    bool flip;
+    face_shape<MA>(node_xy, face, m, nl, flip);
     o_len[r] = (uint8_t)nl;
-    const double2 *src = reinterpret_cast<const double2 *>(fxy) + f * m;
     double2 *dst = reinterpret_cast<double2 *>(o_fxy) + r * m;
-    for (int j = 0; j < nl; j++) dst[j] = src[j];
-    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < MA; j++) {
+        if (j < nl) {
+            const P2 p = load_p2(node_xy, face[j]);
+            xmin = fmin(xmin, p.x);
+            xmax = fmax(xmax, p.x);
+            ymin = fmin(ymin, p.y);
+            ymax = fmax(ymax, p.y);
+            dst[flip ? nl - 1 - j : j] = make_double2(p.x, p.y);
+        }
+    }
     if (INDEX) {
         reinterpret_cast<float4 *>(o_recbb)[r] =
-            make_float4(f32_below(bb.x - x0), f32_above(bb.y - x0), f32_below(bb.z - y0), f32_above(bb.w - y0));
+            make_float4(f32_below(xmin - x0), f32_above(xmax - x0), f32_below(ymin - y0), f32_above(ymax - y0));
     } else {
-        reinterpret_cast<double4 *>(o_bbox)[r] = bb;
+        reinterpret_cast<double4 *>(o_bbox)[r] = make_double4(xmin, xmax, ymin, ymax);
     }
 }
 
@@ -303,10 +375,19 @@ static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams 
                   mesh->bbox.get(), F, g, mp, key.get(), count.get());
     exclusive_scan_i32(count.get(), bucket_start, n_buckets);
     XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
-    if (F > 0)
-        XR_LAUNCH(INDEX ? "index_scatter" : "order_scatter", k_spatial_scatter<INDEX>, dim3(div_up(F, 256)), dim3(256),
-                  0, key.get(), F, mesh->m, bucket_start, count.get(), mesh->fxy.get(), mesh->len.get(),
-                  mesh->bbox.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
+    if (F > 0) {
+        const char *name = INDEX ? "index_scatter" : "order_scatter";
+        const dim3 grid(div_up(F, 256)), block(256);
+        if (mesh->m == 3)
+            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 3>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count.get(),
+                      mesh->node_xy.get(), mesh->faces_raw.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
+        else if (mesh->m == 4)
+            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 4>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count.get(),
+                      mesh->node_xy.get(), mesh->faces_raw.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
+        else
+            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 0>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count.get(),
+                      mesh->node_xy.get(), mesh->faces_raw.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
+    }
 }
 
 void mesh_query_order(xr_mesh *mesh) {
@@ -321,6 +402,7 @@ void mesh_query_order(xr_mesh *mesh) {
     const double mean_jump = F > 0 ? mesh->h_stats[7] / ((double)F * 63.0 / 64.0) : 0.0;
     mesh->query_identity = !force_sort && (F == 0 || mean_jump <= 4.0 * mean_ext);
     if (mesh->query_identity) {
+        mesh_face_coords(mesh); // the caller-order vertex blocks ARE the query-order ones (no-op if prepared with them)
         mesh->query_ready = true;
         return;
     }
@@ -541,6 +623,7 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_invalidate: NULL mesh");
     stream_sync();
     mesh->prepared = false;
+    mesh->fxy_valid = false;
     mesh->query_ready = false;
     mesh->query_identity = false;
     mesh->indexed = false;

@@ -20,7 +20,9 @@ struct xr_mesh {
 
     // ---- prepared (caller's face order)
     bool prepared = false;
-    xr::DevBuf<double> fxy;   // [n_face*m*2] CCW-normalised vertex coordinates per face
+    xr::DevBuf<double> fxy;   // [n_face*m*2] CCW-normalised vertex coordinates per face (only if fxy_valid:
+                              // needed when the mesh is a query kept in the caller's numbering)
+    bool fxy_valid = false;
     xr::DevBuf<uint8_t> len;  // [n_face]
     xr::DevBuf<double> bbox;  // [n_face*4] xmin,xmax,ymin,ymax
     xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order
@@ -99,7 +101,8 @@ struct xr_csr {
 };
 
 namespace xr {
-void mesh_prepare(xr_mesh *mesh);
+void mesh_prepare(xr_mesh *mesh, bool want_fxy = true);
+void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex blocks exist
 void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
 void mesh_read_stats(xr_mesh *mesh);

@@ -920,8 +920,8 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
 }
 
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
-    mesh_prepare(tree);
-    mesh_prepare(query);
+    mesh_prepare(tree, false); // the tree side only needs its records (built from the raw mesh)
+    mesh_prepare(query, true);
     mesh_build_index(tree);
     mesh_query_order(query);
     const int64_t T = query->n_face, S = tree->n_face;
