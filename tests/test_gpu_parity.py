@@ -129,6 +129,23 @@ def test_overlap_long_rows_and_big_queries(hip, oracle):
         assert 128 < np.diff(indptr).max() < 2048
 
 
+def test_overlap_queue_regrow_path(hip, oracle, monkeypatch):
+    """big query faces whose candidates do not fit the pair queue's margin: the queue is regrown and the
+    pending faces are filled by the second launch (XR_QUEUE_MARGIN is a test hook)."""
+    monkeypatch.setenv("XR_QUEUE_MARGIN", "0")
+    sxy, sf = meshgen.triangle_mesh(30000, 3)
+    txy, tf = meshgen.quad_mesh(np.linspace(-0.1, 1.1, 6), np.linspace(0.0, 1.0, 4))
+    csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
+    assert np.diff(indptr).max() > 2000 and hip.engine.DeviceMesh  # rows far beyond 16 * T queue entries
+    # mixed: a fine target with a few huge faces appended
+    fxy, ff = meshgen.triangle_mesh(4000, 4, 10.0, 0.9)
+    big = np.array([[0.02, 0.02], [0.98, 0.03], [0.97, 0.99], [0.03, 0.96]])
+    mxy = np.vstack([fxy, big])
+    n0 = fxy.shape[0]
+    mf = np.vstack([ff, [[n0, n0 + 1, n0 + 2], [n0, n0 + 2, n0 + 3]]])
+    assert_overlap_parity(hip, oracle, sxy, sf, mxy, mf)
+
+
 def test_overlap_graded_mesh_many_levels(hip, oracle):
     """face sizes spanning 4 orders of magnitude -> many grid levels."""
     rng = np.random.default_rng(9)

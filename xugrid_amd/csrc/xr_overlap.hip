@@ -176,8 +176,11 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
 }
 
 // deposit one device word in the host mailbox (pinned memory)
-__global__ void k_publish(const int32_t *__restrict__ src, int32_t *dst) {
-    if (threadIdx.x == 0) *dst = *src;
+__global__ void k_publish(const int32_t *__restrict__ src, int32_t *dst, const int32_t *__restrict__ src2, int32_t *dst2) {
+    if (threadIdx.x == 0) {
+        *dst = *src;
+        *dst2 = *src2;
+    }
 }
 
 // One block per big query face.  The face is scan-converted against the grid: for grid row cy of
@@ -203,19 +206,24 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
     return incl - v;
 }
 
-template <bool FILL>
+// FUSED: count the face's candidates, reserve its stretch of the pair queue with one atomic and -- if the
+// stretch fits the queue as currently allocated -- fill it straight away (second walk by the same block);
+// faces that do not fit are listed and filled by a second launch (FUSED = false) after the host regrew the queue.
+template <bool FUSED>
 __global__ void __launch_bounds__(256)
 k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy,
              const uint8_t *__restrict__ q_len, int q_m, GridParams g,
              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
              const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
              const int32_t *__restrict__ n_big, int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count,
-             int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor) {
+             int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
+             int64_t capacity, int32_t *__restrict__ pending_list, int32_t *__restrict__ n_pending) {
     // one BLOCK per big face: its four waves take the 64-row batches round-robin; candidates are
     // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
     // ranked by tree face id afterwards)
     __shared__ double2 sh_poly[XR_MAX_FACE_NODES];
     __shared__ int sh_cursor;
+    __shared__ int sh_out0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nb = *n_big;
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
@@ -231,7 +239,30 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
         const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
-        const int out0 = FILL ? cand_off[t] : 0;
+        for (int pass = FUSED ? 0 : 1; pass < 2; pass++) {
+        const bool FILL = pass == 1;
+        if (FILL) {
+            if (FUSED) {
+                // (pass 0 left the face's total in sh_cursor)
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    const int n = sh_cursor;
+                    const int base = atomicAdd(queue_cursor, n);
+                    cand_count[t] = n;
+                    cand_off[t] = base;
+                    const bool fits = (int64_t)base + n <= capacity && base >= 0;
+                    if (!fits) pending_list[atomicAdd(n_pending, 1)] = t;
+                    sh_out0 = fits ? base : -1;
+                    sh_cursor = 0;
+                }
+                __syncthreads();
+            } else {
+                if (threadIdx.x == 0) sh_out0 = cand_off[t];
+                __syncthreads();
+            }
+            if (sh_out0 < 0) break;
+        }
+        const int out0 = FILL ? sh_out0 : 0;
         int total = 0;
         int batch_id = 0;
         for (int l = 0; l < g.n_levels; l++) {
@@ -326,12 +357,8 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
         if (!FILL) {
             // block total (every lane of a wave holds the wave's total)
             if (lane == 0) atomicAdd(&sh_cursor, total);
-            __syncthreads();
-            if (threadIdx.x == 0) { // reserve the face's stretch of the pair queue
-                cand_count[t] = sh_cursor;
-                cand_off[t] = atomicAdd(queue_cursor, sh_cursor);
-            }
         }
+        } // pass
     }
 }
 
@@ -951,7 +978,8 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     const int big_grid = engine().num_cu * 8;
     const int64_t n_blocks = div_up(T, 256);
     DevBuf<int2> block_seg((size_t)n_blocks);
-    int64_t capacity = T * SLOTS + ((int64_t)4 << 20);
+    const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
+    int64_t capacity = T * SLOTS + (margin_env ? (int64_t)atoll(margin_env) : ((int64_t)4 << 20));
     XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
     DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity);
     // Rows kept in the caller's (coherent, but typically strip-like) numbering get a coarse Morton key each:
@@ -977,20 +1005,21 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
               cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
               csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr);
-    XR_LAUNCH("search_big_count", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
-              query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
-              tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
-              cand_count.get(), (int32_t *)nullptr, (int32_t *)nullptr, counters.get() + 3);
-    // queue length -> host
+    DevBuf<int32_t> pending((size_t)T);
+    XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
+              query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
+              big_list.get(), counters.get() + 2, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
+              counters.get() + 3, capacity, pending.get(), counters.get() + 1);
+    // queue length and number of big faces still to be filled -> host
     int32_t *mail = const_cast<int32_t *>(engine().mailbox);
-    XR_LAUNCH("publish", k_publish, dim3(1), dim3(64), 0, counters.get() + 3, mail + 0);
+    XR_LAUNCH("publish", k_publish, dim3(1), dim3(64), 0, counters.get() + 3, mail + 0, counters.get() + 1, mail + 3);
     mailbox_wait();
-    const int32_t C32 = mail[0];
+    const int32_t C32 = mail[0], n_pending = mail[3];
     XR_REQUIRE(C32 >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
     const int64_t C = C32;
     tree->last_candidates = C;
-    if (C > capacity) {
-        // the big faces need more room than the margin: move the regular part to a larger queue
+    if (n_pending > 0) {
+        // some big faces need more room than the margin: move what is there to a larger queue, then fill them
         DevBuf<int32_t> bigger_tgt((size_t)C), bigger_src((size_t)C);
         XR_HIP(hipMemcpyAsync(bigger_tgt.get(), cand_tgt.get(), sizeof(int32_t) * (size_t)capacity, hipMemcpyDeviceToDevice, st));
         XR_HIP(hipMemcpyAsync(bigger_src.get(), cand_src.get(), sizeof(int32_t) * (size_t)capacity, hipMemcpyDeviceToDevice, st));
@@ -998,15 +1027,17 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         cand_tgt = std::move(bigger_tgt);
         cand_src = std::move(bigger_src);
         capacity = C;
+        XR_LAUNCH("search_big_fill", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
+                  query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
+                  pending.get(), counters.get() + 1, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
+                  (int32_t *)nullptr, capacity, (int32_t *)nullptr, (int32_t *)nullptr);
     }
+    // counters[1] is reused below as the number of long rows
+    XR_HIP(hipMemsetAsync(counters.get() + 1, 0, sizeof(int32_t), st));
     DevBuf<int32_t> cand_sid((size_t)C), nnz_row((size_t)T);
     DevBuf<double> cand_area((size_t)C);
     XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
     if (C > 0) {
-        XR_LAUNCH("search_big_fill", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(),
-                  query->qo_fxy(), query->qo_len(), query->m, g, tree->cell_start.get(),
-                  tree->rec_bb.get(), tree->rec_face.get(), big_list.get(), counters.get() + 2, cand_off.get(),
-                  (int32_t *)nullptr, cand_tgt.get(), cand_src.get(), (int32_t *)nullptr);
         // --- clip (+ per-row survivor counts)
         launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), cand_sid.get(), counters.get(),
                         nnz_row.get());
