@@ -391,3 +391,28 @@ def test_centroid_locator_device_pipeline(hip, oracle):
     d1, i1, p1 = c.download()
     d0, i0, p0 = rg._device_weights.download()
     assert np.array_equal(i1, i0) and np.array_equal(p1, p0) and np.array_equal(d1, d0)
+
+
+def test_rasterize_known_answers(hip):
+    """tests/test_ugrid2d.py:794-825 (numbers transcribed): two quads under two triangles."""
+    vertices = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0], [0.0, 1.0], [1.0, 1.0], [2.0, 1.0], [1.0, 2.0]])
+    faces = np.array([[0, 1, 4, 3], [1, 2, 5, 4], [3, 4, 6, -1], [4, 5, 6, -1]])
+    grid = xa.Ugrid2d(vertices[:, 0], vertices[:, 1], -1, faces)
+    x, y, index = grid.rasterize(resolution=0.5)
+    assert np.allclose(x, [0.25, 0.75, 1.25, 1.75]) and np.allclose(y, [1.75, 1.25, 0.75, 0.25])
+    assert np.array_equal(index, [[-1, 2, 3, -1], [2, 2, 3, 3], [0, 0, 1, 1], [0, 0, 1, 1]])
+    x, y, index = grid.rasterize(resolution=0.5, bounds=(-1.0, -1.0, 2.0, 2.0))
+    expected = np.array(
+        [
+            [-1, -1, -1, 2, 3, -1],
+            [-1, -1, 2, 2, 3, 3],
+            [-1, -1, 0, 0, 1, 1],
+            [-1, -1, 0, 0, 1, 1],
+            [-1, -1, -1, -1, -1, -1],
+            [-1, -1, -1, -1, -1, -1],
+        ]
+    )
+    assert np.allclose(x, [-0.75, -0.25, 0.25, 0.75, 1.25, 1.75]) and np.allclose(y, [1.75, 1.25, 0.75, 0.25, -0.25, -0.75])
+    assert np.array_equal(index, expected)
+    xs, ys, idx = grid.rasterize_like(np.array([0.5, 1.5]), np.array([0.5]))
+    assert np.array_equal(idx, [[0, 1]])

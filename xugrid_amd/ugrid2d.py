@@ -107,6 +107,31 @@ class Ugrid2d:
     def compute_barycentric_weights(self, points, tolerance=None):
         return self.celltree.compute_barycentric_weights(points, tolerance)
 
+    # ---- point sampling with the same spatial index (ugrid2d.py:1080-1140)
+    def rasterize_like(self, x, y):
+        """Face index at every (y, x) raster node: -> (x, y, index (nrow, ncol)), -1 outside the grid."""
+        x = np.asarray(x, dtype=np.float64)
+        y = np.asarray(y, dtype=np.float64)
+        yy, xx = np.meshgrid(y, x, indexing="ij")
+        nodes = np.column_stack([xx.ravel(), yy.ravel()])
+        index = self.celltree.locate_points(nodes).reshape((y.size, x.size))
+        return x, y, index
+
+    def rasterize(self, resolution, bounds=None):
+        """Sample the grid on a raster of cell centres generated from ``bounds`` (default: the node bounds)
+        and ``resolution``; y runs from top to bottom."""
+        if bounds is None:
+            bounds = self.bounds
+        xmin, ymin, xmax, ymax = bounds
+        d = abs(resolution)
+        xmin = np.floor(xmin / d) * d
+        xmax = np.ceil(xmax / d) * d
+        ymin = np.floor(ymin / d) * d
+        ymax = np.ceil(ymax / d) * d
+        x = np.arange(xmin + 0.5 * d, xmax, d)
+        y = np.arange(ymax - 0.5 * d, ymin, -d)
+        return self.rasterize_like(x, y)
+
     # ---- host-side connectivities (feed the Voronoi pre-step of BarycentricInterpolator)
     @property
     def edge_node_connectivity(self):
