@@ -393,7 +393,8 @@ static constexpr int PLAN_KT = 8;      // source variables per pipeline stage (L
 
 __global__ void __launch_bounds__(AP_BLOCK)
 k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
-             int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc) {
+             int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc,
+             int32_t *__restrict__ max_entries) {
     __shared__ int32_t keys[PLAN_LMAX];
     __shared__ int32_t uniq[PLAN_UMAX];
     __shared__ int32_t sh_wave[4];
@@ -458,6 +459,7 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
     __syncthreads();
     for (int u = threadIdx.x; u < total; u += AP_BLOCK) ucol[(int64_t)blockIdx.x * PLAN_UMAX + u] = uniq[u];
+    if (threadIdx.x == 0) atomicMax(max_entries, n); // the apply kernel sizes its LDS stage for the largest planned block
     if (threadIdx.x == 0) nuniq[blockIdx.x] = total;
     // local index of every entry: binary search in the distinct list
     for (int i = threadIdx.x; i < n; i += AP_BLOCK) {
@@ -482,11 +484,11 @@ __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
              const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
              const int32_t *__restrict__ row_order, bool skip_long, int64_t T, int64_t S,
-             const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
+             const SRC *__restrict__ source, int64_t K, double *__restrict__ out, int lmax) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][PLAN_UMAX]
-    double *sh_w = vals + KTILE * PLAN_UMAX;                              // [PLAN_LMAX]
-    uint16_t *sh_loc = reinterpret_cast<uint16_t *>(sh_w + PLAN_LMAX);    // [PLAN_LMAX]
+    double *sh_w = vals + KTILE * PLAN_UMAX;                              // [lmax] = entries of the largest planned block
+    uint16_t *sh_loc = reinterpret_cast<uint16_t *>(sh_w + lmax);         // [lmax]
     constexpr int UPT = PLAN_UMAX / AP_BLOCK;                             // distinct columns per thread
     // XCD-aware block order: hardware block b runs on XCD b % 8; give every XCD a CONTIGUOUS range of
     // row blocks (= one spatial region), so that lines shared by neighbouring blocks stay in one L2
@@ -755,9 +757,16 @@ static void ensure_plan(const xr_csr *ccsr) {
     csr->plan_ucol.alloc((size_t)nb * PLAN_UMAX);
     csr->plan_nuniq.alloc((size_t)nb);
     csr->plan_loc.alloc((size_t)csr->nnz);
-    if (nb > 0)
+    csr->plan_lmax = 256;
+    if (nb > 0) {
+        DevBuf<int32_t> max_entries(1);
+        fill_i32(max_entries.get(), 0, 1);
         XR_LAUNCH("plan_build", k_plan_build, dim3((unsigned)nb), dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get());
+                  csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get(),
+                  max_entries.get());
+        const int m = read_scalar(max_entries.get());
+        csr->plan_lmax = std::min(PLAN_LMAX, std::max(256, (m + 255) / 256 * 256));
+    }
     csr->plan_ready = true;
 }
 
@@ -1024,17 +1033,20 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             // lists (both built once per matrix)
             ensure_tiled(csr);
             ensure_plan(csr);
-            const size_t shmem = sizeof(double) * (PLAN_KT * PLAN_UMAX + PLAN_LMAX) + sizeof(uint16_t) * PLAN_LMAX;
+            // LDS: one tile of distinct source values + the block's entries (weight + 16-bit local column); sized
+            // for the largest planned block, so typical matrices run three blocks per CU instead of two
+            const size_t shmem_max = sizeof(double) * (PLAN_KT * PLAN_UMAX + PLAN_LMAX) + sizeof(uint16_t) * PLAN_LMAX;
+            const size_t shmem = sizeof(double) * (PLAN_KT * PLAN_UMAX + csr->plan_lmax) + sizeof(uint16_t) * csr->plan_lmax;
             static bool attr_set = false;
             if (!attr_set) {
                 XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_max));
                 attr_set = true;
             }
             XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), dim3((div_up(csr->n, AP_BLOCK) + 7) / 8 * 8), dim3(AP_BLOCK),
                       shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(),
                       csr->plan_nuniq.get(), csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src,
-                      K, out);
+                      K, out, csr->plan_lmax);
         } else {
             // a few variables: register-resident k-tiles, direct gathers, no LDS
             dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
