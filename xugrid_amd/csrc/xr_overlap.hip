@@ -53,7 +53,7 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
          int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
          int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key) {
-    __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS][256]; // [slot][thread]: conflict-free
+    __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
     __shared__ uint8_t sh_owner[SLOTS * 256];
     __shared__ int32_t sh_wave[4];
     __shared__ int32_t sh_base;
@@ -71,17 +71,19 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
         const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+        // Level-0 cells of the bbox corners, once; the level-l cell of x is (level-0 cell) >> l exactly (cell
+        // sizes are power-of-two multiples and the clamped ranges nest), and the cell of x - h_l is that minus one:
+        // no per-level floating-point cell arithmetic.  (A record that can overlap has xmin > q.xmin - 0.999 h_l,
+        // so its cell is >= cell(q.xmin) - 1 for the same monotone cell function the index was built with.)
+        const int c_x0 = cell_coord(bb.x, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(bb.y, g.x0, g.inv_h0, g.nx[0]);
+        const int c_y0 = cell_coord(bb.z, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(bb.w, g.y0, g.inv_h0, g.ny[0]);
         int visited = 0, n_rows = 0;
-        for (int l = 0; l < g.n_levels; l++) {
-            const double h = level_h(g, l), inv_h = level_inv_h(g, l);
-            n_rows += cell_coord(bb.w, g.y0, inv_h, g.ny[l]) - cell_coord(bb.z - h, g.y0, inv_h, g.ny[l]) + 1;
-        }
+        for (int l = 0; l < g.n_levels; l++) n_rows += (c_y1 >> l) - max((c_y0 >> l) - 1, 0) + 1;
         big = n_rows > 8 * g.n_levels + 8;
         for (int l = 0; l < g.n_levels && !big; l++) {
-            const double h = level_h(g, l), inv_h = level_inv_h(g, l);
-            const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
-            const int cx0 = cell_coord(bb.x - h, g.x0, inv_h, nx), cx1 = cell_coord(bb.y, g.x0, inv_h, nx);
-            const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
+            const int nx = g.nx[l], base = g.base[l];
+            const int cx0 = max((c_x0 >> l) - 1, 0), cx1 = c_x1 >> l;
+            const int cy0 = max((c_y0 >> l) - 1, 0), cy1 = c_y1 >> l;
             for (int cyb = cy0; cyb <= cy1 && !big; cyb += 4) {
                 // fetch the record runs of up to four grid rows before walking them
                 int r0[4], r1[4];
@@ -103,22 +105,20 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
                             const float4 b1 = rbb[r + 1 <= last ? r + 1 : last];
                             const float4 b2 = rbb[r + 2 <= last ? r + 2 : last];
                             const float4 b3 = rbb[r + 3 <= last ? r + 3 : last];
-                            if (rec_hit(b0, qx0, qx1, qy0, qy1)) {
-                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r;
-                                count++;
-                            }
-                            if (r + 1 <= last && rec_hit(b1, qx0, qx1, qy0, qy1)) {
-                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r + 1;
-                                count++;
-                            }
-                            if (r + 2 <= last && rec_hit(b2, qx0, qx1, qy0, qy1)) {
-                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r + 2;
-                                count++;
-                            }
-                            if (r + 3 <= last && rec_hit(b3, qx0, qx1, qy0, qy1)) {
-                                if (count < SLOTS) sh_slots[count][threadIdx.x] = r + 3;
-                                count++;
-                            }
+                            // branch-free parking: the slot is written unconditionally and only kept (count
+                            // advances) on a hit; beyond SLOTS everything lands in a trash row
+                            const bool h0 = rec_hit(b0, qx0, qx1, qy0, qy1);
+                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r;
+                            count += h0 ? 1 : 0;
+                            const bool h1 = r + 1 <= last && rec_hit(b1, qx0, qx1, qy0, qy1);
+                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 1;
+                            count += h1 ? 1 : 0;
+                            const bool h2 = r + 2 <= last && rec_hit(b2, qx0, qx1, qy0, qy1);
+                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 2;
+                            count += h2 ? 1 : 0;
+                            const bool h3 = r + 3 <= last && rec_hit(b3, qx0, qx1, qy0, qy1);
+                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 3;
+                            count += h3 ? 1 : 0;
                         }
                     }
                 }
