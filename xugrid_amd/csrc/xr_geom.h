@@ -32,6 +32,8 @@ struct P2 {
 };
 
 static constexpr int MAX_LEVELS = 24;
+// cell size ratio between consecutive grid levels = 2^LEVEL_SHIFT
+static constexpr int LEVEL_SHIFT = 1; // (4x steps halve the level count but were 3 % slower in the search)
 
 struct GridParams {
     double x0, y0;    // grid origin (domain lower-left)
@@ -45,8 +47,8 @@ struct GridParams {
 };
 
 // level-l cell size and its inverse (exact power-of-two scalings of h0 / inv_h0)
-__host__ __device__ inline double level_h(const GridParams &g, int l) { return ldexp(g.h0, l); }
-__host__ __device__ inline double level_inv_h(const GridParams &g, int l) { return ldexp(g.inv_h0, -l); }
+__host__ __device__ inline double level_h(const GridParams &g, int l) { return ldexp(g.h0, l * LEVEL_SHIFT); }
+__host__ __device__ inline double level_inv_h(const GridParams &g, int l) { return ldexp(g.inv_h0, -l * LEVEL_SHIFT); }
 
 // monotone non-decreasing in x: (x - x0) * inv_h, floor, clamp
 __host__ __device__ inline int cell_coord(double x, double origin, double inv_h, int n) {
@@ -59,7 +61,7 @@ __host__ __device__ inline int cell_coord(double x, double origin, double inv_h,
 // lowest level whose cell size strictly dominates the extent (0.1 % slack covers every rounding)
 __host__ __device__ inline int level_of_extent(const GridParams &g, double e) {
     int l = 0;
-    while (l < g.n_levels - 1 && !(e <= 0.999 * ldexp(g.h0, l))) l++;
+    while (l < g.n_levels - 1 && !(e <= 0.999 * level_h(g, l))) l++;
     return l;
 }
 

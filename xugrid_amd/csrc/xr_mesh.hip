@@ -451,11 +451,11 @@ void mesh_build_index(xr_mesh *mesh) {
     g.h0 = h0;
     g.inv_h0 = 1.0 / h0;
     int L = 1;
-    while (L < MAX_LEVELS && !(max_ext <= 0.999 * ldexp(h0, L - 1))) L++;
+    while (L < MAX_LEVELS && !(max_ext <= 0.999 * ldexp(h0, (L - 1) * LEVEL_SHIFT))) L++;
     g.n_levels = L;
     int64_t total = 0;
     for (int l = 0; l < L; l++) {
-        const double inv_h = ldexp(g.inv_h0, -l);
+        const double inv_h = ldexp(g.inv_h0, -l * LEVEL_SHIFT);
         const int64_t nx = (int64_t)floor(W * inv_h) + 1, ny = (int64_t)floor(H * inv_h) + 1;
         XR_REQUIRE(total + nx * ny < ((int64_t)1 << 31), XR_ERR_LIMIT, "spatial index too large");
         g.base[l] = (int)total;

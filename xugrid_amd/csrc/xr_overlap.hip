@@ -78,12 +78,14 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
         const int c_x0 = cell_coord(bb.x, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(bb.y, g.x0, g.inv_h0, g.nx[0]);
         const int c_y0 = cell_coord(bb.z, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(bb.w, g.y0, g.inv_h0, g.ny[0]);
         int visited = 0, n_rows = 0;
-        for (int l = 0; l < g.n_levels; l++) n_rows += (c_y1 >> l) - max((c_y0 >> l) - 1, 0) + 1;
+        for (int l = 0; l < g.n_levels; l++)
+            n_rows += (c_y1 >> (l * LEVEL_SHIFT)) - max((c_y0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
         big = n_rows > 8 * g.n_levels + 8;
         for (int l = 0; l < g.n_levels && !big; l++) {
             const int nx = g.nx[l], base = g.base[l];
-            const int cx0 = max((c_x0 >> l) - 1, 0), cx1 = c_x1 >> l;
-            const int cy0 = max((c_y0 >> l) - 1, 0), cy1 = c_y1 >> l;
+            const int sh = l * LEVEL_SHIFT;
+            const int cx0 = max((c_x0 >> sh) - 1, 0), cx1 = c_x1 >> sh;
+            const int cy0 = max((c_y0 >> sh) - 1, 0), cy1 = c_y1 >> sh;
             for (int cyb = cy0; cyb <= cy1 && !big; cyb += 4) {
                 // fetch the record runs of up to four grid rows before walking them
                 int r0[4], r1[4];
