@@ -18,8 +18,8 @@
 //   scan           -> indptr[T+1]
 //   row_fill       per query face: rank the surviving pairs by tree face id and write the CSR
 //                  row (indices, data); data /= tree face area if relative.  Rows with many
-//                  candidates go to one block each (LDS bitmap rank, k_row_fill_long).
-// Query faces whose bbox spans many grid rows/records are searched by one wave each
+//                  candidates go to one block each (all-pairs or LDS bitmap rank, k_row_fill_long).
+// Query faces whose bbox spans many grid rows/records are searched by one block each
 // (k_search_big) instead of one thread.
 //
 // The clip arithmetic mirrors oracle/xr_oracle.c (clip_polygons / sh_polygon_area) operation
@@ -33,17 +33,17 @@ namespace xr {
 // ---------------------------------------------------------------------------------------------
 // A query face is "big" when its bbox spans many grid rows or many records (hull slivers of a
 // Delaunay mesh, coarse target cells over a fine source): one thread would serialise thousands
-// of tests, so those faces are queued and handled by one wave each (k_search_big).
+// of tests, so those faces are queued and handled by one block each (k_search_big).
 static constexpr int BIG_VISITS = 160; // records visited by one thread before it gives up
 
 __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy0, float qy1) {
     return qx0 < b.y && b.x < qx1 && qy0 < b.w && b.z < qy1;
 }
 
-// One traversal per query face: hits are parked in a fixed-capacity slot row (SLOTS record ids,
-// one 64-byte line per face) and counted; after the scan of the counts a compaction kernel moves
-// them into the dense candidate queue.  Faces with more than SLOTS hits, too many grid rows or too
-// many visited records are "big" and go to the wave-per-face kernels instead.
+// One traversal per query face: hits are parked in SLOTS LDS slots per face and counted; the block
+// then compacts them into its stretch of the candidate-pair queue.  Faces with more than SLOTS
+// hits, too many grid rows or too many visited records are "big" and go to the block-per-face
+// kernel instead.
 static constexpr int SLOTS = 16;
 static constexpr int TILE_RUN = 64; // rows per run in the tiling hint (512-byte output stores per variable)
 
