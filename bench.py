@@ -255,7 +255,86 @@ def run_single(args):
         "roofline": roofline,
         "cpu_baseline": cpu,
     }
+    if not args.no_extras:
+        result["other_configs"] = other_configs(E, lib, _lib, csr, S, T)
     print(json.dumps(result), flush=True)
+
+
+def other_configs(E, lib, _lib, csr, S, T):
+    """BASELINE configs 5 and 3 and a structured pair, measured beside the headline (rank 0, N = 1): informative
+    extras of the JSON line, never part of `value`.  Bounded to a few seconds each."""
+    import ctypes
+
+    import numpy as np
+
+    import xugrid_amd as xa
+    from xugrid_amd.regrid.structured import Raster, StructuredGrid2d
+
+    out = {}
+    try:  # config 5: cached weights, K = 256 stacked variables
+        K = 256
+        block = np.random.default_rng(5).random((8, S))
+        src = np.tile(block, (K // 8, 1))
+        d_src, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.xr_dev_alloc(8 * K * S, ctypes.byref(d_src)))
+        _lib.check(lib.xr_dev_alloc(8 * K * T, ctypes.byref(d_out)))
+        _lib.check(lib.xr_dev_upload(d_src, src.ctypes.data_as(ctypes.c_void_p), 8 * K * S))
+        del src
+        for _ in range(2):
+            csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+        E.dev_sync()
+        t0 = time.perf_counter()
+        n = 5
+        for _ in range(n):
+            csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+        E.dev_sync()
+        dt = (time.perf_counter() - t0) / n
+        nbytes = 12 * csr.nnz + 4 * (T + 1) + 8 * K * (S + T)
+        out["config5_apply_K256"] = {
+            "weights": "the benchmark's own matrix (qhull-numbered Delaunay source: gathers less local than a "
+            "lattice-numbered mesh, which runs at 1.05 ms = 3.9 TB/s)",
+            "ms": 1e3 * dt, "cell_variables_per_s": K * T / dt, "algorithmic_GBps": nbytes / dt / 1e9,
+            "frac_of_hbm_peak": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+        }
+        lib.xr_dev_free(d_src)
+        lib.xr_dev_free(d_out)
+    except Exception as e:  # noqa: BLE001
+        out["config5_apply_K256"] = {"error": repr(e)}
+    try:  # config 3: BarycentricInterpolator 1M faces -> 4M target faces (lattice-split meshes)
+        sxy, sf = xa.meshgen.triangle_mesh(500_000, 0, delaunay=False)
+        txy, tf = xa.meshgen.triangle_mesh(2_000_000, 2, 30.0, 0.7, delaunay=False)
+        src_g = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+        tgt_g = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+        src_g.device_mesh, tgt_g.device_mesh  # uploads are not part of the construction
+        times = []
+        for _ in range(3):
+            E.dev_sync()
+            t0 = time.perf_counter()
+            rg = xa.BarycentricInterpolator(src_g, tgt_g)
+            E.dev_sync()
+            times.append(time.perf_counter() - t0)
+        out["config3_barycentric_1M_to_4M"] = {
+            "construct_ms_first": 1e3 * times[0], "construct_ms_warm": 1e3 * min(times[1:]),
+            "target_points_per_s": tgt_g.n_face / min(times[1:]), "nnz": rg._device_weights.nnz,
+        }
+        del rg, src_g, tgt_g
+    except Exception as e:  # noqa: BLE001
+        out["config3_barycentric_1M_to_4M"] = {"error": repr(e)}
+    try:  # structured pair (SURVEY 8f rank 1): 4000^2 -> 4000^2 raster cells
+        ns = nt = 4000
+        src_r = Raster(x=np.arange(0.5, ns), y=np.arange(ns - 0.5, 0.0, -1.0))
+        tgt_r = Raster(x=0.37 + 0.98 * (np.arange(nt) + 0.5), y=(0.21 + 0.98 * (np.arange(nt) + 0.5))[::-1].copy())
+        s2, t2 = StructuredGrid2d(src_r), StructuredGrid2d(tgt_r)
+        s2.overlap_device(t2, False)
+        E.dev_sync()
+        t0 = time.perf_counter()
+        w = s2.overlap_device(t2, False)
+        E.dev_sync()
+        dt = time.perf_counter() - t0
+        out["structured_4000x4000"] = {"weights_ms": 1e3 * dt, "target_cells_per_s": t2.size / dt, "nnz": w.nnz}
+    except Exception as e:  # noqa: BLE001
+        out["structured_4000x4000"] = {"error": repr(e)}
+    return out
 
 
 def run_multi(args):
@@ -337,6 +416,7 @@ def main():
     ap.add_argument("--points", type=int, default=500_000, help="lattice points per mesh and per GPU (faces ~ 2x)")
     ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the informative extras (configs 3 and 5, structured pair)")
     ap.add_argument("--partition", default="morton", choices=["morton", "hash"])
     ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
                     help="sparse all-to-all of the touched targets (default) or dense reduce-scatter")

@@ -344,8 +344,10 @@ template <int METHOD, typename SRC, int KTILE>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_direct(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                const double *__restrict__ data, const int32_t *__restrict__ row_order, bool skip_long, int64_t T,
-               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
-    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out,
+               const int32_t *__restrict__ block_list) {
+    // block_list != nullptr: only these 256-row blocks (the ones the apply plan could not take)
+    const int64_t t = (int64_t)(block_list ? block_list[blockIdx.x] : blockIdx.x) * AP_BLOCK + threadIdx.x;
     if (t >= T) return;
     const int64_t k0 = (int64_t)blockIdx.y * KTILE;
     const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
@@ -357,7 +359,30 @@ k_apply_direct(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
     if (METHOD == XR_GEOMETRIC_MEAN)
         for (int j = s; j < e; j++) normsum += data[j];
     Red<METHOD> red[KTILE];
-    for (int j = s; j < e; j++) {
+    int j = s;
+    if (KTILE <= 4) {
+        // four entries' gathers in flight before their (sequential, CSR-order) additions: a thread that walks a
+        // long row alone is otherwise one HBM latency per entry
+        for (; j + 3 < e; j += 4) {
+            int64_t col[4];
+            double w[4], v[4][KTILE];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                col[u] = indices[j + u];
+                w[u] = data[j + u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++) v[u][kk] = kk < kn ? ld_src(src, (int64_t)kk * S + col[u]) : 0.0;
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++)
+                    if (kk < kn) red[kk].add(v[u][kk], w[u], normsum);
+        }
+    }
+    for (; j < e; j++) {
         const int64_t col = indices[j];
         const double w = data[j];
         double v[KTILE];
@@ -394,7 +419,7 @@ static constexpr int PLAN_KT = 8;      // source variables per pipeline stage (L
 __global__ void __launch_bounds__(AP_BLOCK)
 k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
              int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc,
-             int32_t *__restrict__ max_entries) {
+             int32_t *__restrict__ max_entries, int32_t *__restrict__ unplanned, int32_t *__restrict__ n_unplanned) {
     __shared__ int32_t keys[PLAN_LMAX];
     __shared__ int32_t uniq[PLAN_UMAX];
     __shared__ int32_t sh_wave[4];
@@ -404,7 +429,10 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     const int seg0 = indptr[row0], seg1 = indptr[row_end];
     const int n = seg1 - seg0;
     if (n > PLAN_LMAX) {
-        if (threadIdx.x == 0) nuniq[blockIdx.x] = -1;
+        if (threadIdx.x == 0) {
+            nuniq[blockIdx.x] = -1;
+            unplanned[atomicAdd(n_unplanned, 1)] = (int32_t)blockIdx.x;
+        }
         return;
     }
     int np2 = 1;
@@ -450,7 +478,10 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
     if (threadIdx.x == 0) sh_total = total;
     if (total > PLAN_UMAX) {
-        if (threadIdx.x == 0) nuniq[blockIdx.x] = -1;
+        if (threadIdx.x == 0) {
+            nuniq[blockIdx.x] = -1;
+            unplanned[atomicAdd(n_unplanned, 1)] = (int32_t)blockIdx.x;
+        }
         return;
     }
     int pos = woff + incl - cnt;
@@ -507,37 +538,7 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
     const bool is_long = skip_long && (e - s > APPLY_LONG); // reduced by k_apply_long
     const int64_t t_out = (t < T && row_order) ? (int64_t)row_order[t] : t;
-    if (nu < 0) {
-        // unplanned block (too many entries / distinct columns): direct gathers
-        if (t >= T || is_long) return;
-        double normsum = 0.0;
-        if (METHOD == XR_GEOMETRIC_MEAN)
-            for (int j = s; j < e; j++) normsum += data[j];
-        for (int64_t k0 = 0; k0 < K; k0 += KTILE) {
-            const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
-            const SRC *src = source + k0 * S;
-            Red<METHOD> red[KTILE];
-            for (int j = s; j < e; j++) {
-                const int64_t col = indices[j];
-                const double w = data[j];
-#pragma unroll
-                for (int kk = 0; kk < KTILE; kk++)
-                    if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
-            }
-#pragma unroll
-            for (int kk = 0; kk < KTILE; kk++) {
-                if (kk < kn) {
-                    double r = NAN;
-                    if (e > s) {
-                        r = red[kk].fin();
-                        if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
-                    }
-                    out[(k0 + kk) * T + t_out] = r;
-                }
-            }
-        }
-        return;
-    }
+    if (nu < 0) return; // unplanned block (too many entries / distinct columns): k_apply_direct over the block list
     // stage the block's entries once
     const int seg0 = indptr[row0], seg1 = indptr[row_end];
     for (int j = seg0 + threadIdx.x; j < seg1; j += AP_BLOCK) {
@@ -758,13 +759,18 @@ static void ensure_plan(const xr_csr *ccsr) {
     csr->plan_nuniq.alloc((size_t)nb);
     csr->plan_loc.alloc((size_t)csr->nnz);
     csr->plan_lmax = 256;
+    csr->plan_n_unplanned = 0;
     if (nb > 0) {
-        DevBuf<int32_t> max_entries(1);
-        fill_i32(max_entries.get(), 0, 1);
+        DevBuf<int32_t> max_entries(2); // [0] largest planned block, [1] number of unplanned blocks
+        fill_i32(max_entries.get(), 0, 2);
+        csr->plan_unplanned.alloc((size_t)nb);
         XR_LAUNCH("plan_build", k_plan_build, dim3((unsigned)nb), dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get(),
-                  max_entries.get());
-        const int m = read_scalar(max_entries.get());
+                  max_entries.get(), csr->plan_unplanned.get(), max_entries.get() + 1);
+        int32_t h[2];
+        d2h(h, max_entries.get(), sizeof(h));
+        const int m = h[0];
+        csr->plan_n_unplanned = h[1];
         csr->plan_lmax = std::min(PLAN_LMAX, std::max(256, (m + 255) / 256 * 256));
     }
     csr->plan_ready = true;
@@ -1047,12 +1053,21 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                       shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(),
                       csr->plan_nuniq.get(), csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src,
                       K, out, csr->plan_lmax);
+            if (csr->plan_n_unplanned > 0) {
+                // the few blocks the plan could not take (hull slivers: too many entries or distinct columns): direct
+                // gathers, parallel over the variable tiles as well so that no thread walks a long row K / 8 times
+                // (tiles of 4 variables: these blocks hold rows of up to 256 entries that one thread walks alone)
+                dim3 grid((unsigned)csr->plan_n_unplanned, div_up(K, 4));
+                XR_LAUNCH("apply_direct", (k_apply_direct<METHOD, SRC, 4>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K,
+                          out, csr->plan_unplanned.get());
+            }
         } else {
             // a few variables: register-resident k-tiles, direct gathers, no LDS
             dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
             XR_LAUNCH("apply_direct", (k_apply_direct<METHOD, SRC, KT>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K,
-                      out);
+                      out, (const int32_t *)nullptr);
         }
     }
     if (csr->has_long) {
