@@ -225,7 +225,7 @@ def run_single(args):
         with np.errstate(invalid="ignore", divide="ignore"):
             max_rel = float(np.nanmax(np.abs(out_gpu[both] - out_cpu[both]) / np.abs(out_cpu[both]))) if both.any() else 0.0
         log(f"[bench] GPU vs CPU oracle: {n_diff} of {T} values differ, max rel {max_rel:.3g} "
-            "(rows > 256 entries are block-reduced; all others bit-identical)")
+            "(rows > 32 entries are reduced cooperatively in a fixed tree order; all others bit-identical)")
         cpu["gpu_values_differing"] = n_diff
         cpu["gpu_max_rel_diff"] = max_rel
     result = {

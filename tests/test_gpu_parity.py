@@ -14,7 +14,7 @@ from xugrid_amd import meshgen
 pytestmark = pytest.mark.gpu
 
 RTOL_GEOMETRIC = 1e-13
-LONG_ROW = 256  # rows with more entries are reduced by a whole block (fixed tree order): ~1e-15 instead of bit-exact
+LONG_ROW = 32  # rows with more entries are reduced cooperatively (wave / block, fixed tree order): ~1e-15 instead of bit-exact
 RTOL_LONG = 1e-13
 
 
@@ -24,7 +24,13 @@ def assert_apply_equal(got, exp, indptr, name=""):
     short = ~long_rows
     assert same_or_nan(got[:, short], exp[:, short]).all(), (name, int((~same_or_nan(got[:, short], exp[:, short])).sum()))
     if long_rows.any():
-        np.testing.assert_allclose(got[:, long_rows], exp[:, long_rows], rtol=RTOL_LONG, equal_nan=True, err_msg=name)
+        # harmonic means of values of both signs cancel catastrophically (sum w / v near zero): there a different
+        # summation order shows up to 1e-10 (the north star's tolerance) instead of a few ulp
+        rtol = 1e-9 if name == "harmonic_mean" else RTOL_LONG
+        # (sums of values of both signs may cancel: absolute floor of a few ulp of the largest result)
+        finite = exp[:, long_rows][np.isfinite(exp[:, long_rows])]
+        atol = 1e-13 * (np.abs(finite).max() if finite.size else 1.0)
+        np.testing.assert_allclose(got[:, long_rows], exp[:, long_rows], rtol=rtol, atol=atol, equal_nan=True, err_msg=name)
 
 
 def gpu_triplets(hip, sxy, sf, txy, tf, relative=False, fill=-1):
@@ -227,7 +233,9 @@ def test_apply_golden_g2(hip, golden, name, mid, p):
         if name == "geometric_mean":
             np.testing.assert_allclose(got, exp, rtol=RTOL_GEOMETRIC, equal_nan=True)
         else:
-            assert same_or_nan(got, exp).all(), "%d mismatches" % (~same_or_nan(got, exp)).sum()
+            # rows of up to LONG_ROW entries: bit-identical to the reference loop; longer rows (here 33-40 entries)
+            # are reduced cooperatively in a fixed tree order
+            assert_apply_equal(got, exp, g["indptr"], name)
 
 
 def test_apply_coo_golden(hip, golden):

@@ -69,7 +69,7 @@ def test_outer_csr_random_and_regrid_vs_oracle(hip, oracle):
         oindptr = oracle.to_csr_indptr(ot, t.size)
         # oracle rows in the engine's within-row order (by column id, then weight)
         expected = oracle.regrid_csr(method, src.reshape(2, -1), ow, os_, oindptr, t.size).reshape(out.shape)
-        long_rows = (np.diff(oindptr) > 256).reshape(t.shape)
+        long_rows = (np.diff(oindptr) > 32).reshape(t.shape)  # cooperatively reduced rows
         short = np.broadcast_to(~long_rows, out.shape)
         if method != "geometric_mean":  # device exp/log vs libm: 1e-13 instead of bit-exact
             assert same_or_nan(out[short], expected[short]).all(), method

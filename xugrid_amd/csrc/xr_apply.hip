@@ -141,11 +141,31 @@ template <> struct Red<XR_SELECT> { // regridder.py:400-409 on CSR rows: the las
     __device__ double fin() const { return a; }
 };
 
-// Rows longer than APPLY_LONG entries are not reduced by one thread (a coarse target cell over a
-// fine source has thousands of entries) but by a whole block: strided per-thread partial states,
-// merged in a fixed butterfly order -> deterministic, but the summation order differs from the
-// reference's sequential loop (agreement ~1e-15 relative instead of bit-exact).
+// Rows longer than APPLY_LONG entries are not reduced by one thread: a coarse target cell over a fine source
+// has tens to thousands of entries, and a thread walking such a row alone reads its CSR entries uncoalesced and
+// waits one memory latency per entry.  They are reduced by one WAVE each (lanes stride the row: coalesced
+// entries, neighbouring columns gathered together) or, beyond APPLY_WAVE entries, by a whole block: strided
+// partial states merged in a fixed butterfly order -> deterministic, but the summation order differs from
+// the reference's sequential loop (agreement ~1e-15 relative instead of bit-exact).
 static constexpr int APPLY_LONG = XR_APPLY_LONG_ROW;
+static constexpr int APPLY_WAVE = XR_APPLY_WAVE_ROW;
+
+template <int METHOD> __device__ __forceinline__ void wave_merge(Red<METHOD> &r) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        Red<METHOD> o;
+        o.a = __shfl_xor(r.a, d, 64);
+        o.b = __shfl_xor(r.b, d, 64);
+        o.c = __shfl_xor(r.c, d, 64);
+        if ((lane & d) == 0) { // lane-independent order: every lane ends with the same value
+            r.merge(o);
+        } else {
+            o.merge(r);
+            r = o;
+        }
+    }
+}
 
 template <int METHOD> __device__ __forceinline__ void block_merge(Red<METHOD> &r, double (*lds)[3]) {
 #pragma unroll
@@ -224,6 +244,134 @@ k_apply_long(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                 out[k * T + t_out] = v;
             }
         }
+    }
+}
+
+// Listed rows with APPLY_LONG < entries <= APPLY_WAVE, KTILE source variables per pass, reduced by a GROUP of
+// G lanes each: G = 16 (four rows per wave) up to APPLY_GROUP16 entries, G = 64 (one row per wave) beyond.
+// The lanes of a group stride the row (entry j goes to lane j % G), so the CSR entries are read coalesced and
+// -- rows are sorted by column -- neighbouring lanes gather neighbouring source values; the group's partial
+// states are merged by a butterfly of log2(G) shuffles.  A lane's first four entries stay in registers across
+// the variable tiles.
+static constexpr int APPLY_GROUP16 = 512;
+
+template <int METHOD, int G> __device__ __forceinline__ void group_merge(Red<METHOD> &r) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) {
+        Red<METHOD> o;
+        o.a = __shfl_xor(r.a, d, 64);
+        o.b = __shfl_xor(r.b, d, 64);
+        o.c = __shfl_xor(r.c, d, 64);
+        if ((lane & d) == 0) { // lane-independent order: every lane of the group ends with the same value
+            r.merge(o);
+        } else {
+            o.merge(r);
+            r = o;
+        }
+    }
+}
+
+template <int METHOD, typename SRC, int KTILE, int G>
+__device__ __forceinline__ void apply_row_group(const int32_t *__restrict__ indices, const double *__restrict__ data,
+                                                int s, int e, int64_t t_out, int64_t T, int64_t S,
+                                                const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
+    const int gl = threadIdx.x & (G - 1); // lane within the group
+    int col4[4];
+    double w4[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int j = s + gl + G * u;
+        col4[u] = j < e ? indices[j] : -1;
+        w4[u] = j < e ? data[j] : 0.0;
+    }
+    double normsum = 0.0;
+    if (METHOD == XR_GEOMETRIC_MEAN) {
+        Red<XR_SUM> ws; // b accumulates the weights
+        for (int j = s + gl; j < e; j += G) ws.b += data[j];
+        group_merge<XR_SUM, G>(ws);
+        normsum = ws.b;
+    }
+    for (int64_t k0 = (int64_t)blockIdx.y * KTILE; k0 < K; k0 += (int64_t)gridDim.y * KTILE) {
+        const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+        const SRC *src = source + k0 * S;
+        Red<METHOD> r[KTILE];
+        double v[4][KTILE];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++)
+                v[u][kk] = (col4[u] >= 0 && kk < kn) ? ld_src(src, (int64_t)kk * S + col4[u]) : 0.0;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (col4[u] >= 0) {
+#pragma unroll
+                for (int kk = 0; kk < KTILE; kk++)
+                    if (kk < kn) r[kk].add(v[u][kk], w4[u], normsum);
+            }
+        }
+        for (int j = s + gl + 4 * G; j < e; j += G) {
+            const int64_t col = indices[j];
+            const double w = data[j];
+            double vv[KTILE];
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++) vv[kk] = kk < kn ? ld_src(src, (int64_t)kk * S + col) : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++)
+                if (kk < kn) r[kk].add(vv[kk], w, normsum);
+        }
+#pragma unroll
+        for (int kk = 0; kk < KTILE; kk++) group_merge<METHOD, G>(r[kk]);
+        if (gl == 0) {
+#pragma unroll
+            for (int kk = 0; kk < KTILE; kk++) {
+                if (kk < kn) {
+                    double res = r[kk].fin();
+                    if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) res = NAN;
+                    out[(k0 + kk) * T + t_out] = res;
+                }
+            }
+        }
+    }
+}
+
+template <int METHOD, typename SRC, int KTILE>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_wave(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+             const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+             const int32_t *__restrict__ n_long, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+             double *__restrict__ out, int32_t *__restrict__ huge_rows) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * AP_BLOCK + threadIdx.x) >> 6, n_waves = gridDim.x * (AP_BLOCK / 64);
+    const int nl = *n_long;
+    // pass 1: four listed rows per wave, 16 lanes each
+    for (int li0 = wave * 4; li0 < nl; li0 += n_waves * 4) {
+        const int li = li0 + (lane >> 4);
+        int s = 0, e = 0;
+        int64_t t_out = 0;
+        if (li < nl) {
+            const int t = long_rows[li];
+            s = indptr[t];
+            e = indptr[t + 1];
+            t_out = row_order ? (int64_t)row_order[t] : t;
+            if (e - s > APPLY_GROUP16) e = s; // other passes
+        }
+        // (the shuffles inside are wave-wide: every lane takes part, idle groups carry empty rows)
+        if (__any(e > s)) {
+            if (e > s) apply_row_group<METHOD, SRC, KTILE, 16>(indices, data, s, e, t_out, T, S, source, K, out);
+        }
+    }
+    // pass 2: one listed row per wave; rows beyond APPLY_WAVE entries are queued for the block kernel
+    for (int li = wave; li < nl; li += n_waves) {
+        const int t = long_rows[li];
+        const int s = indptr[t], e = indptr[t + 1];
+        if (e - s <= APPLY_GROUP16) continue;
+        if (e - s > APPLY_WAVE) { // [0] = count
+            if (lane == 0 && blockIdx.y == 0) huge_rows[1 + atomicAdd(huge_rows, 1)] = t;
+            continue;
+        }
+        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+        apply_row_group<METHOD, SRC, KTILE, 64>(indices, data, s, e, t_out, T, S, source, K, out);
     }
 }
 
@@ -1071,10 +1219,22 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         }
     }
     if (csr->has_long) {
+        DevBuf<int32_t> huge((size_t)(csr->nnz / APPLY_WAVE + 2));
+        XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), engine().stream));
+        {
+            // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: one wave each, 8 variables per pass
+            constexpr int WT = 8;
+            const unsigned wy = (unsigned)std::min<int64_t>(div_up(K, WT), 8);
+            dim3 wgrid((unsigned)engine().num_cu * 16 / wy, wy);
+            XR_LAUNCH("apply_wave", (k_apply_wave<METHOD, SRC, WT>), wgrid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                      csr->n, csr->m, src, K, out, huge.get());
+        }
+        // rows beyond APPLY_WAVE entries, as queued by the wave kernel: one block each
         const unsigned gy = (unsigned)(K < 8 ? K : 8);
-        dim3 grid((unsigned)engine().num_cu * (8 / gy), gy); // 8 blocks per CU; blocks past n_long exit at once
+        dim3 grid((unsigned)engine().num_cu * (8 / gy), gy); // 8 blocks per CU; blocks past the count exit at once
         XR_LAUNCH("apply_long", (k_apply_long<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), huge.get() + 1, huge.get(),
                   csr->n, csr->m, src, K, out);
     }
 }

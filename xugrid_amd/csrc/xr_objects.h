@@ -68,8 +68,11 @@ struct xr_mesh {
     const int32_t *qo_perm() const { return query_identity ? nullptr : q_perm.get(); } // nullptr = identity
 };
 
-// rows with more entries than this are reduced by a whole block in the apply kernels
-static constexpr int XR_APPLY_LONG_ROW = 256;
+// Rows with more entries than this are not walked by one thread but reduced cooperatively in the apply kernels:
+// by one wave each up to XR_APPLY_WAVE_ROW entries, by a whole block beyond.  (Cooperative = fixed butterfly
+// order: deterministic, ~1e-15 from the sequential order of the reference loop.)
+static constexpr int XR_APPLY_LONG_ROW = 32;
+static constexpr int XR_APPLY_WAVE_ROW = 2048;
 
 // Device-resident MatrixCSR (xugrid/core/sparse.py:81-137), int32 structure + float64 data.
 struct xr_csr {
@@ -82,7 +85,7 @@ struct xr_csr {
     // apply kernels scatter their outputs through it; xr_csr_download un-permutes.
     xr::DevBuf<int32_t> row_order; // [n]
     bool has_row_order = false;
-    // stored rows with more than APPLY_LONG entries (reduced by one block each in the apply)
+    // stored rows with more than XR_APPLY_LONG_ROW entries (reduced by one wave or block each in the apply)
     xr::DevBuf<int32_t> long_rows; // [<= n]
     xr::DevBuf<int32_t> n_long;    // [1] device-side count
     bool has_long = false;
