@@ -1221,8 +1221,14 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
     if (csr->has_long) {
         DevBuf<int32_t> huge((size_t)(csr->nnz / APPLY_WAVE + 2));
         XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), engine().stream));
-        {
-            // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: one wave each, 8 variables per pass
+        if (K == 1) {
+            // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: lane groups / waves; a single variable
+            dim3 wgrid((unsigned)engine().num_cu * 16, 1);
+            XR_LAUNCH("apply_wave", (k_apply_wave<METHOD, SRC, 1>), wgrid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                      csr->n, csr->m, src, K, out, huge.get());
+        } else {
+            // ... 8 variables per pass
             constexpr int WT = 8;
             const unsigned wy = (unsigned)std::min<int64_t>(div_up(K, WT), 8);
             dim3 wgrid((unsigned)engine().num_cu * 16 / wy, wy);
