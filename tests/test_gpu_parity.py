@@ -499,3 +499,45 @@ def test_device_pipelines_with_empty_sides(hip):
     assert (c.n, c.nnz) == (5, 0)
     out = c.apply(np.ones((1, sf.shape[0])), E.METHOD_IDS["select"])
     assert out.shape == (1, 5) and np.isnan(out).all()
+
+
+def test_apply_sorted_rows_mode_and_percentiles(hip, oracle):
+    """rows of 33..2048 entries take the wave-sorted kernel for mode / percentiles: values must be IDENTICAL to the
+    reference loops (order statistics and left-to-right weight sums do not depend on the search strategy).  Data with
+    ties, NaN, +-inf, signed zeros and zero weights; float32 sources as well."""
+    from xugrid_amd import engine as E
+
+    rng = np.random.default_rng(12)
+    T, S = 900, 5000
+    lens = np.concatenate([rng.integers(33, 300, 700), rng.integers(300, 2048, 150), rng.integers(0, 33, 50)])
+    rng.shuffle(lens)
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    nnz = int(indptr[-1])
+    indices = np.concatenate([np.sort(rng.choice(S, n, replace=n > S)) for n in lens]).astype(np.int64)
+    data = rng.random(nnz)
+    data[rng.random(nnz) < 0.05] = 0.0
+    zero_rows = rng.choice(T, 20, replace=False)
+    for r in zero_rows[:10]:
+        data[indptr[r]:indptr[r + 1]] = 0.0  # all weights zero -> NaN
+    src = np.empty((4, S))
+    src[0] = rng.integers(0, 7, S)                      # categorical: many ties
+    src[1] = rng.normal(size=S)
+    src[2] = np.where(rng.random(S) < 0.3, np.nan, rng.integers(-2, 3, S) * 0.5)  # NaN + signed zeros
+    src[2][rng.random(S) < 0.05] = -0.0
+    src[3] = rng.normal(size=S)
+    src[3][rng.random(S) < 0.02] = np.inf
+    src[3][rng.random(S) < 0.02] = -np.inf
+    src[3][rng.random(S) < 0.1] = np.nan
+    nan_rows = zero_rows[10:]
+    for r in nan_rows:  # all-NaN rows
+        src[2][indices[indptr[r]:indptr[r + 1]]] = np.nan
+    csr = E.DeviceCSR.from_arrays(data, indices, indptr, T, S)
+    for source in (src, src.astype(np.float32)):
+        for method, mid, p in (("mode", 6, 0.0), ("median", 7, 50.0), (("percentile", 33.3), 7, 33.3),
+                               (("percentile", 0.0), 7, 0.0), (("percentile", 100.0), 7, 100.0), (("percentile", 95.0), 7, 95.0)):
+            got = csr.apply(source, mid, p)
+            exp = oracle.regrid_csr(method, source, data, indices, indptr, T)
+            bad = ~same_or_nan(got, exp)
+            assert not bad.any(), (method, int(bad.sum()), np.argwhere(bad)[:5], got[bad][:5], exp[bad][:5])
+            if method == "mode":
+                assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(exp[~np.isnan(exp)]))

@@ -995,11 +995,12 @@ k_apply_workspace(const int32_t *__restrict__ indptr, const int32_t *__restrict_
                   const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
                   int64_t nnz,
                   const SRC *__restrict__ source, int64_t k_base, double p, double *__restrict__ ws,
-                  double *__restrict__ out) {
+                  double *__restrict__ out, bool skip_sorted) {
     const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
     if (t >= T) return;
     const int64_t k = k_base + blockIdx.y;
     const int s = indptr[t], e = indptr[t + 1], n = e - s;
+    if (skip_sorted && n > APPLY_LONG && n <= APPLY_WAVE) return; // k_apply_sorted
     double res = NAN;
     if (n > 0) {
         const SRC *src = source + k * S;
@@ -1074,6 +1075,143 @@ k_apply_workspace(const int32_t *__restrict__ indptr, const int32_t *__restrict_
         }
     }
     out[k * T + (row_order ? (int64_t)row_order[t] : t)] = res;
+}
+
+// mode / percentile of rows with APPLY_LONG < entries <= APPLY_WAVE: one WAVE per (row, variable).  The row's
+// values are sorted in LDS (bitonic network on (value, entry index) pairs -- a total order, i.e. a stable sort)
+// instead of the reference's per-row O(n^2) linear search (mode) / serial quickselect (percentile):
+//   percentile  order statistics do not depend on how they are found: sorted[k], sorted[k + 1], same
+//               interpolation as reduce.py:196-203 -> identical values
+//   mode        equal values become contiguous in entry order, so the weight of a distinct value is summed
+//               left to right exactly as the reference accumulates it onto the first occurrence
+//               (reduce.py:134-142); the winner is the largest (total weight, value) pair (:150-157)
+static constexpr int SORT_MAX = XR_APPLY_WAVE_ROW; // 2048
+
+template <int METHOD, typename SRC>
+__global__ void __launch_bounds__(64)
+k_apply_sorted(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+               const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+               const int32_t *__restrict__ n_long, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+               double p, double *__restrict__ out) {
+    __shared__ double sv[SORT_MAX];   // value (NaN and padding as +inf: sorted to the end)
+    __shared__ uint16_t si[SORT_MAX]; // entry index within the row; bit 15 = not a valid value (NaN / padding), so that
+                                      // among equal sort keys (+inf) the valid entries come first
+    __shared__ double sw[METHOD == XR_MODE ? SORT_MAX : 1]; // weights in entry order (mode)
+    const int lane = threadIdx.x;
+    const int nl = *n_long;
+    for (int li = blockIdx.x; li < nl; li += gridDim.x) {
+        const int t = long_rows[li];
+        const int s = indptr[t], n = indptr[t + 1] - s;
+        if (n > SORT_MAX) continue; // thread-per-row kernel
+        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+        int np2 = 64;
+        while (np2 < n) np2 <<= 1;
+        for (int64_t k = blockIdx.y; k < K; k += gridDim.y) {
+            const SRC *src = source + k * S;
+            __syncthreads();
+            // load: values, validity count, largest weight of a valid (mode) / any (percentile) entry
+            int n_valid = 0;
+            double w_max = 0.0, v_min = INFINITY, v_max = -INFINITY;
+            for (int i = lane; i < np2; i += 64) {
+                double v = INFINITY;
+                if (i < n) {
+                    const double x = ld_src(src, indices[s + i]);
+                    const double w = data[s + i];
+                    if (METHOD == XR_MODE) sw[i] = w;
+                    const bool ok = x == x;
+                    if (ok) {
+                        v = x;
+                        n_valid++;
+                        v_min = fmin(v_min, x);
+                        v_max = fmax(v_max, x);
+                    }
+                    if (METHOD != XR_MODE || ok) w_max = fmax(w_max, w);
+                }
+                sv[i] = v;
+                si[i] = (uint16_t)(v == INFINITY && !(i < n && ld_src(src, indices[s + i]) == INFINITY) ? (i | 0x8000) : i);
+            }
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) {
+                n_valid += __shfl_xor(n_valid, d, 64);
+                w_max = fmax(w_max, __shfl_xor(w_max, d, 64));
+                v_min = fmin(v_min, __shfl_xor(v_min, d, 64));
+                v_max = fmax(v_max, __shfl_xor(v_max, d, 64));
+            }
+            double res = NAN;
+            if (METHOD == XR_PERCENTILE && (p == 0 || p == 100)) {
+                // reduce.py:172-176: _minimum / _maximum (NaN skipped; NaN if every weight of a valid entry is 0)
+                double wm = 0.0;
+                for (int i = lane; i < n; i += 64)
+                    if (!(si[i] & 0x8000)) wm = fmax(wm, data[s + i]);
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) wm = fmax(wm, __shfl_xor(wm, d, 64));
+                if (w_max != 0.0 && n_valid > 0 && wm != 0.0) res = p == 0 ? v_min : v_max;
+                if (lane == 0) out[k * T + t_out] = res;
+                continue;
+            }
+            const bool trivial = w_max == 0.0 || n_valid == 0;
+            if (!trivial && !(METHOD == XR_PERCENTILE && n_valid == 1)) {
+                // bitonic sort of (value, index) ascending
+                for (int size = 2; size <= np2; size <<= 1) {
+                    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                        __syncthreads();
+                        for (int q = lane; q < np2 / 2; q += 64) {
+                            const int lo = 2 * q - (q & (stride - 1));
+                            const int hi = lo + stride;
+                            const bool up = (lo & size) == 0;
+                            const double a = sv[lo], b = sv[hi];
+                            const uint16_t ia = si[lo], ib = si[hi];
+                            const bool a_gt_b = (a > b) || (a == b && ia > ib);
+                            if (a_gt_b == up) {
+                                sv[lo] = b; sv[hi] = a;
+                                si[lo] = ib; si[hi] = ia;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            if (METHOD == XR_PERCENTILE) {
+                if (!trivial) {
+                    if (n_valid == 1) {
+                        res = v_min;
+                    } else {
+                        // +inf VALUES sort among the padding; their count does not matter: ranks only reach n_valid - 1
+                        const double rank = 1 + (double)(n_valid - 1) * p / 100.0;
+                        const double f = floor(rank);
+                        const double frac = rank - f;
+                        const int kk = (int)(f - 1);
+                        const double lower = sv[kk], upper = sv[kk + 1];
+                        res = lower * (1 - frac) + upper * frac;
+                    }
+                }
+            } else if (!trivial) {
+                // group starts sum their group left to right; then the largest (total, value) pair wins
+                double best_w = -1.0, best_v = -INFINITY;
+                for (int i = lane; i < n_valid; i += 64) {
+                    const double v = sv[i];
+                    if (i == 0 || sv[i - 1] != v) {
+                        double tot = sw[si[i]];
+                        for (int j = i + 1; j < n_valid && sv[j] == v; j++) tot += sw[si[j]];
+                        if (tot > best_w || (tot == best_w && v > best_v)) {
+                            best_w = tot;
+                            best_v = v;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) {
+                    const double ow = __shfl_xor(best_w, d, 64), ov = __shfl_xor(best_v, d, 64);
+                    if (ow > best_w || (ow == best_w && ov > best_v)) {
+                        best_w = ow;
+                        best_v = ov;
+                    }
+                }
+                res = best_v;
+            }
+            if (lane == 0) out[k * T + t_out] = res;
+        }
+    }
 }
 
 // mean partials for source-sharded multi-GPU: num = sum w v, den = sum w over non-NaN v
@@ -1258,7 +1396,15 @@ static void launch_workspace(const xr_csr *csr, const SRC *src, int64_t K, doubl
         dim3 grid(div_up(csr->n, AP_BLOCK), (unsigned)kc);
         XR_LAUNCH("apply_workspace", (k_apply_workspace<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m, csr->nnz, src, k0, p,
-                  ws.get(), out);
+                  ws.get(), out, csr->has_long);
+    }
+    if (csr->has_long) {
+        // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: sorted in LDS by one wave per (row, variable)
+        const unsigned gy = (unsigned)std::min<int64_t>(K, 16);
+        dim3 grid((unsigned)engine().num_cu * 32 / gy, gy);
+        XR_LAUNCH("apply_sorted", (k_apply_sorted<METHOD, SRC>), grid, dim3(64), 0, csr->indptr.get(), csr->indices.get(),
+                  csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(), csr->n, csr->m, src, K, p,
+                  out);
     }
 }
 
