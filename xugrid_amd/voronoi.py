@@ -21,6 +21,7 @@ goldens are interchangeable:
   interpolation_map[k] = the two projection vertex ids the k-th extra corner sits between
 """
 import numpy as np
+import scipy.sparse
 
 from .connectivity import FILL_VALUE, IntDType, close_polygons
 
@@ -207,8 +208,6 @@ def voronoi_topology_device(grid):
     Returns (DeviceMesh of the tessellation, face_index, interpolation_map): the mesh has the same vertices and
     cells, in the same order, as the host function returns as arrays.
     """
-    import scipy.sparse
-
     from . import engine
 
     builder = engine.DeviceVoronoi(grid.device_mesh)
