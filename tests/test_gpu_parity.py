@@ -541,3 +541,15 @@ def test_apply_sorted_rows_mode_and_percentiles(hip, oracle):
             assert not bad.any(), (method, int(bad.sum()), np.argwhere(bad)[:5], got[bad][:5], exp[bad][:5])
             if method == "mode":
                 assert np.array_equal(np.signbit(got[~np.isnan(got)]), np.signbit(exp[~np.isnan(exp)]))
+
+
+def test_full_size_exact_vs_oracle(hip, oracle):
+    """BASELINE config 2 itself (1M -> 1M Delaunay triangles): the whole weight matrix against the CPU oracle --
+    pair sets and areas bit for bit -- and every streaming reducer on it (rows of up to 32 entries bit-identical)."""
+    sxy, sf = meshgen.triangle_mesh(500_000, 0)
+    txy, tf = meshgen.triangle_mesh(500_000, 1, 30.0, 0.7)
+    csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
+    assert csr.nnz > 4_000_000
+    v = meshgen.smooth_field(oracle.centroids(sxy, sf), 0, nan_fraction=0.01)[None, :]
+    for name, mid in (("mean", 0), ("maximum", 5), ("max_overlap", 9), ("sum", 3)):
+        assert_apply_equal(csr.apply(v, mid), oracle.regrid_csr(name, v, data, idx, indptr, csr.n), indptr, name)
