@@ -416,3 +416,18 @@ def test_rasterize_known_answers(hip):
     assert np.array_equal(index, expected)
     xs, ys, idx = grid.rasterize_like(np.array([0.5, 1.5]), np.array([0.5]))
     assert np.array_equal(idx, [[0, 1]])
+
+
+def test_barycentric_full_size_vs_oracle(hip, oracle):
+    """BASELINE config 3 at 1M source faces / 1M query points: device Voronoi pre-step + xr_barycentric_csr against
+    the oracle's step-by-step restatement -- identical triplets."""
+    sxy, sf = meshgen.triangle_mesh(500_000, 0, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(500_000, 2, 30.0, 0.75, delaunay=False)
+    src = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    dcsr = xa.regrid.UnstructuredGrid2d(src).barycentric_device(xa.regrid.UnstructuredGrid2d(tgt))
+    data, indices, indptr = dcsr.download()
+    rows = np.repeat(np.arange(dcsr.n), np.diff(indptr))
+    os_, ot, ow = _oracle_barycentric_triplets(oracle, src, oracle.centroids(txy, tf))
+    assert indices.size == os_.size > 4_000_000
+    assert np.array_equal(indices, os_) and np.array_equal(rows, ot) and np.array_equal(data, ow)
