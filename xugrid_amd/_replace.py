@@ -31,8 +31,10 @@ def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_n
         px, py = vertices[p]
         qx, qy = vertices[q]
         rx, ry = vertices[r]
-        p_q = np.sqrt((qx - px) ** 2 + (qy - py) ** 2)
-        p_r = np.sqrt((rx - px) ** 2 + (ry - py) ** 2)
+        # explicit products: numba lowers ``x ** 2`` to a multiplication, libm's pow(x, 2.0) is not always the
+        # correctly rounded square (found by the randomised soak test: 1 ulp in one weight of 749)
+        p_q = np.sqrt((qx - px) * (qx - px) + (qy - py) * (qy - py))
+        p_r = np.sqrt((rx - px) * (rx - px) + (ry - py) * (ry - py))
         total = p_q + p_r
         weight_q = (p_r / total) * w
         weight_r = (p_q / total) * w
