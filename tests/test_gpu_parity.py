@@ -553,3 +553,21 @@ def test_full_size_exact_vs_oracle(hip, oracle):
     v = meshgen.smooth_field(oracle.centroids(sxy, sf), 0, nan_fraction=0.01)[None, :]
     for name, mid in (("mean", 0), ("maximum", 5), ("max_overlap", 9), ("sum", 3)):
         assert_apply_equal(csr.apply(v, mid), oracle.regrid_csr(name, v, data, idx, indptr, csr.n), indptr, name)
+
+
+def test_apply_host_arrays_in_chunks(hip, oracle, monkeypatch):
+    """xr_apply_csr stages the stacked variables through the device in chunks (any K fits): same result for any
+    chunk size (XR_APPLY_CHUNK_BYTES is a test hook)."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.triangle_mesh(1500, 0)
+    txy, tf = meshgen.triangle_mesh(1800, 1, 30.0, 0.7)
+    csr = E.DeviceMesh(sxy, sf).overlap(E.DeviceMesh(txy, tf))
+    v = np.random.default_rng(3).normal(size=(37, csr.m))
+    whole = csr.apply(v, 0)
+    per_k = csr.m * 8 + csr.n * 8
+    for budget in (per_k, 5 * per_k + 1, 36 * per_k):
+        monkeypatch.setenv("XR_APPLY_CHUNK_BYTES", str(budget))
+        assert np.array_equal(csr.apply(v, 0), whole, equal_nan=True)
+        v32 = v.astype(np.float32)
+        assert np.array_equal(csr.apply(v32, 7, 50.0), csr.apply(v32.astype(np.float64), 7, 50.0), equal_nan=True)

@@ -1790,15 +1790,26 @@ int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *s
     XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
                source_dtype);
     const size_t esz = source_dtype == XR_F64 ? 8 : 4;
-    const size_t n_src = (size_t)K * (size_t)csr->m, n_out = (size_t)K * (size_t)csr->n;
-    DevBuf<char> src(n_src * esz);
-    DevBuf<double> dst(n_out);
-    h2d(src.get(), source, n_src * esz);
-    apply_dev(csr, method, percentile, src.get(), source_dtype, K, dst.get());
-    if (n_out > 0) {
-        XR_HIP(hipMemcpyAsync(out, dst.get(), n_out * sizeof(double), hipMemcpyDeviceToHost, engine().stream));
+    // The stacked variables go through the device in chunks of at most ~4 GiB of staging (source + result), so any
+    // K works whatever the size of HBM; every variable is independent, results do not depend on the chunking.
+    const size_t per_k = (size_t)csr->m * esz + (size_t)csr->n * sizeof(double);
+    const char *chunk_env = getenv("XR_APPLY_CHUNK_BYTES"); // test hook
+    const size_t budget = chunk_env ? (size_t)atoll(chunk_env) : ((size_t)4 << 30);
+    int64_t kchunk = per_k > 0 ? (int64_t)(budget / per_k) : K;
+    if (kchunk < 1) kchunk = 1;
+    if (kchunk > K) kchunk = K;
+    DevBuf<char> src((size_t)kchunk * (size_t)csr->m * esz);
+    DevBuf<double> dst((size_t)kchunk * (size_t)csr->n);
+    for (int64_t k0 = 0; k0 < K; k0 += kchunk) {
+        const int64_t kc = (K - k0) < kchunk ? (K - k0) : kchunk;
+        const size_t n_src = (size_t)kc * (size_t)csr->m, n_out = (size_t)kc * (size_t)csr->n;
+        h2d(src.get(), static_cast<const char *>(source) + (size_t)k0 * (size_t)csr->m * esz, n_src * esz);
+        apply_dev(csr, method, percentile, src.get(), source_dtype, kc, dst.get());
+        if (n_out > 0)
+            XR_HIP(hipMemcpyAsync(out + (size_t)k0 * (size_t)csr->n, dst.get(), n_out * sizeof(double),
+                                  hipMemcpyDeviceToHost, engine().stream));
+        stream_sync();
     }
-    stream_sync();
     XR_API_END
 }
 
