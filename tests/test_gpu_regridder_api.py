@@ -431,3 +431,21 @@ def test_barycentric_full_size_vs_oracle(hip, oracle):
     os_, ot, ow = _oracle_barycentric_triplets(oracle, src, oracle.centroids(txy, tf))
     assert indices.size == os_.size > 4_000_000
     assert np.array_equal(indices, os_) and np.array_equal(rows, ot) and np.array_equal(data, ow)
+
+
+def test_weights_file_round_trip(hip, tmp_path):
+    """to_file / from_file (npz of the reference's dataset variables) for unstructured and structured regridders."""
+    grid, target = disk_like(700, 3), disk_like(650, 4)
+    z = np.stack([meshgen.smooth_field(grid.centroids, k, 0.02) for k in range(2)])
+    cases = [
+        (xa.OverlapRegridder(grid, target, method="mean"), z),
+        (xa.BarycentricInterpolator(grid, target), z),
+        (xa.CentroidLocatorRegridder(grid, target), z),
+        (xa.RelativeOverlapRegridder(grid, raster_b()), z),
+        (xa.OverlapRegridder(raster_a(), raster_b()), np.arange(18.0).reshape(2, 3, 3)),
+    ]
+    for i, (rg, data) in enumerate(cases):
+        path = tmp_path / f"weights_{i}.npz"
+        rg.to_file(path)
+        again = type(rg).from_file(path)
+        assert np.array_equal(again.regrid(data), rg.regrid(data), equal_nan=True)

@@ -229,6 +229,20 @@ class BaseRegridder(abc.ABC):
         instance._source = cls._grid_from_dataset(weights, "__source")
         return instance
 
+    # ---- file persistence of the flat dict (xarray / netCDF are optional and absent here; the variable names are the
+    # reference's, so a netCDF written by xugrid's own ``regridder.to_dataset().to_netcdf()`` maps one to one)
+    def to_file(self, path) -> None:
+        """Write ``to_dataset()`` to a NumPy ``.npz`` archive."""
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in self.to_dataset().items()})
+
+    @classmethod
+    def from_file(cls, path):
+        """Reconstruct the regridder (cached weights + both grids) from ``to_file`` output."""
+        with np.load(path, allow_pickle=False) as archive:
+            dataset = {k: (archive[k].item() if archive[k].ndim == 0 and archive[k].dtype.kind in "US" else archive[k])
+                       for k in archive.files}
+        return cls.from_dataset(dataset)
+
     @classmethod
     def from_dataset(cls, dataset):
         """Reconstruct the regridder from ``to_dataset()`` output (regridder.py:350-361)."""
