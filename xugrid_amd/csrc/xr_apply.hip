@@ -571,7 +571,6 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     __shared__ int32_t keys[PLAN_LMAX];
     __shared__ int32_t uniq[PLAN_UMAX];
     __shared__ int32_t sh_wave[4];
-    __shared__ int32_t sh_total;
     const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
     const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
     const int seg0 = indptr[row0], seg1 = indptr[row_end];
@@ -624,7 +623,6 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         if (w < wave) woff += sh_wave[w];
         total += sh_wave[w];
     }
-    if (threadIdx.x == 0) sh_total = total;
     if (total > PLAN_UMAX) {
         if (threadIdx.x == 0) {
             nuniq[blockIdx.x] = -1;
