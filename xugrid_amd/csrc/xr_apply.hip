@@ -1801,11 +1801,9 @@ int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *s
     for (int64_t k0 = 0; k0 < K; k0 += kchunk) {
         const int64_t kc = (K - k0) < kchunk ? (K - k0) : kchunk;
         const size_t n_src = (size_t)kc * (size_t)csr->m, n_out = (size_t)kc * (size_t)csr->n;
-        h2d(src.get(), static_cast<const char *>(source) + (size_t)k0 * (size_t)csr->m * esz, n_src * esz);
+        h2d_big(src.get(), static_cast<const char *>(source) + (size_t)k0 * (size_t)csr->m * esz, n_src * esz);
         apply_dev(csr, method, percentile, src.get(), source_dtype, kc, dst.get());
-        if (n_out > 0)
-            XR_HIP(hipMemcpyAsync(out + (size_t)k0 * (size_t)csr->n, dst.get(), n_out * sizeof(double),
-                                  hipMemcpyDeviceToHost, engine().stream));
+        if (n_out > 0) d2h_big(out + (size_t)k0 * (size_t)csr->n, dst.get(), n_out * sizeof(double));
         stream_sync();
     }
     XR_API_END

@@ -1,6 +1,10 @@
 // xr_engine.hip -- engine context, HBM block pool, error reporting, kernel timing, raw HBM helpers.
 #include <cstdarg>
 
+#include <algorithm>
+#include <cstring>
+#include <thread>
+
 #include "xr_internal.h"
 
 namespace xr {
@@ -125,6 +129,82 @@ void d2h(void *dst, const void *src, size_t bytes) {
 }
 
 void stream_sync() { XR_HIP(hipStreamSynchronize(engine().stream)); }
+
+// ---------------------------------------------------------------------------------------------
+// staged copies of large pageable host arrays
+// ---------------------------------------------------------------------------------------------
+static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
+static constexpr int STAGE_THREADS = 8;
+static char *g_stage[2] = {nullptr, nullptr};
+static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+
+static void stage_init() {
+    if (g_stage[0]) return;
+    for (int i = 0; i < 2; i++) {
+        void *p = nullptr;
+        XR_HIP(hipHostMalloc(&p, STAGE_BYTES, hipHostMallocDefault));
+        g_stage[i] = static_cast<char *>(p);
+        XR_HIP(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+    }
+}
+
+static void parallel_memcpy(char *dst, const char *src, size_t n) {
+    const size_t per = (n + STAGE_THREADS - 1) / STAGE_THREADS;
+    std::thread workers[STAGE_THREADS];
+    int started = 0;
+    for (int t = 1; t < STAGE_THREADS; t++) {
+        const size_t o = (size_t)t * per;
+        if (o >= n) break;
+        const size_t c = std::min(per, n - o);
+        workers[started++] = std::thread([=] { memcpy(dst + o, src + o, c); });
+    }
+    memcpy(dst, src, std::min(per, n));
+    for (int t = 0; t < started; t++) workers[t].join();
+}
+
+void h2d_big(void *dst, const void *src, size_t bytes) {
+    if (bytes < 2 * STAGE_BYTES) {
+        h2d(dst, src, bytes);
+        return;
+    }
+    stage_init();
+    hipStream_t st = engine().stream;
+    size_t off = 0;
+    for (int i = 0; off < bytes; i ^= 1) {
+        const size_t c = std::min(STAGE_BYTES, bytes - off);
+        XR_HIP(hipEventSynchronize(g_stage_ev[i])); // the DMA that last read this staging buffer is done
+        parallel_memcpy(g_stage[i], static_cast<const char *>(src) + off, c);
+        XR_HIP(hipMemcpyAsync(static_cast<char *>(dst) + off, g_stage[i], c, hipMemcpyHostToDevice, st));
+        XR_HIP(hipEventRecord(g_stage_ev[i], st));
+        off += c;
+    }
+    XR_HIP(hipStreamSynchronize(st));
+}
+
+void d2h_big(void *dst, const void *src, size_t bytes) {
+    if (bytes < 2 * STAGE_BYTES) {
+        XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, engine().stream));
+        XR_HIP(hipStreamSynchronize(engine().stream));
+        return;
+    }
+    stage_init();
+    hipStream_t st = engine().stream;
+    const size_t n_piece = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
+    auto piece = [&](size_t k) { return std::min(STAGE_BYTES, bytes - k * STAGE_BYTES); };
+    XR_HIP(hipMemcpyAsync(g_stage[0], src, piece(0), hipMemcpyDeviceToHost, st));
+    XR_HIP(hipEventRecord(g_stage_ev[0], st));
+    for (size_t k = 0; k < n_piece; k++) {
+        const int i = (int)(k & 1);
+        if (k + 1 < n_piece) { // next piece into the other buffer while this one is copied out
+            XR_HIP(hipMemcpyAsync(g_stage[i ^ 1], static_cast<const char *>(src) + (k + 1) * STAGE_BYTES, piece(k + 1),
+                                  hipMemcpyDeviceToHost, st));
+            XR_HIP(hipEventRecord(g_stage_ev[i ^ 1], st));
+        }
+        XR_HIP(hipEventSynchronize(g_stage_ev[i]));
+        parallel_memcpy(static_cast<char *>(dst) + k * STAGE_BYTES, g_stage[i], piece(k));
+    }
+    XR_HIP(hipStreamSynchronize(st));
+}
 
 void mailbox_wait() {
     XR_HIP(hipEventRecord(engine().mail_event, engine().stream));

@@ -379,13 +379,18 @@ class DeviceCSR:
         check(_lib.load().xr_csr_download(self._h, _ptr(data), _ptr(indices), _ptr(indptr)))
         return data, indices.astype(IntDType, copy=False), indptr.astype(IntDType, copy=False)
 
-    def apply(self, source, method_id=0, percentile=0.0):
-        """make_regrid(f)._regrid(source, A, size): (K, S) -> float64 (K, T)."""
+    def apply(self, source, method_id=0, percentile=0.0, out=None):
+        """make_regrid(f)._regrid(source, A, size): (K, S) -> float64 (K, T).  ``out``: optional preallocated
+        C-contiguous float64 (K, T) array to reuse (for large K the first touch and the release of a fresh result
+        array cost more than the transfer itself)."""
         src, dtype = _source_2d(source)
         if src.shape[1] != self.m:
             raise ValueError(f"source has {src.shape[1]} cells, weights expect {self.m}")
         K = src.shape[0]
-        out = np.empty((K, self.n), dtype=np.float64)
+        if out is None:
+            out = np.empty((K, self.n), dtype=np.float64)
+        elif out.shape != (K, self.n) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float64 array of shape {(K, self.n)}")
         check(_lib.load().xr_apply_csr(self._h, int(method_id), float(percentile), _ptr(src), dtype, K, _ptr(out)))
         return out
 
