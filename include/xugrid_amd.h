@@ -246,6 +246,12 @@ int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double
 /* out_dev[k][t] = acc[t][K+k] == 0 ? NaN : acc[t][k] / acc[t][K+k]   (acc float64 [n_rows, 2K],
  * out float64 [K, n_rows]). */
 int xr_finalize_mean_rows_dev(const double *acc_dev, int64_t n_rows, int64_t K, double *out_dev);
+/* The owner side of the sparse exchange in one launch: rows_dev float64[R, 2K] are the received partial rows
+ * (num[0..K), den[0..K)); target t of this rank's slice sums rows order_dev[indptr_dev[t] .. indptr_dev[t+1]) in
+ * that (sender) order and is finalised: out_dev float64[K, n_targets] = num / den, NaN where den == 0.  Same
+ * additions in the same order as xr_accumulate_rows_dev sender by sender + xr_finalize_mean_rows_dev. */
+int xr_reduce_mean_rows_dev(const double *rows_dev, const int64_t *indptr_dev, const int64_t *order_dev,
+                            int64_t n_targets, int64_t K, double *out_dev);
 
 /* ---- raw HBM helpers for hosts that do not bring their own allocator -------------------- */
 int xr_dev_alloc(int64_t bytes, void **ptr_out);

@@ -58,6 +58,14 @@ class OracleBackend:
         nd = self.partial_mean(w, source)  # (2, K, T)
         return nd.permute(2, 0, 1).reshape(nd.shape[2], -1).contiguous()
 
+    def reduce_mean_rows(self, rows, indptr, order, n_targets, K):
+        rows, indptr, order = rows.numpy(), indptr.numpy(), order.numpy()
+        acc = np.zeros((n_targets, 2 * K))
+        for t in range(n_targets):
+            for j in order[indptr[t]:indptr[t + 1]]:  # sender order
+                acc[t] += rows[j]
+        return self.finalize_mean(torch.as_tensor(acc[:, :K].T.copy()), torch.as_tensor(acc[:, K:].T.copy()))
+
     def accumulate_rows(self, acc, ids, rows):
         acc[ids] += rows
 
@@ -68,6 +76,18 @@ class OracleBackend:
         n, d = num.numpy(), den.numpy()
         with np.errstate(invalid="ignore", divide="ignore"):
             return torch.as_tensor(np.where(d == 0, np.nan, n / d))
+
+
+class _NoFused:
+    """OracleBackend without reduce_mean_rows (attribute lookup fails -> the regridder accumulates sender by sender)."""
+
+    def __init__(self):
+        self._b = OracleBackend()
+
+    def __getattr__(self, name):
+        if name == "reduce_mean_rows":
+            raise AttributeError(name)
+        return getattr(self._b, name)
 
 
 def main():
@@ -88,6 +108,7 @@ def main():
         results[mode + "_1d"] = rg.regrid(data[0])
         results[mode + "_n_local"] = rg.local_faces.size
         results[mode + "_n_local_targets"] = rg.local_targets.size
+    results["morton_legacy"] = ShardedOverlapRegridder(sxy, sf, txy, tf, _NoFused(), partition="morton").regrid(data)
     for method in ("mode", "median", "max_overlap", "minimum", "sum", "mean"):
         tp = TargetPartitionedRegridder(sxy, sf, txy, tf, OracleBackend(), method=method)
         results["tp_" + method] = tp.regrid(data)

@@ -79,6 +79,7 @@ SIGNATURES = {
     "xr_apply_partial_mean_rows_dev": (c_int, [vp, vp, c_int, c_i64, vp]),
     "xr_accumulate_rows_dev": (c_int, [vp, vp, vp, c_i64, c_i64]),
     "xr_finalize_mean_rows_dev": (c_int, [vp, c_i64, c_i64, vp]),
+    "xr_reduce_mean_rows_dev": (c_int, [vp, vp, vp, c_i64, c_i64, vp]),
     "xr_dev_alloc": (c_int, [c_i64, p_vp]),
     "xr_dev_free": (c_int, [vp]),
     "xr_dev_upload": (c_int, [vp, vp, c_i64]),

@@ -1282,6 +1282,23 @@ __global__ void k_accumulate_rows(double *__restrict__ acc, const int64_t *__res
     acc[ids[r] * width + c] += rows[i];
 }
 
+// owner side of the sparse exchange in one launch: target t sums the received rows order[indptr[t] .. indptr[t+1])
+// (sender by sender, i.e. in a fixed order) and finalises the mean
+__global__ void k_reduce_mean_rows(const double *__restrict__ rows, const int64_t *__restrict__ indptr,
+                                   const int64_t *__restrict__ order, int64_t n_targets, int64_t K,
+                                   double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_targets * K) return;
+    const int64_t k = i / n_targets, t = i - k * n_targets;
+    double num = 0.0, den = 0.0;
+    for (int64_t j = indptr[t]; j < indptr[t + 1]; j++) {
+        const double *row = rows + order[j] * 2 * K;
+        num += row[k];
+        den += row[K + k];
+    }
+    out[i] = den == 0 ? NAN : num / den;
+}
+
 __global__ void k_finalize_mean_rows(const double *__restrict__ acc, int64_t n_rows, int64_t K,
                                      double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1894,6 +1911,19 @@ int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double
         XR_REQUIRE(acc_dev && ids_dev && rows_dev, XR_ERR_INVALID, "xr_accumulate_rows_dev: NULL argument");
         XR_LAUNCH("accumulate_rows", k_accumulate_rows, dim3(div_up(n * width, 256)), dim3(256), 0, acc_dev, ids_dev,
                   rows_dev, n, width);
+    }
+    stream_sync();
+    XR_API_END
+}
+
+int xr_reduce_mean_rows_dev(const double *rows_dev, const int64_t *indptr_dev, const int64_t *order_dev, int64_t n_targets,
+                            int64_t K, double *out_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(n_targets >= 0 && K >= 0, XR_ERR_INVALID, "xr_reduce_mean_rows_dev: negative size");
+    if (n_targets > 0 && K > 0) {
+        XR_REQUIRE(indptr_dev && out_dev, XR_ERR_INVALID, "xr_reduce_mean_rows_dev: NULL argument");
+        XR_LAUNCH("reduce_mean_rows", k_reduce_mean_rows, dim3(div_up(n_targets * K, 256)), dim3(256), 0, rows_dev,
+                  indptr_dev, order_dev, n_targets, K, out_dev);
     }
     stream_sync();
     XR_API_END

@@ -139,6 +139,13 @@ class HipBackend:
         self.torch.cuda.current_stream().synchronize()
         self.engine.accumulate_rows_dev(acc.data_ptr(), ids.data_ptr(), rows.data_ptr(), rows.shape[0], rows.shape[1])
 
+    def reduce_mean_rows(self, rows, indptr, order, n_targets, K):
+        """received rows (R, 2K) + per-target lists (indptr, order) -> finalised (K, n_targets) in one launch."""
+        out = self.torch.empty((K, n_targets), dtype=self.torch.float64, device=self.device)
+        self.torch.cuda.current_stream().synchronize()
+        self.engine.reduce_mean_rows_dev(rows.data_ptr(), indptr.data_ptr(), order.data_ptr(), n_targets, K, out.data_ptr())
+        return out
+
     def finalize_mean_rows(self, acc, K):
         """(chunk, 2K) -> (K, chunk)."""
         out = self.torch.empty((K, acc.shape[0]), dtype=self.torch.float64, device=self.device)
@@ -268,6 +275,14 @@ class ShardedOverlapRegridder:
         dist.all_to_all_single(ids_out, ids_in, output_split_sizes=self._recv_counts,
                                input_split_sizes=self._send_counts, group=self.group)
         self._recv_ids = ids_out  # positions inside my slice, grouped by sender
+        # per owned target: the received rows that belong to it, in sender order (stable sort of the positions)
+        ids_host = ids_out.cpu()
+        order = torch.argsort(ids_host, stable=True)
+        counts = torch.bincount(ids_host, minlength=self.t_chunk)
+        indptr = torch.zeros(self.t_chunk + 1, dtype=torch.int64)
+        indptr[1:] = torch.cumsum(counts, 0)
+        self._recv_order = order.to(dev)
+        self._recv_indptr = indptr.to(dev)
 
     def rebuild(self):
         self.weights = self.backend.rebuild_weights()
@@ -290,6 +305,8 @@ class ShardedOverlapRegridder:
             recv = torch.empty((sum(self._recv_counts), 2 * K), dtype=send.dtype, device=send.device)
             self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
                                         input_split_sizes=self._send_counts, group=self.group)
+            if hasattr(self.backend, "reduce_mean_rows"):
+                return self.backend.reduce_mean_rows(recv, self._recv_indptr, self._recv_order, self.t_chunk, K)
             acc = torch.zeros((self.t_chunk, 2 * K), dtype=send.dtype, device=send.device)
             start = 0
             for cnt in self._recv_counts:  # sender by sender: ids are unique within a sender

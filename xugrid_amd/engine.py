@@ -426,6 +426,15 @@ def accumulate_rows_dev(acc_ptr, ids_ptr, rows_ptr, n, width):
     )
 
 
+def reduce_mean_rows_dev(rows_ptr, indptr_ptr, order_ptr, n_targets, K, out_ptr):
+    check(
+        _lib.load().xr_reduce_mean_rows_dev(
+            ctypes.c_void_p(rows_ptr), ctypes.c_void_p(indptr_ptr), ctypes.c_void_p(order_ptr), int(n_targets), int(K),
+            ctypes.c_void_p(out_ptr),
+        )
+    )
+
+
 def finalize_mean_rows_dev(acc_ptr, n_rows, K, out_ptr):
     check(_lib.load().xr_finalize_mean_rows_dev(ctypes.c_void_p(acc_ptr), int(n_rows), int(K), ctypes.c_void_p(out_ptr)))
 
