@@ -332,7 +332,9 @@ k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m_rt, const in
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n) return;
     const int k = key[f];
-    const int64_t r = start[k] + atomicAdd(&cursor[k], 1);
+    // `cursor` still holds the bucket histogram of the count pass: slots are handed out from the top down (the order
+    // inside a bucket is unspecified anyway), which saves re-zeroing the array between the two passes
+    const int64_t r = start[k] + atomicSub(&cursor[k], 1) - 1;
     perm[r] = (int32_t)f;
     int face[MA];
 #pragma unroll
@@ -374,7 +376,6 @@ static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams 
         XR_LAUNCH(INDEX ? "index_count" : "order_count", k_spatial_count<INDEX>, dim3(div_up(F, 256)), dim3(256), 0,
                   mesh->bbox.get(), F, g, mp, key.get(), count.get());
     exclusive_scan_i32(count.get(), bucket_start, n_buckets);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
     if (F > 0) {
         const char *name = INDEX ? "index_scatter" : "order_scatter";
         const dim3 grid(div_up(F, 256)), block(256);
