@@ -52,7 +52,7 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
          const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_off,
          int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
-         int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key) {
+         int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key, int32_t *__restrict__ nnz_row) {
     __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
     __shared__ uint8_t sh_owner[SLOTS * 256];
     __shared__ int32_t sh_wave[4];
@@ -61,6 +61,7 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
     int count = 0;
     bool big = false;
     if (t < n_query) {
+        nnz_row[t] = 0; // the clip kernel counts the surviving pairs of the row into it
         const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
         if (tile_key) {
             // row tiling hint for the many-variable apply: all rows of a run of TILE_RUN consecutive ids share the
@@ -178,10 +179,11 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
 }
 
 // deposit one device word in the host mailbox (pinned memory)
-__global__ void k_publish(const int32_t *__restrict__ src, int32_t *dst, const int32_t *__restrict__ src2, int32_t *dst2) {
+__global__ void k_publish(const int32_t *__restrict__ src, int32_t *dst, int32_t *src2, int32_t *dst2) {
     if (threadIdx.x == 0) {
         *dst = *src;
         *dst2 = *src2;
+        *src2 = 0; // the counter is reused afterwards
     }
 }
 
@@ -983,7 +985,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
     int64_t capacity = T * SLOTS + (margin_env ? (int64_t)atoll(margin_env) : ((int64_t)4 << 20));
     XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
-    DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity);
+    DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     // Rows kept in the caller's (coherent, but typically strip-like) numbering get a coarse Morton key each:
     // tiles of 12-24 mean target extents, runs of TILE_RUN consecutive rows kept together.  A Morton-sorted query order is tiled already.
     MortonParams tile{};
@@ -1006,7 +1008,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->qo_bbox(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
               cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
-              csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr);
+              csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get());
     DevBuf<int32_t> pending((size_t)T);
     XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
               query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
@@ -1029,16 +1031,16 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         cand_tgt = std::move(bigger_tgt);
         cand_src = std::move(bigger_src);
         capacity = C;
+        h2d(counters.get() + 1, &n_pending, sizeof(int32_t)); // (k_publish zeroed the device copy)
         XR_LAUNCH("search_big_fill", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
                   query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
                   pending.get(), counters.get() + 1, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
                   (int32_t *)nullptr, capacity, (int32_t *)nullptr, (int32_t *)nullptr);
+        XR_HIP(hipMemsetAsync(counters.get() + 1, 0, sizeof(int32_t), st));
     }
-    // counters[1] is reused below as the number of long rows
-    XR_HIP(hipMemsetAsync(counters.get() + 1, 0, sizeof(int32_t), st));
-    DevBuf<int32_t> cand_sid((size_t)C), nnz_row((size_t)T);
+    // (counters[1], zeroed again by k_publish, is reused below as the number of long rows)
+    DevBuf<int32_t> cand_sid((size_t)C);
     DevBuf<double> cand_area((size_t)C);
-    XR_HIP(hipMemsetAsync(nnz_row.get(), 0, sizeof(int32_t) * (size_t)T, st));
     if (C > 0) {
         // --- clip (+ per-row survivor counts)
         launch_clip_for(tree, query, cand_tgt.get(), cand_src.get(), C, cand_area.get(), cand_sid.get(), counters.get(),
