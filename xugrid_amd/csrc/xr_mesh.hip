@@ -144,6 +144,25 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
     }
 }
 
+// ingest of the caller's connectivity (xr_mesh_create): fill -> -1, narrow to int32, validate
+template <typename I>
+__global__ void __launch_bounds__(256)
+k_ingest_faces(const I *__restrict__ raw, int64_t cnt, int m, int64_t fill_value, int64_t n_node,
+               int32_t *__restrict__ out, int64_t *__restrict__ err) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= cnt) return;
+    const int64_t v = (int64_t)raw[k];
+    const int64_t f = k / m;
+    const int j = (int)(k - f * m);
+    if (v == fill_value || v == -1) {
+        if (j < 3) atomicMin(reinterpret_cast<unsigned long long *>(err), (unsigned long long)f);
+        out[k] = -1;
+    } else {
+        if (v < 0 || v >= n_node) atomicMin(reinterpret_cast<unsigned long long *>(err + 1), (unsigned long long)f);
+        out[k] = (int32_t)v;
+    }
+}
+
 // CCW-normalised connectivity (xr_mesh_faces; not on the hot path)
 __global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ node_xy,
                                                   const int32_t *__restrict__ faces_raw, int64_t n_face, int m,
@@ -549,25 +568,10 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
                "xr_mesh_create: mesh exceeds the int32 index range");
     XR_REQUIRE((node_xy && faces) || n_face == 0, XR_ERR_INVALID, "xr_mesh_create: NULL arrays");
     engine();
-    // ingest: fill -> -1, range check, narrow to int32 (host side; this is the H2D staging step)
+    // ingest on the device: the raw connectivity (int32 or int64, caller's fill value) is uploaded as it is; one kernel
+    // maps the fill value to -1, narrows to int32 and validates (every face has at least three nodes, every node id
+    // is inside [0, n_node)); the first offending face is reported
     const size_t cnt = (size_t)n_face * (size_t)n_max_node;
-    std::vector<int32_t> f32(cnt ? cnt : 1);
-    for (int64_t f = 0; f < n_face; f++) {
-        for (int64_t j = 0; j < n_max_node; j++) {
-            const size_t k = (size_t)f * n_max_node + j;
-            const int64_t v = faces_itemsize == 8 ? static_cast<const int64_t *>(faces)[k]
-                                                  : (int64_t) static_cast<const int32_t *>(faces)[k];
-            if (v == fill_value || v == -1) {
-                XR_REQUIRE(j >= 3, XR_ERR_INVALID, "xr_mesh_create: face %lld has fewer than 3 nodes", (long long)f);
-                f32[k] = -1;
-            } else {
-                XR_REQUIRE(v >= 0 && v < n_node, XR_ERR_INVALID,
-                           "xr_mesh_create: face %lld references node %lld outside [0,%lld)", (long long)f,
-                           (long long)v, (long long)n_node);
-                f32[k] = (int32_t)v;
-            }
-        }
-    }
     xr_mesh *mesh = new xr_mesh();
     try {
         mesh->n_node = n_node;
@@ -575,8 +579,29 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
         mesh->m = (int)n_max_node;
         mesh->node_xy.alloc((size_t)n_node * 2);
         mesh->faces_raw.alloc(cnt);
-        h2d(mesh->node_xy.get(), node_xy, sizeof(double) * 2 * (size_t)n_node);
-        h2d(mesh->faces_raw.get(), f32.data(), sizeof(int32_t) * cnt);
+        h2d_big(mesh->node_xy.get(), node_xy, sizeof(double) * 2 * (size_t)n_node);
+        if (cnt > 0) {
+            DevBuf<char> raw(cnt * (size_t)faces_itemsize);
+            DevBuf<int64_t> err(2); // [0] first face with fewer than 3 nodes, [1] first face with a node id out of range
+            const int64_t none[2] = {INT64_MAX, INT64_MAX};
+            h2d(err.get(), none, sizeof(none));
+            h2d_big(raw.get(), faces, cnt * (size_t)faces_itemsize);
+            if (faces_itemsize == 8)
+                XR_LAUNCH("ingest_faces", k_ingest_faces<int64_t>, dim3(div_up((int64_t)cnt, 256)), dim3(256), 0,
+                          reinterpret_cast<const int64_t *>(raw.get()), (int64_t)cnt, (int)n_max_node, fill_value, n_node,
+                          mesh->faces_raw.get(), err.get());
+            else
+                XR_LAUNCH("ingest_faces", k_ingest_faces<int32_t>, dim3(div_up((int64_t)cnt, 256)), dim3(256), 0,
+                          reinterpret_cast<const int32_t *>(raw.get()), (int64_t)cnt, (int)n_max_node, fill_value, n_node,
+                          mesh->faces_raw.get(), err.get());
+            int64_t h_err[2];
+            d2h(h_err, err.get(), sizeof(h_err));
+            XR_REQUIRE(h_err[0] == INT64_MAX, XR_ERR_INVALID, "xr_mesh_create: face %lld has fewer than 3 nodes",
+                       (long long)h_err[0]);
+            XR_REQUIRE(h_err[1] == INT64_MAX, XR_ERR_INVALID,
+                       "xr_mesh_create: face %lld references a node outside [0,%lld)", (long long)h_err[1],
+                       (long long)n_node);
+        }
     } catch (...) {
         delete mesh;
         throw;
