@@ -1548,8 +1548,7 @@ static void download_widen(const int32_t *dev, int64_t n, int64_t *host) {
     if (n <= 0) return;
     DevBuf<int64_t> wide((size_t)n);
     XR_LAUNCH("widen_i32", k_widen_i32, dim3(div_up(n, 256)), dim3(256), 0, dev, wide.get(), n);
-    XR_HIP(hipMemcpyAsync(host, wide.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, engine().stream));
-    stream_sync();
+    d2h(host, wide.get(), sizeof(int64_t) * (size_t)n);
 }
 
 } // namespace xr
@@ -1591,9 +1590,7 @@ int xr_csr_download(const xr_csr *csr, double *data, int64_t *indices, int64_t *
         d_data = c_data.get();
     }
     if (data && csr->nnz > 0) {
-        XR_HIP(hipMemcpyAsync(data, d_data, sizeof(double) * (size_t)csr->nnz, hipMemcpyDeviceToHost,
-                              engine().stream));
-        stream_sync();
+        d2h(data, d_data, sizeof(double) * (size_t)csr->nnz);
     }
     if (indices) download_widen(d_indices, csr->nnz, indices);
     if (indptr) download_widen(d_indptr, csr->n + 1, indptr);

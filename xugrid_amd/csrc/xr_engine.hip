@@ -109,8 +109,15 @@ void pool_trim() {
     g_free.clear();
 }
 
+static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
+static constexpr size_t BIG_COPY_BYTES = 2 * STAGE_BYTES; // copies of this size and more are staged
+
 void h2d(void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
+    if (bytes >= BIG_COPY_BYTES) {
+        h2d_big(dst, src, bytes);
+        return;
+    }
     XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, engine().stream));
     XR_HIP(hipStreamSynchronize(engine().stream));
 }
@@ -124,6 +131,10 @@ void d2h(void *dst, const void *src, size_t bytes) {
         memcpy(dst, engine().pinned, bytes);
         return;
     }
+    if (bytes >= BIG_COPY_BYTES) {
+        d2h_big(dst, src, bytes);
+        return;
+    }
     XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, engine().stream));
     XR_HIP(hipStreamSynchronize(engine().stream));
 }
@@ -133,7 +144,6 @@ void stream_sync() { XR_HIP(hipStreamSynchronize(engine().stream)); }
 // ---------------------------------------------------------------------------------------------
 // staged copies of large pageable host arrays
 // ---------------------------------------------------------------------------------------------
-static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
 static constexpr int STAGE_THREADS = 8;
 static char *g_stage[2] = {nullptr, nullptr};
 static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
@@ -163,8 +173,9 @@ static void parallel_memcpy(char *dst, const char *src, size_t n) {
 }
 
 void h2d_big(void *dst, const void *src, size_t bytes) {
-    if (bytes < 2 * STAGE_BYTES) {
-        h2d(dst, src, bytes);
+    if (bytes < BIG_COPY_BYTES) {
+        XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, engine().stream));
+        XR_HIP(hipStreamSynchronize(engine().stream));
         return;
     }
     stage_init();
@@ -182,7 +193,7 @@ void h2d_big(void *dst, const void *src, size_t bytes) {
 }
 
 void d2h_big(void *dst, const void *src, size_t bytes) {
-    if (bytes < 2 * STAGE_BYTES) {
+    if (bytes < BIG_COPY_BYTES) {
         XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, engine().stream));
         XR_HIP(hipStreamSynchronize(engine().stream));
         return;

@@ -286,8 +286,7 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
             XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
                       mesh->rec_len.get(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
                       mesh->rec_face.get(), pts.get(), n, tol, out.get());
-            XR_HIP(hipMemcpyAsync(face_index_out, out.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
-                                  engine().stream));
+            d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             stream_sync();
         } else {
             for (int64_t i = 0; i < n; i++) face_index_out[i] = -1;
@@ -314,10 +313,8 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
             XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
                       mesh->rec_len.get(), m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
                       mesh->rec_face.get(), pts.get(), n, tol, out.get(), w.get());
-            XR_HIP(hipMemcpyAsync(face_index_out, out.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
-                                  engine().stream));
-            XR_HIP(hipMemcpyAsync(weights_out, w.get(), sizeof(double) * (size_t)n * m, hipMemcpyDeviceToHost,
-                                  engine().stream));
+            d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
+            d2h(weights_out, w.get(), sizeof(double) * (size_t)n * m);
             stream_sync();
         } else {
             for (int64_t i = 0; i < n; i++) face_index_out[i] = -1;

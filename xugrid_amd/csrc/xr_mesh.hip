@@ -666,8 +666,7 @@ int xr_mesh_area(xr_mesh *mesh, double *area_out) {
     XR_REQUIRE(mesh && area_out, XR_ERR_INVALID, "xr_mesh_area: NULL argument");
     mesh_prepare(mesh);
     if (mesh->n_face > 0) {
-        XR_HIP(hipMemcpyAsync(area_out, mesh->area.get(), sizeof(double) * (size_t)mesh->n_face,
-                              hipMemcpyDeviceToHost, engine().stream));
+        d2h(area_out, mesh->area.get(), sizeof(double) * (size_t)mesh->n_face);
     }
     stream_sync();
     XR_API_END
@@ -681,8 +680,7 @@ int xr_mesh_centroids(xr_mesh *mesh, double *centroids_out) {
         DevBuf<double> c((size_t)F * 2);
         XR_LAUNCH("centroids", k_centroids, dim3(div_up(F, 256)), dim3(256), 0, mesh->node_xy.get(),
                   mesh->faces_raw.get(), F, mesh->m, c.get());
-        XR_HIP(hipMemcpyAsync(centroids_out, c.get(), sizeof(double) * 2 * (size_t)F, hipMemcpyDeviceToHost,
-                              engine().stream));
+        d2h(centroids_out, c.get(), sizeof(double) * 2 * (size_t)F);
         stream_sync();
     }
     XR_API_END
@@ -696,8 +694,7 @@ int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out) {
         DevBuf<int64_t> wide((size_t)n);
         XR_LAUNCH("faces_ccw", k_faces_ccw, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
                   mesh->faces_raw.get(), mesh->n_face, mesh->m, wide.get());
-        XR_HIP(hipMemcpyAsync(faces_out, wide.get(), sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost,
-                              engine().stream));
+        d2h(faces_out, wide.get(), sizeof(int64_t) * (size_t)n);
         stream_sync();
     }
     XR_API_END
