@@ -71,6 +71,7 @@ extern "C" {
 
 typedef struct xr_mesh xr_mesh; /* device-resident Ugrid2d face topology + spatial index */
 typedef struct xr_csr xr_csr;   /* device-resident MatrixCSR weights */
+typedef struct xr_outer xr_outer; /* separable (rectilinear) weights in factored form */
 
 /* ---- engine ---------------------------------------------------------------------------- */
 const char *xr_last_error(void);
@@ -204,6 +205,21 @@ int xr_csr_from_outer(const int64_t *indptr_y, const int64_t *source_y, const do
                       int64_t n_target_y, int64_t n_source_y, const int64_t *indptr_x,
                       const int64_t *source_x, const double *weight_x, int64_t n_target_x,
                       int64_t n_source_x, xr_csr **out);
+/* The same separable weights kept in FACTORED form (the two per-axis sparse matrices, a few hundred KB for
+ * 4000 x 4000 grids) instead of their P_y * P_x product: xr_apply_outer reduces each target cell by walking its
+ * c_y x c_x entries in the order of the product's CSR row (= the order of the reference's loop,
+ * xugrid/regrid/structured.py:503-601 -> regrid/reduce.py), forming every weight w_y * w_x on the fly, so rows of
+ * ANY length are reduced sequentially and bit-identically to the reference, and the apply reads the source data
+ * once instead of the 12 bytes per entry of a stored matrix.  mode / percentiles (which need a row's values side by
+ * side) and xr_outer_csr materialise the product once and keep it inside the handle. */
+int xr_outer_create(const int64_t *indptr_y, const int64_t *source_y, const double *weight_y,
+                    int64_t n_target_y, int64_t n_source_y, const int64_t *indptr_x,
+                    const int64_t *source_x, const double *weight_x, int64_t n_target_x,
+                    int64_t n_source_x, xr_outer **out);
+int xr_outer_info(const xr_outer *outer, int64_t *n, int64_t *m, int64_t *nnz);
+/* borrowed handle of the materialised product (owned by `outer`; do not destroy) */
+int xr_outer_csr(xr_outer *outer, const xr_csr **out);
+int xr_outer_destroy(xr_outer *outer);
 /* Optional locality hint for matrices that were uploaded (xr_csr_upload / xr_csr_from_triplet, i.e. the
  * from_weights path): one small integer per row such that rows with equal keys are spatial neighbours (e.g. the
  * Morton code of a coarse cell holding the target face's centroid).  With many source variables (K >= 8) the apply
@@ -220,6 +236,11 @@ int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *s
                  int source_dtype, int64_t K, double *out);
 int xr_apply_csr_dev(const xr_csr *csr, int method, double percentile, const void *source_dev,
                      int source_dtype, int64_t K, double *out_dev);
+/* the same two calls on factored separable weights (xr_outer_create) */
+int xr_apply_outer(xr_outer *outer, int method, double percentile, const void *source,
+                   int source_dtype, int64_t K, double *out);
+int xr_apply_outer_dev(xr_outer *outer, int method, double percentile, const void *source_dev,
+                       int source_dtype, int64_t K, double *out_dev);
 /* CentroidLocatorRegridder._regrid, regridder.py:400-409: out[k,row[i]] = source[k,col[i]],
  * NaN elsewhere.  rows must be unique (they are target indices of located centroids). */
 int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,

@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The oracle's C restatement is OpenMP code.  The tests make thousands of SMALL oracle calls; with one spinning
+# thread per hardware thread of a 256-thread host each parallel region costs ~0.2 s (measured on the GPU box), i.e.
+# minutes per test module.  A modest passive team keeps the calls at their ~1 ms compute time.  (Set before
+# libgomp is loaded; results do not depend on the team size.  bench.py's cpu_baseline leg is not affected.)
+os.environ.setdefault("OMP_NUM_THREADS", "16")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")

@@ -69,6 +69,12 @@ SIGNATURES = {
     "xr_csr_upload": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, p_vp]),
     "xr_csr_from_triplet": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, p_vp]),
     "xr_csr_from_outer": (c_int, [vp, vp, vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, p_vp]),
+    "xr_outer_create": (c_int, [vp, vp, vp, c_i64, c_i64, vp, vp, vp, c_i64, c_i64, p_vp]),
+    "xr_outer_info": (c_int, [vp, vp, vp, vp]),
+    "xr_outer_csr": (c_int, [vp, p_vp]),
+    "xr_outer_destroy": (c_int, [vp]),
+    "xr_apply_outer": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
+    "xr_apply_outer_dev": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
     "xr_csr_set_row_keys": (c_int, [vp, vp, c_i64]),
     "xr_csr_destroy": (c_int, [vp]),
     "xr_apply_csr": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),

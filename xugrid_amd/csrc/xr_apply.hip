@@ -12,6 +12,7 @@
 // HBM layout: source (K, S) row-major, out (K, T) row-major (regridder.py:163, :44);
 // CSR = indptr i32[T+1], indices i32[nnz], data f64[nnz].
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "xr_objects.h"
@@ -1496,6 +1497,119 @@ static void set_long_rows(xr_csr *csr, const std::vector<int32_t> &longs) {
     h2d(csr->n_long.get(), &count, sizeof(int32_t));
 }
 
+// ---- matrix-free apply of separable weights: one thread per target cell walks the c_y x c_x entries of its row
+// (y-major, x-minor = the order of the materialised CSR row and of the reference's loop) and forms each weight
+// w_y * w_x on the fly.  Neighbouring threads are neighbouring x-targets, whose x-lists are adjacent source columns:
+// the gathers are coalesced whatever the coarsening ratio, so even rows of thousands of entries are reduced
+// sequentially -- bit-identical to the reference order -- and the P entries of the product are never stored or read.
+template <int METHOD, typename SRC, int KTILE, int CX>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_outer(const int32_t *__restrict__ ipy, const int32_t *__restrict__ sy, const double *__restrict__ wy,
+              const int32_t *__restrict__ ipx, const int32_t *__restrict__ sx, const double *__restrict__ wx, int64_t nty,
+              int64_t ntx, int64_t nsx, int64_t S, int rows_per_block, const SRC *__restrict__ source, int64_t K,
+              double *__restrict__ out) {
+    // blockIdx.x: 256 adjacent x-targets; blockIdx.y: a run of target rows (everything about a y-list is wave-uniform,
+    // i.e. scalar loads); blockIdx.z: tile of KTILE source variables.  CX > 0: every x-list has at most CX entries
+    // and lives in registers for all rows of the run; the CX x KTILE gathers of one source row are then independent
+    // loads issued back to back (lanes past the end of their list re-read their last column and discard it).
+    const int64_t it = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
+    if (it >= ntx) return;
+    const int64_t T = nty * ntx;
+    const int x0 = ipx[it], x1 = ipx[it + 1];
+    const int nx = x1 - x0;
+    constexpr int CXR = CX > 0 ? CX : 1;
+    int sxr[CXR];
+    double wxr[CXR];
+    if (CX > 0) {
+#pragma unroll
+        for (int c = 0; c < CXR; c++) {
+            const int b = c < nx ? x0 + c : (nx > 0 ? x1 - 1 : 0);
+            sxr[c] = nx > 0 ? sx[b] : 0;
+            wxr[c] = nx > 0 ? wx[b] : 0.0;
+        }
+    }
+    const int64_t k0 = (int64_t)blockIdx.z * KTILE;
+    const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+    const SRC *src = source + k0 * S;
+    const int64_t j0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t j1 = (j0 + rows_per_block) < nty ? (j0 + rows_per_block) : nty;
+    for (int64_t jt = j0; jt < j1; jt++) {
+        const int y0 = ipy[jt], y1 = ipy[jt + 1];
+        double normsum = 0.0;
+        if (METHOD == XR_GEOMETRIC_MEAN)
+            for (int a = y0; a < y1; a++)
+                for (int b = x0; b < x1; b++) normsum += wy[a] * wx[b];
+        Red<METHOD> red[KTILE];
+        for (int a = y0; a < y1; a++) {
+            const int64_t rowbase = (int64_t)sy[a] * nsx;
+            const double wa = wy[a];
+            if (CX > 0) {
+                double v[CXR][KTILE];
+#pragma unroll
+                for (int c = 0; c < CXR; c++)
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++)
+                        v[c][kk] = ld_src(src, (int64_t)(kk < kn ? kk : 0) * S + rowbase + sxr[c]);
+#pragma unroll
+                for (int c = 0; c < CXR; c++) {
+                    if (c < nx) {
+                        const double w = wa * wxr[c];
+#pragma unroll
+                        for (int kk = 0; kk < KTILE; kk++) red[kk].add(v[c][kk], w, normsum);
+                    }
+                }
+            } else {
+                for (int b = x0; b < x1; b++) {
+                    const int64_t col = rowbase + sx[b];
+                    const double w = wa * wx[b];
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++)
+                        if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, normsum);
+                }
+            }
+        }
+        const bool empty = y1 == y0 || nx == 0;
+        const int64_t t = jt * ntx + it;
+#pragma unroll
+        for (int kk = 0; kk < KTILE; kk++) {
+            if (kk < kn) {
+                double r = NAN;
+                if (!empty) {
+                    r = red[kk].fin();
+                    if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+                }
+                out[(k0 + kk) * T + t] = r;
+            }
+        }
+    }
+}
+
+template <int METHOD, typename SRC, int KT, int CX>
+static void launch_outer_kt(const xr_outer *o, const SRC *src, int64_t K, double *out) {
+    static const int rpb_env = getenv("XR_OUTER_ROWS") ? atoi(getenv("XR_OUTER_ROWS")) : 0; // tuning hook
+    const int rpb = (int)std::max<int64_t>(rpb_env > 0 ? rpb_env : 4, div_up(o->nty, 65535));
+    const dim3 grid((unsigned)div_up(o->ntx, AP_BLOCK), (unsigned)div_up(o->nty, rpb), (unsigned)div_up(K, KT));
+    XR_LAUNCH("apply_outer", (k_apply_outer<METHOD, SRC, KT, CX>), grid, dim3(AP_BLOCK), 0, o->ipy.get(), o->sy.get(),
+              o->wy.get(), o->ipx.get(), o->sx.get(), o->wx.get(), o->nty, o->ntx, o->nsx, o->nsy * o->nsx, rpb, src, K,
+              out);
+}
+
+template <int METHOD, typename SRC, int KT>
+static void launch_outer_cx(const xr_outer *o, const SRC *src, int64_t K, double *out) {
+    if (o->max_cx <= 2) launch_outer_kt<METHOD, SRC, KT, 2>(o, src, K, out);
+    else if (o->max_cx <= 4) launch_outer_kt<METHOD, SRC, KT, 4>(o, src, K, out);
+    else launch_outer_kt<METHOD, SRC, KT, 0>(o, src, K, out);
+}
+
+template <int METHOD, typename SRC>
+static void launch_outer(const xr_outer *o, const SRC *src, int64_t K, double *out) {
+    if (o->nty * o->ntx == 0 || K == 0) return;
+    XR_REQUIRE(div_up(K, 4) <= 65535, XR_ERR_LIMIT, "apply: too many source variables in one call (%lld)", (long long)K);
+    if (K == 1) launch_outer_cx<METHOD, SRC, 1>(o, src, K, out);
+    else if (K == 2) launch_outer_cx<METHOD, SRC, 2>(o, src, K, out);
+    else launch_outer_cx<METHOD, SRC, 4>(o, src, K, out);
+}
+
 // ---- separable (rectilinear) weights: CSR of the outer product of two per-axis sparse matrices.
 // Row (jt, it) of the product holds cy(jt) * cx(it) entries, y-major / x-minor, i.e. ascending in the
 // column id sy * n_source_x + sx when both axis rows are ascending.  The entries of one jt form a
@@ -1554,6 +1668,136 @@ static void download_widen(const int32_t *dev, int64_t n, int64_t *host) {
 } // namespace xr
 
 using namespace xr;
+
+static void check_axis(const char *name, const int64_t *indptr, const int64_t *source, const double *weight,
+                       int64_t n_target, int64_t n_source) {
+    XR_REQUIRE(indptr, XR_ERR_INVALID, "xr_csr_from_outer: NULL indptr (%s axis)", name);
+    XR_REQUIRE(n_target >= 0 && n_source >= 0, XR_ERR_INVALID, "xr_csr_from_outer: negative size (%s axis)", name);
+    XR_REQUIRE(indptr[0] == 0, XR_ERR_INVALID, "xr_csr_from_outer: indptr[0] != 0 (%s axis)", name);
+    for (int64_t i = 0; i < n_target; i++)
+        XR_REQUIRE(indptr[i + 1] >= indptr[i], XR_ERR_INVALID, "xr_csr_from_outer: indptr decreases at %lld (%s axis)",
+                   (long long)i, name);
+    const int64_t nnz = indptr[n_target];
+    XR_REQUIRE(nnz == 0 || (source && weight), XR_ERR_INVALID, "xr_csr_from_outer: NULL entries (%s axis)", name);
+    for (int64_t i = 0; i < nnz; i++)
+        XR_REQUIRE(source[i] >= 0 && source[i] < n_source, XR_ERR_INVALID,
+                   "xr_csr_from_outer: source index %lld outside [0,%lld) (%s axis)", (long long)source[i],
+                   (long long)n_source, name);
+}
+
+static xr_outer *outer_create(const int64_t *indptr_y, const int64_t *source_y, const double *weight_y, int64_t n_target_y,
+                              int64_t n_source_y, const int64_t *indptr_x, const int64_t *source_x, const double *weight_x,
+                              int64_t n_target_x, int64_t n_source_x) {
+    check_axis("y", indptr_y, source_y, weight_y, n_target_y, n_source_y);
+    check_axis("x", indptr_x, source_x, weight_x, n_target_x, n_source_x);
+    const int64_t Py = indptr_y[n_target_y], Px = indptr_x[n_target_x];
+    const int64_t lim = ((int64_t)1 << 31) - 1;
+    XR_REQUIRE(n_target_y == 0 || n_target_x < lim / n_target_y, XR_ERR_LIMIT,
+               "separable weights: target grid exceeds the int32 index range");
+    XR_REQUIRE(n_source_y == 0 || n_source_x <= lim / n_source_y, XR_ERR_LIMIT,
+               "separable weights: source grid exceeds the int32 index range");
+    xr_outer *o = new xr_outer();
+    try {
+        o->nty = n_target_y; o->nsy = n_source_y; o->ntx = n_target_x; o->nsx = n_source_x; o->Py = Py; o->Px = Px;
+        o->ipy.alloc((size_t)n_target_y + 1); o->ipx.alloc((size_t)n_target_x + 1);
+        o->sy.alloc((size_t)Py); o->sx.alloc((size_t)Px); o->tx.alloc((size_t)Px);
+        o->wy.alloc((size_t)Py); o->wx.alloc((size_t)Px);
+        upload_narrow(indptr_y, n_target_y + 1, o->ipy.get());
+        upload_narrow(indptr_x, n_target_x + 1, o->ipx.get());
+        upload_narrow(source_y, Py, o->sy.get());
+        upload_narrow(source_x, Px, o->sx.get());
+        h2d(o->wy.get(), weight_y, sizeof(double) * (size_t)Py);
+        h2d(o->wx.get(), weight_x, sizeof(double) * (size_t)Px);
+        std::vector<int32_t> owner((size_t)Px);
+        for (int64_t it = 0; it < n_target_x; it++)
+            for (int64_t q = indptr_x[it]; q < indptr_x[it + 1]; q++) owner[(size_t)q] = (int32_t)it;
+        h2d(o->tx.get(), owner.data(), sizeof(int32_t) * (size_t)Px);
+        for (int64_t j = 0; j < n_target_y; j++) o->max_cy = std::max(o->max_cy, indptr_y[j + 1] - indptr_y[j]);
+        for (int64_t i = 0; i < n_target_x; i++) o->max_cx = std::max(o->max_cx, indptr_x[i + 1] - indptr_x[i]);
+        stream_sync();
+    } catch (...) {
+        delete o;
+        throw;
+    }
+    return o;
+}
+
+// the CSR of the outer product, assembled on the device (closed-form offsets: no sort, no scan)
+static xr_csr *outer_materialise(const xr_outer *o) {
+    const int64_t lim = ((int64_t)1 << 31) - 1;
+    XR_REQUIRE(o->Py == 0 || o->Px < lim / o->Py, XR_ERR_LIMIT, "separable weights: %lld x %lld entries exceed the int32 range",
+               (long long)o->Py, (long long)o->Px);
+    const int64_t n = o->nty * o->ntx, m = o->nsy * o->nsx, nnz = o->Py * o->Px;
+    xr_csr *csr = new xr_csr();
+    try {
+        csr->n = n; csr->m = m; csr->nnz = nnz;
+        csr->indptr.alloc((size_t)n + 1);
+        csr->indices.alloc((size_t)nnz);
+        csr->data.alloc((size_t)nnz);
+        csr->long_rows.alloc((size_t)(nnz / XR_APPLY_LONG_ROW + 1));
+        csr->n_long.alloc(1);
+        XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), engine().stream));
+        XR_LAUNCH("outer_indptr", k_outer_indptr, dim3(div_up(n + 1, 256)), dim3(256), 0, o->ipy.get(), o->ipx.get(), o->nty,
+                  o->ntx, o->Px, nnz, csr->indptr.get(), csr->long_rows.get(), csr->n_long.get());
+        if (nnz > 0) {
+            const int64_t gx = std::min<int64_t>(div_up(o->max_cy * o->Px, 256), 1 << 16);
+            const int64_t gy = std::min<int64_t>(o->nty, 32768);
+            XR_LAUNCH("outer_fill", k_outer_fill, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, o->ipy.get(), o->sy.get(),
+                      o->wy.get(), o->ipx.get(), o->sx.get(), o->wx.get(), o->tx.get(), o->nty, o->nsx, o->Px,
+                      csr->indices.get(), csr->data.get());
+        }
+        const int32_t nl = read_scalar(csr->n_long.get());
+        csr->has_long = nl > 0;
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    return csr;
+}
+
+// x-lists of at most 4 entries (similar resolutions, refinement, any coarsening along y only): matrix-free.  Longer
+// x-lists make neighbouring lanes gather columns that lie a whole list apart; there the stored product with its
+// cooperative long-row kernels is the faster engine (and the only one for mode / percentiles, which need a row's
+// values side by side).  Products too large to store (>= 2^31 entries) stay matrix-free.
+static bool outer_matrix_free(const xr_outer *o, int method) {
+    const char *force = getenv("XR_OUTER_APPLY"); // test hook: "free" | "csr"
+    const bool reducible = method != XR_MODE && method != XR_PERCENTILE;
+    const bool fits = o->Py == 0 || o->Px < (((int64_t)1 << 31) - 1) / o->Py;
+    if (!reducible) return false;
+    if (!fits) return true;
+    if (force && !strcmp(force, "free")) return true;
+    if (force && !strcmp(force, "csr")) return false;
+    return o->max_cx <= 4;
+}
+
+template <typename SRC>
+static void apply_outer_dispatch(xr_outer *o, int method, double p, const SRC *src, int64_t K, double *out) {
+    if (!outer_matrix_free(o, method)) {
+        if (!o->csr) o->csr = outer_materialise(o);
+        apply_dispatch<SRC>(o->csr, method, p, src, K, out);
+        return;
+    }
+    switch (method) {
+    case XR_MEAN: launch_outer<XR_MEAN, SRC>(o, src, K, out); break;
+    case XR_HARMONIC_MEAN: launch_outer<XR_HARMONIC_MEAN, SRC>(o, src, K, out); break;
+    case XR_GEOMETRIC_MEAN: launch_outer<XR_GEOMETRIC_MEAN, SRC>(o, src, K, out); break;
+    case XR_SUM: launch_outer<XR_SUM, SRC>(o, src, K, out); break;
+    case XR_MINIMUM: launch_outer<XR_MINIMUM, SRC>(o, src, K, out); break;
+    case XR_MAXIMUM: launch_outer<XR_MAXIMUM, SRC>(o, src, K, out); break;
+    case XR_FIRST_ORDER_CONSERVATIVE: launch_outer<XR_FIRST_ORDER_CONSERVATIVE, SRC>(o, src, K, out); break;
+    case XR_MAX_OVERLAP: launch_outer<XR_MAX_OVERLAP, SRC>(o, src, K, out); break;
+    case XR_SELECT: launch_outer<XR_SELECT, SRC>(o, src, K, out); break;
+    default: XR_REQUIRE(false, XR_ERR_INVALID, "unknown reducer id %d", method);
+    }
+}
+
+static void apply_outer_dev(xr_outer *o, int method, double p, const void *src, int dtype, int64_t K, double *out) {
+    XR_REQUIRE(dtype == XR_F64 || dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", dtype);
+    XR_REQUIRE(method >= 0 && method <= XR_SELECT, XR_ERR_INVALID, "unknown reducer id %d", method);
+    if (dtype == XR_F64) apply_outer_dispatch<double>(o, method, p, static_cast<const double *>(src), K, out);
+    else apply_outer_dispatch<float>(o, method, p, static_cast<const float *>(src), K, out);
+}
+
 
 extern "C" {
 
@@ -1676,80 +1920,94 @@ int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *da
     XR_API_END
 }
 
-static void check_axis(const char *name, const int64_t *indptr, const int64_t *source, const double *weight,
-                       int64_t n_target, int64_t n_source) {
-    XR_REQUIRE(indptr, XR_ERR_INVALID, "xr_csr_from_outer: NULL indptr (%s axis)", name);
-    XR_REQUIRE(n_target >= 0 && n_source >= 0, XR_ERR_INVALID, "xr_csr_from_outer: negative size (%s axis)", name);
-    XR_REQUIRE(indptr[0] == 0, XR_ERR_INVALID, "xr_csr_from_outer: indptr[0] != 0 (%s axis)", name);
-    for (int64_t i = 0; i < n_target; i++)
-        XR_REQUIRE(indptr[i + 1] >= indptr[i], XR_ERR_INVALID, "xr_csr_from_outer: indptr decreases at %lld (%s axis)",
-                   (long long)i, name);
-    const int64_t nnz = indptr[n_target];
-    XR_REQUIRE(nnz == 0 || (source && weight), XR_ERR_INVALID, "xr_csr_from_outer: NULL entries (%s axis)", name);
-    for (int64_t i = 0; i < nnz; i++)
-        XR_REQUIRE(source[i] >= 0 && source[i] < n_source, XR_ERR_INVALID,
-                   "xr_csr_from_outer: source index %lld outside [0,%lld) (%s axis)", (long long)source[i],
-                   (long long)n_source, name);
-}
-
 int xr_csr_from_outer(const int64_t *indptr_y, const int64_t *source_y, const double *weight_y, int64_t n_target_y,
                       int64_t n_source_y, const int64_t *indptr_x, const int64_t *source_x, const double *weight_x,
                       int64_t n_target_x, int64_t n_source_x, xr_csr **out) {
     XR_API_BEGIN
     XR_REQUIRE(out, XR_ERR_INVALID, "xr_csr_from_outer: NULL argument");
-    check_axis("y", indptr_y, source_y, weight_y, n_target_y, n_source_y);
-    check_axis("x", indptr_x, source_x, weight_x, n_target_x, n_source_x);
-    const int64_t Py = indptr_y[n_target_y], Px = indptr_x[n_target_x];
-    const int64_t lim = ((int64_t)1 << 31) - 1;
-    XR_REQUIRE(n_target_y == 0 || n_target_x < lim / n_target_y, XR_ERR_LIMIT,
-               "xr_csr_from_outer: target grid exceeds the int32 index range");
-    XR_REQUIRE(n_source_y == 0 || n_source_x <= lim / n_source_y, XR_ERR_LIMIT,
-               "xr_csr_from_outer: source grid exceeds the int32 index range");
-    XR_REQUIRE(Py == 0 || Px < lim / Py, XR_ERR_LIMIT, "xr_csr_from_outer: %lld x %lld entries exceed the int32 range",
-               (long long)Py, (long long)Px);
-    const int64_t n = n_target_y * n_target_x, m = n_source_y * n_source_x, nnz = Py * Px;
-    xr_csr *csr = new xr_csr();
+    xr_outer *o = outer_create(indptr_y, source_y, weight_y, n_target_y, n_source_y, indptr_x, source_x, weight_x,
+                               n_target_x, n_source_x);
+    xr_csr *csr = nullptr;
     try {
-        csr->n = n; csr->m = m; csr->nnz = nnz;
-        csr->indptr.alloc((size_t)n + 1);
-        csr->indices.alloc((size_t)nnz);
-        csr->data.alloc((size_t)nnz);
-        DevBuf<int32_t> ipy((size_t)n_target_y + 1), ipx((size_t)n_target_x + 1), sy((size_t)Py), sx((size_t)Px),
-            tx((size_t)Px);
-        DevBuf<double> wy((size_t)Py), wx((size_t)Px);
-        upload_narrow(indptr_y, n_target_y + 1, ipy.get());
-        upload_narrow(indptr_x, n_target_x + 1, ipx.get());
-        upload_narrow(source_y, Py, sy.get());
-        upload_narrow(source_x, Px, sx.get());
-        h2d(wy.get(), weight_y, sizeof(double) * (size_t)Py);
-        h2d(wx.get(), weight_x, sizeof(double) * (size_t)Px);
-        std::vector<int32_t> owner((size_t)Px);
-        for (int64_t it = 0; it < n_target_x; it++)
-            for (int64_t q = indptr_x[it]; q < indptr_x[it + 1]; q++) owner[(size_t)q] = (int32_t)it;
-        h2d(tx.get(), owner.data(), sizeof(int32_t) * (size_t)Px);
-        csr->long_rows.alloc((size_t)(nnz / XR_APPLY_LONG_ROW + 1));
-        csr->n_long.alloc(1);
-        XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), engine().stream));
-        XR_LAUNCH("outer_indptr", k_outer_indptr, dim3(div_up(n + 1, 256)), dim3(256), 0, ipy.get(), ipx.get(), n_target_y,
-                  n_target_x, Px, nnz, csr->indptr.get(), csr->long_rows.get(), csr->n_long.get());
-        if (nnz > 0) {
-            int64_t max_cy = 0;
-            for (int64_t j = 0; j < n_target_y; j++) max_cy = std::max(max_cy, indptr_y[j + 1] - indptr_y[j]);
-            const int64_t gx = std::min<int64_t>(div_up(max_cy * Px, 256), 1 << 16);
-            const int64_t gy = std::min<int64_t>(n_target_y, 32768);
-            XR_LAUNCH("outer_fill", k_outer_fill, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, ipy.get(), sy.get(),
-                      wy.get(), ipx.get(), sx.get(), wx.get(), tx.get(), n_target_y, n_source_x, Px, csr->indices.get(),
-                      csr->data.get());
-        }
-        int32_t nl = 0;
-        XR_HIP(hipMemcpyAsync(&nl, csr->n_long.get(), sizeof(int32_t), hipMemcpyDeviceToHost, engine().stream));
-        stream_sync();
-        csr->has_long = nl > 0;
+        csr = outer_materialise(o);
     } catch (...) {
-        delete csr;
+        delete o;
         throw;
     }
+    delete o;
     *out = csr;
+    XR_API_END
+}
+
+int xr_outer_create(const int64_t *indptr_y, const int64_t *source_y, const double *weight_y, int64_t n_target_y,
+                    int64_t n_source_y, const int64_t *indptr_x, const int64_t *source_x, const double *weight_x,
+                    int64_t n_target_x, int64_t n_source_x, xr_outer **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out, XR_ERR_INVALID, "xr_outer_create: NULL argument");
+    *out = outer_create(indptr_y, source_y, weight_y, n_target_y, n_source_y, indptr_x, source_x, weight_x, n_target_x,
+                        n_source_x);
+    XR_API_END
+}
+
+int xr_outer_info(const xr_outer *o, int64_t *n, int64_t *m, int64_t *nnz) {
+    XR_API_BEGIN
+    XR_REQUIRE(o, XR_ERR_INVALID, "xr_outer_info: NULL handle");
+    if (n) *n = o->nty * o->ntx;
+    if (m) *m = o->nsy * o->nsx;
+    if (nnz) *nnz = o->Py * o->Px;
+    XR_API_END
+}
+
+int xr_outer_csr(xr_outer *o, const xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(o && out, XR_ERR_INVALID, "xr_outer_csr: NULL argument");
+    if (!o->csr) o->csr = outer_materialise(o);
+    *out = o->csr;
+    XR_API_END
+}
+
+int xr_outer_destroy(xr_outer *o) {
+    XR_API_BEGIN
+    if (o) {
+        stream_sync();
+        delete o;
+    }
+    XR_API_END
+}
+
+int xr_apply_outer_dev(xr_outer *o, int method, double percentile, const void *source_dev, int source_dtype, int64_t K,
+                       double *out_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(o && (source_dev || K == 0) && (out_dev || K == 0), XR_ERR_INVALID, "xr_apply_outer_dev: NULL argument");
+    XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_outer_dev: negative K");
+    apply_outer_dev(o, method, percentile, source_dev, source_dtype, K, out_dev);
+    stream_sync();
+    XR_API_END
+}
+
+int xr_apply_outer(xr_outer *o, int method, double percentile, const void *source, int source_dtype, int64_t K, double *out) {
+    XR_API_BEGIN
+    XR_REQUIRE(o && (source || K == 0) && (out || K == 0), XR_ERR_INVALID, "xr_apply_outer: NULL argument");
+    XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_outer: negative K");
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
+               source_dtype);
+    const size_t esz = source_dtype == XR_F64 ? 8 : 4;
+    const int64_t n = o->nty * o->ntx, m = o->nsy * o->nsx;
+    const size_t per_k = (size_t)m * esz + (size_t)n * sizeof(double);
+    const char *chunk_env = getenv("XR_APPLY_CHUNK_BYTES"); // test hook
+    const size_t budget = chunk_env ? (size_t)atoll(chunk_env) : ((size_t)4 << 30);
+    int64_t kchunk = per_k > 0 ? (int64_t)(budget / per_k) : K;
+    if (kchunk < 1) kchunk = 1;
+    if (kchunk > K) kchunk = K;
+    DevBuf<char> src((size_t)kchunk * (size_t)m * esz);
+    DevBuf<double> dst((size_t)kchunk * (size_t)n);
+    for (int64_t k0 = 0; k0 < K; k0 += kchunk) {
+        const int64_t kc = (K - k0) < kchunk ? (K - k0) : kchunk;
+        h2d(src.get(), static_cast<const char *>(source) + (size_t)k0 * (size_t)m * esz, (size_t)kc * (size_t)m * esz);
+        apply_outer_dev(o, method, percentile, src.get(), source_dtype, kc, dst.get());
+        d2h(out + (size_t)k0 * (size_t)n, dst.get(), (size_t)kc * (size_t)n * sizeof(double));
+        stream_sync();
+    }
     XR_API_END
 }
 

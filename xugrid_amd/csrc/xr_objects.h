@@ -106,6 +106,19 @@ struct xr_csr {
     xr::DevBuf<uint16_t> plan_loc;   // [nnz]
 };
 
+// Separable (rectilinear) weights kept as the two per-axis sparse matrices (xugrid/regrid/structured.py:503-601): the
+// P = P_y * P_x entries of their outer product are never stored unless somebody asks for the CSR.
+struct xr_outer {
+    int64_t nty = 0, nsy = 0, ntx = 0, nsx = 0, Py = 0, Px = 0;
+    xr::DevBuf<int32_t> ipy, ipx; // [nt + 1]
+    xr::DevBuf<int32_t> sy, sx;   // [P] source index per entry (ascending within a row)
+    xr::DevBuf<double> wy, wx;    // [P]
+    xr::DevBuf<int32_t> tx;       // [Px] x-target owning each x-entry (CSR assembly)
+    int64_t max_cy = 0, max_cx = 0;
+    xr_csr *csr = nullptr;        // materialised on demand (mode / percentiles, downloads)
+    ~xr_outer() { delete csr; }
+};
+
 namespace xr {
 void mesh_prepare(xr_mesh *mesh, bool want_fxy = true);
 void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex blocks exist

@@ -292,18 +292,33 @@ def _source_2d(source):
     return np.ascontiguousarray(a), XR_F64
 
 
+def _axis_arrays(axis_y, axis_x):
+    arrays = []
+    for indptr, source, weight in (axis_y, axis_x):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        source = np.ascontiguousarray(source, dtype=np.int64)
+        weight = np.ascontiguousarray(weight, dtype=np.float64)
+        if indptr.ndim != 1 or indptr.size < 1 or source.shape != weight.shape or source.ndim != 1:
+            raise ValueError("inconsistent axis arrays")
+        if indptr[-1] != source.size:
+            raise ValueError("axis indptr does not span its entries")
+        arrays.append((indptr, source, weight))
+    return arrays
+
+
 class DeviceCSR:
     """MatrixCSR resident in HBM: rows = target faces, columns = source faces."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, owner=None):
         self._h = handle
+        self._owner = owner  # a DeviceOuter that owns the handle (borrowed view): keep it alive, never destroy
         n, m, nnz = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         check(_lib.load().xr_csr_info(handle, ctypes.byref(n), ctypes.byref(m), ctypes.byref(nnz)))
         self.n, self.m, self.nnz = n.value, m.value, nnz.value
 
     def __del__(self):
         h = getattr(self, "_h", None)
-        if h:
+        if h and getattr(self, "_owner", None) is None:
             try:
                 _lib.load().xr_csr_destroy(h)
             except Exception:
@@ -344,17 +359,7 @@ class DeviceCSR:
         CSR of the outer product of two per-axis sparse matrices, each ``(indptr, source, weight)`` with
         the source indices ascending within a row (StructuredGrid2d.broadcast_sorted, structured.py:503-531).
         """
-        arrays = []
-        for indptr, source, weight in (axis_y, axis_x):
-            indptr = np.ascontiguousarray(indptr, dtype=np.int64)
-            source = np.ascontiguousarray(source, dtype=np.int64)
-            weight = np.ascontiguousarray(weight, dtype=np.float64)
-            if indptr.ndim != 1 or indptr.size < 1 or source.shape != weight.shape or source.ndim != 1:
-                raise ValueError("inconsistent axis arrays")
-            if indptr[-1] != source.size:
-                raise ValueError("axis indptr does not span its entries")
-            arrays.append((indptr, source, weight))
-        (ipy, sy, wy), (ipx, sx, wx) = arrays
+        (ipy, sy, wy), (ipx, sx, wx) = _axis_arrays(axis_y, axis_x)
         handle = ctypes.c_void_p()
         check(
             _lib.load().xr_csr_from_outer(
@@ -414,6 +419,64 @@ class DeviceCSR:
         check(
             _lib.load().xr_apply_partial_mean_dev(
                 self._h, ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(numden_ptr)
+            )
+        )
+
+
+class DeviceOuter:
+    """Separable (rectilinear x rectilinear) weights kept as their two per-axis factors in HBM
+    (include/xugrid_amd.h: xr_outer_create).  Same interface as DeviceCSR; the product matrix is only
+    materialised for ``download`` / ``csr`` and for the mode / percentile reducers."""
+
+    def __init__(self, axis_y, n_source_y, axis_x, n_source_x):
+        (ipy, sy, wy), (ipx, sx, wx) = _axis_arrays(axis_y, axis_x)
+        handle = ctypes.c_void_p()
+        check(
+            _lib.load().xr_outer_create(
+                _ptr(ipy), _ptr(sy), _ptr(wy), ipy.size - 1, int(n_source_y),
+                _ptr(ipx), _ptr(sx), _ptr(wx), ipx.size - 1, int(n_source_x), ctypes.byref(handle),
+            )
+        )
+        self._h = handle
+        n, m, nnz = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().xr_outer_info(handle, ctypes.byref(n), ctypes.byref(m), ctypes.byref(nnz)))
+        self.n, self.m, self.nnz = n.value, m.value, nnz.value
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().xr_outer_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    def csr(self) -> "DeviceCSR":
+        """The materialised product (built once, owned by this object)."""
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_outer_csr(self._h, ctypes.byref(handle)))
+        return DeviceCSR(handle, owner=self)
+
+    def download(self):
+        return self.csr().download()
+
+    def apply(self, source, method_id=0, percentile=0.0, out=None):
+        src, dtype = _source_2d(source)
+        if src.shape[1] != self.m:
+            raise ValueError(f"source has {src.shape[1]} cells, weights expect {self.m}")
+        K = src.shape[0]
+        if out is None:
+            out = np.empty((K, self.n), dtype=np.float64)
+        elif out.shape != (K, self.n) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous float64 array of shape {(K, self.n)}")
+        check(_lib.load().xr_apply_outer(self._h, int(method_id), float(percentile), _ptr(src), dtype, K, _ptr(out)))
+        return out
+
+    def apply_dev(self, source_ptr, dtype, K, out_ptr, method_id=0, percentile=0.0):
+        check(
+            _lib.load().xr_apply_outer_dev(
+                self._h, int(method_id), float(percentile), ctypes.c_void_p(source_ptr), int(dtype), int(K),
+                ctypes.c_void_p(out_ptr),
             )
         )
 

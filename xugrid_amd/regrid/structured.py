@@ -300,9 +300,10 @@ class StructuredGrid2d:
         weights = wy[iy] * wx[ix]
         return _by_target_then_source(source_index, target_index, weights)
 
-    def _outer_device(self, other, axes) -> "engine.DeviceCSR":
+    def _outer_device(self, other, axes) -> "engine.DeviceOuter":
+        """The weights in factored form on the device: applied matrix-free, product CSR only on request."""
         (sy, ty, wy), (sx, tx, wx) = axes
-        return engine.DeviceCSR.from_outer(
+        return engine.DeviceOuter(
             _axis_csr(sy, ty, wy, other.ybounds.size), self.ybounds.size,
             _axis_csr(sx, tx, wx, other.xbounds.size), self.xbounds.size,
         )
