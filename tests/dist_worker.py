@@ -21,8 +21,8 @@ from xugrid_amd.distributed import (  # noqa: E402
 
 
 class OracleWeights:
-    def __init__(self, data, indices, indptr, n):
-        self.data, self.indices, self.indptr, self.n = data, indices, indptr, n
+    def __init__(self, data, indices, indptr, n, m=None):
+        self.data, self.indices, self.indptr, self.n, self.m = data, indices, indptr, n, m
 
 
 class OracleBackend:
@@ -31,7 +31,13 @@ class OracleBackend:
     def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces):
         q, s, a = O.CellTree2d(src_xy, src_faces).intersect_faces(tgt_xy, tgt_faces)
         T = np.asarray(tgt_faces).shape[0]
-        return OracleWeights(a, s, O.to_csr_indptr(q, T), T)
+        return OracleWeights(a, s, O.to_csr_indptr(q, T), T, np.asarray(src_faces).shape[0])
+
+    def download_weights(self, w):
+        return w.data, w.indices, w.indptr, w.n, w.m
+
+    def upload_weights(self, data, indices, indptr, n, m):
+        return OracleWeights(np.asarray(data), np.asarray(indices), np.asarray(indptr), n, m)
 
     def to_device(self, array):
         return torch.as_tensor(np.ascontiguousarray(array))
@@ -108,6 +114,14 @@ def main():
         results[mode + "_1d"] = rg.regrid(data[0])
         results[mode + "_n_local"] = rg.local_faces.size
         results[mode + "_n_local_targets"] = rg.local_targets.size
+    # sharded weights written rank by rank and read back without the meshes
+    rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition="morton")
+    rg.to_file(os.path.join(out_dir, "sharded"))
+    dist.barrier()
+    rg2 = ShardedOverlapRegridder.from_file(os.path.join(out_dir, "sharded"), OracleBackend())
+    results["morton_from_file"] = rg2.regrid(data)
+    results["morton_from_file_dense"] = ShardedOverlapRegridder.from_file(
+        os.path.join(out_dir, "sharded"), OracleBackend(), exchange="dense").regrid(data)
     results["morton_legacy"] = ShardedOverlapRegridder(sxy, sf, txy, tf, _NoFused(), partition="morton").regrid(data)
     for method in ("mode", "median", "max_overlap", "minimum", "sum", "mean"):
         tp = TargetPartitionedRegridder(sxy, sf, txy, tf, OracleBackend(), method=method)

@@ -34,6 +34,10 @@ def main():
         results["mean_" + exchange] = rg.regrid(data)
         rg.rebuild()
         results["mean_rebuilt_" + exchange] = rg.regrid(data.astype(np.float32))
+    rg.to_file(os.path.join(out_dir, "sharded"))  # (dense exchange stored; read back as sparse)
+    dist.barrier()
+    results["mean_from_file"] = ShardedOverlapRegridder.from_file(
+        os.path.join(out_dir, "sharded"), backend, exchange="sparse").regrid(data)
     for method in ("mode", "median", "max_overlap", "minimum"):
         results["tp_" + method] = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method=method).regrid(data)
     if rank == 0:

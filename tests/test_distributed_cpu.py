@@ -65,6 +65,9 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     assert int(out["hash_n_local_targets"]) > 0.95 * tf.shape[0]
     # the fused owner-side reduction and the sender-by-sender accumulation are the same additions
     assert np.array_equal(out["morton"], out["morton_legacy"], equal_nan=True)
+    # weights persisted shard by shard and reloaded without meshes: same exchange, same result
+    assert np.array_equal(out["morton"], out["morton_from_file"], equal_nan=True)
+    assert np.array_equal(out["morton_dense"], out["morton_from_file_dense"], equal_nan=True)
     # target-partitioned replicas (row-wise reducers): exactly the single-process result, no collective
     indptr = oracle.to_csr_indptr(q, tf.shape[0])
     for method in ("mode", "median", "max_overlap", "minimum", "sum", "mean"):

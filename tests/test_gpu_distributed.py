@@ -38,6 +38,7 @@ def test_sharded_and_target_partitioned_regridders_rccl(hip, oracle, tmp_path):
         np.testing.assert_allclose(out["mean_" + exchange], exp, rtol=1e-13, equal_nan=True)
         np.testing.assert_allclose(out["mean_rebuilt_" + exchange], exp32, rtol=1e-13, equal_nan=True)
     assert np.array_equal(out["mean_sparse"], out["mean_dense"], equal_nan=True)
+    assert np.array_equal(out["mean_sparse"], out["mean_from_file"], equal_nan=True)  # shard files, no meshes
     for method in ("mode", "median", "max_overlap", "minimum"):
         single = oracle.regrid_csr(method, data, a, s_, indptr, tf.shape[0])
         assert np.array_equal(out["tp_" + method], single, equal_nan=True), method

@@ -93,6 +93,14 @@ class HipBackend:
         self._tgt_mesh.invalidate()
         return self._src_mesh.overlap(self._tgt_mesh, relative=False)
 
+    def download_weights(self, weights):
+        """-> (data, indices, indptr, n, m) host arrays of this rank's shard of the weights."""
+        data, indices, indptr = weights.download()
+        return data, indices, indptr, weights.n, weights.m
+
+    def upload_weights(self, data, indices, indptr, n, m):
+        return self.engine.DeviceCSR.from_arrays(data, indices, indptr, n, m)
+
     def to_device(self, array):
         return self.torch.as_tensor(np.ascontiguousarray(array), device=self.device)
 
@@ -286,6 +294,52 @@ class ShardedOverlapRegridder:
 
     def rebuild(self):
         self.weights = self.backend.rebuild_weights()
+
+    # ---- persistence of the sharded weights: one file per rank, no gather
+    @staticmethod
+    def shard_path(prefix, rank, world):
+        return f"{prefix}.rank{rank}of{world}.npz"
+
+    def to_file(self, prefix) -> str:
+        """Every rank writes its shard -- the local CSR (rows = its touched targets, columns = its source faces)
+        under the variable names of regridder.py:264-271, plus the two global id lists that place the shard in
+        the full matrix -- to ``<prefix>.rank<r>of<W>.npz``.  No communication."""
+        data, indices, indptr, n, m = self.backend.download_weights(self.weights)
+        path = self.shard_path(prefix, self.rank, self.world)
+        np.savez(
+            path, __regrid_data=data, __regrid_indices=indices, __regrid_indptr=indptr, __regrid_n=n, __regrid_m=m,
+            __regrid_nnz=data.size, __shard_source_faces=self.local_faces, __shard_target_faces=self.local_targets,
+            __shard_rank=self.rank, __shard_world=self.world, __n_source=self.n_source, __n_target=self.n_target,
+            __shard_exchange=self.exchange,
+        )
+        return path
+
+    @classmethod
+    def from_file(cls, prefix, backend, group=None, exchange=None):
+        """Counterpart of ``Regridder.from_weights`` for sharded weights: every rank reads its own file (written
+        by a job of the SAME world size) and the exchange lists are set up again; no mesh, no weight construction."""
+        import torch.distributed as dist
+
+        self = cls.__new__(cls)
+        self.dist, self.group, self.backend = dist, group, backend
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        with np.load(cls.shard_path(prefix, self.rank, self.world)) as f:
+            if int(f["__shard_world"]) != self.world or int(f["__shard_rank"]) != self.rank:
+                raise ValueError("sharded weights were written by a job of a different shape")
+            self.exchange = exchange or str(f["__shard_exchange"])
+            self.n_source, self.n_target = int(f["__n_source"]), int(f["__n_target"])
+            self.local_faces = f["__shard_source_faces"].astype(np.int64)
+            self.local_targets = f["__shard_target_faces"].astype(np.int64)
+            n, m = int(f["__regrid_n"]), int(f["__regrid_m"])
+            if n != self.local_targets.size or m != self.local_faces.size:
+                raise ValueError("shard id lists do not match the stored matrix")
+            self.weights = backend.upload_weights(f["__regrid_data"], f["__regrid_indices"], f["__regrid_indptr"], n, m)
+        if self.exchange not in ("sparse", "dense"):
+            raise ValueError(f"unknown exchange mode {self.exchange!r}")
+        self.t_chunk = -(-self.n_target // self.world)
+        self._local_targets_dev = backend.to_device(self.local_targets)
+        self._setup_sparse_exchange()
+        return self
 
     def local_source(self, data):
         """(K, S) global source data -> this rank's (K, S_local) columns, on the device."""
