@@ -220,6 +220,17 @@ int xr_outer_info(const xr_outer *outer, int64_t *n, int64_t *m, int64_t *nnz);
 /* borrowed handle of the materialised product (owned by `outer`; do not destroy) */
 int xr_outer_csr(xr_outer *outer, const xr_csr **out);
 int xr_outer_destroy(xr_outer *outer);
+/* NetworkGridder weights (xugrid/regrid/gridder.py:66-73 through UnstructuredGrid2d.intersection_length,
+ * xugrid/regrid/unstructured.py:203-215): replaces numba_celltree's
+ *     celltree.intersect_edges(edge_coords) -> (edge_index, face_index, intersections[n, 2, 2]),
+ * the length = norm(diff(intersections)) that follows, the argsort by face and MatrixCSR.from_triplet.
+ * edge_xy: (n_edge, 2, 2) float64 end-point coordinates (Ugrid1d.edge_node_coordinates).  Result: rows = faces of
+ * `tree`, columns = edge ids (ascending within a row), data = length of the piece of the edge inside the face
+ * (Cyrus-Beck clip against the convex, CCW-normalised face); only pieces of positive length are entries, so an
+ * edge that merely touches a face corner or runs outside along its boundary adds nothing.  Applied with
+ * xr_apply_csr like any other weights (source variables live on the EDGES).  `relative` lengths are not offered:
+ * the reference never requests them (gridder.py:49) and its formula indexes the edge lengths by face id (:213-214). */
+int xr_edge_length_csr(xr_mesh *tree, const double *edge_xy, int64_t n_edge, xr_csr **out);
 /* Optional locality hint for matrices that were uploaded (xr_csr_upload / xr_csr_from_triplet, i.e. the
  * from_weights path): one small integer per row such that rows with equal keys are spatial neighbours (e.g. the
  * Morton code of a coarse cell holding the target face's centroid).  With many source variables (K >= 8) the apply

@@ -99,6 +99,8 @@ def lib():
             ctypes.c_void_p, _f64p, ctypes.c_int64, _i64p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
             ctypes.c_int64, _i64p, _i64p, _f64p, _i64p,
         ]
+        L.xo_intersect_edges_count.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int64, _i64p]
+        L.xo_intersect_edges_fill.argtypes = [ctypes.c_void_p, _i64p, _i64p, _f64p]
         L.xo_locate_points.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int64, ctypes.c_double, _i64p]
         L.xo_barycentric.argtypes = [ctypes.c_void_p, _f64p, ctypes.c_int64, ctypes.c_double, _i64p, _f64p]
         L.xo_num_threads.restype = ctypes.c_int
@@ -252,6 +254,20 @@ class CellTree2d:
         assert rc == 0, rc
         n = nnz.value
         return q[:n].copy(), s[:n].copy(), a[:n].copy()
+
+    def intersect_edges(self, edge_coords):
+        """numba_celltree CellTree2d.intersect_edges: (n_edge, 2, 2) -> (edge_index, face_index, intersections
+        (n, 2, 2)), ordered by (edge, face).  Called from xugrid/regrid/unstructured.py:203-215."""
+        xy = np.ascontiguousarray(edge_coords, dtype=np.float64)
+        assert xy.ndim == 3 and xy.shape[1:] == (2, 2)
+        n = ctypes.c_int64(0)
+        rc = lib().xo_intersect_edges_count(self._h, _p(xy, _f64p), xy.shape[0], ctypes.byref(n))
+        assert rc == 0, rc
+        e = np.empty(n.value, dtype=np.int64)
+        f = np.empty(n.value, dtype=np.int64)
+        x = np.empty((n.value, 2, 2), dtype=np.float64)
+        lib().xo_intersect_edges_fill(self._h, _p(e, _i64p), _p(f, _i64p), _p(x, _f64p))
+        return e, f, x
 
     def default_tolerance(self):
         return lib().xo_default_tolerance(self._h)

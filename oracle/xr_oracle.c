@@ -459,6 +459,10 @@ struct xo_tree {
     int64_t res_n;
     int64_t *res_q, *res_t;
     double *res_a;
+    /* last intersect_edges result */
+    int64_t edg_n;
+    int64_t *edg_e, *edg_f;
+    double *edg_xy; /* edg_n x 2 x 2 */
 };
 
 /* polygon_length: a minimal polygon is a triangle; stops at the first fill value */
@@ -674,6 +678,7 @@ void xo_tree_destroy(xo_tree *t) {
     if (!t) return;
     free(t->xy); free(t->faces); free(t->len); free(t->bb); free(t->bb_indices); free(t->nodes);
     free(t->res_q); free(t->res_t); free(t->res_a);
+    free(t->edg_e); free(t->edg_f); free(t->edg_xy);
     free(t);
 }
 
@@ -685,7 +690,16 @@ int xo_tree_faces(const xo_tree *t, int64_t *out) {
 }
 
 /* locate_boxes for one query box: explicit-stack traversal; emits tree face ids. */
+static inline int boxes_touch(Box a, Box b) { /* closed boxes: a segment's box may have zero width */
+    return a.xmin <= b.xmax && b.xmin <= a.xmax && a.ymin <= b.ymax && b.ymin <= a.ymax;
+}
+
+static int64_t tree_query_box_ex(const xo_tree *t, Box q, int64_t *out, int closed);
 static int64_t tree_query_box(const xo_tree *t, Box q, int64_t *out /* may be NULL: count only */) {
+    return tree_query_box_ex(t, q, out, 0);
+}
+
+static int64_t tree_query_box_ex(const xo_tree *t, Box q, int64_t *out, int closed) {
     int64_t stack[128];
     int sp = 0;
     int64_t cnt = 0;
@@ -696,7 +710,7 @@ static int64_t tree_query_box(const xo_tree *t, Box q, int64_t *out /* may be NU
         if (nd->child == -1) {
             for (int64_t i = nd->ptr; i < nd->ptr + nd->size; i++) {
                 int64_t f = t->bb_indices[i];
-                if (boxes_intersect(q, t->bb[f])) {
+                if (closed ? boxes_touch(q, t->bb[f]) : boxes_intersect(q, t->bb[f])) {
                     if (out) out[cnt] = f;
                     cnt++;
                 }
@@ -977,6 +991,113 @@ double xo_default_tolerance(const xo_tree *t) {
  * projection falls on the segment (0 <= t <= 1).  Pinned by tests/test_ugrid2d.py:724-730 (a point
  * 0.01 outside is found with tolerance 0.011) and :771-791 (a point 0.01 beyond a corner along
  * the edge direction, or exactly tol away, is NOT found with tolerance 0.01). */
+/* ---- CellTree2d.intersect_edges(edge_coords) -- called from UnstructuredGrid2d.intersection_length,
+ * xugrid/regrid/unstructured.py:203-215 (NetworkGridder weights, regrid/gridder.py:66-73).
+ * numba_celltree restatement: Cyrus-Beck parametric clip of the segment a + t (b - a), t in [0, 1], against the
+ * half-planes of a CONVEX, CCW polygon.  For the polygon edge v0 -> v1 with inward normal n = (-(v1-v0).y, (v1-v0).x):
+ * inside iff n.(a + t s - v0) >= 0, i.e. t den >= num with den = n.s, num = n.(v0 - a); den > 0 raises t0,
+ * den < 0 lowers t1, den == 0 (parallel) rejects iff num > 0 (strictly outside).  A pair is an intersection iff
+ * t0 < t1 and the clipped piece has positive length: touching a corner or an edge from outside gives none
+ * (pinned by tests/test_regrid/test_network_gridder.py: 8 pairs, 11 empty cells, the listed cell means). */
+static int cyrus_beck_clip(const P2 *poly, int n, P2 a, P2 b, P2 *c, P2 *d) {
+    double sx = b.x - a.x, sy = b.y - a.y;
+    double t0 = 0.0, t1 = 1.0;
+    for (int i = 0; i < n; i++) {
+        P2 v0 = poly[i], v1 = poly[(i + 1 < n) ? i + 1 : 0];
+        double wx = v1.x - v0.x, wy = v1.y - v0.y;
+        if (wx == 0.0 && wy == 0.0) continue;
+        double nx = -wy, ny = wx;
+        double den = nx * sx + ny * sy;
+        double num = nx * (v0.x - a.x) + ny * (v0.y - a.y);
+        if (den == 0.0) {
+            if (num > 0.0) return 0;
+            continue;
+        }
+        double t = num / den;
+        if (den > 0.0) {
+            if (t > t0) t0 = t;
+        } else {
+            if (t < t1) t1 = t;
+        }
+    }
+    if (!(t0 < t1)) return 0;
+    c->x = a.x + t0 * sx;
+    c->y = a.y + t0 * sy;
+    d->x = a.x + t1 * sx;
+    d->y = a.y + t1 * sy;
+    return 1;
+}
+
+/* length of an intersection as the reference computes it: norm(diff(intersections)), unstructured.py:212 */
+static double piece_length(P2 c, P2 d) {
+    double ex = d.x - c.x, ey = d.y - c.y;
+    return sqrt(ex * ex + ey * ey);
+}
+
+/* edge_xy: (n_edge, 2, 2).  Result ordered by (edge, face); stored in the tree until _fill copies it out. */
+int xo_intersect_edges_count(xo_tree *t, const double *edge_xy, int64_t n_edge, int64_t *n_found) {
+    if (t->m > XO_MAXV / 2) return -2;
+    int64_t *off = (int64_t *)calloc((size_t)n_edge + 1, sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t e = 0; e < n_edge; e++) {
+        const double *p = edge_xy + 4 * e;
+        if (p[0] != p[0] || p[1] != p[1] || p[2] != p[2] || p[3] != p[3]) continue; /* NaN */
+        Box q = {fmin(p[0], p[2]), fmax(p[0], p[2]), fmin(p[1], p[3]), fmax(p[1], p[3])};
+        off[e + 1] = tree_query_box_ex(t, q, NULL, 1);
+    }
+    for (int64_t e = 0; e < n_edge; e++) off[e + 1] += off[e];
+    int64_t C = off[n_edge];
+    int64_t *cf = (int64_t *)malloc(sizeof(int64_t) * (size_t)(C > 0 ? C : 1));
+    double *cxy = (double *)malloc(sizeof(double) * 4 * (size_t)(C > 0 ? C : 1));
+    char *keep = (char *)calloc((size_t)(C > 0 ? C : 1), 1);
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t e = 0; e < n_edge; e++) {
+        if (off[e + 1] == off[e]) continue;
+        const double *p = edge_xy + 4 * e;
+        Box q = {fmin(p[0], p[2]), fmax(p[0], p[2]), fmin(p[1], p[3]), fmax(p[1], p[3])};
+        int64_t n = tree_query_box_ex(t, q, cf + off[e], 1);
+        isort64(cf + off[e], n);
+        P2 a = {p[0], p[1]}, b = {p[2], p[3]};
+        for (int64_t j = 0; j < n; j++) {
+            int64_t f = cf[off[e] + j];
+            P2 poly[XO_MAXV / 2], c, d;
+            int np = load_poly(t->xy, t->faces + f * t->m, t->len[f], poly);
+            if (cyrus_beck_clip(poly, np, a, b, &c, &d) && piece_length(c, d) > 0.0) {
+                double *o = cxy + 4 * (off[e] + j);
+                o[0] = c.x; o[1] = c.y; o[2] = d.x; o[3] = d.y;
+                keep[off[e] + j] = 1;
+            }
+        }
+    }
+    int64_t P = 0;
+    for (int64_t c = 0; c < C; c++) P += keep[c];
+    free(t->edg_e); free(t->edg_f); free(t->edg_xy);
+    t->edg_n = P;
+    t->edg_e = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P > 0 ? P : 1));
+    t->edg_f = (int64_t *)malloc(sizeof(int64_t) * (size_t)(P > 0 ? P : 1));
+    t->edg_xy = (double *)malloc(sizeof(double) * 4 * (size_t)(P > 0 ? P : 1));
+    int64_t k = 0;
+    for (int64_t e = 0; e < n_edge; e++) {
+        for (int64_t c = off[e]; c < off[e + 1]; c++) {
+            if (!keep[c]) continue;
+            t->edg_e[k] = e;
+            t->edg_f[k] = cf[c];
+            memcpy(t->edg_xy + 4 * k, cxy + 4 * c, sizeof(double) * 4);
+            k++;
+        }
+    }
+    free(off); free(cf); free(cxy); free(keep);
+    *n_found = P;
+    return 0;
+}
+
+int xo_intersect_edges_fill(xo_tree *t, int64_t *edge_idx, int64_t *face_idx, double *intersections) {
+    memcpy(edge_idx, t->edg_e, sizeof(int64_t) * (size_t)t->edg_n);
+    memcpy(face_idx, t->edg_f, sizeof(int64_t) * (size_t)t->edg_n);
+    memcpy(intersections, t->edg_xy, sizeof(double) * 4 * (size_t)t->edg_n);
+    return 0;
+}
+
 static int point_in_poly_or_on_edge(P2 p, const P2 *poly, int n, double tol) {
     int c = 0;
     P2 v0 = poly[n - 1];

@@ -76,6 +76,12 @@ int64_t xo_tree_n_face(const xo_tree *t);
 /* copy of the CCW-normalised connectivity (n_face x m) */
 int xo_tree_faces(const xo_tree *t, int64_t *faces_out);
 
+/* CellTree2d.intersect_edges(edge_coords (n_edge, 2, 2)) -> (edge_index, face_index, intersections (n, 2, 2)),
+ * unstructured.py:203-215: Cyrus-Beck clip of every edge against the convex faces its box reaches; pairs with a
+ * positive-length piece only, ordered by (edge, face).  Two-phase like intersect_faces. */
+int xo_intersect_edges_count(xo_tree *t, const double *edge_xy, int64_t n_edge, int64_t *n_found);
+int xo_intersect_edges_fill(xo_tree *t, int64_t *edge_idx, int64_t *face_idx, double *intersections);
+
 /* CellTree2d.intersect_faces(vertices, faces, fill_value), unstructured.py:124-132.
  * Two-phase: _count runs the whole search+clip and stores the result in the tree,
  * _fill copies it out.  Output is ordered by (query face, tree face).

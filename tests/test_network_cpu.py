@@ -1,0 +1,91 @@
+"""CPU (-m "not gpu"): the oracle's restatement of CellTree2d.intersect_edges (numba_celltree, absent: parity
+unpinned) against the reference's own known answers and size-independent properties; host classes of the
+NetworkGridder path."""
+import numpy as np
+import pytest
+
+from network_cases import csr_from_pairs, random_network, raster_quads, reference_case
+
+
+def test_reference_known_answer(oracle):
+    """tests/test_regrid/test_network_gridder.py:77-105: 8 pairs, 11 of 16 cells empty, the five listed means."""
+    raster, node_xy, edge_nodes, data, (x_loc, y_loc, expected) = reference_case()
+    nodes, faces = raster_quads(np.arange(5.0), np.arange(5.0))  # row j = y in [j, j + 1]
+    tree = oracle.CellTree2d(nodes, faces)
+    e, f, xy = tree.intersect_edges(node_xy[edge_nodes])
+    assert e.size == 8
+    assert np.array_equal(e, [0, 0, 1, 1, 2, 2, 3, 3]) and np.array_equal(f, [0, 5, 5, 6, 3, 6, 6, 11])
+    w, cols, indptr = csr_from_pairs(e, f, xy, 16)
+    out = oracle.regrid_csr("mean", data[None, :], w, cols, indptr, 16)[0]
+    assert np.isnan(out).sum() == 11
+    cells = (np.floor(y_loc).astype(int)) * 4 + np.floor(x_loc).astype(int)
+    np.testing.assert_allclose(out[cells], expected)
+    # transient data: twice the values -> twice the means (:107-131)
+    out2 = oracle.regrid_csr("mean", np.stack([data, 2 * data]), w, cols, indptr, 16)
+    np.testing.assert_allclose(out2[1, cells], 2 * expected)
+
+
+def test_pieces_tile_the_edge(oracle):
+    """Inside a convex mesh the pieces of an edge tile it: lengths add up to the edge length, every piece lies on
+    the edge, and no (edge, face) pair is reported twice."""
+    from xugrid_amd import meshgen
+
+    rng = np.random.default_rng(3)
+    for nodes, faces in (meshgen.triangle_mesh(900, 1), raster_quads(np.linspace(0, 1, 23), np.linspace(0, 1, 31))):
+        tree = oracle.CellTree2d(nodes, faces)
+        lo, hi = nodes.min(), nodes.max()
+        edges = random_network(rng, 400, lo + 0.3 * (hi - lo), lo + 0.7 * (hi - lo), 0.05 * (hi - lo))
+        inside = ((edges >= lo + 0.02 * (hi - lo)) & (edges <= hi - 0.02 * (hi - lo))).all(axis=(1, 2))
+        e, f, xy = tree.intersect_edges(edges)
+        assert np.unique(np.column_stack([e, f]), axis=0).shape[0] == e.size
+        d = np.diff(xy, axis=1)[:, 0, :]
+        length = np.hypot(d[:, 0], d[:, 1])
+        assert (length > 0).all()
+        total = np.bincount(e, weights=length, minlength=edges.shape[0])
+        full = np.hypot(*(edges[:, 1] - edges[:, 0]).T)
+        np.testing.assert_allclose(total[inside], full[inside], rtol=1e-9)
+        # every piece end lies on its edge: cross product with the edge direction vanishes
+        s = (edges[:, 1] - edges[:, 0])[e]
+        for k in (0, 1):
+            r = xy[:, k, :] - edges[e, 0]
+            assert np.abs(s[:, 0] * r[:, 1] - s[:, 1] * r[:, 0]).max() < 1e-12 * (hi - lo) ** 2
+
+
+def test_degenerate_edges(oracle):
+    nodes, faces = raster_quads(np.arange(4.0), np.arange(4.0))
+    tree = oracle.CellTree2d(nodes, faces)
+    edges = np.array([
+        [[0.5, 0.5], [0.5, 0.5]],      # zero length inside a cell: no piece of positive length
+        [[-2.0, -2.0], [-1.0, -1.0]],  # outside
+        [[1.0, 0.0], [1.0, 3.0]],      # along the shared boundary x = 1: both neighbours hold it
+        [[0.0, 3.0], [3.0, 0.0]],      # anti-diagonal through cell corners: corner touches are dropped
+        [[np.nan, 0.0], [1.0, 1.0]],   # NaN coordinate
+    ])
+    e, f, xy = tree.intersect_edges(edges)
+    assert not np.isin(e, [0, 1, 4]).any()
+    assert sorted(f[e == 2]) == [0, 1, 3, 4, 6, 7]
+    assert sorted(f[e == 3]) == [2, 4, 6]
+
+
+def test_ugrid1d_and_network1d():
+    import xugrid_amd as xa
+    from xugrid_amd.regrid.network import Network1d
+
+    _, node_xy, edge_nodes, _, _ = reference_case()
+    grid = xa.Ugrid1d(*node_xy.T, -1, edge_nodes)
+    assert (grid.n_node, grid.n_edge) == (5, 4)
+    assert grid.edge_node_coordinates.shape == (4, 2, 2)
+    np.testing.assert_allclose(grid.edge_length, [1.5 * np.sqrt(2), 1.0, 1.5 * np.sqrt(2), 1.5 * np.sqrt(2)])
+    one_based = xa.Ugrid1d(*node_xy.T, -1, edge_nodes + 1, start_index=1)
+    assert one_based == grid
+    net = Network1d(grid)
+    assert (net.ndim, net.shape, net.size, net.dims) == (1, (4,), 4, (grid.edge_dimension,))
+    assert np.array_equal(net.length, grid.edge_length)
+    again = xa.Ugrid1d.from_dataset(net.to_dataset("__source"), "__source")
+    assert again == grid
+    with pytest.raises(TypeError):
+        Network1d(np.zeros(3))
+    with pytest.raises(ValueError):
+        xa.Ugrid1d(*node_xy.T, -1, np.array([[0, 7]]))
+    with pytest.raises(ValueError):
+        xa.Ugrid1d(*node_xy.T, -1, np.array([0, 1, 2]))

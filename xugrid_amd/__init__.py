@@ -12,11 +12,13 @@ from .celltree import CellTree2d  # noqa: F401
 from .regrid import (  # noqa: F401
     BarycentricInterpolator,
     CentroidLocatorRegridder,
+    NetworkGridder,
     OverlapRegridder,
     Raster,
     RelativeOverlapRegridder,
 )
 from .sparse import MatrixCOO, MatrixCSR  # noqa: F401
+from .ugrid1d import Ugrid1d  # noqa: F401
 from .ugrid2d import Ugrid2d  # noqa: F401
 
 __version__ = "0.1.0"

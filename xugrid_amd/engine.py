@@ -233,6 +233,17 @@ def morton_row_keys(xy, faces_per_tile=144):
     return spread(cell[:, 0]) | (spread(cell[:, 1]) << 1), 1 << (2 * bits)
 
 
+def edge_length_csr(tree: DeviceMesh, edge_node_coordinates) -> "DeviceCSR":
+    """NetworkGridder weights: (n_edge, 2, 2) end points -> CSR rows = faces of ``tree``, columns = edges, data =
+    length of the edge inside the face (include/xugrid_amd.h: xr_edge_length_csr)."""
+    xy = np.ascontiguousarray(edge_node_coordinates, dtype=np.float64)
+    if xy.ndim != 3 or xy.shape[1:] != (2, 2):
+        raise ValueError("edge_node_coordinates must have shape (n_edge, 2, 2)")
+    handle = ctypes.c_void_p()
+    check(_lib.load().xr_edge_length_csr(tree._h, _ptr(xy), xy.shape[0], ctypes.byref(handle)))
+    return DeviceCSR(handle)
+
+
 def locate_csr(tree: DeviceMesh, query: DeviceMesh = None, points=None, tolerance=None) -> "DeviceCSR":
     """locate_centroids + MatrixCOO.from_triplet on the device: one (face, 1.0) entry per located point."""
     tol = -1.0 if tolerance is None else float(tolerance)

@@ -150,6 +150,23 @@ class UnstructuredGrid2d:
         order = np.argsort(target_index, kind="stable")
         return source_index[order], target_index[order], weights[order]
 
+    def intersection_length_device(self, other, relative: bool = False):
+        """unstructured.py:203-215 as a device CSR: rows = faces of this grid, columns = edges of the network
+        ``other`` (ascending within a row), data = length of the edge inside the face."""
+        if relative:
+            # (the reference divides by other.length[face index], :213-214, and never asks for it, gridder.py:49)
+            raise NotImplementedError("relative intersection lengths are not used by NetworkGridder")
+        from .. import engine
+
+        return engine.edge_length_csr(self.ugrid_topology.device_mesh, other.ugrid_topology.edge_node_coordinates)
+
+    def intersection_length(self, other, relative: bool = False):
+        """-> (source_index [edge ids], target_index [face ids, non-decreasing], length); host triplets."""
+        csr = self.intersection_length_device(other, relative)
+        data, indices, indptr = csr.download()
+        target_index = np.repeat(np.arange(csr.n, dtype=IntDType), np.diff(indptr))
+        return indices, target_index, data
+
     def to_dataset(self, name: str):
         ds = self.ugrid_topology.to_dataset(name)
         ds[name + "_type"] = "UnstructuredGrid2d"
