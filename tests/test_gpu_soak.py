@@ -24,3 +24,9 @@ def test_soak_device_pipelines(hip):
     import soak_pipelines
 
     assert soak_pipelines.run(11, 150) == 0
+
+
+def test_soak_network_and_factored_apply(hip, oracle):
+    import soak_network
+
+    assert soak_network.run(11, 60) == 0
