@@ -6,17 +6,20 @@
 //   length = norm(diff(intersections))                                                  (:212)
 // that follows it, its argsort by face (:211) and MatrixCSR.from_triplet (xugrid/regrid/gridder.py:66-73).
 //
-// Per edge the hierarchical grid of the mesh is walked over the edge's bounding box (long edges: only the cells
-// their segment can reach, one block per edge); every candidate face is clipped with the Cyrus-Beck parametric
+// Per edge the hierarchical grid of the mesh is walked over the edge's bounding box (long edges: one block per
+// edge, walking the cells along the segment); every candidate face is clipped with the Cyrus-Beck parametric
 // line clip against its CCW-normalised (convex) polygon.  A pair is kept iff the clipped parameter interval has
 // t0 < t1 -- touching a corner or an edge from outside yields no entry (tests/test_regrid/test_network_gridder.py:
 // nnz == 8 for the four-edge network on the 4 x 4 grid).  The arithmetic mirrors oracle/xr_oracle.c
 // (cyrus_beck_clip) operation for operation; rows come out ordered by edge id.
+#include <cstring>
+
 #include "xr_objects.h"
 
 namespace xr {
 
-static constexpr int EDGE_BIG_CELLS = 192; // edges whose box covers more grid cells go to the block-per-edge kernel
+static constexpr int EDGE_BIG_CELLS = 64;  // edges whose box covers more grid cells (all levels) get a wave of their own
+static constexpr int EDGE_SLOTS = 6;       // hits per edge the count pass keeps for the fill pass (slot-major side buffer)
 static constexpr int ROW_SORT_SMALL = 48;  // rows up to this length are insertion-sorted by one thread
 static constexpr int ROW_SORT_LDS = 4096;  // rows up to this length are sorted in LDS by one block
 
@@ -52,29 +55,6 @@ __device__ __forceinline__ double cyrus_beck_length(const double *__restrict__ p
     return sqrt(ex * ex + ey * ey);
 }
 
-// does the segment reach the closed box?  (slab test; conservative: used only to skip grid cells)
-__device__ __forceinline__ bool segment_reaches_box(P2 a, P2 b, double x0, double x1, double y0, double y1) {
-    double t0 = 0.0, t1 = 1.0;
-    const double sx = b.x - a.x, sy = b.y - a.y;
-    if (sx == 0.0) {
-        if (a.x < x0 || a.x > x1) return false;
-    } else {
-        double u = (x0 - a.x) / sx, v = (x1 - a.x) / sx;
-        if (u > v) { const double w = u; u = v; v = w; }
-        t0 = fmax(t0, u);
-        t1 = fmin(t1, v);
-    }
-    if (sy == 0.0) {
-        if (a.y < y0 || a.y > y1) return false;
-    } else {
-        double u = (y0 - a.y) / sy, v = (y1 - a.y) / sy;
-        if (u > v) { const double w = u; u = v; v = w; }
-        t0 = fmax(t0, u);
-        t1 = fmin(t1, v);
-    }
-    return t0 <= t1 + 1e-9; // (slack: a cell is only ever skipped when clearly unreachable)
-}
-
 struct EdgeBox {
     P2 a, b;
     double xmin, xmax, ymin, ymax;
@@ -96,7 +76,7 @@ __device__ __forceinline__ EdgeBox load_edge(const double *__restrict__ edge_xy,
     return q;
 }
 
-// number of grid cells (all levels) the edge's box has to look at
+// number of grid cells (all levels) under the edge's box
 __device__ __forceinline__ int64_t edge_cells(const EdgeBox &q, const GridParams &g) {
     int64_t total = 0;
     for (int l = 0; l < g.n_levels; l++) {
@@ -121,30 +101,110 @@ __device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, cons
     }
 }
 
-// FILL = false: count the hits per face;  FILL = true: place (edge, length) into the rows (arbitrary order)
-template <bool FILL>
-__global__ void __launch_bounds__(256)
-k_edges(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const int32_t *__restrict__ cell_start,
-        const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m,
-        const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count, const int32_t *__restrict__ indptr,
-        int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ big_list,
-        int32_t *__restrict__ n_big) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_edge) return;
-    const EdgeBox q = load_edge(edge_xy, e, g);
-    if (!(q.xmin == q.xmin && q.ymin == q.ymin && q.xmax == q.xmax && q.ymax == q.ymax)) return; // NaN coordinates
-    if (edge_cells(q, g) > EDGE_BIG_CELLS) {
-        if (!FILL) big_list[atomicAdd(n_big, 1)] = (int32_t)e;
-        return;
+// The walk along an edge.  Per level the cells along the edge's MAJOR axis are visited; for each of them the piece
+// of the segment inside the slab of that cell's records ([origin, origin + 2 h): a record starts in its cell and is
+// shorter than h) gives the few cells of the minor axis that can hold a candidate -- O(length / h) cells per level
+// instead of the O((length / h)^2) of the edge's box.
+struct EdgeWalk {
+    bool xmajor;
+    double a_maj, s_maj, a_min, s_min, org_maj, org_min, lo_maj, hi_maj, lo_min, hi_min;
+};
+
+__device__ __forceinline__ EdgeWalk edge_walk_setup(const EdgeBox &q, const GridParams &g) {
+    EdgeWalk w;
+    const double sx = q.b.x - q.a.x, sy = q.b.y - q.a.y;
+    w.xmajor = fabs(sx) >= fabs(sy);
+    w.a_maj = w.xmajor ? q.a.x : q.a.y;
+    w.s_maj = w.xmajor ? sx : sy;
+    w.a_min = w.xmajor ? q.a.y : q.a.x;
+    w.s_min = w.xmajor ? sy : sx;
+    w.org_maj = w.xmajor ? g.x0 : g.y0;
+    w.org_min = w.xmajor ? g.y0 : g.x0;
+    w.lo_maj = w.xmajor ? q.xmin : q.ymin;
+    w.hi_maj = w.xmajor ? q.xmax : q.ymax;
+    w.lo_min = w.xmajor ? q.ymin : q.xmin;
+    w.hi_min = w.xmajor ? q.ymax : q.xmax;
+    return w;
+}
+
+// minor-axis cell range [ka, kb] of major cell cm on a level (empty: ka > kb)
+__device__ __forceinline__ void edge_minor_range(const EdgeWalk &w, int cm, double h, double inv_h, int n_maj, int n_min,
+                                                 int o0, int o1, int &ka, int &kb) {
+    const double pad = 1e-6 * h;
+    // (the first / last cell of a level also holds whatever the clamping of cell_coord put there: no bound there)
+    const double slab_lo = cm == 0 ? -INFINITY : w.org_maj + cm * h - pad;
+    const double slab_hi = cm == n_maj - 1 ? INFINITY : w.org_maj + (cm + 2) * h + pad;
+    double t0 = 0.0, t1 = 1.0;
+    ka = 1;
+    kb = 0;
+    if (w.s_maj == 0.0) {
+        if (w.a_maj < slab_lo || w.a_maj > slab_hi) return;
+    } else {
+        double u = (slab_lo - w.a_maj) / w.s_maj, v = (slab_hi - w.a_maj) / w.s_maj;
+        if (u > v) { const double x = u; u = v; v = x; }
+        t0 = fmax(t0, u);
+        t1 = fmin(t1, v);
+        if (t0 > t1) return;
     }
-    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-    auto hit = [&](int face, double len) {
-        const int k = atomicAdd(row_count + face, 1);
-        if (FILL) {
-            indices[indptr[face] + k] = (int32_t)e;
-            data[indptr[face] + k] = len;
+    const double m0 = w.a_min + t0 * w.s_min, m1 = w.a_min + t1 * w.s_min;
+    const double mlo = fmin(m0, m1) - pad, mhi = fmax(m0, m1) + pad;
+    ka = cell_coord(mlo - 2.0 * h, w.org_min, inv_h, n_min);
+    kb = cell_coord(mhi, w.org_min, inv_h, n_min);
+    if (ka < o0) ka = o0;
+    if (kb > o1) kb = o1;
+}
+
+// one thread walks the whole edge (BLOCK = false), or the 64 lanes of a wave share it (BLOCK = true)
+template <bool BLOCK, typename Hit>
+__device__ __forceinline__ void edge_walk(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
+                                          const float4 *__restrict__ rbb, const double *__restrict__ rec_fxy,
+                                          const uint8_t *__restrict__ rec_len, int m,
+                                          const int32_t *__restrict__ rec_face, Hit &&hit) {
+    constexpr int MINOR_W = 6;
+    const EdgeWalk w = edge_walk_setup(q, g);
+    for (int l = 0; l < g.n_levels; l++) {
+        const double h = level_h(g, l), inv_h = level_inv_h(g, l);
+        const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
+        const int n_maj = w.xmajor ? nx : ny, n_min = w.xmajor ? ny : nx;
+        const int c0 = cell_coord(w.lo_maj - h, w.org_maj, inv_h, n_maj), c1 = cell_coord(w.hi_maj, w.org_maj, inv_h, n_maj);
+        const int o0 = cell_coord(w.lo_min - h, w.org_min, inv_h, n_min), o1 = cell_coord(w.hi_min, w.org_min, inv_h, n_min);
+        if (BLOCK) {
+            const int64_t work = (int64_t)(c1 - c0 + 1) * MINOR_W;
+            for (int64_t c = threadIdx.x & 63; c < work; c += 64) {
+                const int cm = c0 + (int)(c / MINOR_W), k = (int)(c % MINOR_W);
+                int ka, kb;
+                edge_minor_range(w, cm, h, inv_h, n_maj, n_min, o0, o1, ka, kb);
+                for (int cn = ka + k; cn <= kb; cn += MINOR_W) {
+                    const int cx = w.xmajor ? cm : cn, cy = w.xmajor ? cn : cm;
+                    const int r0 = cell_start[base + cy * nx + cx], r1 = cell_start[base + cy * nx + cx + 1];
+                    if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, m, rec_face, hit);
+                }
+            }
+        } else {
+            for (int cm = c0; cm <= c1; cm++) {
+                int ka, kb;
+                edge_minor_range(w, cm, h, inv_h, n_maj, n_min, o0, o1, ka, kb);
+                if (ka > kb) continue;
+                if (w.xmajor) { // the minor cells of one major cell are cy = ka..kb at fixed cx: separate runs
+                    for (int cy = ka; cy <= kb; cy++) {
+                        const int r0 = cell_start[base + cy * nx + cm], r1 = cell_start[base + cy * nx + cm + 1];
+                        if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, m, rec_face, hit);
+                    }
+                } else { // cells cx = ka..kb of row cm are one contiguous record run
+                    edge_cell(q, cell_start[base + cm * nx + ka], cell_start[base + cm * nx + kb + 1], rbb, rec_fxy, rec_len,
+                              m, rec_face, hit);
+                }
+            }
         }
-    };
+    }
+}
+
+// all grid cells of the edge's box, level by level (short edges: a handful of cells, no per-cell arithmetic)
+template <typename Hit>
+__device__ __forceinline__ void edge_walk_box(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
+                                              const float4 *__restrict__ rbb, const double *__restrict__ rec_fxy,
+                                              const uint8_t *__restrict__ rec_len, int m,
+                                              const int32_t *__restrict__ rec_face, Hit &&hit) {
     for (int l = 0; l < g.n_levels; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], base = g.base[l];
@@ -156,8 +216,101 @@ k_edges(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const 
     }
 }
 
-// long edges: one block per edge, the threads stride over the cells of its box and skip those the segment cannot
-// reach (a record lies within [cell origin, cell origin + 2 h) in both directions)
+// pass 1, one thread per edge: count the hits per face; the first EDGE_SLOTS hits of every edge are kept in a
+// slot-major side buffer so that the fill pass need not walk the grid again.  Edges with more hits are queued for
+// a second walk (redo_list), edges whose box spans many cells for the block-per-edge kernels (big_list).
+// append `item` to a list for the lanes with `flag`: one returning atomic per wave instead of one per lane
+// (every lane of the wave that is still active must call this together)
+__device__ __forceinline__ void wave_append(bool flag, int32_t item, int32_t *__restrict__ list,
+                                            int32_t *__restrict__ count) {
+    const unsigned long long mask = __ballot(flag);
+    if (mask == 0) return;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(count, __popcll(mask));
+    base = __shfl(base, leader);
+    if (flag) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = item;
+}
+
+template <bool MAJOR_WALK>
+__global__ void __launch_bounds__(256)
+k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const int32_t *__restrict__ cell_start,
+              const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+              int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
+              int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
+              int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
+              double *__restrict__ side_len, int big_cells) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = e < n_edge;
+    EdgeBox q{};
+    bool walk = false, big = false;
+    if (live) {
+        q = load_edge(edge_xy, e, g);
+        const bool finite = q.xmin == q.xmin && q.ymin == q.ymin && q.xmax == q.xmax && q.ymax == q.ymax; // no NaN
+        big = finite && edge_cells(q, g) > big_cells;
+        walk = finite && !big;
+    }
+    int nh = 0;
+    if (walk) {
+        auto hit = [&](int face, double len) {
+            atomicAdd(row_count + face, 1);
+            if (nh < EDGE_SLOTS) {
+                side_face[(int64_t)nh * n_edge + e] = face;
+                side_len[(int64_t)nh * n_edge + e] = len;
+            }
+            nh++;
+        };
+        const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
+        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
+    }
+    const bool redo = nh > EDGE_SLOTS;
+    wave_append(big, (int32_t)e, big_list, n_big);
+    wave_append(redo, (int32_t)e, redo_list, n_redo);
+    if (live) edge_hits[e] = redo ? 0 : nh;
+}
+
+// pass 2a: the kept hits go to their rows (arbitrary order within a row)
+__global__ void __launch_bounds__(256)
+k_edges_replay(int64_t n_edge, const int32_t *__restrict__ edge_hits, const int32_t *__restrict__ side_face,
+               const double *__restrict__ side_len, int32_t *__restrict__ row_count,
+               const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_edge) return;
+    const int nh = edge_hits[e];
+    for (int k = 0; k < nh; k++) {
+        const int face = side_face[(int64_t)k * n_edge + e];
+        const int pos = indptr[face] + atomicAdd(row_count + face, 1);
+        indices[pos] = (int32_t)e;
+        data[pos] = side_len[(int64_t)k * n_edge + e];
+    }
+}
+
+// pass 2b: the edges with more than EDGE_SLOTS hits walk the grid once more
+template <bool MAJOR_WALK>
+__global__ void __launch_bounds__(256)
+k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
+             const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+             int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
+             const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
+             const int32_t *__restrict__ redo_list, const int32_t *__restrict__ n_redo) {
+    const int n = *n_redo;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = redo_list[i];
+        const EdgeBox q = load_edge(edge_xy, e, g);
+        auto hit = [&](int face, double len) {
+            const int pos = indptr[face] + atomicAdd(row_count + face, 1);
+            indices[pos] = (int32_t)e;
+            data[pos] = len;
+        };
+        const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
+        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
+    }
+}
+
+// long edges: one wave per edge
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
@@ -165,9 +318,8 @@ k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__r
             int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
             const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
             const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big) {
-    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const int nb = *n_big;
-    for (int i = blockIdx.x; i < nb; i += gridDim.x) {
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nb; i += gridDim.x * 4) {
         const int64_t e = big_list[i];
         const EdgeBox q = load_edge(edge_xy, e, g);
         auto hit = [&](int face, double len) {
@@ -177,24 +329,7 @@ k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__r
                 data[indptr[face] + k] = len;
             }
         };
-        for (int l = 0; l < g.n_levels; l++) {
-            const double h = level_h(g, l), inv_h = level_inv_h(g, l);
-            const int nx = g.nx[l], base = g.base[l];
-            const int cx0 = cell_coord(q.xmin - h, g.x0, inv_h, nx), cx1 = cell_coord(q.xmax, g.x0, inv_h, nx);
-            const int cy0 = cell_coord(q.ymin - h, g.y0, inv_h, g.ny[l]), cy1 = cell_coord(q.ymax, g.y0, inv_h, g.ny[l]);
-            const int w = cx1 - cx0 + 1;
-            const int64_t cells = (int64_t)w * (cy1 - cy0 + 1);
-            for (int64_t c = threadIdx.x; c < cells; c += 256) {
-                const int cy = cy0 + (int)(c / w), cx = cx0 + (int)(c % w);
-                const int r0 = cell_start[base + cy * nx + cx], r1 = cell_start[base + cy * nx + cx + 1];
-                if (r0 == r1) continue;
-                const double bx = g.x0 + cx * h, by = g.y0 + cy * h;
-                // (the first / last cell of a level also holds the records clamped into it)
-                const bool edge_cell_of_grid = cx == 0 || cy == 0 || cx == nx - 1 || cy == g.ny[l] - 1;
-                if (!edge_cell_of_grid && !segment_reaches_box(q.a, q.b, bx, bx + 2.0 * h, by, by + 2.0 * h)) continue;
-                edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, m, rec_face, hit);
-            }
-        }
+        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, m, rec_face, hit);
     }
 }
 
@@ -301,14 +436,24 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     DevBuf<double> edge_xy((size_t)n_edge * 4);
     h2d(edge_xy.get(), edge_xy_host, sizeof(double) * 4 * (size_t)n_edge);
     DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters(4);
+    DevBuf<int32_t> edge_hits((size_t)n_edge), side_face((size_t)n_edge * EDGE_SLOTS), redo_list((size_t)n_edge);
+    DevBuf<double> side_len((size_t)n_edge * EDGE_SLOTS);
     XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
     XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 4, st));
     const GridParams &g = tree->grid;
-    const int big_grid = engine().num_cu * 4;
-    XR_LAUNCH("edges_count", k_edges<false>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
+    const int big_grid = engine().num_cu * 8;
+    const int big_cells = getenv("XR_EDGE_BIG") ? atoi(getenv("XR_EDGE_BIG")) : EDGE_BIG_CELLS; // tuning hook
+    const bool major = getenv("XR_EDGE_WALK") ? !strcmp(getenv("XR_EDGE_WALK"), "major") : false; // tuning hook
+    if (major)
+    XR_LAUNCH("edges_count", k_edges_count<true>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
-              tree->rec_face.get(), row_count.get(), (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
-              big_list.get(), counters.get());
+              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
+              edge_hits.get(), side_face.get(), side_len.get(), big_cells);
+    else
+    XR_LAUNCH("edges_count", k_edges_count<false>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
+              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
+              edge_hits.get(), side_face.get(), side_len.get(), big_cells);
     XR_LAUNCH("edges_big_count", k_edges_big<false>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
               tree->rec_face.get(), row_count.get(), (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
@@ -321,10 +466,18 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     csr->data.alloc((size_t)P);
     if (P == 0) return;
     XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
-    XR_LAUNCH("edges_fill", k_edges<true>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
-              tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
-              big_list.get(), counters.get());
+    XR_LAUNCH("edges_replay", k_edges_replay, dim3(div_up(n_edge, 256)), dim3(256), 0, n_edge, edge_hits.get(),
+              side_face.get(), side_len.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
+    if (major)
+    XR_LAUNCH("edges_redo", k_edges_redo<true>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
+              dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
+              tree->rec_len.get(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
+              csr->data.get(), redo_list.get(), counters.get() + 2);
+    else
+    XR_LAUNCH("edges_redo", k_edges_redo<false>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
+              dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
+              tree->rec_len.get(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
+              csr->data.get(), redo_list.get(), counters.get() + 2);
     XR_LAUNCH("edges_big_fill", k_edges_big<true>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
               tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
