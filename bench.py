@@ -279,12 +279,12 @@ def run_single(args):
         "cpu_baseline": cpu,
     }
     if not args.no_extras:
-        result["other_configs"] = other_configs(E, lib, _lib, csr, S, T)
+        result["other_configs"] = other_configs(E, lib, _lib, csr, S, T, ms, sxy)
     print(json.dumps(result), flush=True)
 
 
-def other_configs(E, lib, _lib, csr, S, T):
-    """BASELINE configs 5 and 3 and a structured pair, measured beside the headline (rank 0, N = 1): informative
+def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy):
+    """BASELINE configs 5 and 3, a structured pair and a network, measured beside the headline (rank 0, N = 1): informative
     extras of the JSON line, never part of `value`.  Bounded to a few seconds each."""
     import ctypes
 
@@ -382,6 +382,28 @@ def other_configs(E, lib, _lib, csr, S, T):
         }
     except Exception as e:  # noqa: BLE001
         out["structured_4000x4000"] = {"error": repr(e)}
+    try:  # NetworkGridder weights: 1M network edges over the benchmark's source mesh
+        rng = np.random.default_rng(7)
+        n_edge = 1_000_000
+        xy_lo, xy_hi = float(mesh_xy.min()), float(mesh_xy.max())
+        a = rng.uniform(xy_lo, xy_hi, (n_edge, 2))
+        ang = rng.uniform(0, 2 * np.pi, n_edge)
+        length = rng.exponential(0.002 * (xy_hi - xy_lo), n_edge)
+        edges = np.stack([a, a + length[:, None] * np.column_stack([np.cos(ang), np.sin(ang)])], axis=1)
+        E.edge_length_csr(mesh, edges)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            w = E.edge_length_csr(mesh, edges)
+            E.dev_sync()
+            times.append(time.perf_counter() - t0)
+        out["network_gridder_1M_edges"] = {
+            "weights_ms": 1e3 * min(times), "edges_per_s": n_edge / min(times), "nnz": w.nnz,
+            "note": "1M random segments (exponential lengths, mean ~2 cell sizes) over the ~1M-triangle source mesh; "
+            "includes the 32 MB upload of the edge coordinates",
+        }
+    except Exception as e:  # noqa: BLE001
+        out["network_gridder_1M_edges"] = {"error": repr(e)}
     return out
 
 
