@@ -47,17 +47,30 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
 static constexpr int SLOTS = 16;
 static constexpr int TILE_RUN = 64; // rows per run in the tiling hint (512-byte output stores per variable)
 
+// XCD-aware block order (launch the grid rounded up to a multiple of 8): hardware block b runs on XCD b % 8; every
+// XCD gets a CONTIGUOUS range of logical blocks (= one spatial region of the Morton-ordered work list), so that the
+// lines shared by neighbouring blocks stay in one L2.  -> logical block (>= n_blocks: nothing to do)
+__device__ __forceinline__ int64_t xcd_block(int64_t n_blocks, bool remap) {
+    if (!remap) return blockIdx.x;
+    const int64_t per_xcd = (n_blocks + 7) >> 3;
+    return (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+}
+
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const int32_t *__restrict__ cell_start,
          const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_off,
          int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
-         int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key, int32_t *__restrict__ nnz_row) {
+         int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key, int32_t *__restrict__ nnz_row,
+         bool remap) {
     __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
     __shared__ uint8_t sh_owner[SLOTS * 256];
     __shared__ int32_t sh_wave[4];
     __shared__ int32_t sh_base;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n_blocks = (n_query + 255) / 256;
+    const int64_t lb = xcd_block(n_blocks, remap);
+    if (lb >= n_blocks) return;
+    const int64_t t = lb * 256 + threadIdx.x;
     int count = 0;
     bool big = false;
     if (t < n_query) {
@@ -170,8 +183,8 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
         cand_off[t] = base + lo;
         cand_count[t] = mine;
     }
-    if (threadIdx.x == 0) block_seg[blockIdx.x] = make_int2(base, total);
-    const int32_t t0 = (int32_t)((int64_t)blockIdx.x * 256);
+    if (threadIdx.x == 0) block_seg[lb] = make_int2(base, total);
+    const int32_t t0 = (int32_t)(lb * 256);
     for (int i = threadIdx.x; i < total; i += 256) {
         cand_tgt[base + i] = t0 + sh_owner[i];
         cand_src[base + i] = flat[i];
@@ -519,10 +532,13 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
              const uint8_t *__restrict__ s_len, int s_m, const int32_t *__restrict__ cand_tgt,
              const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area,
              const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
-             int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
+             int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *out = reinterpret_cast<double2 *>(smem) + threadIdx.x; // out[j * BLOCK]
-    const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int64_t n_blocks = (n_cand + BLOCK - 1) / BLOCK;
+    const int64_t lb = xcd_block(n_blocks, remap);
+    if (lb >= n_blocks) return;
+    const int64_t c = lb * BLOCK + threadIdx.x;
     const bool active = c < n_cand;
     int t = -1;
     double area = 0.0;
@@ -681,17 +697,20 @@ k_row_fill(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ can
            const int32_t *__restrict__ indptr, const double *__restrict__ src_area, bool relative,
            int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ long_rows,
            int32_t *__restrict__ n_long, int32_t *__restrict__ apply_long_rows,
-           int32_t *__restrict__ n_apply_long) {
+           int32_t *__restrict__ n_apply_long, bool remap) {
     __shared__ int32_t sh_src[ROW_LDS];  // tree face id of a survivor, INT_MAX for area <= 0
     __shared__ uint16_t sh_row[ROW_LDS];
     __shared__ int32_t sh_c0[256];   // first candidate of the row (global index)
     __shared__ int32_t sh_lds[257];  // LDS offset of the row (short rows only), [256] = total
     __shared__ int32_t sh_ptr[256];  // CSR offset of the row
     __shared__ int32_t sh_wave[4];
-    const int64_t t0 = (int64_t)blockIdx.x * 256;
+    const int64_t n_blocks = (n_query + 255) / 256;
+    const int64_t lb = xcd_block(n_blocks, remap);
+    if (lb >= n_blocks) return;
+    const int64_t t0 = lb * 256;
     const int64_t t = t0 + threadIdx.x;
     // the candidates of the block's rows that k_search wrote itself (all but its "big" faces) are one stretch
-    const int2 seg = block_seg[blockIdx.x];
+    const int2 seg = block_seg[lb];
     const int seg0 = seg.x, seg1 = seg.x + seg.y;
     int c0 = 0, len = 0;
     bool is_short = true; // packed here; everything else (long rows, and the "big" faces of the search, whose
@@ -909,6 +928,12 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     }
 }
 
+static int xcd_remap_mask() {
+    const char *e = getenv("XR_XCD_REMAP"); // tuning hook: bit 0 clip, bit 1 search, bit 2 row_fill
+    return e ? atoi(e) : 0;
+}
+static unsigned xcd_grid(int64_t n_blocks, bool remap) { return (unsigned)(remap ? (n_blocks + 7) / 8 * 8 : n_blocks); }
+
 template <int MAXV, int BLOCK>
 static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
                         int64_t C, double *cand_area, bool redo_only, int32_t *cand_sid, int32_t *overflow_count,
@@ -930,21 +955,22 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
                             int64_t C, double *cand_area, int32_t *cand_sid, int32_t *overflow_count,
                             int32_t *nnz_row) {
     const int vmax = query->m + tree->m;
+    const bool remap = xcd_remap_mask() & 1;
     if (vmax <= 6) {
         // triangle x triangle: the clipped polygon never has more than 6 vertices
         constexpr int MAXV = 6, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
-        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
-                  query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
+        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
+                  shmem, query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
-                  overflow_count, nnz_row);
+                  overflow_count, nnz_row, remap);
     } else if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
-        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, false>), dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem,
-                  query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
+        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, false>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
+                  shmem, query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
-                  overflow_count, nnz_row);
+                  overflow_count, nnz_row, remap);
     }
     else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
     else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
@@ -1005,10 +1031,11 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->tile_key_range = (int64_t)1 << (2 * bits);
         csr->has_tile_key = bits > 0;
     }
-    XR_LAUNCH("search", k_search, dim3(div_up(T, 256)), dim3(256), 0, query->qo_bbox(), T, g,
+    const bool remap_search = xcd_remap_mask() & 2, remap_rows = xcd_remap_mask() & 4;
+    XR_LAUNCH("search", k_search, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
               cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
-              csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get());
+              csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
     DevBuf<int32_t> pending((size_t)T);
     XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
               query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
@@ -1082,10 +1109,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->n_long.alloc(1);
         csr->has_long = true;
         XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), st));
-        XR_LAUNCH("row_fill", k_row_fill, dim3(div_up(T, 256)), dim3(256), 0, cand_off.get(), cand_count.get(),
+        XR_LAUNCH("row_fill", k_row_fill, dim3(xcd_grid(div_up(T, 256), remap_rows)), dim3(256), 0, cand_off.get(), cand_count.get(),
                   block_seg.get(), is_big.get(), cand_tgt.get(), cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, csr->long_rows.get(),
-                  csr->n_long.get());
+                  csr->n_long.get(), remap_rows);
         const size_t shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
         static bool attr_set = false;
         if (!attr_set) {
