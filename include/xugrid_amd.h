@@ -231,6 +231,10 @@ int xr_outer_destroy(xr_outer *outer);
  * xr_apply_csr like any other weights (source variables live on the EDGES).  `relative` lengths are not offered:
  * the reference never requests them (gridder.py:49) and its formula indexes the edge lengths by face id (:213-214). */
 int xr_edge_length_csr(xr_mesh *tree, const double *edge_xy, int64_t n_edge, xr_csr **out);
+/* The third return value of intersect_edges for the entries of such a matrix: intersections float64[nnz, 2, 2]
+ * (begin and end point of every piece, along the direction of its edge), in the entry order of the CSR. */
+int xr_edge_pieces(xr_mesh *tree, const xr_csr *csr, const double *edge_xy, int64_t n_edge,
+                   double *intersections);
 /* Optional locality hint for matrices that were uploaded (xr_csr_upload / xr_csr_from_triplet, i.e. the
  * from_weights path): one small integer per row such that rows with equal keys are spatial neighbours (e.g. the
  * Morton code of a coarse cell holding the target face's centroid).  With many source variables (K >= 8) the apply

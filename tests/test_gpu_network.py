@@ -146,3 +146,25 @@ def test_network_gridder_large(hip, oracle):
     full = np.hypot(*(edges[:, 1] - edges[:, 0]).T)
     inside = ((edges > lo + 0.05 * span) & (edges < hi - 0.05 * span)).all(axis=(1, 2))
     np.testing.assert_allclose(per_edge[inside], full[inside], rtol=1e-9)
+
+
+def test_celltree_intersect_edges_adapter(hip, oracle):
+    """CellTree2d.intersect_edges (numba_celltree's call shape, unstructured.py:203-215): edge ids, face ids and
+    the end points of every piece equal the oracle's, bit for bit, ordered by (edge, face)."""
+    rng = np.random.default_rng(8)
+    for nodes, faces in (meshgen.triangle_mesh(3000, 3), raster_quads(np.linspace(0, 1, 31), np.linspace(0, 1, 27))):
+        edges = random_network(rng, 2500, -0.05, 1.05, 0.08)
+        edges[:50, 1, 0] = edges[:50, 0, 0]  # some vertical ones
+        tree = xa.CellTree2d(nodes, faces, -1)
+        e, f, xy = tree.intersect_edges(edges)
+        oe, of, oxy = oracle.CellTree2d(nodes, faces).intersect_edges(edges)
+        assert np.array_equal(e, oe) and np.array_equal(f, of)
+        assert np.array_equal(xy, oxy)
+        # the reference's own post-processing of the triple gives the gridder's weights
+        length = np.linalg.norm(np.diff(xy, axis=1)[:, 0, :], axis=-1)
+        csr = engine.edge_length_csr(tree.device_mesh, edges)
+        data, cols, indptr = csr.download()
+        order = np.lexsort((e, f))
+        assert np.array_equal(cols, e[order]) and np.allclose(data, length[order], rtol=1e-15)
+    empty = xa.CellTree2d(nodes, faces, -1).intersect_edges(np.zeros((0, 2, 2)))
+    assert empty[0].size == 0 and empty[2].shape == (0, 2, 2)

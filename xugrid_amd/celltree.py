@@ -6,6 +6,7 @@ runs in the HIP kernels behind ``xugrid_amd.engine.DeviceMesh``.
 """
 import numpy as np
 
+from . import engine
 from .engine import DeviceMesh, IntDType
 
 
@@ -44,3 +45,16 @@ class CellTree2d:
     def compute_barycentric_weights(self, points, tolerance=None):
         """(face index [n], weights [n, n_max_node]) -- xugrid/ugrid/ugrid2d.py:1054-1078."""
         return self.device_mesh.compute_barycentric_weights(points, tolerance)
+
+    def intersect_edges(self, edge_coords):
+        """
+        Intersections of line segments ``(n_edge, 2, 2)`` with the faces (xugrid/regrid/unstructured.py:203-215):
+        ``(edge_index, face_index, intersections (n, 2, 2))`` ordered by edge, faces ascending within an edge.
+        Only pieces of positive length are reported.
+        """
+        csr = engine.edge_length_csr(self.device_mesh, edge_coords)
+        _, edge_index, indptr = csr.download()
+        pieces = engine.edge_pieces(self.device_mesh, csr, edge_coords)
+        face_index = np.repeat(np.arange(csr.n, dtype=IntDType), np.diff(indptr))
+        order = np.lexsort((face_index, edge_index))
+        return edge_index[order], face_index[order], pieces[order]

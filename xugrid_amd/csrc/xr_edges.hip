@@ -23,8 +23,10 @@ static constexpr int EDGE_SLOTS = 6;       // hits per edge the count pass keeps
 static constexpr int ROW_SORT_SMALL = 48;  // rows up to this length are insertion-sorted by one thread
 static constexpr int ROW_SORT_LDS = 4096;  // rows up to this length are sorted in LDS by one block
 
-// a + t (b - a), t in [0, 1], against every half-plane of the CCW polygon.  -> length of the clipped piece, or -1
-__device__ __forceinline__ double cyrus_beck_length(const double *__restrict__ poly, int n, P2 a, P2 b) {
+// a + t (b - a), t in [0, 1], against every half-plane of the CCW polygon.  -> length of the clipped piece, or -1;
+// its end points in c / d when asked for
+__device__ __forceinline__ double cyrus_beck_length(const double *__restrict__ poly, int n, P2 a, P2 b,
+                                                    P2 *c = nullptr, P2 *d = nullptr) {
     const double sx = b.x - a.x, sy = b.y - a.y;
     double t0 = 0.0, t1 = 1.0;
     P2 v0 = load_p2(poly, 0);
@@ -51,6 +53,10 @@ __device__ __forceinline__ double cyrus_beck_length(const double *__restrict__ p
     if (!(t0 < t1)) return -1.0;
     const double cx = a.x + t0 * sx, cy = a.y + t0 * sy;
     const double dx = a.x + t1 * sx, dy = a.y + t1 * sy;
+    if (c) {
+        *c = P2{cx, cy};
+        *d = P2{dx, dy};
+    }
     const double ex = dx - cx, ey = dy - cy;
     return sqrt(ex * ex + ey * ey);
 }
@@ -418,6 +424,22 @@ k_edge_rows_sort_big(const int32_t *__restrict__ indptr, int32_t *__restrict__ i
     }
 }
 
+// the end points of every (face, edge) entry of the CSR, in entry order: intersections[entry][2][2]
+__global__ void __launch_bounds__(256)
+k_edge_pieces(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_face,
+              const double *__restrict__ fxy, const uint8_t *__restrict__ len, int m,
+              const double *__restrict__ edge_xy, double *__restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    for (int p = indptr[f]; p < indptr[f + 1]; p++) {
+        const int e = indices[p];
+        P2 c{NAN, NAN}, d{NAN, NAN};
+        cyrus_beck_length(fxy + f * m * 2, len[f], load_p2(edge_xy, 2 * e), load_p2(edge_xy, 2 * e + 1), &c, &d);
+        double *o = out + (int64_t)p * 4;
+        o[0] = c.x; o[1] = c.y; o[2] = d.x; o[3] = d.y;
+    }
+}
+
 static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n_edge, xr_csr *csr) {
     const int64_t F = tree->n_face;
     csr->n = F;
@@ -521,6 +543,24 @@ int xr_edge_length_csr(xr_mesh *tree, const double *edge_xy, int64_t n_edge, xr_
         throw;
     }
     *out = csr;
+    XR_API_END
+}
+
+int xr_edge_pieces(xr_mesh *tree, const xr_csr *csr, const double *edge_xy, int64_t n_edge, double *intersections) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && csr && (intersections || csr->nnz == 0), XR_ERR_INVALID, "xr_edge_pieces: NULL argument");
+    XR_REQUIRE(csr->n == tree->n_face && csr->m == n_edge && (edge_xy || n_edge == 0), XR_ERR_INVALID,
+               "xr_edge_pieces: the matrix does not belong to this mesh / these edges");
+    if (csr->nnz > 0) {
+        mesh_prepare(tree, true);
+        mesh_face_coords(tree);
+        DevBuf<double> xy((size_t)n_edge * 4), out((size_t)csr->nnz * 4);
+        h2d(xy.get(), edge_xy, sizeof(double) * 4 * (size_t)n_edge);
+        XR_LAUNCH("edge_pieces", k_edge_pieces, dim3(div_up(csr->n, 256)), dim3(256), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->n, tree->fxy.get(), tree->len.get(), tree->m, xy.get(), out.get());
+        d2h(intersections, out.get(), sizeof(double) * 4 * (size_t)csr->nnz);
+        stream_sync();
+    }
     XR_API_END
 }
 

@@ -244,6 +244,14 @@ def edge_length_csr(tree: DeviceMesh, edge_node_coordinates) -> "DeviceCSR":
     return DeviceCSR(handle)
 
 
+def edge_pieces(tree: DeviceMesh, csr: "DeviceCSR", edge_node_coordinates):
+    """End points (nnz, 2, 2) of the pieces behind the entries of an ``edge_length_csr`` matrix, in entry order."""
+    xy = np.ascontiguousarray(edge_node_coordinates, dtype=np.float64)
+    out = np.empty((csr.nnz, 2, 2), dtype=np.float64)
+    check(_lib.load().xr_edge_pieces(tree._h, csr._h, _ptr(xy), xy.shape[0], _ptr(out)))
+    return out
+
+
 def locate_csr(tree: DeviceMesh, query: DeviceMesh = None, points=None, tolerance=None) -> "DeviceCSR":
     """locate_centroids + MatrixCOO.from_triplet on the device: one (face, 1.0) entry per located point."""
     tol = -1.0 if tolerance is None else float(tolerance)
