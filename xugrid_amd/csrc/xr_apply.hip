@@ -1427,6 +1427,19 @@ static void launch_workspace(const xr_csr *csr, const SRC *src, int64_t K, doubl
 template <typename SRC>
 static void apply_dispatch(const xr_csr *csr, int method, double p, const SRC *src, int64_t K, double *out) {
     if (csr->n == 0 || K == 0) return;
+    // Many variables are walked in groups of 128: the blocks in flight then gather from 1 GB of source planes at a
+    // time instead of from all K of them.  Measured at K = 256 on the 1M x 1M benchmark matrix: 2.21 -> 2.07 ms with
+    // qhull-numbered (scattered) columns, 1.10 -> 1.13 ms with lattice-numbered ones; smaller groups lose more on
+    // re-staging the entries than they gain.
+    static const int64_t kgroup = getenv("XR_APPLY_KGROUP") ? atoll(getenv("XR_APPLY_KGROUP")) : 128; // tuning hook
+    if (kgroup > 0 && K > kgroup + kgroup / 2) {
+        for (int64_t k0 = 0; k0 < K; k0 += kgroup) {
+            const int64_t kc = (K - k0) < kgroup + kgroup / 2 ? (K - k0) : kgroup; // (no short tail group)
+            apply_dispatch<SRC>(csr, method, p, src + k0 * csr->m, kc, out + k0 * csr->n);
+            if (kc != kgroup) break;
+        }
+        return;
+    }
     switch (method) {
     case XR_MEAN: launch_stream<XR_MEAN, SRC>(csr, src, K, out); break;
     case XR_HARMONIC_MEAN: launch_stream<XR_HARMONIC_MEAN, SRC>(csr, src, K, out); break;
