@@ -514,7 +514,8 @@ def main():
     ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative extras (configs 3 and 5, structured pair)")
-    ap.add_argument("--partition", default="morton", choices=["morton", "hash"])
+    ap.add_argument("--partition", default="balanced", choices=["balanced", "morton", "hash"],
+                    help="source shards: Morton blocks of equal estimated work (default) / equal face counts, or id mod N")
     ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
                     help="sparse all-to-all of the touched targets (default) or dense reduce-scatter")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")

@@ -104,7 +104,7 @@ def main():
     txy, tf = meshgen.triangle_mesh(1203, 1, 30.0, 0.7)  # T not divisible by the world size
     data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
     results = {}
-    for mode, exchange in (("morton", "sparse"), ("hash", "sparse"), ("morton_dense", "dense")):
+    for mode, exchange in (("morton", "sparse"), ("hash", "sparse"), ("morton_dense", "dense"), ("balanced", "sparse")):
         rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition=mode.split("_")[0], exchange=exchange)
         owned = torch.zeros(sf.shape[0], dtype=torch.int64)
         owned[torch.as_tensor(rg.local_faces)] = 1

@@ -36,6 +36,37 @@ def test_partition_faces_balanced_and_compact():
     assert max(areas) < 0.3
 
 
+def test_work_balanced_partition():
+    """The benchmark pair (target = 0.7 x rotated copy inside the source square): Morton blocks of equal source
+    counts leave the central ranks with several times the targets of the corner ranks; blocks of equal estimated
+    work (1 per source + 4 per attributed target) even that out while staying contiguous along the curve."""
+    from xugrid_amd.distributed import _targets_near_shard, work_weights
+
+    sxy, sf = meshgen.triangle_mesh(40_000, 0, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(40_000, 1, 30.0, 0.7, delaunay=False)
+    cen, tcen = sxy[sf].mean(axis=1), txy[tf].mean(axis=1)
+    w = work_weights(cen, tcen)
+    assert w.shape == (sf.shape[0],) and w.min() >= 1.0
+    # every target is attributed once (the target mesh lies inside the source mesh)
+    np.testing.assert_allclose(w.sum(), sf.shape[0] + 4.0 * tf.shape[0], rtol=1e-3)
+
+    def imbalance(owner):
+        cost = []
+        for r in range(8):
+            local = np.nonzero(owner == r)[0]
+            cost.append(local.size + 4 * _targets_near_shard(sxy, sf[local], txy, tf).size)
+        return max(cost) / np.mean(cost)
+
+    plain = partition_faces(cen, 8, "morton")
+    balanced = partition_faces(cen, 8, "morton", weights=w)
+    assert np.bincount(balanced, minlength=8).min() > 0
+    assert imbalance(plain) > 1.3 and imbalance(balanced) < 1.12
+    per_rank = np.bincount(balanced, weights=w, minlength=8)
+    assert per_rank.max() / per_rank.mean() < 1.01
+    # uniform weights reproduce the equal-count split
+    assert np.array_equal(partition_faces(cen, 8, "morton", weights=np.ones(cen.shape[0])), plain)
+
+
 def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
@@ -51,13 +82,14 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
     q, s, a = oracle.CellTree2d(sxy, sf).intersect_faces(txy, tf)
     exp = oracle.regrid_csr("mean", data, a, s, oracle.to_csr_indptr(q, tf.shape[0]), tf.shape[0])
-    for mode in ("morton", "hash", "morton_dense"):
+    for mode in ("morton", "hash", "morton_dense", "balanced"):
         got = out[mode]
         assert got.shape == exp.shape
         assert np.array_equal(np.isnan(got), np.isnan(exp))
         np.testing.assert_allclose(got, exp, rtol=1e-12, equal_nan=True)  # summation order differs across shards
         np.testing.assert_allclose(out[mode + "_1d"], exp[0], rtol=1e-12, equal_nan=True)
-        assert abs(int(out[mode + "_n_local"]) - sf.shape[0] / 2) <= 1
+        if mode != "balanced":  # (equal work, not equal counts)
+            assert abs(int(out[mode + "_n_local"]) - sf.shape[0] / 2) <= 1
     # the sparse all-to-all exchange and the dense reduce-scatter agree to the last bit on 2 ranks
     assert np.array_equal(out["morton"], out["morton_dense"], equal_nan=True)
     # spatially compact shards only look at the targets near them; hash shards see (almost) all

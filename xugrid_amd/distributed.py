@@ -2,7 +2,7 @@
 Multi-GPU regridding: one process per GPU (``torch.distributed``, backend "nccl" = RCCL over xGMI),
 SOURCE faces partitioned over the ranks, target mesh replicated (BASELINE north_star).
 
-    rank r:  faces_r = {s : part(s) == r}                            # Morton blocks (or s mod N)
+    rank r:  faces_r = {s : part(s) == r}                            # Morton blocks of equal work (or s mod N)
              targets_r = {t : bbox(t) overlaps bbox(faces_r)}         # only these can get weight from r
              W_r     = overlap(source[faces_r], target[targets_r])    # HIP, no communication
              num_r, den_r = sum_j w v, sum_j w  (v not NaN)          # HIP, per (k, target in targets_r)
@@ -34,15 +34,17 @@ import os
 import numpy as np
 
 
-def partition_faces(centroids, world_size, mode="morton"):
+def partition_faces(centroids, world_size, mode="morton", weights=None):
     """
     Owner rank of every source face.
 
     "morton": faces are ordered along a Z-order curve of their centroids and cut into
     ``world_size`` contiguous blocks of equal size -- each rank's shard is spatially compact, so
-    the per-rank search touches ~T/world targets instead of all of them.
+    the per-rank search touches ~T/world targets instead of all of them.  With ``weights`` (one
+    non-negative number per face) the blocks have equal total WEIGHT instead of equal face counts.
     "hash":   ``face id mod world_size`` (BASELINE north_star wording); every rank sees every
     target with ~1/world of its pairs.
+    (``ShardedOverlapRegridder(partition="balanced")`` = "morton" with ``work_weights``.)
     """
     n = centroids.shape[0]
     if mode == "hash":
@@ -63,8 +65,39 @@ def partition_faces(centroids, world_size, mode="morton"):
     code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
     order = np.argsort(code, kind="stable")
     owner = np.empty(n, dtype=np.int32)
-    owner[order] = (np.arange(n) * world_size // max(n, 1)).astype(np.int32)
+    if weights is None:
+        owner[order] = (np.arange(n) * world_size // max(n, 1)).astype(np.int32)
+    else:
+        w = np.asarray(weights, dtype=np.float64)[order]
+        before = np.cumsum(w) - w  # weight in front of each face along the curve
+        total = float(w.sum())
+        cut = before * (world_size / total) if total > 0 else np.arange(n) * (world_size / max(n, 1))
+        owner[order] = np.minimum(cut.astype(np.int64), world_size - 1).astype(np.int32)
     return owner
+
+
+def work_weights(source_centroids, target_centroids, target_cost=4.0, n_grid=None):
+    """
+    Work estimate per source face for the "balanced" partition: 1 for the face itself (prepare + index) plus
+    ``target_cost`` for every target face that falls to it (search, clip, row assembly and apply are per target /
+    per candidate pair; 4 is their measured share relative to the per-source kernels on the 1M x 1M benchmark).
+    Targets are attributed through a coarse raster (~16 sources per cell, at most 256 x 256 cells): the targets of
+    a raster cell are shared by its sources; targets in cells without sources cost nothing (they overlap nothing).
+    """
+    if n_grid is None:
+        n_grid = int(min(256, max(4, np.sqrt(source_centroids.shape[0] / 16.0))))
+    lo = np.minimum(source_centroids.min(axis=0), target_centroids.min(axis=0))
+    hi = np.maximum(source_centroids.max(axis=0), target_centroids.max(axis=0))
+    f = n_grid / np.maximum(hi - lo, 1e-300)
+
+    def cell(c):
+        ij = np.clip(np.floor((c - lo) * f).astype(np.int64), 0, n_grid - 1)
+        return ij[:, 1] * n_grid + ij[:, 0]
+
+    cs = cell(source_centroids)
+    n_src = np.bincount(cs, minlength=n_grid * n_grid)
+    n_tgt = np.bincount(cell(target_centroids), minlength=n_grid * n_grid)
+    return 1.0 + target_cost * n_tgt[cs] / np.maximum(n_src[cs], 1)
 
 
 class HipBackend:
@@ -227,9 +260,11 @@ class ShardedOverlapRegridder:
 
     source_xy/source_faces, target_xy/target_faces: the FULL meshes (every rank passes the same
     arrays; each keeps only its shard of the source faces).
+    partition: "balanced" (default; Morton blocks of equal estimated work, ``work_weights``), "morton" (Morton
+    blocks of equal source-face counts) or "hash" (face id mod world size).
     """
 
-    def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="morton", group=None,
+    def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="balanced", group=None,
                  exchange="sparse"):
         import torch.distributed as dist
 
@@ -249,7 +284,16 @@ class ShardedOverlapRegridder:
         xy = np.asarray(source_xy, dtype=np.float64)
         safe = np.where(valid, source_faces, 0)
         cen = (xy[safe] * valid[..., None]).sum(axis=1) / cnt[:, None]
-        owner = partition_faces(cen, self.world, partition)
+        if partition == "balanced":
+            # Morton blocks of equal estimated WORK: where the target mesh is denser than the source mesh (or covers
+            # only a part of it) equal source counts would leave some ranks with several times the targets of others
+            tfa = np.asarray(target_faces)
+            tv = tfa >= 0
+            tcen = (np.asarray(target_xy, dtype=np.float64)[np.where(tv, tfa, 0)] * tv[..., None]).sum(axis=1)
+            tcen /= tv.sum(axis=1)[:, None]
+            owner = partition_faces(cen, self.world, "morton", weights=work_weights(cen, tcen))
+        else:
+            owner = partition_faces(cen, self.world, partition)
         self.local_faces = np.nonzero(owner == self.rank)[0]  # global ids of this rank's sources
         # only targets whose bbox overlaps the bbox of this rank's source shard can receive weight
         target_faces = np.asarray(target_faces)
