@@ -1617,6 +1617,10 @@ static void launch_outer_cx(const xr_outer *o, const SRC *src, int64_t K, double
 template <int METHOD, typename SRC>
 static void launch_outer(const xr_outer *o, const SRC *src, int64_t K, double *out) {
     if (o->nty * o->ntx == 0 || K == 0) return;
+    if (o->Py == 0 || o->Px == 0) { // no entries at all (e.g. an empty source grid): every row is empty
+        fill_f64(out, NAN, K * o->nty * o->ntx);
+        return;
+    }
     XR_REQUIRE(div_up(K, 4) <= 65535, XR_ERR_LIMIT, "apply: too many source variables in one call (%lld)", (long long)K);
     if (K == 1) launch_outer_cx<METHOD, SRC, 1>(o, src, K, out);
     else if (K == 2) launch_outer_cx<METHOD, SRC, 2>(o, src, K, out);
