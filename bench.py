@@ -341,7 +341,7 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy):
             "construct_ms": 1e3 * min(times), "construct_ms_max_of_3": 1e3 * max(times),
             "target_points_per_s": tgt_g.n_face / min(times), "nnz": rg._device_weights.nnz,
             "note": "source and target meshes resident; Voronoi pre-step (device + O(boundary) host part) + "
-            "xr_barycentric_csr; a fresh process measures 15-30 ms for the first construction",
+            "xr_barycentric_csr; the first constructions of a fresh process take longer (pool warm-up)",
         }
         del rg, src_g, tgt_g
     except Exception as e:  # noqa: BLE001

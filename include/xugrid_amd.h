@@ -154,6 +154,11 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
 int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points,
                        int64_t n, double tolerance, const int64_t *vertex_face,
                        const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
+/* the same with vertex_face given only for the vertices >= n_identity (vertex v < n_identity, a face centroid,
+ * belongs to source face v): spares the host an O(n) array and its upload */
+int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
+                            double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
+                            const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
 
 /* ---- Voronoi pre-step of BarycentricInterpolator (xugrid/ugrid/voronoi.py:330-458 as called from
  * xugrid/regrid/unstructured.py:151-165: add_exterior, add_vertices, skip_concave) ---------------------
@@ -174,6 +179,13 @@ int xr_voronoi_info(const xr_voronoi *v, int64_t *n_node, int64_t *nnz, int64_t 
  * int64[n_edge]) and, optionally, the face centroids float64[n_face, 2]. */
 int xr_voronoi_download(const xr_voronoi *v, int64_t *indptr, int64_t *indices, int64_t *edge_nodes,
                         int64_t *edge_face, double *centroids);
+/* The same information restricted to what the O(boundary) host part reads -- nothing of size O(n) crosses PCIe:
+ * the boundary nodes (end points of exterior edges, ascending), their rows of node_face_connectivity as a small
+ * CSR (row_ptr int64[n_boundary_node + 1], faces int64[n_boundary_entry]) with the centroid of every listed face
+ * (face_xy float64[n_boundary_entry, 2]), the exterior edges as above and the centroid of each edge's face. */
+int xr_voronoi_boundary_info(xr_voronoi *v, int64_t *n_boundary_node, int64_t *n_boundary_entry);
+int xr_voronoi_boundary(xr_voronoi *v, int64_t *nodes, int64_t *row_ptr, int64_t *faces, double *face_xy,
+                        int64_t *edge_nodes, int64_t *edge_face, double *edge_face_xy);
 /* extra_xy float64[n_extra_vertex, 2]: projections and substitute vertices (ids n_face ...);
  * boundary_cells int64[n_boundary_cell, n_max_boundary], -1 padded, counter-clockwise. */
 int xr_voronoi_mesh(const xr_voronoi *v, const double *extra_xy, int64_t n_extra_vertex,

@@ -56,6 +56,8 @@ SIGNATURES = {
     "xr_voronoi_create": (c_int, [vp, p_vp]),
     "xr_voronoi_info": (c_int, [vp, p_i64, p_i64, p_i64, p_i64, p_i64]),
     "xr_voronoi_download": (c_int, [vp, vp, vp, vp, vp, vp]),
+    "xr_voronoi_boundary_info": (c_int, [vp, vp, vp]),
+    "xr_voronoi_boundary": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "xr_voronoi_mesh": (c_int, [vp, vp, c_i64, vp, c_i64, c_i64, p_vp]),
     "xr_voronoi_destroy": (c_int, [vp]),
     "xr_overlap": (c_int, [vp, vp, c_int, p_vp]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "xr_barycentric": (c_int, [vp, vp, c_i64, c_f64, vp, vp]),
     "xr_locate_csr": (c_int, [vp, vp, vp, c_i64, c_f64, p_vp]),
     "xr_barycentric_csr": (c_int, [vp, vp, vp, vp, c_i64, c_f64, vp, vp, c_i64, p_vp]),
+    "xr_barycentric_csr_tail": (c_int, [vp, vp, vp, vp, c_i64, c_f64, c_i64, vp, vp, c_i64, p_vp]),
     "xr_csr_info": (c_int, [vp, p_i64, p_i64, p_i64]),
     "xr_csr_download": (c_int, [vp, vp, vp, vp]),
     "xr_csr_upload": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, p_vp]),

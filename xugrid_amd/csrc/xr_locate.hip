@@ -258,6 +258,11 @@ k_locate_fill(const int32_t *__restrict__ col, const int32_t *__restrict__ indpt
     data[indptr[i]] = 1.0;
 }
 
+__global__ void k_iota_i64(int64_t *__restrict__ p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = i;
+}
+
 static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
     if (tolerance >= 0) return tolerance;
     mesh_read_stats(mesh);
@@ -324,11 +329,16 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
     XR_API_END
 }
 
-int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
-                       double tolerance, const int64_t *vertex_face, const int64_t *node_to_node_map, int64_t n_extra,
-                       xr_csr **out) {
-    XR_API_BEGIN
-    XR_REQUIRE(voronoi && source && out && vertex_face, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
+// vertex v of the tessellation belongs to source face v for v < n_identity (the face centroids come first) and to
+// vertex_face[v - n_identity] beyond (projections: their face; substitute vertices: -1)
+static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
+                            double tolerance, int64_t n_identity, const int64_t *vertex_face,
+                            const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out) {
+    {
+    XR_REQUIRE(voronoi && source && out, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
+    XR_REQUIRE(n_identity >= 0 && n_identity <= voronoi->n_node && n_identity <= source->n_face &&
+                   (vertex_face || n_identity == voronoi->n_node),
+               XR_ERR_INVALID, "xr_barycentric_csr: bad vertex_face");
     XR_REQUIRE((query != nullptr) != (points != nullptr), XR_ERR_INVALID,
                "xr_barycentric_csr: give either a query mesh (its face centroids are the points) or points");
     if (query) n = query->n_face;
@@ -339,8 +349,9 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
     for (int64_t i = 0; i < 2 * n_extra; i++)
         XR_REQUIRE(node_to_node_map[i] >= 0 && node_to_node_map[i] < nv, XR_ERR_INVALID,
                    "xr_barycentric_csr: node_to_node_map entry %lld outside [0,%lld)", (long long)i, (long long)nv);
-    for (int64_t i = 0; i < nv - n_extra; i++)
-        XR_REQUIRE(vertex_face[i] >= 0 && vertex_face[i] < source->n_face, XR_ERR_INVALID,
+    XR_REQUIRE(n_identity <= nv - n_extra, XR_ERR_INVALID, "xr_barycentric_csr: more substitute vertices than vertices");
+    for (int64_t i = n_identity; i < nv - n_extra; i++)
+        XR_REQUIRE(vertex_face[i - n_identity] >= 0 && vertex_face[i - n_identity] < source->n_face, XR_ERR_INVALID,
                    "xr_barycentric_csr: vertex_face[%lld] outside the source grid", (long long)i);
     const int m = voronoi->m;
     xr_csr *csr = new xr_csr();
@@ -364,7 +375,10 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
                 n2n((size_t)(n_extra > 0 ? 2 * n_extra : 1));
             DevBuf<uint8_t> inside((size_t)n);
             DevBuf<int32_t> count((size_t)n);
-            h2d(vface.get(), vertex_face, sizeof(int64_t) * (size_t)nv);
+            if (n_identity > 0)
+                XR_LAUNCH("iota", k_iota_i64, dim3(div_up(n_identity, 256)), dim3(256), 0, vface.get(), n_identity);
+            if (nv > n_identity)
+                h2d(vface.get() + n_identity, vertex_face, sizeof(int64_t) * (size_t)(nv - n_identity));
             if (n_extra > 0) h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_extra);
             mesh_faces_ccw_dev(voronoi, faces_ccw.get());
             XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
@@ -390,6 +404,24 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
         throw;
     }
     *out = csr;
+    }
+}
+
+int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
+                       double tolerance, const int64_t *vertex_face, const int64_t *node_to_node_map, int64_t n_extra,
+                       xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(vertex_face, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
+    barycentric_csr(voronoi, source, query, points, n, tolerance, 0, vertex_face, node_to_node_map, n_extra, out);
+    XR_API_END
+}
+
+int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
+                            double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
+                            const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out) {
+    XR_API_BEGIN
+    barycentric_csr(voronoi, source, query, points, n, tolerance, n_identity, vertex_face_tail, node_to_node_map, n_extra,
+                    out);
     XR_API_END
 }
 

@@ -17,6 +17,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <cstring>
+
 #include "xr_objects.h"
 
 struct xr_voronoi {
@@ -31,6 +33,10 @@ struct xr_voronoi {
     int64_t n_interior = 0;
     int max_degree = 0, min_degree = 0; // over interior nodes
     std::vector<int64_t> edge_lo, edge_hi, edge_face; // exterior edges, lexicographic (lo, hi)
+    // the rows of the boundary nodes (what the O(boundary) host part reads), gathered on first request
+    bool boundary_ready = false;
+    std::vector<int64_t> b_nodes, b_ptr, b_faces; // ascending node ids, CSR offsets, faces ascending per node
+    std::vector<double> b_face_xy, b_edge_face_xy; // centroid of every listed face / of every exterior edge's face
 };
 
 namespace xr {
@@ -187,6 +193,81 @@ __global__ void __launch_bounds__(256) k_vor_widen(const int32_t *__restrict__ i
     if (i < n) out[i] = in[i];
 }
 
+// rows of selected nodes: degree, then faces + their centroids
+__global__ void k_vor_row_degree(const int32_t *__restrict__ indptr, const int64_t *__restrict__ nodes, int64_t n,
+                                 int64_t *__restrict__ deg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) deg[i] = indptr[nodes[i] + 1] - indptr[nodes[i]];
+}
+
+__global__ void k_vor_row_gather(const int32_t *__restrict__ indptr, const int32_t *__restrict__ faces_asc,
+                                 const double *__restrict__ centroids, const int64_t *__restrict__ nodes,
+                                 const int64_t *__restrict__ ptr, int64_t n, int64_t *__restrict__ faces,
+                                 double *__restrict__ xy) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int s = indptr[nodes[i]], e = indptr[nodes[i] + 1];
+    for (int r = s; r < e; r++) {
+        const int f = faces_asc[r];
+        const int64_t o = ptr[i] + (r - s);
+        faces[o] = f;
+        xy[2 * o] = centroids[2 * f];
+        xy[2 * o + 1] = centroids[2 * f + 1];
+    }
+}
+
+__global__ void k_vor_face_xy(const double *__restrict__ centroids, const int64_t *__restrict__ faces, int64_t n,
+                              double *__restrict__ xy) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    xy[2 * i] = centroids[2 * faces[i]];
+    xy[2 * i + 1] = centroids[2 * faces[i] + 1];
+}
+
+static void voronoi_boundary(xr_voronoi *v) {
+    if (v->boundary_ready) return;
+    std::vector<int64_t> nodes(v->edge_lo);
+    nodes.insert(nodes.end(), v->edge_hi.begin(), v->edge_hi.end());
+    std::sort(nodes.begin(), nodes.end());
+    nodes.erase(std::unique(nodes.begin(), nodes.end()), nodes.end());
+    const int64_t nb = (int64_t)nodes.size(), ne = (int64_t)v->edge_face.size();
+    v->b_nodes = nodes;
+    v->b_ptr.assign((size_t)nb + 1, 0);
+    v->b_faces.clear();
+    v->b_face_xy.clear();
+    v->b_edge_face_xy.assign((size_t)ne * 2, 0.0);
+    if (nb > 0) {
+        DevBuf<int64_t> d_nodes((size_t)nb), d_deg((size_t)nb), d_ptr((size_t)nb + 1);
+        h2d(d_nodes.get(), nodes.data(), sizeof(int64_t) * (size_t)nb);
+        XR_LAUNCH("vor_row_degree", k_vor_row_degree, dim3(div_up(nb, 256)), dim3(256), 0, v->indptr.get(), d_nodes.get(), nb,
+                  d_deg.get());
+        std::vector<int64_t> deg((size_t)nb);
+        d2h(deg.data(), d_deg.get(), sizeof(int64_t) * (size_t)nb);
+        for (int64_t i = 0; i < nb; i++) v->b_ptr[(size_t)i + 1] = v->b_ptr[(size_t)i] + deg[(size_t)i];
+        const int64_t total = v->b_ptr[(size_t)nb];
+        v->b_faces.resize((size_t)total);
+        v->b_face_xy.resize((size_t)total * 2);
+        if (total > 0) {
+            DevBuf<int64_t> d_faces((size_t)total);
+            DevBuf<double> d_xy((size_t)total * 2);
+            h2d(d_ptr.get(), v->b_ptr.data(), sizeof(int64_t) * (size_t)(nb + 1));
+            XR_LAUNCH("vor_row_gather", k_vor_row_gather, dim3(div_up(nb, 256)), dim3(256), 0, v->indptr.get(),
+                      v->faces_asc.get(), v->centroids.get(), d_nodes.get(), d_ptr.get(), nb, d_faces.get(), d_xy.get());
+            d2h(v->b_faces.data(), d_faces.get(), sizeof(int64_t) * (size_t)total);
+            d2h(v->b_face_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)total);
+        }
+    }
+    if (ne > 0) {
+        DevBuf<int64_t> d_ef((size_t)ne);
+        DevBuf<double> d_xy((size_t)ne * 2);
+        h2d(d_ef.get(), v->edge_face.data(), sizeof(int64_t) * (size_t)ne);
+        XR_LAUNCH("vor_face_xy", k_vor_face_xy, dim3(div_up(ne, 256)), dim3(256), 0, v->centroids.get(), d_ef.get(), ne,
+                  d_xy.get());
+        d2h(v->b_edge_face_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)ne);
+    }
+    v->boundary_ready = true;
+}
+
 } // namespace xr
 
 using namespace xr;
@@ -303,6 +384,38 @@ int xr_voronoi_download(const xr_voronoi *v, int64_t *indptr, int64_t *indices, 
         edge_face[i] = v->edge_face[i];
     }
     if (centroids && v->n_face > 0) d2h(centroids, v->centroids.get(), sizeof(double) * 2 * (size_t)v->n_face);
+    XR_API_END
+}
+
+int xr_voronoi_boundary_info(xr_voronoi *v, int64_t *n_boundary_node, int64_t *n_boundary_entry) {
+    XR_API_BEGIN
+    XR_REQUIRE(v && n_boundary_node && n_boundary_entry, XR_ERR_INVALID, "xr_voronoi_boundary_info: NULL argument");
+    voronoi_boundary(v);
+    *n_boundary_node = (int64_t)v->b_nodes.size();
+    *n_boundary_entry = (int64_t)v->b_faces.size();
+    XR_API_END
+}
+
+int xr_voronoi_boundary(xr_voronoi *v, int64_t *nodes, int64_t *row_ptr, int64_t *faces, double *face_xy,
+                        int64_t *edge_nodes, int64_t *edge_face, double *edge_face_xy) {
+    XR_API_BEGIN
+    XR_REQUIRE(v && row_ptr, XR_ERR_INVALID, "xr_voronoi_boundary: NULL argument");
+    voronoi_boundary(v);
+    const size_t nb = v->b_nodes.size(), nf = v->b_faces.size(), ne = v->edge_face.size();
+    XR_REQUIRE((nb == 0 || nodes) && (nf == 0 || (faces && face_xy)) && (ne == 0 || (edge_nodes && edge_face && edge_face_xy)),
+               XR_ERR_INVALID, "xr_voronoi_boundary: NULL output array");
+    if (nb) memcpy(nodes, v->b_nodes.data(), sizeof(int64_t) * nb);
+    memcpy(row_ptr, v->b_ptr.data(), sizeof(int64_t) * (nb + 1));
+    if (nf) {
+        memcpy(faces, v->b_faces.data(), sizeof(int64_t) * nf);
+        memcpy(face_xy, v->b_face_xy.data(), sizeof(double) * 2 * nf);
+    }
+    for (size_t i = 0; i < ne; i++) {
+        edge_nodes[2 * i] = v->edge_lo[i];
+        edge_nodes[2 * i + 1] = v->edge_hi[i];
+        edge_face[i] = v->edge_face[i];
+    }
+    if (ne) memcpy(edge_face_xy, v->b_edge_face_xy.data(), sizeof(double) * 2 * ne);
     XR_API_END
 }
 

@@ -194,6 +194,28 @@ class DeviceVoronoi:
         )
         return indptr, indices, edge_nodes, edge_face, centroids
 
+    def download_boundary(self):
+        """What the O(boundary) host part of the Voronoi step reads, and nothing else: ``(nodes, row_ptr, faces,
+        face_xy, edge_nodes, edge_face, edge_face_xy)`` -- the boundary nodes (ascending), their rows of
+        node_face_connectivity as a small CSR with the centroid of every listed face, the exterior edges and the
+        centroid of each edge's face."""
+        nb, ne = ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().xr_voronoi_boundary_info(self._h, ctypes.byref(nb), ctypes.byref(ne)))
+        nodes = np.empty(nb.value, dtype=np.int64)
+        row_ptr = np.empty(nb.value + 1, dtype=np.int64)
+        faces = np.empty(ne.value, dtype=np.int64)
+        face_xy = np.empty((ne.value, 2), dtype=np.float64)
+        edge_nodes = np.empty((self.n_exterior_edge, 2), dtype=np.int64)
+        edge_face = np.empty(self.n_exterior_edge, dtype=np.int64)
+        edge_face_xy = np.empty((self.n_exterior_edge, 2), dtype=np.float64)
+        check(
+            _lib.load().xr_voronoi_boundary(
+                self._h, _ptr(nodes), _ptr(row_ptr), _ptr(faces), _ptr(face_xy), _ptr(edge_nodes), _ptr(edge_face),
+                _ptr(edge_face_xy),
+            )
+        )
+        return nodes, row_ptr, faces, face_xy, edge_nodes, edge_face, edge_face_xy
+
     def assemble(self, extra_xy, boundary_cells) -> DeviceMesh:
         extra_xy = np.ascontiguousarray(extra_xy, dtype=np.float64).reshape(-1, 2)
         cells = np.ascontiguousarray(boundary_cells, dtype=np.int64)
@@ -270,10 +292,12 @@ def locate_csr(tree: DeviceMesh, query: DeviceMesh = None, points=None, toleranc
 
 
 def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,
-                    points=None, tolerance=None) -> "DeviceCSR":
-    """UnstructuredGrid2d.barycentric after the Voronoi pre-step, on the device (see include/xugrid_amd.h)."""
+                    points=None, tolerance=None, n_identity=0) -> "DeviceCSR":
+    """UnstructuredGrid2d.barycentric after the Voronoi pre-step, on the device (see include/xugrid_amd.h).
+    ``n_identity`` > 0: ``vertex_face`` holds only the entries of the vertices ``>= n_identity`` (the first
+    ``n_identity`` vertices are the source face centroids, in face order)."""
     vertex_face = np.ascontiguousarray(vertex_face, dtype=np.int64)
-    if vertex_face.shape != (voronoi.n_node,):
+    if vertex_face.shape != (voronoi.n_node - n_identity,):
         raise ValueError("vertex_face must have one entry per Voronoi vertex")
     if node_to_node_map is None:
         n2n = np.zeros((0, 2), dtype=np.int64)
@@ -290,11 +314,20 @@ def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_t
     else:
         p_arg, n, q_arg = None, query.n_face, query._h
     handle = ctypes.c_void_p()
-    check(
-        _lib.load().xr_barycentric_csr(
-            voronoi._h, source._h, q_arg, p_arg, n, tol, _ptr(vertex_face), _ptr(n2n), n2n.shape[0], ctypes.byref(handle)
+    if n_identity:
+        check(
+            _lib.load().xr_barycentric_csr_tail(
+                voronoi._h, source._h, q_arg, p_arg, n, tol, int(n_identity), _ptr(vertex_face), _ptr(n2n), n2n.shape[0],
+                ctypes.byref(handle),
+            )
         )
-    )
+    else:
+        check(
+            _lib.load().xr_barycentric_csr(
+                voronoi._h, source._h, q_arg, p_arg, n, tol, _ptr(vertex_face), _ptr(n2n), n2n.shape[0],
+                ctypes.byref(handle),
+            )
+        )
     return DeviceCSR(handle)
 
 

@@ -106,14 +106,17 @@ class UnstructuredGrid2d:
         pre-step -- locate + weights, exterior-vertex replacement, masking, compaction -- runs in HBM."""
         from .. import engine, voronoi
 
-        voronoi_mesh, node_to_face_index, node_to_node_map = voronoi.voronoi_topology_device(self.ugrid_topology)
+        voronoi_mesh, face_index_tail, node_to_node_map = voronoi.voronoi_topology_device(
+            self.ugrid_topology, compact=True
+        )
         return engine.barycentric_csr(
             voronoi_mesh,
             self.ugrid_topology.device_mesh,
-            node_to_face_index,
+            face_index_tail,
             node_to_node_map,
             query=other.ugrid_topology.device_mesh,
             tolerance=tolerance,
+            n_identity=self.ugrid_topology.n_face,
         )
 
     def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):

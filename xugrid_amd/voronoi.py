@@ -199,32 +199,50 @@ def voronoi_topology(
     return table, cells, face_index, interp_map
 
 
-def voronoi_topology_device(grid):
+def voronoi_topology_device(grid, compact=False):
     """
     ``voronoi_topology(..., add_exterior=True, add_vertices=True, skip_concave=True)`` of a Ugrid2d with the
     O(n) part on the device (node -> face inversion, exterior edges, counter-clockwise interior cells, assembly;
-    xugrid_amd/csrc/xr_voronoi.hip) and only the cells of the boundary nodes on the host.
+    xugrid_amd/csrc/xr_voronoi.hip) and only the cells of the boundary nodes on the host, computed on a LOCAL
+    problem (boundary nodes, the faces around them) from a few KB the device gathers -- nothing of size O(n)
+    crosses PCIe or is touched by numpy.
 
     Returns (DeviceMesh of the tessellation, face_index, interpolation_map): the mesh has the same vertices and
-    cells, in the same order, as the host function returns as arrays.
+    cells, in the same order, as the host function returns as arrays.  ``compact=True``: ``face_index`` holds only
+    the entries of the vertices beyond the ``n_face`` face centroids (the others are the identity).
     """
     from . import engine
 
     builder = engine.DeviceVoronoi(grid.device_mesh)
-    indptr, indices, edge_nodes, edge_face, centroids = builder.download()
     n_face = grid.n_face
-    nfc = scipy.sparse.csr_matrix(
-        (np.ones(indices.size, dtype=np.int8), indices, indptr), shape=(builder.n_node, n_face)
-    )
+    nodes, row_ptr, faces, face_xy, edge_nodes, edge_face, edge_face_xy = builder.download_boundary()
     if edge_face.size:
-        table, bkeys, bids, face_index, interp_map = _boundary_records(
-            nfc, grid.node_coordinates, centroids, edge_nodes, edge_face, True, True
+        # local numbering: boundary nodes 0..nb-1 (ascending = same order as their global ids), needed faces
+        # 0..nl-1 (ascending), so every sort and grouping below sees the order it would see globally
+        needed, inverse = np.unique(np.concatenate([faces, edge_face]), return_inverse=True)
+        nl = needed.size
+        cen = np.empty((nl, 2))
+        cen[inverse[: faces.size]] = face_xy
+        cen[inverse[faces.size:]] = edge_face_xy
+        nfc = scipy.sparse.csr_matrix(
+            (np.ones(faces.size, dtype=np.int8), inverse[: faces.size], row_ptr), shape=(nodes.size, nl)
         )
-        cells = _pack_rows(bkeys, bids)
-        extra = table[n_face:]
+        node_xy = np.column_stack([grid.node_x[nodes], grid.node_y[nodes]])
+        table, bkeys, bids, findex, interp_map = _boundary_records(
+            nfc, node_xy, cen, np.searchsorted(nodes, edge_nodes), inverse[faces.size:], True, True
+        )
+        shift = n_face - nl  # local id of an added vertex -> its global id
+        bids = np.where(bids < nl, needed[np.minimum(bids, nl - 1)], bids + shift)
+        cells = _pack_rows(bkeys, bids)  # (local keys: same grouping and order as the global node ids)
+        extra = table[nl:]
+        tail = findex[nl:]
+        tail = np.where(tail >= 0, needed[np.maximum(tail, 0)], -1).astype(IntDType)
+        interp_map = interp_map + shift
     else:  # closed surface: nothing to add
         cells = np.zeros((0, 3), dtype=IntDType)
         extra = np.zeros((0, 2))
-        face_index, interp_map = np.arange(n_face), np.zeros((0, 2), dtype=IntDType)
+        tail, interp_map = np.zeros(0, dtype=IntDType), np.zeros((0, 2), dtype=IntDType)
     mesh = builder.assemble(extra, cells)
-    return mesh, face_index, interp_map
+    if compact:
+        return mesh, tail, interp_map
+    return mesh, np.concatenate([np.arange(n_face, dtype=IntDType), tail]), interp_map
