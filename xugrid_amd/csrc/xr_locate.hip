@@ -94,7 +94,8 @@ k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len
 // Wachspress coordinates with the on-edge special case; triangles use plain area coordinates.
 // w points at this point's row of the (n, m) weight table (global memory, zero-initialised);
 // weights are aligned with the CCW-normalised vertex order of the face (as numba_celltree's).
-__device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, double tol, double *__restrict__ w) {
+__device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, double tol, double *__restrict__ w,
+                             int64_t ws = 1) {
     // pass 1: on-edge detection
     for (int i = 0; i < n; i++) {
         const P2 v0 = load_p2(poly, i), v1 = load_p2(poly, (i + 1) % n);
@@ -110,8 +111,8 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
                     double tt = tpar / len2;
                     if (tt < 0) tt = 0;
                     if (tt > 1) tt = 1;
-                    w[i] = 1.0 - tt;
-                    w[(i + 1) % n] = tt;
+                    w[(i) * ws] = 1.0 - tt;
+                    w[((i + 1) % n) * ws] = tt;
                     return;
                 }
             }
@@ -126,9 +127,9 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
     if (n == 3) {
         const double a0 = A(0), a1 = A(1), a2 = A(2);
         const double s = a0 + a1 + a2;
-        w[0] = a1 / s;
-        w[1] = a2 / s;
-        w[2] = a0 / s;
+        w[(0) * ws] = a1 / s;
+        w[(1) * ws] = a2 / s;
+        w[(2) * ws] = a0 / s;
         return;
     }
     double wsum = 0.0;
@@ -137,10 +138,10 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
         const P2 vp = load_p2(poly, ip), vi = load_p2(poly, i), vn = load_p2(poly, in);
         const double cx = (vi.x - vp.x) * (vn.y - vi.y) - (vi.y - vp.y) * (vn.x - vi.x);
         const double wi = cx / (A(ip) * A(i));
-        w[i] = wi;
+        w[(i) * ws] = wi;
         wsum += wi;
     }
-    for (int i = 0; i < n; i++) w[i] = w[i] / wsum;
+    for (int i = 0; i < n; i++) w[(i) * ws] = w[(i) * ws] / wsum;
 }
 
 __global__ void __launch_bounds__(256)
@@ -159,6 +160,26 @@ k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
 }
 
 // ---- BarycentricInterpolator weights assembled on the device (xr_barycentric_csr) ----------------
+// The (n, m) weight table of this pipeline is kept COLUMN-major (weight j of point i at [j * n + i]): the lanes of a
+// wave are neighbouring points, so every access is coalesced, and only the first len(cell) slots of a point are ever
+// touched (m is the largest cell of the tessellation, 15-25 corners at the hull; the typical cell has 6).
+
+__global__ void __launch_bounds__(256)
+k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+                 const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+                 const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+                 int64_t *__restrict__ face_out, double *__restrict__ weights) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const P2 p = load_p2(pts, (int)i);
+    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    face_out[i] = r >= 0 ? rec_face[r] : -1;
+    if (r < 0) return;
+    double *w = weights + i;
+    const int len = rec_len[r];
+    for (int j = 0; j < len; j++) w[(int64_t)j * n] = 0.0;
+    bary_weights(rec_fxy + (int64_t)r * m * 2, len, p, tol, w, n);
+}
 
 __global__ void __launch_bounds__(256)
 k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
@@ -183,34 +204,32 @@ k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__
     if (i >= n) return;
     const int64_t f = face_of_point[i];
     int c = 0;
-    if (f >= 0) {
-        double *w = weights + i * m;
-        if (!inside[i]) {
-            for (int j = 0; j < m; j++) w[j] = 0.0;
-        } else {
-            const int64_t *face = faces_ccw + f * m;
-            for (int j = 0; j < m; j++) {
-                const int64_t pidx = face[j];
-                const double wj = w[j];
-                if (pidx < threshold || wj <= 0) continue;
-                const int64_t index = pidx - threshold;
-                const int64_t q = node_to_node_map[2 * index], r = node_to_node_map[2 * index + 1];
-                const double px = vxy[2 * pidx], py = vxy[2 * pidx + 1];
-                const double qx = vxy[2 * q], qy = vxy[2 * q + 1];
-                const double rx = vxy[2 * r], ry = vxy[2 * r + 1];
-                const double p_q = sqrt((qx - px) * (qx - px) + (qy - py) * (qy - py));
-                const double p_r = sqrt((rx - px) * (rx - px) + (ry - py) * (ry - py));
-                const double total = p_q + p_r;
-                const double weight_q = (p_r / total) * wj;
-                const double weight_r = (p_q / total) * wj;
-                w[j] = 0.0;
-                for (int jj = 0; jj < m; jj++) {
-                    if (face[jj] == q) w[jj] += weight_q;
-                    if (face[jj] == r) w[jj] += weight_r;
-                }
+    if (f >= 0 && inside[i]) { // (a point outside the source grid keeps no weight, unstructured.py:189-190)
+        double *w = weights + i;
+        const int64_t *face = faces_ccw + f * m;
+        int len = 0;
+        while (len < m && face[len] >= 0) len++; // (-1 fill behind the cell's corners)
+        for (int j = 0; j < len; j++) {
+            const int64_t pidx = face[j];
+            const double wj = w[(int64_t)j * n];
+            if (pidx < threshold || wj <= 0) continue;
+            const int64_t index = pidx - threshold;
+            const int64_t q = node_to_node_map[2 * index], r = node_to_node_map[2 * index + 1];
+            const double px = vxy[2 * pidx], py = vxy[2 * pidx + 1];
+            const double qx = vxy[2 * q], qy = vxy[2 * q + 1];
+            const double rx = vxy[2 * r], ry = vxy[2 * r + 1];
+            const double p_q = sqrt((qx - px) * (qx - px) + (qy - py) * (qy - py));
+            const double p_r = sqrt((rx - px) * (rx - px) + (ry - py) * (ry - py));
+            const double total = p_q + p_r;
+            const double weight_q = (p_r / total) * wj;
+            const double weight_r = (p_q / total) * wj;
+            w[(int64_t)j * n] = 0.0;
+            for (int jj = 0; jj < len; jj++) {
+                if (face[jj] == q) w[(int64_t)jj * n] += weight_q;
+                if (face[jj] == r) w[(int64_t)jj * n] += weight_r;
             }
-            for (int j = 0; j < m; j++) c += w[j] > 0;
         }
+        for (int j = 0; j < len; j++) c += w[(int64_t)j * n] > 0;
     }
     count[i] = c;
 }
@@ -225,11 +244,12 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
     int pos = indptr[i];
     if (indptr[i + 1] == pos) return;
     const int64_t *face = faces_ccw + face_of_point[i] * m;
-    const double *w = weights + i * m;
-    for (int j = 0; j < m; j++) {
-        if (w[j] > 0) {
+    const double *w = weights + i;
+    for (int j = 0; j < m && face[j] >= 0; j++) {
+        const double wj = w[(int64_t)j * n];
+        if (wj > 0) {
             indices[pos] = (int32_t)vertex_face[face[j]];
-            data[pos] = w[j];
+            data[pos] = wj;
             pos++;
         }
     }
@@ -381,7 +401,7 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                 h2d(vface.get() + n_identity, vertex_face, sizeof(int64_t) * (size_t)(nv - n_identity));
             if (n_extra > 0) h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_extra);
             mesh_faces_ccw_dev(voronoi, faces_ccw.get());
-            XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
+            XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
                       voronoi->rec_face.get(), pts.get(), n, tol, face.get(), w.get());
             XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
