@@ -95,6 +95,14 @@ int xr_version(void);
  * xr_mesh_build_index. */
 int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int faces_itemsize,
                    int64_t n_face, int64_t n_max_node, int64_t fill_value, xr_mesh **out);
+/* The quad mesh of a rectilinear grid, generated on the device: Ugrid2d.from_structured_bounds ->
+ * _from_intervals_helper (xugrid/ugrid/ugrid2d.py:1973-2034, :1894-1912), which is how a raster enters the polygon
+ * path when the other grid is unstructured (StructuredGrid2d.convert_to, regrid/structured.py:489-501).
+ * x_vertices float64[nx + 1], y_vertices float64[ny + 1]: the cell edges in the raster's own order (ascending or
+ * descending).  Nodes in meshgrid order (node id = j * (nx + 1) + i), face id = j * nx + i, corners
+ * counter-clockwise for ascending axes.  Only the two 1-D arrays cross PCIe. */
+int xr_mesh_create_rectilinear(const double *x_vertices, int64_t nx, const double *y_vertices, int64_t ny,
+                               xr_mesh **out);
 int xr_mesh_destroy(xr_mesh *mesh);
 int xr_mesh_info(const xr_mesh *mesh, int64_t *n_node, int64_t *n_face, int64_t *n_max_node);
 /* Per-face preparation on the device: fill->-1, polygon length, CCW normalisation, bbox, area. */

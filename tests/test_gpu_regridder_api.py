@@ -449,3 +449,46 @@ def test_weights_file_round_trip(hip, tmp_path):
         rg.to_file(path)
         again = type(rg).from_file(path)
         assert np.array_equal(again.regrid(data), rg.regrid(data), equal_nan=True)
+
+
+def test_rectilinear_mesh_generated_on_device(hip):
+    """xr_mesh_create_rectilinear == Ugrid2d.from_structured_bounds (ugrid2d.py:1973-2034) for every combination
+    of ascending / descending axes; the regridders take rasters through it without host copies of the quads."""
+    from xugrid_amd.engine import DeviceMesh
+    from xugrid_amd.regrid.structured import StructuredGrid2d
+    from xugrid_amd.ugrid2d import RectilinearUgrid2d
+
+    rng = np.random.default_rng(5)
+    for flip_x in (False, True):
+        for flip_y in (False, True):
+            xv = np.concatenate(([0.0], np.cumsum(rng.uniform(0.5, 2.0, 37))))
+            yv = np.concatenate(([-3.0], -3.0 + np.cumsum(rng.uniform(0.5, 2.0, 23))))
+            xv, yv = (xv[::-1].copy() if flip_x else xv), (yv[::-1].copy() if flip_y else yv)
+            x_bounds = np.column_stack([np.minimum(xv[:-1], xv[1:]), np.maximum(xv[:-1], xv[1:])])
+            y_bounds = np.column_stack([np.minimum(yv[:-1], yv[1:]), np.maximum(yv[:-1], yv[1:])])
+            host = xa.Ugrid2d.from_structured_bounds(x_bounds, y_bounds)
+            dev = xa.Ugrid2d.from_structured_bounds_device(x_bounds, y_bounds)
+            assert isinstance(dev, RectilinearUgrid2d) and dev._host is None
+            assert (dev.n_node, dev.n_face, dev.n_max_node_per_face) == (host.n_node, host.n_face, 4)
+            xy, faces = dev.device_mesh.download()
+            assert dev._host is None  # nothing was materialised on the host
+            assert np.array_equal(xy, host.node_coordinates) and np.array_equal(faces, host.face_node_connectivity)
+            assert np.array_equal(dev.area, host.area) and np.array_equal(dev.centroids, host.centroids)
+            assert np.array_equal(dev.face_node_connectivity, host.face_node_connectivity)  # lazy host copy
+    # a raster target through the regridder: same weights as with the host-built quads
+    sxy, sf = meshgen.triangle_mesh(3000, 0)
+    src = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    raster = xa.Raster(x=np.linspace(0.05, 0.95, 40), y=np.linspace(0.9, 0.1, 33))
+    rg = xa.OverlapRegridder(src, raster, method="mean")
+    quads = xa.Ugrid2d.from_structured_bounds(
+        StructuredGrid2d(raster).xbounds.directional_bounds, StructuredGrid2d(raster).ybounds.directional_bounds
+    )
+    ref = xa.OverlapRegridder(src, quads, method="mean")
+    a, b = rg.weights_as_dataframe(), ref.weights_as_dataframe()
+    assert a.equals(b)
+    data = np.random.default_rng(0).normal(size=src.n_face)
+    assert np.array_equal(rg.regrid(data).ravel(), ref.regrid(data), equal_nan=True)
+    with pytest.raises(ValueError):
+        DeviceMesh.from_rectilinear(np.array([0.0, np.nan, 2.0]), np.array([0.0, 1.0]))
+    with pytest.raises(ValueError):
+        DeviceMesh.from_rectilinear(np.array([0.0]), np.array([0.0, 1.0]))

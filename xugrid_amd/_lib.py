@@ -44,6 +44,7 @@ SIGNATURES = {
     "xr_trim_pool": (c_int, []),
     "xr_version": (c_int, []),
     "xr_mesh_create": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),
+    "xr_mesh_create_rectilinear": (c_int, [vp, c_i64, vp, c_i64, p_vp]),
     "xr_mesh_destroy": (c_int, [vp]),
     "xr_mesh_info": (c_int, [vp, p_i64, p_i64, p_i64]),
     "xr_mesh_prepare": (c_int, [vp]),

@@ -21,6 +21,16 @@ class CellTree2d:
         self.cells_per_leaf = cells_per_leaf
         self.device_mesh = DeviceMesh(self.vertices, self.faces, fill_value)
 
+    @classmethod
+    def from_device_mesh(cls, device_mesh: DeviceMesh, fill_value=-1):
+        """Adapter around a mesh that already lives on the device (no host copy of its arrays is kept)."""
+        self = cls.__new__(cls)
+        self.vertices = self.faces = None
+        self.fill_value = fill_value
+        self.n_buckets, self.cells_per_leaf = 4, 2
+        self.device_mesh = device_mesh
+        return self
+
     def intersect_faces(self, vertices, faces, fill_value=-1):
         """
         Find all (query face, tree face) pairs with a positive intersection area

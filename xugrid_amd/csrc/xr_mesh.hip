@@ -549,11 +549,73 @@ void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev) {
                   mesh->faces_raw.get(), mesh->n_face, mesh->m, faces_dev);
 }
 
+// Ugrid2d.from_structured_bounds -> _from_intervals_helper (xugrid/ugrid/ugrid2d.py:1973-2034, :1894-1912) on the
+// device: the (ny + 1) x (nx + 1) vertices of a rectilinear grid (node id = j * (nx + 1) + i, the meshgrid order) and
+// one quad per cell (face id = j * nx + i), corners lower-left, lower-right, upper-right, upper-left with "left" and
+// "lower" following the direction of the vertex arrays (a descending axis swaps them).
+__global__ void __launch_bounds__(256)
+k_rect_nodes(const double *__restrict__ xv, const double *__restrict__ yv, int64_t nx1, int64_t n_node,
+             double *__restrict__ node_xy) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n_node) return;
+    const int64_t j = v / nx1, i = v - j * nx1;
+    reinterpret_cast<double2 *>(node_xy)[v] = make_double2(xv[i], yv[j]);
+}
+
+__global__ void __launch_bounds__(256)
+k_rect_faces(int64_t nx, int64_t n_face, bool flip_x, bool flip_y, int32_t *__restrict__ faces) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    const int64_t j = f / nx, i = f - j * nx;
+    const int64_t left = flip_x ? i + 1 : i, right = flip_x ? i : i + 1;
+    const int64_t lower = flip_y ? j + 1 : j, upper = flip_y ? j : j + 1;
+    const int64_t nx1 = nx + 1;
+    reinterpret_cast<int4 *>(faces)[f] = make_int4((int)(lower * nx1 + left), (int)(lower * nx1 + right),
+                                                   (int)(upper * nx1 + right), (int)(upper * nx1 + left));
+}
+
 } // namespace xr
 
 using namespace xr;
 
 extern "C" {
+
+int xr_mesh_create_rectilinear(const double *x_vertices, int64_t nx, const double *y_vertices, int64_t ny,
+                               xr_mesh **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out && x_vertices && y_vertices, XR_ERR_INVALID, "xr_mesh_create_rectilinear: NULL argument");
+    XR_REQUIRE(nx >= 1 && ny >= 1, XR_ERR_INVALID, "xr_mesh_create_rectilinear: at least one cell per axis expected");
+    const int64_t n_node = (nx + 1) * (ny + 1), n_face = nx * ny;
+    XR_REQUIRE((nx + 1) < ((int64_t)1 << 31) / (ny + 1) && n_face * 4 < ((int64_t)1 << 31), XR_ERR_LIMIT,
+               "xr_mesh_create_rectilinear: mesh exceeds the int32 index range");
+    for (int64_t i = 0; i <= nx; i++)
+        XR_REQUIRE(x_vertices[i] == x_vertices[i], XR_ERR_INVALID, "xr_mesh_create_rectilinear: NaN x vertex %lld", (long long)i);
+    for (int64_t j = 0; j <= ny; j++)
+        XR_REQUIRE(y_vertices[j] == y_vertices[j], XR_ERR_INVALID, "xr_mesh_create_rectilinear: NaN y vertex %lld", (long long)j);
+    engine();
+    xr_mesh *mesh = new xr_mesh();
+    try {
+        mesh->n_node = n_node;
+        mesh->n_face = n_face;
+        mesh->m = 4;
+        mesh->node_xy.alloc((size_t)n_node * 2);
+        mesh->faces_raw.alloc((size_t)n_face * 4);
+        DevBuf<double> xv((size_t)nx + 1), yv((size_t)ny + 1);
+        h2d(xv.get(), x_vertices, sizeof(double) * (size_t)(nx + 1));
+        h2d(yv.get(), y_vertices, sizeof(double) * (size_t)(ny + 1));
+        XR_LAUNCH("rect_nodes", k_rect_nodes, dim3(div_up(n_node, 256)), dim3(256), 0, xv.get(), yv.get(), nx + 1, n_node,
+                  mesh->node_xy.get());
+        // (ugrid2d.py:1904-1909: the tests read the flattened vertex arrays; see _from_intervals_helper in ugrid2d.py)
+        XR_LAUNCH("rect_faces", k_rect_faces, dim3(div_up(n_face, 256)), dim3(256), 0, nx, n_face,
+                  x_vertices[1] < x_vertices[0], y_vertices[1] < y_vertices[0], mesh->faces_raw.get());
+        stream_sync();
+    } catch (...) {
+        delete mesh;
+        throw;
+    }
+    *out = mesh;
+    XR_API_END
+}
 
 int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int faces_itemsize, int64_t n_face,
                    int64_t n_max_node, int64_t fill_value, xr_mesh **out) {

@@ -73,6 +73,18 @@ class DeviceMesh:
         self.n_node, self.n_face, self.n_max_node = n_node.value, n_face.value, m.value
         return self
 
+    @classmethod
+    def from_rectilinear(cls, x_vertices, y_vertices):
+        """The quad mesh of a rectilinear grid generated on the device from its two 1-D vertex arrays (cell edges
+        in the raster's own order): include/xugrid_amd.h, xr_mesh_create_rectilinear."""
+        xv = np.ascontiguousarray(x_vertices, dtype=np.float64)
+        yv = np.ascontiguousarray(y_vertices, dtype=np.float64)
+        if xv.ndim != 1 or yv.ndim != 1 or xv.size < 2 or yv.size < 2:
+            raise ValueError("x_vertices and y_vertices must be 1-D arrays of at least two vertices")
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_mesh_create_rectilinear(_ptr(xv), xv.size - 1, _ptr(yv), yv.size - 1, ctypes.byref(handle)))
+        return cls._from_handle(handle)
+
     def download(self):
         """-> (node_xy float64[n_node, 2], faces int64[n_face, n_max_node]) as uploaded / assembled."""
         xy = np.empty((self.n_node, 2), dtype=np.float64)

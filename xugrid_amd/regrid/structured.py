@@ -272,7 +272,8 @@ class StructuredGrid2d:
             return self
         if matched_type == UnstructuredGrid2d:
             if self._unstructured is None:
-                ugrid2d = Ugrid2d.from_structured_bounds(
+                # (the quads are generated on the device; host copies only if somebody asks for them)
+                ugrid2d = Ugrid2d.from_structured_bounds_device(
                     self.xbounds.directional_bounds, self.ybounds.directional_bounds
                 )
                 self._unstructured = UnstructuredGrid2d(ugrid2d)

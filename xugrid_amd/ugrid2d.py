@@ -196,6 +196,19 @@ class Ugrid2d:
         node_y, node_x = (a.ravel() for a in np.meshgrid(y, x, indexing="ij"))
         return Ugrid2d._from_intervals_helper(node_x, node_y, nx, ny, name)
 
+    @staticmethod
+    def from_structured_bounds_device(x_bounds, y_bounds, name="mesh2d"):
+        """``from_structured_bounds`` with the mesh generated on the device: only the two 1-D vertex arrays are
+        uploaded; the host copies of the node and face arrays are made on first access (persistence, host
+        connectivities), never for regridding."""
+        x_bounds = np.asarray(x_bounds, dtype=FloatDType)
+        y_bounds = np.asarray(y_bounds, dtype=FloatDType)
+        if x_bounds.ndim != 2 or y_bounds.ndim != 2:
+            raise ValueError(f"Expected 2 dimensions on bounds, received: {x_bounds.ndim}")
+        return RectilinearUgrid2d(
+            connectivity.bounds1d_to_vertices(x_bounds), connectivity.bounds1d_to_vertices(y_bounds), name
+        )
+
     # ---- persistence (plain dict of arrays; xarray is optional and absent here)
     def to_dataset(self, prefix=None):
         name = prefix if prefix is not None else self.name
@@ -214,3 +227,61 @@ class Ugrid2d:
             np.asarray(dataset[f"{name}_face_nodes"]),
             name=name,
         )
+
+
+class RectilinearUgrid2d(Ugrid2d):
+    """The quads of a rectilinear grid (``Ugrid2d.from_structured_bounds``, ugrid2d.py:1973-2034) whose node and
+    face arrays exist on the DEVICE only: ``xr_mesh_create_rectilinear`` generates them from the two 1-D vertex
+    arrays.  The host arrays of the base class are materialised lazily, on the first access of ``node_x`` /
+    ``node_y`` / ``face_node_connectivity`` (persistence, host-side connectivities)."""
+
+    def __init__(self, x_vertices, y_vertices, name="mesh2d"):
+        self._xv = np.ascontiguousarray(x_vertices, dtype=FloatDType)
+        self._yv = np.ascontiguousarray(y_vertices, dtype=FloatDType)
+        if self._xv.ndim != 1 or self._yv.ndim != 1 or self._xv.size < 2 or self._yv.size < 2:
+            raise ValueError("a rectilinear grid needs at least one cell per axis")
+        self._host = None
+        self.fill_value = FILL_VALUE
+        self.start_index = 0
+        self.name = name
+        self._celltree = None
+        self._area = None
+        self._centroids = None
+        self._edge_node_connectivity = None
+        self._face_edge_connectivity = None
+        self._edge_face_connectivity = None
+        self._node_face_connectivity = None
+
+    def _materialise(self):
+        if self._host is None:
+            node_y, node_x = (a.ravel() for a in np.meshgrid(self._yv, self._xv, indexing="ij"))
+            self._host = Ugrid2d._from_intervals_helper(node_x, node_y, self._xv.size - 1, self._yv.size - 1, self.name)
+        return self._host
+
+    node_x = property(lambda self: self._materialise().node_x)
+    node_y = property(lambda self: self._materialise().node_y)
+    face_node_connectivity = property(lambda self: self._materialise().face_node_connectivity)
+
+    @property
+    def n_node(self):
+        return self._xv.size * self._yv.size
+
+    @property
+    def n_face(self):
+        return (self._xv.size - 1) * (self._yv.size - 1)
+
+    @property
+    def n_max_node_per_face(self):
+        return 4
+
+    @property
+    def bounds(self):
+        return (self._xv.min(), self._yv.min(), self._xv.max(), self._yv.max())
+
+    @property
+    def celltree(self) -> CellTree2d:
+        if self._celltree is None:
+            from .engine import DeviceMesh
+
+            self._celltree = CellTree2d.from_device_mesh(DeviceMesh.from_rectilinear(self._xv, self._yv))
+        return self._celltree
