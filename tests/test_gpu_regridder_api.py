@@ -492,3 +492,20 @@ def test_rectilinear_mesh_generated_on_device(hip):
         DeviceMesh.from_rectilinear(np.array([0.0, np.nan, 2.0]), np.array([0.0, 1.0]))
     with pytest.raises(ValueError):
         DeviceMesh.from_rectilinear(np.array([0.0]), np.array([0.0, 1.0]))
+
+
+def test_barycentric_from_raster_source_paired_with_mesh(hip):
+    """A raster source paired with an unstructured target is promoted to device-generated quads; the Voronoi
+    pre-step then only needs the coordinates of the boundary nodes, which come from the two 1-D vertex arrays --
+    the host copies of the quads are never made.  Same weights as with host-built quads."""
+    from xugrid_amd.regrid.structured import StructuredGrid2d
+
+    raster = xa.Raster(x=np.linspace(0.0, 1.0, 30), y=np.linspace(1.0, 0.0, 25))
+    txy, tf = meshgen.triangle_mesh(2000, 4, 10.0, 0.8)
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    rg = xa.BarycentricInterpolator(raster, tgt)
+    assert rg._source._unstructured.ugrid_topology._host is None
+    grid = StructuredGrid2d(raster)
+    quads = xa.Ugrid2d.from_structured_bounds(grid.xbounds.directional_bounds, grid.ybounds.directional_bounds)
+    ref = xa.BarycentricInterpolator(quads, tgt)
+    assert rg.weights_as_dataframe().equals(ref.weights_as_dataframe())

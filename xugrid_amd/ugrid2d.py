@@ -78,6 +78,10 @@ class Ugrid2d:
     def bounds(self):
         return (self.node_x.min(), self.node_y.min(), self.node_x.max(), self.node_y.max())
 
+    def node_coordinates_of(self, nodes):
+        """(len(nodes), 2) coordinates of the given node ids."""
+        return np.column_stack([self.node_x[nodes], self.node_y[nodes]])
+
     # ---- device-backed geometry
     @property
     def celltree(self) -> CellTree2d:
@@ -277,6 +281,11 @@ class RectilinearUgrid2d(Ugrid2d):
     @property
     def bounds(self):
         return (self._xv.min(), self._yv.min(), self._xv.max(), self._yv.max())
+
+    def node_coordinates_of(self, nodes):
+        nodes = np.asarray(nodes)
+        j, i = np.divmod(nodes, self._xv.size)  # node id = j * (nx + 1) + i (meshgrid order)
+        return np.column_stack([self._xv[i], self._yv[j]])
 
     @property
     def celltree(self) -> CellTree2d:

@@ -227,7 +227,7 @@ def voronoi_topology_device(grid, compact=False):
         nfc = scipy.sparse.csr_matrix(
             (np.ones(faces.size, dtype=np.int8), inverse[: faces.size], row_ptr), shape=(nodes.size, nl)
         )
-        node_xy = np.column_stack([grid.node_x[nodes], grid.node_y[nodes]])
+        node_xy = grid.node_coordinates_of(nodes)
         table, bkeys, bids, findex, interp_map = _boundary_records(
             nfc, node_xy, cen, np.searchsorted(nodes, edge_nodes), inverse[faces.size:], True, True
         )
