@@ -137,6 +137,11 @@ int xr_overlap_stats(const xr_mesh *tree, int64_t *n_candidates);
  * edge shared by several faces is assigned to the LOWEST face index. */
 int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tolerance,
                      int64_t *face_index_out);
+/* Ugrid2d.rasterize_like (xugrid/ugrid/ugrid2d.py:1080-1100): locate_points on the nodes of a raster given by its
+ * two 1-D coordinate arrays; the ny * nx points are generated on the device (point j * nx + i = (x[i], y[j])),
+ * face_index_out int64[ny * nx]. */
+int xr_locate_raster(xr_mesh *mesh, const double *x, int64_t nx, const double *y, int64_t ny,
+                     double tolerance, int64_t *face_index_out);
 /* CellTree2d.compute_barycentric_weights(points, tolerance) (ugrid2d.py:1054-1078).
  * -> face index int64[n] and float64[n, n_max_node] generalized barycentric weights
  * (all zero, face -1 when outside). */

@@ -416,6 +416,14 @@ def test_rasterize_known_answers(hip):
     assert np.array_equal(index, expected)
     xs, ys, idx = grid.rasterize_like(np.array([0.5, 1.5]), np.array([0.5]))
     assert np.array_equal(idx, [[0, 1]])
+    # the raster's nodes are generated on the device: same answer as locate_points on the host-built meshgrid
+    sxy, sf = meshgen.triangle_mesh(4000, 5)
+    big = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    rx, ry = np.linspace(-0.1, 1.1, 173), np.linspace(1.05, -0.05, 131)
+    _, _, idx = big.rasterize_like(rx, ry)
+    yy, xx = np.meshgrid(ry, rx, indexing="ij")
+    assert np.array_equal(idx, big.locate_points(np.column_stack([xx.ravel(), yy.ravel()])).reshape(131, 173))
+    assert big.rasterize_like(np.zeros(0), ry)[2].shape == (131, 0)
 
 
 def test_barycentric_full_size_vs_oracle(hip, oracle):

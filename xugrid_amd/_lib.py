@@ -64,6 +64,7 @@ SIGNATURES = {
     "xr_overlap": (c_int, [vp, vp, c_int, p_vp]),
     "xr_overlap_stats": (c_int, [vp, p_i64]),
     "xr_locate_points": (c_int, [vp, vp, c_i64, c_f64, vp]),
+    "xr_locate_raster": (c_int, [vp, vp, c_i64, vp, c_i64, c_f64, vp]),
     "xr_barycentric": (c_int, [vp, vp, c_i64, c_f64, vp, vp]),
     "xr_locate_csr": (c_int, [vp, vp, vp, c_i64, c_f64, p_vp]),
     "xr_barycentric_csr": (c_int, [vp, vp, vp, vp, c_i64, c_f64, vp, vp, c_i64, p_vp]),

@@ -278,6 +278,16 @@ k_locate_fill(const int32_t *__restrict__ col, const int32_t *__restrict__ indpt
     data[indptr[i]] = 1.0;
 }
 
+// the nodes of a raster, row-major (y, x): point j * nx + i = (x[i], y[j])
+__global__ void __launch_bounds__(256)
+k_raster_points(const double *__restrict__ x, const double *__restrict__ y, int64_t nx, int64_t n,
+                double *__restrict__ pts) {
+    const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    const int64_t j = v / nx, i = v - j * nx;
+    reinterpret_cast<double2 *>(pts)[v] = make_double2(x[i], y[j]);
+}
+
 __global__ void k_iota_i64(int64_t *__restrict__ p, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = i;
@@ -308,6 +318,36 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
         DevBuf<int64_t> out((size_t)n);
         h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
         if (mesh->n_face > 0) {
+            XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
+                      mesh->rec_len.get(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
+                      mesh->rec_face.get(), pts.get(), n, tol, out.get());
+            d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
+            stream_sync();
+        } else {
+            for (int64_t i = 0; i < n; i++) face_index_out[i] = -1;
+        }
+    }
+    XR_API_END
+}
+
+int xr_locate_raster(xr_mesh *mesh, const double *x, int64_t nx, const double *y, int64_t ny, double tolerance,
+                     int64_t *face_index_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh && nx >= 0 && ny >= 0 && (nx * ny == 0 || (x && y && face_index_out)), XR_ERR_INVALID,
+               "xr_locate_raster: bad arguments");
+    XR_REQUIRE(ny == 0 || nx < ((int64_t)1 << 31) / ny, XR_ERR_LIMIT, "xr_locate_raster: too many points");
+    const int64_t n = nx * ny;
+    if (n > 0) {
+        if (mesh->n_face > 0) {
+            mesh_prepare(mesh, false);
+            mesh_build_index(mesh);
+            const double tol = resolve_tolerance(mesh, tolerance);
+            DevBuf<double> dx((size_t)nx), dy((size_t)ny), pts((size_t)n * 2);
+            DevBuf<int64_t> out((size_t)n);
+            h2d(dx.get(), x, sizeof(double) * (size_t)nx);
+            h2d(dy.get(), y, sizeof(double) * (size_t)ny);
+            XR_LAUNCH("raster_points", k_raster_points, dim3(div_up(n, 256)), dim3(256), 0, dx.get(), dy.get(), nx, n,
+                      pts.get());
             XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
                       mesh->rec_len.get(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
                       mesh->rec_face.get(), pts.get(), n, tol, out.get());

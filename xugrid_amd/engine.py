@@ -160,6 +160,19 @@ class DeviceMesh:
         check(_lib.load().xr_locate_points(self._h, _ptr(pts), pts.shape[0], tol, _ptr(out)))
         return out.astype(IntDType, copy=False)
 
+    def locate_raster(self, x, y, tolerance=None):
+        """locate_points on the nodes (x[i], y[j]) of a raster -> index int (len(y), len(x)), -1 outside."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        if x.ndim != 1 or y.ndim != 1:
+            raise ValueError("x and y must be 1-D")
+        tol = -1.0 if tolerance is None else float(tolerance)
+        if tolerance is not None and tol < 0:
+            raise ValueError("tolerance must be non-negative")
+        out = np.empty((y.size, x.size), dtype=np.int64)
+        check(_lib.load().xr_locate_raster(self._h, _ptr(x), x.size, _ptr(y), y.size, tol, _ptr(out)))
+        return out.astype(IntDType, copy=False)
+
     def compute_barycentric_weights(self, points, tolerance=None):
         pts = _as_xy(points)
         face = np.empty(pts.shape[0], dtype=np.int64)

@@ -116,10 +116,8 @@ class Ugrid2d:
         """Face index at every (y, x) raster node: -> (x, y, index (nrow, ncol)), -1 outside the grid."""
         x = np.asarray(x, dtype=np.float64)
         y = np.asarray(y, dtype=np.float64)
-        yy, xx = np.meshgrid(y, x, indexing="ij")
-        nodes = np.column_stack([xx.ravel(), yy.ravel()])
-        index = self.celltree.locate_points(nodes).reshape((y.size, x.size))
-        return x, y, index
+        # (the y.size * x.size sample points are generated on the device from the two 1-D arrays)
+        return x, y, self.device_mesh.locate_raster(x, y)
 
     def rasterize(self, resolution, bounds=None):
         """Sample the grid on a raster of cell centres generated from ``bounds`` (default: the node bounds)
