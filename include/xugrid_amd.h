@@ -85,6 +85,12 @@ int xr_current_device(int *device);
 /* Release cached HBM held by the engine's block pool. */
 int xr_trim_pool(void);
 int xr_version(void);
+/* Share a HIP stream with the caller (e.g. PyTorch's current stream, `torch.cuda.current_stream().cuda_stream`;
+ * the null stream is a valid handle): with external != 0 every kernel, copy and event of the engine goes to
+ * `hip_stream`, so device work of caller and engine is ordered without host synchronisation, and with
+ * async_dev != 0 the *_dev entry points return as soon as their kernels are enqueued.  external == 0 restores the
+ * engine's own stream.  The multi-GPU layer uses this between its kernels and the RCCL collectives. */
+int xr_set_stream(void *hip_stream, int external, int async_dev);
 
 /* ---- seam 1: mesh handle = CellTree2d(vertices, faces, fill_value) --------------------- */
 /* ugrid2d.py:915-921.  node_xy: float64[n_node,2] (node_coordinates, ugridbase.py:576-579);

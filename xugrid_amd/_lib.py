@@ -43,6 +43,7 @@ SIGNATURES = {
     "xr_current_device": (c_int, [p_int]),
     "xr_trim_pool": (c_int, []),
     "xr_version": (c_int, []),
+    "xr_set_stream": (c_int, [vp, c_int, c_int]),
     "xr_mesh_create": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),
     "xr_mesh_create_rectilinear": (c_int, [vp, c_i64, vp, c_i64, p_vp]),
     "xr_mesh_destroy": (c_int, [vp]),

@@ -1998,7 +1998,7 @@ int xr_apply_outer_dev(xr_outer *o, int method, double percentile, const void *s
     XR_REQUIRE(o && (source_dev || K == 0) && (out_dev || K == 0), XR_ERR_INVALID, "xr_apply_outer_dev: NULL argument");
     XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_outer_dev: negative K");
     apply_outer_dev(o, method, percentile, source_dev, source_dtype, K, out_dev);
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2064,7 +2064,7 @@ int xr_apply_csr_dev(const xr_csr *csr, int method, double percentile, const voi
                "xr_apply_csr_dev: NULL argument");
     XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_csr_dev: negative K");
     apply_dev(csr, method, percentile, source_dev, source_dtype, K, out_dev);
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2151,7 +2151,7 @@ int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int sou
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                       static_cast<const float *>(source_dev), K, num, den);
     }
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2172,7 +2172,7 @@ int xr_apply_partial_mean_rows_dev(const xr_csr *csr, const void *source_dev, in
                       csr->indptr.get(), csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                       static_cast<const float *>(source_dev), K, rows_dev);
     }
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2184,7 +2184,7 @@ int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double
         XR_LAUNCH("accumulate_rows", k_accumulate_rows, dim3(div_up(n * width, 256)), dim3(256), 0, acc_dev, ids_dev,
                   rows_dev, n, width);
     }
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2197,7 +2197,7 @@ int xr_reduce_mean_rows_dev(const double *rows_dev, const int64_t *indptr_dev, c
         XR_LAUNCH("reduce_mean_rows", k_reduce_mean_rows, dim3(div_up(n_targets * K, 256)), dim3(256), 0, rows_dev,
                   indptr_dev, order_dev, n_targets, K, out_dev);
     }
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2209,7 +2209,7 @@ int xr_finalize_mean_rows_dev(const double *acc_dev, int64_t n_rows, int64_t K, 
         XR_LAUNCH("finalize_mean_rows", k_finalize_mean_rows, dim3(div_up(n_rows * K, 256)), dim3(256), 0, acc_dev,
                   n_rows, K, out_dev);
     }
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 
@@ -2221,7 +2221,7 @@ int xr_finalize_mean_dev(const double *num_dev, const double *den_dev, int64_t c
         XR_LAUNCH("finalize_mean", k_finalize_mean, dim3(div_up(count, 256)), dim3(256), 0, num_dev, den_dev, count,
                   out_dev);
     }
-    stream_sync();
+    dev_call_done();
     XR_API_END
 }
 

@@ -34,11 +34,12 @@ void engine_init(int device) {
         throw Failure{XR_ERR_NO_DEVICE};
     }
     XR_REQUIRE(device >= 0 && device < count, XR_ERR_INVALID, "device %d out of range [0,%d)", device, count);
-    if (g_engine.device == device && g_engine.stream) return;
+    if (g_engine.device == device && g_engine.own_stream) return;
     XR_REQUIRE(g_engine.device < 0, XR_ERR_INVALID,
                "engine already bound to device %d; one process per GPU", g_engine.device);
     XR_HIP(hipSetDevice(device));
     XR_HIP(hipStreamCreateWithFlags(&g_engine.stream, hipStreamNonBlocking));
+    g_engine.own_stream = g_engine.stream;
     hipDeviceProp_t prop;
     XR_HIP(hipGetDeviceProperties(&prop, device));
     g_engine.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -140,6 +141,9 @@ void d2h(void *dst, const void *src, size_t bytes) {
 }
 
 void stream_sync() { XR_HIP(hipStreamSynchronize(engine().stream)); }
+void dev_call_done() {
+    if (!engine().async_dev) stream_sync();
+}
 
 // ---------------------------------------------------------------------------------------------
 // staged copies of large pageable host arrays
@@ -291,6 +295,15 @@ extern "C" {
 const char *xr_last_error(void) { return g_err; }
 
 int xr_version(void) { return 100; }
+
+int xr_set_stream(void *hip_stream, int external, int async_dev) {
+    XR_API_BEGIN
+    Engine &e = engine();
+    XR_HIP(hipStreamSynchronize(e.stream)); // nothing of the engine may still be in flight on the old stream
+    e.stream = external ? static_cast<hipStream_t>(hip_stream) : e.own_stream;
+    e.async_dev = external && async_dev;
+    XR_API_END
+}
 
 int xr_device_count(int *count) {
     int c = 0;

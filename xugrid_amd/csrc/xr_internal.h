@@ -65,7 +65,9 @@ std::recursive_mutex &engine_mutex();
 // ---------------------------------------------------------------------------------------------
 struct Engine {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // the stream every kernel, copy and event of the engine goes to
+    hipStream_t own_stream = nullptr; // created by engine_init; `stream` points elsewhere after xr_set_stream
+    bool async_dev = false;           // *_dev entry points return without waiting (caller shares the stream)
     int num_cu = 256;
     void *pinned = nullptr; // small pinned staging buffer for scalar read-backs
     // "mailbox": pinned host memory that kernels write the few scalars the host is waiting for into
@@ -116,6 +118,7 @@ template <typename T> struct DevBuf {
 void h2d(void *dst, const void *src, size_t bytes);       // synchronous w.r.t. the host
 void d2h(void *dst, const void *src, size_t bytes);       // stream-ordered, then synchronised
 void stream_sync();
+void dev_call_done(); // end of a *_dev entry point: stream_sync() unless the caller shares the engine's stream
 // Large host <-> device copies of pageable memory through two pinned staging buffers: worker threads move the data
 // between the caller's pages and the staging buffer (page faults of a fresh result array included) while the DMA
 // engine moves the previous piece -- 2-3x the rate of a plain hipMemcpy on pageable memory.  Synchronous.

@@ -113,6 +113,18 @@ class HipBackend:
         torch.cuda.set_device(local_rank)
         engine.init(local_rank)
         self.device = torch.device("cuda", local_rank)
+        # The engine runs on torch's current stream: its kernels, torch's own ops and the RCCL collectives (which
+        # torch orders against the current stream with events) are then ordered on the device, and no host
+        # synchronisation is needed between them.  XR_DIST_OWN_STREAM=1 keeps the engine on its own stream with
+        # host synchronisation at every hand-over (measurement hook).
+        self.shared_stream = os.environ.get("XR_DIST_OWN_STREAM", "") == ""
+        if self.shared_stream:
+            engine.set_stream(torch.cuda.current_stream().cuda_stream, async_dev=True)
+
+    def _handover(self):
+        """Work enqueued by torch must be visible to the engine's stream."""
+        if not self.shared_stream:
+            self.torch.cuda.current_stream().synchronize()
 
     def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces):
         E = self.engine
@@ -143,7 +155,7 @@ class HipBackend:
         K = source.shape[0]
         out = torch.empty((K, weights.n), dtype=torch.float64, device=self.device)
         dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
-        torch.cuda.current_stream().synchronize()
+        self._handover()
         weights.apply_dev(source.data_ptr(), dtype, K, out.data_ptr(), method_id, percentile)
         self.engine.dev_sync()
         return out
@@ -154,13 +166,13 @@ class HipBackend:
         K = source.shape[0]
         out = torch.empty((2, K, weights.n), dtype=torch.float64, device=self.device)
         dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
-        torch.cuda.current_stream().synchronize()  # inputs produced on torch's stream are ready
+        self._handover()  # inputs produced on torch's stream are ready
         weights.partial_mean_dev(source.data_ptr(), dtype, K, out.data_ptr())
         return out
 
     def finalize_mean(self, num, den):
         out = self.torch.empty_like(num)
-        self.torch.cuda.current_stream().synchronize()
+        self._handover()
         self.engine.finalize_mean_dev(num.data_ptr(), den.data_ptr(), num.numel(), out.data_ptr())
         return out
 
@@ -171,26 +183,26 @@ class HipBackend:
         K = source.shape[0]
         rows = torch.empty((weights.n, 2 * K), dtype=torch.float64, device=self.device)
         dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
-        torch.cuda.current_stream().synchronize()
+        self._handover()
         weights.partial_mean_rows_dev(source.data_ptr(), dtype, K, rows.data_ptr())
         return rows
 
     def accumulate_rows(self, acc, ids, rows):
         """acc[ids] += rows (ids distinct)."""
-        self.torch.cuda.current_stream().synchronize()
+        self._handover()
         self.engine.accumulate_rows_dev(acc.data_ptr(), ids.data_ptr(), rows.data_ptr(), rows.shape[0], rows.shape[1])
 
     def reduce_mean_rows(self, rows, indptr, order, n_targets, K):
         """received rows (R, 2K) + per-target lists (indptr, order) -> finalised (K, n_targets) in one launch."""
         out = self.torch.empty((K, n_targets), dtype=self.torch.float64, device=self.device)
-        self.torch.cuda.current_stream().synchronize()
+        self._handover()
         self.engine.reduce_mean_rows_dev(rows.data_ptr(), indptr.data_ptr(), order.data_ptr(), n_targets, K, out.data_ptr())
         return out
 
     def finalize_mean_rows(self, acc, K):
         """(chunk, 2K) -> (K, chunk)."""
         out = self.torch.empty((K, acc.shape[0]), dtype=self.torch.float64, device=self.device)
-        self.torch.cuda.current_stream().synchronize()
+        self._handover()
         self.engine.finalize_mean_rows_dev(acc.data_ptr(), acc.shape[0], K, out.data_ptr())
         return out
 

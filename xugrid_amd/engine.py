@@ -42,6 +42,16 @@ def init(device=0):
     check(_lib.load().xr_init(int(device)))
 
 
+def set_stream(handle=None, async_dev=False):
+    """Run the engine on the caller's HIP stream (``handle``: the integer stream handle, e.g.
+    ``torch.cuda.current_stream().cuda_stream``; 0 is the null stream), or back on its own (``handle=None``).
+    ``async_dev``: the ``*_dev`` calls return without waiting for their kernels."""
+    if handle is None:
+        check(_lib.load().xr_set_stream(None, 0, 0))
+    else:
+        check(_lib.load().xr_set_stream(ctypes.c_void_p(int(handle)), 1, int(bool(async_dev))))
+
+
 def _as_xy(vertices):
     xy = np.ascontiguousarray(vertices, dtype=np.float64)
     if xy.ndim != 2 or xy.shape[1] != 2:
