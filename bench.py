@@ -189,7 +189,7 @@ def run_single(args):
     # (SQ_INSTS_VALU, wave-instructions per launch); a wave64 FP64 instruction occupies its SIMD for 4 cycles
     # (78.6 TFLOP/s FP64 vector peak = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz), a 32-bit one for 2.
     valu = None
-    ppath = os.path.join(ROOT, "profiles", "r01h_pmc_per_launch.json")
+    ppath = os.path.join(ROOT, "profiles", "r01l_pmc_per_launch.json")
     pmc_names = {"clip_small": "k_clip_small<6, 256, true>", "search": "k_search"}
     if os.path.exists(ppath) and dominant in pmc_names:
         try:
@@ -202,7 +202,7 @@ def run_single(args):
                 "issue_floor_ms_all_fp64": floor_fp64_ms,
                 "issue_floor_ms_half_fp64": floor_mixed_ms,
                 "frac_of_issue_limit": [floor_mixed_ms / dom_ms, floor_fp64_ms / dom_ms],
-                "source": "profiles/r01h_pmc_per_launch.json",
+                "source": "profiles/r01l_pmc_per_launch.json",
             }
         except Exception:
             valu = None
