@@ -1,40 +1,35 @@
-"""``Network1d``: the regridder-side adapter of a ``Ugrid1d`` -- xugrid/regrid/network.py:4-36."""
+"""
+``Network1d`` -- what ``NetworkGridder`` keeps of its source: a ``Ugrid1d`` seen as a 1-D grid whose cells are
+the EDGES of the network (counterpart of xugrid/regrid/network.py).  Source data therefore has the edge dimension
+as its last axis, ``size`` is the number of edges and ``length`` their lengths (the denominators the reference
+would use for relative weights).
+"""
 from ..ugrid1d import Ugrid1d
+
+_ACCEPTED = ("Ugrid1d", "UgridDataArray", "UgridDataset")
+
+
+def _topology_of(obj) -> Ugrid1d:
+    if isinstance(obj, Ugrid1d):
+        return obj
+    grid = getattr(obj, "grid", None)  # UgridDataArray / UgridDataset style wrappers carry their topology as .grid
+    if isinstance(grid, Ugrid1d):
+        return grid
+    raise TypeError(f"Expected one of {set(_ACCEPTED)}, received: {type(obj).__name__}")
 
 
 class Network1d:
+    ndim = 1  # one spatial axis: the edges
+
     def __init__(self, obj):
-        if isinstance(obj, Ugrid1d):
-            self.ugrid_topology = obj
-        elif hasattr(obj, "grid") and isinstance(obj.grid, Ugrid1d):
-            self.ugrid_topology = obj.grid  # UgridDataArray-like wrapper
-        else:
-            options = {"Ugrid1d", "UgridDataArray", "UgridDataset"}
-            raise TypeError(f"Expected one of {options}, received: {type(obj).__name__}")
+        self.ugrid_topology = _topology_of(obj)
 
-    @property
-    def ndim(self):
-        return 1
+    size = property(lambda self: self.ugrid_topology.n_edge)
+    shape = property(lambda self: (self.ugrid_topology.n_edge,))
+    dims = property(lambda self: (self.ugrid_topology.edge_dimension,))
+    length = property(lambda self: self.ugrid_topology.edge_length)
 
-    @property
-    def dims(self):
-        return (self.ugrid_topology.edge_dimension,)
-
-    @property
-    def shape(self):
-        return (self.ugrid_topology.n_edge,)
-
-    @property
-    def size(self):
-        return self.ugrid_topology.n_edge
-
-    @property
-    def length(self):
-        return self.ugrid_topology.edge_length
-
-    # (the reference class has no to_dataset, so ``NetworkGridder.weights`` cannot be written there; here the
-    # network is stored next to the weights like any other source grid)
     def to_dataset(self, name: str):
-        ds = self.ugrid_topology.to_dataset(name)
-        ds[name + "_type"] = "Network1d"
-        return ds
+        """The network next to the weights, like any other source grid (the reference class has no ``to_dataset``,
+        so ``NetworkGridder.weights`` cannot be written there)."""
+        return {**self.ugrid_topology.to_dataset(name), name + "_type": "Network1d"}
