@@ -10,13 +10,15 @@
  *     replace_interpolated_weights: restated line-by-line from files that ARE in
  *     /root/reference and PINNED against golden vectors generated from those files
  *     (tests/golden/gen_goldens.py -> tests/golden/ npz files).
- *   - polygon clipping, bbox search, point location, barycentric weights: the arithmetic
+ *   - polygon clipping, bbox search, point location, barycentric weights, segment-in-face
+ *     clipping (intersect_edges): the arithmetic
  *     lives in the third-party package numba_celltree 0.4.2 (pixi.lock:298), which is
  *     neither in /root/reference nor installed.  Restated from its published algorithm
  *     (Sutherland-Hodgman, bounding-box cell tree after Garth & Joy 2010, Wachspress
- *     coordinates).  PARITY UNPINNED for general polygon pairs; pinned only through the
+ *     coordinates, Cyrus-Beck line clipping).  PARITY UNPINNED for general polygon pairs; pinned only through the
  *     reference's own invariants/known answers (rectilinear overlap == overlap_1d goldens,
- *     self-overlap identity, barycentric known answers of tests/test_ugrid2d.py:751-791)
+ *     self-overlap identity, barycentric known answers of tests/test_ugrid2d.py:751-791, the
+ *     NetworkGridder known answers of tests/test_regrid/test_network_gridder.py)
  *     and an exact rational-arithmetic clip (oracle/exact_clip.py).
  *
  * All index arrays are int64 (np.intp in the reference, xugrid/constants.py:10),
