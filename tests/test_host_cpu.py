@@ -178,3 +178,33 @@ def test_replace_interpolated_weights_host_equals_oracle(oracle):
     oracle.replace_interpolated_weights(vertices, faces, face_index, b, n2n, threshold)
     assert not np.array_equal(a, weights)  # something was redistributed
     assert np.array_equal(a, b)
+
+
+def test_rectilinear_ugrid_host_side_is_lazy_and_equal():
+    """RectilinearUgrid2d (quads generated on the device) exposes the same host arrays as
+    Ugrid2d.from_structured_bounds, but only materialises them when they are read."""
+    import xugrid_amd as xa
+    from xugrid_amd.ugrid2d import RectilinearUgrid2d
+
+    rng = np.random.default_rng(2)
+    for flip_x in (False, True):
+        for flip_y in (False, True):
+            xv = np.concatenate(([1.0], 1.0 + np.cumsum(rng.uniform(0.5, 2.0, 11))))
+            yv = np.concatenate(([-2.0], -2.0 + np.cumsum(rng.uniform(0.5, 2.0, 7))))
+            xv, yv = (xv[::-1].copy() if flip_x else xv), (yv[::-1].copy() if flip_y else yv)
+            xb = np.column_stack([np.minimum(xv[:-1], xv[1:]), np.maximum(xv[:-1], xv[1:])])
+            yb = np.column_stack([np.minimum(yv[:-1], yv[1:]), np.maximum(yv[:-1], yv[1:])])
+            host = xa.Ugrid2d.from_structured_bounds(xb, yb)
+            lazy = xa.Ugrid2d.from_structured_bounds_device(xb, yb)
+            assert isinstance(lazy, RectilinearUgrid2d) and lazy._host is None
+            assert (lazy.n_node, lazy.n_face, lazy.n_max_node_per_face) == (host.n_node, host.n_face, 4)
+            assert lazy.bounds == host.bounds
+            nodes = rng.integers(0, host.n_node, 20)
+            assert np.array_equal(lazy.node_coordinates_of(nodes), host.node_coordinates_of(nodes))
+            assert lazy._host is None  # sizes, bounds and single node coordinates need no host arrays
+            assert np.array_equal(lazy.face_node_connectivity, host.face_node_connectivity)
+            assert np.array_equal(lazy.node_x, host.node_x) and np.array_equal(lazy.node_y, host.node_y)
+            again = xa.Ugrid2d.from_dataset(lazy.to_dataset("g"), "g")
+            assert np.array_equal(again.face_node_connectivity, host.face_node_connectivity)
+    with pytest.raises(ValueError):
+        RectilinearUgrid2d(np.array([0.0]), np.array([0.0, 1.0]))
