@@ -6,8 +6,8 @@
 //   length = norm(diff(intersections))                                                  (:212)
 // that follows it, its argsort by face (:211) and MatrixCSR.from_triplet (xugrid/regrid/gridder.py:66-73).
 //
-// Per edge the hierarchical grid of the mesh is walked over the edge's bounding box (long edges: one block per
-// edge, walking the cells along the segment); every candidate face is clipped with the Cyrus-Beck parametric
+// Per edge the hierarchical grid of the mesh is walked over the edge's bounding box (long edges: one wave per
+// edge, walking the cells along the segment's major axis); every candidate face is clipped with the Cyrus-Beck parametric
 // line clip against its CCW-normalised (convex) polygon.  A pair is kept iff the clipped parameter interval has
 // t0 < t1 -- touching a corner or an edge from outside yields no entry (tests/test_regrid/test_network_gridder.py:
 // nnz == 8 for the four-edge network on the 4 x 4 grid).  The arithmetic mirrors oracle/xr_oracle.c
