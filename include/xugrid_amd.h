@@ -154,6 +154,15 @@ int xr_locate_raster(xr_mesh *mesh, const double *x, int64_t nx, const double *y
 int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolerance,
                    int64_t *face_index_out, double *weights_out);
 
+/* replace_interpolated_weights(vertices, faces, face_index, weights, node_to_node_map, node_index_threshold)
+ * (xugrid/regrid/unstructured.py:17-57) as a stand-alone call: the device kernel xr_barycentric_csr runs inside its
+ * pipeline, on caller-owned arrays.  vertices float64[n_vertex, 2]; faces int64[n_face, m] (-1 fill behind the
+ * corners); face_index int64[n] (-1 = point in no cell: row untouched); weights float64[n, m] row-major, updated
+ * IN PLACE as the reference does; node_to_node_map int64[n_map, 2]; node_index_threshold = n_vertex - n_map. */
+int xr_replace_interpolated_weights(const double *vertices, int64_t n_vertex, const int64_t *faces, int64_t n_face,
+                                    int64_t m, const int64_t *face_index, double *weights, int64_t n,
+                                    const int64_t *node_to_node_map, int64_t n_map);
+
 /* UnstructuredGrid2d.locate_centroids (xugrid/regrid/unstructured.py:137-144) + MatrixCOO.from_triplet
  * (regridder.py:386-398) without leaving the device: one row per query point holding (face containing it, 1.0),
  * no entry when the point is in no face.  Query points: `points` float64[n, 2] (query == NULL) or the face

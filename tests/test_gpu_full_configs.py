@@ -1,0 +1,143 @@
+"""
+GPU (-m gpu): BASELINE.json configs 4 and 5 at their full single-GPU sizes, against the CPU oracle.
+
+config 5  1M -> 1M Delaunay triangles, 256 stacked variables re-using cached weights (from_weights route:
+          weights downloaded, uploaded again with xr_csr_upload + xr_csr_set_row_keys): the K > 192 "groups of 128"
+          branch of the many-variable apply, the apply plan at 1M rows, with NaNs and with XR_APPLY_NO_PLAN.
+          Reference: make_regrid(func)._regrid (xugrid/regrid/regridder.py:41-67), from_weights (:334-348).
+config 4  10M -> 10M triangles on ONE GPU (the 8-GPU source-sharded run is the driver's): size-independent
+          properties of the whole matrix plus a bit-exact comparison with the oracle on a 100k-row sample, and the
+          bench's multi-GPU code path (`bench.py --force-dist`) at that size through a one-rank RCCL group.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import same_or_nan
+from test_gpu_parity import assert_apply_equal
+from xugrid_amd import meshgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _stacked_field(centroids, K, seed):
+    """(K, S) float64: the C2 field with a phase shift per variable."""
+    rng = np.random.default_rng(seed)
+    x, y = centroids[:, 0], centroids[:, 1]
+    noise = 0.1 * rng.normal(size=(8, x.size))
+    v = np.empty((K, x.size))
+    for k in range(K):
+        v[k] = np.sin(6 * np.pi * x + 0.37 * k) * np.cos(4 * np.pi * y - 0.11 * k) + noise[k % 8]
+    return v
+
+
+def test_config5_cached_weights_k256(hip, oracle, monkeypatch):
+    from xugrid_amd import engine as E
+
+    K = 256
+    sxy, sf = meshgen.triangle_mesh(500_000, 0)
+    txy, tf = meshgen.triangle_mesh(500_000, 1, 30.0, 0.7)
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    built = ms.overlap(mt)
+    data, idx, indptr = built.download()
+    T, S = built.n, built.m
+    assert T > 990_000 and S > 990_000 and built.nnz > 4_000_000
+    # cached weights: the from_weights route (host arrays -> xr_csr_upload) + the locality hint for uploaded rows
+    cached = E.DeviceCSR.from_arrays(data, idx, indptr, T, S)
+    keys, key_range = E.morton_row_keys(oracle.centroids(txy, tf), faces_per_tile=64)
+    cached.set_row_keys(keys, key_range)
+    v = _stacked_field(oracle.centroids(sxy, sf), K, 5)
+    exp = oracle.regrid_csr("mean", v, data, idx, indptr, T)
+    got = cached.apply(v, 0)  # K = 256 > 192: two groups of 128 (xr_apply.hip: apply_dispatch)
+    assert_apply_equal(got, exp, indptr, "mean K=256 cached")
+    # the matrix xr_overlap left on the device (keys set by the build) gives the same numbers
+    got_built = built.apply(v, 0)
+    assert same_or_nan(got_built, got).all()
+    # downloads are unchanged by the re-tiling
+    d2, i2, p2 = cached.download()
+    assert np.array_equal(d2, data) and np.array_equal(i2, idx) and np.array_equal(p2, indptr)
+    # without the plan (direct gathers)
+    monkeypatch.setenv("XR_APPLY_NO_PLAN", "1")
+    got_np = cached.apply(v, 0)
+    monkeypatch.delenv("XR_APPLY_NO_PLAN")
+    assert_apply_equal(got_np, exp, indptr, "mean K=256 no plan")
+    del got_np, got_built
+    # NaNs: 1 % in every fourth variable, one variable all-NaN (NaN-free tiles take the short path, the others not)
+    rng = np.random.default_rng(9)
+    for k in range(0, K, 4):
+        v[k, rng.random(S) < 0.01] = np.nan
+    v[130] = np.nan
+    exp = oracle.regrid_csr("mean", v, data, idx, indptr, T)
+    got = cached.apply(v, 0)
+    assert_apply_equal(got, exp, indptr, "mean K=256 NaN")
+    assert np.isnan(got[130]).all()
+    # a second reducer on the same plan, float32 sources
+    v32 = v[:200].astype(np.float32)
+    exp = oracle.regrid_csr("maximum", v32, data, idx, indptr, T)
+    assert_apply_equal(cached.apply(v32, 5), exp, indptr, "maximum K=200 f32")
+
+
+def test_config4_10m_single_gpu(hip, oracle):
+    from xugrid_amd import engine as E
+
+    n_points = 5_000_000
+    sxy, sf = meshgen.triangle_mesh(n_points, 0, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(n_points, 1, 30.0, 0.7, delaunay=False)
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    csr = ms.overlap(mt)
+    data, idx, indptr = csr.download()
+    T, S = csr.n, csr.m
+    assert T == tf.shape[0] and S == sf.shape[0] and T > 9_900_000
+    assert data.size == csr.nnz == indptr[-1] and csr.nnz > 40_000_000
+    assert (data > 0).all() and idx.min() >= 0 and idx.max() < S
+    counts = np.diff(indptr)
+    assert (counts > 0).all()  # the target lies inside the source hull
+    inner = np.ones(idx.size, dtype=bool)
+    inner[indptr[:-1]] = False
+    assert (np.diff(idx)[inner[1:]] > 0).all()  # rows strictly ascending in the source index
+    t_area = mt.area()
+    row_sum = np.add.reduceat(data, indptr[:-1])
+    np.testing.assert_allclose(row_sum, t_area, rtol=1e-9)
+    col_sum = np.bincount(idx, weights=data, minlength=S)
+    assert (col_sum <= ms.area() * (1 + 1e-9)).all()
+    assert abs(data.sum() / t_area.sum() - 1) < 1e-10
+    one = csr.apply(np.full((1, S), 3.25))
+    assert np.allclose(one, 3.25, rtol=1e-14)
+    # oracle on a 100k-row sample of the target faces (the tree is built over all 10M source faces)
+    rng = np.random.default_rng(4)
+    sample = np.sort(rng.choice(T, 100_000, replace=False))
+    tree = oracle.CellTree2d(sxy, sf)
+    oq, os_, oa = tree.intersect_faces(txy, tf[sample])
+    o_indptr = oracle.to_csr_indptr(oq, sample.size)
+    assert np.array_equal(np.diff(o_indptr), counts[sample]), "row lengths differ from the oracle"
+    cnt = counts[sample]
+    flat = np.repeat(indptr[sample] - (np.cumsum(cnt) - cnt), cnt) + np.arange(cnt.sum())  # entries of the sampled rows
+    assert np.array_equal(idx[flat], os_), "source indices differ from the oracle"
+    assert np.array_equal(data[flat], oa), "areas not bit-exact"
+    v = meshgen.smooth_field(oracle.centroids(sxy, sf), 0, nan_fraction=0.01)[None, :]
+    got = csr.apply(v, 0)
+    exp = oracle.regrid_csr("mean", v, oa, os_, o_indptr, sample.size)
+    assert_apply_equal(got[:, sample], exp, o_indptr, "mean 10M sample")
+
+
+def test_bench_multi_gpu_path_10m_one_rank():
+    """The SCALE path of bench.py at config 4's size through a one-rank RCCL group (the box has one GPU)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for exchange in ("dense", "sparse"):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--points", "5000000", "--steps", "3",
+               "--warmup", "1", "--exchange", exchange]
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+        assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+        line = json.loads(proc.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 1 and line["config"]["target_faces"] > 9_900_000
+        assert line["value"] > 1e8 and line["config"]["nnz"] > 40_000_000

@@ -517,3 +517,13 @@ def test_barycentric_from_raster_source_paired_with_mesh(hip):
     quads = xa.Ugrid2d.from_structured_bounds(grid.xbounds.directional_bounds, grid.ybounds.directional_bounds)
     ref = xa.BarycentricInterpolator(quads, tgt)
     assert rg.weights_as_dataframe().equals(ref.weights_as_dataframe())
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_replace_interpolated_weights_device_golden(hip, golden, tag):
+    """G10 (reference output of unstructured.py:17-57) through the device kernel of the barycentric pipeline."""
+    g = golden("g10_replace.npz")
+    w = g[f"{tag}_weights_in"].copy()
+    hip.engine.replace_interpolated_weights(g[f"{tag}_vertices"], g[f"{tag}_faces"], g[f"{tag}_face_index"], w,
+                                            g[f"{tag}_node_to_node_map"], int(g[f"{tag}_threshold"]))
+    assert np.array_equal(w, g[f"{tag}_weights_out"])

@@ -186,3 +186,22 @@ def test_conservation_elevation_nl(golden, oracle):
     cell_area = oracle.area(txy, tf)
     row_sum = np.bincount(q, weights=a, minlength=tf.shape[0])
     assert (row_sum <= cell_area * (1 + 1e-10)).all()
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g10_replace_interpolated_weights(golden, oracle, tag):
+    """G10: replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) lifted from the reference
+    (tests/golden/gen_replace.py): the oracle's restatement and the product's host-side counterpart reproduce the
+    weights the reference leaves behind bit for bit -- hot-path-like cells, repeated q / r / p in a face, chains."""
+    from xugrid_amd._replace import replace_interpolated_weights as host_replace
+
+    g = golden("g10_replace.npz")
+    args = [g[f"{tag}_{k}"] for k in ("vertices", "faces", "face_index")]
+    node_map, threshold, exp = g[f"{tag}_node_to_node_map"], int(g[f"{tag}_threshold"]), g[f"{tag}_weights_out"]
+    assert (exp != g[f"{tag}_weights_in"]).sum() > 5000  # the case does exercise the function
+    w = g[f"{tag}_weights_in"].copy()
+    oracle.replace_interpolated_weights(*args, w, node_map, threshold)
+    assert np.array_equal(w, exp)
+    w = g[f"{tag}_weights_in"].copy()
+    host_replace(*args, w, node_map, threshold)
+    assert np.array_equal(w, exp)

@@ -18,14 +18,17 @@ def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_n
     if rows.size == 0:
         return
     face_rows = faces[face_index[rows]]  # (n_valid, m)
-    hit = (face_rows >= node_index_threshold) & (weights[rows] > 0)
-    ii, jj = np.nonzero(hit)
-    for i_local, j in zip(ii, jj):
+    substitute = face_rows >= node_index_threshold
+    # candidate rows: a substitute vertex in the cell and some positive weight.  Inside a row the slots are walked in
+    # the reference's order on the CURRENT weights (a slot may receive weight from an earlier one, or lose it)
+    touched = np.nonzero(substitute.any(axis=1) & (weights[rows] > 0).any(axis=1))[0]
+    ii, jj = np.nonzero(substitute[touched])
+    for i_local, j in zip(touched[ii], jj):
         i = rows[i_local]
         face = face_rows[i_local]
         p = face[j]
         w = weights[i, j]
-        if w <= 0:  # may have been zeroed by an earlier slot of the same row
+        if w <= 0:
             continue
         q, r = node_to_node_map[p - node_index_threshold]
         px, py = vertices[p]

@@ -1335,7 +1335,7 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
     } else {
-        static const bool no_plan = getenv("XR_APPLY_NO_PLAN") != nullptr;
+        const bool no_plan = getenv("XR_APPLY_NO_PLAN") != nullptr; // measurement / test switch, read per call
         if (K >= PLAN_KT && !no_plan) {
             // many variables: rows regrouped into 2-D tiles, then a blocked CSR with per-block distinct-column
             // lists (both built once per matrix)

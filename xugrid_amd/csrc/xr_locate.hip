@@ -485,6 +485,48 @@ int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
     XR_API_END
 }
 
+int xr_replace_interpolated_weights(const double *vertices, int64_t n_vertex, const int64_t *faces, int64_t n_face,
+                                    int64_t m, const int64_t *face_index, double *weights, int64_t n,
+                                    const int64_t *node_to_node_map, int64_t n_map) {
+    XR_API_BEGIN
+    XR_REQUIRE(n >= 0 && m >= 0 && n_vertex >= 0 && n_face >= 0 && n_map >= 0 && n_map <= n_vertex, XR_ERR_INVALID,
+               "xr_replace_interpolated_weights: bad sizes");
+    XR_REQUIRE(m <= XR_MAX_FACE_NODES * 4, XR_ERR_LIMIT, "xr_replace_interpolated_weights: too many slots per face");
+    if (n == 0 || m == 0 || n_map == 0) return XR_OK;
+    XR_REQUIRE(vertices && faces && face_index && weights && node_to_node_map, XR_ERR_INVALID,
+               "xr_replace_interpolated_weights: NULL argument");
+    for (int64_t i = 0; i < n; i++)
+        XR_REQUIRE(face_index[i] >= -1 && face_index[i] < n_face, XR_ERR_INVALID,
+                   "xr_replace_interpolated_weights: face_index[%lld] out of range", (long long)i);
+    for (int64_t i = 0; i < n_face * m; i++)
+        XR_REQUIRE(faces[i] >= -1 && faces[i] < n_vertex, XR_ERR_INVALID,
+                   "xr_replace_interpolated_weights: faces entry %lld out of range", (long long)i);
+    for (int64_t i = 0; i < 2 * n_map; i++)
+        XR_REQUIRE(node_to_node_map[i] >= 0 && node_to_node_map[i] < n_vertex, XR_ERR_INVALID,
+                   "xr_replace_interpolated_weights: node_to_node_map entry %lld out of range", (long long)i);
+    // the kernel walks a COLUMN-major weight table (weight j of point i at [j * n + i])
+    std::vector<double> cm((size_t)n * m);
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < m; j++) cm[(size_t)j * n + i] = weights[(size_t)i * m + j];
+    DevBuf<double> w((size_t)n * m), vxy((size_t)(n_vertex > 0 ? n_vertex : 1) * 2);
+    DevBuf<int64_t> face((size_t)n), fc((size_t)(n_face > 0 ? n_face : 1) * m), n2n((size_t)n_map * 2);
+    DevBuf<uint8_t> inside((size_t)n);
+    DevBuf<int32_t> count((size_t)n);
+    h2d(w.get(), cm.data(), sizeof(double) * cm.size());
+    h2d(vxy.get(), vertices, sizeof(double) * 2 * (size_t)n_vertex);
+    h2d(face.get(), face_index, sizeof(int64_t) * (size_t)n);
+    h2d(fc.get(), faces, sizeof(int64_t) * (size_t)n_face * m);
+    h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_map);
+    XR_HIP(hipMemsetAsync(inside.get(), 1, (size_t)n, engine().stream));
+    XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), (int)m,
+              fc.get(), vxy.get(), n2n.get(), n_vertex - n_map, inside.get(), n, count.get());
+    d2h(cm.data(), w.get(), sizeof(double) * cm.size());
+    stream_sync();
+    for (int64_t i = 0; i < n; i++)
+        for (int64_t j = 0; j < m; j++) weights[(size_t)i * m + j] = cm[(size_t)j * n + i];
+    XR_API_END
+}
+
 int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n, double tolerance, xr_csr **out) {
     XR_API_BEGIN
     XR_REQUIRE(tree && out, XR_ERR_INVALID, "xr_locate_csr: NULL argument");

@@ -121,6 +121,20 @@ class HipBackend:
         if self.shared_stream:
             engine.set_stream(torch.cuda.current_stream().cuda_stream, async_dev=True)
 
+    def _typed(self, source):
+        """-> (tensor, XR dtype id).  float32 / float64 go to the kernels as they are; integer, bool and half inputs
+        are cast to float64 first (engine._source_2d does the same for host arrays); anything else is an error --
+        never hand the kernels an element size they do not read."""
+        torch = self.torch
+        if source.dtype == torch.float64:
+            return source.contiguous(), self.engine.XR_F64
+        if source.dtype == torch.float32:
+            return source.contiguous(), self.engine.XR_F32
+        if source.dtype in (torch.float16, torch.bfloat16, torch.bool, torch.uint8, torch.int8, torch.int16,
+                            torch.int32, torch.int64):
+            return source.to(torch.float64).contiguous(), self.engine.XR_F64
+        raise TypeError(f"unsupported source dtype {source.dtype}")
+
     def _handover(self):
         """Work enqueued by torch must be visible to the engine's stream."""
         if not self.shared_stream:
@@ -154,7 +168,7 @@ class HipBackend:
         torch = self.torch
         K = source.shape[0]
         out = torch.empty((K, weights.n), dtype=torch.float64, device=self.device)
-        dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
+        source, dtype = self._typed(source)
         self._handover()
         weights.apply_dev(source.data_ptr(), dtype, K, out.data_ptr(), method_id, percentile)
         self.engine.dev_sync()
@@ -165,7 +179,7 @@ class HipBackend:
         torch = self.torch
         K = source.shape[0]
         out = torch.empty((2, K, weights.n), dtype=torch.float64, device=self.device)
-        dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
+        source, dtype = self._typed(source)
         self._handover()  # inputs produced on torch's stream are ready
         weights.partial_mean_dev(source.data_ptr(), dtype, K, out.data_ptr())
         return out
@@ -182,7 +196,7 @@ class HipBackend:
         torch = self.torch
         K = source.shape[0]
         rows = torch.empty((weights.n, 2 * K), dtype=torch.float64, device=self.device)
-        dtype = self.engine.XR_F64 if source.dtype == torch.float64 else self.engine.XR_F32
+        source, dtype = self._typed(source)
         self._handover()
         weights.partial_mean_rows_dev(source.data_ptr(), dtype, K, rows.data_ptr())
         return rows
@@ -402,6 +416,10 @@ class ShardedOverlapRegridder:
         data = np.asarray(data)
         if data.ndim == 1:
             data = data[None, :]
+        if data.dtype not in (np.float32, np.float64):
+            if data.dtype.kind not in "biuf":
+                raise TypeError(f"unsupported source dtype {data.dtype}")
+            data = data.astype(np.float64)  # as the single-GPU path (engine._source_2d)
         return self.backend.to_device(data[:, self.local_faces])
 
     def regrid_local(self, local_source):
@@ -489,6 +507,10 @@ class TargetPartitionedRegridder:
         data = np.asarray(data)
         if data.ndim == 1:
             data = data[None, :]
+        if data.dtype not in (np.float32, np.float64):
+            if data.dtype.kind not in "biuf":
+                raise TypeError(f"unsupported source dtype {data.dtype}")
+            data = data.astype(np.float64)  # as the single-GPU path (engine._source_2d)
         return self.backend.to_device(data[:, self.local_faces])
 
     def regrid_local(self, local_source):

@@ -326,6 +326,23 @@ def locate_csr(tree: DeviceMesh, query: DeviceMesh = None, points=None, toleranc
     return DeviceCSR(handle)
 
 
+def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_node_map, node_index_threshold):
+    """xugrid/regrid/unstructured.py:17-57 on the device; ``weights`` (float64, C-contiguous) is updated in place."""
+    v = _as_xy(vertices)
+    f = np.ascontiguousarray(faces, dtype=np.int64)
+    fi = np.ascontiguousarray(face_index, dtype=np.int64)
+    nm = np.ascontiguousarray(node_to_node_map, dtype=np.int64).reshape(-1, 2)
+    if weights.dtype != np.float64 or not weights.flags.c_contiguous or weights.ndim != 2:
+        raise ValueError("weights must be a C-contiguous float64 (n, m) array (it is updated in place)")
+    if int(node_index_threshold) != v.shape[0] - nm.shape[0]:
+        raise ValueError("node_index_threshold must be len(vertices) - len(node_to_node_map)")
+    if weights.shape != (fi.size, f.shape[1]):
+        raise ValueError("weights must have one row per point and one column per face slot")
+    check(_lib.load().xr_replace_interpolated_weights(
+        _ptr(v), v.shape[0], _ptr(f), f.shape[0], f.shape[1], _ptr(fi), _ptr(weights), fi.size, _ptr(nm), nm.shape[0]))
+    return weights
+
+
 def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,
                     points=None, tolerance=None, n_identity=0) -> "DeviceCSR":
     """UnstructuredGrid2d.barycentric after the Voronoi pre-step, on the device (see include/xugrid_amd.h).
