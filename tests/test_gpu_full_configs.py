@@ -103,7 +103,8 @@ def test_config4_10m_single_gpu(hip, oracle):
     assert (np.diff(idx)[inner[1:]] > 0).all()  # rows strictly ascending in the source index
     t_area = mt.area()
     row_sum = np.add.reduceat(data, indptr[:-1])
-    np.testing.assert_allclose(row_sum, t_area, rtol=1e-9)
+    # (a handful of the 10M jittered-lattice faces are near-degenerate slivers: absolute floor of 1e-12 mean areas)
+    np.testing.assert_allclose(row_sum, t_area, rtol=1e-9, atol=1e-12 * t_area.mean())
     col_sum = np.bincount(idx, weights=data, minlength=S)
     assert (col_sum <= ms.area() * (1 + 1e-9)).all()
     assert abs(data.sum() / t_area.sum() - 1) < 1e-10
@@ -138,6 +139,6 @@ def test_bench_multi_gpu_path_10m_one_rank():
                "--warmup", "1", "--exchange", exchange]
         proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
         assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
-        line = json.loads(proc.stdout.strip().splitlines()[-1])
+        line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])  # (RCCL prints banners)
         assert line["n_gpus"] == 1 and line["config"]["target_faces"] > 9_900_000
         assert line["value"] > 1e8 and line["config"]["nnz"] > 40_000_000
