@@ -1,0 +1,27 @@
+// CPU harness of xugrid_amd/csrc/xr_clip_tri.h (test infrastructure): one "lane", BLOCK = 1.
+#include "xr_clip_tri.h"
+
+extern "C" double host_tri_clip_area(const double *tv_, const double *sv_) {
+    static uint32_t lut[xr::TRI_LUT];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < xr::TRI_LUT; i++) {
+            threadIdx.x = i;
+            xr::tri_lut_init(lut);
+        }
+        threadIdx.x = 0;
+        init = true;
+    }
+    xr::P2 tv[3], sv[3];
+    for (int j = 0; j < 3; j++) {
+        tv[j] = xr::P2{tv_[2 * j], tv_[2 * j + 1]};
+        sv[j] = xr::P2{sv_[2 * j], sv_[2 * j + 1]};
+    }
+    double2 col[xr::TRI_MAXV + 1];
+    for (auto &c : col) c = double2{NAN, NAN};
+    return xr::tri_clip_area<1>(tv, sv, col, lut, true);
+}
+
+extern "C" void host_tri_clip_many(const double *tv, const double *sv, long n, double *out) {
+    for (long i = 0; i < n; i++) out[i] = host_tri_clip_area(tv + 6 * i, sv + 6 * i);
+}

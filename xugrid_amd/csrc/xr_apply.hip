@@ -390,7 +390,9 @@ k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
                int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
     __shared__ double sh_w[CH];
     __shared__ double sh_v[KTILE][CH];
-    const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
+    // (last row blocks first: weights built by xr_overlap keep the rows of the big target faces -- the long ones --
+    // at the end, and a kernel should start with its heaviest blocks)
+    const int64_t row0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * AP_BLOCK;
     const int64_t t = row0 + threadIdx.x;
     const int64_t row_end = (row0 + AP_BLOCK < T) ? row0 + AP_BLOCK : T;
     const int64_t k0 = (int64_t)blockIdx.y * KTILE;

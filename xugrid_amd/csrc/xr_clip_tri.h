@@ -1,0 +1,225 @@
+// xr_clip_tri.h -- triangle x triangle Sutherland-Hodgman clip + fan area, per lane, few instructions.
+//
+// Same arithmetic, in the same order, as clip_polygons / sh_polygon_area of oracle/xr_oracle.c (the restatement of
+// numba_celltree's clip the parity tests compare with bit for bit): every floating-point value below is produced by
+// the expression the oracle uses.  What differs is the bookkeeping around it.
+//
+// One clip stage (clipper edge r -> s) of the oracle walks the subject polygon vertex by vertex and, per vertex,
+// evaluates an inside test AND (under divergence: for every slot in which any lane of the wave crosses the edge)
+// an intersection with its division.  Here a stage is
+//   1. the inside flags of all vertices (5 flops each), packed into a per-lane bit mask F,
+//   2. the transition slots (f_{j-1} != f_j) by bit arithmetic on F; a convex polygon cut by a line has 0 or 2,
+//   3. exactly two intersections, their end points fetched from the lane's LDS column by dynamic index,
+//   4. a compaction in the oracle's emission order (for j ascending: [crossing point of edge j-1 -> j] [vertex j if
+//      inside]): the positions come from a 64-entry table indexed by (n, F), built once per block in LDS; vertices
+//      outside go to a trash row, so the stores are unconditional,
+//   5. the static-index read-back of the column into registers.
+// Lanes whose polygon is not "regular" run the oracle's loop itself for that stage (tri_stage_generic: same results
+// by construction, only slower, and only for those lanes): more than two transitions, a crossing edge parallel to
+// the clip line (the oracle's keep-b quirk), more vertices than the stage was unrolled for, or a REPEATED vertex
+// (the oracle skips zero-length edges).  Repeated vertices are detected where they are made -- a crossing point
+// equal to an end point of its edge or to the other crossing point, a degenerate input triangle, any output of the
+// generic loop -- and make the lane "dirty" for its remaining stages.  Shared-vertex mesh pairs (a mesh against
+// itself or its refinement) take that branch often; random mesh pairs practically never.
+#pragma once
+
+#include "xr_geom.h"
+
+namespace xr {
+
+static constexpr double TRI_AREA_OVERFLOW = -1.0; // sentinel: more than 6 vertices (floating-point degenerate pair)
+static constexpr int TRI_MAXV = 6;                // rows 0..5 of the LDS column; row 6 = trash row
+static constexpr int TRI_LUT = 64;                // compaction table entries (uint32 each)
+
+// Compaction table: entry (1 << n) + F, n = 3..5 vertices, F = inside mask.  Bits 3j..3j+2 (j < 5): position of
+// vertex j in the output (6 = trash row if outside or j >= n); bits 15..17 / 18..20: positions of the crossing points of
+// the first / second transition slot.  Call with all threads of the block, then __syncthreads().
+__device__ __forceinline__ void tri_lut_init(uint32_t *lut) {
+    const int i = threadIdx.x;
+    if (i >= TRI_LUT) return;
+    uint32_t e = 0;
+    if (i >= 8) {
+        const int n = 31 - __clz(i);
+        const uint32_t F = (uint32_t)i - (1u << n);
+        int before = 0, n_t = 0;
+        for (int j = 0; j < n; j++) {
+            const bool fj = (F >> j) & 1u, fp = (F >> ((j + n - 1) % n)) & 1u;
+            if (fj != fp) {
+                if (n_t < 2) e |= (uint32_t)before << (15 + 3 * n_t);
+                n_t++;
+                before++;
+            }
+            if (fj) e |= (uint32_t)(before++) << (3 * j);
+            else e |= 6u << (3 * j);
+        }
+        for (int j = n; j < 5; j++) e |= 6u << (3 * j); // slots beyond the polygon: trash row
+    }
+    lut[i] = e;
+}
+
+__device__ __forceinline__ bool p2_eq(P2 a, P2 b) { return a.x == b.x && a.y == b.y; }
+__device__ __forceinline__ bool p2_eq(P2 a, double2 b) { return a.x == b.x && a.y == b.y; }
+
+// The oracle's stage loop on a register polygon (static indexing, predicated on the current length); output
+// pushed into the lane's LDS column (row TRI_MAXV = trash row for clamped pushes).
+template <int BLOCK>
+__device__ __forceinline__ void tri_stage_generic(P2 (&v)[TRI_MAXV], int &n, const P2 r, const P2 U, bool &alive,
+                                                  bool &overflow, double2 *col) {
+    const P2 N{-U.y, U.x};
+    int n_output = 0;
+    P2 a = v[0];
+#pragma unroll
+    for (int j = 1; j < TRI_MAXV; j++)
+        if (j < n) a = v[j];
+    bool a_inside = U.x * (a.y - r.y) > U.y * (a.x - r.x);
+#pragma unroll
+    for (int j = 0; j < TRI_MAXV; j++) {
+        if (j < n) {
+            const P2 b = v[j];
+            const P2 V{b.x - a.x, b.y - a.y};
+            const bool live = !(V.x == 0 && V.y == 0);
+            bool b_inside = U.x * (b.y - r.y) > U.y * (b.x - r.x);
+            const bool cross = live && (b_inside != a_inside);
+            P2 pt{0.0, 0.0};
+            bool have_pt = false;
+            if (cross) {
+                const double wx = r.x - a.x, wy = r.y - a.y;
+                const double nw = N.x * wx + N.y * wy;
+                const double nv = N.x * V.x + N.y * V.y;
+                if (nv != 0) {
+                    const double tt = nw / nv;
+                    pt.x = a.x + tt * V.x;
+                    pt.y = a.y + tt * V.y;
+                    have_pt = true;
+                }
+            }
+            const bool quirk = cross && !b_inside && !have_pt; // parallel edge: keep b, which then counts as inside
+            if (cross && have_pt) {
+                col[(n_output < TRI_MAXV ? n_output : TRI_MAXV) * BLOCK] = make_double2(pt.x, pt.y);
+                n_output++;
+            }
+            b_inside = b_inside || quirk;
+            if (live && b_inside) {
+                col[(n_output < TRI_MAXV ? n_output : TRI_MAXV) * BLOCK] = make_double2(b.x, b.y);
+                n_output++;
+            }
+            if (live) {
+                a = b;
+                a_inside = b_inside;
+            }
+        }
+    }
+    if (n_output > TRI_MAXV) {
+        overflow = true;
+        alive = false;
+    } else if (n_output < 3) {
+        alive = false;
+    }
+    n = n_output;
+    if (alive) {
+#pragma unroll
+        for (int k = 0; k < TRI_MAXV; k++) {
+            if (k < n) {
+                const double2 q = col[k * BLOCK];
+                v[k] = P2{q.x, q.y};
+            }
+        }
+    }
+}
+
+// One stage.  NIN = number of vertices the fast path is unrolled for (3, 4, 5 for the three edges of a triangle
+// clipper: a regular stage adds at most one vertex).
+template <int NIN, int BLOCK>
+__device__ __forceinline__ void tri_stage(P2 (&v)[TRI_MAXV], int &n, P2 &r, const P2 s, bool &alive, bool &dirty,
+                                          bool &overflow, double2 *col, const uint32_t *lut) {
+    const P2 U{s.x - r.x, s.y - r.y};
+    const bool work = alive && !(U.x == 0 && U.y == 0); // zero-length clipper edge: the oracle skips the stage, r stays
+    // ---- inside flags as a bit mask (slots >= n masked off)
+    uint32_t F = 0;
+#pragma unroll
+    for (int j = 0; j < NIN; j++) F |= (U.x * (v[j].y - r.y) > U.y * (v[j].x - r.x)) ? (1u << j) : 0u;
+    const uint32_t nmask = (1u << n) - 1u;
+    F &= nmask;
+    const uint32_t Tm = (F ^ ((F << 1) | (F >> ((n - 1) & 31)))) & nmask; // bit j: edge (j-1 -> j) crosses the clip line
+    const int n_tr = __popc(Tm);
+    bool irregular = work && (dirty || n > NIN || (n_tr != 0 && n_tr != 2));
+    const bool two = work && !irregular && n_tr == 2;
+    if (two) {
+        // end points of the two crossing edges from the lane's LDS column (it always holds the current polygon)
+        const int j1 = __ffs(Tm) - 1, j2 = 31 - __clz(Tm);
+        const int p1 = j1 == 0 ? n - 1 : j1 - 1, p2 = j2 - 1;
+        const double2 a1 = col[p1 * BLOCK], b1 = col[j1 * BLOCK], a2 = col[p2 * BLOCK], b2 = col[j2 * BLOCK];
+        const uint32_t e = lut[F + (1u << n)];
+        const P2 N{-U.y, U.x};
+        const P2 V1{b1.x - a1.x, b1.y - a1.y}, V2{b2.x - a2.x, b2.y - a2.y};
+        const double nw1 = N.x * (r.x - a1.x) + N.y * (r.y - a1.y), nv1 = N.x * V1.x + N.y * V1.y;
+        const double nw2 = N.x * (r.x - a2.x) + N.y * (r.y - a2.y), nv2 = N.x * V2.x + N.y * V2.y;
+        const double tt1 = nw1 / nv1, tt2 = nw2 / nv2;
+        const P2 pt1{a1.x + tt1 * V1.x, a1.y + tt1 * V1.y}, pt2{a2.x + tt2 * V2.x, a2.y + tt2 * V2.y};
+        irregular = nv1 == 0 || nv2 == 0; // parallel crossing edge: the oracle's keep-b quirk
+        if (!irregular) {
+            // a crossing point that coincides with a neighbour in the output is a repeated vertex for later stages
+            dirty = p2_eq(pt1, a1) || p2_eq(pt1, b1) || p2_eq(pt2, a2) || p2_eq(pt2, b2) || p2_eq(pt1, pt2);
+            // compaction in the oracle's emission order; vertices outside land in the trash row
+#pragma unroll
+            for (int j = 0; j < NIN; j++) col[((e >> (3 * j)) & 7u) * BLOCK] = make_double2(v[j].x, v[j].y);
+            col[((e >> 15) & 7u) * BLOCK] = make_double2(pt1.x, pt1.y);
+            col[((e >> 18) & 7u) * BLOCK] = make_double2(pt2.x, pt2.y);
+            n = __popc(F) + 2; // (>= 3: a transition implies an inside vertex)
+#pragma unroll
+            for (int k = 0; k < NIN + 1; k++) {
+                const double2 q = col[k * BLOCK]; // (rows >= n: stale values, never used)
+                v[k] = P2{q.x, q.y};
+            }
+        }
+    } else if (work && !irregular && !(F & 1u)) {
+        alive = false; // no transition, first vertex outside: everything is outside
+    }
+    // (no transition, first vertex inside: the polygon is unchanged)
+    if (irregular) {
+        tri_stage_generic<BLOCK>(v, n, r, U, alive, overflow, col);
+        dirty = true; // (the generic loop may emit repeated vertices)
+    }
+    if (work) r = s;
+}
+
+// area of (target triangle tv) clipped by (source triangle sv, counter-clockwise), or TRI_AREA_OVERFLOW.
+// col: the lane's LDS column, col[j * BLOCK], j = 0 .. TRI_MAXV (TRI_MAXV + 1 rows); lut: tri_lut_init's table.
+template <int BLOCK>
+__device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv)[3], double2 *col,
+                                                const uint32_t *lut, bool active) {
+    P2 v[TRI_MAXV];
+#pragma unroll
+    for (int j = 0; j < TRI_MAXV; j++) v[j] = tv[j < 3 ? j : 0];
+    int n = 3;
+    bool alive = active, overflow = false;
+    bool dirty = p2_eq(tv[0], tv[1]) || p2_eq(tv[1], tv[2]) || p2_eq(tv[2], tv[0]);
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) col[j * BLOCK] = make_double2(tv[j].x, tv[j].y);
+    }
+    P2 r = sv[2];
+    tri_stage<3, BLOCK>(v, n, r, sv[0], alive, dirty, overflow, col, lut);
+    tri_stage<4, BLOCK>(v, n, r, sv[1], alive, dirty, overflow, col, lut);
+    tri_stage<5, BLOCK>(v, n, r, sv[2], alive, dirty, overflow, col, lut);
+    if (overflow) return TRI_AREA_OVERFLOW;
+    double area = 0.0;
+    if (alive) {
+        // fan area from the first clipped vertex (local origin)
+        const P2 a0 = v[0];
+        double ux = v[1].x - a0.x, uy = v[1].y - a0.y;
+#pragma unroll
+        for (int i = 2; i < TRI_MAXV; i++) {
+            if (i < n) {
+                const double vx = a0.x - v[i].x, vy = a0.y - v[i].y;
+                area += fabs(ux * vy - uy * vx);
+                ux = vx;
+                uy = vy;
+            }
+        }
+        area = 0.5 * area;
+    }
+    return area;
+}
+
+} // namespace xr

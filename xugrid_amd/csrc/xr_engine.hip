@@ -48,6 +48,9 @@ void engine_init(int device) {
     XR_HIP(hipHostMalloc(&mail, 4096, hipHostMallocCoherent));
     g_engine.mailbox = static_cast<volatile int32_t *>(mail);
     XR_HIP(hipEventCreateWithFlags(&g_engine.mail_event, hipEventDisableTiming | hipEventReleaseToSystem));
+    XR_HIP(hipStreamCreateWithFlags(&g_engine.side, hipStreamNonBlocking));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, hipEventDisableTiming));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, hipEventDisableTiming));
     g_engine.device = device;
 }
 
@@ -257,18 +260,35 @@ ProfScope::ProfScope(const char *n) : name(n) {
     if (!g_engine.prof) return;
     e0 = get_event();
     e1 = get_event();
-    (void)hipEventRecord(e0, engine().stream);
+    (void)hipEventRecord(e0, launch_stream());
+    on_side = g_engine.on_side;
 }
 
 ProfScope::~ProfScope() {
     if (!e0) return;
-    (void)hipEventRecord(e1, g_engine.stream);
+    (void)hipEventRecord(e1, on_side ? g_engine.side : g_engine.stream);
     g_pending.push_back({name, e0, e1});
+}
+
+SideScope::SideScope() {
+    Engine &e = engine();
+    XR_HIP(hipEventRecord(e.fork_event, e.stream));
+    XR_HIP(hipStreamWaitEvent(e.side, e.fork_event, 0));
+    e.on_side = true;
+}
+SideScope::~SideScope() {
+    g_engine.on_side = false;
+    (void)hipEventRecord(g_engine.join_event, g_engine.side);
+}
+void side_join() {
+    Engine &e = engine();
+    XR_HIP(hipStreamWaitEvent(e.stream, e.join_event, 0));
 }
 
 void prof_flush() {
     if (g_pending.empty()) return;
     (void)hipStreamSynchronize(g_engine.stream);
+    (void)hipStreamSynchronize(g_engine.side);
     for (auto &p : g_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {

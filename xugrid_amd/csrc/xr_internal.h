@@ -76,7 +76,13 @@ struct Engine {
     volatile int32_t *mailbox = nullptr; // [1024]
     hipEvent_t mail_event = nullptr;
     bool prof = false;
+    // side stream for work that is independent of the main chain for a while (the big target faces of xr_overlap):
+    // forked / joined with events, never synchronised with the host on its own
+    hipStream_t side = nullptr;
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
+    bool on_side = false; // XR_LAUNCH and the kernel timer go to the side stream while set
 };
+inline hipStream_t launch_stream();
 void mailbox_wait(); // everything enqueued so far has executed and its mailbox writes are visible
 Engine &engine();      // initialises device 0 on first use
 void engine_init(int device);
@@ -136,6 +142,7 @@ template <typename T> T read_scalar(const T *dev) {
 struct ProfScope {
     const char *name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool on_side = false;
     explicit ProfScope(const char *name);
     ~ProfScope();
 };
@@ -144,9 +151,19 @@ void prof_flush(); // resolve pending events into the per-name table
 #define XR_LAUNCH(name, kernel, grid, block, shmem, ...)                                        \
     do {                                                                                        \
         xr::ProfScope _ps(name);                                                                \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, xr::engine().stream, __VA_ARGS__);       \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, xr::launch_stream(), __VA_ARGS__);       \
         XR_HIP(hipGetLastError());                                                              \
     } while (0)
+
+inline hipStream_t launch_stream() { return engine().on_side ? engine().side : engine().stream; }
+
+// RAII: launches inside the scope go to the side stream, which first waits for everything enqueued on the main
+// stream so far; join() makes the main stream wait for the side stream's work
+struct SideScope {
+    SideScope();
+    ~SideScope();
+};
+void side_join();
 
 inline unsigned div_up(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 

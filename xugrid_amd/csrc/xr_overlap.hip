@@ -25,6 +25,7 @@
 // The clip arithmetic mirrors oracle/xr_oracle.c (clip_polygons / sh_polygon_area) operation
 // for operation; both are built with -ffp-contract=off, so areas agree bit for bit.
 #include "xr_objects.h"
+#include "xr_clip_tri.h"
 
 namespace xr {
 
@@ -663,6 +664,64 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
     }
 }
 
+// Triangle x triangle pairs (both meshes pure triangle meshes): the flag / compaction formulation of
+// xr_clip_tri.h -- about half the instructions of k_clip_small<6, 256, true>, same areas bit for bit.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__ s_fxy, int s_m,
+           const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
+           double *__restrict__ cand_area, const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
+           int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x; // col[j * BLOCK]
+    __shared__ uint32_t sh_lut[TRI_LUT];
+    const int64_t n_blocks = (n_cand + BLOCK - 1) / BLOCK;
+    const int64_t lb = xcd_block(n_blocks, remap);
+    if (lb >= n_blocks) return;
+    tri_lut_init(sh_lut);
+    __syncthreads();
+    const int64_t c = lb * BLOCK + threadIdx.x;
+    const bool active = c < n_cand;
+    int t = -1;
+    P2 tv[3] = {{0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
+    if (active) {
+        t = cand_tgt[c];
+        const int s = cand_src[c];
+        cand_sid[c] = rec_face[s];
+        const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
+        const double2 *sf = reinterpret_cast<const double2 *>(s_fxy) + (int64_t)s * s_m;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double2 a = tf[j], b = sf[j];
+            tv[j] = P2{a.x, a.y};
+            sv[j] = P2{b.x, b.y};
+        }
+    }
+    double area = tri_clip_area<BLOCK>(tv, sv, col, sh_lut, active);
+    if (active) {
+        if (area == TRI_AREA_OVERFLOW) {
+            area = AREA_OVERFLOW;
+            atomicAdd(overflow_count, 1);
+        }
+        cand_area[c] = area;
+    }
+    {
+        const int lane = threadIdx.x & 63;
+        const int t_prev = __shfl_up(t, 1, 64);
+        const bool head = lane == 0 || t_prev != t;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long surv = __ballot(active && area > 0);
+        if (head && t >= 0) {
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+            unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
+            run &= ~((1ull << lane) - 1);
+            const int n = __popcll(surv & run);
+            if (n > 0) atomicAdd(&nnz_row[t], n);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // CSR assembly
 // ---------------------------------------------------------------------------------------------
@@ -807,7 +866,8 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 const double *__restrict__ cand_area, const int32_t *__restrict__ indptr,
                 const double *__restrict__ src_area, bool relative, int64_t n_tree, int32_t *__restrict__ indices,
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
-                const int32_t *__restrict__ n_long) {
+                const int32_t *__restrict__ n_long, int64_t row_base /* >= 0: list entry li is stored row row_base + li */,
+                const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);          // [BM_WORDS]
     uint32_t *tbase = bm + BM_WORDS;                            // [256] exclusive over thread segments
@@ -815,11 +875,12 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     int32_t *stage = red + 8;                                   // [BM_STAGE]
     uint16_t *gcnt = reinterpret_cast<uint16_t *>(stage + BM_STAGE); // [BM_WORDS / 8] bits per 8 words -> prefix in segment
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (skip_if && *skip_if > 0) return;
     const int nl = *n_long;
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
         const int c0 = cand_off[t], n = cand_count[t];
-        const int base = indptr[t];
+        const int base = row_base >= 0 ? indptr[row_base + li] : indptr[t];
         __syncthreads();
         // park the row: survivor id or -1 (four independent pairs of loads per thread and trip)
         for (int i0 = tid; i0 < n && i0 < BM_STAGE; i0 += 4 * 256) {
@@ -928,6 +989,10 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     }
 }
 
+} // namespace xr
+#include "xr_overlap_fused.h"
+namespace xr {
+
 static int xcd_remap_mask() {
     // bit 0 clip, bit 1 search, bit 2 row_fill.  Default: clip + search -- 15 % fewer HBM bytes fetched by both
     // (PMC: clip 161 -> 130 MB, search 56 -> 48 MB per launch) at an unchanged clip time and a 5 % shorter search;
@@ -963,10 +1028,16 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
         // triangle x triangle: the clipped polygon never has more than 6 vertices
         constexpr int MAXV = 6, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
-        XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
-                  shmem, query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
-                  tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
-                  overflow_count, nnz_row, remap);
+        static const bool old_clip = getenv("XR_CLIP_OLD") != nullptr; // measurement switch: the slot-loop kernel
+        if (old_clip)
+            XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
+                      shmem, query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
+                      tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
+                      overflow_count, nnz_row, remap);
+        else
+            XR_LAUNCH("clip_tri", (k_clip_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
+                      query->qo_fxy(), query->m, tree->rec_fxy.get(), tree->m, cand_tgt, cand_src, C, cand_area,
+                      tree->rec_face.get(), cand_sid, overflow_count, nnz_row, remap);
     } else if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
@@ -977,6 +1048,119 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
     }
     else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
     else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
+}
+
+// Triangle x triangle pairs (xr_overlap_fused.h): search -> persistent clip -> assembly with a look-back scan, the big
+// faces of the search (hull slivers ...) on a side stream, their rows stored behind the regular ones; ONE host round
+// trip at the very end (sizes + error bits).  -> false if the pair has to go through the general pipeline after all
+// (a clip that needs more than 6 vertices: floating-point degenerate input; or the look-back chain gave up).
+static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, const MortonParams &tile) {
+    const int64_t T = query->n_face;
+    const GridParams &g = tree->grid;
+    hipStream_t st = engine().stream;
+    const int64_t n_blocks = div_up(T, FB);
+    const bool remap = xcd_remap_mask() & 2;
+    const unsigned grid = xcd_grid(n_blocks, remap);
+    const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
+    int64_t big_capacity = margin_env ? std::max<int64_t>((int64_t)atoll(margin_env), 1) : ((int64_t)4 << 20);
+    const int64_t reg_capacity = T * SLOTS;
+    int64_t per_face = 8; // CSR entries reserved per target face (+ the big queue); regrown if the matrix is denser
+    int32_t *mail = const_cast<int32_t *>(engine().mailbox);
+    static_assert(sizeof(FusedCounters) == 32, "FusedCounters layout");
+    // ctl: [0] regular queue cursor, [1] big queue cursor, [2] big faces, [3] big faces that did not fit, [4] clip
+    // overflows among the big pairs | FusedCounters | look-back status words
+    DevBuf<int32_t> ctl(8 + sizeof(FusedCounters) / 4 + 2 * (size_t)grid);
+    FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl.get() + 8);
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl.get() + 16);
+    DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T), pending((size_t)T), nnz_row((size_t)T),
+        slot_face((size_t)T), big_indptr((size_t)T + 1);
+    DevBuf<uint8_t> is_big((size_t)T);
+    DevBuf<int2> block_seg((size_t)n_blocks);
+    DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)reg_capacity);
+    DevBuf<double> cand_area((size_t)reg_capacity);
+    csr->n_long.alloc(1);
+    csr->row_order.alloc((size_t)T);
+    csr->has_row_order = true;
+    const int big_grid = engine().num_cu * 8;
+    constexpr int CLIP_BLOCK = 256;
+    const size_t clip_shmem = (size_t)(TRI_MAXV + 1) * CLIP_BLOCK * sizeof(double2);
+    const size_t fill_shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_row_fill_long),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)fill_shmem));
+        attr_set = true;
+    }
+    for (int attempt = 0;; attempt++) {
+        XR_REQUIRE(attempt < 8, XR_ERR_LIMIT, "xr_overlap: the weight matrix does not fit the device buffers");
+        const int64_t cap = per_face * T + big_capacity;
+        XR_REQUIRE(cap < ((int64_t)1 << 31), XR_ERR_LIMIT, "nnz exceeds the int32 range");
+        csr->indices.alloc((size_t)cap);
+        csr->data.alloc((size_t)cap);
+        csr->long_rows.alloc((size_t)(cap / XR_APPLY_LONG_ROW + 1));
+        DevBuf<int32_t> big_tgt((size_t)big_capacity), big_src((size_t)big_capacity), big_sid((size_t)big_capacity),
+            big_indices((size_t)big_capacity);
+        DevBuf<double> big_area((size_t)big_capacity), big_data((size_t)big_capacity);
+        XR_HIP(hipMemsetAsync(ctl.get(), 0, ctl.bytes(), st));
+        XR_LAUNCH("search", k_search, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->cell_start.get(),
+                  tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl.get() + 0,
+                  block_seg.get(), is_big.get(), big_list.get(), ctl.get() + 2, tile, (int32_t *)nullptr, nnz_row.get(),
+                  remap);
+        {
+            // ---- side stream: everything about the big faces except their final placement
+            SideScope side;
+            XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
+                      query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
+                      big_list.get(), ctl.get() + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
+                      ctl.get() + 1, big_capacity, pending.get(), ctl.get() + 3);
+            // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
+            XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
+                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl.get() + 1,
+                      big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl.get() + 3);
+            XR_LAUNCH("big_order", k_big_order, dim3(1), dim3(256), 0, big_list.get(), ctl.get() + 2, nnz_row.get(),
+                      slot_face.get(), big_indptr.get(), fc, ctl.get() + 3);
+            XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
+                      cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree->area.get(), relative,
+                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3);
+        }
+        XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu * 5), dim3(CLIP_BLOCK), clip_shmem,
+                  query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
+                  ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                  (const int32_t *)nullptr);
+        XR_LAUNCH("assemble", k_assemble, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
+                  cand_off.get(), cand_count.get(), block_seg.get(), is_big.get(), cand_area.get(), cand_sid.get(),
+                  tree->area.get(), relative, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc,
+                  status, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
+                  csr->long_rows.get(), cap, remap);
+        side_join();
+        XR_LAUNCH("place_big", k_place_big, dim3(64), dim3(256), 0, ctl.get() + 2, slot_face.get(), big_indptr.get(),
+                  big_indices.get(), big_data.get(), T, query->qo_perm(), query->qo_bbox(), tile,
+                  csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, csr->indptr.get(), csr->indices.get(),
+                  csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, ctl.get() + 3);
+        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl.get(), fc, csr->n_long.get(), mail);
+        mailbox_wait();
+        const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], n_pending = mail[3], big_overflow = mail[4];
+        const int32_t err = mail[5], rows_regular = mail[6], p_regular = mail[8], p_big = mail[9];
+        XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
+        if (getenv("XR_DEBUG_FUSED"))
+            fprintf(stderr, "[tri] T=%lld C=%d big: %d faces %d pairs (%d pending) p_regular=%d p_big=%d err=%d rows=%d long=%d\n",
+                    (long long)T, C_reg, n_big, C_big, n_pending, p_regular, p_big, err, rows_regular, mail[7]);
+        (void)big_overflow;
+        if (err & (1 | 8)) return false;
+        if (n_pending > 0 || C_big > big_capacity) { // some big faces needed more room than the margin
+            big_capacity = (int64_t)C_big + 1024;
+            continue;
+        }
+        if ((err & 4) || (int64_t)p_regular + p_big > cap) {
+            per_face *= 2;
+            continue;
+        }
+        XR_REQUIRE(rows_regular == T - n_big, XR_ERR_INVALID, "xr_overlap: internal row count mismatch");
+        tree->last_candidates = (int64_t)C_reg + C_big;
+        csr->nnz = (int64_t)p_regular + p_big;
+        csr->has_long = true;
+        return true;
+    }
 }
 
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
@@ -999,22 +1183,6 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     }
     const GridParams &g = tree->grid;
     hipStream_t st = engine().stream;
-    // counters: [0] clip overflow, [1] number of long rows, [2] number of big query faces, [3] pair-queue cursor
-    DevBuf<int32_t> counters(4);
-    XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 4, st));
-    // --- candidate search.  k_search appends the candidates of its 256 faces to the pair queue itself (one
-    // atomic reservation per block); the few "big" faces are counted, reserve their stretch, and are filled by
-    // the block-per-face kernels.  The queue is sized for the regular faces (at most SLOTS candidates each) plus
-    // a margin for the big ones; if the big faces need more, it is regrown before they are filled (rare).
-    DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
-    DevBuf<uint8_t> is_big((size_t)T);
-    const int big_grid = engine().num_cu * 8;
-    const int64_t n_blocks = div_up(T, 256);
-    DevBuf<int2> block_seg((size_t)n_blocks);
-    const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
-    int64_t capacity = T * SLOTS + (margin_env ? (int64_t)atoll(margin_env) : ((int64_t)4 << 20));
-    XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
-    DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     // Rows kept in the caller's (coherent, but typically strip-like) numbering get a coarse Morton key each:
     // tiles of 12-24 mean target extents, runs of TILE_RUN consecutive rows kept together.  A Morton-sorted query order is tiled already.
     MortonParams tile{};
@@ -1034,6 +1202,30 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->tile_key_range = (int64_t)1 << (2 * bits);
         csr->has_tile_key = bits > 0;
     }
+    {
+        // triangle x triangle: clip + assembly in one kernel (XR_OVERLAP_FUSED=0: measurement switch back to the kernel chain)
+        static const bool fused_on = !(getenv("XR_OVERLAP_FUSED") && atoi(getenv("XR_OVERLAP_FUSED")) == 0);
+        if (fused_on && tree->m == 3 && query->m == 3 && T * SLOTS < ((int64_t)1 << 31)) {
+            if (overlap_tri(tree, query, relative, csr, tile)) return;
+            csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
+        }
+    }
+    // counters: [0] clip overflow, [1] number of long rows, [2] number of big query faces, [3] pair-queue cursor
+    DevBuf<int32_t> counters(4);
+    XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 4, st));
+    // --- candidate search.  k_search appends the candidates of its 256 faces to the pair queue itself (one
+    // atomic reservation per block); the few "big" faces are counted, reserve their stretch, and are filled by
+    // the block-per-face kernels.  The queue is sized for the regular faces (at most SLOTS candidates each) plus
+    // a margin for the big ones; if the big faces need more, it is regrown before they are filled (rare).
+    DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T);
+    DevBuf<uint8_t> is_big((size_t)T);
+    const int big_grid = engine().num_cu * 8;
+    const int64_t n_blocks = div_up(T, 256);
+    DevBuf<int2> block_seg((size_t)n_blocks);
+    const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
+    int64_t capacity = T * SLOTS + (margin_env ? (int64_t)atoll(margin_env) : ((int64_t)4 << 20));
+    XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
+    DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     const bool remap_search = xcd_remap_mask() & 2, remap_rows = xcd_remap_mask() & 4;
     XR_LAUNCH("search", k_search, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
@@ -1125,7 +1317,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         }
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
                   cand_count.get(), cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, tree->n_face,
-                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1);
+                  csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, (int64_t)-1, (const int32_t *)nullptr);
     }
 }
 

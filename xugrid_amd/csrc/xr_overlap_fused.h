@@ -1,0 +1,398 @@
+// xr_overlap_fused.h -- triangle x triangle pairs without the host in the loop (included by xr_overlap.hip; reference
+// seam: CellTree2d.intersect_faces + weights /= area + MatrixCSR.from_triplet, xugrid/regrid/unstructured.py:109-135,
+// xugrid/regrid/regridder.py:433-435).
+//
+// The general kernel chain search -> [host: C] -> clip (+ row counts by global atomics) -> scan (2 launches) -> [host: nnz]
+// -> row_fill needs the host twice.  For triangle meshes:
+//   k_search / k_search_big   as before, big faces into their own queue
+//   k_clip_tri_queue          persistent clip over the regular pair queue; its length is read from device memory, so
+//                             the launch does not wait for the host; chunks software-pipelined
+//   k_assemble                the block that owns 256 consecutive target faces counts its survivors in LDS, learns its
+//                             first stored row and its CSR base from a decoupled look-back scan over (rows, entries),
+//                             ranks every survivor among its row and writes the final CSR.  No scan pass, no row
+//                             counters in HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)
+//   big faces (hull slivers, > SLOTS hits; 0.1 % of the faces, but their block-per-face kernels are chains of dependent
+//   phases: 15 % of the step when run in line) on a SIDE STREAM, forked behind k_search: k_search_big -> k_clip_tri_queue on
+//   their own pair queue -> k_big_order (rows in face order, scan of their lengths) -> k_row_fill_long into a small
+//   CSR of their own; joined behind k_assemble, k_place_big copies those rows BEHIND the regular ones.
+//   [host: sizes + error bits: ONE round trip for the whole weight matrix]
+// Measured and discarded on the way (MI355X, benchmark pair): a fully fused search + clip + assembly block (pairs never
+// leave LDS): correct, but the grid walk is a chain of dependent loads that needs ~7 waves per SIMD, the LDS staging
+// allows 2 -- 0.68 ms against 0.31 ms for separate kernels; clip + assembly in one kernel: the clip is FP64-issue bound
+// and needs 5 waves per SIMD, the staging leaves 3 -- 0.33 ms against 0.25 ms (and with the look-back inside, 1 ... 16
+// clip rounds per block make every generation of resident blocks last as long as its slowest member); rows of the
+// assembly placed by ONE returning 64-bit atomic per block instead of the look-back: 4000 atomics on one address cost
+// 30 us (and a "last block done" counter another 27 us).
+#pragma once
+
+namespace xr {
+
+static constexpr int FB = 256;            // faces (= threads) per block: the block granularity of k_search's queue stretches
+static constexpr int FWAVES = FB / 64;
+
+struct FusedCounters {                    // device words, zeroed before the launch
+    int32_t n_apply_long;                 // rows with more than XR_APPLY_LONG_ROW entries
+    int32_t error;                        // bit 0: clip buffer overflow, bit 2: CSR capacity, bit 3: look-back aborted
+    int32_t p_regular;                    // entries of all regular rows (k_assemble)
+    int32_t rows_regular;                 // regular rows
+    int32_t p_big;                        // entries of the big faces' rows (k_big_order)
+    int32_t pad[3];
+};
+
+// Decoupled look-back: one 64-bit status word per block -- nothing yet / the block's own aggregate / its inclusive prefix.
+// Value: rows in bits 31..61, entries in bits 0..30 (both totals stay below 2^31, so sums never carry across).  Blocks
+// are chained in blockIdx order (the dispatcher starts blocks in that order, so a predecessor is running or done; no
+// ticket counter: 4000 returning atomics on one address cost 30-40 us by themselves).  HIP does not PROMISE that order,
+// so every spin is bounded: a block that waits longer than LB_SPIN_LIMIT polls raises the abort bit and the host
+// falls back to the scan-based pipeline.
+static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
+static constexpr int LB_SPIN_LIMIT = 1 << 16; // polls (~20 ms): far beyond any real wait
+
+// exclusive prefix of this block's aggregate over all earlier blocks (called by the 64 lanes of wave 0); -1 = aborted
+__device__ __forceinline__ long long lookback_exclusive(unsigned long long *status, int b, long long aggregate, int lane,
+                                                        int32_t *error_bits) {
+    if (b == 0) {
+        if (lane == 0) __hip_atomic_store(&status[0], LB_PREFIX | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&status[b], LB_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    long long exclusive = 0;
+    int look = b - 1, spins = 0;
+    while (true) {
+        const int idx = look - lane;
+        unsigned long long word = LB_PREFIX; // (virtual block -1: prefix 0)
+        if (idx >= 0) word = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long flag = word >> 62;
+        const unsigned long long not_ready = __ballot(flag == 0), has_prefix = __ballot(flag == 2);
+        const int first_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : 64;
+        const int first_wait = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+        if (first_wait < first_prefix) { // a predecessor in the window has published nothing yet
+            if (++spins > LB_SPIN_LIMIT || (__hip_atomic_load(error_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8)) {
+                if (lane == 0) atomicOr(error_bits, 8);
+                exclusive = -1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        long long v = lane <= first_prefix ? (long long)(word & LB_VALUE) : 0;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        exclusive += v;
+        if (first_prefix < 64) break;
+        look -= 64;
+    }
+    // (after an abort the prefix is garbage, but it is published all the same so that nobody else spins)
+    if (lane == 0)
+        __hip_atomic_store(&status[b], LB_PREFIX | (unsigned long long)((exclusive < 0 ? 0 : exclusive) + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return exclusive;
+}
+
+// block-wide exclusive scan of one int per thread (FB threads); returns the exclusive value, total in *total
+__device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += u;
+    }
+    __syncthreads(); // (sh_wave may still be read from an earlier scan)
+    if (lane == 63) sh_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FWAVES; w++) {
+        if (w < wave) woff += sh_wave[w];
+        tot += sh_wave[w];
+    }
+    *total = tot;
+    return woff + incl - v;
+}
+
+// Persistent triangle x triangle clip over the regular pair queue: the number of pairs is read from device memory
+// (the search's queue cursor), so the launch needs no host round trip; every block walks chunks of 256 pairs.  Chunks are dealt so that every XCD works on one contiguous eighth of the queue (the order
+// k_search wrote it in: the vertex blocks are in that XCD's L2).
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
+                 const int32_t *__restrict__ rec_face, const int32_t *__restrict__ cand_tgt,
+                 const int32_t *__restrict__ cand_src, const int32_t *__restrict__ n_cand_dev, int64_t capacity,
+                 double *__restrict__ cand_area, int32_t *__restrict__ cand_sid, int32_t *__restrict__ error_bits,
+                 int32_t *__restrict__ nnz_row /* optional: survivors per target face, counted by atomics */,
+                 const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x; // col[j * BLOCK]
+    __shared__ uint32_t sh_lut[TRI_LUT];
+    if (skip_if && *skip_if > 0) return; // (big faces that did not fit their queue: the host redoes everything)
+    tri_lut_init(sh_lut);
+    __syncthreads();
+    const int64_t n_cand = *n_cand_dev < capacity ? *n_cand_dev : capacity; // (a queue that overflowed is redone by the host)
+    const int64_t n_chunks = (n_cand + BLOCK - 1) / BLOCK;
+    const int64_t per_xcd = (n_chunks + 7) >> 3;
+    const int64_t n_slots = per_xcd * 8; // chunk slots incl. the empty ones of the last eighths
+    auto chunk_of = [&](int64_t j) -> int64_t { // j-th slot -> logical chunk (>= n_chunks: nothing)
+        return (j & 7) * per_xcd + (j >> 3);
+    };
+    const double2 *tfx = reinterpret_cast<const double2 *>(q_fxy);
+    const double2 *sfx = reinterpret_cast<const double2 *>(rec_fxy);
+    const int tid = threadIdx.x;
+    // the pair indices of the NEXT chunk are fetched while a chunk is clipped (its vertex gathers then start at once;
+    // prefetching the vertex blocks as well costs 36 more registers = a wave per SIMD, and the clip is issue bound)
+    int n_tq = 0, n_s = 0;
+    auto load_idx = [&](int64_t slot, int &tq, int &s) {
+        tq = 0;
+        s = 0;
+        if (slot < n_slots) {
+            const int64_t c = chunk_of(slot) * BLOCK + tid;
+            if (c < n_cand) {
+                tq = cand_tgt[c];
+                s = cand_src[c];
+            }
+        }
+    };
+    const int64_t stride = gridDim.x;
+    int64_t slot = blockIdx.x;
+    load_idx(slot, n_tq, n_s);
+    bool overflow = false;
+    for (; slot < n_slots; slot += stride) {
+        const int64_t c = chunk_of(slot) * BLOCK + tid;
+        const bool active = c < n_cand;
+        P2 tv[3] = {{0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
+        int sid = 0;
+        const int cur_tq = n_tq;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double2 a = tfx[(int64_t)n_tq * 3 + j], b2 = sfx[(int64_t)n_s * 3 + j];
+                tv[j] = P2{a.x, a.y};
+                sv[j] = P2{b2.x, b2.y};
+            }
+            sid = rec_face[n_s];
+        }
+        load_idx(slot + stride, n_tq, n_s);
+        const double area = tri_clip_area<BLOCK>(tv, sv, col, sh_lut, active);
+        const int tq_now = active ? cur_tq : -1;
+        if (active) {
+            overflow = overflow || area == TRI_AREA_OVERFLOW;
+            cand_area[c] = area;
+            cand_sid[c] = area > 0 ? sid : 0x7fffffff;
+        }
+        if (nnz_row) {
+            // pairs of one target face are contiguous: the head lane of each run of equal faces adds the run's survivors
+            const int lane = tid & 63;
+            const int t_prev = __shfl_up(tq_now, 1, 64);
+            const bool head = lane == 0 || t_prev != tq_now;
+            const unsigned long long heads = __ballot(head);
+            const unsigned long long surv = __ballot(active && area > 0);
+            if (head && tq_now >= 0) {
+                const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+                const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+                unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
+                run &= ~((1ull << lane) - 1);
+                const int n = __popcll(surv & run);
+                if (n > 0) atomicAdd(&nnz_row[tq_now], n);
+            }
+        }
+    }
+    if (overflow) atomicOr(error_bits, 1);
+}
+
+// CSR assembly for the regular faces: the block that owns 256 consecutive target faces stages the source ids of its
+// stretch of the pair queue in LDS ("dead" for area <= 0), counts the survivors per face (LDS atomics), reserves its
+// rows and entries with ONE atomic, ranks every survivor among its row and writes it to its final CSR position.
+__global__ void __launch_bounds__(FB)
+k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm, int64_t n_query,
+           const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_off,
+           const int32_t *__restrict__ cand_count, const int2 *__restrict__ block_seg,
+           const uint8_t *__restrict__ is_big, const double *__restrict__ cand_area,
+           const int32_t *__restrict__ cand_sid, const double *__restrict__ src_area, bool relative, MortonParams tile,
+           int32_t *__restrict__ tile_key, FusedCounters *__restrict__ counters, unsigned long long *__restrict__ status,
+           int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ row_order,
+           int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap) {
+    __shared__ int32_t sh_stage[SLOTS * FB];
+    __shared__ uint8_t sh_owner[SLOTS * FB];
+    __shared__ int32_t sh_nnz[FB];     // survivors of the face (LDS atomics)
+    __shared__ uint16_t sh_lo[FB];     // offset of the face's pairs inside the stretch
+    __shared__ uint16_t sh_rowoff[FB]; // CSR offset of the face's row inside the block
+    __shared__ uint8_t sh_cnt[FB];     // pairs of the face (0 for big faces)
+    __shared__ int32_t sh_wave[FWAVES];
+    __shared__ long long sh_base;
+    const int tid = threadIdx.x;
+    const int64_t n_blocks = (n_query + FB - 1) / FB;
+    const int64_t lb = xcd_block(n_blocks, remap); // (blocks beyond n_blocks carry no faces but stay in the chain)
+    const bool valid_block = lb < n_blocks;
+    sh_nnz[tid] = 0;
+    const int64_t t0 = lb * FB;
+    const int64_t t = t0 + tid;
+    const bool in_range = valid_block && t < n_query;
+    const int2 seg = valid_block ? block_seg[lb] : make_int2(0, 0);
+    const int total = seg.y;
+    bool regular = false;
+    int my_cnt = 0;
+    if (in_range) {
+        regular = !is_big[t];
+        my_cnt = regular ? cand_count[t] : 0;
+        sh_lo[tid] = (uint16_t)(regular ? cand_off[t] - seg.x : 0);
+    } else {
+        sh_lo[tid] = 0;
+    }
+    sh_cnt[tid] = (uint8_t)my_cnt;
+    __syncthreads();
+    for (int i = tid; i < total; i += FB) {
+        const int64_t c = (int64_t)seg.x + i;
+        const int s = cand_sid[c];
+        const int row = cand_tgt[c] - (int)t0;
+        sh_stage[i] = s;
+        sh_owner[i] = (uint8_t)row;
+        if (s != 0x7fffffff) atomicAdd(&sh_nnz[row], 1);
+    }
+    __syncthreads();
+    const int my_nnz = regular ? sh_nnz[tid] : 0;
+    int block_nnz = 0, block_rows = 0;
+    const int rowoff = block_excl_scan(my_nnz, sh_wave, &block_nnz);
+    const int rowidx = block_excl_scan(regular ? 1 : 0, sh_wave, &block_rows);
+    sh_rowoff[tid] = (uint16_t)rowoff;
+    const int b = (int)blockIdx.x, n_chain = (int)gridDim.x;
+    if (tid < 64) {
+        const long long packed = lookback_exclusive(status, b, ((long long)block_rows << 31) | (long long)block_nnz, tid, &counters->error);
+        if (tid == 0) sh_base = packed;
+    }
+    __syncthreads();
+    if (sh_base < 0) return; // aborted (the host falls back)
+    const long long base = sh_base & 0x7fffffffll, row_base = sh_base >> 31;
+    if (b == n_chain - 1 && tid == 0) {
+        const long long entries = base + block_nnz, rows = row_base + block_rows;
+        counters->p_regular = (int32_t)entries; // entries of all regular rows
+        counters->rows_regular = (int32_t)rows;
+        indptr[rows] = (int32_t)entries;        // (= indptr[T] when there are no big faces)
+    }
+    if (regular) {
+        const long long r = row_base + rowidx; // stored row of the face
+        indptr[r] = (int32_t)(base + rowoff);
+        row_order[r] = q_perm ? q_perm[t] : (int32_t)t;
+        if (tile_key) {
+            const int64_t mid = (t & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
+            tile_key[r] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
+        }
+        if (my_nnz > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+    }
+    bool overflow_cap = false;
+    for (int i = tid; i < total; i += FB) {
+        const int s = sh_stage[i];
+        if (s == 0x7fffffff) continue;
+        const int row = sh_owner[i];
+        const int a0 = sh_lo[row], a1 = a0 + sh_cnt[row];
+        int rank = 0;
+        for (int j = a0; j < a1; j++) rank += sh_stage[j] < s ? 1 : 0;
+        const long long pos = base + sh_rowoff[row] + rank;
+        const double a = cand_area[(int64_t)seg.x + i];
+        if (pos < csr_capacity) {
+            indices[pos] = s;
+            data[pos] = relative ? a / src_area[s] : a;
+        } else {
+            overflow_cap = true;
+        }
+    }
+    if (overflow_cap) atomicOr(&counters->error, 4);
+}
+
+// ---- the big faces' rows (side stream) -------------------------------------------------------------------------------
+// Order of the big faces' rows: by face id (k_search lists them in finishing order; ranking makes the stored matrix the
+// same from run to run), and the exclusive scan of their lengths.  One block; the list sits in LDS up to BIG_LDS faces,
+// longer lists (a coarse target over a fine source) keep the order they were found in.
+static constexpr int BIG_LDS = 8192;
+__global__ void __launch_bounds__(256)
+k_big_order(const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big_dev,
+            const int32_t *__restrict__ nnz_row /* per face */, int32_t *__restrict__ slot_face,
+            int32_t *__restrict__ big_indptr /* [n_big + 1] */, FusedCounters *counters,
+            const int32_t *__restrict__ skip_if) {
+    if (*skip_if > 0) return;
+    __shared__ int32_t sh_part[256];
+    __shared__ int32_t sh_face[BIG_LDS];
+    const int tid = threadIdx.x;
+    const int n_big = *n_big_dev;
+    const bool sorted = n_big <= BIG_LDS;
+    for (int k = tid; k < n_big && sorted; k += 256) sh_face[k] = big_list[k];
+    __syncthreads();
+    for (int k = tid; k < n_big; k += 256) {
+        const int f = big_list[k];
+        int rank = sorted ? 0 : k;
+        for (int j = 0; j < n_big && sorted; j++) rank += sh_face[j] < f ? 1 : 0;
+        slot_face[rank] = f;
+    }
+    __syncthreads(); // (slot_face: written by this block, read back below through L2)
+    const int chunk = (n_big + 255) / 256;
+    const int k0 = min(tid * chunk, n_big), k1 = min(k0 + chunk, n_big);
+    int sum = 0;
+    for (int k = k0; k < k1; k++) sum += nnz_row[__hip_atomic_load(&slot_face[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    sh_part[tid] = sum;
+    __syncthreads();
+    long long off = 0, all = 0;
+    for (int j = 0; j < 256; j++) {
+        if (j < tid) off += sh_part[j];
+        all += sh_part[j];
+    }
+    for (int k = k0; k < k1; k++) {
+        big_indptr[k] = (int32_t)off;
+        off += nnz_row[__hip_atomic_load(&slot_face[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    }
+    if (tid == 0) {
+        big_indptr[n_big] = (int32_t)(all > 0x7fffffffll ? 0x7fffffff : all);
+        counters->p_big = big_indptr[n_big];
+    }
+}
+
+// The finished rows of the big faces (ranked by k_row_fill_long into big_indices / big_data on the side stream) go
+// BEHIND the regular rows: stored row T - n_big + slot.  Grid-stride over rows and entries.
+__global__ void __launch_bounds__(256)
+k_place_big(const int32_t *__restrict__ n_big_dev, const int32_t *__restrict__ slot_face,
+            const int32_t *__restrict__ big_indptr, const int32_t *__restrict__ big_indices,
+            const double *__restrict__ big_data, int64_t n_query, const int32_t *__restrict__ q_perm,
+            const double *__restrict__ q_bbox, MortonParams tile, int32_t *__restrict__ tile_key,
+            FusedCounters *counters, int32_t *__restrict__ indptr, int32_t *__restrict__ indices,
+            double *__restrict__ data, int32_t *__restrict__ row_order, int32_t *__restrict__ apply_long_rows,
+            int64_t csr_capacity, const int32_t *__restrict__ skip_if) {
+    const int n_big = *n_big_dev;
+    if (n_big == 0 || *skip_if > 0) return;
+    const int64_t p_regular = counters->p_regular, t_reg = n_query - n_big;
+    const int64_t p_big = big_indptr[n_big];
+    if (p_regular + p_big > csr_capacity) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&counters->error, 4);
+        return;
+    }
+    const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    for (int64_t k = i0; k < n_big; k += stride) {
+        const int f = slot_face[k];
+        const int64_t r = t_reg + k;
+        const int n = big_indptr[k + 1] - big_indptr[k];
+        indptr[r] = (int32_t)(p_regular + big_indptr[k]);
+        row_order[r] = q_perm ? q_perm[f] : f;
+        if (tile_key) {
+            const int64_t mid = ((int64_t)f & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
+            tile_key[r] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
+        }
+        if (n > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+    }
+    for (int64_t e = i0; e < p_big; e += stride) {
+        indices[p_regular + e] = big_indices[e];
+        data[p_regular + e] = big_data[e];
+    }
+    if (i0 == 0) indptr[n_query] = (int32_t)(p_regular + p_big);
+}
+
+// sizes, error bits and the long-row count -> host mailbox / device word of the matrix (after everything else)
+__global__ void k_publish_all(const int32_t *__restrict__ c /* search counters */, const FusedCounters *__restrict__ fc,
+                              int32_t *__restrict__ n_apply_long_out, int32_t *mail) {
+    if (threadIdx.x < 5) mail[threadIdx.x] = c[threadIdx.x]; // regular pairs, big pairs, big faces, not fitting, (unused)
+    if (threadIdx.x == 0) {
+        mail[5] = fc->error;
+        mail[6] = fc->rows_regular;
+        mail[7] = fc->n_apply_long;
+        mail[8] = fc->p_regular;
+        mail[9] = fc->p_big;
+        *n_apply_long_out = fc->n_apply_long;
+    }
+}
+
+} // namespace xr
