@@ -2,7 +2,7 @@
 #include "xr_clip_tri.h"
 
 extern "C" double host_tri_clip_area(const double *tv_, const double *sv_) {
-    static uint32_t lut[xr::TRI_LUT];
+    static uint2 lut[xr::TRI_LUT];
     static bool init = false;
     if (!init) {
         for (int i = 0; i < xr::TRI_LUT; i++) {
@@ -19,7 +19,7 @@ extern "C" double host_tri_clip_area(const double *tv_, const double *sv_) {
     }
     double2 col[xr::TRI_MAXV + 1];
     for (auto &c : col) c = double2{NAN, NAN};
-    return xr::tri_clip_area<1>(tv, sv, col, lut, true);
+    return xr::tri_clip_area(tv, sv, col, lut, true);
 }
 
 extern "C" void host_tri_clip_many(const double *tv, const double *sv, long n, double *out) {

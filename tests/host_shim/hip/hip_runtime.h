@@ -9,6 +9,7 @@
 #define __forceinline__ inline
 struct double2 { double x, y; };
 struct double4 { double x, y, z, w; };
+struct uint2 { unsigned x, y; };
 static inline double2 make_double2(double x, double y) { return double2{x, y}; }
 static inline int __popc(unsigned x) { return __builtin_popcount(x); }
 static inline int __ffs(unsigned x) { return __builtin_ffs((int)x); }

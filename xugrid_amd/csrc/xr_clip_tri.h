@@ -12,8 +12,8 @@
 //   3. exactly two intersections, their end points fetched from the lane's LDS column by dynamic index,
 //   4. a compaction in the oracle's emission order (for j ascending: [crossing point of edge j-1 -> j] [vertex j if
 //      inside]): the positions come from a 64-entry table indexed by (n, F), built once per block in LDS; vertices
-//      outside go to a trash row, so the stores are unconditional,
-//   5. the static-index read-back of the column into registers.
+//      outside go to a trash slot, so the stores are unconditional,
+//   5. the next stage starts by reading the column back with static indices.
 // Lanes whose polygon is not "regular" run the oracle's loop itself for that stage (tri_stage_generic: same results
 // by construction, only slower, and only for those lanes): more than two transitions, a crossing edge parallel to
 // the clip line (the oracle's keep-b quirk), more vertices than the stage was unrolled for, or a REPEATED vertex
@@ -28,16 +28,20 @@
 namespace xr {
 
 static constexpr double TRI_AREA_OVERFLOW = -1.0; // sentinel: more than 6 vertices (floating-point degenerate pair)
-static constexpr int TRI_MAXV = 6;                // rows 0..5 of the LDS column; row 6 = trash row
-static constexpr int TRI_LUT = 64;                // compaction table entries (uint32 each)
+static constexpr int TRI_MAXV = 6;                // slots 0..5 of the lane's LDS column; slot 6 = trash
+static constexpr int TRI_LUT = 64;                // compaction table entries (uint2 each)
 
-// Compaction table: entry (1 << n) + F, n = 3..5 vertices, F = inside mask.  Bits 3j..3j+2 (j < 5): position of
-// vertex j in the output (6 = trash row if outside or j >= n); bits 15..17 / 18..20: positions of the crossing points of
-// the first / second transition slot.  Call with all threads of the block, then __syncthreads().
-__device__ __forceinline__ void tri_lut_init(uint32_t *lut) {
+// LDS layout: every lane owns TRI_MAXV + 1 consecutive double2 slots (col[slot]); 16 lanes x 112 bytes fall on
+// disjoint banks for the 16-byte accesses.  Positions in the table are BYTE offsets (slot * 16), one per byte, so an
+// address is lane base + one extracted byte.
+//
+// Compaction table: entry (1 << n) + F, n = 3..5 vertices, F = inside mask.  .x bytes 0..3: output offset of vertex
+// 0..3; .y byte 0: vertex 4, byte 1 / 2: the crossing points of the first / second transition slot.  A vertex that is
+// outside (or beyond the polygon) goes to the trash slot.  Call with all threads of the block, then __syncthreads().
+__device__ __forceinline__ void tri_lut_init(uint2 *lut) {
     const int i = threadIdx.x;
     if (i >= TRI_LUT) return;
-    uint32_t e = 0;
+    uint32_t pos[7] = {6, 6, 6, 6, 6, 6, 6}; // vertex 0..4, crossing point 1, 2
     if (i >= 8) {
         const int n = 31 - __clz(i);
         const uint32_t F = (uint32_t)i - (1u << n);
@@ -45,25 +49,28 @@ __device__ __forceinline__ void tri_lut_init(uint32_t *lut) {
         for (int j = 0; j < n; j++) {
             const bool fj = (F >> j) & 1u, fp = (F >> ((j + n - 1) % n)) & 1u;
             if (fj != fp) {
-                if (n_t < 2) e |= (uint32_t)before << (15 + 3 * n_t);
+                if (n_t < 2) pos[5 + n_t] = (uint32_t)before;
                 n_t++;
                 before++;
             }
-            if (fj) e |= (uint32_t)(before++) << (3 * j);
-            else e |= 6u << (3 * j);
+            if (fj) pos[j] = (uint32_t)(before++);
         }
-        for (int j = n; j < 5; j++) e |= 6u << (3 * j); // slots beyond the polygon: trash row
     }
+    uint2 e;
+    e.x = (pos[0] << 4) | (pos[1] << 12) | (pos[2] << 20) | (pos[3] << 28);
+    e.y = (pos[4] << 4) | (pos[5] << 12) | (pos[6] << 20);
     lut[i] = e;
 }
 
 __device__ __forceinline__ bool p2_eq(P2 a, P2 b) { return a.x == b.x && a.y == b.y; }
 __device__ __forceinline__ bool p2_eq(P2 a, double2 b) { return a.x == b.x && a.y == b.y; }
+__device__ __forceinline__ double2 *tri_slot(double2 *col, uint32_t byte_offset) {
+    return reinterpret_cast<double2 *>(reinterpret_cast<char *>(col) + byte_offset);
+}
 
 // The oracle's stage loop on a register polygon (static indexing, predicated on the current length); output
-// pushed into the lane's LDS column (row TRI_MAXV = trash row for clamped pushes).
-template <int BLOCK>
-__device__ __forceinline__ void tri_stage_generic(P2 (&v)[TRI_MAXV], int &n, const P2 r, const P2 U, bool &alive,
+// pushed into the lane's LDS column (slot TRI_MAXV = trash for clamped pushes).
+__device__ __forceinline__ void tri_stage_generic(const P2 (&v)[TRI_MAXV], int &n, const P2 r, const P2 U, bool &alive,
                                                   bool &overflow, double2 *col) {
     const P2 N{-U.y, U.x};
     int n_output = 0;
@@ -95,12 +102,12 @@ __device__ __forceinline__ void tri_stage_generic(P2 (&v)[TRI_MAXV], int &n, con
             }
             const bool quirk = cross && !b_inside && !have_pt; // parallel edge: keep b, which then counts as inside
             if (cross && have_pt) {
-                col[(n_output < TRI_MAXV ? n_output : TRI_MAXV) * BLOCK] = make_double2(pt.x, pt.y);
+                col[n_output < TRI_MAXV ? n_output : TRI_MAXV] = make_double2(pt.x, pt.y);
                 n_output++;
             }
             b_inside = b_inside || quirk;
             if (live && b_inside) {
-                col[(n_output < TRI_MAXV ? n_output : TRI_MAXV) * BLOCK] = make_double2(b.x, b.y);
+                col[n_output < TRI_MAXV ? n_output : TRI_MAXV] = make_double2(b.x, b.y);
                 n_output++;
             }
             if (live) {
@@ -116,24 +123,26 @@ __device__ __forceinline__ void tri_stage_generic(P2 (&v)[TRI_MAXV], int &n, con
         alive = false;
     }
     n = n_output;
-    if (alive) {
-#pragma unroll
-        for (int k = 0; k < TRI_MAXV; k++) {
-            if (k < n) {
-                const double2 q = col[k * BLOCK];
-                v[k] = P2{q.x, q.y};
-            }
-        }
-    }
 }
 
 // One stage.  NIN = number of vertices the fast path is unrolled for (3, 4, 5 for the three edges of a triangle
-// clipper: a regular stage adds at most one vertex).
-template <int NIN, int BLOCK>
-__device__ __forceinline__ void tri_stage(P2 (&v)[TRI_MAXV], int &n, P2 &r, const P2 s, bool &alive, bool &dirty,
-                                          bool &overflow, double2 *col, const uint32_t *lut) {
+// clipper: a regular stage adds at most one vertex).  The lane's LDS column holds the current polygon before and
+// after; registers are only a per-stage copy.
+template <int NIN>
+__device__ __forceinline__ void tri_stage(int &n, P2 &r, const P2 s, bool &alive, bool &dirty, bool &overflow,
+                                          double2 *col, const uint2 *lut) {
     const P2 U{s.x - r.x, s.y - r.y};
     const bool work = alive && !(U.x == 0 && U.y == 0); // zero-length clipper edge: the oracle skips the stage, r stays
+    P2 v[TRI_MAXV];
+#pragma unroll
+    for (int j = 0; j < TRI_MAXV; j++) {
+        if (j < NIN) {
+            const double2 q = col[j]; // (slots >= n: stale values, masked below)
+            v[j] = P2{q.x, q.y};
+        } else {
+            v[j] = P2{0.0, 0.0};
+        }
+    }
     // ---- inside flags as a bit mask (slots >= n masked off)
     uint32_t F = 0;
 #pragma unroll
@@ -145,11 +154,11 @@ __device__ __forceinline__ void tri_stage(P2 (&v)[TRI_MAXV], int &n, P2 &r, cons
     bool irregular = work && (dirty || n > NIN || (n_tr != 0 && n_tr != 2));
     const bool two = work && !irregular && n_tr == 2;
     if (two) {
-        // end points of the two crossing edges from the lane's LDS column (it always holds the current polygon)
+        // end points of the two crossing edges from the lane's LDS column
         const int j1 = __ffs(Tm) - 1, j2 = 31 - __clz(Tm);
         const int p1 = j1 == 0 ? n - 1 : j1 - 1, p2 = j2 - 1;
-        const double2 a1 = col[p1 * BLOCK], b1 = col[j1 * BLOCK], a2 = col[p2 * BLOCK], b2 = col[j2 * BLOCK];
-        const uint32_t e = lut[F + (1u << n)];
+        const double2 a1 = col[p1], b1 = col[j1], a2 = col[p2], b2 = col[j2];
+        const uint2 e = lut[F + (1u << n)];
         const P2 N{-U.y, U.x};
         const P2 V1{b1.x - a1.x, b1.y - a1.y}, V2{b2.x - a2.x, b2.y - a2.y};
         const double nw1 = N.x * (r.x - a1.x) + N.y * (r.y - a1.y), nv1 = N.x * V1.x + N.y * V1.y;
@@ -159,59 +168,66 @@ __device__ __forceinline__ void tri_stage(P2 (&v)[TRI_MAXV], int &n, P2 &r, cons
         irregular = nv1 == 0 || nv2 == 0; // parallel crossing edge: the oracle's keep-b quirk
         if (!irregular) {
             // a crossing point that coincides with a neighbour in the output is a repeated vertex for later stages
-            dirty = p2_eq(pt1, a1) || p2_eq(pt1, b1) || p2_eq(pt2, a2) || p2_eq(pt2, b2) || p2_eq(pt1, pt2);
-            // compaction in the oracle's emission order; vertices outside land in the trash row
-#pragma unroll
-            for (int j = 0; j < NIN; j++) col[((e >> (3 * j)) & 7u) * BLOCK] = make_double2(v[j].x, v[j].y);
-            col[((e >> 15) & 7u) * BLOCK] = make_double2(pt1.x, pt1.y);
-            col[((e >> 18) & 7u) * BLOCK] = make_double2(pt2.x, pt2.y);
+            // (x first: the y comparisons only run when some lane has an equal x)
+            if (pt1.x == a1.x || pt1.x == b1.x || pt2.x == a2.x || pt2.x == b2.x || pt1.x == pt2.x)
+                dirty = p2_eq(pt1, a1) || p2_eq(pt1, b1) || p2_eq(pt2, a2) || p2_eq(pt2, b2) || p2_eq(pt1, pt2);
+            // compaction in the oracle's emission order; vertices outside land in the trash slot
+            *tri_slot(col, e.x & 0xffu) = make_double2(v[0].x, v[0].y);
+            *tri_slot(col, (e.x >> 8) & 0xffu) = make_double2(v[1].x, v[1].y);
+            *tri_slot(col, (e.x >> 16) & 0xffu) = make_double2(v[2].x, v[2].y);
+            if (NIN > 3) *tri_slot(col, e.x >> 24) = make_double2(v[3].x, v[3].y);
+            if (NIN > 4) *tri_slot(col, e.y & 0xffu) = make_double2(v[4].x, v[4].y);
+            *tri_slot(col, (e.y >> 8) & 0xffu) = make_double2(pt1.x, pt1.y);
+            *tri_slot(col, (e.y >> 16) & 0xffu) = make_double2(pt2.x, pt2.y);
             n = __popc(F) + 2; // (>= 3: a transition implies an inside vertex)
-#pragma unroll
-            for (int k = 0; k < NIN + 1; k++) {
-                const double2 q = col[k * BLOCK]; // (rows >= n: stale values, never used)
-                v[k] = P2{q.x, q.y};
-            }
         }
     } else if (work && !irregular && !(F & 1u)) {
         alive = false; // no transition, first vertex outside: everything is outside
     }
     // (no transition, first vertex inside: the polygon is unchanged)
     if (irregular) {
-        tri_stage_generic<BLOCK>(v, n, r, U, alive, overflow, col);
+        if (n > NIN) { // (only after an earlier generic stage: fetch the vertices the fast path does not unroll)
+#pragma unroll
+            for (int j = NIN; j < TRI_MAXV; j++) {
+                if (j < n) {
+                    const double2 q = col[j];
+                    v[j] = P2{q.x, q.y};
+                }
+            }
+        }
+        tri_stage_generic(v, n, r, U, alive, overflow, col);
         dirty = true; // (the generic loop may emit repeated vertices)
     }
     if (work) r = s;
 }
 
 // area of (target triangle tv) clipped by (source triangle sv, counter-clockwise), or TRI_AREA_OVERFLOW.
-// col: the lane's LDS column, col[j * BLOCK], j = 0 .. TRI_MAXV (TRI_MAXV + 1 rows); lut: tri_lut_init's table.
-template <int BLOCK>
-__device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv)[3], double2 *col,
-                                                const uint32_t *lut, bool active) {
-    P2 v[TRI_MAXV];
-#pragma unroll
-    for (int j = 0; j < TRI_MAXV; j++) v[j] = tv[j < 3 ? j : 0];
+// col: the lane's LDS column, col[0 .. TRI_MAXV] (TRI_MAXV + 1 double2 slots, contiguous); lut: tri_lut_init's table.
+__device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv)[3], double2 *col, const uint2 *lut,
+                                                bool active) {
     int n = 3;
     bool alive = active, overflow = false;
     bool dirty = p2_eq(tv[0], tv[1]) || p2_eq(tv[1], tv[2]) || p2_eq(tv[2], tv[0]);
     if (active) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) col[j * BLOCK] = make_double2(tv[j].x, tv[j].y);
+        for (int j = 0; j < 3; j++) col[j] = make_double2(tv[j].x, tv[j].y);
     }
     P2 r = sv[2];
-    tri_stage<3, BLOCK>(v, n, r, sv[0], alive, dirty, overflow, col, lut);
-    tri_stage<4, BLOCK>(v, n, r, sv[1], alive, dirty, overflow, col, lut);
-    tri_stage<5, BLOCK>(v, n, r, sv[2], alive, dirty, overflow, col, lut);
+    tri_stage<3>(n, r, sv[0], alive, dirty, overflow, col, lut);
+    tri_stage<4>(n, r, sv[1], alive, dirty, overflow, col, lut);
+    tri_stage<5>(n, r, sv[2], alive, dirty, overflow, col, lut);
     if (overflow) return TRI_AREA_OVERFLOW;
     double area = 0.0;
     if (alive) {
         // fan area from the first clipped vertex (local origin)
-        const P2 a0 = v[0];
-        double ux = v[1].x - a0.x, uy = v[1].y - a0.y;
+        const double2 q0 = col[0], q1 = col[1];
+        const P2 a0{q0.x, q0.y};
+        double ux = q1.x - a0.x, uy = q1.y - a0.y;
 #pragma unroll
         for (int i = 2; i < TRI_MAXV; i++) {
             if (i < n) {
-                const double vx = a0.x - v[i].x, vy = a0.y - v[i].y;
+                const double2 q = col[i];
+                const double vx = a0.x - q.x, vy = a0.y - q.y;
                 area += fabs(ux * vy - uy * vx);
                 ux = vx;
                 uy = vy;

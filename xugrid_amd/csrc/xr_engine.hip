@@ -48,7 +48,12 @@ void engine_init(int device) {
     XR_HIP(hipHostMalloc(&mail, 4096, hipHostMallocCoherent));
     g_engine.mailbox = static_cast<volatile int32_t *>(mail);
     XR_HIP(hipEventCreateWithFlags(&g_engine.mail_event, hipEventDisableTiming | hipEventReleaseToSystem));
-    XR_HIP(hipStreamCreateWithFlags(&g_engine.side, hipStreamNonBlocking));
+    {
+        // the side stream carries short latency-bound kernels next to a long one on the main stream: highest priority
+        int lo = 0, hi = 0;
+        XR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, hi));
+    }
     XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, hipEventDisableTiming));
     XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, hipEventDisableTiming));
     g_engine.device = device;
@@ -99,16 +104,33 @@ void *pool_alloc(size_t bytes) {
     return p;
 }
 
+// Blocks are handed out again in stream order, which is only safe with ONE stream.  From the moment a side stream is
+// forked until the host has seen both streams drained, freed blocks are parked instead of being reused: a block freed
+// by code on one stream could otherwise be given to the other while a kernel of the first still touches it.
+static bool g_side_active = false;
+static std::vector<std::pair<size_t, void *>> g_deferred;
+
 void pool_free(void *p) {
     if (!p) return;
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
-    g_free.emplace(it->second, p);
+    if (g_side_active) g_deferred.emplace_back(it->second, p);
+    else g_free.emplace(it->second, p);
     g_live.erase(it);
+}
+
+// called after the main stream has been synchronised with the host
+static void pool_release_deferred() {
+    if (!g_side_active) return;
+    (void)hipStreamSynchronize(g_engine.side);
+    for (auto &kv : g_deferred) g_free.emplace(kv.first, kv.second);
+    g_deferred.clear();
+    g_side_active = false;
 }
 
 void pool_trim() {
     if (g_engine.stream) (void)hipStreamSynchronize(g_engine.stream);
+    pool_release_deferred();
     for (auto &kv : g_free) (void)hipFree(kv.second);
     g_free.clear();
 }
@@ -143,7 +165,10 @@ void d2h(void *dst, const void *src, size_t bytes) {
     XR_HIP(hipStreamSynchronize(engine().stream));
 }
 
-void stream_sync() { XR_HIP(hipStreamSynchronize(engine().stream)); }
+void stream_sync() {
+    XR_HIP(hipStreamSynchronize(engine().stream));
+    pool_release_deferred();
+}
 void dev_call_done() {
     if (!engine().async_dev) stream_sync();
 }
@@ -227,6 +252,7 @@ void d2h_big(void *dst, const void *src, size_t bytes) {
 void mailbox_wait() {
     XR_HIP(hipEventRecord(engine().mail_event, engine().stream));
     XR_HIP(hipEventSynchronize(engine().mail_event));
+    pool_release_deferred();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -275,6 +301,7 @@ SideScope::SideScope() {
     XR_HIP(hipEventRecord(e.fork_event, e.stream));
     XR_HIP(hipStreamWaitEvent(e.side, e.fork_event, 0));
     e.on_side = true;
+    g_side_active = true;
 }
 SideScope::~SideScope() {
     g_engine.on_side = false;

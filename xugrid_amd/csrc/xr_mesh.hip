@@ -289,7 +289,7 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
     }
     XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
               mesh->stats_host);
-    XR_HIP(hipEventRecord(mesh->stats_event, engine().stream));
+    XR_HIP(hipEventRecord(mesh->stats_event, launch_stream()));
     mesh->prepared = true;
     mesh->stats_valid = false;
 }
@@ -390,7 +390,7 @@ static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams 
                          float *o_recbb) {
     const int64_t F = mesh->n_face;
     DevBuf<int32_t> key((size_t)F), count((size_t)n_buckets);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, engine().stream));
+    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, launch_stream()));
     if (F > 0)
         XR_LAUNCH(INDEX ? "index_count" : "order_count", k_spatial_count<INDEX>, dim3(div_up(F, 256)), dim3(256), 0,
                   mesh->bbox.get(), F, g, mp, key.get(), count.get());

@@ -57,8 +57,17 @@ __device__ __forceinline__ int64_t xcd_block(int64_t n_blocks, bool remap) {
     return (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
 }
 
+// Level split: the walk only visits the grid levels that hold the bulk of the records.  The records of the upper
+// levels (a Delaunay hull's slivers: a few hundred of a million) are the TAIL of the record arrays (levels are
+// concatenated); when that tail is short (<= BIGREC_MAX) every block filters it against its own bounding box once
+// (coalesced) and its faces test the few survivors from LDS, instead of every face walking 5-6 all but empty levels:
+// the dependent cell_start -> record round trips of those levels were most of the search time.
+static constexpr int BIGREC_MAX = 1024;  // records of the upper grid levels handled as a list
+static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may touch one block's bounding box
+
 __global__ void __launch_bounds__(256)
-k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const int32_t *__restrict__ cell_start,
+k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
+         const int32_t *__restrict__ cell_start,
          const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_off,
          int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
@@ -66,26 +75,82 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
          bool remap) {
     __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
     __shared__ uint8_t sh_owner[SLOTS * 256];
+    __shared__ __attribute__((aligned(16))) float4 sh_bigbb[BIGREC_BLOCK];
+    __shared__ int32_t sh_bigrec[BIGREC_BLOCK];
+    __shared__ float sh_box[4][4];
+    __shared__ int32_t sh_nbig;
     __shared__ int32_t sh_wave[4];
     __shared__ int32_t sh_base;
     const int64_t n_blocks = (n_query + 255) / 256;
     const int64_t lb = xcd_block(n_blocks, remap);
     if (lb >= n_blocks) return;
     const int64_t t = lb * 256 + threadIdx.x;
+    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+    // ---- level split (uniform: scalar loads)
+    int l_split = g.n_levels, big0 = (int)n_tree;
+    for (int l = g.n_levels - 1; l >= 1; l--) {
+        const int first = cell_start[g.base[l]];
+        if ((int)n_tree - first > BIGREC_MAX) break;
+        l_split = l;
+        big0 = first;
+    }
+    double4 bb = make_double4(0, 0, 0, 0);
+    float qx0 = INFINITY, qx1 = -INFINITY, qy0 = INFINITY, qy1 = -INFINITY;
+    if (t < n_query) {
+        bb = reinterpret_cast<const double4 *>(q_bbox)[t];
+        qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
+        qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
+    }
+    if (threadIdx.x == 0) sh_nbig = 0;
+    if (big0 < (int)n_tree) {
+        // the block's bounding box, then one coalesced pass over the big records
+        float bx0 = qx0, bx1 = qx1, by0 = qy0, by1 = qy1;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+            bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+            by0 = fminf(by0, __shfl_xor(by0, d, 64));
+            by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            sh_box[w][0] = bx0; sh_box[w][1] = bx1; sh_box[w][2] = by0; sh_box[w][3] = by1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            bx0 = fminf(bx0, sh_box[w][0]); bx1 = fmaxf(bx1, sh_box[w][1]);
+            by0 = fminf(by0, sh_box[w][2]); by1 = fmaxf(by1, sh_box[w][3]);
+        }
+        for (int r = big0 + threadIdx.x; r < (int)n_tree; r += 256) {
+            const float4 rb = rbb[r];
+            if (rec_hit(rb, bx0, bx1, by0, by1)) {
+                const int k = atomicAdd(&sh_nbig, 1);
+                if (k < BIGREC_BLOCK) {
+                    sh_bigrec[k] = r;
+                    sh_bigbb[k] = rb;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh_nbig > BIGREC_BLOCK) { // too many for the list: this block walks every level
+            l_split = g.n_levels;
+            __syncthreads();
+            if (threadIdx.x == 0) sh_nbig = 0;
+        }
+    }
+    __syncthreads();
+    const int n_bigblk = sh_nbig;
     int count = 0;
     bool big = false;
     if (t < n_query) {
         nnz_row[t] = 0; // the clip kernel counts the surviving pairs of the row into it
-        const double4 bb = reinterpret_cast<const double4 *>(q_bbox)[t];
         if (tile_key) {
             // row tiling hint for the many-variable apply: all rows of a run of TILE_RUN consecutive ids share the
             // key of the run's middle row, so runs stay contiguous (long output stores) and neighbouring runs meet
             const int64_t mid = (t & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
             tile_key[t] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
         }
-        const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
-        const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
-        const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
         // Level-0 cells of the bbox corners, once; the level-l cell of x is (level-0 cell) >> l exactly (cell
         // sizes are power-of-two multiples and the clamped ranges nest), and the cell of x - h_l is that minus one:
         // no per-level floating-point cell arithmetic.  (A record that can overlap has xmin > q.xmin - 0.999 h_l,
@@ -93,10 +158,10 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
         const int c_x0 = cell_coord(bb.x, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(bb.y, g.x0, g.inv_h0, g.nx[0]);
         const int c_y0 = cell_coord(bb.z, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(bb.w, g.y0, g.inv_h0, g.ny[0]);
         int visited = 0, n_rows = 0;
-        for (int l = 0; l < g.n_levels; l++)
+        for (int l = 0; l < l_split; l++)
             n_rows += (c_y1 >> (l * LEVEL_SHIFT)) - max((c_y0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
-        big = n_rows > 8 * g.n_levels + 8;
-        for (int l = 0; l < g.n_levels && !big; l++) {
+        big = n_rows > 8 * l_split + 8;
+        for (int l = 0; l < l_split && !big; l++) {
             const int nx = g.nx[l], base = g.base[l];
             const int sh = l * LEVEL_SHIFT;
             const int cx0 = max((c_x0 >> sh) - 1, 0), cx1 = c_x1 >> sh;
@@ -140,6 +205,12 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, const
                     }
                 }
             }
+        }
+        // the big records that touch the block (from LDS)
+        for (int k = 0; k < n_bigblk && !big; k++) {
+            const bool h = rec_hit(sh_bigbb[k], qx0, qx1, qy0, qy1);
+            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = sh_bigrec[k];
+            count += h ? 1 : 0;
         }
         if (count > SLOTS) big = true;
         is_big[t] = big ? 1 : 0;
@@ -224,9 +295,14 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
     return incl - v;
 }
 
-// FUSED: count the face's candidates, reserve its stretch of the pair queue with one atomic and -- if the
-// stretch fits the queue as currently allocated -- fill it straight away (second walk by the same block);
-// faces that do not fit are listed and filled by a second launch (FUSED = false) after the host regrew the queue.
+// FUSED: ONE walk parks the face's candidates in LDS (up to BIG_STAGE of them); the block then reserves the face's
+// stretch of the pair queue with one atomic and copies them out.  Faces with more candidates than the stage holds
+// walk a second time and write straight to the queue (the first walk has counted them); faces whose stretch does
+// not fit the queue as currently allocated are listed and filled by a second launch (FUSED = false) after the host
+// regrew it.  (The two-walk version -- count, reserve, fill -- took twice as long per face, and a big face is a
+// chain of dependent phases: the kernel's duration is the slowest face's.)
+static constexpr int BIG_STAGE = 6144;
+
 template <bool FUSED>
 __global__ void __launch_bounds__(256)
 k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy,
@@ -240,6 +316,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
     // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
     // ranked by tree face id afterwards)
     __shared__ double2 sh_poly[XR_MAX_FACE_NODES];
+    __shared__ int32_t sh_stage[FUSED ? BIG_STAGE : 1];
     __shared__ int sh_cursor;
     __shared__ int sh_out0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -258,13 +335,14 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
         const float qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         const float qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
         for (int pass = FUSED ? 0 : 1; pass < 2; pass++) {
-        const bool FILL = pass == 1;
-        if (FILL) {
+        const bool STAGE = pass == 0; // first walk: park in LDS (and count); second walk: write to the queue
+        if (!STAGE) {
             if (FUSED) {
-                // (pass 0 left the face's total in sh_cursor)
+                // (the first walk left the face's total in sh_cursor)
+                __syncthreads();
+                const int n = sh_cursor;
                 __syncthreads();
                 if (threadIdx.x == 0) {
-                    const int n = sh_cursor;
                     const int base = atomicAdd(queue_cursor, n);
                     cand_count[t] = n;
                     cand_off[t] = base;
@@ -274,22 +352,30 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                     sh_cursor = 0;
                 }
                 __syncthreads();
+                const int out = sh_out0;
+                if (out < 0) break;
+                if (n <= BIG_STAGE) { // everything is parked: copy it out, no second walk
+                    for (int i = threadIdx.x; i < n; i += 256) {
+                        cand_tgt[out + i] = t;
+                        cand_src[out + i] = sh_stage[i];
+                    }
+                    break;
+                }
             } else {
                 if (threadIdx.x == 0) sh_out0 = cand_off[t];
                 __syncthreads();
             }
             if (sh_out0 < 0) break;
         }
-        const int out0 = FILL ? sh_out0 : 0;
-        int total = 0;
-        int batch_id = 0;
+        const int out0 = STAGE ? 0 : sh_out0;
         for (int l = 0; l < g.n_levels; l++) {
             const double h = level_h(g, l), inv_h = level_inv_h(g, l);
             const double eps = 1e-6 * h;
             const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
             const int cy0 = cell_coord(bb.z - h, g.y0, inv_h, ny), cy1 = cell_coord(bb.w, g.y0, inv_h, ny);
+            int batch_id = 0;
             for (int cyb = cy0; cyb <= cy1; cyb += 64, batch_id++) {
-                if ((batch_id & 3) != wv) continue;
+                if (((batch_id + l) & 3) != wv) continue;
                 const int cy = cyb + lane;
                 int r0 = 0, r1 = 0;
                 if (cy <= cy1) {
@@ -337,17 +423,20 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                         const bool hit = r < R1 && rec_hit(rbb[r], qx0, qx1, qy0, qy1);
                         const unsigned long long mask = __ballot(hit);
                         const int n = __popcll(mask);
-                        if (FILL && n > 0) {
+                        if (n > 0) {
                             int slot0 = 0;
                             if (lane == 0) slot0 = atomicAdd(&sh_cursor, n);
                             slot0 = __shfl(slot0, 0, 64);
                             if (hit) {
-                                const int slot = out0 + slot0 + __popcll(mask & lt_mask);
-                                cand_tgt[slot] = t;
-                                cand_src[slot] = r;
+                                const int slot = slot0 + __popcll(mask & lt_mask);
+                                if (STAGE) {
+                                    if (slot < BIG_STAGE) sh_stage[FUSED ? slot : 0] = r;
+                                } else {
+                                    cand_tgt[out0 + slot] = t;
+                                    cand_src[out0 + slot] = r;
+                                }
                             }
                         }
-                        total += n;
                     }
                 }
                 // (2) short runs: one lane per grid row
@@ -356,25 +445,24 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                 for (int r = r0; r < my_r1; r++) cnt += rec_hit(rbb[r], qx0, qx1, qy0, qy1) ? 1 : 0;
                 const int excl = wave_excl_scan_i32(cnt, lane);
                 const int batch = __shfl(excl + cnt, 63, 64);
-                if (FILL && batch > 0) {
+                if (batch > 0) {
                     int slot0 = 0;
                     if (lane == 0) slot0 = atomicAdd(&sh_cursor, batch);
                     slot0 = __shfl(slot0, 0, 64);
-                    int pos = out0 + slot0 + excl;
+                    int pos = slot0 + excl;
                     for (int r = r0; r < my_r1; r++) {
                         if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
-                            cand_tgt[pos] = t;
-                            cand_src[pos] = r;
+                            if (STAGE) {
+                                if (pos < BIG_STAGE) sh_stage[FUSED ? pos : 0] = r;
+                            } else {
+                                cand_tgt[out0 + pos] = t;
+                                cand_src[out0 + pos] = r;
+                            }
                             pos++;
                         }
                     }
                 }
-                total += batch;
             }
-        }
-        if (!FILL) {
-            // block total (every lane of a wave holds the wave's total)
-            if (lane == 0) atomicAdd(&sh_cursor, total);
         }
         } // pass
     }
@@ -673,8 +761,8 @@ k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__
            double *__restrict__ cand_area, const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
            int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x; // col[j * BLOCK]
-    __shared__ uint32_t sh_lut[TRI_LUT];
+    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
+    __shared__ uint2 sh_lut[TRI_LUT];
     const int64_t n_blocks = (n_cand + BLOCK - 1) / BLOCK;
     const int64_t lb = xcd_block(n_blocks, remap);
     if (lb >= n_blocks) return;
@@ -697,7 +785,7 @@ k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__
             sv[j] = P2{b.x, b.y};
         }
     }
-    double area = tri_clip_area<BLOCK>(tv, sv, col, sh_lut, active);
+    double area = tri_clip_area(tv, sv, col, sh_lut, active);
     if (active) {
         if (area == TRI_AREA_OVERFLOW) {
             area = AREA_OVERFLOW;
@@ -1102,7 +1190,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *cs
             big_indices((size_t)big_capacity);
         DevBuf<double> big_area((size_t)big_capacity), big_data((size_t)big_capacity);
         XR_HIP(hipMemsetAsync(ctl.get(), 0, ctl.bytes(), st));
-        XR_LAUNCH("search", k_search, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->cell_start.get(),
+        XR_LAUNCH("search", k_search, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
                   tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl.get() + 0,
                   block_seg.get(), is_big.get(), big_list.get(), ctl.get() + 2, tile, (int32_t *)nullptr, nnz_row.get(),
                   remap);
@@ -1117,13 +1205,16 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *cs
             XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl.get() + 1,
                       big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl.get() + 3);
-            XR_LAUNCH("big_order", k_big_order, dim3(1), dim3(256), 0, big_list.get(), ctl.get() + 2, nnz_row.get(),
-                      slot_face.get(), big_indptr.get(), fc, ctl.get() + 3);
+            XR_LAUNCH("big_rank", k_big_rank, dim3(64), dim3(256), 0, big_list.get(), ctl.get() + 2, slot_face.get(),
+                      ctl.get() + 3);
+            XR_LAUNCH("big_scan", k_big_scan, dim3(1), dim3(256), 0, slot_face.get(), ctl.get() + 2, nnz_row.get(),
+                      big_indptr.get(), fc, ctl.get() + 3);
             XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
                       cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree->area.get(), relative,
                       tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3);
         }
-        XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu * 5), dim3(CLIP_BLOCK), clip_shmem,
+        static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5; // tuning hook: persistent blocks per CU
+        XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                   query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                   ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                   (const int32_t *)nullptr);
@@ -1164,6 +1255,8 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *cs
 }
 
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
+    // (the query side on the side stream next to the tree side was measured: the prepare kernels are bandwidth bound and
+    // just slow each other down, 0.684 -> 0.706 ms per step)
     mesh_prepare(tree, false); // the tree side only needs its records (built from the raw mesh)
     mesh_prepare(query, true);
     mesh_build_index(tree);
@@ -1228,7 +1321,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     const bool remap_search = xcd_remap_mask() & 2, remap_rows = xcd_remap_mask() & 4;
     XR_LAUNCH("search", k_search, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
-              tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
+              tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
               cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
               csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
     DevBuf<int32_t> pending((size_t)T);

@@ -13,7 +13,7 @@
 //                             counters in HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)
 //   big faces (hull slivers, > SLOTS hits; 0.1 % of the faces, but their block-per-face kernels are chains of dependent
 //   phases: 15 % of the step when run in line) on a SIDE STREAM, forked behind k_search: k_search_big -> k_clip_tri_queue on
-//   their own pair queue -> k_big_order (rows in face order, scan of their lengths) -> k_row_fill_long into a small
+//   their own pair queue -> k_big_rank / k_big_scan (rows in face order, scan of their lengths) -> k_row_fill_long into a small
 //   CSR of their own; joined behind k_assemble, k_place_big copies those rows BEHIND the regular ones.
 //   [host: sizes + error bits: ONE round trip for the whole weight matrix]
 // Measured and discarded on the way (MI355X, benchmark pair): a fully fused search + clip + assembly block (pairs never
@@ -122,8 +122,8 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
                  int32_t *__restrict__ nnz_row /* optional: survivors per target face, counted by atomics */,
                  const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x; // col[j * BLOCK]
-    __shared__ uint32_t sh_lut[TRI_LUT];
+    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
+    __shared__ uint2 sh_lut[TRI_LUT];
     if (skip_if && *skip_if > 0) return; // (big faces that did not fit their queue: the host redoes everything)
     tri_lut_init(sh_lut);
     __syncthreads();
@@ -171,7 +171,7 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
             sid = rec_face[n_s];
         }
         load_idx(slot + stride, n_tq, n_s);
-        const double area = tri_clip_area<BLOCK>(tv, sv, col, sh_lut, active);
+        const double area = tri_clip_area(tv, sv, col, sh_lut, active);
         const int tq_now = active ? cur_tq : -1;
         if (active) {
             overflow = overflow || area == TRI_AREA_OVERFLOW;
@@ -299,33 +299,49 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
 
 // ---- the big faces' rows (side stream) -------------------------------------------------------------------------------
 // Order of the big faces' rows: by face id (k_search lists them in finishing order; ranking makes the stored matrix the
-// same from run to run), and the exclusive scan of their lengths.  One block; the list sits in LDS up to BIG_LDS faces,
-// longer lists (a coarse target over a fine source) keep the order they were found in.
-static constexpr int BIG_LDS = 8192;
+// same from run to run).  All-pairs rank, the list read through LDS in tiles; several blocks (the list length is only
+// known on the device: grid-stride).  Lists beyond BIG_RANK_MAX faces (a coarse target over a fine source) keep the
+// order they were found in.
+static constexpr int BIG_RANK_MAX = 1 << 16;
 __global__ void __launch_bounds__(256)
-k_big_order(const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big_dev,
-            const int32_t *__restrict__ nnz_row /* per face */, int32_t *__restrict__ slot_face,
-            int32_t *__restrict__ big_indptr /* [n_big + 1] */, FusedCounters *counters,
-            const int32_t *__restrict__ skip_if) {
+k_big_rank(const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big_dev, int32_t *__restrict__ slot_face,
+           const int32_t *__restrict__ skip_if) {
     if (*skip_if > 0) return;
-    __shared__ int32_t sh_part[256];
-    __shared__ int32_t sh_face[BIG_LDS];
+    __shared__ int32_t sh_face[1024];
     const int tid = threadIdx.x;
     const int n_big = *n_big_dev;
-    const bool sorted = n_big <= BIG_LDS;
-    for (int k = tid; k < n_big && sorted; k += 256) sh_face[k] = big_list[k];
-    __syncthreads();
-    for (int k = tid; k < n_big; k += 256) {
-        const int f = big_list[k];
+    const bool sorted = n_big <= BIG_RANK_MAX;
+    for (int k0 = blockIdx.x * 256; k0 < n_big; k0 += gridDim.x * 256) {
+        const int k = k0 + tid;
+        const int f = k < n_big ? big_list[k] : 0x7fffffff;
         int rank = sorted ? 0 : k;
-        for (int j = 0; j < n_big && sorted; j++) rank += sh_face[j] < f ? 1 : 0;
-        slot_face[rank] = f;
+        for (int j0 = 0; j0 < n_big && sorted; j0 += 1024) {
+            __syncthreads();
+            for (int j = tid; j < 1024; j += 256) sh_face[j] = j0 + j < n_big ? big_list[j0 + j] : 0x7fffffff;
+            __syncthreads();
+            const int4 *quad = reinterpret_cast<const int4 *>(sh_face);
+            for (int j = 0; j < 256; j++) {
+                const int4 q = quad[j];
+                rank += (q.x < f) + (q.y < f) + (q.z < f) + (q.w < f);
+            }
+        }
+        if (k < n_big) slot_face[rank] = f;
     }
-    __syncthreads(); // (slot_face: written by this block, read back below through L2)
+}
+
+// exclusive scan of the big rows' lengths in slot order (one block)
+__global__ void __launch_bounds__(256)
+k_big_scan(const int32_t *__restrict__ slot_face, const int32_t *__restrict__ n_big_dev,
+           const int32_t *__restrict__ nnz_row /* per face */, int32_t *__restrict__ big_indptr /* [n_big + 1] */,
+           FusedCounters *counters, const int32_t *__restrict__ skip_if) {
+    if (*skip_if > 0) return;
+    __shared__ int32_t sh_part[256];
+    const int tid = threadIdx.x;
+    const int n_big = *n_big_dev;
     const int chunk = (n_big + 255) / 256;
     const int k0 = min(tid * chunk, n_big), k1 = min(k0 + chunk, n_big);
     int sum = 0;
-    for (int k = k0; k < k1; k++) sum += nnz_row[__hip_atomic_load(&slot_face[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+    for (int k = k0; k < k1; k++) sum += nnz_row[slot_face[k]];
     sh_part[tid] = sum;
     __syncthreads();
     long long off = 0, all = 0;
@@ -335,7 +351,7 @@ k_big_order(const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_
     }
     for (int k = k0; k < k1; k++) {
         big_indptr[k] = (int32_t)off;
-        off += nnz_row[__hip_atomic_load(&slot_face[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)];
+        off += nnz_row[slot_face[k]];
     }
     if (tid == 0) {
         big_indptr[n_big] = (int32_t)(all > 0x7fffffffll ? 0x7fffffff : all);
