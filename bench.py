@@ -55,48 +55,103 @@ def make_meshes(points_per_mesh, delaunay=True):
     return sxy, sf, txy, tf
 
 
-def algorithmic_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
-    """Per-kernel algorithmic HBM bytes of one step: every array a kernel has
-    to read or write once -- int32 connectivity / indices, f64 coordinates / areas, the face-major
-    vertex blocks (16 M bytes per face) and 16-byte f32 record boxes the engine keeps in HBM."""
-    vs, vt = 16 * Ms, 16 * Mt  # face-major vertex block bytes
-    b = {}
-    b["prepare_faces"] = 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + (vs + 1 + 32 + 8) * S + (vt + 1 + 32 + 8) * T
-    b["index_count"] = 32 * S + 4 * S
-    b["order_count"] = 32 * T + 4 * T
-    b["index_scatter"] = (4 + vs + 1 + 32) * S + (4 + vs + 1 + 16) * S
-    b["order_scatter"] = (4 + vt + 1 + 32) * T + (4 + vt + 1 + 32) * T
-    b["search"] = 32 * T + 16 * S + 8 * T + 8 * C  # query boxes, record boxes once, count + offset, pair queue out
-    b["clip_small"] = 8 * C + vt * T + vs * S + (S + T) + 4 * S + 12 * C + 4 * T  # queue, vertex blocks, area + face id out
-    b["row_fill"] = 4 * T + 16 * C + 4 * T + 12 * P
-    b["apply_stream"] = 12 * P + 4 * (T + 1) + 4 * T + 8 * (S + T)
-    # whole weight construction, SURVEY.md 8(d): read both meshes once, write the CSR once
-    b["build_total"] = 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + 12 * P + 4 * (T + 1)
-    return b
+def algorithmic_bytes(S, T, Ns, Nt, P, K=1, Ms=3, Mt=3):
+    """SURVEY.md section 8(d), the contract for `roofline.achieved` (int32 structure, f64 geometry and weights):
+    weights build  B_build = 4 (sum Ms + sum Mt) + 16 (Ns + Nt) + 12 P + 4 (T + 1)   (both meshes once, the CSR once)
+    apply          B_apply = 12 P + 4 (T + 1) + 8 K (S + T)                            (weights once, data once)"""
+    build = 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + 12 * P + 4 * (T + 1)
+    apply_ = 12 * P + 4 * (T + 1) + 8 * K * (S + T)
+    return {"build": build, "apply": apply_, "step": build + apply_}
+
+
+def kernel_model_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
+    """The engine's OWN per-kernel byte model (every array a kernel has to read or write once, intermediate
+    arrays included: face-major vertex blocks, f32 record boxes, the pair queue).  Not the roofline contract --
+    kept under `roofline.kernel_model` to show where the bytes beyond section 8(d) come from."""
+    vs, vt = 16 * Ms, 16 * Mt
+    return {
+        "prepare_faces": 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + (vs + 1 + 32 + 8) * S + (vt + 1 + 32 + 8) * T,
+        "index_count": 32 * S + 4 * S,
+        "index_scatter": (4 + vs + 1 + 32) * S + (4 + vs + 1 + 16) * S,
+        "search": 32 * T + 16 * S + 8 * T + 8 * C,
+        "clip_tri": 8 * C + vt * T + vs * S + 4 * S + 12 * C,
+        "assemble": 16 * C + 8 * T + 8 * T + 12 * P + 4 * T,
+        "apply_stream": 12 * P + 4 * (T + 1) + 4 * T + 8 * (S + T),
+    }
+
+
+def source_sha():
+    """sha1 over the kernel sources (as profiles/pmc_summary.py): PMC numbers of other kernels are refused."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "xugrid_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "xugrid_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
 
 
 def cpu_baseline(sxy, sf, txy, tf, data):
-    """The CPU oracle (oracle/xr_oracle.c: cell tree + SAT + Sutherland-Hodgman + CSR + mean apply,
-    OpenMP over queries / candidate pairs, apply threaded over K only as numba's prange) timed once
-    on the full workload."""
+    """The CPU oracle (oracle/xr_oracle.c: cell tree + SAT + Sutherland-Hodgman + CSR + mean apply) timed on this
+    box's host cores, SURVEY.md section 8(d):
+      faithful   the reference's parallel structure: tree build serial, search parallel over target faces, clip
+                 parallel over candidate pairs, apply parallel over K only (numba prange, regridder.py:50) -- all cores,
+                 the whole workload once; this is `value`
+      favourable the same with the apply parallel over target rows as well
+      one thread the tree build and the apply on the whole workload, search + clip on a sample of the target faces,
+                 extrapolated linearly (bounded to a few seconds)"""
     from oracle import oracle as O
 
     O.build()
     cores = O.num_threads()
+    T = tf.shape[0]
     t0 = time.perf_counter()
     tree = O.CellTree2d(sxy, sf)
+    t_tree = time.perf_counter() - t0
+    t0 = time.perf_counter()
     q, s, a = tree.intersect_faces(txy, tf)
-    indptr = O.to_csr_indptr(q, tf.shape[0])
-    t1 = time.perf_counter()
-    out = O.regrid_csr("mean", data[None, :], a, s, indptr, tf.shape[0], parallel_rows=False)
-    t2 = time.perf_counter()
-    log(f"[bench] cpu oracle: weights {t1 - t0:.2f}s apply {t2 - t1:.3f}s on {cores} threads, nnz {a.size}")
+    indptr = O.to_csr_indptr(q, T)
+    t_pairs = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    out = O.regrid_csr("mean", data[None, :], a, s, indptr, T, parallel_rows=False)
+    t_apply = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.regrid_csr("mean", data[None, :], a, s, indptr, T, parallel_rows=True)
+    t_apply_rows = time.perf_counter() - t0
+    # one thread: bounded sample of the target faces
+    n_sample = min(T, 40_000)
+    sample = np.sort(np.random.default_rng(0).choice(T, n_sample, replace=False))
+    O.set_num_threads(1)
+    t0 = time.perf_counter()
+    tree1 = O.CellTree2d(sxy, sf)
+    t_tree1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tree1.intersect_faces(txy, tf[sample])
+    t_pairs1 = (time.perf_counter() - t0) * (T / n_sample)
+    t0 = time.perf_counter()
+    O.regrid_csr("mean", data[None, :], a, s, indptr, T, parallel_rows=False)
+    t_apply1 = time.perf_counter() - t0
+    O.set_num_threads(cores)
+    faithful = t_tree + t_pairs + t_apply
+    log(f"[bench] cpu oracle, {cores} threads: tree {t_tree:.2f}s pairs {t_pairs:.2f}s apply {t_apply:.3f}s "
+        f"(rows-parallel {t_apply_rows:.3f}s); 1 thread: tree {t_tree1:.2f}s pairs ~{t_pairs1:.1f}s apply {t_apply1:.3f}s; nnz {a.size}")
     return {
-        "value": tf.shape[0] / (t2 - t0),
+        "value": T / faithful,
         "unit": "target cells/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"full workload once: S={sf.shape[0]} T={tf.shape[0]} K=1 (weights {t1 - t0:.2f}s + apply {t2 - t1:.3f}s)",
+        "sample": f"full workload once: S={sf.shape[0]} T={T} K=1 (tree {t_tree:.2f}s + search/clip {t_pairs:.2f}s + apply {t_apply:.3f}s)",
+        "variants": {
+            "faithful_all_cores": {"cells_per_s": T / faithful, "cores": cores, "seconds": faithful},
+            "favourable_all_cores": {"cells_per_s": T / (t_tree + t_pairs + t_apply_rows), "cores": cores,
+                                     "seconds": t_tree + t_pairs + t_apply_rows,
+                                     "note": "apply parallel over target rows as well (the reference's is over K only)"},
+            "one_thread": {"cells_per_s": T / (t_tree1 + t_pairs1 + t_apply1), "cores": 1,
+                           "seconds_extrapolated": t_tree1 + t_pairs1 + t_apply1,
+                           "sample": f"tree build and apply on the whole workload, search + clip on {n_sample} of {T} target "
+                                     "faces (random, seed 0), scaled linearly"},
+        },
     }, out[0]
 
 
@@ -170,67 +225,88 @@ def run_single(args):
             step()
     kernels = {k: (n, t / n) for k, (n, t) in kt.records.items()}  # name -> (launches, avg ms)
     per_step = {k: n * avg / args.steps for k, (n, avg) in kernels.items()}
-    dominant = max(per_step, key=per_step.get)
-    ab = algorithmic_bytes(S, T, Ns, Nt, C, P)
-    dom_bytes = ab.get(dominant)
+    # the dominant kernel of the MAIN stream chain (the big faces' kernels run beside it on the side stream)
+    side = {"search_big", "clip_big", "big_rank", "big_scan", "row_fill_long"}
+    dominant = max((k for k in per_step if k not in side), key=per_step.get)
+    ab = algorithmic_bytes(S, T, Ns, Nt, P)
     dom_ms = kernels[dominant][1]
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_bytes else None
-    traffic = None
+    build_names = [k for k in per_step if not k.startswith("apply")]
+    build_kernel_ms = sum(per_step[k] for k in build_names)
+    apply_ms_kernels = sum(v for k, v in per_step.items() if k.startswith("apply"))
+    gbps = lambda nbytes, ms: nbytes / (ms * 1e-3) / 1e9  # noqa: E731
+    # HBM-side traffic from the committed PMC passes -- only if they were taken on THESE kernel sources
+    traffic, traffic_ratio, pmc_note = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc = None
     if os.path.exists(tpath):
         try:
-            entry = json.load(open(tpath)).get(dominant)
-            # HBM-side bytes per launch from the PMC passes (2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction)
-            traffic = entry["hbm_bytes_corrected"] if entry else None
-        except Exception:
-            traffic = None
-    # The dominant kernel (the clip) is FP64-VALU work, not HBM traffic: next to the HBM fraction the contract asks
-    # for, report how close it runs to the VALU issue limit.  Instruction count from the committed PMC pass
-    # (SQ_INSTS_VALU, wave-instructions per launch); a wave64 FP64 instruction occupies its SIMD for 4 cycles
-    # (78.6 TFLOP/s FP64 vector peak = 256 CUs x 4 SIMDs x 16 lanes x 2 x 2.4 GHz), a 32-bit one for 2.
+            pmc = json.load(open(tpath))
+            if pmc.get("_meta", {}).get("source_sha") != source_sha():
+                pmc_note = "profiles/pmc_traffic.json belongs to other kernel sources: traffic not reported (re-run profiles/collect.sh)"
+                pmc = None
+        except Exception as e:  # noqa: BLE001
+            pmc_note, pmc = repr(e), None
+    else:
+        pmc_note = "profiles/pmc_traffic.json missing"
+    pmc_names = {"prepare_faces": "k_prepare_faces", "reduce_stats": "k_reduce_stats", "index_count": "k_spatial_count",
+                 "index_scatter": "k_spatial_scatter", "search": "k_search", "search_big": "k_search_big",
+                 "clip_tri": "k_clip_tri_queue", "clip_big": "k_clip_tri_queue", "assemble": "k_assemble",
+                 "big_rank": "k_big_rank", "big_scan": "k_big_scan", "row_fill_long": "k_row_fill_long",
+                 "place_big": "k_place_big", "publish": "k_publish_all", "scan_reduce": "k_scan_reduce",
+                 "scan_apply": "k_scan_apply_fused", "apply_stream": "k_apply_stream", "apply_wave": "k_apply_wave",
+                 "apply_long": "k_apply_long"}
+    if pmc:
+        def per_step_bytes(name):
+            e = pmc.get("k_clip_tri_queue@65536" if name == "clip_big" else pmc_names.get(name, name))
+            return e["hbm_bytes_corrected"] * kernels[name][0] / args.steps if e else 0.0
+
+        e = pmc.get(pmc_names.get(dominant, dominant))
+        traffic = e["hbm_bytes_corrected"] if e else None
+        build_traffic = sum(per_step_bytes(k) for k in build_names)
+        traffic_ratio = build_traffic / ab["build"]
+    # The clip is FP64 issue work: next to the HBM fraction the contract asks for, how close it runs to the VALU issue
+    # limit (SQ_INSTS_VALU of the committed PMC pass; ~4 SIMD cycles per wave64 instruction, measured
+    # SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU).
     valu = None
-    ppath = os.path.join(ROOT, "profiles", "r01l_pmc_per_launch.json")
-    pmc_names = {"clip_small": "k_clip_small<6, 256, true>", "search": "k_search"}
-    if os.path.exists(ppath) and dominant in pmc_names:
+    ppath = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
+    if pmc and os.path.exists(ppath):
         try:
-            insts = json.load(open(ppath))[pmc_names[dominant]]["SQ_INSTS_VALU"]
-            n_simd, clock = 256 * 4, 2.4e9
-            floor_fp64_ms = insts * 4 / n_simd / clock * 1e3
-            floor_mixed_ms = insts * 3 / n_simd / clock * 1e3
-            valu = {
-                "wave_instructions_per_launch": insts,
-                "issue_floor_ms_all_fp64": floor_fp64_ms,
-                "issue_floor_ms_half_fp64": floor_mixed_ms,
-                "frac_of_issue_limit": [floor_mixed_ms / dom_ms, floor_fp64_ms / dom_ms],
-                "source": "profiles/r01l_pmc_per_launch.json",
-            }
+            insts = json.load(open(ppath))["k_clip_tri_queue"]["SQ_INSTS_VALU"]
+            floor_ms = insts * 4 / (256 * 4) / 2.4e9 * 1e3
+            clip_ms = kernels["clip_tri"][1] if "clip_tri" in kernels else None
+            valu = {"kernel": "clip_tri", "wave_instructions_per_launch": insts, "issue_floor_ms": floor_ms,
+                    "frac_of_issue_limit": floor_ms / clip_ms if clip_ms else None, "source": "profiles/pmc_per_launch.json"}
         except Exception:
             valu = None
-    build_kernel_ms = sum(v for k, v in per_step.items() if not k.startswith("apply"))
+    km = kernel_model_bytes(S, T, Ns, Nt, C, P)
     roofline = {
         "bound": "hbm",
         "kernel": dominant,
-        "achieved": achieved,
+        # algorithmic bytes of the whole weight build (93 B per target cell x the T cells one launch processes)
+        # / the dominant kernel's average launch duration
+        "achieved": gbps(ab["build"], dom_ms),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS if achieved else None,
+        "frac": gbps(ab["build"], dom_ms) / HBM_PEAK_GBS,
         "traffic": traffic,
-        "algorithmic_bytes_per_launch": dom_bytes,
+        "traffic_ratio_build": traffic_ratio,
+        "traffic_note": pmc_note,
+        "algorithmic_bytes_per_launch": ab["build"],
         "avg_launch_ms": dom_ms,
+        "figures": {
+            "dominant_kernel": {"kernel": dominant, "bytes": ab["build"], "ms": dom_ms, "frac": gbps(ab["build"], dom_ms) / HBM_PEAK_GBS},
+            "build": {"bytes": ab["build"], "kernel_ms_sum": build_kernel_ms, "wall_ms": build_ms,
+                      "frac_of_kernel_sum": gbps(ab["build"], build_kernel_ms) / HBM_PEAK_GBS,
+                      "frac_of_wall": gbps(ab["build"], build_ms) / HBM_PEAK_GBS,
+                      "note": "kernel_ms_sum counts the side-stream kernels of the big faces although they overlap the main chain"},
+            "apply_K1": {"bytes": ab["apply"], "kernel_ms_sum": apply_ms_kernels, "wall_ms": apply_ms,
+                         "frac_of_wall": gbps(ab["apply"], apply_ms) / HBM_PEAK_GBS},
+            "step": {"bytes": ab["step"], "ms": ms_per_step, "frac": gbps(ab["step"], ms_per_step) / HBM_PEAK_GBS},
+        },
         "valu_issue": valu,
         "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
-        "build_aggregate": {
-            "algorithmic_bytes": ab["build_total"],
-            "kernel_ms": build_kernel_ms,
-            "GBps": ab["build_total"] / (build_kernel_ms * 1e-3) / 1e9,
-            "frac": ab["build_total"] / (build_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        },
-        "apply": {
-            "algorithmic_bytes": ab["apply_stream"],
-            "avg_launch_ms": kernels["apply_stream"][1],
-            "GBps": ab["apply_stream"] / (kernels["apply_stream"][1] * 1e-3) / 1e9,
-            "frac": ab["apply_stream"] / (kernels["apply_stream"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        },
+        "kernel_model": {k: {"bytes": km[k], "frac": gbps(km[k], kernels[k][1]) / HBM_PEAK_GBS}
+                         for k in km if k in kernels},
     }
 
     out_gpu = np.empty(T)
@@ -418,34 +494,54 @@ def run_multi(args):
     rank, world = dist.get_rank(), dist.get_world_size()
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     backend = HipBackend(local_rank)
-    # weak scaling: N x 500k points per mesh.  The lattice-split triangulation keeps the set-up of
-    # the N-times larger meshes to seconds on every rank (qhull on 4M points takes minutes).
-    sxy, sf, txy, tf = make_meshes(args.points * world, delaunay=False)
+    # Weak scaling: N tiles of the single-GPU benchmark pair (the same Delaunay meshes, hull slivers included, side by
+    # side), N x 1M faces per mesh.  One qhull run serves any N; with --points > 600k (config 4's 10M faces on one box)
+    # or --no-delaunay the lattice-split triangulation is used so that set-up stays within seconds.
+    t_gen = time.perf_counter()
+    if args.no_delaunay or args.points > 600_000:
+        sxy, sf, txy, tf = make_meshes(args.points * world, delaunay=False)
+        mesh_kind = "lattice-split triangulation"
+    else:
+        sxy, sf, txy, tf = make_meshes(args.points, delaunay=True)
+        sxy, sf = meshgen.tiled_mesh(sxy, sf, world)
+        txy, tf = meshgen.tiled_mesh(txy, tf, world)
+        mesh_kind = f"{world} tile(s) of the Delaunay benchmark pair"
     S, T = sf.shape[0], tf.shape[0]
-    rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=args.exchange)
     data = meshgen.smooth_field(sxy[sf].mean(axis=1), 0)
-    local = rg.local_source(data)
+    t_gen = time.perf_counter() - t_gen
 
-    def step():
-        rg.rebuild()
-        return rg.regrid_local(local)
+    def measure(exchange):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=exchange)
+        torch.cuda.synchronize()
+        setup_s = time.perf_counter() - t0
+        local = rg.local_source(data)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=backend.device)
-    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
-    nnz = torch.tensor([rg.weights.nnz], dtype=torch.int64, device=backend.device)
-    dist.all_reduce(nnz)
+        def step():
+            rg.rebuild()
+            return rg.regrid_local(local)
+
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=backend.device)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        nnz = torch.tensor([rg.weights.nnz], dtype=torch.int64, device=backend.device)
+        dist.all_reduce(nnz)
+        return rg, step, float(elapsed.item()), int(nnz.item()), setup_s
+
+    rg, step, elapsed, nnz, setup_s = measure(args.exchange)
+    other = "dense" if args.exchange == "sparse" else "sparse"
+    _, _, elapsed_other, _, _ = measure(other)
     # rank 0's kernels of a few more steps (hipEvents around every launch): roofline of its dominant kernel
     roofline = None
     from xugrid_amd import engine as E
@@ -458,11 +554,11 @@ def run_multi(args):
         try:
             kernels = {k: (n, t / n) for k, (n, t) in kt.records.items()}
             per_step = {k: n * avg / 3 for k, (n, avg) in kernels.items()}
-            dominant = max(per_step, key=per_step.get)
+            side = {"search_big", "clip_big", "big_rank", "big_scan", "row_fill_long"}
+            dominant = max((k for k in per_step if k not in side), key=per_step.get)
             s_loc, t_loc = rg.local_faces.size, rg.local_targets.size
-            ab = algorithmic_bytes(s_loc, t_loc, sxy.shape[0], txy.shape[0], backend._src_mesh.last_candidates(),
-                                   rg.weights.nnz)
-            dom_bytes, dom_ms = ab.get(dominant), kernels[dominant][1]
+            ab = algorithmic_bytes(s_loc, t_loc, sxy.shape[0] // world, txy.shape[0] // world, rg.weights.nnz)
+            dom_bytes, dom_ms = ab["build"], kernels[dominant][1]
             achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_bytes else None
             roofline = {
                 "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -474,6 +570,8 @@ def run_multi(args):
         except Exception as e:  # noqa: BLE001
             roofline = {"error": repr(e)}
     if rank == 0:
+        exchange_name = {"sparse": "RCCL sparse all-to-all (the reduce-scatter restricted to the touched targets) of per-target partial sums",
+                         "dense": "RCCL reduce-scatter of per-target partial sums"}
         result = {
             "metric": "target cells regridded/s (OverlapRegridder 1M->1M tri per GPU, weights + mean apply)",
             "value": T / (elapsed / args.steps),
@@ -488,14 +586,20 @@ def run_multi(args):
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{world} x BASELINE config 2: ~{S} source -> ~{T} target triangles (lattice-split "
-                "triangulation), OverlapRegridder mean, K=1",
+                "workload": f"{world} x BASELINE config 2 ({mesh_kind}): {S} source -> {T} target triangles, "
+                "OverlapRegridder mean, K=1",
                 "source_faces": S,
                 "target_faces": T,
-                "nnz": int(nnz.item()),
+                "nnz": nnz,
                 "parallelism": f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
-                + ("RCCL sparse all-to-all (reduce-scatter restricted to the touched targets) of per-target partial sums"
-                   if args.exchange == "sparse" else "RCCL reduce-scatter of per-target partial sums"),
+                + exchange_name[args.exchange],
+                "exchange": args.exchange,
+                "other_exchange": {"exchange": other, "ms_per_step": 1e3 * elapsed_other / args.steps,
+                                   "value": T / (elapsed_other / args.steps), "what": exchange_name[other]},
+                "setup_s_untimed": {"mesh_generation": t_gen, "partition_filter_first_build": setup_s,
+                                    "note": "set-up (torch ops on the device: centroids, Morton partition, work estimate, "
+                                    "near-shard filter, mesh upload, first weight build, exchange lists) is done once "
+                                    "per regridder and is not part of the step"},
             },
             "roofline": roofline,
             "cpu_baseline": None,

@@ -301,33 +301,34 @@ int xr_apply_outer_dev(xr_outer *outer, int method, double percentile, const voi
 int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,
                  const void *source, int source_dtype, int64_t K, int64_t S, double *out);
 
-/* Multi-GPU (source faces sharded over ranks).  For the sum-decomposable
- * reducer `mean`: per-rank partial sums over this rank's columns,
- *   numden_dev[0][k][t] = sum_j w_j v_j (v not NaN),  numden_dev[1][k][t] = sum_j w_j (v not NaN),
- * laid out float64 [2, K, T]; the ranks then reduce-scatter (RCCL, sum) and finalise. */
-int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int source_dtype,
-                              int64_t K, double *numden_dev);
-/* out[i] = den[i] == 0 ? NaN : num[i] / den[i]  for i < count (mean's epilogue, reduce.py:24-27). */
-int xr_finalize_mean_dev(const double *num_dev, const double *den_dev, int64_t count,
-                         double *out_dev);
-/* Row layout of the same partial sums, for the sparse exchange (one message row per target):
- *   rows_dev[t][0..K) = num[k][t],  rows_dev[t][K..2K) = den[k][t]      float64 [T, 2K]
- * t runs over the CALLER's row order of the matrix. */
-int xr_apply_partial_mean_rows_dev(const xr_csr *csr, const void *source_dev, int source_dtype,
-                                   int64_t K, double *rows_dev);
-/* acc_dev[ids_dev[i]][:] += rows_dev[i][:]  for i < n, rows of `width` float64; the ids of one call
- * must be distinct (one sender's contribution), so the addition order is deterministic. */
-int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double *rows_dev,
-                           int64_t n, int64_t width);
-/* out_dev[k][t] = acc[t][K+k] == 0 ? NaN : acc[t][k] / acc[t][K+k]   (acc float64 [n_rows, 2K],
- * out float64 [K, n_rows]). */
-int xr_finalize_mean_rows_dev(const double *acc_dev, int64_t n_rows, int64_t K, double *out_dev);
-/* The owner side of the sparse exchange in one launch: rows_dev float64[R, 2K] are the received partial rows
- * (num[0..K), den[0..K)); target t of this rank's slice sums rows order_dev[indptr_dev[t] .. indptr_dev[t+1]) in
- * that (sender) order and is finalised: out_dev float64[K, n_targets] = num / den, NaN where den == 0.  Same
- * additions in the same order as xr_accumulate_rows_dev sender by sender + xr_finalize_mean_rows_dev. */
-int xr_reduce_mean_rows_dev(const double *rows_dev, const int64_t *indptr_dev, const int64_t *order_dev,
-                            int64_t n_targets, int64_t K, double *out_dev);
+/* Multi-GPU (source faces sharded over ranks).  For EVERY reducer that decomposes over source shards
+ * (xugrid/regrid/reduce.py:16-123, 206-222) each rank reduces the entries of its own columns to a few partial STATE components per (target, variable),
+ * the ranks combine the components element-wise with ONE collective (sum, or max for minimum / maximum), the owner of a
+ * target finalises.  Components (v = value, w = weight; "valid" = v not NaN):
+ *   XR_MEAN, XR_FIRST_ORDER_CONSERVATIVE   [sum w v, sum w]                     over valid          -> c0 / c1 resp. c0
+ *   XR_SUM                                 [sum v,   sum w]                     over valid          -> c0
+ *   XR_HARMONIC_MEAN                       [sum w,   sum w / v]                 valid, v != 0, w > 0 -> c0 / c1
+ *   XR_GEOMETRIC_MEAN                      [sum w (ALL entries), sum w ln v, sum w (v > 0, w > 0), #(v < 0)]
+ *                                                                                                     -> exp(c1 / c2)
+ *   XR_MINIMUM / XR_MAXIMUM                [max(-v) resp. max v, max w]         over valid (combine with MAX)
+ * with NaN where the reference returns NaN (zero weight sum, a negative value under the geometric mean ...).
+ * xr_partial_components(method) -> number of components (0: the reducer needs whole rows: mode, percentiles,
+ * max_overlap), xr_partial_combine_is_max(method) -> 1 if the collective is MAX.
+ * Layouts: planes float64 [C, K, T] (dense exchange) or rows float64 [T, C * K] (sparse exchange, component-major
+ * inside a row); t runs over the CALLER's row order of the matrix. */
+int xr_partial_components(int method);
+int xr_partial_combine_is_max(int method);
+int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, int source_dtype, int64_t K,
+                         double *out_dev, int rows_layout);
+/* identity element of the combine step in the same layouts (buffers of targets a rank has no weight for) */
+int xr_partial_fill_identity_dev(int method, double *planes_dev, int64_t K, int64_t T);
+/* out_dev float64 [K, T] from combined planes [C, K, T] */
+int xr_finalize_partial_dev(int method, const double *planes_dev, int64_t K, int64_t T, double *out_dev);
+/* owner side of the sparse exchange in one launch: rows_dev float64 [R, C * K] received partial rows; target t of this
+ * rank's slice combines rows order_dev[indptr_dev[t] .. indptr_dev[t+1]) in that (sender) order and is finalised:
+ * out_dev float64 [K, n_targets]. */
+int xr_reduce_partial_rows_dev(int method, const double *rows_dev, const int64_t *indptr_dev, const int64_t *order_dev,
+                               int64_t n_targets, int64_t K, double *out_dev);
 
 /* ---- raw HBM helpers for hosts that do not bring their own allocator -------------------- */
 int xr_dev_alloc(int64_t bytes, void **ptr_out);

@@ -124,6 +124,10 @@ def num_threads():
     return lib().xo_num_threads()
 
 
+def set_num_threads(n):
+    lib().xo_set_num_threads(int(n))
+
+
 def reduce(method, values, weights):
     mid, p = method_to_id(method)
     v = np.ascontiguousarray(values, dtype=np.float64)

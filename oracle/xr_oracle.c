@@ -18,6 +18,14 @@
 #define XO_FILL (-1)
 #define XO_MAXV 64 /* max vertices of a clipped polygon (numba_celltree MAX_N_VERTEX=32, x2) */
 
+void xo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int xo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -118,6 +118,7 @@ int xo_barycentric(const xo_tree *t, const double *pts, int64_t n, double tolera
 double xo_default_tolerance(const xo_tree *t);
 
 int xo_num_threads(void);
+void xo_set_num_threads(int n); /* OpenMP team size of the following calls (bench.py: 1-thread baseline) */
 
 #ifdef __cplusplus
 }

@@ -24,14 +24,20 @@ def short(name):
 
 
 def main(root):
-    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    # per (kernel, grid size): the same kernel launched with different grids (the persistent clip over the regular and
+    # over the big pair queue) is kept apart -- the largest grid under the plain name, the others as name@grid
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
     for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
         f = os.path.join(d, "pmc_counter_collection.csv")
         if not os.path.exists(f):
             continue
         for r in csv.DictReader(open(f)):
-            agg[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+            agg[short(r["Kernel_Name"])][int(r.get("Grid_Size", 0) or 0)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for k, grids in agg.items():
+        for g in grids:
+            name = k if g == max(grids) else f"{k}@{g}"
+            out[name] = {c: sum(v) / len(v) for c, v in grids[g].items()}
     names = sorted({c for k in out for c in out[k]})
     for k in sorted(out, key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0)):
         print(k)

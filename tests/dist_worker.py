@@ -25,11 +25,22 @@ class OracleWeights:
         self.data, self.indices, self.indptr, self.n, self.m = data, indices, indptr, n, m
 
 
-class OracleBackend:
-    """Same three methods as xugrid_amd.distributed.HipBackend, computed by the CPU oracle."""
+COMPONENTS = {0: 2, 8: 2, 3: 2, 1: 2, 2: 4, 4: 2, 5: 2}  # method id -> partial-state components (include/xugrid_amd.h)
+NAMES = {0: "mean", 1: "harmonic_mean", 2: "geometric_mean", 3: "sum", 4: "minimum", 5: "maximum", 6: "mode",
+         8: "first_order_conservative", 9: "max_overlap"}
 
-    def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces):
+
+class OracleBackend:
+    """Same methods as xugrid_amd.distributed.HipBackend, computed on the CPU: weights and whole-row reducers by the
+    oracle, the partial states of the shard-decomposable reducers by a numpy restatement of the component table of
+    include/xugrid_amd.h (reduce.py:16-123, 206-222)."""
+
+    device = None
+
+    def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces, relative=False):
         q, s, a = O.CellTree2d(src_xy, src_faces).intersect_faces(tgt_xy, tgt_faces)
+        if relative:
+            a = a / O.area(src_xy, src_faces)[s]
         T = np.asarray(tgt_faces).shape[0]
         return OracleWeights(a, s, O.to_csr_indptr(q, T), T, np.asarray(src_faces).shape[0])
 
@@ -43,57 +54,80 @@ class OracleBackend:
         return torch.as_tensor(np.ascontiguousarray(array))
 
     def apply(self, w, source, method_id, percentile=0.0):
-        names = {0: "mean", 1: "harmonic_mean", 2: "geometric_mean", 3: "sum", 4: "minimum", 5: "maximum", 6: "mode",
-                 8: "first_order_conservative", 9: "max_overlap"}
-        method = ("percentile", percentile) if method_id == 7 else names[method_id]
+        method = ("percentile", percentile) if method_id == 7 else NAMES[method_id]
         return torch.as_tensor(O.regrid_csr(method, source.numpy(), w.data, w.indices, w.indptr, w.n))
 
-    def partial_mean(self, w, source):
-        src = source.numpy().astype(np.float64)
-        K = src.shape[0]
-        out = np.zeros((2, K, w.n))
-        rows = np.repeat(np.arange(w.n), np.diff(w.indptr))
-        for k in range(K):
-            v = src[k, w.indices]
-            ok = ~np.isnan(v)
-            out[0, k] = np.bincount(rows[ok], weights=(w.data * v)[ok], minlength=w.n)
-            out[1, k] = np.bincount(rows[ok], weights=w.data[ok], minlength=w.n)
+    def n_components(self, method_id):
+        return COMPONENTS[method_id]
+
+    def combine_is_max(self, method_id):
+        return method_id in (4, 5)
+
+    def identity(self, method_id, K, n):
+        out = np.zeros((COMPONENTS[method_id], K, n))
+        if self.combine_is_max(method_id):
+            out[0] = -np.inf
         return torch.as_tensor(out)
 
-    def partial_mean_rows(self, w, source):
-        nd = self.partial_mean(w, source)  # (2, K, T)
-        return nd.permute(2, 0, 1).reshape(nd.shape[2], -1).contiguous()
+    def partial(self, w, source, method_id, rows_layout):
+        src = source.numpy().astype(np.float64)
+        K, C = src.shape[0], COMPONENTS[method_id]
+        out = self.identity(method_id, K, w.n).numpy()
+        rows = np.repeat(np.arange(w.n), np.diff(w.indptr))
+        for k in range(K):
+            v, wt = src[k, w.indices], w.data
+            ok = ~np.isnan(v)
 
-    def reduce_mean_rows(self, rows, indptr, order, n_targets, K):
+            def acc(mask, values):
+                return np.bincount(rows[mask], weights=values[mask], minlength=w.n)
+
+            with np.errstate(all="ignore"):
+                if method_id in (0, 8):
+                    out[0, k], out[1, k] = acc(ok, wt * v), acc(ok, wt)
+                elif method_id == 3:
+                    out[0, k], out[1, k] = acc(ok, v), acc(ok, wt)
+                elif method_id == 1:
+                    m = ok & (v != 0) & (wt > 0)
+                    out[0, k], out[1, k] = acc(m, wt), acc(m, wt / v)
+                elif method_id == 2:
+                    m = (v > 0) & (wt > 0)
+                    out[0, k] = acc(np.ones_like(ok), wt)
+                    out[1, k], out[2, k] = acc(m, wt * np.log(np.abs(v))), acc(m, wt)
+                    out[3, k] = acc(~m & (v < 0), np.ones_like(wt))
+                else:
+                    sv = -v if method_id == 4 else v
+                    np.maximum.at(out[0, k], rows[ok], sv[ok])
+                    np.maximum.at(out[1, k], rows[ok], wt[ok])
+        if rows_layout:
+            return torch.as_tensor(np.ascontiguousarray(out.transpose(2, 0, 1).reshape(w.n, C * K)))
+        return torch.as_tensor(out)
+
+    def finalize(self, method_id, planes):
+        c = planes.numpy()
+        with np.errstate(all="ignore"):
+            if method_id == 0:
+                out = np.where(c[1] == 0, np.nan, c[0] / c[1])
+            elif method_id in (8, 3):
+                out = np.where(c[1] == 0, np.nan, c[0])
+            elif method_id == 1:
+                out = np.where((c[1] == 0) | (c[0] == 0), np.nan, c[0] / c[1])
+            elif method_id == 2:
+                out = np.where((c[0] == 0) | (c[3] > 0) | (c[2] == 0), np.nan, np.exp(c[1] / c[2]))
+            elif method_id == 4:
+                out = np.where(c[1] == 0, np.nan, -c[0])
+            else:
+                out = np.where(c[1] == 0, np.nan, c[0])
+        return torch.as_tensor(out)
+
+    def reduce_rows(self, method_id, rows, indptr, order, n_targets, K):
         rows, indptr, order = rows.numpy(), indptr.numpy(), order.numpy()
-        acc = np.zeros((n_targets, 2 * K))
+        C = COMPONENTS[method_id]
+        acc = self.identity(method_id, K, n_targets).numpy()
         for t in range(n_targets):
             for j in order[indptr[t]:indptr[t + 1]]:  # sender order
-                acc[t] += rows[j]
-        return self.finalize_mean(torch.as_tensor(acc[:, :K].T.copy()), torch.as_tensor(acc[:, K:].T.copy()))
-
-    def accumulate_rows(self, acc, ids, rows):
-        acc[ids] += rows
-
-    def finalize_mean_rows(self, acc, K):
-        return self.finalize_mean(acc[:, :K].t().contiguous(), acc[:, K:].t().contiguous())
-
-    def finalize_mean(self, num, den):
-        n, d = num.numpy(), den.numpy()
-        with np.errstate(invalid="ignore", divide="ignore"):
-            return torch.as_tensor(np.where(d == 0, np.nan, n / d))
-
-
-class _NoFused:
-    """OracleBackend without reduce_mean_rows (attribute lookup fails -> the regridder accumulates sender by sender)."""
-
-    def __init__(self):
-        self._b = OracleBackend()
-
-    def __getattr__(self, name):
-        if name == "reduce_mean_rows":
-            raise AttributeError(name)
-        return getattr(self._b, name)
+                r = rows[j].reshape(C, K)
+                acc[:, :, t] = np.maximum(acc[:, :, t], r) if self.combine_is_max(method_id) else acc[:, :, t] + r
+        return self.finalize(method_id, torch.as_tensor(acc))
 
 
 def main():
@@ -122,7 +156,18 @@ def main():
     results["morton_from_file"] = rg2.regrid(data)
     results["morton_from_file_dense"] = ShardedOverlapRegridder.from_file(
         os.path.join(out_dir, "sharded"), OracleBackend(), exchange="dense").regrid(data)
-    results["morton_legacy"] = ShardedOverlapRegridder(sxy, sf, txy, tf, _NoFused(), partition="morton").regrid(data)
+    # every shard-decomposable reducer, both exchanges; the variables in tiles of 2 (pipelined collectives)
+    data7 = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(7)])
+    data7[1] = np.abs(data7[1]) + 0.1      # (a variable without negatives: geometric mean defined)
+    data7[2, ::3] = 0.0                    # zeros (harmonic / geometric means skip them)
+    data7[5] = np.nan                      # an all-NaN variable
+    for method in ("sum", "first_order_conservative", "harmonic_mean", "geometric_mean", "minimum", "maximum", "mean"):
+        for exchange in ("sparse", "dense"):
+            rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition="morton", exchange=exchange,
+                                         method=method, k_tile=2)
+            results[f"m_{method}_{exchange}"] = rg.regrid(data7)
+    results["int_source"] = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition="morton").regrid(
+        np.nan_to_num(10 * data).astype(np.int32))
     for method in ("mode", "median", "max_overlap", "minimum", "sum", "mean"):
         tp = TargetPartitionedRegridder(sxy, sf, txy, tf, OracleBackend(), method=method)
         results["tp_" + method] = tp.regrid(data)

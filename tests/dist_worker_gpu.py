@@ -38,6 +38,16 @@ def main():
     dist.barrier()
     results["mean_from_file"] = ShardedOverlapRegridder.from_file(
         os.path.join(out_dir, "sharded"), backend, exchange="sparse").regrid(data)
+    # every shard-decomposable reducer through the HIP partial-state kernels, K exchanged in tiles of 2
+    data7 = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(7)])
+    data7[1] = np.abs(data7[1]) + 0.1
+    data7[2, ::3] = 0.0
+    data7[5] = np.nan
+    for method in ("sum", "first_order_conservative", "harmonic_mean", "geometric_mean", "minimum", "maximum"):
+        for exchange in ("sparse", "dense"):
+            rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, exchange=exchange, method=method, k_tile=2)
+            results[f"m_{method}_{exchange}"] = rg.regrid(data7)
+    results["int_source"] = ShardedOverlapRegridder(sxy, sf, txy, tf, backend).regrid(np.nan_to_num(10 * data).astype(np.int32))
     for method in ("mode", "median", "max_overlap", "minimum"):
         results["tp_" + method] = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method=method).regrid(data)
     if rank == 0:

@@ -95,8 +95,27 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     # spatially compact shards only look at the targets near them; hash shards see (almost) all
     assert int(out["morton_n_local_targets"]) < 0.8 * tf.shape[0]
     assert int(out["hash_n_local_targets"]) > 0.95 * tf.shape[0]
-    # the fused owner-side reduction and the sender-by-sender accumulation are the same additions
-    assert np.array_equal(out["morton"], out["morton_legacy"], equal_nan=True)
+    # every reducer that decomposes over source shards (reduce.py:16-123, 206-222), sparse and dense exchange, the
+    # variables exchanged in tiles of 2: against the single-process oracle on the unsharded matrix
+    data7 = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(7)])
+    data7[1] = np.abs(data7[1]) + 0.1
+    data7[2, ::3] = 0.0
+    data7[5] = np.nan
+    indptr7 = oracle.to_csr_indptr(q, tf.shape[0])
+    rel = a / oracle.area(sxy, sf)[s]
+    for method in ("sum", "first_order_conservative", "harmonic_mean", "geometric_mean", "minimum", "maximum", "mean"):
+        w = rel if method == "first_order_conservative" else a
+        single = oracle.regrid_csr(method, data7, w, s, indptr7, tf.shape[0])
+        for exchange in ("sparse", "dense"):
+            got = out[f"m_{method}_{exchange}"]
+            assert np.array_equal(np.isnan(got), np.isnan(single)), (method, exchange)
+            rtol = 1e-9 if method == "harmonic_mean" else 1e-12  # (mixed-sign harmonic sums cancel)
+            np.testing.assert_allclose(got, single, rtol=rtol, equal_nan=True, err_msg=f"{method} {exchange}")
+        assert np.array_equal(out[f"m_{method}_sparse"], out[f"m_{method}_dense"], equal_nan=True), method
+    assert np.isnan(out["m_mean_sparse"][5]).all()
+    # integer source data are cast to float64 (as engine._source_2d), never reinterpreted
+    np.testing.assert_allclose(out["int_source"], oracle.regrid_csr("mean", np.nan_to_num(10 * data).astype(np.int32).astype(np.float64),
+                                                                  a, s, indptr7, tf.shape[0]), rtol=1e-12, equal_nan=True)
     # weights persisted shard by shard and reloaded without meshes: same exchange, same result
     assert np.array_equal(out["morton"], out["morton_from_file"], equal_nan=True)
     assert np.array_equal(out["morton_dense"], out["morton_from_file_dense"], equal_nan=True)

@@ -39,6 +39,20 @@ def test_sharded_and_target_partitioned_regridders_rccl(hip, oracle, tmp_path):
         np.testing.assert_allclose(out["mean_rebuilt_" + exchange], exp32, rtol=1e-13, equal_nan=True)
     assert np.array_equal(out["mean_sparse"], out["mean_dense"], equal_nan=True)
     assert np.array_equal(out["mean_sparse"], out["mean_from_file"], equal_nan=True)  # shard files, no meshes
+    data7 = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(7)])
+    data7[1] = np.abs(data7[1]) + 0.1
+    data7[2, ::3] = 0.0
+    data7[5] = np.nan
+    rel = a / oracle.area(sxy, sf)[s_]
+    for method in ("sum", "first_order_conservative", "harmonic_mean", "geometric_mean", "minimum", "maximum"):
+        single = oracle.regrid_csr(method, data7, rel if method == "first_order_conservative" else a, s_, indptr, tf.shape[0])
+        for exchange in ("sparse", "dense"):
+            got = out[f"m_{method}_{exchange}"]
+            assert np.array_equal(np.isnan(got), np.isnan(single)), (method, exchange)
+            np.testing.assert_allclose(got, single, rtol=1e-9 if method == "harmonic_mean" else 1e-12, equal_nan=True,
+                                       err_msg=f"{method} {exchange}")
+    np.testing.assert_allclose(out["int_source"], oracle.regrid_csr("mean", np.nan_to_num(10 * data).astype(np.int32).astype(np.float64),
+                                                                  a, s_, indptr, tf.shape[0]), rtol=1e-12, equal_nan=True)
     for method in ("mode", "median", "max_overlap", "minimum"):
         single = oracle.regrid_csr(method, data, a, s_, indptr, tf.shape[0])
         assert np.array_equal(out["tp_" + method], single, equal_nan=True), method

@@ -89,12 +89,12 @@ SIGNATURES = {
     "xr_apply_csr": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
     "xr_apply_csr_dev": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
     "xr_apply_coo": (c_int, [vp, vp, c_i64, c_i64, vp, c_int, c_i64, c_i64, vp]),
-    "xr_apply_partial_mean_dev": (c_int, [vp, vp, c_int, c_i64, vp]),
-    "xr_finalize_mean_dev": (c_int, [vp, vp, c_i64, vp]),
-    "xr_apply_partial_mean_rows_dev": (c_int, [vp, vp, c_int, c_i64, vp]),
-    "xr_accumulate_rows_dev": (c_int, [vp, vp, vp, c_i64, c_i64]),
-    "xr_finalize_mean_rows_dev": (c_int, [vp, c_i64, c_i64, vp]),
-    "xr_reduce_mean_rows_dev": (c_int, [vp, vp, vp, c_i64, c_i64, vp]),
+    "xr_partial_components": (c_int, [c_int]),
+    "xr_partial_combine_is_max": (c_int, [c_int]),
+    "xr_apply_partial_dev": (c_int, [vp, c_int, vp, c_int, c_i64, vp, c_int]),
+    "xr_partial_fill_identity_dev": (c_int, [c_int, vp, c_i64, c_i64]),
+    "xr_finalize_partial_dev": (c_int, [c_int, vp, c_i64, c_i64, vp]),
+    "xr_reduce_partial_rows_dev": (c_int, [c_int, vp, vp, vp, c_i64, c_i64, vp]),
     "xr_dev_alloc": (c_int, [c_i64, p_vp]),
     "xr_dev_free": (c_int, [vp]),
     "xr_dev_upload": (c_int, [vp, vp, c_i64]),

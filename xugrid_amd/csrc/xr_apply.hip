@@ -1215,106 +1215,156 @@ k_apply_sorted(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
     }
 }
 
-// mean partials for source-sharded multi-GPU: num = sum w v, den = sum w over non-NaN v
-template <typename SRC>
-__global__ void __launch_bounds__(AP_BLOCK)
-k_apply_partial_mean(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                     const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
-                     const SRC *__restrict__ source,
-                     int64_t K, double *__restrict__ num, double *__restrict__ den) {
-    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
-    if (t >= T) return;
-    const int64_t k0 = (int64_t)blockIdx.y * KT;
-    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
-    const int s = indptr[t], e = indptr[t + 1];
-    Red<XR_MEAN> red[KT];
-    const SRC *src = source + k0 * S;
-    for (int j = s; j < e; j++) {
-        const int64_t col = indices[j];
-        const double w = data[j];
-#pragma unroll
-        for (int kk = 0; kk < KT; kk++)
-            if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, 0.0);
+// ---- partial states of every shard-decomposable reducer (multi-GPU split over the source faces) ------------------
+// (reduce.py:16-123, 206-222; component table in include/xugrid_amd.h)
+__host__ __device__ inline int partial_components(int method) {
+    switch (method) {
+    case XR_MEAN: case XR_FIRST_ORDER_CONSERVATIVE: case XR_SUM: case XR_HARMONIC_MEAN: case XR_MINIMUM: case XR_MAXIMUM: return 2;
+    case XR_GEOMETRIC_MEAN: return 4;
+    default: return 0;
     }
+}
+__host__ __device__ inline bool partial_is_max(int method) { return method == XR_MINIMUM || method == XR_MAXIMUM; }
+
+struct PartialState {
+    double c[4];
+};
+__device__ __forceinline__ PartialState partial_identity(int method) {
+    PartialState st{{0.0, 0.0, 0.0, 0.0}};
+    if (partial_is_max(method)) st.c[0] = -INFINITY;
+    return st;
+}
+__device__ __forceinline__ void partial_add(int method, PartialState &st, double v, double w) {
+    switch (method) {
+    case XR_MEAN: case XR_FIRST_ORDER_CONSERVATIVE:
+        if (v == v) { st.c[0] += w * v; st.c[1] += w; }
+        break;
+    case XR_SUM:
+        if (v == v) { st.c[0] += v; st.c[1] += w; }
+        break;
+    case XR_HARMONIC_MEAN:
+        if (v == v && v != 0 && w > 0) { st.c[0] += w; st.c[1] += w / v; }
+        break;
+    case XR_GEOMETRIC_MEAN:
+        st.c[0] += w;
+        if (v > 0 && w > 0) { st.c[1] += w * log(fabs(v)); st.c[2] += w; }
+        else if (v < 0) st.c[3] += 1.0;
+        break;
+    case XR_MINIMUM:
+        if (v == v) { st.c[0] = fmax(st.c[0], -v); st.c[1] = fmax(st.c[1], w); }
+        break;
+    case XR_MAXIMUM:
+        if (v == v) { st.c[0] = fmax(st.c[0], v); st.c[1] = fmax(st.c[1], w); }
+        break;
+    }
+}
+__device__ __forceinline__ void partial_combine(int method, PartialState &a, const double *b, int64_t stride, int C) {
+    if (partial_is_max(method)) {
+        for (int c = 0; c < C; c++) a.c[c] = fmax(a.c[c], b[c * stride]);
+    } else {
+        for (int c = 0; c < C; c++) a.c[c] += b[c * stride];
+    }
+}
+__device__ __forceinline__ double partial_finalize(int method, const PartialState &st) {
+    switch (method) {
+    case XR_MEAN: return st.c[1] == 0 ? NAN : st.c[0] / st.c[1];
+    case XR_FIRST_ORDER_CONSERVATIVE: case XR_SUM: return st.c[1] == 0 ? NAN : st.c[0];
+    case XR_HARMONIC_MEAN: return (st.c[1] == 0 || st.c[0] == 0) ? NAN : st.c[0] / st.c[1];
+    case XR_GEOMETRIC_MEAN:
+        // (the reference normalises the weights by their sum first: exp(sum (w / W) ln v / sum (w / W)) -- the same
+        // number up to rounding)
+        if (st.c[0] == 0 || st.c[3] > 0 || st.c[2] == 0) return NAN;
+        return exp((1.0 / (st.c[2] / st.c[0])) * (st.c[1] / st.c[0]));
+    case XR_MINIMUM: return st.c[1] == 0 ? NAN : -st.c[0];
+    case XR_MAXIMUM: return st.c[1] == 0 ? NAN : st.c[0];
+    }
+    return NAN;
+}
+
+// one thread per (stored row, variable)
+template <typename SRC>
+__global__ void __launch_bounds__(256)
+k_apply_partial(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
+                const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool rows_layout, bool skip_long) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k = blockIdx.y;
+    if (t >= T) return;
+    if (skip_long && indptr[t + 1] - indptr[t] > APPLY_LONG) return; // reduced by one wave each (k_apply_partial_long)
+    PartialState st = partial_identity(method);
+    const SRC *src = source + k * S;
+    for (int j = indptr[t]; j < indptr[t + 1]; j++) partial_add(method, st, ld_src(src, indices[j]), data[j]);
+    const int C = partial_components(method);
     const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+    for (int c = 0; c < C; c++) {
+        if (rows_layout) out[t_out * (C * K) + c * K + k] = st.c[c];
+        else out[((int64_t)c * K + k) * T + t_out] = st.c[c];
+    }
+}
+
+// the listed long rows (hull slivers: thousands of entries): one wave per (row, variable), lanes stride the row,
+// butterfly combine of the states (fixed order)
+template <typename SRC>
+__global__ void __launch_bounds__(256)
+k_apply_partial_long(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                     const double *__restrict__ data, const int32_t *__restrict__ row_order,
+                     const int32_t *__restrict__ long_rows, const int32_t *__restrict__ n_long, int64_t T, int64_t S,
+                     const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool rows_layout) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
+    const int64_t k = blockIdx.y;
+    const int nl = *n_long;
+    const int C = partial_components(method);
+    const SRC *src = source + k * S;
+    for (int64_t li = wave; li < nl; li += n_waves) {
+        const int t = long_rows[li];
+        PartialState st = partial_identity(method);
+        for (int j = indptr[t] + lane; j < indptr[t + 1]; j += 64) partial_add(method, st, ld_src(src, indices[j]), data[j]);
+        for (int c = 0; c < C; c++) {
 #pragma unroll
-    for (int kk = 0; kk < KT; kk++) {
-        if (kk < kn) {
-            num[(k0 + kk) * T + t_out] = red[kk].a;
-            den[(k0 + kk) * T + t_out] = red[kk].b;
+            for (int d = 32; d >= 1; d >>= 1) {
+                const double o = __shfl_xor(st.c[c], d, 64);
+                st.c[c] = partial_is_max(method) ? fmax(st.c[c], o) : st.c[c] + o;
+            }
+        }
+        if (lane == 0) {
+            const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+            for (int c = 0; c < C; c++) {
+                if (rows_layout) out[t_out * (C * K) + c * K + k] = st.c[c];
+                else out[((int64_t)c * K + k) * T + t_out] = st.c[c];
+            }
         }
     }
 }
 
-// row layout of the partial sums (sparse multi-GPU exchange): rows[t_out][0..K) = num, [K..2K) = den
-template <typename SRC>
-__global__ void __launch_bounds__(AP_BLOCK)
-k_apply_partial_mean_rows(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-                          const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T,
-                          int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ rows) {
-    const int64_t t = (int64_t)blockIdx.x * AP_BLOCK + threadIdx.x;
-    if (t >= T) return;
-    const int64_t k0 = (int64_t)blockIdx.y * KT;
-    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
-    const int s = indptr[t], e = indptr[t + 1];
-    Red<XR_MEAN> red[KT];
-    const SRC *src = source + k0 * S;
-    for (int j = s; j < e; j++) {
-        const int64_t col = indices[j];
-        const double w = data[j];
-#pragma unroll
-        for (int kk = 0; kk < KT; kk++)
-            if (kk < kn) red[kk].add(ld_src(src, (int64_t)kk * S + col), w, 0.0);
-    }
-    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
-    double *row = rows + t_out * 2 * K;
-#pragma unroll
-    for (int kk = 0; kk < KT; kk++) {
-        if (kk < kn) {
-            row[k0 + kk] = red[kk].a;
-            row[K + k0 + kk] = red[kk].b;
-        }
-    }
-}
-
-__global__ void k_accumulate_rows(double *__restrict__ acc, const int64_t *__restrict__ ids,
-                                  const double *__restrict__ rows, int64_t n, int64_t width) {
+__global__ void k_partial_identity(int method, double *__restrict__ planes, int64_t per_component) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n * width) return;
-    const int64_t r = i / width, c = i - r * width;
-    acc[ids[r] * width + c] += rows[i];
+    const int C = partial_components(method);
+    if (i >= per_component * C) return;
+    const PartialState st = partial_identity(method);
+    planes[i] = st.c[i / per_component];
 }
 
-// owner side of the sparse exchange in one launch: target t sums the received rows order[indptr[t] .. indptr[t+1])
-// (sender by sender, i.e. in a fixed order) and finalises the mean
-__global__ void k_reduce_mean_rows(const double *__restrict__ rows, const int64_t *__restrict__ indptr,
-                                   const int64_t *__restrict__ order, int64_t n_targets, int64_t K,
+__global__ void k_finalize_partial(int method, const double *__restrict__ planes, int64_t n /* K * T */,
                                    double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    PartialState st;
+    const int C = partial_components(method);
+    for (int c = 0; c < C; c++) st.c[c] = planes[(int64_t)c * n + i];
+    out[i] = partial_finalize(method, st);
+}
+
+__global__ void k_reduce_partial_rows(int method, const double *__restrict__ rows, const int64_t *__restrict__ indptr,
+                                      const int64_t *__restrict__ order, int64_t n_targets, int64_t K,
+                                      double *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_targets * K) return;
     const int64_t k = i / n_targets, t = i - k * n_targets;
-    double num = 0.0, den = 0.0;
-    for (int64_t j = indptr[t]; j < indptr[t + 1]; j++) {
-        const double *row = rows + order[j] * 2 * K;
-        num += row[k];
-        den += row[K + k];
-    }
-    out[i] = den == 0 ? NAN : num / den;
-}
-
-__global__ void k_finalize_mean_rows(const double *__restrict__ acc, int64_t n_rows, int64_t K,
-                                     double *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_rows * K) return;
-    const int64_t k = i / n_rows, t = i - k * n_rows;
-    const double num = acc[t * 2 * K + k], den = acc[t * 2 * K + K + k];
-    out[i] = den == 0 ? NAN : num / den;
-}
-
-__global__ void k_finalize_mean(const double *__restrict__ num, const double *__restrict__ den, int64_t n,
-                                double *__restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = den[i] == 0 ? NAN : num[i] / den[i];
+    const int C = partial_components(method);
+    PartialState st = partial_identity(method);
+    for (int64_t j = indptr[t]; j < indptr[t + 1]; j++) partial_combine(method, st, rows + order[j] * (C * K) + k, K, C);
+    out[i] = partial_finalize(method, st);
 }
 
 template <typename SRC>
@@ -2135,93 +2185,78 @@ int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,
     XR_API_END
 }
 
-int xr_apply_partial_mean_dev(const xr_csr *csr, const void *source_dev, int source_dtype, int64_t K,
-                              double *numden_dev) {
+int xr_partial_components(int method) { return partial_components(method); }
+int xr_partial_combine_is_max(int method) { return partial_is_max(method) ? 1 : 0; }
+
+int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, int source_dtype, int64_t K,
+                         double *out_dev, int rows_layout) {
     XR_API_BEGIN
-    XR_REQUIRE(csr && numden_dev, XR_ERR_INVALID, "xr_apply_partial_mean_dev: NULL argument");
-    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
-               source_dtype);
+    XR_REQUIRE(csr && out_dev, XR_ERR_INVALID, "xr_apply_partial_dev: NULL argument");
+    XR_REQUIRE(partial_components(method) > 0, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", source_dtype);
+    XR_REQUIRE(K >= 0 && K < 65536, XR_ERR_LIMIT, "xr_apply_partial_dev: K out of range (tile the variables)");
     if (csr->n > 0 && K > 0) {
-        dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
-        double *num = numden_dev, *den = numden_dev + K * csr->n;
+        XR_REQUIRE(source_dev || csr->m == 0, XR_ERR_INVALID, "xr_apply_partial_dev: NULL source");
+        dim3 grid(div_up(csr->n, 256), (unsigned)K);
         if (source_dtype == XR_F64)
-            XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<double>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+            XR_LAUNCH("apply_partial", k_apply_partial<double>, grid, dim3(256), 0, method, csr->indptr.get(),
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
-                      static_cast<const double *>(source_dev), K, num, den);
+                      static_cast<const double *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
         else
-            XR_LAUNCH("apply_partial_mean", k_apply_partial_mean<float>, grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+            XR_LAUNCH("apply_partial", k_apply_partial<float>, grid, dim3(256), 0, method, csr->indptr.get(),
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
-                      static_cast<const float *>(source_dev), K, num, den);
+                      static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
+        if (csr->has_long) {
+            dim3 lgrid(64, (unsigned)K);
+            if (source_dtype == XR_F64)
+                XR_LAUNCH("apply_partial_long", k_apply_partial_long<double>, lgrid, dim3(256), 0, method, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                          csr->n, csr->m, static_cast<const double *>(source_dev), K, out_dev, rows_layout != 0);
+            else
+                XR_LAUNCH("apply_partial_long", k_apply_partial_long<float>, lgrid, dim3(256), 0, method, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                          csr->n, csr->m, static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0);
+        }
     }
     dev_call_done();
     XR_API_END
 }
 
-int xr_apply_partial_mean_rows_dev(const xr_csr *csr, const void *source_dev, int source_dtype, int64_t K,
-                                   double *rows_dev) {
+int xr_partial_fill_identity_dev(int method, double *planes_dev, int64_t K, int64_t T) {
     XR_API_BEGIN
-    XR_REQUIRE(csr && rows_dev, XR_ERR_INVALID, "xr_apply_partial_mean_rows_dev: NULL argument");
-    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d",
-               source_dtype);
-    if (csr->n > 0 && K > 0) {
-        dim3 grid(div_up(csr->n, AP_BLOCK), div_up(K, KT));
-        if (source_dtype == XR_F64)
-            XR_LAUNCH("apply_partial_mean_rows", k_apply_partial_mean_rows<double>, grid, dim3(AP_BLOCK), 0,
-                      csr->indptr.get(), csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
-                      static_cast<const double *>(source_dev), K, rows_dev);
-        else
-            XR_LAUNCH("apply_partial_mean_rows", k_apply_partial_mean_rows<float>, grid, dim3(AP_BLOCK), 0,
-                      csr->indptr.get(), csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
-                      static_cast<const float *>(source_dev), K, rows_dev);
+    XR_REQUIRE(partial_components(method) > 0, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
+    XR_REQUIRE(K >= 0 && T >= 0, XR_ERR_INVALID, "xr_partial_fill_identity_dev: negative size");
+    if (K * T > 0) {
+        XR_REQUIRE(planes_dev, XR_ERR_INVALID, "xr_partial_fill_identity_dev: NULL argument");
+        XR_LAUNCH("partial_identity", k_partial_identity, dim3(div_up(K * T * partial_components(method), 256)), dim3(256), 0,
+                  method, planes_dev, K * T);
     }
     dev_call_done();
     XR_API_END
 }
 
-int xr_accumulate_rows_dev(double *acc_dev, const int64_t *ids_dev, const double *rows_dev, int64_t n, int64_t width) {
+int xr_finalize_partial_dev(int method, const double *planes_dev, int64_t K, int64_t T, double *out_dev) {
     XR_API_BEGIN
-    XR_REQUIRE(n >= 0 && width >= 0, XR_ERR_INVALID, "xr_accumulate_rows_dev: negative size");
-    if (n > 0 && width > 0) {
-        XR_REQUIRE(acc_dev && ids_dev && rows_dev, XR_ERR_INVALID, "xr_accumulate_rows_dev: NULL argument");
-        XR_LAUNCH("accumulate_rows", k_accumulate_rows, dim3(div_up(n * width, 256)), dim3(256), 0, acc_dev, ids_dev,
-                  rows_dev, n, width);
-    }
-    dev_call_done();
-    XR_API_END
-}
-
-int xr_reduce_mean_rows_dev(const double *rows_dev, const int64_t *indptr_dev, const int64_t *order_dev, int64_t n_targets,
-                            int64_t K, double *out_dev) {
-    XR_API_BEGIN
-    XR_REQUIRE(n_targets >= 0 && K >= 0, XR_ERR_INVALID, "xr_reduce_mean_rows_dev: negative size");
-    if (n_targets > 0 && K > 0) {
-        XR_REQUIRE(indptr_dev && out_dev, XR_ERR_INVALID, "xr_reduce_mean_rows_dev: NULL argument");
-        XR_LAUNCH("reduce_mean_rows", k_reduce_mean_rows, dim3(div_up(n_targets * K, 256)), dim3(256), 0, rows_dev,
-                  indptr_dev, order_dev, n_targets, K, out_dev);
-    }
-    dev_call_done();
-    XR_API_END
-}
-
-int xr_finalize_mean_rows_dev(const double *acc_dev, int64_t n_rows, int64_t K, double *out_dev) {
-    XR_API_BEGIN
-    XR_REQUIRE(n_rows >= 0 && K >= 0, XR_ERR_INVALID, "xr_finalize_mean_rows_dev: negative size");
-    if (n_rows > 0 && K > 0) {
-        XR_REQUIRE(acc_dev && out_dev, XR_ERR_INVALID, "xr_finalize_mean_rows_dev: NULL argument");
-        XR_LAUNCH("finalize_mean_rows", k_finalize_mean_rows, dim3(div_up(n_rows * K, 256)), dim3(256), 0, acc_dev,
-                  n_rows, K, out_dev);
-    }
-    dev_call_done();
-    XR_API_END
-}
-
-int xr_finalize_mean_dev(const double *num_dev, const double *den_dev, int64_t count, double *out_dev) {
-    XR_API_BEGIN
-    XR_REQUIRE(count >= 0, XR_ERR_INVALID, "xr_finalize_mean_dev: negative count");
-    if (count > 0) {
-        XR_REQUIRE(num_dev && den_dev && out_dev, XR_ERR_INVALID, "xr_finalize_mean_dev: NULL argument");
-        XR_LAUNCH("finalize_mean", k_finalize_mean, dim3(div_up(count, 256)), dim3(256), 0, num_dev, den_dev, count,
+    XR_REQUIRE(partial_components(method) > 0, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
+    XR_REQUIRE(K >= 0 && T >= 0, XR_ERR_INVALID, "xr_finalize_partial_dev: negative size");
+    if (K * T > 0) {
+        XR_REQUIRE(planes_dev && out_dev, XR_ERR_INVALID, "xr_finalize_partial_dev: NULL argument");
+        XR_LAUNCH("finalize_partial", k_finalize_partial, dim3(div_up(K * T, 256)), dim3(256), 0, method, planes_dev, K * T,
                   out_dev);
+    }
+    dev_call_done();
+    XR_API_END
+}
+
+int xr_reduce_partial_rows_dev(int method, const double *rows_dev, const int64_t *indptr_dev, const int64_t *order_dev,
+                               int64_t n_targets, int64_t K, double *out_dev) {
+    XR_API_BEGIN
+    XR_REQUIRE(partial_components(method) > 0, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
+    XR_REQUIRE(n_targets >= 0 && K >= 0, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: negative size");
+    if (n_targets * K > 0) {
+        XR_REQUIRE(indptr_dev && out_dev, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: NULL argument");
+        XR_LAUNCH("reduce_partial_rows", k_reduce_partial_rows, dim3(div_up(n_targets * K, 256)), dim3(256), 0, method,
+                  rows_dev, indptr_dev, order_dev, n_targets, K, out_dev);
     }
     dev_call_done();
     XR_API_END

@@ -5,35 +5,169 @@ SOURCE faces partitioned over the ranks, target mesh replicated (SURVEY.md 8e, B
     rank r:  faces_r = {s : part(s) == r}                            # Morton blocks of equal work (or s mod N)
              targets_r = {t : bbox(t) overlaps bbox(faces_r)}         # only these can get weight from r
              W_r     = overlap(source[faces_r], target[targets_r])    # HIP, no communication
-             num_r, den_r = sum_j w v, sum_j w  (v not NaN)          # HIP, per (k, target in targets_r)
-    all:     reduce_scatter(sum) of [num ; den] over the target axis  # the ONE exchange step
-    rank r:  out[k, t] = num / den (NaN where den == 0)  for its slice of targets
+             state_r = partial reducer state per (k, target in targets_r) over r's columns     # HIP
+    all:     ONE collective over the target axis -- sum, or max for minimum / maximum
+    rank r:  out[k, t] = finalise(state)  for its slice of targets
 
-With spatially compact shards the per-rank work is ~(S + T) / N plus a boundary layer.  The
+Every reducer whose state decomposes over source shards is handled this way (xugrid/regrid/reduce.py:16-123, 206-222):
+``mean``, ``sum``, ``first_order_conservative`` / ``conductance`` (relative weights), ``harmonic_mean``,
+``geometric_mean`` as partial sums, ``minimum`` / ``maximum`` with a MAX collective on (-v | v, w) -- component table in
+include/xugrid_amd.h.  With spatially compact shards the per-rank work is ~(S + T) / N plus a boundary layer.  The
 exchange step comes in two forms:
   "dense"   reduce_scatter_tensor over the whole target axis, as worded in the north star: every
-            rank contributes a [2, K, T] buffer (zeros where it has no weight) -- O(T) bytes per rank;
+            rank contributes a [C, K, T] buffer (the identity where it has no weight) -- O(T) bytes per rank;
   "sparse"  (default) the same reduction restricted to the entries that exist: each rank sends, to
-            the owner of every target it touched, that target's (num, den) -- an
-            all_to_all_single of ~T/N rows per rank; the owner adds the contributions sender by
-            sender (deterministic order).  Index lists are exchanged once at set-up.
+            the owner of every target it touched, that target's state -- an all_to_all_single of ~T/N rows per
+            rank; the owner combines the contributions sender by sender (deterministic order).  Index lists are
+            exchanged once at set-up.
+Many stacked variables are exchanged in TILES of ``k_tile`` variables: the collective of tile i (async) overlaps the
+partial-state kernel of tile i + 1, and the exchange buffer is C x k_tile x T instead of C x K x T (K = 256, T = 1M:
+0.5 GB per tile of 32 instead of 4 GB).
 
-Only sum-decomposable reducers shard over sources; ``mean`` is implemented that way (it is the reducer
-of OverlapRegridder's default and of BarycentricInterpolator).  Every other reducer -- ``mode``, percentiles,
-``max_overlap``, ``minimum`` ... -- needs the whole row of a target: ``TargetPartitionedRegridder`` gives each
+``mode``, percentiles and ``max_overlap`` need the whole row of a target: ``TargetPartitionedRegridder`` gives each
 rank a contiguous slice of the TARGETS plus the sources near them (the same occupancy-raster filter, the other
 way round), so a rank holds complete rows, applies any reducer locally, bit-identically to one GPU, and the only
 communication is the optional gather of the output slices (SURVEY.md 8e "not shardable over sources").
 
+Set-up (centroids, Morton partition, work estimate, near-shard filter) is torch tensor code on the rank's device
+(``backend.device``): on a GPU the full meshes are uploaded once and no O(S + T) numpy pass runs on the host.
+
 The compute backend is a parameter: the product uses ``HipBackend`` (C ABI, device pointers of
 torch tensors); the world_size-2 gloo tests on CPU inject an oracle-backed backend with the same
-three methods.  There is no CPU fallback in the product path.
+methods.  There is no CPU fallback in the product path.
 """
 import os
 
 import numpy as np
 
+SHARD_METHODS = ("mean", "sum", "first_order_conservative", "conductance", "harmonic_mean", "geometric_mean",
+                 "minimum", "maximum")
 
+
+# ---------------------------------------------------------------------------------------------------------------------
+# set-up on tensors (any device)
+# ---------------------------------------------------------------------------------------------------------------------
+def _t(x, device=None):
+    import torch
+
+    return torch.as_tensor(np.ascontiguousarray(x) if isinstance(x, np.ndarray) else x, device=device)
+
+
+def _centroids_t(xy, faces):
+    """mean of the valid nodes of every face: (F, 2)"""
+    valid = faces >= 0
+    safe = faces.clamp(min=0)
+    pts = xy[safe] * valid[..., None]
+    return pts.sum(dim=1) / valid.sum(dim=1, keepdim=True).clamp(min=1)
+
+
+def _face_boxes_t(xy, faces):
+    import torch
+
+    valid = faces >= 0
+    safe = faces.clamp(min=0)
+    px, py = xy[safe, 0], xy[safe, 1]
+    inf = torch.tensor(float("inf"), dtype=xy.dtype, device=xy.device)
+    return (torch.where(valid, px, inf).amin(dim=1), torch.where(valid, px, -inf).amax(dim=1),
+            torch.where(valid, py, inf).amin(dim=1), torch.where(valid, py, -inf).amax(dim=1))
+
+
+def _spread16(v):
+    v = (v | (v << 8)) & 0x00FF00FF
+    v = (v | (v << 4)) & 0x0F0F0F0F
+    v = (v | (v << 2)) & 0x33333333
+    v = (v | (v << 1)) & 0x55555555
+    return v
+
+
+def _partition_faces_t(centroids, world_size, mode="morton", weights=None):
+    import torch
+
+    n = centroids.shape[0]
+    dev = centroids.device
+    if mode == "hash":
+        return (torch.arange(n, device=dev) % world_size).to(torch.int32)
+    if mode != "morton":
+        raise ValueError(f"unknown partition mode {mode!r}")
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int32, device=dev)
+    lo = centroids.amin(dim=0)
+    span = (centroids.amax(dim=0) - lo).clamp(min=1e-300)
+    q = ((centroids - lo) / span * 65536.0).to(torch.int64).clamp(max=65535)
+    code = _spread16(q[:, 0]) | (_spread16(q[:, 1]) << 1)
+    order = torch.argsort(code, stable=True)
+    owner = torch.empty(n, dtype=torch.int32, device=dev)
+    if weights is None:
+        owner[order] = (torch.arange(n, device=dev) * world_size // max(n, 1)).to(torch.int32)
+    else:
+        w = weights.to(torch.float64)[order]
+        before = torch.cumsum(w, 0) - w  # weight in front of each face along the curve
+        total = float(w.sum())
+        cut = before * (world_size / total) if total > 0 else torch.arange(n, device=dev) * (world_size / max(n, 1))
+        owner[order] = cut.to(torch.int64).clamp(max=world_size - 1).to(torch.int32)
+    return owner
+
+
+def _work_weights_t(source_centroids, target_centroids, target_cost=4.0, n_grid=None):
+    import torch
+
+    if n_grid is None:
+        n_grid = int(min(256, max(4, np.sqrt(source_centroids.shape[0] / 16.0))))
+    lo = torch.minimum(source_centroids.amin(dim=0), target_centroids.amin(dim=0))
+    hi = torch.maximum(source_centroids.amax(dim=0), target_centroids.amax(dim=0))
+    f = n_grid / (hi - lo).clamp(min=1e-300)
+
+    def cell(c):
+        ij = torch.floor((c - lo) * f).to(torch.int64).clamp(0, n_grid - 1)
+        return ij[:, 1] * n_grid + ij[:, 0]
+
+    cs = cell(source_centroids)
+    n_src = torch.bincount(cs, minlength=n_grid * n_grid)
+    n_tgt = torch.bincount(cell(target_centroids), minlength=n_grid * n_grid)
+    return 1.0 + target_cost * n_tgt[cs].to(torch.float64) / n_src[cs].clamp(min=1).to(torch.float64)
+
+
+def _targets_near_shard_t(src_boxes, tgt_boxes, n_grid=128):
+    """
+    ids of the faces of the second set that can overlap the first set (a shard): a coarse occupancy raster of the
+    shard's face bboxes (2-D difference array + cumulative sums), queried with the other faces' bboxes through an
+    integral image.  Conservative (cell granularity), and -- unlike one bbox per shard -- not spoiled by a few long
+    hull slivers.  Boxes: tuples (xmin, xmax, ymin, ymax) of 1-D tensors.
+    """
+    import torch
+
+    sx0, sx1, sy0, sy1 = src_boxes
+    tx0, tx1, ty0, ty1 = tgt_boxes
+    dev = tx0.device
+    if sx0.numel() == 0 or tx0.numel() == 0:
+        return torch.zeros(0, dtype=torch.int64, device=dev)
+    x_lo, y_lo = torch.minimum(sx0.min(), tx0.min()), torch.minimum(sy0.min(), ty0.min())
+    x_hi, y_hi = torch.maximum(sx1.max(), tx1.max()), torch.maximum(sy1.max(), ty1.max())
+    fx = n_grid / (x_hi - x_lo).clamp(min=1e-300)
+    fy = n_grid / (y_hi - y_lo).clamp(min=1e-300)
+
+    def cells(v, lo, f):
+        return torch.floor((v - lo) * f).to(torch.int64).clamp(0, n_grid - 1)
+
+    cx0, cx1 = cells(sx0, x_lo, fx), cells(sx1, x_lo, fx)
+    cy0, cy1 = cells(sy0, y_lo, fy), cells(sy1, y_lo, fy)
+    stride = n_grid + 1
+    diff = torch.zeros(stride * stride, dtype=torch.int64, device=dev)
+    one = torch.ones_like(cx0)
+    diff.index_put_((cy0 * stride + cx0,), one, accumulate=True)
+    diff.index_put_((cy0 * stride + cx1 + 1,), -one, accumulate=True)
+    diff.index_put_(((cy1 + 1) * stride + cx0,), -one, accumulate=True)
+    diff.index_put_(((cy1 + 1) * stride + cx1 + 1,), one, accumulate=True)
+    occupied = (diff.view(stride, stride).cumsum(0).cumsum(1)[:n_grid, :n_grid] > 0).to(torch.int64)
+    integral = torch.zeros((stride, stride), dtype=torch.int64, device=dev)
+    integral[1:, 1:] = occupied.cumsum(0).cumsum(1)
+    qx0, qx1 = cells(tx0, x_lo, fx), cells(tx1, x_lo, fx) + 1
+    qy0, qy1 = cells(ty0, y_lo, fy), cells(ty1, y_lo, fy) + 1
+    hits = integral[qy1, qx1] - integral[qy0, qx1] - integral[qy1, qx0] + integral[qy0, qx0]
+    return torch.nonzero(hits > 0)[:, 0]
+
+
+# numpy-facing wrappers (tests, small problems)
 def partition_faces(centroids, world_size, mode="morton", weights=None):
     """
     Owner rank of every source face.
@@ -46,34 +180,8 @@ def partition_faces(centroids, world_size, mode="morton", weights=None):
     target with ~1/world of its pairs.
     (``ShardedOverlapRegridder(partition="balanced")`` = "morton" with ``work_weights``.)
     """
-    n = centroids.shape[0]
-    if mode == "hash":
-        return (np.arange(n) % world_size).astype(np.int32)
-    if mode != "morton":
-        raise ValueError(f"unknown partition mode {mode!r}")
-    lo = centroids.min(axis=0)
-    span = np.maximum(centroids.max(axis=0) - lo, 1e-300)
-    q = np.minimum(((centroids - lo) / span * 65536.0).astype(np.uint64), 65535)
-
-    def spread(v):
-        v = (v | (v << 8)) & np.uint64(0x00FF00FF)
-        v = (v | (v << 4)) & np.uint64(0x0F0F0F0F)
-        v = (v | (v << 2)) & np.uint64(0x33333333)
-        v = (v | (v << 1)) & np.uint64(0x55555555)
-        return v
-
-    code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
-    order = np.argsort(code, kind="stable")
-    owner = np.empty(n, dtype=np.int32)
-    if weights is None:
-        owner[order] = (np.arange(n) * world_size // max(n, 1)).astype(np.int32)
-    else:
-        w = np.asarray(weights, dtype=np.float64)[order]
-        before = np.cumsum(w) - w  # weight in front of each face along the curve
-        total = float(w.sum())
-        cut = before * (world_size / total) if total > 0 else np.arange(n) * (world_size / max(n, 1))
-        owner[order] = np.minimum(cut.astype(np.int64), world_size - 1).astype(np.int32)
-    return owner
+    w = None if weights is None else _t(np.asarray(weights, dtype=np.float64))
+    return _partition_faces_t(_t(np.asarray(centroids, dtype=np.float64)), world_size, mode, w).numpy()
 
 
 def work_weights(source_centroids, target_centroids, target_cost=4.0, n_grid=None):
@@ -84,22 +192,19 @@ def work_weights(source_centroids, target_centroids, target_cost=4.0, n_grid=Non
     Targets are attributed through a coarse raster (~16 sources per cell, at most 256 x 256 cells): the targets of
     a raster cell are shared by its sources; targets in cells without sources cost nothing (they overlap nothing).
     """
-    if n_grid is None:
-        n_grid = int(min(256, max(4, np.sqrt(source_centroids.shape[0] / 16.0))))
-    lo = np.minimum(source_centroids.min(axis=0), target_centroids.min(axis=0))
-    hi = np.maximum(source_centroids.max(axis=0), target_centroids.max(axis=0))
-    f = n_grid / np.maximum(hi - lo, 1e-300)
-
-    def cell(c):
-        ij = np.clip(np.floor((c - lo) * f).astype(np.int64), 0, n_grid - 1)
-        return ij[:, 1] * n_grid + ij[:, 0]
-
-    cs = cell(source_centroids)
-    n_src = np.bincount(cs, minlength=n_grid * n_grid)
-    n_tgt = np.bincount(cell(target_centroids), minlength=n_grid * n_grid)
-    return 1.0 + target_cost * n_tgt[cs] / np.maximum(n_src[cs], 1)
+    return _work_weights_t(_t(np.asarray(source_centroids, dtype=np.float64)),
+                           _t(np.asarray(target_centroids, dtype=np.float64)), target_cost, n_grid).numpy()
 
 
+def _targets_near_shard(src_xy, src_faces, tgt_xy, tgt_faces, n_grid=128):
+    sb = _face_boxes_t(_t(np.asarray(src_xy, dtype=np.float64)), _t(np.asarray(src_faces, dtype=np.int64)))
+    tb = _face_boxes_t(_t(np.asarray(tgt_xy, dtype=np.float64)), _t(np.asarray(tgt_faces, dtype=np.int64)))
+    return _targets_near_shard_t(sb, tb, n_grid).numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# compute backend
+# ---------------------------------------------------------------------------------------------------------------------
 class HipBackend:
     """Device compute through the C ABI; tensors are torch CUDA(HIP) tensors of this rank's GPU."""
 
@@ -140,17 +245,18 @@ class HipBackend:
         if not self.shared_stream:
             self.torch.cuda.current_stream().synchronize()
 
-    def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces):
+    def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces, relative=False):
         E = self.engine
         self._src_mesh = E.DeviceMesh(src_xy, src_faces)
         self._tgt_mesh = E.DeviceMesh(tgt_xy, tgt_faces)
-        return self._src_mesh.overlap(self._tgt_mesh, relative=False)
+        self._relative = bool(relative)
+        return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
 
     def rebuild_weights(self):
         """Benchmark hook: redo prepare + index + overlap from the HBM-resident raw meshes."""
         self._src_mesh.invalidate()
         self._tgt_mesh.invalidate()
-        return self._src_mesh.overlap(self._tgt_mesh, relative=False)
+        return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
 
     def download_weights(self, weights):
         """-> (data, indices, indptr, n, m) host arrays of this rank's shard of the weights."""
@@ -174,162 +280,128 @@ class HipBackend:
         self.engine.dev_sync()
         return out
 
-    def partial_mean(self, weights, source):
-        """source: (K, S_local) float64/float32 device tensor -> (2, K, T) float64 device tensor."""
+    # ---- shard-decomposable reducers: partial state, identity, finalise (include/xugrid_amd.h)
+    def n_components(self, method_id):
+        return self.engine.partial_components(method_id)
+
+    def combine_is_max(self, method_id):
+        return self.engine.partial_combine_is_max(method_id)
+
+    def partial(self, weights, source, method_id, rows_layout):
+        """(K, S_local) -> float64 planes (C, K, T_local) or rows (T_local, C * K)."""
         torch = self.torch
-        K = source.shape[0]
-        out = torch.empty((2, K, weights.n), dtype=torch.float64, device=self.device)
+        K, C = source.shape[0], self.n_components(method_id)
+        shape = (weights.n, C * K) if rows_layout else (C, K, weights.n)
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
         source, dtype = self._typed(source)
         self._handover()  # inputs produced on torch's stream are ready
-        weights.partial_mean_dev(source.data_ptr(), dtype, K, out.data_ptr())
+        weights.partial_dev(source.data_ptr(), dtype, K, out.data_ptr(), method_id, rows_layout)
         return out
 
-    def finalize_mean(self, num, den):
-        out = self.torch.empty_like(num)
+    def identity(self, method_id, K, n):
+        C = self.n_components(method_id)
+        out = self.torch.empty((C, K, n), dtype=self.torch.float64, device=self.device)
         self._handover()
-        self.engine.finalize_mean_dev(num.data_ptr(), den.data_ptr(), num.numel(), out.data_ptr())
+        self.engine.partial_fill_identity_dev(method_id, out.data_ptr(), K, n)
         return out
 
-    # ---- row layout used by the sparse exchange
-    def partial_mean_rows(self, weights, source):
-        """-> (T_local, 2K) float64: [num_0..num_K-1, den_0..den_K-1] per target."""
-        torch = self.torch
-        K = source.shape[0]
-        rows = torch.empty((weights.n, 2 * K), dtype=torch.float64, device=self.device)
-        source, dtype = self._typed(source)
+    def finalize(self, method_id, planes):
+        """combined planes (C, K, n) -> (K, n)"""
+        C, K, n = planes.shape
+        out = self.torch.empty((K, n), dtype=self.torch.float64, device=self.device)
+        planes = planes.contiguous()
         self._handover()
-        weights.partial_mean_rows_dev(source.data_ptr(), dtype, K, rows.data_ptr())
-        return rows
+        self.engine.finalize_partial_dev(method_id, planes.data_ptr(), K, n, out.data_ptr())
+        return out
 
-    def accumulate_rows(self, acc, ids, rows):
-        """acc[ids] += rows (ids distinct)."""
-        self._handover()
-        self.engine.accumulate_rows_dev(acc.data_ptr(), ids.data_ptr(), rows.data_ptr(), rows.shape[0], rows.shape[1])
-
-    def reduce_mean_rows(self, rows, indptr, order, n_targets, K):
-        """received rows (R, 2K) + per-target lists (indptr, order) -> finalised (K, n_targets) in one launch."""
+    def reduce_rows(self, method_id, rows, indptr, order, n_targets, K):
+        """received rows (R, C * K) + per-target lists (indptr, order) -> finalised (K, n_targets) in one launch."""
         out = self.torch.empty((K, n_targets), dtype=self.torch.float64, device=self.device)
         self._handover()
-        self.engine.reduce_mean_rows_dev(rows.data_ptr(), indptr.data_ptr(), order.data_ptr(), n_targets, K, out.data_ptr())
-        return out
-
-    def finalize_mean_rows(self, acc, K):
-        """(chunk, 2K) -> (K, chunk)."""
-        out = self.torch.empty((K, acc.shape[0]), dtype=self.torch.float64, device=self.device)
-        self._handover()
-        self.engine.finalize_mean_rows_dev(acc.data_ptr(), acc.shape[0], K, out.data_ptr())
+        self.engine.reduce_partial_rows_dev(method_id, rows.data_ptr(), indptr.data_ptr(), order.data_ptr(), n_targets, K,
+                                            out.data_ptr())
         return out
 
 
-def _face_boxes(xy, faces):
-    valid = faces >= 0
-    safe = np.where(valid, faces, 0)
-    px = np.where(valid, xy[safe, 0], np.nan)
-    py = np.where(valid, xy[safe, 1], np.nan)
-    return np.nanmin(px, axis=1), np.nanmax(px, axis=1), np.nanmin(py, axis=1), np.nanmax(py, axis=1)
-
-
-def _targets_near_shard(src_xy, src_faces, tgt_xy, tgt_faces, n_grid=128):
-    """
-    ids of the target faces that can overlap the given source shard: a coarse occupancy raster of
-    the shard's face bboxes (2-D difference array + cumulative sums), queried with the target face
-    bboxes through an integral image.  Conservative (cell granularity), and -- unlike one bbox per
-    shard -- not spoiled by a few long hull slivers.
-    """
-    n_t = tgt_faces.shape[0]
-    if src_faces.shape[0] == 0 or n_t == 0:
-        return np.zeros(0, dtype=np.int64)
-    sx0, sx1, sy0, sy1 = _face_boxes(src_xy, src_faces)
-    tx0, tx1, ty0, ty1 = _face_boxes(tgt_xy, tgt_faces)
-    x_lo, y_lo = min(sx0.min(), tx0.min()), min(sy0.min(), ty0.min())
-    x_hi, y_hi = max(sx1.max(), tx1.max()), max(sy1.max(), ty1.max())
-    fx = n_grid / max(x_hi - x_lo, 1e-300)
-    fy = n_grid / max(y_hi - y_lo, 1e-300)
-
-    def cells(v, lo, f):
-        return np.clip(np.floor((v - lo) * f).astype(np.int64), 0, n_grid - 1)
-
-    cx0, cx1 = cells(sx0, x_lo, fx), cells(sx1, x_lo, fx)
-    cy0, cy1 = cells(sy0, y_lo, fy), cells(sy1, y_lo, fy)
-    diff = np.zeros((n_grid + 1, n_grid + 1), dtype=np.int64)
-    np.add.at(diff, (cy0, cx0), 1)
-    np.add.at(diff, (cy0, cx1 + 1), -1)
-    np.add.at(diff, (cy1 + 1, cx0), -1)
-    np.add.at(diff, (cy1 + 1, cx1 + 1), 1)
-    occupied = (diff.cumsum(axis=0).cumsum(axis=1)[:n_grid, :n_grid] > 0).astype(np.int64)
-    integral = np.zeros((n_grid + 1, n_grid + 1), dtype=np.int64)
-    integral[1:, 1:] = occupied.cumsum(axis=0).cumsum(axis=1)
-    qx0, qx1 = cells(tx0, x_lo, fx), cells(tx1, x_lo, fx) + 1
-    qy0, qy1 = cells(ty0, y_lo, fy), cells(ty1, y_lo, fy) + 1
-    hits = integral[qy1, qx1] - integral[qy0, qx1] - integral[qy1, qx0] + integral[qy0, qx0]
-    return np.nonzero(hits > 0)[0]
-
-
-def _reduce_scatter_sum(dist, tensor, world_size, group=None):
-    """tensor: (world, ...) contiguous -> this rank's (...) slice of the element-wise sum."""
+def _combine(dist, tensor, world_size, is_max, group=None, async_op=False):
+    """tensor: (world, ...) contiguous -> (this rank's (...) slice of the element-wise sum / max, work, full buffer)."""
     import torch
 
+    op = dist.ReduceOp.MAX if is_max else dist.ReduceOp.SUM
     out = torch.empty_like(tensor[0])
     if dist.get_backend(group) == "nccl":
-        dist.reduce_scatter_tensor(out, tensor, op=dist.ReduceOp.SUM, group=group)
-    else:  # gloo (CPU tests) has no reduce_scatter: all_reduce, then keep the own slice
-        full = tensor.clone()
-        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
-        out.copy_(full[dist.get_rank(group)])
-    return out
+        work = dist.reduce_scatter_tensor(out, tensor, op=op, group=group, async_op=async_op)
+        return out, work, None
+    # gloo (CPU tests) has no reduce_scatter: all_reduce, then keep the own slice
+    full = tensor.clone()
+    work = dist.all_reduce(full, op=op, group=group, async_op=async_op)
+    return out, work, full
+
+
+def _method(method):
+    from .reduce import ABSOLUTE_OVERLAP_METHODS, RELATIVE_OVERLAP_METHODS, Method
+
+    if isinstance(method, Method):
+        return method, method.name in RELATIVE_OVERLAP_METHODS
+    table = {**ABSOLUTE_OVERLAP_METHODS, **RELATIVE_OVERLAP_METHODS}
+    if method not in table:
+        raise ValueError("Invalid regridding method. Available methods are: {}".format(table.keys()))
+    return table[method], method in RELATIVE_OVERLAP_METHODS
 
 
 class ShardedOverlapRegridder:
     """
-    ``OverlapRegridder(source, target, method="mean")`` with the source faces sharded over the
-    ranks of ``torch.distributed``.
+    ``OverlapRegridder(source, target, method)`` / ``RelativeOverlapRegridder`` with the source faces sharded over the
+    ranks of ``torch.distributed``, for the reducers of ``SHARD_METHODS``.
 
     source_xy/source_faces, target_xy/target_faces: the FULL meshes (every rank passes the same
     arrays; each keeps only its shard of the source faces).
     partition: "balanced" (default; Morton blocks of equal estimated work, ``work_weights``), "morton" (Morton
     blocks of equal source-face counts) or "hash" (face id mod world size).
+    k_tile: stacked variables exchanged per collective (tiles are pipelined).
     """
 
     def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="balanced", group=None,
-                 exchange="sparse"):
+                 exchange="sparse", method="mean", k_tile=32):
+        import torch
         import torch.distributed as dist
 
         if exchange not in ("sparse", "dense"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
+        self.method, self.relative = _method(method)
+        if self.method.name not in SHARD_METHODS:
+            raise ValueError(f"{self.method.name!r} needs whole rows: use TargetPartitionedRegridder "
+                             f"(source-sharded reducers: {', '.join(SHARD_METHODS)})")
         self.exchange = exchange
+        self.k_tile = max(1, int(k_tile))
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend
-        source_faces = np.asarray(source_faces)
-        self.n_source = source_faces.shape[0]
-        self.n_target = np.asarray(target_faces).shape[0]
-        valid = source_faces >= 0
-        cnt = valid.sum(axis=1)
-        xy = np.asarray(source_xy, dtype=np.float64)
-        safe = np.where(valid, source_faces, 0)
-        cen = (xy[safe] * valid[..., None]).sum(axis=1) / cnt[:, None]
+        dev = getattr(backend, "device", None)
+        source_xy = np.asarray(source_xy, dtype=np.float64)
+        target_xy = np.asarray(target_xy, dtype=np.float64)
+        source_faces, target_faces = np.asarray(source_faces), np.asarray(target_faces)
+        sxy, sfa = _t(source_xy, dev), _t(source_faces.astype(np.int64), dev)
+        txy, tfa = _t(target_xy, dev), _t(target_faces.astype(np.int64), dev)
+        self.n_source, self.n_target = int(sfa.shape[0]), int(tfa.shape[0])
+        cen = _centroids_t(sxy, sfa)
         if partition == "balanced":
             # Morton blocks of equal estimated WORK: where the target mesh is denser than the source mesh (or covers
             # only a part of it) equal source counts would leave some ranks with several times the targets of others
-            tfa = np.asarray(target_faces)
-            tv = tfa >= 0
-            tcen = (np.asarray(target_xy, dtype=np.float64)[np.where(tv, tfa, 0)] * tv[..., None]).sum(axis=1)
-            tcen /= tv.sum(axis=1)[:, None]
-            owner = partition_faces(cen, self.world, "morton", weights=work_weights(cen, tcen))
+            owner = _partition_faces_t(cen, self.world, "morton", weights=_work_weights_t(cen, _centroids_t(txy, tfa)))
         else:
-            owner = partition_faces(cen, self.world, partition)
-        self.local_faces = np.nonzero(owner == self.rank)[0]  # global ids of this rank's sources
-        # only targets whose bbox overlaps the bbox of this rank's source shard can receive weight
-        target_faces = np.asarray(target_faces)
-        txy = np.asarray(target_xy, dtype=np.float64)
-        self.local_targets = _targets_near_shard(xy, source_faces[self.local_faces], txy, target_faces)
+            owner = _partition_faces_t(cen, self.world, partition)
+        local_faces = torch.nonzero(owner == self.rank)[:, 0]  # global ids of this rank's sources
+        # only targets whose bbox overlaps the occupancy raster of this rank's source shard can receive weight
+        local_targets = _targets_near_shard_t(_face_boxes_t(sxy, sfa[local_faces]), _face_boxes_t(txy, tfa))
+        self.local_faces = local_faces.cpu().numpy()
+        self.local_targets = local_targets.cpu().numpy()
         # target rows are cut into `world` equal slices (padded): rank r finalises slice r
         self.t_chunk = -(-self.n_target // self.world)
-        self.weights = backend.build_weights(
-            xy, source_faces[self.local_faces], txy, target_faces[self.local_targets]
-        )
+        self.weights = backend.build_weights(source_xy, source_faces[self.local_faces], target_xy,
+                                             target_faces[self.local_targets], relative=self.relative)
         self._local_targets_dev = backend.to_device(self.local_targets.astype(np.int64))
         self._setup_sparse_exchange()
 
@@ -352,15 +424,13 @@ class ShardedOverlapRegridder:
         ids_out = torch.empty(sum(self._recv_counts), dtype=torch.int64, device=dev)
         dist.all_to_all_single(ids_out, ids_in, output_split_sizes=self._recv_counts,
                                input_split_sizes=self._send_counts, group=self.group)
-        self._recv_ids = ids_out  # positions inside my slice, grouped by sender
         # per owned target: the received rows that belong to it, in sender order (stable sort of the positions)
-        ids_host = ids_out.cpu()
-        order = torch.argsort(ids_host, stable=True)
-        counts = torch.bincount(ids_host, minlength=self.t_chunk)
-        indptr = torch.zeros(self.t_chunk + 1, dtype=torch.int64)
+        order = torch.argsort(ids_out, stable=True)
+        counts = torch.bincount(ids_out, minlength=self.t_chunk)
+        indptr = torch.zeros(self.t_chunk + 1, dtype=torch.int64, device=dev)
         indptr[1:] = torch.cumsum(counts, 0)
-        self._recv_order = order.to(dev)
-        self._recv_indptr = indptr.to(dev)
+        self._recv_order = order
+        self._recv_indptr = indptr
 
     def rebuild(self):
         self.weights = self.backend.rebuild_weights()
@@ -380,12 +450,12 @@ class ShardedOverlapRegridder:
             path, __regrid_data=data, __regrid_indices=indices, __regrid_indptr=indptr, __regrid_n=n, __regrid_m=m,
             __regrid_nnz=data.size, __shard_source_faces=self.local_faces, __shard_target_faces=self.local_targets,
             __shard_rank=self.rank, __shard_world=self.world, __n_source=self.n_source, __n_target=self.n_target,
-            __shard_exchange=self.exchange,
+            __shard_exchange=self.exchange, __shard_method=self.method.name,
         )
         return path
 
     @classmethod
-    def from_file(cls, prefix, backend, group=None, exchange=None):
+    def from_file(cls, prefix, backend, group=None, exchange=None, method=None, k_tile=32):
         """Counterpart of ``Regridder.from_weights`` for sharded weights: every rank reads its own file (written
         by a job of the SAME world size) and the exchange lists are set up again; no mesh, no weight construction."""
         import torch.distributed as dist
@@ -393,10 +463,15 @@ class ShardedOverlapRegridder:
         self = cls.__new__(cls)
         self.dist, self.group, self.backend = dist, group, backend
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.k_tile = max(1, int(k_tile))
         with np.load(cls.shard_path(prefix, self.rank, self.world)) as f:
             if int(f["__shard_world"]) != self.world or int(f["__shard_rank"]) != self.rank:
                 raise ValueError("sharded weights were written by a job of a different shape")
             self.exchange = exchange or str(f["__shard_exchange"])
+            stored = str(f["__shard_method"]) if "__shard_method" in f.files else "mean"
+            self.method, self.relative = _method(method or stored)
+            if self.relative != _method(stored)[1]:
+                raise ValueError("relative and absolute overlap weights are not interchangeable")
             self.n_source, self.n_target = int(f["__n_source"]), int(f["__n_target"])
             self.local_faces = f["__shard_source_faces"].astype(np.int64)
             self.local_targets = f["__shard_target_faces"].astype(np.int64)
@@ -406,6 +481,8 @@ class ShardedOverlapRegridder:
             self.weights = backend.upload_weights(f["__regrid_data"], f["__regrid_indices"], f["__regrid_indptr"], n, m)
         if self.exchange not in ("sparse", "dense"):
             raise ValueError(f"unknown exchange mode {self.exchange!r}")
+        if self.method.name not in SHARD_METHODS:
+            raise ValueError(f"{self.method.name!r} needs whole rows: use TargetPartitionedRegridder")
         self.t_chunk = -(-self.n_target // self.world)
         self._local_targets_dev = backend.to_device(self.local_targets)
         self._setup_sparse_exchange()
@@ -422,34 +499,58 @@ class ShardedOverlapRegridder:
             data = data.astype(np.float64)  # as the single-GPU path (engine._source_2d)
         return self.backend.to_device(data[:, self.local_faces])
 
+    # ---- the exchange step, one tile of variables
+    def _start_tile(self, src_tile):
+        import torch
+
+        be, mid, W = self.backend, self.method.method_id, self.world
+        kt = src_tile.shape[0]
+        if self.exchange == "sparse":
+            # one row of C * kt values per touched target, rows grouped by owner rank
+            send = be.partial(self.weights, src_tile, mid, True)  # (T_local, C * kt)
+            recv = torch.empty((sum(self._recv_counts), send.shape[1]), dtype=send.dtype, device=send.device)
+            work = self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
+                                               input_split_sizes=self._send_counts, group=self.group, async_op=True)
+            return ("sparse", work, recv, send, kt)
+        part = be.partial(self.weights, src_tile, mid, False)  # (C, kt, T_local)
+        t_pad = self.t_chunk * W
+        nd = be.identity(mid, kt, t_pad)  # dense exchange buffer, the combine step's identity elsewhere
+        nd.index_copy_(2, self._local_targets_dev, part)
+        C = nd.shape[0]
+        # (C, kt, world, chunk) -> (world, C, kt, chunk): slice w of the target axis goes to rank w
+        send = nd.view(C, kt, W, self.t_chunk).permute(2, 0, 1, 3).contiguous()
+        out, work, full = _combine(self.dist, send, W, be.combine_is_max(mid), self.group, async_op=True)
+        return ("dense", work, out, (full, send), kt)
+
+    def _finish_tile(self, pending):
+        kind, work, buf, aux, kt = pending
+        if work is not None:
+            work.wait()
+        be, mid = self.backend, self.method.method_id
+        if kind == "sparse":
+            return be.reduce_rows(mid, buf, self._recv_indptr, self._recv_order, self.t_chunk, kt)
+        if aux[0] is not None:  # gloo: all_reduce of the whole buffer, own slice
+            buf = aux[0][self.dist.get_rank(self.group)]
+        return be.finalize(mid, buf)  # (C, kt, chunk) -> (kt, chunk)
+
     def regrid_local(self, local_source):
-        """local (K, S_local) device tensor -> this rank's (K, t_chunk) slice of the result."""
+        """local (K, S_local) device tensor -> this rank's (K, t_chunk) slice of the result.  The variables go
+        through the exchange in tiles of ``k_tile``: the collective of a tile overlaps the kernel of the next."""
         import torch
 
         K = local_source.shape[0]
-        if self.exchange == "sparse":
-            # one row of 2K values per touched target, rows grouped by owner rank
-            send = self.backend.partial_mean_rows(self.weights, local_source)  # (T_local, 2K)
-            recv = torch.empty((sum(self._recv_counts), 2 * K), dtype=send.dtype, device=send.device)
-            self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
-                                        input_split_sizes=self._send_counts, group=self.group)
-            if hasattr(self.backend, "reduce_mean_rows"):
-                return self.backend.reduce_mean_rows(recv, self._recv_indptr, self._recv_order, self.t_chunk, K)
-            acc = torch.zeros((self.t_chunk, 2 * K), dtype=send.dtype, device=send.device)
-            start = 0
-            for cnt in self._recv_counts:  # sender by sender: ids are unique within a sender
-                if cnt:
-                    self.backend.accumulate_rows(acc, self._recv_ids[start:start + cnt], recv[start:start + cnt])
-                start += cnt
-            return self.backend.finalize_mean_rows(acc, K)
-        part = self.backend.partial_mean(self.weights, local_source)  # (2, K, T_local)
-        t_pad = self.t_chunk * self.world
-        nd = torch.zeros((2, K, t_pad), dtype=part.dtype, device=part.device)
-        nd.index_copy_(2, self._local_targets_dev, part)  # dense exchange buffer, zeros elsewhere
-        # (2, K, world, chunk) -> (world, 2, K, chunk): slice w of the target axis goes to rank w
-        send = nd.view(2, K, self.world, self.t_chunk).permute(2, 0, 1, 3).contiguous()
-        mine = _reduce_scatter_sum(self.dist, send, self.world, self.group)  # (2, K, chunk)
-        return self.backend.finalize_mean(mine[0].contiguous(), mine[1].contiguous())
+        if K <= self.k_tile:
+            return self._finish_tile(self._start_tile(local_source))
+        out = torch.empty((K, self.t_chunk), dtype=torch.float64, device=local_source.device)
+        pending, k_prev = None, 0
+        for k0 in range(0, K, self.k_tile):
+            k1 = min(k0 + self.k_tile, K)
+            nxt = self._start_tile(local_source[k0:k1])
+            if pending is not None:
+                out[k_prev:k0] = self._finish_tile(pending)
+            pending, k_prev = nxt, k0
+        out[k_prev:K] = self._finish_tile(pending)
+        return out
 
     def regrid(self, data, gather=True):
         """(K, S) or (S,) global source data -> (K, T) float64 on every rank (gather=True)."""
@@ -476,20 +577,13 @@ class TargetPartitionedRegridder:
     def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, method="mean", group=None):
         import torch.distributed as dist
 
-        from .reduce import ABSOLUTE_OVERLAP_METHODS, RELATIVE_OVERLAP_METHODS, Method
-
-        if isinstance(method, Method):
-            self.method = method
-        else:
-            table = {**ABSOLUTE_OVERLAP_METHODS, **RELATIVE_OVERLAP_METHODS}
-            if method not in table:
-                raise ValueError("Invalid regridding method. Available methods are: {}".format(table.keys()))
-            self.method = table[method]
+        self.method, self.relative = _method(method)
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend
+        dev = getattr(backend, "device", None)
         source_faces = np.asarray(source_faces)
         target_faces = np.asarray(target_faces)
         sxy = np.asarray(source_xy, dtype=np.float64)
@@ -500,8 +594,11 @@ class TargetPartitionedRegridder:
         hi = min(lo + self.t_chunk, self.n_target)
         self.local_targets = np.arange(lo, hi)
         # sources that can overlap the owned targets (conservative filter; complete rows guaranteed)
-        self.local_faces = _targets_near_shard(txy, target_faces[lo:hi], sxy, source_faces)
-        self.weights = backend.build_weights(sxy, source_faces[self.local_faces], txy, target_faces[lo:hi])
+        near = _targets_near_shard_t(_face_boxes_t(_t(txy, dev), _t(target_faces[lo:hi].astype(np.int64), dev)),
+                                     _face_boxes_t(_t(sxy, dev), _t(source_faces.astype(np.int64), dev)))
+        self.local_faces = near.cpu().numpy()
+        self.weights = backend.build_weights(sxy, source_faces[self.local_faces], txy, target_faces[lo:hi],
+                                             relative=self.relative)
 
     def local_source(self, data):
         data = np.asarray(data)

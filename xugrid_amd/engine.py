@@ -512,17 +512,12 @@ class DeviceCSR:
             )
         )
 
-    def partial_mean_rows_dev(self, source_ptr, dtype, K, rows_ptr):
+    def partial_dev(self, source_ptr, dtype, K, out_ptr, method_id, rows_layout):
+        """partial reducer state over this matrix' columns (multi-GPU split): planes [C, K, n] or rows [n, C * K]"""
         check(
-            _lib.load().xr_apply_partial_mean_rows_dev(
-                self._h, ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(rows_ptr)
-            )
-        )
-
-    def partial_mean_dev(self, source_ptr, dtype, K, numden_ptr):
-        check(
-            _lib.load().xr_apply_partial_mean_dev(
-                self._h, ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(numden_ptr)
+            _lib.load().xr_apply_partial_dev(
+                self._h, int(method_id), ctypes.c_void_p(source_ptr), int(dtype), int(K), ctypes.c_void_p(out_ptr),
+                1 if rows_layout else 0,
             )
         )
 
@@ -585,33 +580,28 @@ class DeviceOuter:
         )
 
 
-def accumulate_rows_dev(acc_ptr, ids_ptr, rows_ptr, n, width):
-    check(
-        _lib.load().xr_accumulate_rows_dev(
-            ctypes.c_void_p(acc_ptr), ctypes.c_void_p(ids_ptr), ctypes.c_void_p(rows_ptr), int(n), int(width)
-        )
-    )
+def partial_components(method_id):
+    """number of partial-state components of a shard-decomposable reducer (0: the reducer needs whole rows)"""
+    return int(_lib.load().xr_partial_components(int(method_id)))
 
 
-def reduce_mean_rows_dev(rows_ptr, indptr_ptr, order_ptr, n_targets, K, out_ptr):
-    check(
-        _lib.load().xr_reduce_mean_rows_dev(
-            ctypes.c_void_p(rows_ptr), ctypes.c_void_p(indptr_ptr), ctypes.c_void_p(order_ptr), int(n_targets), int(K),
-            ctypes.c_void_p(out_ptr),
-        )
-    )
+def partial_combine_is_max(method_id):
+    return bool(_lib.load().xr_partial_combine_is_max(int(method_id)))
 
 
-def finalize_mean_rows_dev(acc_ptr, n_rows, K, out_ptr):
-    check(_lib.load().xr_finalize_mean_rows_dev(ctypes.c_void_p(acc_ptr), int(n_rows), int(K), ctypes.c_void_p(out_ptr)))
+def partial_fill_identity_dev(method_id, planes_ptr, K, n):
+    check(_lib.load().xr_partial_fill_identity_dev(int(method_id), ctypes.c_void_p(planes_ptr), int(K), int(n)))
 
 
-def finalize_mean_dev(num_ptr, den_ptr, count, out_ptr):
-    check(
-        _lib.load().xr_finalize_mean_dev(
-            ctypes.c_void_p(num_ptr), ctypes.c_void_p(den_ptr), int(count), ctypes.c_void_p(out_ptr)
-        )
-    )
+def finalize_partial_dev(method_id, planes_ptr, K, n, out_ptr):
+    check(_lib.load().xr_finalize_partial_dev(int(method_id), ctypes.c_void_p(planes_ptr), int(K), int(n),
+                                              ctypes.c_void_p(out_ptr)))
+
+
+def reduce_partial_rows_dev(method_id, rows_ptr, indptr_ptr, order_ptr, n_targets, K, out_ptr):
+    check(_lib.load().xr_reduce_partial_rows_dev(int(method_id), ctypes.c_void_p(rows_ptr), ctypes.c_void_p(indptr_ptr),
+                                                 ctypes.c_void_p(order_ptr), int(n_targets), int(K),
+                                                 ctypes.c_void_p(out_ptr)))
 
 
 def apply_coo(row, col, n_target, source):

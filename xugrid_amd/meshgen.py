@@ -74,6 +74,19 @@ def triangle_mesh(n_points, seed, rotate_deg=0.0, scale=1.0, delaunay=True):
     return np.ascontiguousarray(points), np.ascontiguousarray(faces)
 
 
+def tiled_mesh(node_xy, faces, n_tiles):
+    """n_tiles copies of a mesh side by side (tile t shifted by (t mod c, t div c) * 1.25 with c = ceil(sqrt(n_tiles))):
+    the weak-scaling workload of the multi-GPU benchmark -- every tile is the single-GPU benchmark mesh, hull slivers
+    included, and one qhull run serves any number of GPUs."""
+    n_tiles = int(n_tiles)
+    if n_tiles <= 1:
+        return node_xy, faces
+    c = int(math.ceil(math.sqrt(n_tiles)))
+    xy = np.concatenate([node_xy + 1.25 * np.array([t % c, t // c], dtype=np.float64) for t in range(n_tiles)])
+    f = np.concatenate([faces + t * node_xy.shape[0] for t in range(n_tiles)])
+    return np.ascontiguousarray(xy), np.ascontiguousarray(f)
+
+
 def quad_mesh(x_edges, y_edges):
     """Rectilinear quads: face id = row-major (y, x); CCW for ascending edges."""
     xe = np.asarray(x_edges, dtype=np.float64)
