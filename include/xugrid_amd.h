@@ -183,10 +183,14 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
                        int64_t n, double tolerance, const int64_t *vertex_face,
                        const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
 /* the same with vertex_face given only for the vertices >= n_identity (vertex v < n_identity, a face centroid,
- * belongs to source face v): spares the host an O(n) array and its upload */
+ * belongs to source face v): spares the host an O(n) array and its upload.
+ * reference_order: the weight of slot j of a cell is paired with vertex j of the cell in the TREE's own
+ * (counter-clockwise-normalised) vertex order (0, default) or in the CALLER's order as the reference does
+ * (unstructured.py:175,193; 1).  The two differ only for cells the tree stores reversed (clockwise or concave exterior
+ * cells that start at a reflex corner); with 1 the reference's pairing is reproduced for those too. */
 int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
                             double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
-                            const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
+                            const int64_t *node_to_node_map, int64_t n_extra, int reference_order, xr_csr **out);
 
 /* ---- Voronoi pre-step of BarycentricInterpolator (xugrid/ugrid/voronoi.py:330-458 as called from
  * xugrid/regrid/unstructured.py:151-165: add_exterior, add_vertices, skip_concave) ---------------------

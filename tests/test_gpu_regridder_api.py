@@ -527,3 +527,58 @@ def test_replace_interpolated_weights_device_golden(hip, golden, tag):
     hip.engine.replace_interpolated_weights(g[f"{tag}_vertices"], g[f"{tag}_faces"], g[f"{tag}_face_index"], w,
                                             g[f"{tag}_node_to_node_map"], int(g[f"{tag}_threshold"]))
     assert np.array_equal(w, g[f"{tag}_weights_out"])
+
+
+def _reversed_cells(voronoi_mesh):
+    """Voronoi cells the tree stores in another vertex order than the caller's (download = caller's order)."""
+    _, faces = voronoi_mesh.download()
+    ccw = voronoi_mesh.faces_ccw()
+    k = min(faces.shape[1], ccw.shape[1])
+    return int((faces[:, :k] != ccw[:, :k]).any(axis=1).sum())
+
+
+@pytest.mark.parametrize("case", ["g6c", "delaunay_100k", "clockwise_source"])
+def test_barycentric_reference_order_blast_radius(hip, golden, case):
+    """the weight slots of a Voronoi cell are paired with the tree's counter-clockwise vertex
+    order by default and with the caller's order under reference_order=True (the reference's pairing,
+    unstructured.py:175,193).  The two can only differ for cells the tree stores reversed.  MEASURED here (printed; the
+    numbers are quoted in DESIGN.md section 7): how many cells that is -- concave exterior cells only, a fraction of
+    the boundary -- and how many (source, target) entries change.  The host step-by-step path equals the device
+    pipeline entry for entry under BOTH settings; entries only differ when reversed cells exist."""
+    from xugrid_amd import voronoi
+
+    if case == "g6c":
+        g = golden("g6_voronoi.npz")
+        xy, faces = g["c_xy"], g["c_faces"]
+    else:
+        xy, faces = meshgen.triangle_mesh(50_000, 5)
+        if case == "clockwise_source":
+            faces = faces[:, ::-1].copy()
+    rng = np.random.default_rng(8)
+    lo, hi = xy.min(axis=0), xy.max(axis=0)
+    points = lo + (hi - lo) * rng.random((40_000, 2))
+    src = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+    tgt_xy, tgt_f = meshgen.triangle_mesh(20_000, 6, 0.0, 1.0, delaunay=False)
+    tgt_xy = lo + (hi - lo) * tgt_xy
+    tgt = xa.Ugrid2d(tgt_xy[:, 0], tgt_xy[:, 1], -1, tgt_f)
+    mesh, _, _ = voronoi.voronoi_topology_device(src)
+    n_rev = _reversed_cells(mesh)
+    a = xa.regrid.UnstructuredGrid2d(src)
+    b = xa.regrid.UnstructuredGrid2d(tgt)
+    trip = {}
+    for ref in (False, True):
+        s_i, t_i, w = a.barycentric(b, reference_order=ref)
+        d = a.barycentric_device(b, reference_order=ref)
+        data, idx, indptr = d.download()
+        rows = np.repeat(np.arange(d.n), np.diff(indptr))
+        assert np.array_equal(idx, s_i) and np.array_equal(rows, t_i) and np.array_equal(data, w), (case, ref)
+        trip[ref] = (s_i, t_i, w)
+    same = all(np.array_equal(x, y) for x, y in zip(trip[False], trip[True]))
+    n_diff = 0 if same else int(np.setxor1d(trip[False][0] * (tgt_f.shape[0] + 1) + trip[False][1],
+                                            trip[True][0] * (tgt_f.shape[0] + 1) + trip[True][1]).size)
+    print(f"[blast radius] {case}: {n_rev} reversed Voronoi cells of {mesh.n_face}, {n_diff} (source, target) entries differ "
+          f"of {trip[False][0].size}")
+    assert (n_diff == 0) == same and (n_rev > 0 or same), (case, n_rev, n_diff)
+    assert n_rev <= 0.02 * mesh.n_face  # exterior cells only
+    assert n_diff <= 0.05 * trip[False][0].size
+    del points

@@ -393,7 +393,7 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 // vertex_face[v - n_identity] beyond (projections: their face; substitute vertices: -1)
 static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
                             double tolerance, int64_t n_identity, const int64_t *vertex_face,
-                            const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out) {
+                            const int64_t *node_to_node_map, int64_t n_extra, bool reference_order, xr_csr **out) {
     {
     XR_REQUIRE(voronoi && source && out, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
     XR_REQUIRE(n_identity >= 0 && n_identity <= voronoi->n_node && n_identity <= source->n_face &&
@@ -440,7 +440,9 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             if (nv > n_identity)
                 h2d(vface.get() + n_identity, vertex_face, sizeof(int64_t) * (size_t)(nv - n_identity));
             if (n_extra > 0) h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_extra);
-            mesh_faces_ccw_dev(voronoi, faces_ccw.get());
+            // the vertex table the weight slots are paired with: the tree's own counter-clockwise order, or -- to reproduce
+            // the reference's indexing (unstructured.py:175,193) also for the cells the tree reversed -- the caller's
+            mesh_faces_ccw_dev(voronoi, faces_ccw.get(), reference_order);
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
                       voronoi->rec_face.get(), pts.get(), n, tol, face.get(), w.get());
@@ -472,16 +474,16 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
                        xr_csr **out) {
     XR_API_BEGIN
     XR_REQUIRE(vertex_face, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
-    barycentric_csr(voronoi, source, query, points, n, tolerance, 0, vertex_face, node_to_node_map, n_extra, out);
+    barycentric_csr(voronoi, source, query, points, n, tolerance, 0, vertex_face, node_to_node_map, n_extra, false, out);
     XR_API_END
 }
 
 int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
                             double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
-                            const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out) {
+                            const int64_t *node_to_node_map, int64_t n_extra, int reference_order, xr_csr **out) {
     XR_API_BEGIN
     barycentric_csr(voronoi, source, query, points, n, tolerance, n_identity, vertex_face_tail, node_to_node_map, n_extra,
-                    out);
+                    reference_order != 0, out);
     XR_API_END
 }
 

@@ -166,7 +166,7 @@ k_ingest_faces(const I *__restrict__ raw, int64_t cnt, int m, int64_t fill_value
 // CCW-normalised connectivity (xr_mesh_faces; not on the hot path)
 __global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ node_xy,
                                                   const int32_t *__restrict__ faces_raw, int64_t n_face, int m,
-                                                  int64_t *__restrict__ out) {
+                                                  int64_t *__restrict__ out, bool caller_order) {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n_face) return;
     int face[XR_MAX_FACE_NODES];
@@ -174,6 +174,7 @@ __global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ no
     int n;
     bool flip;
     face_shape<XR_MAX_FACE_NODES>(node_xy, face, m, n, flip);
+    if (caller_order) flip = false; // (fill normalised to -1, vertex order untouched)
     for (int j = 0; j < m; j++) out[f * m + j] = (flip && j < n) ? face[n - 1 - j] : face[j];
 }
 
@@ -543,10 +544,10 @@ void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev) {
                   mesh->faces_raw.get(), mesh->n_face, mesh->m, cxy_dev);
 }
 
-void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev) {
+void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order) {
     if (mesh->n_face > 0)
         XR_LAUNCH("faces_ccw", k_faces_ccw, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
-                  mesh->faces_raw.get(), mesh->n_face, mesh->m, faces_dev);
+                  mesh->faces_raw.get(), mesh->n_face, mesh->m, faces_dev, caller_order);
 }
 
 // Ugrid2d.from_structured_bounds -> _from_intervals_helper (xugrid/ugrid/ugrid2d.py:1973-2034, :1894-1912) on the
@@ -755,7 +756,7 @@ int xr_mesh_faces(xr_mesh *mesh, int64_t *faces_out) {
     if (n > 0) {
         DevBuf<int64_t> wide((size_t)n);
         XR_LAUNCH("faces_ccw", k_faces_ccw, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
-                  mesh->faces_raw.get(), mesh->n_face, mesh->m, wide.get());
+                  mesh->faces_raw.get(), mesh->n_face, mesh->m, wide.get(), false);
         d2h(faces_out, wide.get(), sizeof(int64_t) * (size_t)n);
         stream_sync();
     }

@@ -126,5 +126,5 @@ void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
 void mesh_read_stats(xr_mesh *mesh);
 void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev);    // connectivity.centroids into device memory [n_face*2]
-void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev); // CCW-normalised connectivity [n_face*m]
+void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order = false); // CCW-normalised (or the caller's) connectivity [n_face*m]
 } // namespace xr

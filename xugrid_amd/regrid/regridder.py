@@ -368,7 +368,11 @@ class BarycentricInterpolator(BaseRegridder):
 
     _METHODS = {"mean": ABSOLUTE_OVERLAP_METHODS["mean"]}
 
-    def __init__(self, source, target, tolerance: Optional[float] = None):
+    def __init__(self, source, target, tolerance: Optional[float] = None, reference_order: bool = False):
+        # reference_order (not in the reference's signature, regridder.py:613-622): pair the weight slots of the concave
+        # exterior Voronoi cells with the caller's vertex order as the reference does, instead of the order the
+        # weights were computed in (UnstructuredGrid2d.barycentric; DESIGN.md section 7: 0.1-0.7 % of the entries)
+        self._reference_order = bool(reference_order)
         super().__init__(source, target, tolerance)
         self._setup_regrid("mean")
 
@@ -379,7 +383,7 @@ class BarycentricInterpolator(BaseRegridder):
             self._device_weights = source.linear_weights_device(target)
             self._weights = None
             return
-        self._device_weights = source.barycentric_device(target, tolerance)
+        self._device_weights = source.barycentric_device(target, tolerance, reference_order=self._reference_order)
         self._weights = None
 
     @classmethod
