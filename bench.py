@@ -390,11 +390,29 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy):
         dt = (time.perf_counter() - t0) / n
         nbytes = 12 * csr.nnz + 4 * (T + 1) + 8 * K * (S + T)
         out["config5_apply_K256"] = {
-            "weights": "the benchmark's own matrix (qhull-numbered Delaunay source: gathers less local than a "
-            "lattice-numbered mesh, which runs at 1.05 ms = 3.9 TB/s)",
+            "weights": "the benchmark's own matrix (qhull-numbered Delaunay meshes: a compact block of target rows is many short "
+            "runs of row ids, so gathers and output stores are less local than on a lattice-numbered pair, which runs at "
+            "0.99 ms = 4.2 TB/s)",
             "ms": 1e3 * dt, "cell_variables_per_s": K * T / dt, "algorithmic_GBps": nbytes / dt / 1e9,
             "frac_of_hbm_peak": nbytes / dt / 1e9 / HBM_PEAK_GBS,
         }
+        # the same with the source cells renumbered along a Morton curve (xr_csr_set_col_keys): once with the caller's
+        # block (a gather pass per apply puts it in the stored order), once with a block that already is in that order
+        keys, key_range = E.morton_row_keys(mesh.centroids(), faces_per_tile=64)
+        csr.set_col_keys(keys, key_range)
+        for tag, permuted in (("caller_order_source", False), ("stored_order_source", True)):
+            csr.expect_permuted(permuted)
+            for _ in range(2):
+                csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+            E.dev_sync()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+            E.dev_sync()
+            dt2 = (time.perf_counter() - t0) / n
+            out["config5_apply_K256"]["morton_columns_" + tag] = {
+                "ms": 1e3 * dt2, "algorithmic_GBps": nbytes / dt2 / 1e9, "frac_of_hbm_peak": nbytes / dt2 / 1e9 / HBM_PEAK_GBS}
+        csr.expect_permuted(False)
         lib.xr_dev_free(d_src)
         lib.xr_dev_free(d_out)
     except Exception as e:  # noqa: BLE001

@@ -285,6 +285,18 @@ int xr_edge_pieces(xr_mesh *tree, const xr_csr *csr, const double *edge_xy, int6
  * regroups the STORED rows by key once -- results and xr_csr_download are unaffected.  xr_overlap attaches such
  * keys itself. */
 int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range);
+/* The same for the COLUMNS (source cells): one small integer per column such that columns with equal keys are spatial
+ * neighbours.  The columns are renumbered once by key (stable), so that the source values a block of target rows
+ * gathers are neighbours in memory whatever the caller's cell numbering (a qhull-numbered mesh: half the fetched bytes
+ * were unused).  Entry order inside the rows is untouched -- reducers add in the same order, results are bit-identical
+ * -- and xr_csr_download returns the caller's column ids.  The source block handed to the apply entry points is either
+ * in the caller's cell order (default: one gather pass per call puts it in the stored order) or, after
+ * xr_csr_expect_permuted(csr, 1), already in the stored order: source_permuted[k][j] = source[k][order[j]] with
+ * order = xr_csr_col_order (int64[m]) -- for data that stays on the device across many applies, or producers that can
+ * write in that order. */
+int xr_csr_set_col_keys(xr_csr *csr, const int64_t *keys, int64_t key_range);
+int xr_csr_col_order(const xr_csr *csr, int64_t *order_out);
+int xr_csr_expect_permuted(xr_csr *csr, int permuted);
 int xr_csr_destroy(xr_csr *csr);
 
 /* ---- seam 2: apply ---------------------------------------------------------------------- */

@@ -571,3 +571,39 @@ def test_apply_host_arrays_in_chunks(hip, oracle, monkeypatch):
         assert np.array_equal(csr.apply(v, 0), whole, equal_nan=True)
         v32 = v.astype(np.float32)
         assert np.array_equal(csr.apply(v32, 7, 50.0), csr.apply(v32.astype(np.float64), 7, 50.0), equal_nan=True)
+
+
+def test_apply_columns_renumbered_by_spatial_key(hip, oracle):
+    """xr_csr_set_col_keys: the columns (source cells) are renumbered by a spatial key so that the gathers of a row
+    block are neighbours in memory; entry order inside the rows is untouched -> results bit-identical, downloads in
+    the caller's ids, and a source block handed over in the stored order (expect_permuted) gives the same numbers."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.triangle_mesh(20000, 3)  # qhull numbering
+    txy, tf = meshgen.triangle_mesh(24000, 4, 30.0, 0.8)
+    csr = E.DeviceMesh(sxy, sf).overlap(E.DeviceMesh(txy, tf))
+    data, idx, indptr = csr.download()
+    rng = np.random.default_rng(6)
+    v = rng.normal(size=(24, csr.m))
+    v[5, ::7] = np.nan
+    ref = {mid: csr.apply(v, mid) for mid in (0, 3, 5, 9)}
+    ref1 = csr.apply(v[:1], 0)
+    med = csr.apply(v[:4], 7, 50.0)
+    keys, key_range = E.morton_row_keys(oracle.centroids(sxy, sf), faces_per_tile=64)
+    csr.set_col_keys(keys, key_range)
+    order = csr.col_order()
+    assert np.array_equal(np.sort(order), np.arange(csr.m)) and not np.array_equal(order, np.arange(csr.m))
+    d2, i2, p2 = csr.download()
+    assert np.array_equal(d2, data) and np.array_equal(i2, idx) and np.array_equal(p2, indptr)
+    for mid, exp in ref.items():
+        assert same_or_nan(csr.apply(v, mid), exp).all(), mid
+    assert same_or_nan(csr.apply(v[:1], 0), ref1).all()
+    assert same_or_nan(csr.apply(v[:4], 7, 50.0), med).all()
+    csr.expect_permuted(True)
+    vp = np.ascontiguousarray(v[:, order])
+    for mid, exp in ref.items():
+        assert same_or_nan(csr.apply(vp, mid), exp).all(), mid
+    csr.expect_permuted(False)
+    assert same_or_nan(csr.apply(v.astype(np.float32), 0), csr.apply(v.astype(np.float32).astype(np.float64), 0)).all()
+    with pytest.raises(ValueError):
+        csr.set_col_keys(keys, key_range)  # already renumbered

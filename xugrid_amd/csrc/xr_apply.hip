@@ -570,7 +570,8 @@ static constexpr int PLAN_KT = 8;      // source variables per pipeline stage (L
 __global__ void __launch_bounds__(AP_BLOCK)
 k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
              int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc,
-             int32_t *__restrict__ max_entries, int32_t *__restrict__ unplanned, int32_t *__restrict__ n_unplanned) {
+             int32_t *__restrict__ max_entries, int32_t *__restrict__ unplanned, int32_t *__restrict__ n_unplanned,
+             int entry_cap) {
     __shared__ int32_t keys[PLAN_LMAX];
     __shared__ int32_t uniq[PLAN_UMAX];
     __shared__ int32_t sh_wave[4];
@@ -578,7 +579,7 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
     const int seg0 = indptr[row0], seg1 = indptr[row_end];
     const int n = seg1 - seg0;
-    if (n > PLAN_LMAX) {
+    if (n > entry_cap) {
         if (threadIdx.x == 0) {
             nuniq[blockIdx.x] = -1;
             unplanned[atomicAdd(n_unplanned, 1)] = (int32_t)blockIdx.x;
@@ -909,18 +910,31 @@ static void ensure_plan(const xr_csr *ccsr) {
     csr->plan_loc.alloc((size_t)csr->nnz);
     csr->plan_lmax = 256;
     csr->plan_n_unplanned = 0;
+    // The apply sizes its LDS stage for the LARGEST planned block, and that decides how many blocks a CU holds: one block
+    // of 4096 entries among thousands of 1000 (a Delaunay hull) costs every block a third of the occupancy (K = 256 on
+    // the benchmark matrix: 1.76 -> 1.2 ms).  Blocks beyond 2048 entries (twice the typical triangle-mesh block) go to
+    // the direct kernel instead.
+    static const int plan_cap = getenv("XR_PLAN_CAP") ? std::min(PLAN_LMAX, std::max(256, atoi(getenv("XR_PLAN_CAP")))) : 2048;
     if (nb > 0) {
         DevBuf<int32_t> max_entries(2); // [0] largest planned block, [1] number of unplanned blocks
         fill_i32(max_entries.get(), 0, 2);
         csr->plan_unplanned.alloc((size_t)nb);
         XR_LAUNCH("plan_build", k_plan_build, dim3((unsigned)nb), dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get(),
-                  max_entries.get(), csr->plan_unplanned.get(), max_entries.get() + 1);
+                  max_entries.get(), csr->plan_unplanned.get(), max_entries.get() + 1, plan_cap);
         int32_t h[2];
         d2h(h, max_entries.get(), sizeof(h));
         const int m = h[0];
         csr->plan_n_unplanned = h[1];
         csr->plan_lmax = std::min(PLAN_LMAX, std::max(256, (m + 255) / 256 * 256));
+        if (getenv("XR_DEBUG_PLAN")) {
+            std::vector<int32_t> nu((size_t)nb);
+            d2h(nu.data(), csr->plan_nuniq.get(), sizeof(int32_t) * (size_t)nb);
+            double sum = 0; int cnt = 0, mx = 0;
+            for (auto v : nu) if (v >= 0) { sum += v; cnt++; mx = std::max(mx, (int)v); }
+            fprintf(stderr, "[plan] blocks %lld planned %d unplanned %d lmax %d avg distinct columns %.1f max %d nnz/block %.1f\n", (long long)nb, cnt,
+                    csr->plan_n_unplanned, csr->plan_lmax, cnt ? sum / cnt : 0.0, mx, (double)csr->nnz / nb);
+        }
     }
     csr->plan_ready = true;
 }
@@ -1512,8 +1526,40 @@ static void apply_dispatch(const xr_csr *csr, int method, double p, const SRC *s
     }
 }
 
+// the caller's source block into the stored column order: dst[k][j] = src[k][col_of[j]] (every source line is read once;
+// the columns of a line are spatial neighbours, so they are consumed within a short stretch of j: L2 hits)
+template <typename SRC>
+__global__ void __launch_bounds__(256)
+k_permute_source(const SRC *__restrict__ src, const int32_t *__restrict__ col_of, int64_t S, SRC *__restrict__ dst) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k = blockIdx.y;
+    if (j < S) dst[k * S + j] = src[k * S + col_of[j]];
+}
+
+// -> the source block in the STORED column order (the caller's block itself unless the columns were renumbered)
+static const void *stored_source(const xr_csr *csr, const void *src, int dtype, int64_t K, DevBuf<char> &permuted) {
+    if (!(csr->has_col_perm && !csr->source_permuted && K > 0 && csr->m > 0)) return src;
+    const size_t esz = dtype == XR_F64 ? 8 : 4;
+    permuted.alloc((size_t)K * (size_t)csr->m * esz);
+    for (int64_t k0 = 0; k0 < K; k0 += 65535) {
+        const int64_t kc = std::min<int64_t>(K - k0, 65535);
+        dim3 grid(div_up(csr->m, 256), (unsigned)kc);
+        if (dtype == XR_F64)
+            XR_LAUNCH("permute_source", k_permute_source<double>, grid, dim3(256), 0,
+                      static_cast<const double *>(src) + k0 * csr->m, csr->col_of.get(), csr->m,
+                      reinterpret_cast<double *>(permuted.get()) + k0 * csr->m);
+        else
+            XR_LAUNCH("permute_source", k_permute_source<float>, grid, dim3(256), 0,
+                      static_cast<const float *>(src) + k0 * csr->m, csr->col_of.get(), csr->m,
+                      reinterpret_cast<float *>(permuted.get()) + k0 * csr->m);
+    }
+    return permuted.get();
+}
+
 static void apply_dev(const xr_csr *csr, int method, double p, const void *src, int dtype, int64_t K, double *out) {
     XR_REQUIRE(dtype == XR_F64 || dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", dtype);
+    DevBuf<char> permuted; // (goes back to the pool at return; the pool hands blocks out in stream order)
+    src = stored_source(csr, src, dtype, K, permuted);
     if (dtype == XR_F64) apply_dispatch<double>(csr, method, p, static_cast<const double *>(src), K, out);
     else apply_dispatch<float>(csr, method, p, static_cast<const float *>(src), K, out);
 }
@@ -1529,6 +1575,20 @@ __global__ void k_widen_i32(const int32_t *__restrict__ in, int64_t *__restrict_
 __global__ void k_bincount(const int32_t *__restrict__ row, int64_t nnz, int32_t *__restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < nnz) atomicAdd(&count[row[i]], 1);
+}
+
+__global__ void k_gather_i32(const int32_t *__restrict__ table, const int32_t *__restrict__ idx, int64_t n,
+                             int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = table[idx[i]];
+}
+__global__ void k_scatter_iota_i32(const int32_t *__restrict__ perm, int64_t n, int32_t *__restrict__ inverse) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) inverse[perm[i]] = (int32_t)i;
+}
+__global__ void k_relabel_i32(const int32_t *__restrict__ table, int32_t *__restrict__ idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) idx[i] = table[idx[i]];
 }
 
 // stored row r -> caller row row_order[r]
@@ -1905,7 +1965,16 @@ int xr_csr_download(const xr_csr *csr, double *data, int64_t *indices, int64_t *
     if (data && csr->nnz > 0) {
         d2h(data, d_data, sizeof(double) * (size_t)csr->nnz);
     }
-    if (indices) download_widen(d_indices, csr->nnz, indices);
+    if (indices) {
+        DevBuf<int32_t> caller_ids;
+        if (csr->has_col_perm && csr->nnz > 0) { // stored column ids -> the caller's
+            caller_ids.alloc((size_t)csr->nnz);
+            XR_LAUNCH("col_ids", k_gather_i32, dim3(div_up(csr->nnz, 256)), dim3(256), 0, csr->col_of.get(), d_indices,
+                      csr->nnz, caller_ids.get());
+            d_indices = caller_ids.get();
+        }
+        download_widen(d_indices, csr->nnz, indices);
+    }
     if (indptr) download_widen(d_indptr, csr->n + 1, indptr);
     stream_sync();
     XR_API_END
@@ -2100,6 +2169,60 @@ int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range) {
     XR_API_END
 }
 
+int xr_csr_set_col_keys(xr_csr *csr, const int64_t *keys, int64_t key_range) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && (keys || csr->m == 0), XR_ERR_INVALID, "xr_csr_set_col_keys: NULL argument");
+    XR_REQUIRE(key_range >= 1 && key_range <= ((int64_t)1 << 24), XR_ERR_INVALID,
+               "xr_csr_set_col_keys: key_range must be in [1, 2^24]");
+    XR_REQUIRE(!csr->has_col_perm, XR_ERR_INVALID, "xr_csr_set_col_keys: the columns of this matrix are renumbered already");
+    for (int64_t i = 0; i < csr->m; i++)
+        XR_REQUIRE(keys[i] >= 0 && keys[i] < key_range, XR_ERR_INVALID, "xr_csr_set_col_keys: key %lld outside [0,%lld)",
+                   (long long)keys[i], (long long)key_range);
+    const int64_t m = csr->m;
+    if (m > 0 && key_range > 1) {
+        // stable counting sort of the columns by key (the tiling kernels of the rows): col_of[new] = caller's column
+        DevBuf<int32_t> key((size_t)m), hist((size_t)key_range + 1), start((size_t)key_range + 1), members((size_t)m),
+            rank((size_t)m);
+        upload_narrow(keys, m, key.get());
+        fill_i32(hist.get(), 0, key_range + 1);
+        XR_LAUNCH("bincount", k_bincount, dim3(div_up(m, 256)), dim3(256), 0, key.get(), m, hist.get());
+        exclusive_scan_i32(hist.get(), start.get(), key_range);
+        fill_i32(hist.get(), 0, key_range + 1);
+        XR_LAUNCH("tile_scatter", k_tile_scatter, dim3(div_up(m, 256)), dim3(256), 0, key.get(), m, start.get(), hist.get(),
+                  members.get());
+        csr->col_of.alloc((size_t)m);
+        XR_LAUNCH("tile_rank", k_tile_rank, dim3(div_up(m, 256)), dim3(256), 0, key.get(), start.get(), members.get(), m,
+                  csr->col_of.get());
+        XR_LAUNCH("col_inverse", k_scatter_iota_i32, dim3(div_up(m, 256)), dim3(256), 0, csr->col_of.get(), m, rank.get());
+        if (csr->nnz > 0)
+            XR_LAUNCH("col_relabel", k_relabel_i32, dim3(div_up(csr->nnz, 256)), dim3(256), 0, rank.get(),
+                      csr->indices.get(), csr->nnz);
+        stream_sync();
+        csr->has_col_perm = true;
+        csr->plan_ready = false;
+    }
+    XR_API_END
+}
+
+int xr_csr_col_order(const xr_csr *csr, int64_t *order_out) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && (order_out || csr->m == 0), XR_ERR_INVALID, "xr_csr_col_order: NULL argument");
+    if (csr->has_col_perm) {
+        download_widen(csr->col_of.get(), csr->m, order_out);
+        stream_sync();
+    } else {
+        for (int64_t i = 0; i < csr->m; i++) order_out[i] = i;
+    }
+    XR_API_END
+}
+
+int xr_csr_expect_permuted(xr_csr *csr, int permuted) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_expect_permuted: NULL argument");
+    csr->source_permuted = permuted != 0;
+    XR_API_END
+}
+
 int xr_csr_destroy(xr_csr *csr) {
     XR_API_BEGIN
     if (csr) {
@@ -2197,6 +2320,8 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
     XR_REQUIRE(K >= 0 && K < 65536, XR_ERR_LIMIT, "xr_apply_partial_dev: K out of range (tile the variables)");
     if (csr->n > 0 && K > 0) {
         XR_REQUIRE(source_dev || csr->m == 0, XR_ERR_INVALID, "xr_apply_partial_dev: NULL source");
+        DevBuf<char> permuted;
+        source_dev = stored_source(csr, source_dev, source_dtype, K, permuted);
         dim3 grid(div_up(csr->n, 256), (unsigned)K);
         if (source_dtype == XR_F64)
             XR_LAUNCH("apply_partial", k_apply_partial<double>, grid, dim3(256), 0, method, csr->indptr.get(),

@@ -95,6 +95,11 @@ struct xr_csr {
     xr::DevBuf<int32_t> tile_key; // [n]
     bool has_tile_key = false;
     int64_t tile_key_range = 0;   // keys are in [0, tile_key_range)
+    // Columns renumbered by a spatial key (xr_csr_set_col_keys): stored column j is the caller's column col_of[j].
+    // The apply gathers the caller's source block into the stored order first unless the caller says it already is.
+    xr::DevBuf<int32_t> col_of; // [m]
+    bool has_col_perm = false;
+    bool source_permuted = false;
     // "apply plan" for many source variables (built lazily, xr_apply.hip): per block of 256 stored
     // rows the sorted list of DISTINCT column ids and, per entry, its 16-bit position in that list
     bool plan_ready = false;

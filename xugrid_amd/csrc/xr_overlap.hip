@@ -46,7 +46,9 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
 // hits, too many grid rows or too many visited records are "big" and go to the block-per-face
 // kernel instead.
 static constexpr int SLOTS = 16;
-static constexpr int TILE_RUN = 64; // rows per run in the tiling hint (512-byte output stores per variable)
+static constexpr int TILE_RUN = 16; // rows per run in the tiling hint (128-byte output stores per variable).  Measured, K = 256 on
+                                    // the benchmark matrix: runs of 64 rows / tiles of 24 extents 2.10 ms, 16 / 12: 1.72 ms (a qhull-numbered
+                                    // target: long runs of consecutive ids are not compact); a lattice-numbered pair 0.99 ms either way
 
 // XCD-aware block order (launch the grid rounded up to a multiple of 8): hardware block b runs on XCD b % 8; every
 // XCD gets a CONTIGUOUS range of logical blocks (= one spatial region of the Morton-ordered work list), so that the
@@ -1284,13 +1286,15 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         const double *hs = query->h_stats;
         double span = std::max(hs[1] - hs[0], hs[3] - hs[2]);
         if (!(span > 0)) span = 1.0;
-        // tile edge <= 24 mean extents (the side count is a power of two); measured flat between 8 and 32
-        double h = 24.0 * hs[4] / (double)T;
+        // tile edge <= 12 mean extents (the side count is a power of two): about one block of 256 triangles per tile
+        static const double tile_ext = getenv("XR_TILE_EXT") ? atof(getenv("XR_TILE_EXT")) : 12.0; // tuning hook
+        double h = tile_ext * hs[4] / (double)T;
         if (!(h > 0)) h = span;
         int bits = 0;
-        while (bits < 10 && ldexp(h, bits) < span) bits++;
+        while (bits < 12 && ldexp(h, bits) < span) bits++;
         tile = MortonParams{hs[0], hs[2], (double)(1 << bits) / (span * (1.0 + 1e-9)), 1 << bits};
-        tile.n_run = TILE_RUN;
+        static const int tile_run = getenv("XR_TILE_RUN") ? atoi(getenv("XR_TILE_RUN")) : TILE_RUN; // tuning hook (power of two)
+        tile.n_run = tile_run;
         csr->tile_key.alloc((size_t)T);
         csr->tile_key_range = (int64_t)1 << (2 * bits);
         csr->has_tile_key = bits > 0;

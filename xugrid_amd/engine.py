@@ -481,6 +481,24 @@ class DeviceCSR:
             raise ValueError("one key per row expected")
         check(_lib.load().xr_csr_set_row_keys(self._h, _ptr(keys), int(key_range)))
 
+    def set_col_keys(self, keys, key_range):
+        """Renumber the columns (source cells) by a spatial key (see include/xugrid_amd.h: xr_csr_set_col_keys)."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64)
+        if keys.shape != (self.m,):
+            raise ValueError("one key per column expected")
+        check(_lib.load().xr_csr_set_col_keys(self._h, _ptr(keys), int(key_range)))
+
+    def col_order(self):
+        """stored column j holds the caller's column ``col_order()[j]``"""
+        out = np.empty(self.m, dtype=np.int64)
+        check(_lib.load().xr_csr_col_order(self._h, _ptr(out)))
+        return out
+
+    def expect_permuted(self, permuted=True):
+        """The source blocks of the following applies are already in the stored column order
+        (``source[:, col_order()]``)."""
+        check(_lib.load().xr_csr_expect_permuted(self._h, 1 if permuted else 0))
+
     def download(self):
         """-> (data float64[nnz], indices intp[nnz], indptr intp[n+1])"""
         data = np.empty(self.nnz, dtype=np.float64)
