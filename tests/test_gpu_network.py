@@ -168,3 +168,26 @@ def test_celltree_intersect_edges_adapter(hip, oracle):
         assert np.array_equal(cols, e[order]) and np.allclose(data, length[order], rtol=1e-15)
     empty = xa.CellTree2d(nodes, faces, -1).intersect_edges(np.zeros((0, 2, 2)))
     assert empty[0].size == 0 and empty[2].shape == (0, 2, 2)
+
+
+def test_intersection_length_relative_reproduces_reference_formula(hip):
+    """unstructured.py:213-214: ``length /= other.length[source_index]`` with source_index = FACE ids (quirk kept)."""
+    import xugrid_amd as xa
+    from xugrid_amd.regrid.network import Network1d
+    from xugrid_amd.regrid.unstructured import UnstructuredGrid2d
+
+    xy, faces = meshgen.quad_mesh(np.arange(0.0, 5.0), np.arange(0.0, 3.0))  # 8 faces
+    grid = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+    nodes = np.array([[0.2, 0.5], [3.7, 0.5], [3.7, 1.6], [0.3, 1.9], [2.2, 0.1], [2.4, 1.9], [0.1, 0.1], [3.9, 1.9],
+                      [1.0, 1.0]])
+    edges = np.array([[0, 1], [1, 2], [2, 3], [4, 5], [6, 7], [3, 8], [8, 4], [0, 8]])  # 8 edges >= max face id + 1
+    net = Network1d(xa.Ugrid1d(nodes[:, 0], nodes[:, 1], -1, edges))
+    g = UnstructuredGrid2d(grid)
+    s_abs, t_abs, l_abs = g.intersection_length(net, relative=False)
+    s_rel, t_rel, l_rel = g.intersection_length(net, relative=True)
+    assert np.array_equal(s_abs, s_rel) and np.array_equal(t_abs, t_rel)
+    assert np.array_equal(l_rel, l_abs / net.length[t_abs])
+    # fewer edges than faces: the reference's indexing runs out of range, and so does this
+    small = Network1d(xa.Ugrid1d(nodes[:, 0], nodes[:, 1], -1, edges[:3]))
+    with pytest.raises(IndexError):
+        g.intersection_length(small, relative=True)

@@ -624,14 +624,20 @@ def reduce_partial_rows_dev(method_id, rows_ptr, indptr_ptr, order_ptr, n_target
 
 
 def apply_coo(row, col, n_target, source):
-    """CentroidLocatorRegridder._regrid (regridder.py:400-409)."""
-    src, dtype = _source_2d(source)
+    """CentroidLocatorRegridder._regrid (regridder.py:400-409) for externally supplied, unsorted COO weights:
+    ``out[k, row[i]] = source[k, col[i]]`` in entry order, i.e. the LAST entry of a target wins.  A scatter with one
+    thread per entry would race on repeated targets, so the triplets are stably sorted by row and applied as CSR rows
+    with the ``select`` reducer (the value of the row's last entry) -- deterministic, and any K."""
+    src, _ = _source_2d(source)
     row = np.ascontiguousarray(row, dtype=np.int64)
     col = np.ascontiguousarray(col, dtype=np.int64)
-    K, S = src.shape
-    out = np.empty((K, n_target), dtype=np.float64)
-    check(_lib.load().xr_apply_coo(_ptr(row), _ptr(col), row.size, int(n_target), _ptr(src), dtype, K, S, _ptr(out)))
-    return out
+    if row.shape != col.shape or row.ndim != 1:
+        raise ValueError("row and col must be 1-D arrays of equal length")
+    if row.size and (row.min() < 0 or row.max() >= n_target or col.min() < 0 or col.max() >= src.shape[1]):
+        raise ValueError("COO entry out of range")
+    order = np.argsort(row, kind="stable")
+    csr = DeviceCSR.from_triplet(row[order], col[order], np.ones(row.size), int(n_target), src.shape[1])
+    return csr.apply(src, METHOD_IDS["select"], 0.0)
 
 
 class KernelTimer:

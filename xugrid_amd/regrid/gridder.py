@@ -45,7 +45,9 @@ class NetworkGridder(BaseRegridder):
 
     def _compute_weights(self, source, target, relative: bool = False) -> None:
         source, target = convert_to_match(source, target)
-        self._device_weights = target.intersection_length_device(source, relative=relative)
+        if relative:  # (never requested by the reference either, gridder.py:49; the host path reproduces its formula)
+            raise NotImplementedError("NetworkGridder uses absolute intersection lengths")
+        self._device_weights = target.intersection_length_device(source)
         self._weights = None
 
     @property

@@ -91,7 +91,8 @@ class BaseRegridder(abc.ABC):
     # ---- apply
     def _regrid(self, source: np.ndarray, size: int) -> np.ndarray:
         out = self._ensure_device_weights().apply(source, self._method.method_id, self._method.percentile)
-        assert out.shape[1] == size
+        if out.shape[1] != size:
+            raise ValueError(f"the weights have {out.shape[1]} rows, the target grid {size} cells")
         return out
 
     def _regrid_array(self, source):
@@ -123,7 +124,19 @@ class BaseRegridder(abc.ABC):
         if isinstance(data, np.ndarray):
             return self._regrid_array(data)
         if hasattr(data, "values") and hasattr(data, "dims"):
-            return self._regrid_array(np.asarray(data.values))
+            values = np.asarray(data.values)
+            # regridder.py:247-251, 197-210: the source dims are looked up BY NAME and moved to the end (apply_ufunc's
+            # input_core_dims); a plain trailing-shape check would silently regrid the wrong axes of e.g. (x, y) data
+            # with nx == ny
+            source_dims = tuple(getattr(self._source, "dims", ()) or ())
+            dims = tuple(data.dims)
+            if source_dims and all(isinstance(d, str) for d in source_dims):
+                missing = set(source_dims) - set(dims)
+                if missing:
+                    raise ValueError(f"data does not contain regridder source dimensions: {missing}")
+                other = [d for d in dims if d not in source_dims]
+                values = np.transpose(values, [dims.index(d) for d in other] + [dims.index(d) for d in source_dims])
+            return self._regrid_array(np.ascontiguousarray(values))
         raise TypeError(f"Expected DataArray or UgridDataAray, received: {type(data).__name__}")
 
     # ---- weights access / persistence (regridder.py:264-361)
@@ -227,10 +240,16 @@ class BaseRegridder(abc.ABC):
         instance._device_weights = None
         instance._target = setup_grid(target)
         instance._source = cls._grid_from_dataset(weights, "__source")
+        w = instance._weights
+        if w.n != instance._target.size:
+            raise ValueError(f"the weights have {w.n} rows, the target grid {instance._target.size} cells")
+        if w.m != instance._source.size:
+            raise ValueError(f"the weights have {w.m} columns, the source grid {instance._source.size} cells")
         return instance
 
-    # ---- file persistence of the flat dict (xarray / netCDF are optional and absent here; the variable names are the
-    # reference's, so a netCDF written by xugrid's own ``regridder.to_dataset().to_netcdf()`` maps one to one)
+    # ---- file persistence of the flat dict (xarray / netCDF are optional and absent here).  The weight variables
+    # carry the reference's names (regridder.py:264-271); the GRID variables are this package's own (the reference
+    # writes UGRID topologies with attrs-typed markers), so files are not interchangeable with xugrid's netCDF.
     def to_file(self, path) -> None:
         """Write ``to_dataset()`` to a NumPy ``.npz`` archive."""
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in self.to_dataset().items()})
@@ -272,7 +291,8 @@ class CentroidLocatorRegridder(BaseRegridder):
             # externally supplied, unsorted COO weights: plain scatter (regridder.py:400-409)
             return engine.apply_coo(A.row, A.col, size, source)
         out = self._ensure_device_weights().apply(source, engine.METHOD_IDS["select"], 0.0)
-        assert out.shape[1] == size
+        if out.shape[1] != size:
+            raise ValueError(f"the weights have {out.shape[1]} rows, the target grid {size} cells")
         return out
 
     def _ensure_host_weights(self):

@@ -164,21 +164,25 @@ class UnstructuredGrid2d:
         order = np.argsort(target_index, kind="stable")
         return source_index[order], target_index[order], weights[order]
 
-    def intersection_length_device(self, other, relative: bool = False):
-        """unstructured.py:203-215 as a device CSR: rows = faces of this grid, columns = edges of the network
+    def intersection_length_device(self, other):
+        """unstructured.py:203-212 as a device CSR: rows = faces of this grid, columns = edges of the network
         ``other`` (ascending within a row), data = length of the edge inside the face."""
-        if relative:
-            # (the reference divides by other.length[face index], :213-214, and never asks for it, gridder.py:49)
-            raise NotImplementedError("relative intersection lengths are not used by NetworkGridder")
         from .. import engine
 
         return engine.edge_length_csr(self.ugrid_topology.device_mesh, other.ugrid_topology.edge_node_coordinates)
 
     def intersection_length(self, other, relative: bool = False):
-        """-> (source_index [edge ids], target_index [face ids, non-decreasing], length); host triplets."""
-        csr = self.intersection_length_device(other, relative)
+        """-> (source_index [edge ids], target_index [face ids, non-decreasing], length); host triplets.
+
+        ``relative=True`` reproduces unstructured.py:213-214 to the letter: ``length /= other.length[source_index]``
+        where ``source_index`` holds the FACE ids of the pairs (second return value of ``intersect_edges``) -- the edge
+        lengths are indexed by face id, which raises IndexError as soon as a face id exceeds the number of edges.
+        NetworkGridder never asks for it (gridder.py:49); it is here so that the method is complete, quirk included."""
+        csr = self.intersection_length_device(other)
         data, indices, indptr = csr.download()
         target_index = np.repeat(np.arange(csr.n, dtype=IntDType), np.diff(indptr))
+        if relative:
+            data = data / np.asarray(other.length)[target_index]
         return indices, target_index, data
 
     def to_dataset(self, name: str):
