@@ -582,3 +582,66 @@ def test_barycentric_reference_order_blast_radius(hip, golden, case):
     assert n_rev <= 0.02 * mesh.n_face  # exterior cells only
     assert n_diff <= 0.05 * trip[False][0].size
     del points
+
+
+def test_concurrent_applies_from_threads(hip, oracle):
+    """dask's threaded scheduler calls ``_regrid`` from several threads at once (regridder.py:177-185): the apply
+    entry points run under the engine's SHARED scope, each thread on a lane of its own.  Four threads hammer four
+    different weight matrices (and one shared one) with different reducers and K; every result must equal the
+    single-threaded one bit for bit."""
+    import threading
+
+    from xugrid_amd import engine as E
+
+    rng = np.random.default_rng(12)
+    cases = []
+    for i in range(4):
+        sxy, sf = meshgen.triangle_mesh(6000 + 1500 * i, 20 + i)
+        txy, tf = meshgen.triangle_mesh(5000 + 1000 * i, 30 + i, 30.0, 0.7)
+        csr = E.DeviceMesh(sxy, sf).overlap(E.DeviceMesh(txy, tf))
+        K = (1, 3, 12, 40)[i]
+        v = rng.normal(size=(K, csr.m))
+        v[0, ::9] = np.nan
+        mid = (0, 5, 0, 3)[i]
+        cases.append((csr, v, mid, csr.apply(v, mid)))
+    shared_csr, shared_v, _, _ = cases[2]
+    shared_exp = shared_csr.apply(shared_v, 9)
+    errors = []
+
+    def worker(i):
+        try:
+            csr, v, mid, exp = cases[i]
+            for it in range(25):
+                got = csr.apply(v, mid)
+                if not same_or_nan(got, exp).all():
+                    errors.append((i, it, "own"))
+                    return
+                if it % 5 == 0 and not same_or_nan(shared_csr.apply(shared_v, 9), shared_exp).all():
+                    errors.append((i, it, "shared"))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    # building weights (exclusive scope) while other threads apply
+    def builder():
+        try:
+            sxy, sf = meshgen.triangle_mesh(4000, 50)
+            txy, tf = meshgen.triangle_mesh(3000, 51, 30.0, 0.7)
+            for _ in range(5):
+                c = E.DeviceMesh(sxy, sf).overlap(E.DeviceMesh(txy, tf))
+                assert c.nnz > 0
+        except Exception as e:  # noqa: BLE001
+            errors.append(("builder", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)] + [threading.Thread(target=builder)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

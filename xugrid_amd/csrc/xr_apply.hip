@@ -869,7 +869,7 @@ static void ensure_tiled(const xr_csr *ccsr) {
         csr->tile_key.release();
         return;
     }
-    hipStream_t st = engine().stream;
+    hipStream_t st = launch_stream();
     DevBuf<int32_t> hist((size_t)R + 1), start((size_t)R + 1), members((size_t)n), perm((size_t)n), len((size_t)n);
     fill_i32(hist.get(), 0, R + 1);
     XR_LAUNCH("bincount", k_bincount, dim3(div_up(n, 256)), dim3(256), 0, csr->tile_key.get(), n, hist.get());
@@ -1440,7 +1440,7 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
     }
     if (csr->has_long) {
         DevBuf<int32_t> huge((size_t)(csr->nnz / APPLY_WAVE + 2));
-        XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), engine().stream));
+        XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), launch_stream()));
         if (K == 1) {
             // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: lane groups / waves; a single variable
             dim3 wgrid((unsigned)engine().num_cu * 16, 1);
@@ -1865,7 +1865,7 @@ static xr_csr *outer_materialise(const xr_outer *o) {
         csr->data.alloc((size_t)nnz);
         csr->long_rows.alloc((size_t)(nnz / XR_APPLY_LONG_ROW + 1));
         csr->n_long.alloc(1);
-        XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), engine().stream));
+        XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), launch_stream()));
         XR_LAUNCH("outer_indptr", k_outer_indptr, dim3(div_up(n + 1, 256)), dim3(256), 0, o->ipy.get(), o->ipx.get(), o->nty,
                   o->ntx, o->Px, nnz, csr->indptr.get(), csr->long_rows.get(), csr->n_long.get());
         if (nnz > 0) {
@@ -2040,7 +2040,7 @@ int xr_csr_from_triplet(const int64_t *row, const int64_t *col, const double *da
         upload_narrow(row, nnz, row32.get());
         upload_narrow(col, nnz, csr->indices.get());
         h2d(csr->data.get(), data, sizeof(double) * (size_t)nnz);
-        XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)(n > 0 ? n : 1), engine().stream));
+        XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)(n > 0 ? n : 1), launch_stream()));
         if (nnz > 0) XR_LAUNCH("bincount", k_bincount, dim3(div_up(nnz, 256)), dim3(256), 0, row32.get(), nnz, count.get());
         exclusive_scan_i32(count.get(), csr->indptr.get(), n);
         std::vector<int32_t> longs;
@@ -2232,9 +2232,25 @@ int xr_csr_destroy(xr_csr *csr) {
     XR_API_END
 }
 
+// Everything an apply may build lazily inside the matrix (row tiling, apply plan) is built here, under the EXCLUSIVE
+// scope; the apply proper then only reads the matrix and runs under the shared scope next to other threads' applies.
+static int prepare_for_apply(const xr_csr *csr, int64_t K) {
+    XR_API_BEGIN
+    if (csr && csr->n > 0 && K >= PLAN_KT && !getenv("XR_APPLY_NO_PLAN") && (csr->has_tile_key || !csr->plan_ready)) {
+        ensure_tiled(csr);
+        ensure_plan(csr);
+        stream_sync();
+    }
+    XR_API_END
+}
+
 int xr_apply_csr_dev(const xr_csr *csr, int method, double percentile, const void *source_dev, int source_dtype,
                      int64_t K, double *out_dev) {
-    XR_API_BEGIN
+    {
+        const int rc = prepare_for_apply(csr, K);
+        if (rc != XR_OK) return rc;
+    }
+    XR_API_BEGIN_SHARED
     XR_REQUIRE(csr && (source_dev || csr->m == 0 || K == 0) && (out_dev || csr->n == 0 || K == 0), XR_ERR_INVALID,
                "xr_apply_csr_dev: NULL argument");
     XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_csr_dev: negative K");
@@ -2245,7 +2261,11 @@ int xr_apply_csr_dev(const xr_csr *csr, int method, double percentile, const voi
 
 int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *source, int source_dtype, int64_t K,
                  double *out) {
-    XR_API_BEGIN
+    {
+        const int rc = prepare_for_apply(csr, K);
+        if (rc != XR_OK) return rc;
+    }
+    XR_API_BEGIN_SHARED
     XR_REQUIRE(csr && (source || csr->m == 0 || K == 0) && (out || csr->n == 0 || K == 0), XR_ERR_INVALID,
                "xr_apply_csr: NULL argument");
     XR_REQUIRE(K >= 0, XR_ERR_INVALID, "xr_apply_csr: negative K");
@@ -2302,7 +2322,7 @@ int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,
                       reinterpret_cast<const float *>(src.get()), dst.get());
     }
     if (n_out > 0) {
-        XR_HIP(hipMemcpyAsync(out, dst.get(), n_out * sizeof(double), hipMemcpyDeviceToHost, engine().stream));
+        XR_HIP(hipMemcpyAsync(out, dst.get(), n_out * sizeof(double), hipMemcpyDeviceToHost, launch_stream()));
     }
     stream_sync();
     XR_API_END

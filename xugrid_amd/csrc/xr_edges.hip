@@ -446,7 +446,7 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     csr->m = n_edge;
     csr->nnz = 0;
     csr->indptr.alloc((size_t)F + 1);
-    hipStream_t st = engine().stream;
+    hipStream_t st = launch_stream();
     if (F == 0 || n_edge == 0) {
         XR_HIP(hipMemsetAsync(csr->indptr.get(), 0, sizeof(int32_t) * ((size_t)F + 1), st));
         csr->indices.alloc(0);

@@ -22,6 +22,71 @@ std::recursive_mutex &engine_mutex() {
     static std::recursive_mutex m;
     return m;
 }
+std::shared_mutex &engine_rw() {
+    static std::shared_mutex m;
+    return m;
+}
+
+// ---- exclusive / shared use of the engine ------------------------------------------------------------------------
+static thread_local int t_exclusive_depth = 0;
+static thread_local Lane *t_lane = nullptr;
+static constexpr int N_LANES = 4;
+static Lane g_lanes[N_LANES];
+static std::mutex g_pool_mutex; // the block pool and the kernel-timer tables are shared by all threads
+
+Lane *current_lane() { return t_lane; }
+
+ExclusiveScope::ExclusiveScope() {
+    if (t_exclusive_depth++ == 0) {
+        engine_mutex().lock();
+        engine_rw().lock();
+    }
+}
+ExclusiveScope::~ExclusiveScope() {
+    if (--t_exclusive_depth == 0) {
+        engine_rw().unlock();
+        engine_mutex().unlock();
+    }
+}
+
+static void lane_release_blocks(Lane *lane);
+
+SharedScope::SharedScope() {
+    if (t_exclusive_depth > 0 || t_lane) return; // nested inside another entry point: that one's context is used
+    engine_rw().lock_shared();
+    leased = true;
+    Engine &e = engine();
+    if (e.stream != e.own_stream) return; // bound to the caller's stream (xr_set_stream): ordered there, no lane
+    // a free lane, else wait for "this thread's" one
+    const size_t h = std::hash<std::thread::id>()(std::this_thread::get_id());
+    Lane *lane = nullptr;
+    for (int i = 0; i < N_LANES && !lane; i++) {
+        Lane &c = g_lanes[(h + i) % N_LANES];
+        if (c.busy.try_lock()) lane = &c;
+    }
+    if (!lane) {
+        lane = &g_lanes[h % N_LANES];
+        lane->busy.lock();
+    }
+    if (!lane->stream) {
+        if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) {
+            lane->busy.unlock();
+            return; // (no lane: the call runs on the engine's stream, still correct for one thread)
+        }
+    }
+    t_lane = lane;
+}
+SharedScope::~SharedScope() {
+    if (!leased) return;
+    if (t_lane) {
+        (void)hipStreamSynchronize(t_lane->stream); // the call is over: nothing of it is in flight
+        lane_release_blocks(t_lane);
+        Lane *lane = t_lane;
+        t_lane = nullptr;
+        lane->busy.unlock();
+    }
+    engine_rw().unlock_shared();
+}
 
 static Engine g_engine;
 
@@ -69,6 +134,8 @@ Engine &engine() {
 // ---------------------------------------------------------------------------------------------
 static std::map<void *, size_t> g_live;                  // ptr -> class size
 static std::multimap<size_t, void *> g_free;             // class size -> ptr
+// blocks freed by a thread on a lane: reused only by that lane (stream order) until the lane is drained
+static std::map<Lane *, std::multimap<size_t, void *>> g_lane_free;
 
 static size_t size_class(size_t bytes) {
     size_t b = bytes < 4096 ? 4096 : bytes;
@@ -86,8 +153,21 @@ static size_t size_class(size_t bytes) {
 void *pool_alloc(size_t bytes) {
     engine();
     size_t c = size_class(bytes);
-    auto it = g_free.find(c);
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     void *p = nullptr;
+    if (t_lane) {
+        auto &mine = g_lane_free[t_lane];
+        auto lt = mine.find(c);
+        if (lt != mine.end()) {
+            p = lt->second;
+            mine.erase(lt);
+            g_live[p] = c;
+            return p;
+        }
+    }
+    // (the common list only holds blocks nothing in flight touches: exclusive calls end synchronised, lanes hand their
+    // blocks over when drained)
+    auto it = g_free.find(c);
     if (it != g_free.end()) {
         p = it->second;
         g_free.erase(it);
@@ -96,7 +176,8 @@ void *pool_alloc(size_t bytes) {
         if (e != hipSuccess) {
             // give cached blocks back and retry once
             (void)hipGetLastError();
-            pool_trim();
+            for (auto &kv : g_free) (void)hipFree(kv.second);
+            g_free.clear();
             XR_HIP(hipMalloc(&p, c));
         }
     }
@@ -112,17 +193,27 @@ static std::vector<std::pair<size_t, void *>> g_deferred;
 
 void pool_free(void *p) {
     if (!p) return;
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
-    if (g_side_active) g_deferred.emplace_back(it->second, p);
+    if (t_lane) g_lane_free[t_lane].emplace(it->second, p);
+    else if (g_side_active) g_deferred.emplace_back(it->second, p);
     else g_free.emplace(it->second, p);
     g_live.erase(it);
 }
 
+static void lane_release_blocks(Lane *lane) {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    auto &mine = g_lane_free[lane];
+    for (auto &kv : mine) g_free.emplace(kv.first, kv.second);
+    mine.clear();
+}
+
 // called after the main stream has been synchronised with the host
 static void pool_release_deferred() {
-    if (!g_side_active) return;
+    if (!g_side_active || t_lane) return;
     (void)hipStreamSynchronize(g_engine.side);
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &kv : g_deferred) g_free.emplace(kv.first, kv.second);
     g_deferred.clear();
     g_side_active = false;
@@ -131,6 +222,7 @@ static void pool_release_deferred() {
 void pool_trim() {
     if (g_engine.stream) (void)hipStreamSynchronize(g_engine.stream);
     pool_release_deferred();
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &kv : g_free) (void)hipFree(kv.second);
     g_free.clear();
 }
@@ -144,8 +236,8 @@ void h2d(void *dst, const void *src, size_t bytes) {
         h2d_big(dst, src, bytes);
         return;
     }
-    XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, engine().stream));
-    XR_HIP(hipStreamSynchronize(engine().stream));
+    XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, launch_stream()));
+    XR_HIP(hipStreamSynchronize(launch_stream()));
 }
 
 void d2h(void *dst, const void *src, size_t bytes) {
@@ -161,12 +253,12 @@ void d2h(void *dst, const void *src, size_t bytes) {
         d2h_big(dst, src, bytes);
         return;
     }
-    XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, engine().stream));
-    XR_HIP(hipStreamSynchronize(engine().stream));
+    XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, launch_stream()));
+    XR_HIP(hipStreamSynchronize(launch_stream()));
 }
 
 void stream_sync() {
-    XR_HIP(hipStreamSynchronize(engine().stream));
+    XR_HIP(hipStreamSynchronize(launch_stream()));
     pool_release_deferred();
 }
 void dev_call_done() {
@@ -177,17 +269,19 @@ void dev_call_done() {
 // staged copies of large pageable host arrays
 // ---------------------------------------------------------------------------------------------
 static constexpr int STAGE_THREADS = 8;
-static char *g_stage[2] = {nullptr, nullptr};
-static hipEvent_t g_stage_ev[2] = {nullptr, nullptr};
+static Lane g_main_staging; // staging buffers of the engine's own path
 
-static void stage_init() {
-    if (g_stage[0]) return;
+// -> the staging buffers of the calling thread's lane (allocated on first use: 2 x 64 MiB of pinned host memory)
+static Lane &stage_init() {
+    Lane &l = t_lane ? *t_lane : g_main_staging;
+    if (l.stage[0]) return l;
     for (int i = 0; i < 2; i++) {
         void *p = nullptr;
         XR_HIP(hipHostMalloc(&p, STAGE_BYTES, hipHostMallocDefault));
-        g_stage[i] = static_cast<char *>(p);
-        XR_HIP(hipEventCreateWithFlags(&g_stage_ev[i], hipEventDisableTiming));
+        l.stage[i] = static_cast<char *>(p);
+        XR_HIP(hipEventCreateWithFlags(&l.stage_ev[i], hipEventDisableTiming));
     }
+    return l;
 }
 
 static void parallel_memcpy(char *dst, const char *src, size_t n) {
@@ -206,12 +300,14 @@ static void parallel_memcpy(char *dst, const char *src, size_t n) {
 
 void h2d_big(void *dst, const void *src, size_t bytes) {
     if (bytes < BIG_COPY_BYTES) {
-        XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, engine().stream));
-        XR_HIP(hipStreamSynchronize(engine().stream));
+        XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, launch_stream()));
+        XR_HIP(hipStreamSynchronize(launch_stream()));
         return;
     }
-    stage_init();
-    hipStream_t st = engine().stream;
+    Lane &sl = stage_init();
+    char **g_stage = sl.stage;
+    hipEvent_t *g_stage_ev = sl.stage_ev;
+    hipStream_t st = launch_stream();
     size_t off = 0;
     for (int i = 0; off < bytes; i ^= 1) {
         const size_t c = std::min(STAGE_BYTES, bytes - off);
@@ -226,12 +322,14 @@ void h2d_big(void *dst, const void *src, size_t bytes) {
 
 void d2h_big(void *dst, const void *src, size_t bytes) {
     if (bytes < BIG_COPY_BYTES) {
-        XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, engine().stream));
-        XR_HIP(hipStreamSynchronize(engine().stream));
+        XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, launch_stream()));
+        XR_HIP(hipStreamSynchronize(launch_stream()));
         return;
     }
-    stage_init();
-    hipStream_t st = engine().stream;
+    Lane &sl = stage_init();
+    char **g_stage = sl.stage;
+    hipEvent_t *g_stage_ev = sl.stage_ev;
+    hipStream_t st = launch_stream();
     const size_t n_piece = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
     auto piece = [&](size_t k) { return std::min(STAGE_BYTES, bytes - k * STAGE_BYTES); };
     XR_HIP(hipMemcpyAsync(g_stage[0], src, piece(0), hipMemcpyDeviceToHost, st));
@@ -272,6 +370,7 @@ static std::vector<Pending> g_pending;
 static std::vector<hipEvent_t> g_event_pool;
 
 static hipEvent_t get_event() {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     if (!g_event_pool.empty()) {
         hipEvent_t e = g_event_pool.back();
         g_event_pool.pop_back();
@@ -288,11 +387,13 @@ ProfScope::ProfScope(const char *n) : name(n) {
     e1 = get_event();
     (void)hipEventRecord(e0, launch_stream());
     on_side = g_engine.on_side;
+    lane_stream = t_lane ? t_lane->stream : nullptr;
 }
 
 ProfScope::~ProfScope() {
     if (!e0) return;
-    (void)hipEventRecord(e1, on_side ? g_engine.side : g_engine.stream);
+    (void)hipEventRecord(e1, lane_stream ? lane_stream : (on_side ? g_engine.side : g_engine.stream));
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     g_pending.push_back({name, e0, e1});
 }
 
@@ -316,6 +417,9 @@ void prof_flush() {
     if (g_pending.empty()) return;
     (void)hipStreamSynchronize(g_engine.stream);
     (void)hipStreamSynchronize(g_engine.side);
+    for (auto &l : g_lanes)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &p : g_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {

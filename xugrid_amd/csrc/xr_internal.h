@@ -9,6 +9,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -43,10 +44,17 @@ struct Failure {
         }                                                                                       \
     } while (0)
 
-// Every extern "C" entry point wraps its body:  XR_API_BEGIN ... XR_API_END
+// Every extern "C" entry point wraps its body:  XR_API_BEGIN ... XR_API_END.  XR_API_BEGIN holds the engine EXCLUSIVELY
+// (everything that builds or changes objects); the apply entry points use XR_API_BEGIN_SHARED instead: any number of
+// threads apply finished weights at the same time (dask's threaded scheduler calls _regrid from several threads,
+// regridder.py:177-185), each on a lane of its own -- a stream, staging buffers and a stream-ordered free list -- and
+// only wait for each other where they share a lane.
 #define XR_API_BEGIN                                                                            \
     try {                                                                                       \
-        std::lock_guard<std::recursive_mutex> _guard(xr::engine_mutex());
+        xr::ExclusiveScope _guard;
+#define XR_API_BEGIN_SHARED                                                                     \
+    try {                                                                                       \
+        xr::SharedScope _guard;
 #define XR_API_END                                                                              \
     return XR_OK;                                                                               \
     }                                                                                           \
@@ -59,6 +67,19 @@ struct Failure {
     }
 
 std::recursive_mutex &engine_mutex();
+std::shared_mutex &engine_rw();
+
+// exclusive use of the engine by this thread (re-entrant: entry points may call each other)
+struct ExclusiveScope {
+    ExclusiveScope();
+    ~ExclusiveScope();
+};
+// shared use: concurrent applies; takes a lane for the calling thread (see Lane below)
+struct SharedScope {
+    SharedScope();
+    ~SharedScope();
+    bool leased = false;
+};
 
 // ---------------------------------------------------------------------------------------------
 // engine context: one device + one stream per process
@@ -143,6 +164,7 @@ struct ProfScope {
     const char *name;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool on_side = false;
+    hipStream_t lane_stream = nullptr;
     explicit ProfScope(const char *name);
     ~ProfScope();
 };
@@ -155,7 +177,20 @@ void prof_flush(); // resolve pending events into the per-name table
         XR_HIP(hipGetLastError());                                                              \
     } while (0)
 
-inline hipStream_t launch_stream() { return engine().on_side ? engine().side : engine().stream; }
+// A lane: what a thread needs to use the device next to other threads.  Lane streams carry whole apply calls; a call
+// ends with the lane drained, so blocks a lane frees can go back to the common pool then.
+struct Lane {
+    hipStream_t stream = nullptr;
+    char *stage[2] = {nullptr, nullptr}; // pinned staging buffers of the big host <-> device copies
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    std::mutex busy;
+};
+Lane *current_lane(); // the calling thread's lane, nullptr on the engine's own (exclusive) path
+
+inline hipStream_t launch_stream() {
+    if (Lane *l = current_lane()) return l->stream;
+    return engine().on_side ? engine().side : engine().stream;
+}
 
 // RAII: launches inside the scope go to the side stream, which first waits for everything enqueued on the main
 // stream so far; join() makes the main stream wait for the side stream's work

@@ -519,7 +519,7 @@ int xr_replace_interpolated_weights(const double *vertices, int64_t n_vertex, co
     h2d(face.get(), face_index, sizeof(int64_t) * (size_t)n);
     h2d(fc.get(), faces, sizeof(int64_t) * (size_t)n_face * m);
     h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_map);
-    XR_HIP(hipMemsetAsync(inside.get(), 1, (size_t)n, engine().stream));
+    XR_HIP(hipMemsetAsync(inside.get(), 1, (size_t)n, launch_stream()));
     XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), (int)m,
               fc.get(), vxy.get(), n2n.get(), n_vertex - n_map, inside.get(), n, count.get());
     d2h(cm.data(), w.get(), sizeof(double) * cm.size());

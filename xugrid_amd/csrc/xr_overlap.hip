@@ -1147,7 +1147,7 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
 static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, const MortonParams &tile) {
     const int64_t T = query->n_face;
     const GridParams &g = tree->grid;
-    hipStream_t st = engine().stream;
+    hipStream_t st = launch_stream();
     const int64_t n_blocks = div_up(T, FB);
     const bool remap = xcd_remap_mask() & 2;
     const unsigned grid = xcd_grid(n_blocks, remap);
@@ -1271,13 +1271,13 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     csr->indptr.alloc((size_t)T + 1);
     tree->last_candidates = 0;
     if (T == 0 || S == 0) {
-        XR_HIP(hipMemsetAsync(csr->indptr.get(), 0, sizeof(int32_t) * ((size_t)T + 1), engine().stream));
+        XR_HIP(hipMemsetAsync(csr->indptr.get(), 0, sizeof(int32_t) * ((size_t)T + 1), launch_stream()));
         csr->indices.alloc(0);
         csr->data.alloc(0);
         return;
     }
     const GridParams &g = tree->grid;
-    hipStream_t st = engine().stream;
+    hipStream_t st = launch_stream();
     // Rows kept in the caller's (coherent, but typically strip-like) numbering get a coarse Morton key each:
     // tiles of 12-24 mean target extents, runs of TILE_RUN consecutive rows kept together.  A Morton-sorted query order is tiled already.
     MortonParams tile{};

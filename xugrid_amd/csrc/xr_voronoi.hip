@@ -298,7 +298,7 @@ int xr_voronoi_create(xr_mesh *mesh, xr_voronoi **out) {
         v->centroids.alloc((size_t)F * 2);
         DevBuf<uint8_t> on_boundary((size_t)N);
         DevBuf<int32_t> flag32((size_t)N), counters(4), e_lo((size_t)total), e_hi((size_t)total), e_face((size_t)total);
-        XR_HIP(hipMemsetAsync(on_boundary.get(), 0, (size_t)(N > 0 ? N : 1), engine().stream));
+        XR_HIP(hipMemsetAsync(on_boundary.get(), 0, (size_t)(N > 0 ? N : 1), launch_stream()));
         const int32_t init[4] = {0, INT32_MAX, 0, 0}; // n_edges, min degree, max degree
         h2d(counters.get(), init, sizeof(init));
         if (total > 0) {
@@ -458,7 +458,7 @@ int xr_voronoi_mesh(const xr_voronoi *v, const double *extra_xy, int64_t n_extra
         mesh->faces_raw.alloc((size_t)(n_cell * m));
         if (v->n_face > 0)
             XR_HIP(hipMemcpyAsync(mesh->node_xy.get(), v->centroids.get(), sizeof(double) * 2 * (size_t)v->n_face,
-                                  hipMemcpyDeviceToDevice, engine().stream));
+                                  hipMemcpyDeviceToDevice, launch_stream()));
         if (n_extra_vertex > 0)
             h2d(mesh->node_xy.get() + 2 * v->n_face, extra_xy, sizeof(double) * 2 * (size_t)n_extra_vertex);
         if (v->n_node > 0 && v->n_interior > 0)
