@@ -431,8 +431,12 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy):
             rg = xa.BarycentricInterpolator(src_g, tgt_g)
             E.dev_sync()
             times.append(time.perf_counter() - t0)
+        nnz_b, n_pts, S3, Ns3 = rg._device_weights.nnz, tgt_g.n_face, src_g.n_face, sxy.shape[0]
+        # B_bary = 16 n + 4 sum(M_v) + 16 N_vv + 4 sum(M_s) + 16 Ns + 16 nnz_b  with sum(M_v) ~ 3 S, N_vv ~ S
+        b_bary = 16 * n_pts + 12 * S3 + 16 * S3 + 12 * S3 + 16 * Ns3 + 16 * nnz_b
         out["config3_barycentric_1M_to_4M"] = {
             "construct_ms": 1e3 * min(times), "construct_ms_max_of_3": 1e3 * max(times),
+            "algorithmic_bytes": b_bary, "frac_of_hbm_peak": b_bary / min(times) / 1e9 / HBM_PEAK_GBS,
             "target_points_per_s": tgt_g.n_face / min(times), "nnz": rg._device_weights.nnz,
             "note": "source and target meshes resident; Voronoi pre-step (device + O(boundary) host part) + "
             "xr_barycentric_csr; the first constructions of a fresh process take longer (pool warm-up)",

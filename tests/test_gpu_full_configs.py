@@ -142,3 +142,42 @@ def test_bench_multi_gpu_path_10m_one_rank():
         line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])  # (RCCL prints banners)
         assert line["n_gpus"] == 1 and line["config"]["target_faces"] > 9_900_000
         assert line["value"] > 1e8 and line["config"]["nnz"] > 40_000_000
+
+
+def test_config3_barycentric_4m_targets(hip, oracle):
+    """BASELINE config 3 at its full size: 1M-triangle source, 4M target faces (their centroids are the 4M query
+    points, unstructured.py:147).  Size-independent properties of the whole weight matrix, and the oracle's
+    step-by-step restatement on a 150k-point sample of the same points: identical triplets."""
+    import xugrid_amd as xa
+    from test_gpu_regridder_api import _oracle_barycentric_triplets
+
+    sxy, sf = meshgen.triangle_mesh(500_000, 0, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(2_000_000, 2, 30.0, 0.7, delaunay=False)
+    src = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    dcsr = xa.regrid.UnstructuredGrid2d(src).barycentric_device(xa.regrid.UnstructuredGrid2d(tgt))
+    data, indices, indptr = dcsr.download()
+    n = tf.shape[0]
+    assert dcsr.n == n > 3_900_000 and dcsr.m == sf.shape[0] and data.size == dcsr.nnz > 20_000_000
+    counts = np.diff(indptr)
+    assert (counts >= 1).all() and counts.max() <= 32  # every target centroid lies inside the source mesh
+    assert (data > 0).all() and indices.min() >= 0 and indices.max() < dcsr.m
+    # barycentric weights sum to one -- except in the concave exterior Voronoi cells, where the generalised weights have
+    # negative components that the reference drops (unstructured.py:191-198: weights > 0 only; `mean` renormalises)
+    sums = np.add.reduceat(data, indptr[:-1])
+    assert (np.abs(sums - 1.0) < 1e-12).mean() > 0.999 and sums.min() > 0
+    # linear fields are reproduced at interior points (barycentric interpolation is exact for them): v = 2x - 3y + 1
+    cen_s = oracle.centroids(sxy, sf)
+    cen_t = oracle.centroids(txy, tf)
+    lin = dcsr.apply((2.0 * cen_s[:, 0] - 3.0 * cen_s[:, 1] + 1.0)[None, :], 0)[0]
+    interior = counts >= 3
+    err = np.abs(lin - (2.0 * cen_t[:, 0] - 3.0 * cen_t[:, 1] + 1.0))[interior]
+    assert np.percentile(err, 99.9) < 1e-9
+    # oracle on a sample of the query points
+    rng = np.random.default_rng(3)
+    sample = np.sort(rng.choice(n, 150_000, replace=False))
+    os_, ot, ow = _oracle_barycentric_triplets(oracle, src, cen_t[sample])
+    cnt = counts[sample]
+    flat = np.repeat(indptr[sample] - (np.cumsum(cnt) - cnt), cnt) + np.arange(cnt.sum())
+    assert np.array_equal(np.bincount(ot, minlength=sample.size), cnt), "row lengths differ from the oracle"
+    assert np.array_equal(indices[flat], os_) and np.array_equal(data[flat], ow)
