@@ -59,11 +59,45 @@ __device__ __forceinline__ void face_shape(const double *__restrict__ node_xy, c
     }
 }
 
+// connectivity.area on the caller's order (connectivity.py:372-382, 615-633): fill slots and the closing slot
+// repeat node 0; everything relative to node 0.  Only `relative` overlap weights and xr_mesh_area read it, so it
+// is computed on demand (mesh_area) and not by the preparation pass.
 template <int MC>
+__global__ void __launch_bounds__(256)
+k_face_area(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face, int m_rt,
+            double *__restrict__ area) {
+    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
+    const int m = MC > 0 ? MC : m_rt;
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_face) return;
+    int face[MA];
+#pragma unroll
+    for (int j = 0; j < MA; j++)
+        if (j < m) face[j] = faces_raw[f * m + j];
+    const P2 p0 = load_p2(node_xy, face[0]);
+    double det = 0.0;
+#pragma unroll
+    for (int i = 0; i < MA; i++) {
+        if (i < m) {
+            const int ia = face[i] < 0 ? face[0] : face[i];
+            int ib = face[0];
+            if (i + 1 < m) ib = face[i + 1] < 0 ? face[0] : face[i + 1];
+            const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib);
+            const double ax = a.x - p0.x, ay = a.y - p0.y;
+            const double bx = b.x - p0.x, by = b.y - p0.y;
+            det += ax * by - ay * bx;
+        }
+    }
+    area[f] = 0.5 * fabs(det);
+}
+
+// LIGHT: statistics only (a mesh that is only ever the TREE: its records are built from the raw mesh by
+// k_spatial_scatter, nothing reads caller-order per-face arrays)
+template <int MC, bool LIGHT>
 __global__ void __launch_bounds__(PREP_BLOCK)
 k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face,
                 int m_rt, double *__restrict__ fxy, uint8_t *__restrict__ len_out, double *__restrict__ bbox,
-                double *__restrict__ area, double *__restrict__ partials) {
+                double *__restrict__ partials) {
     constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * PREP_BLOCK + threadIdx.x;
@@ -75,29 +109,10 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
         for (int j = 0; j < MA; j++)
             if (j < m) face[j] = faces_raw[f * m + j];
 
-        // connectivity.area on the caller's order (connectivity.py:372-382, 615-633):
-        // fill slots and the closing slot repeat node 0; everything relative to node 0.
-        {
-            const P2 p0 = load_p2(node_xy, face[0]);
-            double det = 0.0;
-#pragma unroll
-            for (int i = 0; i < MA; i++) {
-                if (i < m) {
-                    const int ia = face[i] < 0 ? face[0] : face[i];
-                    int ib = face[0];
-                    if (i + 1 < m) ib = face[i + 1] < 0 ? face[0] : face[i + 1];
-                    const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib);
-                    const double ax = a.x - p0.x, ay = a.y - p0.y;
-                    const double bx = b.x - p0.x, by = b.y - p0.y;
-                    det += ax * by - ay * bx;
-                }
-            }
-            area[f] = 0.5 * fabs(det);
-        }
         int n;
         bool flip;
         face_shape<MA>(node_xy, face, m, n, flip);
-        len_out[f] = (uint8_t)n;
+        if (!LIGHT) len_out[f] = (uint8_t)n;
         double2 *fx = reinterpret_cast<double2 *>(fxy) + f * m;
 #pragma unroll
         for (int j = 0; j < MA; j++) {
@@ -107,11 +122,10 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
                 xmax = fmax(xmax, p.x);
                 ymin = fmin(ymin, p.y);
                 ymax = fmax(ymax, p.y);
-                if (fxy) fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y); // (tree-only meshes skip this array)
+                if (!LIGHT && fxy) fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
             }
         }
-        double4 *bb = reinterpret_cast<double4 *>(bbox);
-        bb[f] = make_double4(xmin, xmax, ymin, ymax);
+        if (!LIGHT) reinterpret_cast<double4 *>(bbox)[f] = make_double4(xmin, xmax, ymin, ymax);
         ext = fmax(xmax - xmin, ymax - ymin);
         const double dx = xmax - xmin, dy = ymax - ymin;
         diag = sqrt(dx * dx + dy * dy);
@@ -208,80 +222,39 @@ __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__
     }
 }
 
-// caller-order vertex blocks for a mesh that was prepared without them (tree-only so far) and now becomes a
-// query kept in its own numbering
-template <int MC>
-__global__ void __launch_bounds__(256)
-k_face_coords(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face, int m_rt,
-              double *__restrict__ fxy) {
-    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
-    const int m = MC > 0 ? MC : m_rt;
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_face) return;
-    int face[MA];
-#pragma unroll
-    for (int j = 0; j < MA; j++)
-        if (j < m) face[j] = faces_raw[f * m + j];
-    int n;
-    bool flip;
-    face_shape<MA>(node_xy, face, m, n, flip);
-    double2 *fx = reinterpret_cast<double2 *>(fxy) + f * m;
-#pragma unroll
-    for (int j = 0; j < MA; j++) {
-        if (j < n) {
-            const P2 p = load_p2(node_xy, face[j]);
-            fx[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
-        }
-    }
-}
-
-void mesh_face_coords(xr_mesh *mesh) {
-    mesh_prepare(mesh, true);
-    if (mesh->fxy_valid) return;
-    const int64_t F = mesh->n_face;
-    mesh->fxy.alloc((size_t)F * mesh->m * 2);
-    if (F > 0) {
-        const dim3 grid(div_up(F, 256)), block(256);
-        if (mesh->m == 3)
-            XR_LAUNCH("face_coords", k_face_coords<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
-                      mesh->fxy.get());
-        else if (mesh->m == 4)
-            XR_LAUNCH("face_coords", k_face_coords<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
-                      mesh->fxy.get());
-        else
-            XR_LAUNCH("face_coords", k_face_coords<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
-                      mesh->fxy.get());
-    }
-    mesh->fxy_valid = true;
-}
+void mesh_face_coords(xr_mesh *mesh) { mesh_prepare(mesh, true); }
 
 void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
-    if (mesh->prepared) return;
+    // two depths: statistics only (want_fxy = false: the mesh is used as a tree) or statistics + the caller-order
+    // len / bbox / vertex blocks a query needs.  A mesh prepared light and later used as a query is prepared again.
+    if (mesh->prepared && (mesh->has_attrs || !want_fxy)) return;
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
-    if (want_fxy) mesh->fxy.alloc((size_t)F * m * 2);
-    else mesh->fxy.release();
+    if (want_fxy) {
+        mesh->fxy.alloc((size_t)F * m * 2);
+        mesh->len.alloc((size_t)F);
+        mesh->bbox.alloc((size_t)F * 4);
+    }
     mesh->fxy_valid = want_fxy;
-    mesh->len.alloc((size_t)F);
-    mesh->bbox.alloc((size_t)F * 4);
-    mesh->area.alloc((size_t)F);
+    mesh->has_attrs = want_fxy;
     mesh->stats.alloc(8);
     const int64_t nb = std::max<int64_t>(1, (F + PREP_BLOCK - 1) / PREP_BLOCK);
     DevBuf<double> partials((size_t)nb * 8);
     dim3 grid((unsigned)nb), block(PREP_BLOCK);
-    if (m == 3) {
-        XR_LAUNCH("prepare_faces", k_prepare_faces<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  want_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(), mesh->bbox.get(), mesh->area.get(),
-                  partials.get());
-    } else if (m == 4) {
-        XR_LAUNCH("prepare_faces", k_prepare_faces<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  want_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(), mesh->bbox.get(), mesh->area.get(),
-                  partials.get());
-    } else {
-        XR_LAUNCH("prepare_faces", k_prepare_faces<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, m,
-                  want_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(), mesh->bbox.get(), mesh->area.get(),
-                  partials.get());
-    }
+#define XR_PREP(MC)                                                                                                    \
+    do {                                                                                                               \
+        if (want_fxy)                                                                                                  \
+            XR_LAUNCH("prepare_faces", (k_prepare_faces<MC, false>), grid, block, 0, mesh->node_xy.get(),              \
+                      mesh->faces_raw.get(), F, m, mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), partials.get()); \
+        else                                                                                                           \
+            XR_LAUNCH("prepare_stats", (k_prepare_faces<MC, true>), grid, block, 0, mesh->node_xy.get(),               \
+                      mesh->faces_raw.get(), F, m, (double *)nullptr, (uint8_t *)nullptr, (double *)nullptr,           \
+                      partials.get());                                                                                 \
+    } while (0)
+    if (m == 3) XR_PREP(3);
+    else if (m == 4) XR_PREP(4);
+    else XR_PREP(0);
+#undef XR_PREP
     if (!mesh->stats_host) {
         void *p = nullptr;
         XR_HIP(hipHostMalloc(&p, sizeof(double) * 8, hipHostMallocCoherent));
@@ -295,8 +268,28 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
     mesh->stats_valid = false;
 }
 
+const double *mesh_area(xr_mesh *mesh) {
+    if (mesh->area_valid) return mesh->area.get();
+    const int64_t F = mesh->n_face;
+    mesh->area.alloc((size_t)F);
+    if (F > 0) {
+        const dim3 grid(div_up(F, 256)), block(256);
+        if (mesh->m == 3)
+            XR_LAUNCH("face_area", k_face_area<3>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
+                      mesh->area.get());
+        else if (mesh->m == 4)
+            XR_LAUNCH("face_area", k_face_area<4>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
+                      mesh->area.get());
+        else
+            XR_LAUNCH("face_area", k_face_area<0>, grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F, mesh->m,
+                      mesh->area.get());
+    }
+    mesh->area_valid = true;
+    return mesh->area.get();
+}
+
 void mesh_read_stats(xr_mesh *mesh) {
-    mesh_prepare(mesh);
+    mesh_prepare(mesh, false);
     if (mesh->stats_valid) return;
     XR_HIP(hipEventSynchronize(mesh->stats_event));
     for (int i = 0; i < 8; i++) mesh->h_stats[i] = mesh->stats_host[i];
@@ -325,13 +318,32 @@ __device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
     return g.base[l] + cy * g.nx[l] + cx;
 }
 
-template <bool INDEX>
-__global__ void __launch_bounds__(256) k_spatial_count(const double *__restrict__ bbox, int64_t n, GridParams g,
-                                                      MortonParams mp, int32_t *__restrict__ key,
-                                                      int32_t *__restrict__ count) {
+// (the bbox comes from the raw mesh, like in the scatter pass: node gathers hit the L2-resident node array)
+template <bool INDEX, int MC>
+__global__ void __launch_bounds__(256)
+k_spatial_count(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n, int m_rt,
+                GridParams g, MortonParams mp, int32_t *__restrict__ key, int32_t *__restrict__ count) {
+    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
+    const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n) return;
-    const double4 bb = reinterpret_cast<const double4 *>(bbox)[f];
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    bool open = true;
+#pragma unroll
+    for (int j = 0; j < MA; j++) {
+        if (j < m) {
+            const int v = faces_raw[f * m + j];
+            open = open && !(j >= 3 && v < 0); // polygon_length: stop at the first fill value
+            if (open) {
+                const P2 p = load_p2(node_xy, v);
+                xmin = fmin(xmin, p.x);
+                xmax = fmax(xmax, p.x);
+                ymin = fmin(ymin, p.y);
+                ymax = fmax(ymax, p.y);
+            }
+        }
+    }
+    const double4 bb = make_double4(xmin, xmax, ymin, ymax);
     const int k = INDEX ? face_cell(g, bb) : morton_key(mp, bb);
     key[f] = k;
     atomicAdd(&count[k], 1);
@@ -392,9 +404,19 @@ static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams 
     const int64_t F = mesh->n_face;
     DevBuf<int32_t> key((size_t)F), count((size_t)n_buckets);
     XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, launch_stream()));
-    if (F > 0)
-        XR_LAUNCH(INDEX ? "index_count" : "order_count", k_spatial_count<INDEX>, dim3(div_up(F, 256)), dim3(256), 0,
-                  mesh->bbox.get(), F, g, mp, key.get(), count.get());
+    if (F > 0) {
+        const char *name = INDEX ? "index_count" : "order_count";
+        const dim3 grid(div_up(F, 256)), block(256);
+        if (mesh->m == 3)
+            XR_LAUNCH(name, (k_spatial_count<INDEX, 3>), grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F,
+                      mesh->m, g, mp, key.get(), count.get());
+        else if (mesh->m == 4)
+            XR_LAUNCH(name, (k_spatial_count<INDEX, 4>), grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F,
+                      mesh->m, g, mp, key.get(), count.get());
+        else
+            XR_LAUNCH(name, (k_spatial_count<INDEX, 0>), grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F,
+                      mesh->m, g, mp, key.get(), count.get());
+    }
     exclusive_scan_i32(count.get(), bucket_start, n_buckets);
     if (F > 0) {
         const char *name = INDEX ? "index_scatter" : "order_scatter";
@@ -712,6 +734,8 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_invalidate: NULL mesh");
     stream_sync();
     mesh->prepared = false;
+    mesh->has_attrs = false;
+    mesh->area_valid = false;
     mesh->fxy_valid = false;
     mesh->query_ready = false;
     mesh->query_identity = false;
@@ -727,9 +751,9 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
 int xr_mesh_area(xr_mesh *mesh, double *area_out) {
     XR_API_BEGIN
     XR_REQUIRE(mesh && area_out, XR_ERR_INVALID, "xr_mesh_area: NULL argument");
-    mesh_prepare(mesh);
+    const double *area = mesh_area(mesh);
     if (mesh->n_face > 0) {
-        d2h(area_out, mesh->area.get(), sizeof(double) * (size_t)mesh->n_face);
+        d2h(area_out, area, sizeof(double) * (size_t)mesh->n_face);
     }
     stream_sync();
     XR_API_END

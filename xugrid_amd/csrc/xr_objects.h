@@ -19,13 +19,15 @@ struct xr_mesh {
     xr::DevBuf<int32_t> faces_raw; // [n_face*m] caller's vertex order, fill -> -1
 
     // ---- prepared (caller's face order)
-    bool prepared = false;
+    bool prepared = false;  // statistics known
+    bool has_attrs = false; // ... and len / bbox / fxy filled (prepared as a query)
+    bool area_valid = false;
     xr::DevBuf<double> fxy;   // [n_face*m*2] CCW-normalised vertex coordinates per face (only if fxy_valid:
                               // needed when the mesh is a query kept in the caller's numbering)
     bool fxy_valid = false;
     xr::DevBuf<uint8_t> len;  // [n_face]
     xr::DevBuf<double> bbox;  // [n_face*4] xmin,xmax,ymin,ymax
-    xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order
+    xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order (mesh_area, on demand)
     xr::DevBuf<double> stats; // [8] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal,sum_jump (device)
     bool stats_valid = false;
     double h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -126,6 +128,7 @@ struct xr_outer {
 
 namespace xr {
 void mesh_prepare(xr_mesh *mesh, bool want_fxy = true);
+const double *mesh_area(xr_mesh *mesh); // connectivity.area in the caller's face order (computed on first use)
 void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex blocks exist
 void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);

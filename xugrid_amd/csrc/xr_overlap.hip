@@ -1144,7 +1144,8 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
 // faces of the search (hull slivers ...) on a side stream, their rows stored behind the regular ones; ONE host round
 // trip at the very end (sizes + error bits).  -> false if the pair has to go through the general pipeline after all
 // (a clip that needs more than 6 vertices: floating-point degenerate input; or the look-back chain gave up).
-static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, const MortonParams &tile) {
+static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, bool relative, xr_csr *csr,
+                        const MortonParams &tile) {
     const int64_t T = query->n_face;
     const GridParams &g = tree->grid;
     hipStream_t st = launch_stream();
@@ -1212,7 +1213,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *cs
             XR_LAUNCH("big_scan", k_big_scan, dim3(1), dim3(256), 0, slot_face.get(), ctl.get() + 2, nnz_row.get(),
                       big_indptr.get(), fc, ctl.get() + 3);
             XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
-                      cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree->area.get(), relative,
+                      cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
                       tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3);
         }
         static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5; // tuning hook: persistent blocks per CU
@@ -1222,7 +1223,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *cs
                   (const int32_t *)nullptr);
         XR_LAUNCH("assemble", k_assemble, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
                   cand_off.get(), cand_count.get(), block_seg.get(), is_big.get(), cand_area.get(), cand_sid.get(),
-                  tree->area.get(), relative, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc,
+                  tree_area, relative, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc,
                   status, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
                   csr->long_rows.get(), cap, remap);
         side_join();
@@ -1263,6 +1264,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     mesh_prepare(query, true);
     mesh_build_index(tree);
     mesh_query_order(query);
+    const double *tree_area = relative ? mesh_area(tree) : nullptr;
     const int64_t T = query->n_face, S = tree->n_face;
     XR_REQUIRE(T < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "too many query faces for int32 row offsets");
     csr->n = T;
@@ -1303,7 +1305,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         // triangle x triangle: clip + assembly in one kernel (XR_OVERLAP_FUSED=0: measurement switch back to the kernel chain)
         static const bool fused_on = !(getenv("XR_OVERLAP_FUSED") && atoi(getenv("XR_OVERLAP_FUSED")) == 0);
         if (fused_on && tree->m == 3 && query->m == 3 && T * SLOTS < ((int64_t)1 << 31)) {
-            if (overlap_tri(tree, query, relative, csr, tile)) return;
+            if (overlap_tri(tree, query, tree_area, relative, csr, tile)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
         }
     }
@@ -1402,7 +1404,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->has_long = true;
         XR_HIP(hipMemsetAsync(csr->n_long.get(), 0, sizeof(int32_t), st));
         XR_LAUNCH("row_fill", k_row_fill, dim3(xcd_grid(div_up(T, 256), remap_rows)), dim3(256), 0, cand_off.get(), cand_count.get(),
-                  block_seg.get(), is_big.get(), cand_tgt.get(), cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree->area.get(), relative,
+                  block_seg.get(), is_big.get(), cand_tgt.get(), cand_sid.get(), cand_area.get(), T, csr->indptr.get(), tree_area, relative,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, csr->long_rows.get(),
                   csr->n_long.get(), remap_rows);
         const size_t shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
@@ -1413,7 +1415,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
             attr_set = true;
         }
         XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), shmem, cand_off.get(),
-                  cand_count.get(), cand_sid.get(), cand_area.get(), csr->indptr.get(), tree->area.get(), relative, tree->n_face,
+                  cand_count.get(), cand_sid.get(), cand_area.get(), csr->indptr.get(), tree_area, relative, tree->n_face,
                   csr->indices.get(), csr->data.get(), long_rows.get(), counters.get() + 1, (int64_t)-1, (const int32_t *)nullptr);
     }
 }
