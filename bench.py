@@ -92,6 +92,19 @@ def source_sha():
     return h.hexdigest()
 
 
+def usable_cores(n_threads):
+    """Threads worth starting: the scheduler affinity and the cgroup CPU quota of this container bound what OpenMP's
+    default (one thread per visible processor) can actually use -- 256 threads on a 16-CPU quota run SLOWER than 16."""
+    n = min(n_threads, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(sxy, sf, txy, tf, data):
     """The CPU oracle (oracle/xr_oracle.c: cell tree + SAT + Sutherland-Hodgman + CSR + mean apply) timed on this
     box's host cores, SURVEY.md section 8(d):
@@ -104,7 +117,8 @@ def cpu_baseline(sxy, sf, txy, tf, data):
     from oracle import oracle as O
 
     O.build()
-    cores = O.num_threads()
+    cores = usable_cores(O.num_threads())
+    O.set_num_threads(cores)
     T = tf.shape[0]
     t0 = time.perf_counter()
     tree = O.CellTree2d(sxy, sf)

@@ -9,6 +9,7 @@
  */
 #include "xr_oracle.h"
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -733,7 +734,16 @@ static int64_t tree_query_box_ex(const xo_tree *t, Box q, int64_t *out, int clos
     return cnt;
 }
 
+static int cmp_i64(const void *x, const void *y) {
+    const int64_t a = *(const int64_t *)x, b = *(const int64_t *)y;
+    return (a > b) - (a < b);
+}
+
 static void isort64(int64_t *a, int64_t n) {
+    if (n > 64) { /* hull slivers collect thousands of candidates: insertion sort would dominate the whole search */
+        qsort(a, (size_t)n, sizeof(int64_t), cmp_i64);
+        return;
+    }
     for (int64_t i = 1; i < n; i++) {
         int64_t v = a[i], j = i - 1;
         while (j >= 0 && a[j] > v) {
@@ -892,7 +902,11 @@ int xo_intersect_faces_count(xo_tree *t, const double *q_xy, int64_t q_n_node,
     (void)q_n_node;
     if (t->m > XO_MAXV / 2 || q_m > XO_MAXV / 2) return -2;
     QMesh q;
+    const int timing = getenv("XO_TIMING") != NULL;
+    double tt[8];
+    tt[0] = omp_get_wtime();
     qmesh_init(&q, q_xy, q_faces, q_n_face, q_m, q_fill);
+    tt[1] = omp_get_wtime();
     /* pass 1: count bbox candidates per query face (parallel over queries) */
     int64_t *off = (int64_t *)calloc((size_t)q_n_face + 1, sizeof(int64_t));
 #pragma omp parallel for schedule(dynamic, 256)
@@ -900,6 +914,7 @@ int xo_intersect_faces_count(xo_tree *t, const double *q_xy, int64_t q_n_node,
     for (int64_t i = 0; i < q_n_face; i++) off[i + 1] += off[i];
     int64_t C = off[q_n_face];
     if (n_candidates) *n_candidates = C;
+    tt[2] = omp_get_wtime();
     int64_t *cq = (int64_t *)malloc(sizeof(int64_t) * (size_t)(C > 0 ? C : 1));
     int64_t *cs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(C > 0 ? C : 1));
     double *ca = (double *)malloc(sizeof(double) * (size_t)(C > 0 ? C : 1));
@@ -910,6 +925,7 @@ int xo_intersect_faces_count(xo_tree *t, const double *q_xy, int64_t q_n_node,
         isort64(cs + off[i], n);
         for (int64_t j = 0; j < n; j++) cq[off[i] + j] = i;
     }
+    tt[3] = omp_get_wtime();
     /* pass 3: SAT filter + clip + area, parallel over candidate pairs */
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int64_t c = 0; c < C; c++) {
@@ -922,6 +938,7 @@ int xo_intersect_faces_count(xo_tree *t, const double *q_xy, int64_t q_n_node,
         }
         ca[c] = clip_polygons(a, na, b, nb);
     }
+    tt[4] = omp_get_wtime();
     /* pass 4: keep area > 0 */
     int64_t P = 0;
     for (int64_t c = 0; c < C; c++)
@@ -942,6 +959,10 @@ int xo_intersect_faces_count(xo_tree *t, const double *q_xy, int64_t q_n_node,
     qmesh_free(&q);
     store_result(t, P, rq, rs, ra);
     *nnz = P;
+    tt[5] = omp_get_wtime();
+    if (timing)
+        fprintf(stderr, "[xo] intersect_faces %d threads: normalise %.3f count %.3f fill %.3f clip %.3f compact %.3f s\n",
+                omp_get_max_threads(), tt[1] - tt[0], tt[2] - tt[1], tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
     return 0;
 }
 
