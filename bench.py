@@ -70,9 +70,10 @@ def kernel_model_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
     kept under `roofline.kernel_model` to show where the bytes beyond section 8(d) come from."""
     vs, vt = 16 * Ms, 16 * Mt
     return {
-        "prepare_faces": 4 * (Ms * S + Mt * T) + 16 * (Ns + Nt) + (vs + 1 + 32 + 8) * S + (vt + 1 + 32 + 8) * T,
-        "index_count": 32 * S + 4 * S,
-        "index_scatter": (4 + vs + 1 + 32) * S + (4 + vs + 1 + 16) * S,
+        "prepare_stats": 4 * Ms * S + 16 * Ns,                      # tree side: statistics only
+        "prepare_faces": 4 * Mt * T + 16 * Nt + (vt + 1 + 32) * T,   # query side: vertex blocks, length, bbox
+        "index_count": 4 * Ms * S + 16 * Ns + 4 * S,
+        "index_scatter": 4 * S + 4 * Ms * S + 16 * Ns + (4 + vs + 1 + 16) * S,
         "search": 32 * T + 16 * S + 8 * T + 8 * C,
         "clip_tri": 8 * C + vt * T + vs * S + 4 * S + 12 * C,
         "assemble": 16 * C + 8 * T + 8 * T + 12 * P + 4 * T,

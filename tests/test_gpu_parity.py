@@ -152,6 +152,24 @@ def test_overlap_queue_regrow_path(hip, oracle, monkeypatch):
     assert_overlap_parity(hip, oracle, sxy, sf, mxy, mf)
 
 
+def test_overlap_fused_matches_general_chain(hip, monkeypatch):
+    """triangle x triangle pairs take the single-round-trip pipeline (persistent clip, look-back assembly, big faces on a
+    side stream); XR_OVERLAP_FUSED=0 sends the same meshes through the general chain (search -> clip -> scan -> row_fill):
+    identical CSR, absolute and relative weights."""
+    sxy, sf = meshgen.triangle_mesh(40000, 11)
+    txy, tf = meshgen.triangle_mesh(30000, 12, 25.0, 0.8)
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("XR_OVERLAP_FUSED", mode)
+        for relative in (False, True):
+            results[mode, relative] = gpu_triplets(hip, sxy, sf, txy, tf, relative)[2:]
+    for relative in (False, True):
+        a, b = results["1", relative], results["0", relative]
+        assert a[0].size > 100000
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
 def test_overlap_graded_mesh_many_levels(hip, oracle):
     """face sizes spanning 4 orders of magnitude -> many grid levels."""
     rng = np.random.default_rng(9)

@@ -1302,8 +1302,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         csr->has_tile_key = bits > 0;
     }
     {
-        // triangle x triangle: clip + assembly in one kernel (XR_OVERLAP_FUSED=0: measurement switch back to the kernel chain)
-        static const bool fused_on = !(getenv("XR_OVERLAP_FUSED") && atoi(getenv("XR_OVERLAP_FUSED")) == 0);
+        // triangle x triangle: the single-round-trip pipeline of xr_overlap_fused.h (XR_OVERLAP_FUSED=0, read per call:
+        // measurement / test switch back to the general kernel chain)
+        const char *fused_env = getenv("XR_OVERLAP_FUSED");
+        const bool fused_on = !(fused_env && atoi(fused_env) == 0);
         if (fused_on && tree->m == 3 && query->m == 3 && T * SLOTS < ((int64_t)1 << 31)) {
             if (overlap_tri(tree, query, tree_area, relative, csr, tile)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
