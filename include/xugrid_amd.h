@@ -112,6 +112,9 @@ int xr_mesh_create_rectilinear(const double *x_vertices, int64_t nx, const doubl
                                xr_mesh **out);
 int xr_mesh_destroy(xr_mesh *mesh);
 int xr_mesh_info(const xr_mesh *mesh, int64_t *n_node, int64_t *n_face, int64_t *n_max_node);
+/* HBM currently held by the handle (raw arrays, prepared arrays, query order, tree index).  Vertex blocks of meshes with
+ * more than 4 nodes per face are stored flat with offsets (sum of the real polygon lengths, not n_face * n_max_node). */
+int xr_mesh_device_bytes(const xr_mesh *mesh, int64_t *bytes);
 /* Per-face preparation on the device: fill->-1, polygon length, CCW normalisation, bbox, area. */
 int xr_mesh_prepare(xr_mesh *mesh);
 /* Spatial index over the faces of this mesh (the "tree" side): hierarchical uniform grid. */

@@ -109,6 +109,47 @@ def test_overlap_polygons_up_to_hexagons(hip, oracle):
     assert_overlap_parity(hip, oracle, txy, tf, v, cells)
 
 
+def test_polygon_meshes_flat_vertex_blocks(hip, oracle):
+    """Meshes with more than 4 nodes per face keep their vertex blocks FLAT with offsets (xr_geom.h): one 32-gon among
+    60k triangles must not cost n_face * 32 * 16 bytes three times over.  Overlap (both roles, caller-coherent and shuffled
+    numbering), locate and the network-edge lengths agree with the oracle bit for bit on such a mesh."""
+    E = hip.engine
+    xy, faces = meshgen.triangle_mesh(30_000, 21)
+    F = faces.shape[0]
+    # a regular 32-gon far outside the unit square, appended as one more face of a 32-wide connectivity table
+    ang = 2 * np.pi * np.arange(32) / 32
+    gon = np.column_stack([3.0 + 0.5 * np.cos(ang), 0.5 + 0.5 * np.sin(ang)])
+    pxy = np.vstack([xy, gon])
+    pf = np.full((F + 1, 32), -1, dtype=np.int64)
+    pf[:F, :3] = faces
+    pf[F] = np.arange(32) + xy.shape[0]
+    txy, tf = meshgen.triangle_mesh(20_000, 22, 15.0, 0.9)
+    txy = np.vstack([txy, [[2.4, 0.0], [3.6, 0.1], [3.1, 1.1]]])  # + one triangle over the 32-gon
+    tf = np.vstack([tf, [[txy.shape[0] - 3, txy.shape[0] - 2, txy.shape[0] - 1]]])
+
+    assert_overlap_parity(hip, oracle, pxy, pf, txy, tf)          # polygon mesh as the tree
+    csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, txy, tf, pxy, pf)   # ... and as the query
+    assert indptr[F + 1] - indptr[F] >= 1                         # the 32-gon meets its triangle
+    perm = np.random.default_rng(3).permutation(F + 1)            # incoherent numbering: Morton query order, flat too
+    assert_overlap_parity(hip, oracle, txy, tf, pxy, pf[perm])
+    assert_overlap_parity(hip, oracle, pxy, pf[perm], txy, tf, relative=True)
+
+    mesh = E.DeviceMesh(pxy, pf)
+    pts = np.vstack([np.random.default_rng(4).random((5000, 2)), gon.mean(axis=0)[None, :] + [[0.0, 0.0], [0.2, 0.1]]])
+    tree = oracle.CellTree2d(pxy, pf)
+    assert np.array_equal(mesh.locate_points(pts), tree.locate_points(pts))
+    from test_gpu_network import device_vs_oracle
+
+    edges = np.random.default_rng(5).random((3000, 2, 2)) * [3.8, 1.0]
+    device_vs_oracle(oracle, pxy, pf, edges)
+
+    # memory: raw table (4 B per slot) + flat blocks; dense blocks alone would be (F + 1) * 32 * 16 B per copy
+    mesh.build_index()
+    E.DeviceMesh(txy, tf).overlap(mesh)   # (also prepares `mesh` as a query: caller-order blocks)
+    dense_copy = (F + 1) * 32 * 16
+    assert mesh.device_bytes() < 0.6 * dense_copy, (mesh.device_bytes(), dense_copy)
+
+
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
 def test_overlap_rectilinear_goldens(hip, golden, tag):
     """HIP clip of quads == the reference's separable structured overlap (golden G4)."""

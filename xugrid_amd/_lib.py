@@ -48,6 +48,7 @@ SIGNATURES = {
     "xr_mesh_create_rectilinear": (c_int, [vp, c_i64, vp, c_i64, p_vp]),
     "xr_mesh_destroy": (c_int, [vp]),
     "xr_mesh_info": (c_int, [vp, p_i64, p_i64, p_i64]),
+    "xr_mesh_device_bytes": (c_int, [vp, p_i64]),
     "xr_mesh_prepare": (c_int, [vp]),
     "xr_mesh_build_index": (c_int, [vp]),
     "xr_mesh_invalidate": (c_int, [vp]),

@@ -97,12 +97,12 @@ __device__ __forceinline__ int64_t edge_cells(const EdgeBox &q, const GridParams
 // the records of one grid cell against the edge; HIT(face id, length) for every kept pair
 template <typename Hit>
 __device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, const float4 *__restrict__ rbb,
-                                          const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+                                          const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
                                           int m, const int32_t *__restrict__ rec_face, Hit &&hit) {
     for (int r = r0; r < r1; r++) {
         const float4 bb = rbb[r];
         if (!(q.qx0 <= bb.y && bb.x <= q.qx1 && q.qy0 <= bb.w && bb.z <= q.qy1)) continue;
-        const double len = cyrus_beck_length(rec_fxy + (int64_t)r * m * 2, rec_len[r], q.a, q.b);
+        const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, r, m), rec_len[r], q.a, q.b);
         if (len > 0.0) hit(rec_face[r], len); // (a degenerate piece of zero length is no intersection)
     }
 }
@@ -164,7 +164,7 @@ __device__ __forceinline__ void edge_minor_range(const EdgeWalk &w, int cm, doub
 template <bool BLOCK, typename Hit>
 __device__ __forceinline__ void edge_walk(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
                                           const float4 *__restrict__ rbb, const double *__restrict__ rec_fxy,
-                                          const uint8_t *__restrict__ rec_len, int m,
+                                          const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
                                           const int32_t *__restrict__ rec_face, Hit &&hit) {
     constexpr int MINOR_W = 6;
     const EdgeWalk w = edge_walk_setup(q, g);
@@ -183,7 +183,7 @@ __device__ __forceinline__ void edge_walk(const EdgeBox &q, const GridParams &g,
                 for (int cn = ka + k; cn <= kb; cn += MINOR_W) {
                     const int cx = w.xmajor ? cm : cn, cy = w.xmajor ? cn : cm;
                     const int r0 = cell_start[base + cy * nx + cx], r1 = cell_start[base + cy * nx + cx + 1];
-                    if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, m, rec_face, hit);
+                    if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
                 }
             }
         } else {
@@ -194,10 +194,10 @@ __device__ __forceinline__ void edge_walk(const EdgeBox &q, const GridParams &g,
                 if (w.xmajor) { // the minor cells of one major cell are cy = ka..kb at fixed cx: separate runs
                     for (int cy = ka; cy <= kb; cy++) {
                         const int r0 = cell_start[base + cy * nx + cm], r1 = cell_start[base + cy * nx + cm + 1];
-                        if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, m, rec_face, hit);
+                        if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
                     }
                 } else { // cells cx = ka..kb of row cm are one contiguous record run
-                    edge_cell(q, cell_start[base + cm * nx + ka], cell_start[base + cm * nx + kb + 1], rbb, rec_fxy, rec_len,
+                    edge_cell(q, cell_start[base + cm * nx + ka], cell_start[base + cm * nx + kb + 1], rbb, rec_fxy, rec_len, rec_off,
                               m, rec_face, hit);
                 }
             }
@@ -209,7 +209,7 @@ __device__ __forceinline__ void edge_walk(const EdgeBox &q, const GridParams &g,
 template <typename Hit>
 __device__ __forceinline__ void edge_walk_box(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
                                               const float4 *__restrict__ rbb, const double *__restrict__ rec_fxy,
-                                              const uint8_t *__restrict__ rec_len, int m,
+                                              const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
                                               const int32_t *__restrict__ rec_face, Hit &&hit) {
     for (int l = 0; l < g.n_levels; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
@@ -217,7 +217,7 @@ __device__ __forceinline__ void edge_walk_box(const EdgeBox &q, const GridParams
         const int cx0 = cell_coord(q.xmin - h, g.x0, inv_h, nx), cx1 = cell_coord(q.xmax, g.x0, inv_h, nx);
         const int cy0 = cell_coord(q.ymin - h, g.y0, inv_h, g.ny[l]), cy1 = cell_coord(q.ymax, g.y0, inv_h, g.ny[l]);
         for (int cy = cy0; cy <= cy1; cy++)
-            edge_cell(q, cell_start[base + cy * nx + cx0], cell_start[base + cy * nx + cx1 + 1], rbb, rec_fxy, rec_len, m,
+            edge_cell(q, cell_start[base + cy * nx + cx0], cell_start[base + cy * nx + cx1 + 1], rbb, rec_fxy, rec_len, rec_off, m,
                       rec_face, hit);
     }
 }
@@ -242,7 +242,7 @@ __device__ __forceinline__ void wave_append(bool flag, int32_t item, int32_t *__
 template <bool MAJOR_WALK>
 __global__ void __launch_bounds__(256)
 k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const int32_t *__restrict__ cell_start,
-              const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+              const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
               int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
               int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
               int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
@@ -268,8 +268,8 @@ k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, 
             nh++;
         };
         const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
-        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
+        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
     }
     const bool redo = nh > EDGE_SLOTS;
     wave_append(big, (int32_t)e, big_list, n_big);
@@ -297,7 +297,7 @@ k_edges_replay(int64_t n_edge, const int32_t *__restrict__ edge_hits, const int3
 template <bool MAJOR_WALK>
 __global__ void __launch_bounds__(256)
 k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
-             const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+             const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
              int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
              const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
              const int32_t *__restrict__ redo_list, const int32_t *__restrict__ n_redo) {
@@ -311,8 +311,8 @@ k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__
             data[pos] = len;
         };
         const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
-        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, m, rec_face, hit);
+        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
     }
 }
 
@@ -320,7 +320,7 @@ k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__
 template <bool FILL>
 __global__ void __launch_bounds__(256)
 k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
-            const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+            const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
             int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
             const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
             const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big) {
@@ -335,7 +335,7 @@ k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__r
                 data[indptr[face] + k] = len;
             }
         };
-        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, m, rec_face, hit);
+        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, rec_off, m, rec_face, hit);
     }
 }
 
@@ -427,14 +427,14 @@ k_edge_rows_sort_big(const int32_t *__restrict__ indptr, int32_t *__restrict__ i
 // the end points of every (face, edge) entry of the CSR, in entry order: intersections[entry][2][2]
 __global__ void __launch_bounds__(256)
 k_edge_pieces(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t n_face,
-              const double *__restrict__ fxy, const uint8_t *__restrict__ len, int m,
+              const double *__restrict__ fxy, const uint8_t *__restrict__ len, const int32_t *__restrict__ off, int m,
               const double *__restrict__ edge_xy, double *__restrict__ out) {
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n_face) return;
     for (int p = indptr[f]; p < indptr[f + 1]; p++) {
         const int e = indices[p];
         P2 c{NAN, NAN}, d{NAN, NAN};
-        cyrus_beck_length(fxy + f * m * 2, len[f], load_p2(edge_xy, 2 * e), load_p2(edge_xy, 2 * e + 1), &c, &d);
+        cyrus_beck_length(fxy + 2 * face_vertex_base(off, f, m), len[f], load_p2(edge_xy, 2 * e), load_p2(edge_xy, 2 * e + 1), &c, &d);
         double *o = out + (int64_t)p * 4;
         o[0] = c.x; o[1] = c.y; o[2] = d.x; o[3] = d.y;
     }
@@ -468,16 +468,16 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     const bool major = getenv("XR_EDGE_WALK") ? !strcmp(getenv("XR_EDGE_WALK"), "major") : false; // tuning hook
     if (major)
     XR_LAUNCH("edges_count", k_edges_count<true>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
               edge_hits.get(), side_face.get(), side_len.get(), big_cells);
     else
     XR_LAUNCH("edges_count", k_edges_count<false>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
               edge_hits.get(), side_face.get(), side_len.get(), big_cells);
     XR_LAUNCH("edges_big_count", k_edges_big<false>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
               big_list.get(), counters.get());
     exclusive_scan_i32(row_count.get(), csr->indptr.get(), F);
@@ -493,15 +493,15 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     if (major)
     XR_LAUNCH("edges_redo", k_edges_redo<true>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
               dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
-              tree->rec_len.get(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
+              tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
               csr->data.get(), redo_list.get(), counters.get() + 2);
     else
     XR_LAUNCH("edges_redo", k_edges_redo<false>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
               dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
-              tree->rec_len.get(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
+              tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
               csr->data.get(), redo_list.get(), counters.get() + 2);
     XR_LAUNCH("edges_big_fill", k_edges_big<true>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
               big_list.get(), counters.get());
     DevBuf<int32_t> sort_list((size_t)(P / ROW_SORT_SMALL + 1));
@@ -557,7 +557,7 @@ int xr_edge_pieces(xr_mesh *tree, const xr_csr *csr, const double *edge_xy, int6
         DevBuf<double> xy((size_t)n_edge * 4), out((size_t)csr->nnz * 4);
         h2d(xy.get(), edge_xy, sizeof(double) * 4 * (size_t)n_edge);
         XR_LAUNCH("edge_pieces", k_edge_pieces, dim3(div_up(csr->n, 256)), dim3(256), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->n, tree->fxy.get(), tree->len.get(), tree->m, xy.get(), out.get());
+                  csr->indices.get(), csr->n, tree->fxy.get(), tree->len.get(), tree->caller_off(), tree->m, xy.get(), out.get());
         d2h(intersections, out.get(), sizeof(double) * 4 * (size_t)csr->nnz);
         stream_sync();
     }

@@ -3,7 +3,10 @@
 // HBM layout of a mesh (struct xr_mesh), all face-major so that no hot kernel chases
 // connectivity -> node indirections:
 //   fxy   f64 [n_face][M][2]  CCW-normalised vertex coordinates of every face (M = n_max_node;
-//                             48 B per triangle); slots >= len are never read
+//                             48 B per triangle); slots >= len are never read.  Meshes with M > DENSE_MAX_NODES
+//                             (polygon meshes, e.g. the M = 22 Voronoi mesh of the barycentric path with ~6 real
+//                             vertices per cell) keep the blocks FLAT with offsets instead: f64 [sum len][2] +
+//                             off i32 [n_face + 1] (fxy_off / q_off / rec_off); face_vertex_base() hides the difference
 //   len   u8  [n_face]        number of valid vertices (polygon_length)
 //   bbox  f64 [n_face][4]     xmin, xmax, ymin, ymax
 //   area  f64 [n_face]        connectivity.area on the caller's vertex order
@@ -30,6 +33,9 @@ namespace xr {
 struct P2 {
     double x, y;
 };
+
+// vertex blocks of meshes with at most this many nodes per face are dense [n_face][M]; wider meshes: flat + offsets
+static constexpr int DENSE_MAX_NODES = 4;
 
 static constexpr int MAX_LEVELS = 24;
 // cell size ratio between consecutive grid levels = 2^LEVEL_SHIFT
@@ -66,6 +72,11 @@ __host__ __device__ inline int level_of_extent(const GridParams &g, double e) {
 }
 
 #ifdef __HIPCC__
+// index (in vertices) of the first vertex of face / record r: flat layout with offsets, or dense [.][m]
+__device__ __forceinline__ int64_t face_vertex_base(const int32_t *__restrict__ off, int64_t r, int m) {
+    return off ? (int64_t)off[r] : r * m;
+}
+
 __device__ __forceinline__ P2 load_p2(const double *__restrict__ xy, int i) {
     const double2 v = reinterpret_cast<const double2 *>(xy)[i];
     return P2{v.x, v.y};

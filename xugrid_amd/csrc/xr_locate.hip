@@ -37,7 +37,7 @@ __device__ bool point_in_face(const double *__restrict__ poly, int n, P2 p, doub
 }
 
 // -> record index of the matching face with the LOWEST caller face id, or -1
-__device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m,
+__device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
                             const GridParams &g, const int32_t *__restrict__ cell_start,
                             const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, P2 p, double tol) {
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
@@ -57,7 +57,7 @@ __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *_
                 if (!(qx0 <= b.y && b.x <= qx1 && qy0 <= b.w && b.z <= qy1)) continue;
                 const int f = rec_face[r];
                 if (best >= 0 && f > best) continue;
-                const double *poly = rec_fxy + (int64_t)r * m * 2;
+                const double *poly = rec_fxy + 2 * face_vertex_base(rec_off, r, m);
                 const int n = rec_len[r];
                 // exact bbox of the face (the same min/max the prepare kernel stored)
                 double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
@@ -80,14 +80,14 @@ __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *_
 }
 
 __global__ void __launch_bounds__(256)
-k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
          const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
          const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
          int64_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
     out[i] = r >= 0 ? rec_face[r] : -1;
 }
 
@@ -145,18 +145,18 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
 }
 
 __global__ void __launch_bounds__(256)
-k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
               const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
               const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
               int64_t *__restrict__ face_out, double *__restrict__ weights) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
     face_out[i] = r >= 0 ? rec_face[r] : -1;
     double *w = weights + i * m;
     for (int j = 0; j < m; j++) w[j] = 0.0;
-    if (r >= 0) bary_weights(rec_fxy + (int64_t)r * m * 2, rec_len[r], p, tol, w);
+    if (r >= 0) bary_weights(rec_fxy + 2 * face_vertex_base(rec_off, r, m), rec_len[r], p, tol, w);
 }
 
 // ---- BarycentricInterpolator weights assembled on the device (xr_barycentric_csr) ----------------
@@ -165,31 +165,31 @@ k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
 // touched (m is the largest cell of the tessellation, 15-25 corners at the hull; the typical cell has 6).
 
 __global__ void __launch_bounds__(256)
-k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
                  const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
                  const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
                  int64_t *__restrict__ face_out, double *__restrict__ weights) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
     face_out[i] = r >= 0 ? rec_face[r] : -1;
     if (r < 0) return;
     double *w = weights + i;
     const int len = rec_len[r];
     for (int j = 0; j < len; j++) w[(int64_t)j * n] = 0.0;
-    bary_weights(rec_fxy + (int64_t)r * m * 2, len, p, tol, w, n);
+    bary_weights(rec_fxy + 2 * face_vertex_base(rec_off, r, m), len, p, tol, w, n);
 }
 
 __global__ void __launch_bounds__(256)
-k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
               const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
               const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
               uint8_t *__restrict__ inside) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    inside[i] = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol) >= 0;
+    inside[i] = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol) >= 0;
 }
 
 // replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) on the point's own row, then the
@@ -257,14 +257,14 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
 
 // ---- locator weights as CSR (xr_locate_csr) -------------------------------------------------------
 __global__ void __launch_bounds__(256)
-k_locate_col(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, int m, GridParams g,
+k_locate_col(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
              const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
              int32_t *__restrict__ col, int32_t *__restrict__ found) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
     col[i] = r >= 0 ? rec_face[r] : -1;
     found[i] = r >= 0;
 }
@@ -319,7 +319,7 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
         h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
         if (mesh->n_face > 0) {
             XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
-                      mesh->rec_len.get(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
+                      mesh->rec_len.get(), mesh->record_off(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
                       mesh->rec_face.get(), pts.get(), n, tol, out.get());
             d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             stream_sync();
@@ -349,7 +349,7 @@ int xr_locate_raster(xr_mesh *mesh, const double *x, int64_t nx, const double *y
             XR_LAUNCH("raster_points", k_raster_points, dim3(div_up(n, 256)), dim3(256), 0, dx.get(), dy.get(), nx, n,
                       pts.get());
             XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
-                      mesh->rec_len.get(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
+                      mesh->rec_len.get(), mesh->record_off(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
                       mesh->rec_face.get(), pts.get(), n, tol, out.get());
             d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             stream_sync();
@@ -376,7 +376,7 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
             DevBuf<int64_t> out((size_t)n);
             h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
             XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
-                      mesh->rec_len.get(), m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
+                      mesh->rec_len.get(), mesh->record_off(), m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
                       mesh->rec_face.get(), pts.get(), n, tol, out.get(), w.get());
             d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             d2h(weights_out, w.get(), sizeof(double) * (size_t)n * m);
@@ -444,10 +444,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             // the reference's indexing (unstructured.py:175,193) also for the cells the tree reversed -- the caller's
             mesh_faces_ccw_dev(voronoi, faces_ccw.get(), reference_order);
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
-                      voronoi->rec_len.get(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
+                      voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
                       voronoi->rec_face.get(), pts.get(), n, tol, face.get(), w.get());
             XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
-                      source->rec_len.get(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
+                      source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
                       source->rec_face.get(), pts.get(), n, tol_source, inside.get());
             XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                       faces_ccw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
@@ -554,7 +554,7 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
             else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
             DevBuf<int32_t> col((size_t)n), found((size_t)n);
             XR_LAUNCH("locate_col", k_locate_col, dim3(div_up(n, 256)), dim3(256), 0, tree->rec_fxy.get(),
-                      tree->rec_len.get(), tree->m, tree->grid, tree->cell_start.get(), tree->rec_bb.get(),
+                      tree->rec_len.get(), tree->record_off(), tree->m, tree->grid, tree->cell_start.get(), tree->rec_bb.get(),
                       tree->rec_face.get(), pts.get(), n, tol, col.get(), found.get());
             exclusive_scan_i32(found.get(), csr->indptr.get(), n);
             csr->nnz = read_scalar(csr->indptr.get() + n);

@@ -222,7 +222,51 @@ __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__
     }
 }
 
-void mesh_face_coords(xr_mesh *mesh) { mesh_prepare(mesh, true); }
+// ---- flat vertex blocks of polygon meshes (m > DENSE_MAX_NODES): offsets = exclusive scan of the lengths, then one
+// pass writes the len[r] CCW-normalised vertices of face perm[r] (perm == nullptr: r) from the raw mesh
+__global__ void __launch_bounds__(256) k_widen_len(const uint8_t *__restrict__ len, int64_t n, int32_t *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = len[i];
+}
+
+__global__ void __launch_bounds__(256)
+k_fill_ragged(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face, int m,
+              const int32_t *__restrict__ perm, const int32_t *__restrict__ off, double *__restrict__ out_xy) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_face) return;
+    const int64_t f = perm ? perm[r] : r;
+    int face[XR_MAX_FACE_NODES];
+    for (int j = 0; j < m; j++) face[j] = faces_raw[f * m + j];
+    int n;
+    bool flip;
+    face_shape<XR_MAX_FACE_NODES>(node_xy, face, m, n, flip);
+    double2 *dst = reinterpret_cast<double2 *>(out_xy) + off[r];
+    for (int j = 0; j < n; j++) {
+        const P2 p = load_p2(node_xy, face[j]);
+        dst[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
+    }
+}
+
+static void ragged_fill(xr_mesh *mesh, const int32_t *perm, const uint8_t *len, DevBuf<int32_t> &off, DevBuf<double> &xy) {
+    const int64_t F = mesh->n_face;
+    off.alloc((size_t)F + 1);
+    DevBuf<int32_t> len32((size_t)std::max<int64_t>(F, 1));
+    if (F > 0) XR_LAUNCH("widen_len", k_widen_len, dim3(div_up(F, 256)), dim3(256), 0, len, F, len32.get());
+    exclusive_scan_i32(len32.get(), off.get(), F);
+    const int64_t total = F > 0 ? read_scalar(off.get() + F) : 0;
+    XR_REQUIRE(total >= 0, XR_ERR_LIMIT, "mesh has too many face vertices for int32 offsets");
+    xy.alloc((size_t)std::max<int64_t>(total, 1) * 2);
+    if (F > 0)
+        XR_LAUNCH("fill_ragged", k_fill_ragged, dim3(div_up(F, 256)), dim3(256), 0, mesh->node_xy.get(),
+                  mesh->faces_raw.get(), F, mesh->m, perm, off.get(), xy.get());
+}
+
+void mesh_face_coords(xr_mesh *mesh) {
+    mesh_prepare(mesh, true);
+    if (mesh->fxy_valid) return;
+    ragged_fill(mesh, nullptr, mesh->len.get(), mesh->fxy_off, mesh->fxy); // (dense blocks are written by the prepare pass)
+    mesh->fxy_valid = true;
+}
 
 void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
     // two depths: statistics only (want_fxy = false: the mesh is used as a tree) or statistics + the caller-order
@@ -230,12 +274,13 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
     if (mesh->prepared && (mesh->has_attrs || !want_fxy)) return;
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
+    const bool dense_fxy = want_fxy && !mesh->ragged(); // (ragged: flat blocks, filled on demand by mesh_face_coords)
     if (want_fxy) {
-        mesh->fxy.alloc((size_t)F * m * 2);
+        if (dense_fxy) mesh->fxy.alloc((size_t)F * m * 2);
         mesh->len.alloc((size_t)F);
         mesh->bbox.alloc((size_t)F * 4);
     }
-    mesh->fxy_valid = want_fxy;
+    mesh->fxy_valid = dense_fxy;
     mesh->has_attrs = want_fxy;
     mesh->stats.alloc(8);
     const int64_t nb = std::max<int64_t>(1, (F + PREP_BLOCK - 1) / PREP_BLOCK);
@@ -245,7 +290,8 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
     do {                                                                                                               \
         if (want_fxy)                                                                                                  \
             XR_LAUNCH("prepare_faces", (k_prepare_faces<MC, false>), grid, block, 0, mesh->node_xy.get(),              \
-                      mesh->faces_raw.get(), F, m, mesh->fxy.get(), mesh->len.get(), mesh->bbox.get(), partials.get()); \
+                      mesh->faces_raw.get(), F, m, dense_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(),  \
+                      mesh->bbox.get(), partials.get());                                                               \
         else                                                                                                           \
             XR_LAUNCH("prepare_stats", (k_prepare_faces<MC, true>), grid, block, 0, mesh->node_xy.get(),               \
                       mesh->faces_raw.get(), F, m, (double *)nullptr, (uint8_t *)nullptr, (double *)nullptr,           \
@@ -386,7 +432,7 @@ k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m_rt, const in
             xmax = fmax(xmax, p.x);
             ymin = fmin(ymin, p.y);
             ymax = fmax(ymax, p.y);
-            dst[flip ? nl - 1 - j : j] = make_double2(p.x, p.y);
+            if (o_fxy) dst[flip ? nl - 1 - j : j] = make_double2(p.x, p.y); // (ragged meshes: ragged_fill writes them)
         }
     }
     if (INDEX) {
@@ -450,7 +496,7 @@ void mesh_query_order(xr_mesh *mesh) {
         return;
     }
     mesh->q_perm.alloc((size_t)F);
-    mesh->q_fxy.alloc((size_t)F * m * 2);
+    if (!mesh->ragged()) mesh->q_fxy.alloc((size_t)F * m * 2);
     mesh->q_len.alloc((size_t)F);
     mesh->q_bbox.alloc((size_t)F * 4);
     if (F > 0) {
@@ -464,9 +510,11 @@ void mesh_query_order(xr_mesh *mesh) {
         MortonParams mp{xmin, ymin, (double)(1 << bits) / (span * (1.0 + 1e-9)), 1 << bits};
         GridParams g{};
         DevBuf<int32_t> start(((size_t)1 << (2 * bits)) + 1);
-        spatial_sort<false>(mesh, g, mp, (int64_t)1 << (2 * bits), start.get(), mesh->q_perm.get(), mesh->q_fxy.get(),
-                            mesh->q_len.get(), mesh->q_bbox.get(), nullptr);
+        spatial_sort<false>(mesh, g, mp, (int64_t)1 << (2 * bits), start.get(), mesh->q_perm.get(),
+                            mesh->ragged() ? (double *)nullptr : mesh->q_fxy.get(), mesh->q_len.get(), mesh->q_bbox.get(),
+                            nullptr);
     }
+    if (mesh->ragged()) ragged_fill(mesh, mesh->q_perm.get(), mesh->q_len.get(), mesh->q_off, mesh->q_fxy);
     mesh->query_ready = true;
 }
 
@@ -512,11 +560,13 @@ void mesh_build_index(xr_mesh *mesh) {
     mesh->cell_start.alloc((size_t)total + 1);
     mesh->rec_bb.alloc((size_t)F * 4);
     mesh->rec_face.alloc((size_t)F);
-    mesh->rec_fxy.alloc((size_t)F * m * 2);
+    if (!mesh->ragged()) mesh->rec_fxy.alloc((size_t)F * m * 2);
     mesh->rec_len.alloc((size_t)F);
     MortonParams mp{};
-    spatial_sort<true>(mesh, g, mp, total, mesh->cell_start.get(), mesh->rec_face.get(), mesh->rec_fxy.get(),
-                       mesh->rec_len.get(), nullptr, mesh->rec_bb.get());
+    spatial_sort<true>(mesh, g, mp, total, mesh->cell_start.get(), mesh->rec_face.get(),
+                       mesh->ragged() ? (double *)nullptr : mesh->rec_fxy.get(), mesh->rec_len.get(), nullptr,
+                       mesh->rec_bb.get());
+    if (mesh->ragged()) ragged_fill(mesh, mesh->rec_face.get(), mesh->rec_len.get(), mesh->rec_off, mesh->rec_fxy);
     mesh->indexed = true;
 }
 
@@ -713,6 +763,18 @@ int xr_mesh_info(const xr_mesh *mesh, int64_t *n_node, int64_t *n_face, int64_t 
     XR_API_END
 }
 
+int xr_mesh_device_bytes(const xr_mesh *mesh, int64_t *bytes) {
+    XR_API_BEGIN
+    XR_REQUIRE(mesh && bytes, XR_ERR_INVALID, "xr_mesh_device_bytes: NULL argument");
+    size_t b = mesh->node_xy.bytes() + mesh->faces_raw.bytes() + mesh->fxy.bytes() + mesh->fxy_off.bytes() +
+               mesh->len.bytes() + mesh->bbox.bytes() + mesh->area.bytes() + mesh->stats.bytes() + mesh->q_perm.bytes() +
+               mesh->q_fxy.bytes() + mesh->q_off.bytes() + mesh->q_len.bytes() + mesh->q_bbox.bytes() +
+               mesh->cell_start.bytes() + mesh->rec_bb.bytes() + mesh->rec_face.bytes() + mesh->rec_fxy.bytes() +
+               mesh->rec_off.bytes() + mesh->rec_len.bytes();
+    *bytes = (int64_t)b;
+    XR_API_END
+}
+
 int xr_mesh_prepare(xr_mesh *mesh) {
     XR_API_BEGIN
     XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_prepare: NULL mesh");
@@ -742,7 +804,8 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     mesh->indexed = false;
     mesh->stats_valid = false;
     mesh->fxy.release(); mesh->len.release(); mesh->bbox.release(); mesh->area.release(); mesh->stats.release();
-    mesh->q_perm.release(); mesh->q_fxy.release(); mesh->q_len.release(); mesh->q_bbox.release();
+    mesh->q_perm.release(); mesh->q_fxy.release(); mesh->q_len.release(); mesh->q_bbox.release(); mesh->q_off.release();
+    mesh->fxy_off.release(); mesh->rec_off.release();
     mesh->cell_start.release(); mesh->rec_bb.release(); mesh->rec_face.release(); mesh->rec_fxy.release();
     mesh->rec_len.release();
     XR_API_END

@@ -25,6 +25,7 @@ struct xr_mesh {
     xr::DevBuf<double> fxy;   // [n_face*m*2] CCW-normalised vertex coordinates per face (only if fxy_valid:
                               // needed when the mesh is a query kept in the caller's numbering)
     bool fxy_valid = false;
+    xr::DevBuf<int32_t> fxy_off; // [n_face+1] only for ragged() meshes: fxy is flat, face f starts at vertex fxy_off[f]
     xr::DevBuf<uint8_t> len;  // [n_face]
     xr::DevBuf<double> bbox;  // [n_face*4] xmin,xmax,ymin,ymax
     xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order (mesh_area, on demand)
@@ -49,7 +50,8 @@ struct xr_mesh {
     bool query_ready = false;
     bool query_identity = false;
     xr::DevBuf<int32_t> q_perm; // [n_face] position -> caller's face id
-    xr::DevBuf<double> q_fxy;   // [n_face*m*2]
+    xr::DevBuf<double> q_fxy;   // [n_face*m*2], ragged(): [sum len * 2]
+    xr::DevBuf<int32_t> q_off;  // [n_face+1] ragged() only
     xr::DevBuf<uint8_t> q_len;  // [n_face]
     xr::DevBuf<double> q_bbox;  // [n_face*4]
 
@@ -59,11 +61,17 @@ struct xr_mesh {
     xr::DevBuf<int32_t> cell_start; // [n_cells+1]
     xr::DevBuf<float> rec_bb;       // [n_face*4] conservative f32 bbox relative to the grid origin
     xr::DevBuf<int32_t> rec_face;   // [n_face]   record -> caller's face id
-    xr::DevBuf<double> rec_fxy;     // [n_face*m*2]
+    xr::DevBuf<double> rec_fxy;     // [n_face*m*2], ragged(): [sum len * 2]
+    xr::DevBuf<int32_t> rec_off;    // [n_face+1] ragged() only
     xr::DevBuf<uint8_t> rec_len;    // [n_face]
 
     int64_t last_candidates = 0;
 
+    // vertex blocks flat + offsets instead of dense [n_face][m] (xr_geom.h)
+    bool ragged() const { return m > xr::DENSE_MAX_NODES; }
+    const int32_t *caller_off() const { return ragged() ? fxy_off.get() : nullptr; }
+    const int32_t *record_off() const { return ragged() ? rec_off.get() : nullptr; }
+    const int32_t *qo_off() const { return !ragged() ? nullptr : query_identity ? fxy_off.get() : q_off.get(); }
     const double *qo_fxy() const { return query_identity ? fxy.get() : q_fxy.get(); }
     const uint8_t *qo_len() const { return query_identity ? len.get() : q_len.get(); }
     const double *qo_bbox() const { return query_identity ? bbox.get() : q_bbox.get(); }

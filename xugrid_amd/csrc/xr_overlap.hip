@@ -308,7 +308,7 @@ static constexpr int BIG_STAGE = 6144;
 template <bool FUSED>
 __global__ void __launch_bounds__(256)
 k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy,
-             const uint8_t *__restrict__ q_len, int q_m, GridParams g,
+             const uint8_t *__restrict__ q_len, const int32_t *__restrict__ q_off, int q_m, GridParams g,
              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
              const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
              const int32_t *__restrict__ n_big, int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count,
@@ -329,7 +329,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
         const int t = big_list[bi];
         const int np = q_len[t];
         __syncthreads();
-        if (threadIdx.x < np) sh_poly[threadIdx.x] = reinterpret_cast<const double2 *>(q_fxy)[(int64_t)t * q_m + threadIdx.x];
+        if (threadIdx.x < np) sh_poly[threadIdx.x] = reinterpret_cast<const double2 *>(q_fxy)[face_vertex_base(q_off, t, q_m) + threadIdx.x];
         if (threadIdx.x == 0) sh_cursor = 0;
         __syncthreads();
         const double2 *poly = sh_poly;
@@ -492,8 +492,8 @@ static constexpr double AREA_OVERFLOW = -1.0; // sentinel: polygon buffer too sm
 
 template <int MAXV, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int q_m,
-       const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy, const uint8_t *__restrict__ s_len,
+k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, const int32_t *__restrict__ q_off, int q_m,
+       const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy, const uint8_t *__restrict__ s_len, const int32_t *__restrict__ s_off,
        int s_m, const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
        double *__restrict__ cand_area, bool redo_only, const int32_t *__restrict__ rec_face,
        int32_t *__restrict__ cand_sid, int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
@@ -510,8 +510,8 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int 
     const int nt = q_len[t], ns = s_len[s];
     double2 *out = sh + threadIdx.x;                // out[j * BLOCK]
     double2 *in = sh + MAXV * BLOCK + threadIdx.x;  // in[j * BLOCK]
-    const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
-    const double *sf = s_fxy + (int64_t)s * s_m * 2;
+    const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + face_vertex_base(q_off, t, q_m);
+    const double *sf = s_fxy + 2 * face_vertex_base(s_off, s, s_m);
     for (int j = 0; j < nt; j++) out[j * BLOCK] = tf[j];
     int n_output = nt;
     bool overflow = false;
@@ -618,9 +618,9 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int 
 // The arithmetic and its order are those of k_clip / the oracle.
 template <int MAXV, int BLOCK, bool TRI>
 __global__ void __launch_bounds__(BLOCK)
-k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, int q_m,
+k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, const int32_t *__restrict__ q_off, int q_m,
              const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy,
-             const uint8_t *__restrict__ s_len, int s_m, const int32_t *__restrict__ cand_tgt,
+             const uint8_t *__restrict__ s_len, const int32_t *__restrict__ s_off, int s_m, const int32_t *__restrict__ cand_tgt,
              const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area,
              const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
              int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
@@ -639,8 +639,8 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
         cand_sid[c] = rec_face[s];
         // TRI: both meshes are pure triangle meshes -> vertex counts are compile-time constants
         const int nt = TRI ? 3 : q_len[t], ns = TRI ? 3 : s_len[s];
-        const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
-        const double *sf = s_fxy + (int64_t)s * s_m * 2;
+        const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + face_vertex_base(q_off, t, q_m);
+        const double *sf = s_fxy + 2 * face_vertex_base(s_off, s, s_m);
         P2 in[MAXV];
         P2 last{0.0, 0.0};
 #pragma unroll
@@ -1104,8 +1104,8 @@ static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t
         attr_set = true;
     }
     XR_LAUNCH(MAXV == 8 ? "clip_v8" : (MAXV == 16 ? "clip_v16" : "clip_v64"), (k_clip<MAXV, BLOCK>),
-              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->qo_fxy(), query->qo_len(), query->m,
-              query->qo_perm(), tree->rec_fxy.get(), tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area,
+              dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m,
+              query->qo_perm(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area,
               redo_only, tree->rec_face.get(), cand_sid, overflow_count, nnz_row);
 }
 
@@ -1121,8 +1121,8 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
         static const bool old_clip = getenv("XR_CLIP_OLD") != nullptr; // measurement switch: the slot-loop kernel
         if (old_clip)
             XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
-                      shmem, query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
-                      tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
+                      shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m, query->qo_perm(), tree->rec_fxy.get(),
+                      tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
                       overflow_count, nnz_row, remap);
         else
             XR_LAUNCH("clip_tri", (k_clip_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
@@ -1132,8 +1132,8 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
         XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, false>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
-                  shmem, query->qo_fxy(), query->qo_len(), query->m, query->qo_perm(), tree->rec_fxy.get(),
-                  tree->rec_len.get(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
+                  shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m, query->qo_perm(), tree->rec_fxy.get(),
+                  tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
                   overflow_count, nnz_row, remap);
     }
     else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
@@ -1201,7 +1201,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             // ---- side stream: everything about the big faces except their final placement
             SideScope side;
             XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
-                      query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
+                      query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
                       big_list.get(), ctl.get() + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
                       ctl.get() + 1, big_capacity, pending.get(), ctl.get() + 3);
             // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
@@ -1334,7 +1334,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
               csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
     DevBuf<int32_t> pending((size_t)T);
     XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
-              query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
+              query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
               big_list.get(), counters.get() + 2, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
               counters.get() + 3, capacity, pending.get(), counters.get() + 1);
     // queue length and number of big faces still to be filled -> host
@@ -1356,7 +1356,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         capacity = C;
         h2d(counters.get() + 1, &n_pending, sizeof(int32_t)); // (k_publish zeroed the device copy)
         XR_LAUNCH("search_big_fill", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
-                  query->qo_len(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
+                  query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
                   pending.get(), counters.get() + 1, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
                   (int32_t *)nullptr, capacity, (int32_t *)nullptr, (int32_t *)nullptr);
         XR_HIP(hipMemsetAsync(counters.get() + 1, 0, sizeof(int32_t), st));

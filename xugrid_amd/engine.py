@@ -135,6 +135,12 @@ class DeviceMesh:
     def invalidate(self):
         check(_lib.load().xr_mesh_invalidate(self._h))
 
+    def device_bytes(self):
+        """HBM currently held by the handle (raw + prepared + query order + tree index)."""
+        n = ctypes.c_int64(0)
+        check(_lib.load().xr_mesh_device_bytes(self._h, ctypes.byref(n)))
+        return n.value
+
     def area(self):
         out = np.empty(self.n_face, dtype=np.float64)
         check(_lib.load().xr_mesh_area(self._h, _ptr(out)))
