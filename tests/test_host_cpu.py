@@ -70,6 +70,13 @@ def test_sparse_containers(golden):
     assert np.array_equal(small.indptr, [0, 2, 4, 6, 8, 10]) and small.n == 5 and small.m == 3
     C = MatrixCOO.from_triplet(np.array([0, 1]), np.array([3, 1]), np.ones(2), n=7, m=9)  # shape override
     assert (C.n, C.m, C.nnz) == (7, 9, 2)
+    # row helpers (core/sparse.py:129-158)
+    from xugrid_amd.sparse import columns_and_values, nzrange, row_slice
+
+    for r in (0, 3, A.n - 1):
+        sl = row_slice(A, r)
+        assert list(nzrange(A, r)) == list(range(sl.start, sl.stop))
+        assert [(c, v) for c, v in columns_and_values(A, sl)] == list(zip(A.indices[sl], A.data[sl]))
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])

@@ -53,3 +53,19 @@ class MatrixCSR(NamedTuple):
     def to_coo(self) -> MatrixCOO:
         row = np.repeat(np.arange(self.n, dtype=IntDType), np.diff(self.indptr))
         return MatrixCOO(self.data, row, self.indices, self.n, self.m, self.nnz)
+
+
+# Row helpers of the reference (core/sparse.py:129-158; numba-inlined there, plain Python here: they serve host-side
+# code that walks a downloaded matrix -- the device kernels index ``indptr`` directly).
+def nzrange(A: MatrixCSR, row: int) -> range:
+    """The positions of the entries of one row."""
+    return range(int(A.indptr[row]), int(A.indptr[row + 1]))
+
+
+def row_slice(A: MatrixCSR, row: int) -> slice:
+    """The slice of ``indices`` / ``data`` holding one row."""
+    return slice(int(A.indptr[row]), int(A.indptr[row + 1]))
+
+
+def columns_and_values(A: MatrixCSR, slice):  # noqa: A002  (the reference's argument name)
+    return zip(A.indices[slice], A.data[slice])
