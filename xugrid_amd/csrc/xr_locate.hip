@@ -36,15 +36,115 @@ __device__ bool point_in_face(const double *__restrict__ poly, int n, P2 p, doub
     return c;
 }
 
+// Level split (as in xr_overlap.hip:k_search): the records of the upper grid levels -- the hull slivers of a Delaunay
+// mesh, a few hundred of a million faces on ~10 all but empty levels -- are the TAIL of the record arrays.  When that tail
+// is short every block filters it once against the bounding box of its 256 points into an LDS list, and the points walk
+// only the levels below: each skipped level was two dependent cell_start -> record round trips per point.
+static constexpr int LOC_BIG_MAX = 1024;  // upper-level records handled as a list
+static constexpr int LOC_BIG_BLOCK = 64;  // ... of which at most this many may touch one block's bounding box
+// The walk only PARKS the records whose f32 box holds the point (LDS, [slot][thread]); the exact tests -- f64 box, crossing
+// number with a division, on-edge test with a square root: ~300 instructions per triangle -- run afterwards in a loop all
+// lanes of a wave step through together.  Run from inside the walk, every lane that found a candidate made the whole wave
+// execute them: 6700 VALU instructions per wave (PMC), 9x the polygon clip.
+static constexpr int LOC_CAND = 8;        // parked candidates per point; further ones are tested on the spot
+
+struct LocateBig { // per block, in LDS
+    int32_t cand[LOC_CAND][256];
+    float4 bb[LOC_BIG_BLOCK];
+    int32_t rec[LOC_BIG_BLOCK];
+    float box[4][4];
+    int32_t n;
+};
+
+// Block-cooperative (call with all 256 threads, `valid` = the thread has a point).  -> number of levels to walk;
+// sh.n = length of the block's list of upper-level records
+__device__ int locate_prepare(LocateBig &sh, const GridParams &g, const int32_t *__restrict__ cell_start,
+                              const float *__restrict__ rec_bb, int64_t n_tree, P2 p, bool valid, double tol) {
+    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+    int l_split = g.n_levels, big0 = (int)n_tree;
+    for (int l = g.n_levels - 1; l >= 1; l--) { // uniform: scalar loads
+        const int first = cell_start[g.base[l]];
+        if ((int)n_tree - first > LOC_BIG_MAX) break;
+        l_split = l;
+        big0 = first;
+    }
+    if (threadIdx.x == 0) sh.n = 0;
+    if (big0 < (int)n_tree) {
+        float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+        if (valid) {
+            bx0 = f32_below(p.x - tol - g.x0), bx1 = f32_above(p.x + tol - g.x0);
+            by0 = f32_below(p.y - tol - g.y0), by1 = f32_above(p.y + tol - g.y0);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            bx0 = fminf(bx0, __shfl_xor(bx0, d, 64));
+            bx1 = fmaxf(bx1, __shfl_xor(bx1, d, 64));
+            by0 = fminf(by0, __shfl_xor(by0, d, 64));
+            by1 = fmaxf(by1, __shfl_xor(by1, d, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            sh.box[w][0] = bx0; sh.box[w][1] = bx1; sh.box[w][2] = by0; sh.box[w][3] = by1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            bx0 = fminf(bx0, sh.box[w][0]); bx1 = fmaxf(bx1, sh.box[w][1]);
+            by0 = fminf(by0, sh.box[w][2]); by1 = fmaxf(by1, sh.box[w][3]);
+        }
+        for (int r = big0 + threadIdx.x; r < (int)n_tree; r += 256) {
+            const float4 b = rbb[r];
+            if (bx0 <= b.y && b.x <= bx1 && by0 <= b.w && b.z <= by1) {
+                const int k = atomicAdd(&sh.n, 1);
+                if (k < LOC_BIG_BLOCK) {
+                    sh.rec[k] = r;
+                    sh.bb[k] = b;
+                }
+            }
+        }
+        __syncthreads();
+        if (sh.n > LOC_BIG_BLOCK) { // too many for the list: this block walks every level
+            l_split = g.n_levels;
+            __syncthreads();
+            if (threadIdx.x == 0) sh.n = 0;
+        }
+    }
+    __syncthreads();
+    return l_split;
+}
+
 // -> record index of the matching face with the LOWEST caller face id, or -1
 __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
                             const GridParams &g, const int32_t *__restrict__ cell_start,
-                            const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, P2 p, double tol) {
+                            const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, P2 p, double tol,
+                            LocateBig &big, int l_split) {
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const float qx0 = f32_below(p.x - tol - g.x0), qx1 = f32_above(p.x + tol - g.x0);
     const float qy0 = f32_below(p.y - tol - g.y0), qy1 = f32_above(p.y + tol - g.y0);
     int best = -1, best_rec = -1;
-    for (int l = 0; l < g.n_levels; l++) {
+    // record r passed the f32 bbox test: exact bbox, then the polygon test; the lowest face id wins
+    auto consider = [&](int r) {
+        const int f = rec_face[r];
+        if (best >= 0 && f > best) return;
+        const double *poly = rec_fxy + 2 * face_vertex_base(rec_off, r, m);
+        const int n = rec_len[r];
+        // exact bbox of the face (the same min/max the prepare kernel stored)
+        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        for (int j = 0; j < n; j++) {
+            const P2 v = load_p2(poly, j);
+            xmin = fmin(xmin, v.x);
+            xmax = fmax(xmax, v.x);
+            ymin = fmin(ymin, v.y);
+            ymax = fmax(ymax, v.y);
+        }
+        if (p.x < xmin - tol || p.x > xmax + tol || p.y < ymin - tol || p.y > ymax + tol) return;
+        if (point_in_face(poly, n, p, tol)) {
+            best = f;
+            best_rec = r;
+        }
+    };
+    int nc = 0;
+    for (int l = 0; l < l_split; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
         const int cx0 = cell_coord(p.x - tol - h, g.x0, inv_h, nx), cx1 = cell_coord(p.x + tol, g.x0, inv_h, nx);
@@ -55,39 +155,37 @@ __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *_
             for (int r = r0; r < r1; r++) {
                 const float4 b = rbb[r];
                 if (!(qx0 <= b.y && b.x <= qx1 && qy0 <= b.w && b.z <= qy1)) continue;
-                const int f = rec_face[r];
-                if (best >= 0 && f > best) continue;
-                const double *poly = rec_fxy + 2 * face_vertex_base(rec_off, r, m);
-                const int n = rec_len[r];
-                // exact bbox of the face (the same min/max the prepare kernel stored)
-                double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-                for (int j = 0; j < n; j++) {
-                    const P2 v = load_p2(poly, j);
-                    xmin = fmin(xmin, v.x);
-                    xmax = fmax(xmax, v.x);
-                    ymin = fmin(ymin, v.y);
-                    ymax = fmax(ymax, v.y);
-                }
-                if (p.x < xmin - tol || p.x > xmax + tol || p.y < ymin - tol || p.y > ymax + tol) continue;
-                if (point_in_face(poly, n, p, tol)) {
-                    best = f;
-                    best_rec = r;
-                }
+                if (nc < LOC_CAND) big.cand[nc][threadIdx.x] = r;
+                else consider(r);
+                nc++;
             }
         }
     }
+    const int nb = big.n;
+    for (int k = 0; k < nb; k++) { // the upper-level records that touch this block (from LDS)
+        const float4 b = big.bb[k];
+        if (!(qx0 <= b.y && b.x <= qx1 && qy0 <= b.w && b.z <= qy1)) continue;
+        if (nc < LOC_CAND) big.cand[nc][threadIdx.x] = big.rec[k];
+        else consider(big.rec[k]);
+        nc++;
+    }
+    const int parked = nc < LOC_CAND ? nc : LOC_CAND;
+    for (int k = 0; k < parked; k++) consider(big.cand[k][threadIdx.x]);
     return best_rec;
 }
 
 __global__ void __launch_bounds__(256)
 k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
          const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
-         const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+         const int32_t *__restrict__ rec_face, int64_t n_tree, const double *__restrict__ pts, int64_t n, double tol,
          int64_t *__restrict__ out) {
+    __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const bool valid = i < n;
+    const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
+    const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    if (!valid) return;
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     out[i] = r >= 0 ? rec_face[r] : -1;
 }
 
@@ -147,12 +245,15 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
 __global__ void __launch_bounds__(256)
 k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
               const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
-              const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+              const int32_t *__restrict__ rec_face, int64_t n_tree, const double *__restrict__ pts, int64_t n, double tol,
               int64_t *__restrict__ face_out, double *__restrict__ weights) {
+    __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const bool valid = i < n;
+    const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
+    const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    if (!valid) return;
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     face_out[i] = r >= 0 ? rec_face[r] : -1;
     double *w = weights + i * m;
     for (int j = 0; j < m; j++) w[j] = 0.0;
@@ -167,12 +268,15 @@ k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
 __global__ void __launch_bounds__(256)
 k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
                  const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
-                 const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+                 const int32_t *__restrict__ rec_face, int64_t n_tree, const double *__restrict__ pts, int64_t n, double tol,
                  int64_t *__restrict__ face_out, double *__restrict__ weights) {
+    __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const bool valid = i < n;
+    const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
+    const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    if (!valid) return;
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     face_out[i] = r >= 0 ? rec_face[r] : -1;
     if (r < 0) return;
     double *w = weights + i;
@@ -184,12 +288,15 @@ k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__
 __global__ void __launch_bounds__(256)
 k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
               const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
-              const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+              const int32_t *__restrict__ rec_face, int64_t n_tree, const double *__restrict__ pts, int64_t n, double tol,
               uint8_t *__restrict__ inside) {
+    __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const P2 p = load_p2(pts, (int)i);
-    inside[i] = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol) >= 0;
+    const bool valid = i < n;
+    const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
+    const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    if (!valid) return;
+    inside[i] = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split) >= 0;
 }
 
 // replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) on the point's own row, then the
@@ -259,12 +366,15 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
 __global__ void __launch_bounds__(256)
 k_locate_col(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
              const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
-             const int32_t *__restrict__ rec_face, const double *__restrict__ pts, int64_t n, double tol,
+             const int32_t *__restrict__ rec_face, int64_t n_tree, const double *__restrict__ pts, int64_t n, double tol,
              int32_t *__restrict__ col, int32_t *__restrict__ found) {
+    __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const P2 p = load_p2(pts, (int)i);
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol);
+    const bool valid = i < n;
+    const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
+    const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    if (!valid) return;
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     col[i] = r >= 0 ? rec_face[r] : -1;
     found[i] = r >= 0;
 }
@@ -320,7 +430,7 @@ int xr_locate_points(xr_mesh *mesh, const double *points, int64_t n, double tole
         if (mesh->n_face > 0) {
             XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
                       mesh->rec_len.get(), mesh->record_off(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
-                      mesh->rec_face.get(), pts.get(), n, tol, out.get());
+                      mesh->rec_face.get(), mesh->n_face, pts.get(), n, tol, out.get());
             d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             stream_sync();
         } else {
@@ -350,7 +460,7 @@ int xr_locate_raster(xr_mesh *mesh, const double *x, int64_t nx, const double *y
                       pts.get());
             XR_LAUNCH("locate_points", k_locate, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
                       mesh->rec_len.get(), mesh->record_off(), mesh->m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
-                      mesh->rec_face.get(), pts.get(), n, tol, out.get());
+                      mesh->rec_face.get(), mesh->n_face, pts.get(), n, tol, out.get());
             d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             stream_sync();
         } else {
@@ -377,7 +487,7 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
             h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
             XR_LAUNCH("barycentric", k_barycentric, dim3(div_up(n, 256)), dim3(256), 0, mesh->rec_fxy.get(),
                       mesh->rec_len.get(), mesh->record_off(), m, mesh->grid, mesh->cell_start.get(), mesh->rec_bb.get(),
-                      mesh->rec_face.get(), pts.get(), n, tol, out.get(), w.get());
+                      mesh->rec_face.get(), mesh->n_face, pts.get(), n, tol, out.get(), w.get());
             d2h(face_index_out, out.get(), sizeof(int64_t) * (size_t)n);
             d2h(weights_out, w.get(), sizeof(double) * (size_t)n * m);
             stream_sync();
@@ -445,10 +555,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             mesh_faces_ccw_dev(voronoi, faces_ccw.get(), reference_order);
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
-                      voronoi->rec_face.get(), pts.get(), n, tol, face.get(), w.get());
+                      voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get());
             XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
                       source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
-                      source->rec_face.get(), pts.get(), n, tol_source, inside.get());
+                      source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
             XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                       faces_ccw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
             exclusive_scan_i32(count.get(), csr->indptr.get(), n);
@@ -555,7 +665,7 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
             DevBuf<int32_t> col((size_t)n), found((size_t)n);
             XR_LAUNCH("locate_col", k_locate_col, dim3(div_up(n, 256)), dim3(256), 0, tree->rec_fxy.get(),
                       tree->rec_len.get(), tree->record_off(), tree->m, tree->grid, tree->cell_start.get(), tree->rec_bb.get(),
-                      tree->rec_face.get(), pts.get(), n, tol, col.get(), found.get());
+                      tree->rec_face.get(), tree->n_face, pts.get(), n, tol, col.get(), found.get());
             exclusive_scan_i32(found.get(), csr->indptr.get(), n);
             csr->nnz = read_scalar(csr->indptr.get() + n);
             csr->indices.alloc((size_t)csr->nnz);
