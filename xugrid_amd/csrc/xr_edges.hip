@@ -94,18 +94,31 @@ __device__ __forceinline__ int64_t edge_cells(const EdgeBox &q, const GridParams
     return total;
 }
 
-// the records of one grid cell against the edge; HIT(face id, length) for every kept pair
-template <typename Hit>
+// the records of one grid cell against the edge's f32 box: CAND(record) for every record that passes.  The exact clip
+// (edge_test) is NOT run from here by the thread-per-edge kernels: they park the candidates in LDS and clip them
+// afterwards in a loop all lanes of a wave step through together (a clip is ~150 instructions with a division per face
+// side; run from inside the walk, every lane that found a candidate made the whole wave execute it).
+template <typename Cand>
 __device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, const float4 *__restrict__ rbb,
-                                          const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
-                                          int m, const int32_t *__restrict__ rec_face, Hit &&hit) {
+                                          const double *__restrict__, const uint8_t *__restrict__, const int32_t *__restrict__,
+                                          int, const int32_t *__restrict__, Cand &&cand) {
     for (int r = r0; r < r1; r++) {
         const float4 bb = rbb[r];
         if (!(q.qx0 <= bb.y && bb.x <= q.qx1 && q.qy0 <= bb.w && bb.z <= q.qy1)) continue;
-        const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, r, m), rec_len[r], q.a, q.b);
-        if (len > 0.0) hit(rec_face[r], len); // (a degenerate piece of zero length is no intersection)
+        cand(r);
     }
 }
+
+// exact clip of the edge against record r; HIT(face id, length) for a piece of positive length
+template <typename Hit>
+__device__ __forceinline__ void edge_test(const EdgeBox &q, int r, const double *__restrict__ rec_fxy,
+                                          const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
+                                          const int32_t *__restrict__ rec_face, Hit &&hit) {
+    const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, r, m), rec_len[r], q.a, q.b);
+    if (len > 0.0) hit(rec_face[r], len); // (a degenerate piece of zero length is no intersection)
+}
+
+static constexpr int EDGE_PARK = 16; // candidates parked per edge; further ones are clipped on the spot
 
 // The walk along an edge.  Per level the cells along the edge's MAJOR axis are visited; for each of them the piece
 // of the segment inside the slab of that cell's records ([origin, origin + 2 h): a record starts in its cell and is
@@ -247,6 +260,7 @@ k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, 
               int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
               int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
               double *__restrict__ side_len, int big_cells) {
+    __shared__ int32_t sh_park[EDGE_PARK][256];
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = e < n_edge;
     EdgeBox q{};
@@ -268,8 +282,16 @@ k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, 
             nh++;
         };
         const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
-        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+        int np = 0;
+        auto park = [&](int r) {
+            if (np < EDGE_PARK) sh_park[np][threadIdx.x] = r;
+            else edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+            np++;
+        };
+        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
+        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
+        const int parked = np < EDGE_PARK ? np : EDGE_PARK;
+        for (int k = 0; k < parked; k++) edge_test(q, sh_park[k][threadIdx.x], rec_fxy, rec_len, rec_off, m, rec_face, hit);
     }
     const bool redo = nh > EDGE_SLOTS;
     wave_append(big, (int32_t)e, big_list, n_big);
@@ -301,6 +323,7 @@ k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__
              int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
              const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
              const int32_t *__restrict__ redo_list, const int32_t *__restrict__ n_redo) {
+    __shared__ int32_t sh_park[EDGE_PARK][256];
     const int n = *n_redo;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t e = redo_list[i];
@@ -311,8 +334,16 @@ k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__
             data[pos] = len;
         };
         const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
-        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+        int np = 0;
+        auto park = [&](int r) {
+            if (np < EDGE_PARK) sh_park[np][threadIdx.x] = r;
+            else edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+            np++;
+        };
+        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
+        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
+        const int parked = np < EDGE_PARK ? np : EDGE_PARK;
+        for (int k = 0; k < parked; k++) edge_test(q, sh_park[k][threadIdx.x], rec_fxy, rec_len, rec_off, m, rec_face, hit);
     }
 }
 
@@ -335,7 +366,8 @@ k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__r
                 data[indptr[face] + k] = len;
             }
         };
-        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, rec_off, m, rec_face, hit);
+        auto cand = [&](int r) { edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit); };
+        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, rec_off, m, rec_face, cand);
     }
 }
 
