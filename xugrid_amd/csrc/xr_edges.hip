@@ -104,8 +104,7 @@ __device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, cons
                                           int, const int32_t *__restrict__, Cand &&cand) {
     for (int r = r0; r < r1; r++) {
         const float4 bb = rbb[r];
-        if (!(q.qx0 <= bb.y && bb.x <= q.qx1 && q.qy0 <= bb.w && bb.z <= q.qy1)) continue;
-        cand(r);
+        if (box_gap(bb, q.qx0, q.qx1, q.qy0, q.qy1) <= 0.0f) cand(r);
     }
 }
 

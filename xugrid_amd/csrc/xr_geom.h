@@ -82,6 +82,15 @@ __device__ __forceinline__ P2 load_p2(const double *__restrict__ xy, int i) {
     return P2{v.x, v.y};
 }
 
+// f32 box test as ONE float.  b = (xmin, xmax, ymin, ymax) of a record, q = the query box: the value is negative iff all
+// four STRICT inequalities qx0 < b.xmax, b.xmin < qx1, qy0 < b.ymax, b.ymin < qy1 hold, and <= 0 iff the non-strict ones do
+// (a < b <=> a - b < 0 exactly in IEEE arithmetic; NaN fails both).  Seven VALU instructions and no branch: the obvious
+// `a && b && c && d` compiles to a compare / select / shift / bit-op chain of twice that, and `in_range && hit` to a branch
+// per record with the record's load and its wait INSIDE the branch (the loads are then no longer in flight together).
+__device__ __forceinline__ float box_gap(float4 b, float qx0, float qx1, float qy0, float qy1) {
+    return fmaxf(fmaxf(qx0 - b.y, b.x - qx1), fmaxf(qy0 - b.w, b.z - qy1));
+}
+
 // conservative float bounds: strictly below / above the double value
 __device__ __forceinline__ float f32_below(double v) {
     return nextafterf(__double2float_rd(v), -INFINITY);

@@ -94,7 +94,7 @@ __device__ int locate_prepare(LocateBig &sh, const GridParams &g, const int32_t 
         }
         for (int r = big0 + threadIdx.x; r < (int)n_tree; r += 256) {
             const float4 b = rbb[r];
-            if (bx0 <= b.y && b.x <= bx1 && by0 <= b.w && b.z <= by1) {
+            if (box_gap(b, bx0, bx1, by0, by1) <= 0.0f) {
                 const int k = atomicAdd(&sh.n, 1);
                 if (k < LOC_BIG_BLOCK) {
                     sh.rec[k] = r;
@@ -144,6 +144,11 @@ __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *_
         }
     };
     int nc = 0;
+    auto park = [&](int r) {
+        if (nc < LOC_CAND) big.cand[nc][threadIdx.x] = r;
+        else consider(r);
+        nc++;
+    };
     for (int l = 0; l < l_split; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
@@ -152,22 +157,28 @@ __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *_
         for (int cy = cy0; cy <= cy1; cy++) {
             const int r0 = cell_start[base + cy * nx + cx0];
             const int r1 = cell_start[base + cy * nx + cx1 + 1];
-            for (int r = r0; r < r1; r++) {
-                const float4 b = rbb[r];
-                if (!(qx0 <= b.y && b.x <= qx1 && qy0 <= b.w && b.z <= qy1)) continue;
-                if (nc < LOC_CAND) big.cand[nc][threadIdx.x] = r;
-                else consider(r);
-                nc++;
+            for (int r = r0; r < r1; r += 4) {
+                // four independent 16-byte loads in flight per step (indices clamped; the range guard is folded into the gap)
+                const int last = r1 - 1;
+                const float4 b0 = rbb[r];
+                const float4 b1 = rbb[r + 1 <= last ? r + 1 : last];
+                const float4 b2 = rbb[r + 2 <= last ? r + 2 : last];
+                const float4 b3 = rbb[r + 3 <= last ? r + 3 : last];
+                const float g0 = box_gap(b0, qx0, qx1, qy0, qy1);
+                const float g1 = fmaxf(box_gap(b1, qx0, qx1, qy0, qy1), r + 1 <= last ? -INFINITY : 1.0f);
+                const float g2 = fmaxf(box_gap(b2, qx0, qx1, qy0, qy1), r + 2 <= last ? -INFINITY : 1.0f);
+                const float g3 = fmaxf(box_gap(b3, qx0, qx1, qy0, qy1), r + 3 <= last ? -INFINITY : 1.0f);
+                if (g0 <= 0.0f) park(r);
+                if (g1 <= 0.0f) park(r + 1);
+                if (g2 <= 0.0f) park(r + 2);
+                if (g3 <= 0.0f) park(r + 3);
             }
         }
     }
     const int nb = big.n;
     for (int k = 0; k < nb; k++) { // the upper-level records that touch this block (from LDS)
         const float4 b = big.bb[k];
-        if (!(qx0 <= b.y && b.x <= qx1 && qy0 <= b.w && b.z <= qy1)) continue;
-        if (nc < LOC_CAND) big.cand[nc][threadIdx.x] = big.rec[k];
-        else consider(big.rec[k]);
-        nc++;
+        if (box_gap(b, qx0, qx1, qy0, qy1) <= 0.0f) park(big.rec[k]);
     }
     const int parked = nc < LOC_CAND ? nc : LOC_CAND;
     for (int k = 0; k < parked; k++) consider(big.cand[k][threadIdx.x]);

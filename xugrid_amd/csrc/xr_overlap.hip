@@ -37,15 +37,8 @@ namespace xr {
 // of tests, so those faces are queued and handled by one block each (k_search_big).
 static constexpr int BIG_VISITS = 160; // records visited by one thread before it gives up
 
-// f32 box test as ONE float: negative iff all four strict inequalities qx0 < b.y, b.x < qx1, qy0 < b.w, b.z < qy1 hold
-// (a < b <=> a - b < 0 exactly in IEEE arithmetic; NaN -> no hit either way).  Seven VALU instructions and no branch: the
-// obvious `a && b && c && d` compiles to a compare / select / shift / bit-op chain of twice that, and `in_range && hit`
-// to a branch per record with the record's load and its wait INSIDE the branch (no loads in flight together any more).
-__device__ __forceinline__ float rec_gap(float4 b, float qx0, float qx1, float qy0, float qy1) {
-    return fmaxf(fmaxf(qx0 - b.y, b.x - qx1), fmaxf(qy0 - b.w, b.z - qy1));
-}
 __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy0, float qy1) {
-    return rec_gap(b, qx0, qx1, qy0, qy1) < 0.0f;
+    return box_gap(b, qx0, qx1, qy0, qy1) < 0.0f;
 }
 
 // One traversal per query face: hits are parked in SLOTS LDS slots per face and counted; the block
@@ -198,16 +191,16 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
                             const float4 b3 = rbb[r + 3 <= last ? r + 3 : last];
                             // branch-free parking: the slot is written unconditionally and only kept (count
                             // advances) on a hit; beyond SLOTS everything lands in a trash row
-                            const bool h0 = rec_gap(b0, qx0, qx1, qy0, qy1) < 0.0f;
+                            const bool h0 = box_gap(b0, qx0, qx1, qy0, qy1) < 0.0f;
                             sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r;
                             count += h0 ? 1 : 0;
-                            const bool h1 = fmaxf(rec_gap(b1, qx0, qx1, qy0, qy1), r + 1 <= last ? -INFINITY : 1.0f) < 0.0f;
+                            const bool h1 = fmaxf(box_gap(b1, qx0, qx1, qy0, qy1), r + 1 <= last ? -INFINITY : 1.0f) < 0.0f;
                             sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 1;
                             count += h1 ? 1 : 0;
-                            const bool h2 = fmaxf(rec_gap(b2, qx0, qx1, qy0, qy1), r + 2 <= last ? -INFINITY : 1.0f) < 0.0f;
+                            const bool h2 = fmaxf(box_gap(b2, qx0, qx1, qy0, qy1), r + 2 <= last ? -INFINITY : 1.0f) < 0.0f;
                             sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 2;
                             count += h2 ? 1 : 0;
-                            const bool h3 = fmaxf(rec_gap(b3, qx0, qx1, qy0, qy1), r + 3 <= last ? -INFINITY : 1.0f) < 0.0f;
+                            const bool h3 = fmaxf(box_gap(b3, qx0, qx1, qy0, qy1), r + 3 <= last ? -INFINITY : 1.0f) < 0.0f;
                             sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 3;
                             count += h3 ? 1 : 0;
                         }
