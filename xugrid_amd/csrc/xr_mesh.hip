@@ -409,25 +409,35 @@ k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m_rt, const in
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= n) return;
-    const int k = key[f];
-    // `cursor` still holds the bucket histogram of the count pass: slots are handed out from the top down (the order
-    // inside a bucket is unspecified anyway), which saves re-zeroing the array between the two passes
-    const int64_t r = start[k] + atomicSub(&cursor[k], 1) - 1;
-    perm[r] = (int32_t)f;
+    // Two round trips instead of three: the face's node ids and the key go out together; then the returning atomic, and
+    // behind it -- not waiting for it -- the node gathers.  (Written key, atomic, node ids, gathers, the compiler issues the
+    // node ids only with the atomic and the gathers after its wait.)
     int face[MA];
 #pragma unroll
     for (int j = 0; j < MA; j++)
         if (j < m) face[j] = faces_raw[f * m + j];
+    const int k = key[f];
+    // `cursor` still holds the bucket histogram of the count pass: slots are handed out from the top down (the order
+    // inside a bucket is unspecified anyway), which saves re-zeroing the array between the two passes
+    const int64_t r = start[k] + atomicSub(&cursor[k], 1) - 1;
     int nl;
     bool flip;
     face_shape<MA>(node_xy, face, m, nl, flip);
+    constexpr bool PREFETCH = MC > 0; // (general polygons, up to 32 nodes: gathered in the loop below, not held in registers)
+    P2 pts[PREFETCH ? MA : 1];
+    if (PREFETCH) {
+#pragma unroll
+        for (int j = 0; j < MA; j++)
+            if (j < nl) pts[j] = load_p2(node_xy, face[j]);
+    }
+    perm[r] = (int32_t)f;
     o_len[r] = (uint8_t)nl;
     double2 *dst = reinterpret_cast<double2 *>(o_fxy) + r * m;
     double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
 #pragma unroll
     for (int j = 0; j < MA; j++) {
         if (j < nl) {
-            const P2 p = load_p2(node_xy, face[j]);
+            const P2 p = PREFETCH ? pts[PREFETCH ? j : 0] : load_p2(node_xy, face[j]);
             xmin = fmin(xmin, p.x);
             xmax = fmax(xmax, p.x);
             ymin = fmin(ymin, p.y);
