@@ -47,6 +47,7 @@ struct FusedCounters {                    // device words, zeroed before the lau
 // falls back to the scan-based pipeline.
 static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
 static constexpr int LB_SPIN_LIMIT = 1 << 16; // polls (~20 ms): far beyond any real wait
+static constexpr int LB_WIN = 8;              // status words per lane and poll: a look-back window of 512 blocks
 
 // exclusive prefix of this block's aggregate over all earlier blocks (called by the 64 lanes of wave 0); -1 = aborted
 __device__ __forceinline__ long long lookback_exclusive(unsigned long long *status, int b, long long aggregate, int lane,
@@ -56,31 +57,49 @@ __device__ __forceinline__ long long lookback_exclusive(unsigned long long *stat
         return 0;
     }
     if (lane == 0) __hip_atomic_store(&status[b], LB_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // Every round trip fetches the status words of LB_WIN * 64 predecessors (LB_WIN loads per lane, in flight together):
+    // all resident blocks start at about the same time, so the nearest PUBLISHED prefix is up to ~2000 blocks back and a
+    // 64-wide window needed ~30 dependent round trips per block (a third of the kernel's time, measured with clock64).
     long long exclusive = 0;
     int look = b - 1, spins = 0;
     while (true) {
-        const int idx = look - lane;
-        unsigned long long word = LB_PREFIX; // (virtual block -1: prefix 0)
-        if (idx >= 0) word = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long flag = word >> 62;
-        const unsigned long long not_ready = __ballot(flag == 0), has_prefix = __ballot(flag == 2);
-        const int first_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : 64;
-        const int first_wait = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
-        if (first_wait < first_prefix) { // a predecessor in the window has published nothing yet
+        unsigned long long word[LB_WIN];
+#pragma unroll
+        for (int k = 0; k < LB_WIN; k++) {
+            const int idx = look - lane - 64 * k;
+            word[k] = LB_PREFIX; // (virtual block -1: prefix 0)
+            if (idx >= 0) word[k] = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bool done = false, wait = false;
+        int advanced = 0;
+#pragma unroll
+        for (int k = 0; k < LB_WIN; k++) {
+            if (done || wait) continue; // (uniform)
+            const unsigned long long flag = word[k] >> 62;
+            const unsigned long long not_ready = __ballot(flag == 0), has_prefix = __ballot(flag == 2);
+            const int first_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : 64;
+            const int first_wait = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
+            if (first_wait < first_prefix) { // a predecessor in this window has published nothing yet
+                wait = true;
+                continue;
+            }
+            long long v = lane <= first_prefix ? (long long)(word[k] & LB_VALUE) : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            exclusive += v;
+            advanced = k + 1;
+            if (first_prefix < 64) done = true;
+        }
+        if (done) break;
+        look -= 64 * advanced; // (windows summed so far held aggregates only: they are final)
+        if (wait) {
             if (++spins > LB_SPIN_LIMIT || (__hip_atomic_load(error_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8)) {
                 if (lane == 0) atomicOr(error_bits, 8);
                 exclusive = -1;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
-            continue;
         }
-        long long v = lane <= first_prefix ? (long long)(word & LB_VALUE) : 0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        exclusive += v;
-        if (first_prefix < 64) break;
-        look -= 64;
     }
     // (after an abort the prefix is garbage, but it is published all the same so that nobody else spins)
     if (lane == 0)
@@ -201,7 +220,7 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
 // CSR assembly for the regular faces: the block that owns 256 consecutive target faces stages the source ids of its
 // stretch of the pair queue in LDS ("dead" for area <= 0), counts the survivors per face (LDS atomics), reserves its
 // rows and entries with ONE atomic, ranks every survivor among its row and writes it to its final CSR position.
-__global__ void __launch_bounds__(FB)
+__global__ void __launch_bounds__(FB, 2)
 k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm, int64_t n_query,
            const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_off,
            const int32_t *__restrict__ cand_count, const int2 *__restrict__ block_seg,
@@ -211,7 +230,6 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
            int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ row_order,
            int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap) {
     __shared__ int32_t sh_stage[SLOTS * FB];
-    __shared__ uint8_t sh_owner[SLOTS * FB];
     __shared__ int32_t sh_nnz[FB];     // survivors of the face (LDS atomics)
     __shared__ uint16_t sh_lo[FB];     // offset of the face's pairs inside the stretch
     __shared__ uint16_t sh_rowoff[FB]; // CSR offset of the face's row inside the block
@@ -239,13 +257,25 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
     }
     sh_cnt[tid] = (uint8_t)my_cnt;
     __syncthreads();
-    for (int i = tid; i < total; i += FB) {
-        const int64_t c = (int64_t)seg.x + i;
-        const int s = cand_sid[c];
-        const int row = cand_tgt[c] - (int)t0;
-        sh_stage[i] = s;
-        sh_owner[i] = (uint8_t)row;
-        if (s != 0x7fffffff) atomicAdd(&sh_nnz[row], 1);
+    // (the kernel is latency bound -- 84 % of its wave cycles wait, PMC -- so both entry loops keep the loads of four
+    // steps in flight instead of one)
+    for (int i0 = tid; i0 < total; i0 += 4 * FB) {
+        int s[4], row[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * FB;
+            const int64_t c = (int64_t)seg.x + (i < total ? i : total - 1);
+            s[u] = cand_sid[c];
+            row[u] = cand_tgt[c] - (int)t0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * FB;
+            if (i < total) {
+                sh_stage[i] = s[u];
+                if (s[u] != 0x7fffffff) atomicAdd(&sh_nnz[row[u]], 1);
+            }
+        }
     }
     __syncthreads();
     const int my_nnz = regular ? sh_nnz[tid] : 0;
@@ -278,20 +308,32 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
         if (my_nnz > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
     }
     bool overflow_cap = false;
-    for (int i = tid; i < total; i += FB) {
-        const int s = sh_stage[i];
-        if (s == 0x7fffffff) continue;
-        const int row = sh_owner[i];
-        const int a0 = sh_lo[row], a1 = a0 + sh_cnt[row];
-        int rank = 0;
-        for (int j = a0; j < a1; j++) rank += sh_stage[j] < s ? 1 : 0;
-        const long long pos = base + sh_rowoff[row] + rank;
-        const double a = cand_area[(int64_t)seg.x + i];
-        if (pos < csr_capacity) {
-            indices[pos] = s;
-            data[pos] = relative ? a / src_area[s] : a;
-        } else {
-            overflow_cap = true;
+    for (int i0 = tid; i0 < total; i0 += 4 * FB) {
+        double area[4];
+        int row[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * FB;
+            const int64_t c = (int64_t)seg.x + (i < total ? i : total - 1);
+            area[u] = cand_area[c];
+            row[u] = cand_tgt[c] - (int)t0; // (read again -- an L2 hit -- rather than kept in LDS)
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * FB;
+            if (i >= total) continue;
+            const int s = sh_stage[i];
+            if (s == 0x7fffffff) continue;
+            const int a0 = sh_lo[row[u]], a1 = a0 + sh_cnt[row[u]];
+            int rank = 0;
+            for (int j = a0; j < a1; j++) rank += sh_stage[j] < s ? 1 : 0;
+            const long long pos = base + sh_rowoff[row[u]] + rank;
+            if (pos < csr_capacity) {
+                indices[pos] = s;
+                data[pos] = relative ? area[u] / src_area[s] : area[u];
+            } else {
+                overflow_cap = true;
+            }
         }
     }
     if (overflow_cap) atomicOr(&counters->error, 4);
