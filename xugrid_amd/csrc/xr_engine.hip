@@ -397,7 +397,14 @@ ProfScope::~ProfScope() {
     g_pending.push_back({name, e0, e1});
 }
 
+// XR_NO_SIDE=1 (measurement hook): the "side" work runs in line on the main stream -- every kernel alone on the device
+static bool side_disabled() {
+    const char *v = getenv("XR_NO_SIDE");
+    return v && atoi(v) != 0;
+}
+
 SideScope::SideScope() {
+    if (side_disabled()) return;
     Engine &e = engine();
     XR_HIP(hipEventRecord(e.fork_event, e.stream));
     XR_HIP(hipStreamWaitEvent(e.side, e.fork_event, 0));
@@ -405,10 +412,12 @@ SideScope::SideScope() {
     g_side_active = true;
 }
 SideScope::~SideScope() {
+    if (side_disabled()) return;
     g_engine.on_side = false;
     (void)hipEventRecord(g_engine.join_event, g_engine.side);
 }
 void side_join() {
+    if (side_disabled()) return;
     Engine &e = engine();
     XR_HIP(hipStreamWaitEvent(e.stream, e.join_event, 0));
 }

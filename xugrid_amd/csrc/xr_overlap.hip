@@ -303,7 +303,7 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
 // not fit the queue as currently allocated are listed and filled by a second launch (FUSED = false) after the host
 // regrew it.  (The two-walk version -- count, reserve, fill -- took twice as long per face, and a big face is a
 // chain of dependent phases: the kernel's duration is the slowest face's.)
-static constexpr int BIG_STAGE = 6144;
+static constexpr int BIG_STAGE = 5120;
 
 template <bool FUSED>
 __global__ void __launch_bounds__(256)
@@ -314,6 +314,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
              const int32_t *__restrict__ n_big, int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count,
              int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
              int64_t capacity, int32_t *__restrict__ pending_list, int32_t *__restrict__ n_pending) {
+    __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     // one BLOCK per big face: its four waves take the 64-row batches round-robin; candidates are
     // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
     // ranked by tree face id afterwards)
@@ -958,6 +959,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
                 const int32_t *__restrict__ n_long, int64_t row_base /* >= 0: list entry li is stored row row_base + li */,
                 const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */) {
+    __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);          // [BM_WORDS]
     uint32_t *tbase = bm + BM_WORDS;                            // [256] exclusive over thread segments
@@ -1216,7 +1218,15 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                       cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
                       tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3);
         }
-        static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5; // tuning hook: persistent blocks per CU
+        // Persistent blocks per CU.  Five fill the LDS (5 x 28.5 KiB of 160): best for the clip alone, but then no block of
+        // the side stream's search_big (25 KiB each) can start before the clip ends, and the big faces' chain sticks out
+        // behind k_assemble.  With slivers in the target mesh (largest face extent >> the mean) three blocks per CU leave
+        // room for two or three search_big blocks: the clip itself takes 0.153 instead of 0.131 ms, the step 0.650 instead
+        // of 0.668 ms (benchmark pair).  XR_CLIP_BPC overrides (tuning hook).
+        static const int clip_bpc_env = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 0;
+        const double q_mean_ext = T > 0 ? query->h_stats[4] / (double)T : 0.0;
+        const bool slivers = query->h_stats[5] > 24.0 * q_mean_ext;
+        const int clip_bpc = clip_bpc_env > 0 ? clip_bpc_env : (slivers ? 3 : 5);
         XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                   query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                   ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,

@@ -143,6 +143,7 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
     __shared__ uint2 sh_lut[TRI_LUT];
+    if (skip_if) __builtin_amdgcn_s_setprio(3); // (the big faces' queue, on the side stream: issue priority over the main clip)
     if (skip_if && *skip_if > 0) return; // (big faces that did not fit their queue: the host redoes everything)
     tri_lut_init(sh_lut);
     __syncthreads();
@@ -348,6 +349,7 @@ static constexpr int BIG_RANK_MAX = 1 << 16;
 __global__ void __launch_bounds__(256)
 k_big_rank(const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big_dev, int32_t *__restrict__ slot_face,
            const int32_t *__restrict__ skip_if) {
+    __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     if (*skip_if > 0) return;
     __shared__ int32_t sh_face[1024];
     const int tid = threadIdx.x;
@@ -376,6 +378,7 @@ __global__ void __launch_bounds__(256)
 k_big_scan(const int32_t *__restrict__ slot_face, const int32_t *__restrict__ n_big_dev,
            const int32_t *__restrict__ nnz_row /* per face */, int32_t *__restrict__ big_indptr /* [n_big + 1] */,
            FusedCounters *counters, const int32_t *__restrict__ skip_if) {
+    __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     if (*skip_if > 0) return;
     __shared__ int32_t sh_part[256];
     const int tid = threadIdx.x;
