@@ -304,6 +304,7 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
 // regrew it.  (The two-walk version -- count, reserve, fill -- took twice as long per face, and a big face is a
 // chain of dependent phases: the kernel's duration is the slowest face's.)
 static constexpr int BIG_STAGE = 5120;
+static constexpr int BIG_RANK_MAX = 1 << 16; // big faces ranked by id (all-pairs, inside k_search_big); longer lists keep their order
 
 template <bool FUSED>
 __global__ void __launch_bounds__(256)
@@ -313,7 +314,8 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
              const int32_t *__restrict__ rec_face, const int32_t *__restrict__ big_list,
              const int32_t *__restrict__ n_big, int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count,
              int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
-             int64_t capacity, int32_t *__restrict__ pending_list, int32_t *__restrict__ n_pending) {
+             int64_t capacity, int32_t *__restrict__ pending_list, int32_t *__restrict__ n_pending,
+             int32_t *__restrict__ slot_face = nullptr /* optional: the listed faces in ascending id order, written */) {
     __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     // one BLOCK per big face: its four waves take the 64-row batches round-robin; candidates are
     // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
@@ -326,10 +328,23 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
     const int nb = *n_big;
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    __shared__ int32_t sh_rankw[4];
     for (int bi = blockIdx.x; bi < nb; bi += gridDim.x) {
         const int t = big_list[bi];
         const int np = q_len[t];
+        if (slot_face) {
+            // the face's rank among the listed ones by face id (k_search lists them in finishing order; ranking makes the
+            // stored matrix the same from run to run).  Lists beyond BIG_RANK_MAX faces keep the order they were found in.
+            int c = 0;
+            if (nb <= BIG_RANK_MAX)
+                for (int j = threadIdx.x; j < nb; j += 256) c += big_list[j] < t ? 1 : 0;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+            if (lane == 0) sh_rankw[wv] = c;
+        }
         __syncthreads();
+        if (slot_face && threadIdx.x == 0)
+            slot_face[nb <= BIG_RANK_MAX ? sh_rankw[0] + sh_rankw[1] + sh_rankw[2] + sh_rankw[3] : bi] = t;
         if (threadIdx.x < np) sh_poly[threadIdx.x] = reinterpret_cast<const double2 *>(q_fxy)[face_vertex_base(q_off, t, q_m) + threadIdx.x];
         if (threadIdx.x == 0) sh_cursor = 0;
         __syncthreads();
@@ -958,7 +973,11 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 const double *__restrict__ src_area, bool relative, int64_t n_tree, int32_t *__restrict__ indices,
                 double *__restrict__ data, const int32_t *__restrict__ long_rows,
                 const int32_t *__restrict__ n_long, int64_t row_base /* >= 0: list entry li is stored row row_base + li */,
-                const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */) {
+                const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */,
+                const int32_t *__restrict__ scan_nnz = nullptr /* optional: row lengths per FACE; the offsets of the listed rows
+                                                                  are then computed here (exclusive scan in list order) */,
+                int32_t *__restrict__ scan_indptr = nullptr /* [n_long + 1], written */,
+                int32_t *__restrict__ scan_total = nullptr /* total entries, written */) {
     __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint32_t *bm = reinterpret_cast<uint32_t *>(smem);          // [BM_WORDS]
@@ -969,10 +988,45 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (skip_if && *skip_if > 0) return;
     const int nl = *n_long;
+    // block-wide sum of the lengths of the listed rows [k0, k1) (scan_nnz mode)
+    auto length_sum = [&](int k0, int k1) -> long long {
+        long long v = 0;
+        for (int k = k0 + tid; k < k1; k += 256) v += scan_nnz[long_rows[k]];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = (int32_t)(v > 0x7fffffffll ? 0x7fffffff : v);
+        __syncthreads();
+        return (long long)red[0] + red[1] + red[2] + red[3];
+    };
+    long long scan_base = 0; // offset of row blockIdx.x, advanced by gridDim.x rows per trip
+    if (scan_nnz) {
+        scan_base = length_sum(0, blockIdx.x < nl ? (int)blockIdx.x : nl);
+        if (blockIdx.x == 0 && nl == 0 && tid == 0) {
+            scan_indptr[0] = 0;
+            *scan_total = 0;
+        }
+    }
     for (int li = blockIdx.x; li < nl; li += gridDim.x) {
         const int t = long_rows[li];
         const int c0 = cand_off[t], n = cand_count[t];
-        const int base = row_base >= 0 ? indptr[row_base + li] : indptr[t];
+        int base;
+        if (scan_nnz) {
+            const long long capped = scan_base > 0x7fffffffll ? 0x7fffffffll : scan_base;
+            base = (int)capped;
+            if (tid == 0) {
+                scan_indptr[li] = base;
+                if (li == nl - 1) { // the last listed row closes the offsets
+                    const long long all = capped + scan_nnz[t];
+                    scan_indptr[nl] = (int32_t)(all > 0x7fffffffll ? 0x7fffffff : all);
+                    *scan_total = scan_indptr[nl];
+                }
+            }
+            const int next = li + (int)gridDim.x;
+            scan_base += length_sum(li, next < nl ? next : nl);
+        } else {
+            base = row_base >= 0 ? indptr[row_base + li] : indptr[t];
+        }
         __syncthreads();
         // park the row: survivor id or -1 (four independent pairs of loads per thread and trip)
         for (int i0 = tid; i0 < n && i0 < BM_STAGE; i0 += 4 * 256) {
@@ -1205,28 +1259,24 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
                       query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
                       big_list.get(), ctl.get() + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
-                      ctl.get() + 1, big_capacity, pending.get(), ctl.get() + 3);
+                      ctl.get() + 1, big_capacity, pending.get(), ctl.get() + 3, slot_face.get());
             // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
             XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl.get() + 1,
                       big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl.get() + 3);
-            XR_LAUNCH("big_rank", k_big_rank, dim3(64), dim3(256), 0, big_list.get(), ctl.get() + 2, slot_face.get(),
-                      ctl.get() + 3);
-            XR_LAUNCH("big_scan", k_big_scan, dim3(1), dim3(256), 0, slot_face.get(), ctl.get() + 2, nnz_row.get(),
-                      big_indptr.get(), fc, ctl.get() + 3);
+            // (rows in face order: ranked inside search_big; their offsets: scanned inside row_fill_long -- two launches less
+            // in what is the critical path of the whole weight build)
             XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
                       cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
-                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3);
+                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3,
+                      nnz_row.get(), big_indptr.get(), &fc->p_big);
         }
-        // Persistent blocks per CU.  Five fill the LDS (5 x 28.5 KiB of 160): best for the clip alone, but then no block of
-        // the side stream's search_big (25 KiB each) can start before the clip ends, and the big faces' chain sticks out
-        // behind k_assemble.  With slivers in the target mesh (largest face extent >> the mean) three blocks per CU leave
-        // room for two or three search_big blocks: the clip itself takes 0.153 instead of 0.131 ms, the step 0.650 instead
-        // of 0.668 ms (benchmark pair).  XR_CLIP_BPC overrides (tuning hook).
-        static const int clip_bpc_env = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 0;
-        const double q_mean_ext = T > 0 ? query->h_stats[4] / (double)T : 0.0;
-        const bool slivers = query->h_stats[5] > 24.0 * q_mean_ext;
-        const int clip_bpc = clip_bpc_env > 0 ? clip_bpc_env : (slivers ? 3 : 5);
+        // Persistent blocks per CU: five fill the LDS and the register files (best for the clip alone).  The big faces' chain
+        // on the side stream then gets few wave slots while the clip runs; with its kernels at raised wave priority and only
+        // three launches long (search_big -> clip -> row_fill_long) it still ends about when k_assemble does: 3, 4 and 5
+        // blocks per CU all give the same step (0.635 ms) -- measured after the chain lost two launches; before, 3 was
+        // 4 % faster because the chain was the critical path.  XR_CLIP_BPC overrides (tuning hook).
+        static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5;
         XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                   query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                   ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,

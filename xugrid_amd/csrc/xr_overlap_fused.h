@@ -13,7 +13,7 @@
 //                             counters in HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)
 //   big faces (hull slivers, > SLOTS hits; 0.1 % of the faces, but their block-per-face kernels are chains of dependent
 //   phases: 15 % of the step when run in line) on a SIDE STREAM, forked behind k_search: k_search_big -> k_clip_tri_queue on
-//   their own pair queue -> k_big_rank / k_big_scan (rows in face order, scan of their lengths) -> k_row_fill_long into a small
+//   their own pair queue -> k_row_fill_long (rows in face order as ranked by k_search_big; scans their lengths itself) into a small
 //   CSR of their own; joined behind k_assemble, k_place_big copies those rows BEHIND the regular ones.
 //   [host: sizes + error bits: ONE round trip for the whole weight matrix]
 // Measured and discarded on the way (MI355X, benchmark pair): a fully fused search + clip + assembly block (pairs never
@@ -341,68 +341,8 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
 }
 
 // ---- the big faces' rows (side stream) -------------------------------------------------------------------------------
-// Order of the big faces' rows: by face id (k_search lists them in finishing order; ranking makes the stored matrix the
-// same from run to run).  All-pairs rank, the list read through LDS in tiles; several blocks (the list length is only
-// known on the device: grid-stride).  Lists beyond BIG_RANK_MAX faces (a coarse target over a fine source) keep the
-// order they were found in.
-static constexpr int BIG_RANK_MAX = 1 << 16;
-__global__ void __launch_bounds__(256)
-k_big_rank(const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big_dev, int32_t *__restrict__ slot_face,
-           const int32_t *__restrict__ skip_if) {
-    __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
-    if (*skip_if > 0) return;
-    __shared__ int32_t sh_face[1024];
-    const int tid = threadIdx.x;
-    const int n_big = *n_big_dev;
-    const bool sorted = n_big <= BIG_RANK_MAX;
-    for (int k0 = blockIdx.x * 256; k0 < n_big; k0 += gridDim.x * 256) {
-        const int k = k0 + tid;
-        const int f = k < n_big ? big_list[k] : 0x7fffffff;
-        int rank = sorted ? 0 : k;
-        for (int j0 = 0; j0 < n_big && sorted; j0 += 1024) {
-            __syncthreads();
-            for (int j = tid; j < 1024; j += 256) sh_face[j] = j0 + j < n_big ? big_list[j0 + j] : 0x7fffffff;
-            __syncthreads();
-            const int4 *quad = reinterpret_cast<const int4 *>(sh_face);
-            for (int j = 0; j < 256; j++) {
-                const int4 q = quad[j];
-                rank += (q.x < f) + (q.y < f) + (q.z < f) + (q.w < f);
-            }
-        }
-        if (k < n_big) slot_face[rank] = f;
-    }
-}
-
-// exclusive scan of the big rows' lengths in slot order (one block)
-__global__ void __launch_bounds__(256)
-k_big_scan(const int32_t *__restrict__ slot_face, const int32_t *__restrict__ n_big_dev,
-           const int32_t *__restrict__ nnz_row /* per face */, int32_t *__restrict__ big_indptr /* [n_big + 1] */,
-           FusedCounters *counters, const int32_t *__restrict__ skip_if) {
-    __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
-    if (*skip_if > 0) return;
-    __shared__ int32_t sh_part[256];
-    const int tid = threadIdx.x;
-    const int n_big = *n_big_dev;
-    const int chunk = (n_big + 255) / 256;
-    const int k0 = min(tid * chunk, n_big), k1 = min(k0 + chunk, n_big);
-    int sum = 0;
-    for (int k = k0; k < k1; k++) sum += nnz_row[slot_face[k]];
-    sh_part[tid] = sum;
-    __syncthreads();
-    long long off = 0, all = 0;
-    for (int j = 0; j < 256; j++) {
-        if (j < tid) off += sh_part[j];
-        all += sh_part[j];
-    }
-    for (int k = k0; k < k1; k++) {
-        big_indptr[k] = (int32_t)off;
-        off += nnz_row[slot_face[k]];
-    }
-    if (tid == 0) {
-        big_indptr[n_big] = (int32_t)(all > 0x7fffffffll ? 0x7fffffff : all);
-        counters->p_big = big_indptr[n_big];
-    }
-}
+// Their order (by face id) is established inside k_search_big (slot_face), their offsets inside k_row_fill_long (scan_nnz
+// mode): the chain search_big -> clip -> row_fill_long is the critical path of the weight build, every launch less counts.
 
 // The finished rows of the big faces (ranked by k_row_fill_long into big_indices / big_data on the side stream) go
 // BEHIND the regular rows: stored row T - n_big + slot.  Grid-stride over rows and entries.
