@@ -15,6 +15,8 @@
 #include <cstring>
 #include <vector>
 
+#include <memory>
+
 #include "xr_objects.h"
 
 namespace xr {
@@ -1396,6 +1398,38 @@ static inline const int32_t *row_order_of(const xr_csr *csr) {
 
 template <int METHOD, typename SRC>
 static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *out) {
+    // With many variables the long rows (hull slivers: a few hundred latency-bound rows, 0.25 ms of the 1.9 ms at K = 256) run
+    // on the side stream BESIDE the short ones -- disjoint output rows -- instead of behind them.  For one variable the
+    // fork / join events cost more than the 30 us they could hide (0.069 -> 0.075 ms): in line there.
+    DevBuf<int32_t> huge;
+    std::unique_ptr<SideScope> side;
+    if (csr->has_long) {
+        huge.alloc((size_t)(csr->nnz / APPLY_WAVE + 2));
+        if (K >= PLAN_KT) side.reset(new SideScope);
+        XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), launch_stream()));
+        if (K == 1) {
+            // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: lane groups / waves; a single variable
+            dim3 wgrid((unsigned)engine().num_cu * 16, 1);
+            XR_LAUNCH("apply_wave", (k_apply_wave<METHOD, SRC, 1>), wgrid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                      csr->n, csr->m, src, K, out, huge.get());
+        } else {
+            // ... 8 variables per pass
+            constexpr int WT = 8;
+            const unsigned wy = (unsigned)std::min<int64_t>(div_up(K, WT), 8);
+            dim3 wgrid((unsigned)engine().num_cu * 16 / wy, wy);
+            XR_LAUNCH("apply_wave", (k_apply_wave<METHOD, SRC, WT>), wgrid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
+                      csr->n, csr->m, src, K, out, huge.get());
+        }
+        // rows beyond APPLY_WAVE entries, as queued by the wave kernel: one block each
+        const unsigned gy = (unsigned)(K < 8 ? K : 8);
+        dim3 grid((unsigned)engine().num_cu * (8 / gy), gy); // 8 blocks per CU; blocks past the count exit at once
+        XR_LAUNCH("apply_long", (k_apply_long<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), huge.get() + 1, huge.get(),
+                  csr->n, csr->m, src, K, out);
+        side.reset(); // (end of the side scope: later launches go to the main stream again)
+    }
     if (K == 1) {
         dim3 grid(div_up(csr->n, AP_BLOCK), 1);
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
@@ -1438,31 +1472,7 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                       out, (const int32_t *)nullptr);
         }
     }
-    if (csr->has_long) {
-        DevBuf<int32_t> huge((size_t)(csr->nnz / APPLY_WAVE + 2));
-        XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), launch_stream()));
-        if (K == 1) {
-            // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: lane groups / waves; a single variable
-            dim3 wgrid((unsigned)engine().num_cu * 16, 1);
-            XR_LAUNCH("apply_wave", (k_apply_wave<METHOD, SRC, 1>), wgrid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
-                      csr->n, csr->m, src, K, out, huge.get());
-        } else {
-            // ... 8 variables per pass
-            constexpr int WT = 8;
-            const unsigned wy = (unsigned)std::min<int64_t>(div_up(K, WT), 8);
-            dim3 wgrid((unsigned)engine().num_cu * 16 / wy, wy);
-            XR_LAUNCH("apply_wave", (k_apply_wave<METHOD, SRC, WT>), wgrid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
-                      csr->n, csr->m, src, K, out, huge.get());
-        }
-        // rows beyond APPLY_WAVE entries, as queued by the wave kernel: one block each
-        const unsigned gy = (unsigned)(K < 8 ? K : 8);
-        dim3 grid((unsigned)engine().num_cu * (8 / gy), gy); // 8 blocks per CU; blocks past the count exit at once
-        XR_LAUNCH("apply_long", (k_apply_long<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), huge.get() + 1, huge.get(),
-                  csr->n, csr->m, src, K, out);
-    }
+    if (csr->has_long && K >= PLAN_KT) side_join();
 }
 
 template <int METHOD, typename SRC>

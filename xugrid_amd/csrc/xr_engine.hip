@@ -2,6 +2,7 @@
 #include <cstdarg>
 
 #include <algorithm>
+#include <map>
 #include <cstring>
 #include <thread>
 
@@ -80,6 +81,11 @@ SharedScope::~SharedScope() {
     if (!leased) return;
     if (t_lane) {
         (void)hipStreamSynchronize(t_lane->stream); // the call is over: nothing of it is in flight
+        if (t_lane->side_active) { // (a call that failed between fork and join)
+            (void)hipStreamSynchronize(t_lane->side);
+            t_lane->side_active = false;
+            t_lane->on_side = false;
+        }
         lane_release_blocks(t_lane);
         Lane *lane = t_lane;
         t_lane = nullptr;
@@ -190,13 +196,15 @@ void *pool_alloc(size_t bytes) {
 // by code on one stream could otherwise be given to the other while a kernel of the first still touches it.
 static bool g_side_active = false;
 static std::vector<std::pair<size_t, void *>> g_deferred;
+static std::map<Lane *, std::vector<std::pair<size_t, void *>>> g_lane_deferred; // the same per lane, until its side_join()
 
 void pool_free(void *p) {
     if (!p) return;
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     auto it = g_live.find(p);
     if (it == g_live.end()) return;
-    if (t_lane) g_lane_free[t_lane].emplace(it->second, p);
+    if (t_lane && t_lane->side_active) g_lane_deferred[t_lane].emplace_back(it->second, p);
+    else if (t_lane) g_lane_free[t_lane].emplace(it->second, p);
     else if (g_side_active) g_deferred.emplace_back(it->second, p);
     else g_free.emplace(it->second, p);
     g_live.erase(it);
@@ -205,6 +213,8 @@ void pool_free(void *p) {
 static void lane_release_blocks(Lane *lane) {
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     auto &mine = g_lane_free[lane];
+    for (auto &kv : g_lane_deferred[lane]) mine.emplace(kv.first, kv.second); // (the lane, side stream included, is drained)
+    g_lane_deferred[lane].clear();
     for (auto &kv : mine) g_free.emplace(kv.first, kv.second);
     mine.clear();
 }
@@ -405,19 +415,58 @@ static bool side_disabled() {
 
 SideScope::SideScope() {
     if (side_disabled()) return;
+    if (Lane *l = current_lane()) {
+        if (!l->side) {
+            hipStream_t st = nullptr;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError();
+                return; // (no side stream: in line)
+            }
+            l->side = st;
+            l->fork_event = a;
+            l->join_event = b;
+        }
+        XR_HIP(hipEventRecord(l->fork_event, l->stream));
+        XR_HIP(hipStreamWaitEvent(l->side, l->fork_event, 0));
+        l->on_side = true;
+        l->side_active = true;
+        mode = 2;
+        return;
+    }
+    if (t_exclusive_depth == 0) return; // a shared call on a caller's stream: several threads may be here, no common side stream
     Engine &e = engine();
     XR_HIP(hipEventRecord(e.fork_event, e.stream));
     XR_HIP(hipStreamWaitEvent(e.side, e.fork_event, 0));
     e.on_side = true;
     g_side_active = true;
+    mode = 1;
 }
 SideScope::~SideScope() {
-    if (side_disabled()) return;
-    g_engine.on_side = false;
-    (void)hipEventRecord(g_engine.join_event, g_engine.side);
+    if (mode == 2) {
+        Lane *l = current_lane();
+        l->on_side = false;
+        (void)hipEventRecord(l->join_event, l->side);
+    } else if (mode == 1) {
+        g_engine.on_side = false;
+        (void)hipEventRecord(g_engine.join_event, g_engine.side);
+    }
 }
 void side_join() {
     if (side_disabled()) return;
+    if (Lane *l = current_lane()) {
+        if (!l->side_active) return;
+        XR_HIP(hipStreamWaitEvent(l->stream, l->join_event, 0));
+        l->side_active = false; // everything enqueued on the lane's stream from here on runs behind the side work
+        std::lock_guard<std::mutex> lock(g_pool_mutex);
+        auto &mine = g_lane_free[l];
+        for (auto &kv : g_lane_deferred[l]) mine.emplace(kv.first, kv.second);
+        g_lane_deferred[l].clear();
+        return;
+    }
+    if (t_exclusive_depth == 0) return;
     Engine &e = engine();
     XR_HIP(hipStreamWaitEvent(e.stream, e.join_event, 0));
 }
@@ -426,8 +475,10 @@ void prof_flush() {
     if (g_pending.empty()) return;
     (void)hipStreamSynchronize(g_engine.stream);
     (void)hipStreamSynchronize(g_engine.side);
-    for (auto &l : g_lanes)
+    for (auto &l : g_lanes) {
         if (l.stream) (void)hipStreamSynchronize(l.stream);
+        if (l.side) (void)hipStreamSynchronize(l.side);
+    }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &p : g_pending) {
         float ms = 0.f;

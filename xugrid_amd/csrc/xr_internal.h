@@ -183,20 +183,28 @@ struct Lane {
     hipStream_t stream = nullptr;
     char *stage[2] = {nullptr, nullptr}; // pinned staging buffers of the big host <-> device copies
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    // the lane's own side stream (SideScope inside a shared call: e.g. the long rows of an apply beside the short ones)
+    hipStream_t side = nullptr;
+    hipEvent_t fork_event = nullptr, join_event = nullptr;
+    bool on_side = false;     // launches go to `side`
+    bool side_active = false; // forked and not yet joined: blocks freed meanwhile are parked (see pool_free)
     std::mutex busy;
 };
 Lane *current_lane(); // the calling thread's lane, nullptr on the engine's own (exclusive) path
 
 inline hipStream_t launch_stream() {
-    if (Lane *l = current_lane()) return l->stream;
+    if (Lane *l = current_lane()) return l->on_side ? l->side : l->stream;
     return engine().on_side ? engine().side : engine().stream;
 }
 
 // RAII: launches inside the scope go to the side stream, which first waits for everything enqueued on the main
 // stream so far; join() makes the main stream wait for the side stream's work
+// Works on the engine's own (exclusive) path and inside a shared call that has a lane; elsewhere (a shared call bound to
+// a caller's stream) the scope is a no-op and the work simply runs in line.
 struct SideScope {
     SideScope();
     ~SideScope();
+    int mode = 0; // 0: in line, 1: engine side stream, 2: the lane's side stream
 };
 void side_join();
 
