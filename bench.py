@@ -649,8 +649,8 @@ def run_multi(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--points", type=int, default=500_000, help="lattice points per mesh and per GPU (faces ~ 2x)")
     ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")

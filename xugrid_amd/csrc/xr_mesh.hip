@@ -355,13 +355,43 @@ void mesh_read_stats(xr_mesh *mesh) {
 // so that final results do not depend on it.
 // ---------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ int face_cell(const GridParams &g, double4 bb) {
+// ---- one global atomic per DISTINCT key of a block instead of one per face.  Faces arrive spatially coherent: the 256 faces
+// of a block fall into ~80 cells; device-scope atomics on scattered addresses are what bounds both sorting passes
+// (1 M of them: ~30 us).  Open-addressing table in LDS; key -1 = no face.
+static constexpr int AGG_SLOTS = 512;
+struct KeyTable {
+    int32_t key[AGG_SLOTS];
+    int32_t cnt[AGG_SLOTS];
+    int32_t base[AGG_SLOTS];
+};
+__device__ __forceinline__ void agg_clear(KeyTable &t) {
+    for (int s = threadIdx.x; s < AGG_SLOTS; s += 256) {
+        t.key[s] = -1;
+        t.cnt[s] = 0;
+    }
+}
+// -> slot of the key in the table; `rank` = position of this face among the block's faces with the same key
+__device__ __forceinline__ int agg_insert(KeyTable &t, int k, int &rank) {
+    int s = (int)(((unsigned)k * 2654435761u) >> 23) & (AGG_SLOTS - 1);
+    while (true) {
+        const int prev = atomicCAS(&t.key[s], -1, k);
+        if (prev == -1 || prev == k) break;
+        s = (s + 1) & (AGG_SLOTS - 1);
+    }
+    rank = atomicAdd(&t.cnt[s], 1);
+    return s;
+}
+
+// (`lv` = the per-level grid sizes in LDS, [0..L) nx, [L..2L) ny, [2L..3L) base: the level differs from lane to lane, and
+// indexing the kernel ARGUMENT g.nx[l] with it compiles to three dependent global loads per face)
+__device__ __forceinline__ int face_cell(const GridParams &g, const int32_t *lv, double4 bb) {
     const double e = fmax(bb.y - bb.x, bb.w - bb.z);
     const int l = level_of_extent(g, e);
     const double inv_h = level_inv_h(g, l);
-    const int cx = cell_coord(bb.x, g.x0, inv_h, g.nx[l]);
-    const int cy = cell_coord(bb.z, g.y0, inv_h, g.ny[l]);
-    return g.base[l] + cy * g.nx[l] + cx;
+    const int nx = lv[l], ny = lv[MAX_LEVELS + l], base = lv[2 * MAX_LEVELS + l];
+    const int cx = cell_coord(bb.x, g.x0, inv_h, nx);
+    const int cy = cell_coord(bb.z, g.y0, inv_h, ny);
+    return base + cy * nx + cx;
 }
 
 // (the bbox comes from the raw mesh, like in the scatter pass: node gathers hit the L2-resident node array)
@@ -371,28 +401,45 @@ k_spatial_count(const double *__restrict__ node_xy, const int32_t *__restrict__ 
                 GridParams g, MortonParams mp, int32_t *__restrict__ key, int32_t *__restrict__ count) {
     constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
     const int m = MC > 0 ? MC : m_rt;
+    __shared__ int32_t sh_lv[3 * MAX_LEVELS];
+    if (INDEX) {
+        if (threadIdx.x < MAX_LEVELS) {
+            sh_lv[threadIdx.x] = g.nx[threadIdx.x];
+            sh_lv[MAX_LEVELS + threadIdx.x] = g.ny[threadIdx.x];
+            sh_lv[2 * MAX_LEVELS + threadIdx.x] = g.base[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    __shared__ KeyTable sh_tab;
+    agg_clear(sh_tab);
+    __syncthreads();
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n) return;
-    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-    bool open = true;
+    if (f < n) {
+        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        bool open = true;
 #pragma unroll
-    for (int j = 0; j < MA; j++) {
-        if (j < m) {
-            const int v = faces_raw[f * m + j];
-            open = open && !(j >= 3 && v < 0); // polygon_length: stop at the first fill value
-            if (open) {
-                const P2 p = load_p2(node_xy, v);
-                xmin = fmin(xmin, p.x);
-                xmax = fmax(xmax, p.x);
-                ymin = fmin(ymin, p.y);
-                ymax = fmax(ymax, p.y);
+        for (int j = 0; j < MA; j++) {
+            if (j < m) {
+                const int v = faces_raw[f * m + j];
+                open = open && !(j >= 3 && v < 0); // polygon_length: stop at the first fill value
+                if (open) {
+                    const P2 p = load_p2(node_xy, v);
+                    xmin = fmin(xmin, p.x);
+                    xmax = fmax(xmax, p.x);
+                    ymin = fmin(ymin, p.y);
+                    ymax = fmax(ymax, p.y);
+                }
             }
         }
+        const double4 bb = make_double4(xmin, xmax, ymin, ymax);
+        const int k = INDEX ? face_cell(g, sh_lv, bb) : morton_key(mp, bb);
+        key[f] = k;
+        int rank;
+        agg_insert(sh_tab, k, rank);
     }
-    const double4 bb = make_double4(xmin, xmax, ymin, ymax);
-    const int k = INDEX ? face_cell(g, bb) : morton_key(mp, bb);
-    key[f] = k;
-    atomicAdd(&count[k], 1);
+    __syncthreads();
+    for (int s = threadIdx.x; s < AGG_SLOTS; s += 256)
+        if (sh_tab.key[s] >= 0) atomicAdd(&count[sh_tab.key[s]], sh_tab.cnt[s]);
 }
 
 // The face's CCW-normalised vertex block and its bbox are recomputed from the raw mesh (node gathers hit the
