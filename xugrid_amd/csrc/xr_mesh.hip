@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <memory>
+
 #include "xr_objects.h"
 
 namespace xr {
@@ -268,7 +270,7 @@ void mesh_face_coords(xr_mesh *mesh) {
     mesh->fxy_valid = true;
 }
 
-void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
+void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side) {
     // two depths: statistics only (want_fxy = false: the mesh is used as a tree) or statistics + the caller-order
     // len / bbox / vertex blocks a query needs.  A mesh prepared light and later used as a query is prepared again.
     if (mesh->prepared && (mesh->has_attrs || !want_fxy)) return;
@@ -307,9 +309,14 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy) {
         mesh->stats_host = static_cast<double *>(p);
         XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
     }
-    XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
-              mesh->stats_host);
-    XR_HIP(hipEventRecord(mesh->stats_event, launch_stream()));
+    {
+        // (a one-block kernel that ends with writes to pinned host memory: ~10 us, which only the host waits for)
+        std::unique_ptr<SideScope> side;
+        if (stats_on_side) side.reset(new SideScope);
+        XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
+                  mesh->stats_host);
+        XR_HIP(hipEventRecord(mesh->stats_event, launch_stream()));
+    }
     mesh->prepared = true;
     mesh->stats_valid = false;
 }

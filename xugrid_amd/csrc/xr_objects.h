@@ -135,7 +135,8 @@ struct xr_outer {
 };
 
 namespace xr {
-void mesh_prepare(xr_mesh *mesh, bool want_fxy = true);
+void mesh_prepare(xr_mesh *mesh, bool want_fxy = true, bool stats_on_side = false); // stats_on_side: the reduction of the
+    // statistics (only the HOST reads them) leaves the main stream: kernels queued behind the prepare pass do not wait for it
 const double *mesh_area(xr_mesh *mesh); // connectivity.area in the caller's face order (computed on first use)
 void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex blocks exist
 void mesh_query_order(xr_mesh *mesh);

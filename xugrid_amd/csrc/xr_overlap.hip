@@ -1321,7 +1321,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     // (the query side on the side stream next to the tree side was measured: the prepare kernels are bandwidth bound and
     // just slow each other down, 0.684 -> 0.706 ms per step)
     mesh_prepare(tree, false); // the tree side only needs its records (built from the raw mesh)
-    mesh_prepare(query, true);
+    mesh_prepare(query, true, /*stats_on_side=*/true); // (its statistics are first read by mesh_query_order below)
     mesh_build_index(tree);
     mesh_query_order(query);
     const double *tree_area = relative ? mesh_area(tree) : nullptr;
