@@ -389,8 +389,10 @@ template <int METHOD, typename SRC, int KTILE, int CH>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                const double *__restrict__ data, const int32_t *__restrict__ row_order, bool skip_long, int64_t T,
-               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out) {
+               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out,
+               int32_t *__restrict__ zero_word = nullptr /* optional: counter of the long-row kernels queued behind */) {
     __shared__ double sh_w[CH];
+    if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0;
     __shared__ double sh_v[KTILE][CH];
     // (last row blocks first: weights built by xr_overlap keep the rows of the big target faces -- the long ones --
     // at the end, and a kernel should start with its heaviest blocks)
@@ -1398,15 +1400,15 @@ static inline const int32_t *row_order_of(const xr_csr *csr) {
 
 template <int METHOD, typename SRC>
 static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *out) {
-    // With many variables the long rows (hull slivers: a few hundred latency-bound rows, 0.25 ms of the 1.9 ms at K = 256) run
-    // on the side stream BESIDE the short ones -- disjoint output rows -- instead of behind them.  For one variable the
-    // fork / join events cost more than the 30 us they could hide (0.069 -> 0.075 ms): in line there.
+    // The long rows (hull slivers: a few hundred latency-bound rows).  With many variables they run on the side stream BESIDE
+    // the short ones -- disjoint output rows (0.25 ms of the 1.9 ms at K = 256).  For one variable the fork / join events
+    // cost more than the 30 us they could hide (0.069 -> 0.075 ms): there they follow apply_stream in line, which also
+    // zeroes their queue counter (no memset launch), and the block-per-row kernel is skipped when the builder reported
+    // that no row exceeds the wave kernel's reach.
     DevBuf<int32_t> huge;
-    std::unique_ptr<SideScope> side;
-    if (csr->has_long) {
-        huge.alloc((size_t)(csr->nnz / APPLY_WAVE + 2));
-        if (K >= PLAN_KT) side.reset(new SideScope);
-        XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), launch_stream()));
+    if (csr->has_long) huge.alloc((size_t)(csr->nnz / APPLY_WAVE + 2));
+    auto launch_long_rows = [&](bool zeroed) {
+        if (!zeroed) XR_HIP(hipMemsetAsync(huge.get(), 0, sizeof(int32_t), launch_stream()));
         if (K == 1) {
             // rows of APPLY_LONG + 1 ... APPLY_WAVE entries: lane groups / waves; a single variable
             dim3 wgrid((unsigned)engine().num_cu * 16, 1);
@@ -1422,18 +1424,25 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
                       csr->n, csr->m, src, K, out, huge.get());
         }
+        if (csr->max_row_len >= 0 && csr->max_row_len <= APPLY_WAVE) return; // no row for the block kernel
         // rows beyond APPLY_WAVE entries, as queued by the wave kernel: one block each
         const unsigned gy = (unsigned)(K < 8 ? K : 8);
         dim3 grid((unsigned)engine().num_cu * (8 / gy), gy); // 8 blocks per CU; blocks past the count exit at once
         XR_LAUNCH("apply_long", (k_apply_long<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->data.get(), row_order_of(csr), huge.get() + 1, huge.get(),
                   csr->n, csr->m, src, K, out);
-        side.reset(); // (end of the side scope: later launches go to the main stream again)
+    };
+    const bool long_on_side = csr->has_long && K >= PLAN_KT;
+    if (long_on_side) {
+        SideScope side;
+        launch_long_rows(false);
     }
     if (K == 1) {
         dim3 grid(div_up(csr->n, AP_BLOCK), 1);
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out);
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out,
+                  csr->has_long ? huge.get() : (int32_t *)nullptr);
+        if (csr->has_long) launch_long_rows(true);
     } else {
         const bool no_plan = getenv("XR_APPLY_NO_PLAN") != nullptr; // measurement / test switch, read per call
         if (K >= PLAN_KT && !no_plan) {
@@ -1472,7 +1481,8 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                       out, (const int32_t *)nullptr);
         }
     }
-    if (csr->has_long && K >= PLAN_KT) side_join();
+    if (csr->has_long && K > 1 && !long_on_side) launch_long_rows(false); // (a few variables: in line, behind the short rows)
+    if (long_on_side) side_join();
 }
 
 template <int METHOD, typename SRC>

@@ -98,6 +98,7 @@ struct xr_csr {
     // stored rows with more than XR_APPLY_LONG_ROW entries (reduced by one wave or block each in the apply)
     xr::DevBuf<int32_t> long_rows; // [<= n]
     xr::DevBuf<int32_t> n_long;    // [1] device-side count
+    int64_t max_row_len = -1;      // entries of the longest row if the builder reported it (-1: unknown)
     bool has_long = false;
     // Coarse Morton key per STORED row (tile of ~12 target extents).  Set by xr_overlap when the rows are kept
     // in the caller's order, or by xr_csr_set_row_keys; consumed once by the many-variable apply, which regroups

@@ -1312,7 +1312,8 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         XR_REQUIRE(rows_regular == T - n_big, XR_ERR_INVALID, "xr_overlap: internal row count mismatch");
         tree->last_candidates = (int64_t)C_reg + C_big;
         csr->nnz = (int64_t)p_regular + p_big;
-        csr->has_long = true;
+        csr->has_long = mail[7] > 0;   // rows of more than XR_APPLY_LONG_ROW entries (none: the apply skips their kernels)
+        csr->max_row_len = mail[7] > 0 ? mail[10] : XR_APPLY_LONG_ROW;
         return true;
     }
 }

@@ -36,7 +36,9 @@ struct FusedCounters {                    // device words, zeroed before the lau
     int32_t p_regular;                    // entries of all regular rows (k_assemble)
     int32_t rows_regular;                 // regular rows
     int32_t p_big;                        // entries of the big faces' rows (k_big_order)
-    int32_t pad[3];
+    int32_t pad0;                         // (unused)
+    int32_t max_row;                      // entries of the longest row (atomicMax)
+    int32_t pad2;
 };
 
 // Decoupled look-back: one 64-bit status word per block -- nothing yet / the block's own aggregate / its inclusive prefix.
@@ -306,7 +308,10 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
             const int64_t mid = (t & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
             tile_key[r] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
         }
-        if (my_nnz > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+        if (my_nnz > XR_APPLY_LONG_ROW) {
+            apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+            atomicMax(&counters->max_row, my_nnz); // (long rows only: the apply asks whether any row exceeds its wave kernel)
+        }
     }
     bool overflow_cap = false;
     for (int i0 = tid; i0 < total; i0 += 4 * FB) {
@@ -373,7 +378,10 @@ k_place_big(const int32_t *__restrict__ n_big_dev, const int32_t *__restrict__ s
             const int64_t mid = ((int64_t)f & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
             tile_key[r] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
         }
-        if (n > XR_APPLY_LONG_ROW) apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+        if (n > XR_APPLY_LONG_ROW) {
+            apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+            atomicMax(&counters->max_row, n);
+        }
     }
     for (int64_t e = i0; e < p_big; e += stride) {
         indices[p_regular + e] = big_indices[e];
@@ -392,6 +400,7 @@ __global__ void k_publish_all(const int32_t *__restrict__ c /* search counters *
         mail[7] = fc->n_apply_long;
         mail[8] = fc->p_regular;
         mail[9] = fc->p_big;
+        mail[10] = fc->max_row;
         *n_apply_long_out = fc->n_apply_long;
     }
 }
