@@ -202,9 +202,11 @@ int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
  * (ugrid2d.py:700-713, connectivity.py:247-259), the exterior edges (the only part of edge_node_connectivity /
  * edge_face_connectivity the Voronoi step reads, voronoi.py:77-97; ugrid2d.py:497-509, :661-677) and the cells
  * of all nodes that touch no exterior edge: the centroids of the surrounding faces ordered counter-clockwise
- * about the node (voronoi.py:355-372).  The cells of boundary nodes are O(boundary) host work
- * (xugrid_amd/voronoi.py) that needs what xr_voronoi_download returns and hands its result to
- * xr_voronoi_mesh, which assembles the Voronoi tessellation as a device-resident mesh:
+ * about the node (voronoi.py:355-372).  The cells of the boundary nodes (projections on the exterior edges, one extra
+ * corner per boundary node, the convexity choice: voronoi.py:59-327) are O(boundary) work on a few KB the device gathers:
+ * done by the library itself in native host code (xr_voronoi_mesh_auto; a dozen dependent sorts / scans over a few thousand
+ * items take tens of microseconds there, as device kernels each would be a launch and a round trip) or by the caller
+ * (xr_voronoi_boundary -> xr_voronoi_mesh).  The Voronoi tessellation is assembled as a device-resident mesh:
  *   vertices = [face centroids ; extra_xy]      cells = [interior nodes ascending ; boundary_cells]. */
 typedef struct xr_voronoi xr_voronoi;
 int xr_voronoi_create(xr_mesh *mesh, xr_voronoi **out); /* `mesh` must outlive the handle */
@@ -227,6 +229,15 @@ int xr_voronoi_boundary(xr_voronoi *v, int64_t *nodes, int64_t *row_ptr, int64_t
 int xr_voronoi_mesh(const xr_voronoi *v, const double *extra_xy, int64_t n_extra_vertex,
                     const int64_t *boundary_cells, int64_t n_boundary_cell, int64_t n_max_boundary,
                     xr_mesh **out);
+/* The whole pre-step in one call: boundary cells by the library, assembly on the device.  n_tail = vertices added behind
+ * the n_face centroids, n_map = rows of the interpolation map (voronoi.py:interpolation_map); xr_voronoi_tail copies
+ * tail_face_index int64[n_tail] (source face of every added vertex, -1 for the per-node extra corners) and
+ * interpolation_map int64[n_map, 2] (global vertex ids).  xr_voronoi_boundary_cells[_info]: the boundary cells themselves
+ * (extra_xy float64[n_extra_vertex, 2], cells int64[n_cell, n_max], -1 padded) as xr_voronoi_mesh expects them. */
+int xr_voronoi_mesh_auto(xr_voronoi *v, xr_mesh **out, int64_t *n_tail, int64_t *n_map);
+int xr_voronoi_tail(xr_voronoi *v, int64_t *tail_face_index, int64_t *interpolation_map);
+int xr_voronoi_boundary_cells_info(xr_voronoi *v, int64_t *n_extra_vertex, int64_t *n_cell, int64_t *n_max);
+int xr_voronoi_boundary_cells(xr_voronoi *v, double *extra_xy, int64_t *cells);
 int xr_voronoi_destroy(xr_voronoi *v);
 
 /* ---- seam 3: MatrixCSR handle ----------------------------------------------------------- */

@@ -335,10 +335,17 @@ def test_voronoi_device_mixed_and_large(hip):
     tri_b = np.column_stack([qf[:300, 0], qf[:300, 2], qf[:300, 3], np.full(300, -1)])
     mixed = np.vstack([tri_a, tri_b, qf[300:]])
     lxy, lf = meshgen.triangle_mesh(100_000, 5, delaunay=False)
-    for xy, faces in ((qxy, qf), (qxy, mixed), (lxy, lf)):
+    dxy, df = meshgen.triangle_mesh(30_000, 6)  # Delaunay: concave exterior cells, hull slivers
+    for xy, faces in ((qxy, qf), (qxy, mixed), (lxy, lf), (dxy, df)):
         grid = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
-        mesh, face_i, nmap = voronoi.voronoi_topology_device(grid)
+        mesh, face_i, nmap = voronoi.voronoi_topology_device(grid)  # boundary cells by the library (native code)
         v, f = mesh.download()
+        # ... and with the numpy restatement of the boundary part: the same tessellation bit for bit (straight lattice
+        # boundaries included, where the convexity choice hangs on the summation order of the polygon areas)
+        mesh_h, face_h, nmap_h = voronoi.voronoi_topology_device(grid, host_boundary=True)
+        v_h, f_h = mesh_h.download()
+        assert np.array_equal(v, v_h) and np.array_equal(f, f_h)
+        assert np.array_equal(face_i, face_h) and np.array_equal(nmap, nmap_h)
         hv, hf, hfi, hnm = voronoi.voronoi_topology(
             grid.node_face_connectivity, grid.node_coordinates, grid.centroids, grid.edge_face_connectivity,
             grid.edge_node_connectivity, add_exterior=True, add_vertices=True, skip_concave=True,

@@ -62,6 +62,10 @@ SIGNATURES = {
     "xr_voronoi_boundary_info": (c_int, [vp, vp, vp]),
     "xr_voronoi_boundary": (c_int, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "xr_voronoi_mesh": (c_int, [vp, vp, c_i64, vp, c_i64, c_i64, p_vp]),
+    "xr_voronoi_mesh_auto": (c_int, [vp, p_vp, p_i64, p_i64]),
+    "xr_voronoi_tail": (c_int, [vp, vp, vp]),
+    "xr_voronoi_boundary_cells_info": (c_int, [vp, p_i64, p_i64, p_i64]),
+    "xr_voronoi_boundary_cells": (c_int, [vp, vp, vp]),
     "xr_voronoi_destroy": (c_int, [vp]),
     "xr_overlap": (c_int, [vp, vp, c_int, p_vp]),
     "xr_overlap_stats": (c_int, [vp, p_i64]),

@@ -15,6 +15,8 @@
 // choice: voronoi.py:59-327) are O(boundary) and stay host numpy (xugrid_amd/voronoi.py); they are handed
 // back in as a small table.
 #include <algorithm>
+#include <chrono>
+#include <cmath>
 #include <vector>
 
 #include <cstring>
@@ -37,6 +39,14 @@ struct xr_voronoi {
     bool boundary_ready = false;
     std::vector<int64_t> b_nodes, b_ptr, b_faces; // ascending node ids, CSR offsets, faces ascending per node
     std::vector<double> b_face_xy, b_edge_face_xy; // centroid of every listed face / of every exterior edge's face
+    std::vector<double> b_node_xy;                 // coordinates of the boundary nodes
+    // the cells of the boundary nodes (voronoi_boundary_cells: native O(boundary) host part)
+    bool cells_ready = false;
+    std::vector<double> c_extra_xy;   // vertices added behind the n_face centroids: kept projections, then one per boundary node
+    std::vector<int64_t> c_cells;     // [c_n_cell][c_m] global vertex ids, -1 padded, counter-clockwise
+    int64_t c_n_cell = 0, c_m = 0;
+    std::vector<int64_t> c_tail;      // source face of every added vertex (-1: the per-node extras)
+    std::vector<int64_t> c_interp;    // [n_extra][2] the two projection vertex ids an extra corner sits between
 };
 
 namespace xr {
@@ -257,6 +267,15 @@ static void voronoi_boundary(xr_voronoi *v) {
             d2h(v->b_face_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)total);
         }
     }
+    v->b_node_xy.assign((size_t)nb * 2, 0.0);
+    if (nb > 0) {
+        DevBuf<int64_t> d_nodes((size_t)nb);
+        DevBuf<double> d_xy((size_t)nb * 2);
+        h2d(d_nodes.get(), nodes.data(), sizeof(int64_t) * (size_t)nb);
+        XR_LAUNCH("vor_node_xy", k_vor_face_xy, dim3(div_up(nb, 256)), dim3(256), 0, v->mesh->node_xy.get(), d_nodes.get(), nb,
+                  d_xy.get());
+        d2h(v->b_node_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)nb);
+    }
     if (ne > 0) {
         DevBuf<int64_t> d_ef((size_t)ne);
         DevBuf<double> d_xy((size_t)ne * 2);
@@ -266,6 +285,198 @@ static void voronoi_boundary(xr_voronoi *v) {
         d2h(v->b_edge_face_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)ne);
     }
     v->boundary_ready = true;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The cells of the boundary nodes (voronoi.py:59-327 for add_exterior = add_vertices = skip_concave = True): native host
+// code on the few KB voronoi_boundary() gathered -- a LOCAL problem (boundary nodes 0..nb-1, the faces around them
+// 0..nl-1, both ascending like their global ids, so every grouping and stable sort sees the order it would see globally).
+// O(boundary) items in a dozen dependent steps (sorts, a scan, a per-cell convexity choice): tens of microseconds here; as
+// device kernels each step would be a launch plus a round trip.  The arithmetic follows xugrid_amd/voronoi.py
+// (_boundary_records) operation for operation, including numpy's pairwise summation in the polygon areas: on a straight
+// boundary the two candidate areas of the convexity choice differ by rounding only.
+// ---------------------------------------------------------------------------------------------------------------------
+static double np_pairwise_sum(const double *a, int64_t n) { // numpy's DOUBLE_pairwise_sum for n <= 128
+    if (n < 8) {
+        double res = 0.0;
+        for (int64_t i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    double r[8];
+    for (int j = 0; j < 8; j++) r[j] = a[j];
+    int64_t i = 8;
+    for (; i < n - (n % 8); i += 8)
+        for (int j = 0; j < 8; j++) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+
+static void voronoi_boundary_cells(xr_voronoi *v) {
+    if (v->cells_ready) return;
+    voronoi_boundary(v);
+    const auto tk0 = std::chrono::steady_clock::now();
+    const int64_t nb = (int64_t)v->b_nodes.size(), ne = (int64_t)v->edge_face.size(), n_face = v->n_face;
+    v->c_extra_xy.clear(); v->c_cells.clear(); v->c_tail.clear(); v->c_interp.clear();
+    v->c_n_cell = 0; v->c_m = 0;
+    if (ne == 0) { // closed surface: nothing to add
+        v->cells_ready = true;
+        return;
+    }
+    XR_REQUIRE(n_face + 3 * ne < ((int64_t)1 << 31), XR_ERR_LIMIT, "voronoi: vertex ids exceed the int32 range");
+    // Vertex ids are GLOBAL from the start (face centroid f -> f, kept projection r -> n_face + r, extra corner k ->
+    // n_face + n_proj + k): the local renumbering of the numpy restatement only exists to keep its arrays small; every
+    // record carries its corner's coordinates, so no vertex table is needed either.  Cell keys are local node ranks
+    // (ascending like the global node ids).
+    struct Rec {
+        int64_t key, id;
+        double x, y, angle;
+    };
+    std::vector<Rec> rec;
+    rec.reserve(v->b_faces.size() + 3 * (size_t)ne);
+    for (int64_t i = 0; i < nb; i++) // corners that are face centroids: nodes shared by several faces ...
+        if (v->b_ptr[(size_t)i + 1] - v->b_ptr[(size_t)i] > 1)
+            for (int64_t r = v->b_ptr[(size_t)i]; r < v->b_ptr[(size_t)i + 1]; r++)
+                rec.push_back({i, v->b_faces[(size_t)r], v->b_face_xy[2 * (size_t)r], v->b_face_xy[2 * (size_t)r + 1], 0.0});
+    for (int64_t i = 0; i < nb; i++) // ... then corner nodes owned by exactly one face
+        if (v->b_ptr[(size_t)i + 1] - v->b_ptr[(size_t)i] == 1) {
+            const size_t r = (size_t)v->b_ptr[(size_t)i];
+            rec.push_back({i, v->b_faces[r], v->b_face_xy[2 * r], v->b_face_xy[2 * r + 1], 0.0});
+        }
+    // projections of the adjacent face centroid on every exterior edge
+    auto local_node = [&](int64_t g) { return (int64_t)(std::lower_bound(v->b_nodes.begin(), v->b_nodes.end(), g) - v->b_nodes.begin()); };
+    const double *nxy = v->b_node_xy.data();
+    const double merge_tol = 1.0e-8 * 1.0e-8;
+    std::vector<int64_t> e_n0((size_t)ne), e_n1((size_t)ne), kept_rank((size_t)ne, -1);
+    std::vector<double> proj_all((size_t)ne * 2);
+    int64_t n_proj = 0;
+    for (int64_t e = 0; e < ne; e++) {
+        e_n0[(size_t)e] = local_node(v->edge_lo[(size_t)e]);
+        e_n1[(size_t)e] = local_node(v->edge_hi[(size_t)e]);
+        const double ax = nxy[2 * e_n0[(size_t)e]], ay = nxy[2 * e_n0[(size_t)e] + 1];
+        const double bx = nxy[2 * e_n1[(size_t)e]], by = nxy[2 * e_n1[(size_t)e] + 1];
+        const double cx = v->b_edge_face_xy[2 * (size_t)e], cy = v->b_edge_face_xy[2 * (size_t)e + 1];
+        const double vx = bx - ax, vy = by - ay, ux = cx - ax, uy = cy - ay;
+        const double sc = (ux * vx + uy * vy) / (vx * vx + vy * vy);
+        const double px = ax + sc * vx, py = ay + sc * vy;
+        proj_all[2 * (size_t)e] = px;
+        proj_all[2 * (size_t)e + 1] = py;
+        const double dx = px - cx, dy = py - cy;
+        if (std::sqrt(dx * dx + dy * dy) > merge_tol) kept_rank[(size_t)e] = n_proj++;
+    }
+    const int64_t first_new = n_face + n_proj; // id of the first extra corner
+    for (int64_t e = 0; e < ne; e++)
+        if (kept_rank[(size_t)e] >= 0) { // both end nodes use the projection
+            const int64_t id = n_face + kept_rank[(size_t)e];
+            rec.push_back({e_n0[(size_t)e], id, proj_all[2 * (size_t)e], proj_all[2 * (size_t)e + 1], 0.0});
+            rec.push_back({e_n1[(size_t)e], id, proj_all[2 * (size_t)e], proj_all[2 * (size_t)e + 1], 0.0});
+            v->c_tail.push_back(v->edge_face[(size_t)e]);
+        }
+    // one extra corner per boundary node, between the node's two projections: the (edge, end) records sorted by node id
+    // (stable), paired off two by two; the interpolation map refers to the UNFILTERED projection numbering exactly as the
+    // reference does
+    std::vector<int64_t> by_node((size_t)(2 * ne));
+    for (int64_t j = 0; j < 2 * ne; j++) by_node[(size_t)j] = j;
+    auto flat_node = [&](int64_t j) { return (j & 1) ? e_n1[(size_t)(j >> 1)] : e_n0[(size_t)(j >> 1)]; };
+    std::stable_sort(by_node.begin(), by_node.end(), [&](int64_t a, int64_t b) { return flat_node(a) < flat_node(b); });
+    const int64_t n_extra = ne; // (2 ne records, two per extra corner)
+    std::vector<double> extra_xy((size_t)n_extra * 2), true_corner((size_t)n_extra * 2);
+    v->c_interp.resize((size_t)n_extra * 2);
+    for (int64_t k = 0; k < n_extra; k++) {
+        const int64_t p0 = by_node[(size_t)(2 * k)] >> 1, p1 = by_node[(size_t)(2 * k + 1)] >> 1;
+        extra_xy[2 * (size_t)k] = 0.5 * (proj_all[2 * (size_t)p0] + proj_all[2 * (size_t)p1]);
+        extra_xy[2 * (size_t)k + 1] = 0.5 * (proj_all[2 * (size_t)p0 + 1] + proj_all[2 * (size_t)p1 + 1]);
+        const int64_t node = flat_node(by_node[(size_t)(2 * k)]);
+        rec.push_back({node, first_new + k, extra_xy[2 * (size_t)k], extra_xy[2 * (size_t)k + 1], 0.0});
+        v->c_interp[2 * (size_t)k] = p0 + n_face;
+        v->c_interp[2 * (size_t)k + 1] = p1 + n_face;
+        true_corner[2 * (size_t)k] = nxy[2 * node];
+        true_corner[2 * (size_t)k + 1] = nxy[2 * node + 1];
+    }
+    v->c_tail.insert(v->c_tail.end(), (size_t)n_extra, (int64_t)-1);
+    const auto tk1 = std::chrono::steady_clock::now();
+    // ---- counter-clockwise order about the mean of each cell's corners (sums in record order, as np.bincount)
+    const int64_t n_rec = (int64_t)rec.size();
+    std::vector<double> sx((size_t)nb, 0.0), sy((size_t)nb, 0.0), cnt((size_t)nb, 0.0);
+    for (const Rec &r : rec) {
+        sx[(size_t)r.key] += r.x;
+        sy[(size_t)r.key] += r.y;
+        cnt[(size_t)r.key] += 1.0;
+    }
+    for (Rec &r : rec) {
+        const double px = sx[(size_t)r.key] / cnt[(size_t)r.key], py = sy[(size_t)r.key] / cnt[(size_t)r.key];
+        r.angle = std::atan2(r.y - py, r.x - px);
+    }
+    std::stable_sort(rec.begin(), rec.end(), [](const Rec &a, const Rec &b) {
+        if (a.key != b.key) return a.key < b.key;
+        return a.angle < b.angle;
+    });
+    const auto tk2 = std::chrono::steady_clock::now();
+    // ---- dense table: one row per distinct key (ascending), -1 padded
+    std::vector<int64_t> row_start;
+    for (int64_t r = 0; r < n_rec; r++)
+        if (r == 0 || rec[(size_t)r].key != rec[(size_t)r - 1].key) row_start.push_back(r);
+    const int64_t n_cell = (int64_t)row_start.size();
+    row_start.push_back(n_rec);
+    int64_t m = 0;
+    for (int64_t c = 0; c < n_cell; c++) m = std::max(m, row_start[(size_t)c + 1] - row_start[(size_t)c]);
+    XR_REQUIRE(m <= 128, XR_ERR_LIMIT, "voronoi: a boundary cell has %lld corners", (long long)m);
+    std::vector<int64_t> cells((size_t)(n_cell * m), -1);
+    // ---- keep the true boundary node where it does not make the cell concave: the cell's area with the true node against
+    // its area with the midpoint substitute (closed polygon: fill slots and the closing slot repeat corner 0)
+    std::vector<double> term((size_t)m);
+    for (int64_t c = 0; c < n_cell; c++) {
+        const Rec *row = rec.data() + row_start[(size_t)c];
+        const int64_t len = row_start[(size_t)c + 1] - row_start[(size_t)c];
+        for (int64_t j = 0; j < len; j++) cells[(size_t)(c * m + j)] = row[j].id;
+        auto vertex = [&](int64_t j, bool use_true, double &x, double &y) { // corner j of the closed polygon
+            const Rec &r = row[j < len ? j : 0];
+            if (use_true && r.id >= first_new) {
+                x = true_corner[2 * (size_t)(r.id - first_new)];
+                y = true_corner[2 * (size_t)(r.id - first_new) + 1];
+            } else {
+                x = r.x;
+                y = r.y;
+            }
+        };
+        double area[2];
+        for (int t = 0; t < 2; t++) {
+            double x0, y0;
+            vertex(0, t == 1, x0, y0);
+            for (int64_t i = 0; i < m; i++) { // closed[i], closed[i + 1] with closed[m] = corner 0
+                double xa, ya, xb, yb;
+                vertex(i, t == 1, xa, ya);
+                vertex(i + 1 < m ? i + 1 : len, t == 1, xb, yb);
+                const double a0 = xa - x0, a1 = ya - y0, b0 = xb - x0, b1 = yb - y0;
+                term[(size_t)i] = a0 * b1 - a1 * b0;
+            }
+            area[t] = 0.5 * std::fabs(np_pairwise_sum(term.data(), m));
+        }
+        if (area[1] >= area[0])
+            for (int64_t j = 0; j < len; j++)
+                if (row[j].id >= first_new) {
+                    const int64_t k = row[j].id - first_new;
+                    extra_xy[2 * (size_t)k] = true_corner[2 * (size_t)k];
+                    extra_xy[2 * (size_t)k + 1] = true_corner[2 * (size_t)k + 1];
+                }
+    }
+    const auto tk3 = std::chrono::steady_clock::now();
+    if (getenv("XR_DEBUG_VORONOI"))
+        fprintf(stderr, "[voronoi] records %lld: set-up %.3f, sort %.3f, cells + convexity %.3f ms\n", (long long)n_rec,
+                std::chrono::duration<double, std::milli>(tk1 - tk0).count(), std::chrono::duration<double, std::milli>(tk2 - tk1).count(),
+                std::chrono::duration<double, std::milli>(tk3 - tk2).count());
+    v->c_cells = std::move(cells);
+    v->c_n_cell = n_cell;
+    v->c_m = m;
+    v->c_extra_xy.resize((size_t)(n_proj + n_extra) * 2);
+    for (int64_t e = 0; e < ne; e++)
+        if (kept_rank[(size_t)e] >= 0) {
+            v->c_extra_xy[2 * (size_t)kept_rank[(size_t)e]] = proj_all[2 * (size_t)e];
+            v->c_extra_xy[2 * (size_t)kept_rank[(size_t)e] + 1] = proj_all[2 * (size_t)e + 1];
+        }
+    std::copy(extra_xy.begin(), extra_xy.end(), v->c_extra_xy.begin() + 2 * n_proj);
+    v->cells_ready = true;
 }
 
 } // namespace xr
@@ -477,6 +688,62 @@ int xr_voronoi_mesh(const xr_voronoi *v, const double *extra_xy, int64_t n_extra
         throw;
     }
     *out = mesh;
+    XR_API_END
+}
+
+/* The whole pre-step without a host language in between: the cells of the boundary nodes are computed by the library
+ * (voronoi_boundary_cells) and the tessellation is assembled on the device.  n_tail = vertices added behind the face
+ * centroids, n_map = rows of the interpolation map; fetch them with xr_voronoi_tail. */
+int xr_voronoi_mesh_auto(xr_voronoi *v, xr_mesh **out, int64_t *n_tail, int64_t *n_map) {
+    XR_API_BEGIN
+    XR_REQUIRE(v && out && n_tail && n_map, XR_ERR_INVALID, "xr_voronoi_mesh_auto: NULL argument");
+    const bool dbg = getenv("XR_DEBUG_VORONOI") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    voronoi_boundary(v);
+    const auto t1 = std::chrono::steady_clock::now();
+    voronoi_boundary_cells(v);
+    const auto t2 = std::chrono::steady_clock::now();
+    if (dbg)
+        fprintf(stderr, "[voronoi] gather %.3f ms, boundary cells %.3f ms\n",
+                std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(t2 - t1).count());
+    *n_tail = (int64_t)v->c_tail.size();
+    *n_map = (int64_t)v->c_interp.size() / 2;
+    const int rc = xr_voronoi_mesh(v, v->c_extra_xy.data(), (int64_t)v->c_extra_xy.size() / 2, v->c_cells.data(), v->c_n_cell,
+                                   v->c_m, out);
+    if (rc != XR_OK) return rc;
+    XR_API_END
+}
+
+int xr_voronoi_tail(xr_voronoi *v, int64_t *tail_face_index, int64_t *interpolation_map) {
+    XR_API_BEGIN
+    XR_REQUIRE(v, XR_ERR_INVALID, "xr_voronoi_tail: NULL argument");
+    voronoi_boundary_cells(v);
+    XR_REQUIRE((v->c_tail.empty() || tail_face_index) && (v->c_interp.empty() || interpolation_map), XR_ERR_INVALID,
+               "xr_voronoi_tail: NULL output array");
+    if (!v->c_tail.empty()) memcpy(tail_face_index, v->c_tail.data(), sizeof(int64_t) * v->c_tail.size());
+    if (!v->c_interp.empty()) memcpy(interpolation_map, v->c_interp.data(), sizeof(int64_t) * v->c_interp.size());
+    XR_API_END
+}
+
+/* the boundary cells themselves (tests, hosts that assemble on their own): sizes, then the arrays */
+int xr_voronoi_boundary_cells_info(xr_voronoi *v, int64_t *n_extra_vertex, int64_t *n_cell, int64_t *n_max) {
+    XR_API_BEGIN
+    XR_REQUIRE(v && n_extra_vertex && n_cell && n_max, XR_ERR_INVALID, "xr_voronoi_boundary_cells_info: NULL argument");
+    voronoi_boundary_cells(v);
+    *n_extra_vertex = (int64_t)v->c_extra_xy.size() / 2;
+    *n_cell = v->c_n_cell;
+    *n_max = v->c_m;
+    XR_API_END
+}
+
+int xr_voronoi_boundary_cells(xr_voronoi *v, double *extra_xy, int64_t *cells) {
+    XR_API_BEGIN
+    XR_REQUIRE(v, XR_ERR_INVALID, "xr_voronoi_boundary_cells: NULL argument");
+    voronoi_boundary_cells(v);
+    XR_REQUIRE((v->c_extra_xy.empty() || extra_xy) && (v->c_cells.empty() || cells), XR_ERR_INVALID,
+               "xr_voronoi_boundary_cells: NULL output array");
+    if (!v->c_extra_xy.empty()) memcpy(extra_xy, v->c_extra_xy.data(), sizeof(double) * v->c_extra_xy.size());
+    if (!v->c_cells.empty()) memcpy(cells, v->c_cells.data(), sizeof(int64_t) * v->c_cells.size());
     XR_API_END
 }
 

@@ -257,6 +257,28 @@ class DeviceVoronoi:
         )
         return nodes, row_ptr, faces, face_xy, edge_nodes, edge_face, edge_face_xy
 
+    def boundary_cells(self):
+        """The cells of the boundary nodes as the library computes them (native O(boundary) host part):
+        ``(extra_xy (n_extra, 2), cells (n_cell, n_max) int64, -1 padded)``."""
+        ne, nc, nm = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().xr_voronoi_boundary_cells_info(self._h, ctypes.byref(ne), ctypes.byref(nc), ctypes.byref(nm)))
+        extra = np.empty((ne.value, 2), dtype=np.float64)
+        cells = np.empty((nc.value, nm.value), dtype=np.int64)
+        check(_lib.load().xr_voronoi_boundary_cells(self._h, _ptr(extra), _ptr(cells)))
+        return extra, cells
+
+    def assemble_auto(self):
+        """-> (DeviceMesh of the tessellation, tail_face_index, interpolation_map): boundary cells by the library,
+        assembly on the device (xr_voronoi_mesh_auto)."""
+        handle = ctypes.c_void_p()
+        nt, nm = ctypes.c_int64(), ctypes.c_int64()
+        check(_lib.load().xr_voronoi_mesh_auto(self._h, ctypes.byref(handle), ctypes.byref(nt), ctypes.byref(nm)))
+        mesh = DeviceMesh._from_handle(handle)
+        tail = np.empty(nt.value, dtype=np.int64)
+        imap = np.empty((nm.value, 2), dtype=np.int64)
+        check(_lib.load().xr_voronoi_tail(self._h, _ptr(tail), _ptr(imap)))
+        return mesh, tail, imap
+
     def assemble(self, extra_xy, boundary_cells) -> DeviceMesh:
         extra_xy = np.ascontiguousarray(extra_xy, dtype=np.float64).reshape(-1, 2)
         cells = np.ascontiguousarray(boundary_cells, dtype=np.int64)

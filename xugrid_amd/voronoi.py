@@ -199,7 +199,7 @@ def voronoi_topology(
     return table, cells, face_index, interp_map
 
 
-def voronoi_topology_device(grid, compact=False):
+def voronoi_topology_device(grid, compact=False, host_boundary=False):
     """
     ``voronoi_topology(..., add_exterior=True, add_vertices=True, skip_concave=True)`` of a Ugrid2d with the
     O(n) part on the device (node -> face inversion, exterior edges, counter-clockwise interior cells, assembly;
@@ -210,11 +210,22 @@ def voronoi_topology_device(grid, compact=False):
     Returns (DeviceMesh of the tessellation, face_index, interpolation_map): the mesh has the same vertices and
     cells, in the same order, as the host function returns as arrays.  ``compact=True``: ``face_index`` holds only
     the entries of the vertices beyond the ``n_face`` face centroids (the others are the identity).
+
+    The cells of the boundary nodes are computed by the library itself (native code, ``xr_voronoi_mesh_auto``);
+    ``host_boundary=True`` uses the numpy restatement below instead (kept as the readable cross-check: both give the
+    same vertices, cells, face index and interpolation map bit for bit).
     """
     from . import engine
 
     builder = engine.DeviceVoronoi(grid.device_mesh)
     n_face = grid.n_face
+    if not host_boundary:
+        mesh, tail, interp_map = builder.assemble_auto()
+        tail = tail.astype(IntDType, copy=False)
+        interp_map = interp_map.astype(IntDType, copy=False)
+        if compact:
+            return mesh, tail, interp_map
+        return mesh, np.concatenate([np.arange(n_face, dtype=IntDType), tail]), interp_map
     nodes, row_ptr, faces, face_xy, edge_nodes, edge_face, edge_face_xy = builder.download_boundary()
     if edge_face.size:
         # local numbering: boundary nodes 0..nb-1 (ascending = same order as their global ids), needed faces
