@@ -74,7 +74,7 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
          int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
          int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key, int32_t *__restrict__ nnz_row,
-         bool remap) {
+         bool remap, int32_t *__restrict__ blk_rows = nullptr /* optional: regular (non-big) faces per block, written */) {
     __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
     __shared__ uint8_t sh_owner[SLOTS * 256];
     __shared__ __attribute__((aligned(16))) float4 sh_bigbb[BIGREC_BLOCK];
@@ -223,6 +223,10 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
     // slot array, no global scan, no compaction pass; blocks land in the queue in arbitrary order (nothing
     // downstream depends on it: rows are re-ranked by tree face id), the rows of one block stay contiguous.
     const int mine = (t < n_query && !big) ? count : 0;
+    if (blk_rows) {
+        const int n_regular = __syncthreads_count(t < n_query && !big);
+        if (threadIdx.x == 0) blk_rows[lb] = n_regular;
+    }
     int own[SLOTS];
 #pragma unroll
     for (int j = 0; j < SLOTS; j++) own[j] = j < mine ? sh_slots[j][threadIdx.x] : 0;
@@ -1216,9 +1220,15 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     static_assert(sizeof(FusedCounters) == 32, "FusedCounters layout");
     // ctl: [0] regular queue cursor, [1] big queue cursor, [2] big faces, [3] big faces that did not fit, [4] clip
     // overflows among the big pairs | FusedCounters | look-back status words
-    DevBuf<int32_t> ctl(8 + sizeof(FusedCounters) / 4 + 2 * (size_t)grid);
+    // | per block of 256 target faces: survivors (clip), regular faces (search)
+    DevBuf<int32_t> ctl(8 + sizeof(FusedCounters) / 4 + 4 * (size_t)grid);
     FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl.get() + 8);
     unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl.get() + 16);
+    int32_t *blk_surv = ctl.get() + 16 + 2 * (size_t)grid, *blk_rows = blk_surv + grid;
+    DevBuf<int32_t> blk_base(2 * (size_t)grid); // first stored row / CSR base of every hardware block (k_assemble_scan)
+    // XR_ASSEMBLE_SCAN=0: the assembly finds its bases by the decoupled look-back instead (measurement / fallback switch)
+    const char *scan_env = getenv("XR_ASSEMBLE_SCAN");
+    const bool scan_bases = !(scan_env && atoi(scan_env) == 0);
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T), pending((size_t)T), nnz_row((size_t)T),
         slot_face((size_t)T), big_indptr((size_t)T + 1);
     DevBuf<uint8_t> is_big((size_t)T);
@@ -1252,7 +1262,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         XR_LAUNCH("search", k_search, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
                   tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl.get() + 0,
                   block_seg.get(), is_big.get(), big_list.get(), ctl.get() + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                  remap);
+                  remap, scan_bases ? blk_rows : (int32_t *)nullptr);
         {
             // ---- side stream: everything about the big faces except their final placement
             SideScope side;
@@ -1261,7 +1271,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                       big_list.get(), ctl.get() + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
                       ctl.get() + 1, big_capacity, pending.get(), ctl.get() + 3, slot_face.get());
             // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
-            XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
+            XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl.get() + 1,
                       big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl.get() + 3);
             // (rows in face order: ranked inside search_big; their offsets: scanned inside row_fill_long -- two launches less
@@ -1277,15 +1287,25 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         // blocks per CU all give the same step (0.635 ms) -- measured after the chain lost two launches; before, 3 was
         // 4 % faster because the chain was the critical path.  XR_CLIP_BPC overrides (tuning hook).
         static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5;
-        XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
-                  query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                  ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                  (const int32_t *)nullptr);
+        if (scan_bases)
+            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
+                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
+                      ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      (const int32_t *)nullptr, blk_surv);
+        else
+            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 0>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
+                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
+                      ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      (const int32_t *)nullptr, (int32_t *)nullptr);
+        if (scan_bases)
+            XR_LAUNCH("assemble_scan", k_assemble_scan, dim3(1), dim3(1024), 0, blk_rows, blk_surv, (int64_t)n_blocks, (int)grid,
+                      remap, blk_base.get(), blk_base.get() + grid, fc, csr->indptr.get());
         XR_LAUNCH("assemble", k_assemble, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
                   cand_off.get(), cand_count.get(), block_seg.get(), is_big.get(), cand_area.get(), cand_sid.get(),
                   tree_area, relative, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc,
                   status, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
-                  csr->long_rows.get(), cap, remap);
+                  csr->long_rows.get(), cap, remap, scan_bases ? blk_base.get() : (const int32_t *)nullptr,
+                  scan_bases ? blk_base.get() + grid : (const int32_t *)nullptr);
         side_join();
         XR_LAUNCH("place_big", k_place_big, dim3(64), dim3(256), 0, ctl.get() + 2, slot_face.get(), big_indptr.get(),
                   big_indices.get(), big_data.get(), T, query->qo_perm(), query->qo_bbox(), tile,

@@ -134,14 +134,17 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/,
 // Persistent triangle x triangle clip over the regular pair queue: the number of pairs is read from device memory
 // (the search's queue cursor), so the launch needs no host round trip; every block walks chunks of 256 pairs.  Chunks are dealt so that every XCD works on one contiguous eighth of the queue (the order
 // k_search wrote it in: the vertex blocks are in that XCD's L2).
-template <int BLOCK>
+// COUNT: which survivor counts the kernel keeps (two instantiations: both paths in one kernel cost registers -> scratch)
+//   0 none, 1 per block of FB target faces (regular queue: blk_surv), 2 per target face (big faces' queue: nnz_row)
+template <int BLOCK, int COUNT>
 __global__ void __launch_bounds__(BLOCK)
 k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
                  const int32_t *__restrict__ rec_face, const int32_t *__restrict__ cand_tgt,
                  const int32_t *__restrict__ cand_src, const int32_t *__restrict__ n_cand_dev, int64_t capacity,
                  double *__restrict__ cand_area, int32_t *__restrict__ cand_sid, int32_t *__restrict__ error_bits,
                  int32_t *__restrict__ nnz_row /* optional: survivors per target face, counted by atomics */,
-                 const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */) {
+                 const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */,
+                 int32_t *__restrict__ blk_surv = nullptr /* optional: survivors per BLOCK of 256 target faces (k_assemble_scan) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
     __shared__ uint2 sh_lut[TRI_LUT];
@@ -200,7 +203,30 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
             cand_area[c] = area;
             cand_sid[c] = area > 0 ? sid : 0x7fffffff;
         }
-        if (nnz_row) {
+        if (COUNT == 1) {
+            // survivors per block of FB target faces.  The pairs of a block are one stretch of the queue (1700 on average):
+            // most waves see a single block -- one atomic by lane 0; the others add per run of equal block ids
+            const int lane = tid & 63;
+            const int blk_now = active ? (cur_tq >> 8) : -1;
+            const unsigned long long surv = __ballot(active && area > 0);
+            const int blk_first = __builtin_amdgcn_readfirstlane(blk_now), blk_last = __shfl(blk_now, 63, 64);
+            if (blk_first == blk_last) { // (uniform)
+                if (lane == 0 && blk_first >= 0 && surv) atomicAdd(&blk_surv[blk_first], __popcll(surv));
+            } else {
+                const int blk_prev = __shfl_up(blk_now, 1, 64);
+                const bool head = lane == 0 || blk_prev != blk_now;
+                const unsigned long long heads = __ballot(head);
+                if (head && blk_now >= 0) {
+                    const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+                    const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+                    unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
+                    run &= ~((1ull << lane) - 1);
+                    const int n = __popcll(surv & run);
+                    if (n > 0) atomicAdd(&blk_surv[blk_now], n);
+                }
+            }
+        }
+        if (COUNT == 2) {
             // pairs of one target face are contiguous: the head lane of each run of equal faces adds the run's survivors
             const int lane = tid & 63;
             const int t_prev = __shfl_up(tq_now, 1, 64);
@@ -221,6 +247,56 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
 }
 
 // CSR assembly for the regular faces: the block that owns 256 consecutive target faces stages the source ids of its
+// (k_assemble_scan: the blocks' first stored row and CSR base from counts the search and the clip left per block -- one
+// block scans the few thousand (rows, entries) pairs in the order the assembly assigns stored rows, i.e. hardware block
+// order; replaces the look-back chain inside k_assemble when those counts exist)
+__global__ void __launch_bounds__(1024)
+k_assemble_scan(const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ blk_surv, int64_t n_blocks, int n_chain,
+                bool remap, int32_t *__restrict__ base_rows, int32_t *__restrict__ base_nnz, FusedCounters *counters,
+                int32_t *__restrict__ indptr) {
+    __shared__ long long sh_w[16];
+    __shared__ long long sh_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) sh_carry = 0;
+    __syncthreads();
+    const int64_t per_xcd = (n_blocks + 7) >> 3;
+    for (int b0 = 0; b0 < n_chain; b0 += 1024) {
+        const int b = b0 + tid;
+        long long v = 0;
+        if (b < n_chain) {
+            const int64_t lb = remap ? (int64_t)(b & 7) * per_xcd + (b >> 3) : b;
+            if (lb < n_blocks) v = ((long long)blk_rows[lb] << 31) | (long long)blk_surv[lb];
+        }
+        long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const long long o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) sh_w[wave] = incl;
+        __syncthreads();
+        long long woff = 0, tot = 0;
+        for (int w = 0; w < 16; w++) {
+            if (w < wave) woff += sh_w[w];
+            tot += sh_w[w];
+        }
+        const long long excl = sh_carry + woff + incl - v;
+        if (b < n_chain) {
+            base_nnz[b] = (int32_t)(excl & 0x7fffffffll);
+            base_rows[b] = (int32_t)(excl >> 31);
+        }
+        __syncthreads();
+        if (tid == 0) sh_carry += tot;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const long long entries = sh_carry & 0x7fffffffll, rows = sh_carry >> 31;
+        counters->p_regular = (int32_t)entries; // entries of all regular rows
+        counters->rows_regular = (int32_t)rows;
+        indptr[rows] = (int32_t)entries;        // (= indptr[T] when there are no big faces)
+    }
+}
+
 // stretch of the pair queue in LDS ("dead" for area <= 0), counts the survivors per face (LDS atomics), reserves its
 // rows and entries with ONE atomic, ranks every survivor among its row and writes it to its final CSR position.
 __global__ void __launch_bounds__(FB, 2)
@@ -231,7 +307,8 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
            const int32_t *__restrict__ cand_sid, const double *__restrict__ src_area, bool relative, MortonParams tile,
            int32_t *__restrict__ tile_key, FusedCounters *__restrict__ counters, unsigned long long *__restrict__ status,
            int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ row_order,
-           int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap) {
+           int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap,
+           const int32_t *__restrict__ base_rows = nullptr, const int32_t *__restrict__ base_nnz = nullptr) {
     __shared__ int32_t sh_stage[SLOTS * FB];
     __shared__ int32_t sh_nnz[FB];     // survivors of the face (LDS atomics)
     __shared__ uint16_t sh_lo[FB];     // offset of the face's pairs inside the stretch
@@ -287,14 +364,16 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
     const int rowidx = block_excl_scan(regular ? 1 : 0, sh_wave, &block_rows);
     sh_rowoff[tid] = (uint16_t)rowoff;
     const int b = (int)blockIdx.x, n_chain = (int)gridDim.x;
-    if (tid < 64) {
+    if (base_nnz) { // scanned beforehand (k_assemble_scan)
+        if (tid == 0) sh_base = ((long long)base_rows[b] << 31) | (long long)base_nnz[b];
+    } else if (tid < 64) {
         const long long packed = lookback_exclusive(status, b, ((long long)block_rows << 31) | (long long)block_nnz, tid, &counters->error);
         if (tid == 0) sh_base = packed;
     }
     __syncthreads();
     if (sh_base < 0) return; // aborted (the host falls back)
     const long long base = sh_base & 0x7fffffffll, row_base = sh_base >> 31;
-    if (b == n_chain - 1 && tid == 0) {
+    if (!base_nnz && b == n_chain - 1 && tid == 0) {
         const long long entries = base + block_nnz, rows = row_base + block_rows;
         counters->p_regular = (int32_t)entries; // entries of all regular rows
         counters->rows_regular = (int32_t)rows;
