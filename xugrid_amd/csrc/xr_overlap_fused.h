@@ -7,10 +7,13 @@
 //   k_search / k_search_big   as before, big faces into their own queue
 //   k_clip_tri_queue          persistent clip over the regular pair queue; its length is read from device memory, so
 //                             the launch does not wait for the host; chunks software-pipelined
-//   k_assemble                the block that owns 256 consecutive target faces counts its survivors in LDS, learns its
-//                             first stored row and its CSR base from a decoupled look-back scan over (rows, entries),
-//                             ranks every survivor among its row and writes the final CSR.  No scan pass, no row
-//                             counters in HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)
+//   k_assemble_scan           the search leaves the number of regular faces per block of 256 target faces, the clip the
+//                             number of surviving pairs per block (one atomic per wave): ONE small block scans the few
+//                             thousand (rows, entries) pairs into every block's first stored row and CSR base
+//   k_assemble                the block that owns 256 consecutive target faces counts its survivors per row in LDS, ranks
+//                             every survivor among its row and writes the final CSR at its base.  No row counters in
+//                             HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)  XR_ASSEMBLE_SCAN=0: the
+//                             bases come from a decoupled look-back inside k_assemble instead (bounded spins, abort bit)
 //   big faces (hull slivers, > SLOTS hits; 0.1 % of the faces, but their block-per-face kernels are chains of dependent
 //   phases: 15 % of the step when run in line) on a SIDE STREAM, forked behind k_search: k_search_big -> k_clip_tri_queue on
 //   their own pair queue -> k_row_fill_long (rows in face order as ranked by k_search_big; scans their lengths itself) into a small
