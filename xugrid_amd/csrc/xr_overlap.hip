@@ -5,7 +5,9 @@
 // normalisation (:133-134) and MatrixCSR.from_triplet (xugrid/regrid/regridder.py:433-435,
 // xugrid/core/sparse.py:61-78).
 //
-// Pipeline (all on the engine stream):
+// Two pipelines.  Triangle x triangle pairs (the benchmark) take overlap_tri() below: search -> persistent bit-mask clip
+// -> per-block scan -> assembly, big faces on a side stream, ONE host round trip (kernels in xr_overlap_fused.h,
+// xr_clip_tri.h).  Everything else takes the general chain (all on the engine stream):
 //   search         one thread per query (target) face walks the tree mesh's hierarchical grid and
 //                  parks the bbox-overlapping tree records in 16 LDS slots; the block reserves its
 //                  stretch of the candidate-pair queue with one atomic and writes it compacted
