@@ -346,6 +346,14 @@ def test_voronoi_device_mixed_and_large(hip):
         v_h, f_h = mesh_h.download()
         assert np.array_equal(v, v_h) and np.array_equal(f, f_h)
         assert np.array_equal(face_i, face_h) and np.array_equal(nmap, nmap_h)
+        # the boundary cells as the C ABI hands them out (xr_voronoi_boundary_cells): the tail of the tessellation
+        from xugrid_amd import engine
+
+        extra, bcells = engine.DeviceVoronoi(grid.device_mesh).boundary_cells()
+        assert np.array_equal(extra, v[grid.n_face:])
+        nb = bcells.shape[0]
+        k = min(bcells.shape[1], f.shape[1])
+        assert np.array_equal(bcells[:, :k], f[f.shape[0] - nb:, :k]) and (bcells[:, k:] == -1).all()
         hv, hf, hfi, hnm = voronoi.voronoi_topology(
             grid.node_face_connectivity, grid.node_coordinates, grid.centroids, grid.edge_face_connectivity,
             grid.edge_node_connectivity, add_exterior=True, add_vertices=True, skip_concave=True,
