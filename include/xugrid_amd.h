@@ -188,13 +188,14 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
                        const int64_t *node_to_node_map, int64_t n_extra, xr_csr **out);
 /* the same with vertex_face given only for the vertices >= n_identity (vertex v < n_identity, a face centroid,
  * belongs to source face v): spares the host an O(n) array and its upload.
- * reference_order: the weight of slot j of a cell is paired with vertex j of the cell in the TREE's own
- * (counter-clockwise-normalised) vertex order (0, default) or in the CALLER's order as the reference does
- * (unstructured.py:175,193; 1).  The two differ only for cells the tree stores reversed (clockwise or concave exterior
- * cells that start at a reflex corner); with 1 the reference's pairing is reproduced for those too. */
+ * The weight of slot j of a cell is paired with vertex j of the cell in the CALLER's vertex order, exactly as the
+ * reference does (unstructured.py:175,193) -- also in xr_barycentric_csr above.  tree_order = 1 (opt-in, NOT the
+ * reference's result): paired with vertex j in the TREE's own counter-clockwise-normalised order, the order the
+ * weights were computed in.  The two differ only for cells the tree stores reversed (clockwise cells, or concave
+ * exterior cells that start at a reflex corner). */
 int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
                             double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
-                            const int64_t *node_to_node_map, int64_t n_extra, int reference_order, xr_csr **out);
+                            const int64_t *node_to_node_map, int64_t n_extra, int tree_order, xr_csr **out);
 
 /* ---- Voronoi pre-step of BarycentricInterpolator (xugrid/ugrid/voronoi.py:330-458 as called from
  * xugrid/regrid/unstructured.py:151-165: add_exterior, add_vertices, skip_concave) ---------------------

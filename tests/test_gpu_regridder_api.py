@@ -219,8 +219,10 @@ def test_celltree_adapter_matches_numba_celltree_call_shape(hip, oracle):
     assert (np.diff(i) >= 0).all()
 
 
-def _oracle_barycentric_triplets(oracle, grid, points, tolerance=None):
-    """unstructured.py:146-201 step by step with the CPU oracle (Voronoi pre-step: xugrid_amd.voronoi, pinned by G6)."""
+def _oracle_barycentric_triplets(oracle, grid, points, tolerance=None, tree_order=False):
+    """unstructured.py:146-201 step by step with the CPU oracle (Voronoi pre-step: xugrid_amd.voronoi, pinned by G6).
+    The weight slots are paired with the CALLER's vertex order of every Voronoi cell, as :175,193 do (default);
+    ``tree_order``: with the tree's counter-clockwise-normalised copy instead (the product's opt-in)."""
     from xugrid_amd import voronoi
 
     xy = grid.node_coordinates
@@ -232,11 +234,13 @@ def _oracle_barycentric_triplets(oracle, grid, points, tolerance=None):
     )
     vtree = oracle.CellTree2d(vertices, vfaces, -1)
     face_index, weights = vtree.compute_barycentric_weights(points, tolerance)
-    oracle.replace_interpolated_weights(vertices, vtree.faces, face_index, weights, n2n, len(vertices) - len(n2n))
+    pair_faces = vtree.faces if tree_order else np.asarray(vfaces)
+    assert pair_faces.shape == vtree.faces.shape
+    oracle.replace_interpolated_weights(vertices, pair_faces, face_index, weights, n2n, len(vertices) - len(n2n))
     outside = oracle.CellTree2d(xy, faces, -1).locate_points(points) == -1
     weights[outside] = 0
     keep = weights.ravel() > 0
-    source_index = node_to_face_index[vtree.faces[face_index]].ravel()[keep]
+    source_index = node_to_face_index[pair_faces[face_index]].ravel()[keep]
     n, m = weights.shape
     target_index = np.repeat(np.arange(n), m)[keep]
     return source_index, target_index, weights.ravel()[keep]
@@ -553,10 +557,10 @@ def _reversed_cells(voronoi_mesh):
 
 
 @pytest.mark.parametrize("case", ["g6c", "delaunay_100k", "clockwise_source"])
-def test_barycentric_reference_order_blast_radius(hip, golden, case):
-    """the weight slots of a Voronoi cell are paired with the tree's counter-clockwise vertex
-    order by default and with the caller's order under reference_order=True (the reference's pairing,
-    unstructured.py:175,193).  The two can only differ for cells the tree stores reversed.  MEASURED here (printed; the
+def test_barycentric_tree_order_blast_radius(hip, oracle, golden, case):
+    """the weight slots of a Voronoi cell are paired with the caller's vertex order by default (the
+    reference's pairing, unstructured.py:175,193) and with the tree's counter-clockwise vertex order under the opt-in
+    tree_order=True.  The two can only differ for cells the tree stores reversed.  MEASURED here (printed; the
     numbers are quoted in DESIGN.md section 7): how many cells that is -- concave exterior cells only, a fraction of
     the boundary -- and how many (source, target) entries change.  The host step-by-step path equals the device
     pipeline entry for entry under BOTH settings; entries only differ when reversed cells exist."""
@@ -582,11 +586,13 @@ def test_barycentric_reference_order_blast_radius(hip, golden, case):
     b = xa.regrid.UnstructuredGrid2d(tgt)
     trip = {}
     for ref in (False, True):
-        s_i, t_i, w = a.barycentric(b, reference_order=ref)
-        d = a.barycentric_device(b, reference_order=ref)
+        s_i, t_i, w = a.barycentric(b, tree_order=ref)
+        d = a.barycentric_device(b, tree_order=ref)
         data, idx, indptr = d.download()
         rows = np.repeat(np.arange(d.n), np.diff(indptr))
         assert np.array_equal(idx, s_i) and np.array_equal(rows, t_i) and np.array_equal(data, w), (case, ref)
+        o_s, o_t, o_w = _oracle_barycentric_triplets(oracle, src, tgt.centroids, tree_order=ref)
+        assert np.array_equal(idx, o_s) and np.array_equal(rows, o_t) and np.array_equal(data, o_w), (case, ref)
         trip[ref] = (s_i, t_i, w)
     same = all(np.array_equal(x, y) for x, y in zip(trip[False], trip[True]))
     n_diff = 0 if same else int(np.setxor1d(trip[False][0] * (tgt_f.shape[0] + 1) + trip[False][1],

@@ -618,16 +618,16 @@ int xr_barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const 
                        xr_csr **out) {
     XR_API_BEGIN
     XR_REQUIRE(vertex_face, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
-    barycentric_csr(voronoi, source, query, points, n, tolerance, 0, vertex_face, node_to_node_map, n_extra, false, out);
+    barycentric_csr(voronoi, source, query, points, n, tolerance, 0, vertex_face, node_to_node_map, n_extra, true, out);
     XR_API_END
 }
 
 int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
                             double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
-                            const int64_t *node_to_node_map, int64_t n_extra, int reference_order, xr_csr **out) {
+                            const int64_t *node_to_node_map, int64_t n_extra, int tree_order, xr_csr **out) {
     XR_API_BEGIN
     barycentric_csr(voronoi, source, query, points, n, tolerance, n_identity, vertex_face_tail, node_to_node_map, n_extra,
-                    reference_order != 0, out);
+                    tree_order == 0, out);
     XR_API_END
 }
 

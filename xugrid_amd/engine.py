@@ -372,11 +372,12 @@ def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_n
 
 
 def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,
-                    points=None, tolerance=None, n_identity=0, reference_order=False) -> "DeviceCSR":
+                    points=None, tolerance=None, n_identity=0, reference_order=True) -> "DeviceCSR":
     """UnstructuredGrid2d.barycentric after the Voronoi pre-step, on the device (see include/xugrid_amd.h).
     ``n_identity`` > 0: ``vertex_face`` holds only the entries of the vertices ``>= n_identity`` (the first
-    ``n_identity`` vertices are the source face centroids, in face order).  ``reference_order``: pair the weight
-    slots with the caller's vertex order of every cell, as the reference does (default: the tree's own order)."""
+    ``n_identity`` vertices are the source face centroids, in face order).  ``reference_order`` (default): pair the
+    weight slots with the caller's vertex order of every cell, as the reference does (unstructured.py:175,193);
+    False = the tree's own counter-clockwise order (opt-in, not the reference's result)."""
     vertex_face = np.ascontiguousarray(vertex_face, dtype=np.int64)
     if vertex_face.shape != (voronoi.n_node - n_identity,):
         raise ValueError("vertex_face must have one entry per Voronoi vertex")
@@ -395,11 +396,11 @@ def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_t
     else:
         p_arg, n, q_arg = None, query.n_face, query._h
     handle = ctypes.c_void_p()
-    if n_identity or reference_order:
+    if n_identity or not reference_order:
         check(
             _lib.load().xr_barycentric_csr_tail(
                 voronoi._h, source._h, q_arg, p_arg, n, tol, int(n_identity), _ptr(vertex_face), _ptr(n2n), n2n.shape[0],
-                1 if reference_order else 0, ctypes.byref(handle),
+                0 if reference_order else 1, ctypes.byref(handle),
             )
         )
     else:

@@ -23,6 +23,7 @@ from .. import engine
 from ..reduce import ABSOLUTE_OVERLAP_METHODS, RELATIVE_OVERLAP_METHODS, Method, create_percentile_method
 from ..sparse import MatrixCOO, MatrixCSR
 from ..ugrid2d import Ugrid2d
+from . import persist
 from .structured import Raster, StructuredGrid2d
 from .unstructured import UnstructuredGrid2d
 
@@ -125,19 +126,36 @@ class BaseRegridder(abc.ABC):
             return self._regrid_array(data)
         if hasattr(data, "values") and hasattr(data, "dims"):
             values = np.asarray(data.values)
-            # regridder.py:247-251, 197-210: the source dims are looked up BY NAME and moved to the end (apply_ufunc's
-            # input_core_dims); a plain trailing-shape check would silently regrid the wrong axes of e.g. (x, y) data
-            # with nx == ny
-            source_dims = tuple(getattr(self._source, "dims", ()) or ())
             dims = tuple(data.dims)
-            if source_dims and all(isinstance(d, str) for d in source_dims):
-                missing = set(source_dims) - set(dims)
-                if missing:
-                    raise ValueError(f"data does not contain regridder source dimensions: {missing}")
-                other = [d for d in dims if d not in source_dims]
-                values = np.transpose(values, [dims.index(d) for d in other] + [dims.index(d) for d in source_dims])
+            # regridder.py:231-251: the source dims come from the DATA, not from the regridder's source grid -- after
+            # from_weights / from_dataset that grid is called "__source" and its face dim "__source_nFaces" (the
+            # reference's FIXME at :231-236).  Structured data: ("y", "x") (:239); unstructured data: the core
+            # dimension of the data's own grid (:242).  The dims are looked up BY NAME and moved to the end
+            # (apply_ufunc's input_core_dims, :197-210); a bare trailing-shape check would silently regrid the wrong
+            # axes of e.g. (x, y) data with nx == ny.
+            source_dims = self._data_source_dims(data, dims)
+            missing = set(source_dims) - set(dims)
+            if missing:
+                raise ValueError(f"data does not contain regridder source dimensions: {missing}")
+            other = [d for d in dims if d not in source_dims]
+            values = np.transpose(values, [dims.index(d) for d in other] + [dims.index(d) for d in source_dims])
             return self._regrid_array(np.ascontiguousarray(values))
         raise TypeError(f"Expected DataArray or UgridDataAray, received: {type(data).__name__}")
+
+    def _data_source_dims(self, data, dims):
+        if isinstance(self._source, StructuredGrid2d):
+            named = tuple(self._source.dims)
+            return named if set(named) <= set(dims) else ("y", "x")
+        grid = getattr(getattr(data, "ugrid", None), "grid", None) or getattr(data, "grid", None)
+        core = getattr(grid, "core_dimension", None) or getattr(grid, "face_dimension", None)
+        if isinstance(core, str):
+            return (core,)
+        # a bare DataArray-like over an unstructured source: the regridder's own face dim when the data names it,
+        # else the data's last dim (the layout contract of _regrid_array, regridder.py:145-163)
+        named = tuple(self._source.dims)
+        if set(named) <= set(dims):
+            return named
+        return (dims[-1],) if dims else ()
 
     # ---- weights access / persistence (regridder.py:264-361)
     def _ensure_host_weights(self):
@@ -225,6 +243,11 @@ class BaseRegridder(abc.ABC):
     def _weights_from_dataset(cls, dataset):
         """Return either COO or CSR weights."""
 
+    @classmethod
+    def _weights_from_reference(cls, dataset):
+        """The same from the reference's layout (CSR unless the class stores COO)."""
+        return persist.csr_from_reference(dataset)
+
     @staticmethod
     def _grid_from_dataset(dataset, name):
         kind = dataset[name + "_type"]
@@ -233,13 +256,42 @@ class BaseRegridder(abc.ABC):
             return setup_grid(Ugrid2d.from_dataset(dataset, name))
         return StructuredGrid2d.from_dataset(dataset, name)
 
+    # ---- the reference's own dataset layout (regridder.py:264-271, :334-361; regrid/persist.py)
+    def to_reference_dataset(self) -> "persist.RefDataset":
+        """``to_dataset()`` in the layout xugrid itself writes: attrs-typed ``__source_type`` / ``__target_type``
+        markers, UGRID topology variables, ascending midpoints + bounds for rasters -- a ``RefDataset`` of
+        (dims, data, attrs) variables (``.to_xarray()`` when xarray is present; ``.save(path)`` otherwise).
+        xugrid's ``Regridder.from_dataset`` / ``from_weights`` read it as it is."""
+        ds = persist.weights_to_reference(self._ensure_host_weights())
+        ds.merge(persist.grid_to_reference(self._source, "__source"))
+        ds.merge(persist.grid_to_reference(self._target, "__target"))
+        return ds
+
+    @classmethod
+    def from_reference_dataset(cls, dataset, target=None, **kwargs):
+        """Reconstruct from a dataset in the reference's layout: a ``RefDataset`` or a real ``xr.Dataset`` written by
+        xugrid (``regridder.to_dataset()``).  ``target``: as in ``from_weights`` (regridder.py:334-347); without it
+        the target is read from the dataset too (``from_dataset``, :350-361).  kwargs: ``method`` where the class
+        takes one."""
+        if target is None:
+            if persist.grid_kind(dataset, "__target") != "UnstructuredGrid2d":
+                # (the reference leaves ``target`` unbound for structured targets, :355-360; here they are read)
+                target = persist.structured2d_from_reference(dataset, "__target")
+            else:
+                target = persist.ugrid2d_from_reference(dataset, "__target")
+        return cls.from_weights(dataset, target, **kwargs)
+
     @classmethod
     def from_weights(cls, weights, target):
         instance = cls.__new__(cls)
-        instance._weights = cls._weights_from_dataset(weights)
         instance._device_weights = None
         instance._target = setup_grid(target)
-        instance._source = cls._grid_from_dataset(weights, "__source")
+        if persist.is_reference_layout(weights):
+            instance._weights = cls._weights_from_reference(weights)
+            instance._source = persist.grid_from_reference(weights, "__source")
+        else:
+            instance._weights = cls._weights_from_dataset(weights)
+            instance._source = cls._grid_from_dataset(weights, "__source")
         w = instance._weights
         if w.n != instance._target.size:
             raise ValueError(f"the weights have {w.n} rows, the target grid {instance._target.size} cells")
@@ -247,24 +299,35 @@ class BaseRegridder(abc.ABC):
             raise ValueError(f"the weights have {w.m} columns, the source grid {instance._source.size} cells")
         return instance
 
-    # ---- file persistence of the flat dict (xarray / netCDF are optional and absent here).  The weight variables
-    # carry the reference's names (regridder.py:264-271); the GRID variables are this package's own (the reference
-    # writes UGRID topologies with attrs-typed markers), so files are not interchangeable with xugrid's netCDF.
-    def to_file(self, path) -> None:
-        """Write ``to_dataset()`` to a NumPy ``.npz`` archive."""
+    # ---- file persistence (xarray / netCDF are optional and absent here).  layout="flat": the flat dict of
+    # ``to_dataset`` (the reference's weight variable names, this package's own grid variables); layout="reference":
+    # ``to_reference_dataset()`` -- the reference's variables, dims and attrs one to one, i.e. what
+    # ``xr.Dataset.to_netcdf`` would carry -- in an .npz with a JSON sidecar for dims / attrs.
+    def to_file(self, path, layout: str = "flat") -> None:
+        """Write the weights and both grids to a NumPy ``.npz`` archive."""
+        if layout == "reference":
+            self.to_reference_dataset().save(path)
+            return
+        if layout != "flat":
+            raise ValueError(f'layout must be "flat" or "reference", received {layout!r}')
         np.savez_compressed(path, **{k: np.asarray(v) for k, v in self.to_dataset().items()})
 
     @classmethod
     def from_file(cls, path):
-        """Reconstruct the regridder (cached weights + both grids) from ``to_file`` output."""
+        """Reconstruct the regridder (cached weights + both grids) from ``to_file`` output (either layout)."""
         with np.load(path, allow_pickle=False) as archive:
+            if "__meta__" in archive.files:
+                return cls.from_reference_dataset(persist.RefDataset.load(path))
             dataset = {k: (archive[k].item() if archive[k].ndim == 0 and archive[k].dtype.kind in "US" else archive[k])
                        for k in archive.files}
         return cls.from_dataset(dataset)
 
     @classmethod
     def from_dataset(cls, dataset):
-        """Reconstruct the regridder from ``to_dataset()`` output (regridder.py:350-361)."""
+        """Reconstruct the regridder from ``to_dataset()`` output (regridder.py:350-361); a dataset in the
+        reference's own layout (``to_reference_dataset``, or an ``xr.Dataset`` written by xugrid) is recognised."""
+        if persist.is_reference_layout(dataset):
+            return cls.from_reference_dataset(dataset)
         target = cls._grid_from_dataset(dataset, "__target")
         return cls.from_weights(dataset, target)
 
@@ -316,6 +379,10 @@ class CentroidLocatorRegridder(BaseRegridder):
     @classmethod
     def _weights_from_dataset(cls, dataset) -> MatrixCOO:
         return cls._coo_from_dataset(dataset)
+
+    @classmethod
+    def _weights_from_reference(cls, dataset) -> MatrixCOO:
+        return persist.coo_from_reference(dataset)
 
 
 class BaseOverlapRegridder(BaseRegridder, abc.ABC):
@@ -388,11 +455,12 @@ class BarycentricInterpolator(BaseRegridder):
 
     _METHODS = {"mean": ABSOLUTE_OVERLAP_METHODS["mean"]}
 
-    def __init__(self, source, target, tolerance: Optional[float] = None, reference_order: bool = False):
-        # reference_order (not in the reference's signature, regridder.py:613-622): pair the weight slots of the concave
-        # exterior Voronoi cells with the caller's vertex order as the reference does, instead of the order the
-        # weights were computed in (UnstructuredGrid2d.barycentric; DESIGN.md section 7: 0.1-0.7 % of the entries)
-        self._reference_order = bool(reference_order)
+    def __init__(self, source, target, tolerance: Optional[float] = None, tree_order: bool = False):
+        # Default = the reference's result (regridder.py:613-622, unstructured.py:175,193: weight slots paired with
+        # the caller's vertex order).  tree_order (opt-in, not in the reference's signature): pair the slots of the
+        # concave exterior Voronoi cells with the order the weights were computed in instead
+        # (UnstructuredGrid2d.barycentric; DESIGN.md section 7: changes 0.1-0.7 % of the entries)
+        self._tree_order = bool(tree_order)
         super().__init__(source, target, tolerance)
         self._setup_regrid("mean")
 
@@ -403,7 +471,7 @@ class BarycentricInterpolator(BaseRegridder):
             self._device_weights = source.linear_weights_device(target)
             self._weights = None
             return
-        self._device_weights = source.barycentric_device(target, tolerance, reference_order=self._reference_order)
+        self._device_weights = source.barycentric_device(target, tolerance, tree_order=self._tree_order)
         self._weights = None
 
     @classmethod

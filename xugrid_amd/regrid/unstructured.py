@@ -102,10 +102,10 @@ class UnstructuredGrid2d:
         return voronoi_grid, vertices, faces, node_to_face_index, node_to_node_map
 
     def barycentric_device(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None,
-                           reference_order: bool = False):
+                           tree_order: bool = False):
         """The barycentric weights as a device CSR (rows = faces of ``other``): everything after the Voronoi
         pre-step -- locate + weights, exterior-vertex replacement, masking, compaction -- runs in HBM.
-        ``reference_order``: see ``barycentric``."""
+        ``tree_order``: see ``barycentric``."""
         from .. import engine, voronoi
 
         voronoi_mesh, face_index_tail, node_to_node_map = voronoi.voronoi_topology_device(
@@ -119,29 +119,30 @@ class UnstructuredGrid2d:
             query=other.ugrid_topology.device_mesh,
             tolerance=tolerance,
             n_identity=self.ugrid_topology.n_face,
-            reference_order=reference_order,
+            reference_order=not tree_order,
         )
 
-    def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None, reference_order: bool = False):
+    def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None, tree_order: bool = False):
         """-> (source_index, target_index, weights) on the host, step by step as unstructured.py:146-201.
 
-        ``reference_order=False`` (default): the weight of slot j of a Voronoi cell is paired with vertex j of the cell
-        in the tree's own counter-clockwise-normalised vertex order -- the order the weights were computed in.
-        ``reference_order=True``: paired with vertex j in the CALLER's order, as the reference does
-        (unstructured.py:175,193).  The two only differ for cells the tree stores reversed -- concave exterior cells
-        that start at a reflex corner; tests/test_gpu_regridder_api.py::test_barycentric_reference_order_blast_radius
-        counts them and the entries they change."""
+        Default (``tree_order=False``): the weight of slot j of a Voronoi cell is paired with vertex j of the cell in
+        the CALLER's vertex order -- exactly what the reference does (unstructured.py:175,193).
+        ``tree_order=True`` (opt-in, NOT the reference's result): paired with vertex j in the tree's own
+        counter-clockwise-normalised vertex order, the order the weights were computed in.  The two only differ for
+        cells the tree stores reversed -- concave exterior cells that start at a reflex corner;
+        tests/test_gpu_regridder_api.py::test_barycentric_tree_order_blast_radius counts them and the entries they
+        change."""
         from .._replace import replace_interpolated_weights
 
         points = other.ugrid_topology.centroids
         grid = self.ugrid_topology
         voronoi_grid, vertices, faces, node_to_face_index, node_to_node_map = self._voronoi()
         face_index, weights = voronoi_grid.compute_barycentric_weights(points, tolerance)
-        # The weights are aligned with the tree's own vertex order of each cell (numba_celltree normalises
-        # its copy of the faces to counter-clockwise: the first non-collinear vertex triple decides, which
-        # reverses a concave cell that starts at a reflex corner).  The reference indexes with the caller's
-        # order (unstructured.py:175,193), which misaligns exactly those cells; here the tree's order is used.
-        if not reference_order:
+        # The weights come back aligned with the tree's own vertex order of each cell (the tree normalises its copy
+        # of the faces to counter-clockwise: the first non-collinear vertex triple decides, which reverses a concave
+        # cell that starts at a reflex corner).  The reference indexes them with the caller's order
+        # (unstructured.py:175,193) and so does the default here; ``tree_order`` re-aligns those cells instead.
+        if tree_order:
             faces = voronoi_grid.device_mesh.faces_ccw()
         replace_interpolated_weights(
             vertices=vertices,
