@@ -27,9 +27,11 @@
  *     e.g. torch tensor .data_ptr()) and do no host transfer; they run on the engine stream and
  *     synchronise it before returning unless stated otherwise.
  *   - Handles (xr_mesh, xr_csr) own HBM; they are not tied to a host thread.  Re-entrancy (dask calls
- *     the apply seam from several threads, regridder.py:177-185): entry points that only READ a
- *     weight matrix (xr_apply_csr[_dev], the partial-state entries) run concurrently, each calling
- *     thread on a HIP stream of its own; entry points that build or mutate a handle are exclusive.
+ *     the apply seam from several threads, regridder.py:177-185): the apply entry points
+ *     xr_apply_csr[_dev], which only READ a weight matrix, run concurrently, each calling thread on a
+ *     HIP stream of its own; every other entry point (building or mutating a handle, and the
+ *     partial-state entries of the multi-GPU split, one thread per process by design) is exclusive:
+ *     callable from any thread, serialised inside the library.
  *   - There is NO CPU fallback: without a HIP device every compute entry point fails with
  *     XR_ERR_NO_DEVICE.
  */

@@ -125,3 +125,57 @@ def test_sharded_regridder_world2_gloo(tmp_path, oracle):
         single = oracle.regrid_csr(method, data, a, s, indptr, tf.shape[0])
         assert np.array_equal(out["tp_" + method], single, equal_nan=True), method
     assert int(out["tp_n_local_sources"]) < 0.85 * sf.shape[0]
+
+
+def test_sharded_regridder_world3_and_8_loopback(oracle):
+    """The same product code with W = 3 and W = 8 ranks as threads of this process and looped-back collectives
+    (tests/loopback_dist.py; the GPU suite runs the HIP backend through the very same harness,
+    tests/test_gpu_sharded_loopback.py).  Oracle-backed compute backend, expected values from the unsharded matrix."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from dist_worker import OracleBackend
+    from loopback_dist import run_ranks
+
+    from xugrid_amd.distributed import ShardedOverlapRegridder
+
+    sxy, sf = meshgen.triangle_mesh(900, 0)
+    txy, tf = meshgen.triangle_mesh(701, 1, 30.0, 0.7)
+    data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(5)])
+    data[1] = np.abs(data[1]) + 0.1
+    data[3] = np.nan
+    q, s_, a = oracle.CellTree2d(sxy, sf).intersect_faces(txy, tf)
+    T = tf.shape[0]
+    indptr = oracle.to_csr_indptr(q, T)
+    for W, partition in ((3, "balanced"), (8, "hash")):
+        def body(dist, rank, partition=partition):
+            rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition=partition, k_tile=2, dist=dist)
+            out = {}
+            for method in ("mean", "sum", "geometric_mean", "minimum"):
+                rg.set_method(method)
+                for exchange in ("sparse", "dense"):
+                    rg.exchange = exchange
+                    out[method, exchange] = rg.regrid(data)
+            out["senders"] = int(np.diff(rg._recv_indptr.numpy()).max())
+            out["n_local"] = rg.local_faces.size
+            return out
+
+        per_rank, world = run_ranks(W, body)
+        assert sum(o["n_local"] for o in per_rank) == sf.shape[0]
+        assert max(o["senders"] for o in per_rank) >= (W if partition == "hash" else 2)
+        assert min(world.sent_bytes) > 0
+        for method in ("mean", "sum", "geometric_mean", "minimum"):
+            expected = oracle.regrid_csr(method, data, a, s_, indptr, T)
+            for exchange in ("sparse", "dense"):
+                for o in per_rank:
+                    np.testing.assert_allclose(o[method, exchange], expected, rtol=1e-12, atol=1e-14, equal_nan=True)
+    # relative and absolute weights are not interchangeable; whole-row reducers are refused
+    def refuse(dist, rank):
+        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), dist=dist)
+        for bad in ("first_order_conservative", "median"):
+            try:
+                rg.set_method(bad)
+            except ValueError:
+                continue
+            raise AssertionError(bad)
+        return True
+
+    assert run_ranks(2, refuse)[0] == [True, True]

@@ -1454,12 +1454,14 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             // for the largest planned block, so typical matrices run three blocks per CU instead of two
             const size_t shmem_max = sizeof(double) * (PLAN_KT * PLAN_UMAX + PLAN_LMAX) + sizeof(uint16_t) * PLAN_LMAX;
             const size_t shmem = sizeof(double) * (PLAN_KT * PLAN_UMAX + csr->plan_lmax) + sizeof(uint16_t) * csr->plan_lmax;
-            static bool attr_set = false;
-            if (!attr_set) {
-                XR_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_max));
-                attr_set = true;
-            }
+            // (applies run concurrently under the shared scope: the one-time attribute is set behind a once_flag)
+            static std::once_flag attr_once;
+            hipError_t attr_rc = hipSuccess;
+            std::call_once(attr_once, [&] {
+                attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_max);
+            });
+            XR_HIP(attr_rc);
             XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), dim3((div_up(csr->n, AP_BLOCK) + 7) / 8 * 8), dim3(AP_BLOCK),
                       shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(),
                       csr->plan_nuniq.get(), csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src,

@@ -71,8 +71,15 @@ SharedScope::SharedScope() {
     }
     if (!lane->stream) {
         if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess) {
+            // no lane, no concurrency: running on the engine's own stream under the SHARED lock would race with the
+            // other lanes' pool blocks -- fail the call instead
+            (void)hipGetLastError();
+            lane->stream = nullptr;
             lane->busy.unlock();
-            return; // (no lane: the call runs on the engine's stream, still correct for one thread)
+            engine_rw().unlock_shared();
+            leased = false;
+            set_error("could not create a HIP stream for a concurrent apply");
+            throw Failure{XR_ERR_HIP};
         }
     }
     t_lane = lane;
@@ -156,6 +163,13 @@ static size_t size_class(size_t bytes) {
     return p;
 }
 
+// Blocks are handed out again in stream order, which is only safe with ONE stream.  From the moment a side stream is
+// forked until the host has seen both streams drained, freed blocks are parked instead of being reused: a block freed
+// by code on one stream could otherwise be given to the other while a kernel of the first still touches it.
+static bool g_side_active = false;
+static std::vector<std::pair<size_t, void *>> g_deferred;
+static std::map<Lane *, std::vector<std::pair<size_t, void *>>> g_lane_deferred; // the same per lane, until its side_join()
+
 void *pool_alloc(size_t bytes) {
     engine();
     size_t c = size_class(bytes);
@@ -180,10 +194,23 @@ void *pool_alloc(size_t bytes) {
     } else {
         hipError_t e = hipMalloc(&p, c);
         if (e != hipSuccess) {
-            // give cached blocks back and retry once
+            // give cached blocks back and retry once.  The lanes' own lists and the parked (deferred) blocks may still
+            // be touched by kernels in flight: wait for the device first, then every cached block is really free
+            // (lists are only changed under g_pool_mutex, which is held here).
             (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
             for (auto &kv : g_free) (void)hipFree(kv.second);
             g_free.clear();
+            for (auto &lane : g_lane_free) {
+                for (auto &kv : lane.second) (void)hipFree(kv.second);
+                lane.second.clear();
+            }
+            for (auto &kv : g_deferred) (void)hipFree(kv.second);
+            g_deferred.clear();
+            for (auto &lane : g_lane_deferred) {
+                for (auto &kv : lane.second) (void)hipFree(kv.second);
+                lane.second.clear();
+            }
             XR_HIP(hipMalloc(&p, c));
         }
     }
@@ -191,12 +218,6 @@ void *pool_alloc(size_t bytes) {
     return p;
 }
 
-// Blocks are handed out again in stream order, which is only safe with ONE stream.  From the moment a side stream is
-// forked until the host has seen both streams drained, freed blocks are parked instead of being reused: a block freed
-// by code on one stream could otherwise be given to the other while a kernel of the first still touches it.
-static bool g_side_active = false;
-static std::vector<std::pair<size_t, void *>> g_deferred;
-static std::map<Lane *, std::vector<std::pair<size_t, void *>>> g_lane_deferred; // the same per lane, until its side_join()
 
 void pool_free(void *p) {
     if (!p) return;

@@ -100,11 +100,13 @@ def _partition_faces_t(centroids, world_size, mode="morton", weights=None):
     if weights is None:
         owner[order] = (torch.arange(n, device=dev) * world_size // max(n, 1)).to(torch.int32)
     else:
-        w = weights.to(torch.float64)[order]
+        # Every rank computes the cut on its own device, so the arithmetic must be EXACT: a floating-point cumsum is
+        # not deterministic on a GPU, and two ranks disagreeing on one cut by an ulp would leave a source face with
+        # two owners or with none.  Fixed-point work weights (1/4096 units) and an int64 cumsum are.
+        w = (weights.to(torch.float64)[order] * 4096.0).round().to(torch.int64).clamp(min=1)
         before = torch.cumsum(w, 0) - w  # weight in front of each face along the curve
-        total = float(w.sum())
-        cut = before * (world_size / total) if total > 0 else torch.arange(n, device=dev) * (world_size / max(n, 1))
-        owner[order] = cut.to(torch.int64).clamp(max=world_size - 1).to(torch.int32)
+        total = int(w.sum())
+        owner[order] = torch.div(before * world_size, total, rounding_mode="floor").clamp(max=world_size - 1).to(torch.int32)
     return owner
 
 
@@ -362,10 +364,11 @@ class ShardedOverlapRegridder:
     """
 
     def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="balanced", group=None,
-                 exchange="sparse", method="mean", k_tile=32):
+                 exchange="sparse", method="mean", k_tile=32, dist=None):
         import torch
-        import torch.distributed as dist
 
+        if dist is None:  # (tests inject a loop-back implementation of the four collectives used here)
+            import torch.distributed as dist
         if exchange not in ("sparse", "dense"):
             raise ValueError(f"unknown exchange mode {exchange!r}")
         self.method, self.relative = _method(method)
@@ -435,6 +438,15 @@ class ShardedOverlapRegridder:
     def rebuild(self):
         self.weights = self.backend.rebuild_weights()
 
+    def set_method(self, method):
+        """Another reducer on the same sharded weights (absolute and relative overlap weights are not interchangeable)."""
+        new, relative = _method(method)
+        if new.name not in SHARD_METHODS:
+            raise ValueError(f"{new.name!r} needs whole rows: use TargetPartitionedRegridder")
+        if relative != self.relative:
+            raise ValueError("relative and absolute overlap weights are not interchangeable")
+        self.method = new
+
     # ---- persistence of the sharded weights (SURVEY 8f rank 3): one file per rank, no gather
     @staticmethod
     def shard_path(prefix, rank, world):
@@ -455,10 +467,11 @@ class ShardedOverlapRegridder:
         return path
 
     @classmethod
-    def from_file(cls, prefix, backend, group=None, exchange=None, method=None, k_tile=32):
+    def from_file(cls, prefix, backend, group=None, exchange=None, method=None, k_tile=32, dist=None):
         """Counterpart of ``Regridder.from_weights`` for sharded weights: every rank reads its own file (written
         by a job of the SAME world size) and the exchange lists are set up again; no mesh, no weight construction."""
-        import torch.distributed as dist
+        if dist is None:
+            import torch.distributed as dist
 
         self = cls.__new__(cls)
         self.dist, self.group, self.backend = dist, group, backend
