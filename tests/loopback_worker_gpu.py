@@ -111,6 +111,11 @@ def full(out_dir, n_points):
 
 
 if __name__ == "__main__":
+    import faulthandler
+
+    # a stuck collective (a rank that never arrives) would otherwise hang silently until the caller's timeout:
+    # dump every thread's stack to stderr after XR_LOOPBACK_DUMP_S seconds (and again at every multiple)
+    faulthandler.dump_traceback_later(int(os.environ.get("XR_LOOPBACK_DUMP_S", "600")), repeat=True, file=sys.stderr)
     if sys.argv[2] == "small":
         small(sys.argv[1])
     else:

@@ -204,6 +204,47 @@ template <int METHOD> __device__ __forceinline__ void block_merge(Red<METHOD> &r
     r = t;
 }
 
+// one listed row reduced by the whole block (all threads call; rows beyond APPLY_WAVE entries)
+template <int METHOD, typename SRC>
+__device__ __forceinline__ void apply_row_block(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                const double *__restrict__ data, const int32_t *__restrict__ row_order,
+                                                int t, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+                                                double *__restrict__ out, double (*lds)[3]) {
+    const int s = indptr[t], e = indptr[t + 1];
+    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+    double normsum = 0.0;
+    if (METHOD == XR_GEOMETRIC_MEAN) {
+        Red<XR_SUM> ws; // b accumulates the weights
+        for (int j = s + threadIdx.x; j < e; j += AP_BLOCK) ws.b += data[j];
+        block_merge<XR_SUM>(ws, lds);
+        normsum = ws.b;
+    }
+    for (int64_t k = blockIdx.y; k < K; k += gridDim.y) {
+        const SRC *src = source + k * S;
+        Red<METHOD> r;
+        int j = s + threadIdx.x;
+        // four entries in flight per thread; the additions keep their sequential order
+        for (; j + 3 * AP_BLOCK < e; j += 4 * AP_BLOCK) {
+            const int c0 = indices[j], c1 = indices[j + AP_BLOCK], c2 = indices[j + 2 * AP_BLOCK],
+                      c3 = indices[j + 3 * AP_BLOCK];
+            const double w0 = data[j], w1 = data[j + AP_BLOCK], w2 = data[j + 2 * AP_BLOCK],
+                         w3 = data[j + 3 * AP_BLOCK];
+            const double v0 = ld_src(src, c0), v1 = ld_src(src, c1), v2 = ld_src(src, c2), v3 = ld_src(src, c3);
+            r.add(v0, w0, normsum);
+            r.add(v1, w1, normsum);
+            r.add(v2, w2, normsum);
+            r.add(v3, w3, normsum);
+        }
+        for (; j < e; j += AP_BLOCK) r.add(ld_src(src, indices[j]), data[j], normsum);
+        block_merge<METHOD>(r, lds);
+        if (threadIdx.x == 0) {
+            double v = r.fin();
+            if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) v = NAN;
+            out[k * T + t_out] = v;
+        }
+    }
+}
+
 template <int METHOD, typename SRC>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_long(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
@@ -212,42 +253,8 @@ k_apply_long(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
              double *__restrict__ out) {
     __shared__ double lds[AP_BLOCK / 64][3];
     const int nl = *n_long;
-    for (int li = blockIdx.x; li < nl; li += gridDim.x) {
-        const int t = long_rows[li];
-        const int s = indptr[t], e = indptr[t + 1];
-        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
-        double normsum = 0.0;
-        if (METHOD == XR_GEOMETRIC_MEAN) {
-            Red<XR_SUM> ws; // b accumulates the weights
-            for (int j = s + threadIdx.x; j < e; j += AP_BLOCK) ws.b += data[j];
-            block_merge<XR_SUM>(ws, lds);
-            normsum = ws.b;
-        }
-        for (int64_t k = blockIdx.y; k < K; k += gridDim.y) {
-            const SRC *src = source + k * S;
-            Red<METHOD> r;
-            int j = s + threadIdx.x;
-            // four entries in flight per thread; the additions keep their sequential order
-            for (; j + 3 * AP_BLOCK < e; j += 4 * AP_BLOCK) {
-                const int c0 = indices[j], c1 = indices[j + AP_BLOCK], c2 = indices[j + 2 * AP_BLOCK],
-                          c3 = indices[j + 3 * AP_BLOCK];
-                const double w0 = data[j], w1 = data[j + AP_BLOCK], w2 = data[j + 2 * AP_BLOCK],
-                             w3 = data[j + 3 * AP_BLOCK];
-                const double v0 = ld_src(src, c0), v1 = ld_src(src, c1), v2 = ld_src(src, c2), v3 = ld_src(src, c3);
-                r.add(v0, w0, normsum);
-                r.add(v1, w1, normsum);
-                r.add(v2, w2, normsum);
-                r.add(v3, w3, normsum);
-            }
-            for (; j < e; j += AP_BLOCK) r.add(ld_src(src, indices[j]), data[j], normsum);
-            block_merge<METHOD>(r, lds);
-            if (threadIdx.x == 0) {
-                double v = r.fin();
-                if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) v = NAN;
-                out[k * T + t_out] = v;
-            }
-        }
-    }
+    for (int li = blockIdx.x; li < nl; li += gridDim.x)
+        apply_row_block<METHOD, SRC>(indptr, indices, data, row_order, long_rows[li], T, S, source, K, out, lds);
 }
 
 // Listed rows with APPLY_LONG < entries <= APPLY_WAVE, KTILE source variables per pass, reduced by a GROUP of
@@ -338,15 +345,15 @@ __device__ __forceinline__ void apply_row_group(const int32_t *__restrict__ indi
     }
 }
 
+// the listed rows of APPLY_LONG + 1 ... APPLY_WAVE entries, dealt to `n_waves` waves (this one is `wave`); rows beyond
+// APPLY_WAVE entries are queued in huge_rows ([0] = count) when given, else left to the caller
 template <int METHOD, typename SRC, int KTILE>
-__global__ void __launch_bounds__(AP_BLOCK)
-k_apply_wave(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
-             const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
-             const int32_t *__restrict__ n_long, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
-             double *__restrict__ out, int32_t *__restrict__ huge_rows) {
+__device__ __forceinline__ void apply_wave_rows(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                const double *__restrict__ data, const int32_t *__restrict__ row_order,
+                                                const int32_t *__restrict__ long_rows, int nl, int wave, int n_waves,
+                                                int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+                                                double *__restrict__ out, int32_t *__restrict__ huge_rows) {
     const int lane = threadIdx.x & 63;
-    const int wave = (blockIdx.x * AP_BLOCK + threadIdx.x) >> 6, n_waves = gridDim.x * (AP_BLOCK / 64);
-    const int nl = *n_long;
     // pass 1: four listed rows per wave, 16 lanes each
     for (int li0 = wave * 4; li0 < nl; li0 += n_waves * 4) {
         const int li = li0 + (lane >> 4);
@@ -370,11 +377,137 @@ k_apply_wave(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         const int s = indptr[t], e = indptr[t + 1];
         if (e - s <= APPLY_GROUP16) continue;
         if (e - s > APPLY_WAVE) { // [0] = count
-            if (lane == 0 && blockIdx.y == 0) huge_rows[1 + atomicAdd(huge_rows, 1)] = t;
+            if (huge_rows && lane == 0 && blockIdx.y == 0) huge_rows[1 + atomicAdd(huge_rows, 1)] = t;
             continue;
         }
         const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
         apply_row_group<METHOD, SRC, KTILE, 64>(indices, data, s, e, t_out, T, S, source, K, out);
+    }
+}
+
+template <int METHOD, typename SRC, int KTILE>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_wave(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+             const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+             const int32_t *__restrict__ n_long, int64_t T, int64_t S, const SRC *__restrict__ source, int64_t K,
+             double *__restrict__ out, int32_t *__restrict__ huge_rows) {
+    const int wave = (blockIdx.x * AP_BLOCK + threadIdx.x) >> 6, n_waves = gridDim.x * (AP_BLOCK / 64);
+    apply_wave_rows<METHOD, SRC, KTILE>(indptr, indices, data, row_order, long_rows, *n_long, wave, n_waves, T, S, source, K,
+                                        out, huge_rows);
+}
+
+// K = 1, every row in ONE launch.  Blocks [0, n_long_blocks) take the listed long rows (lane groups / waves, then the rows
+// beyond APPLY_WAVE entries block by block) -- they are dispatched first and run beside the short rows, no second and third
+// launch behind the kernel, no fork / join.  The other blocks take AP_BLOCK stored rows each, every WAVE on its own: a wave
+// stages the CSR segment of its 64 consecutive rows -- contiguous -- in a private LDS window in chunks of W1_CAP entries
+// (column and weight loaded coalesced, the source value gathered by the same lane and parked next to the weight), then every
+// lane reduces ITS row from the window, sequentially in CSR order (bit-identical to the reference loop,
+// regridder.py:52-62).  No block barrier anywhere and 5 KB of LDS per wave: 32 waves per CU keep three dependent
+// round trips (row pointers -> entries -> source values) in flight, where the block-wide version (k_apply_stream, 32 KB
+// and four barriers per block) held 20 (MI355X, 1M x 1M benchmark: 42.6 -> see DESIGN section 5).
+static constexpr int W1_CAP = 320; // entries per wave window: 64 rows x 4 entries (the mean of a triangle pair) + slack
+template <int METHOD, typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_rows1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+              const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
+              const int32_t *__restrict__ n_long, int n_long_blocks, bool any_huge, int64_t T, int64_t S,
+              const SRC *__restrict__ source, double *__restrict__ out) {
+    __shared__ double2 sh_win[AP_BLOCK / 64][W1_CAP]; // (.x = weight, .y = source value); 20 KB: 8 blocks per CU
+    double(*sh_merge)[3] = reinterpret_cast<double(*)[3]>(&sh_win[0][0]); // (long-row blocks stage nothing)
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    if ((int)blockIdx.x < n_long_blocks) {
+        const int nl = *n_long;
+        apply_wave_rows<METHOD, SRC, 1>(indptr, indices, data, row_order, long_rows, nl, (int)blockIdx.x * (AP_BLOCK / 64) + wib,
+                                        n_long_blocks * (AP_BLOCK / 64), T, S, source, 1, out, nullptr);
+        if (any_huge) { // (uniform per block: every thread walks the list)
+            for (int li = blockIdx.x; li < nl; li += n_long_blocks) {
+                const int t = long_rows[li];
+                if (indptr[t + 1] - indptr[t] > APPLY_WAVE)
+                    apply_row_block<METHOD, SRC>(indptr, indices, data, row_order, t, T, S, source, 1, out, sh_merge);
+            }
+        }
+        return;
+    }
+    // (last row blocks first: weights built by xr_overlap keep the rows of the big target faces at the end)
+    const int64_t row0 = ((int64_t)(gridDim.x - 1 - blockIdx.x) * (AP_BLOCK / 64) + wib) * 64;
+    if (row0 >= T) return;
+    const int64_t t = row0 + lane;
+    int s = 0, e = 0;
+    if (t < T) {
+        s = indptr[t];
+        e = indptr[t + 1];
+    }
+    const bool skip = n_long_blocks > 0 && (e - s > APPLY_LONG); // reduced by the long-row blocks
+    const int seg0 = __shfl(s, 0, 64);
+    int seg1 = e; // (lanes beyond T hold 0: the maximum is the end of the last valid row)
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) seg1 = max(seg1, __shfl_xor(seg1, d, 64));
+    if (skip) e = s;
+    const bool jumpy = __any(skip);
+    double2 *win = sh_win[wib];
+    // first entry any lane still needs at or behind c0 (a window must not stream the entries of skipped long rows)
+    auto next_chunk = [&](int c0) -> int {
+        if (!jumpy) return c0;
+        int mine = (e > s && e > c0) ? (s > c0 ? s : c0) : INT_MAX;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine = min(mine, __shfl_xor(mine, d, 64));
+        return mine;
+    };
+    double normsum = 0.0;
+    if (METHOD == XR_GEOMETRIC_MEAN) {
+        for (int c0 = seg0; c0 < seg1; c0 += W1_CAP) {
+            c0 = next_chunk(c0);
+            if (c0 >= seg1) break;
+            for (int j = c0 + lane; j < c0 + W1_CAP && j < seg1; j += 64) win[j - c0].x = data[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int a = s > c0 ? s : c0, b = e < c0 + W1_CAP ? e : c0 + W1_CAP;
+            for (int j = a; j < b; j++) normsum += win[j - c0].x;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    Red<METHOD> red;
+    for (int c0 = seg0; c0 < seg1; c0 += W1_CAP) {
+        c0 = next_chunk(c0);
+        if (c0 >= seg1) break;
+        {
+            constexpr int PER = W1_CAP / 64;
+            int col[PER];
+            double w[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int j = c0 + u * 64 + lane;
+                col[u] = j < seg1 ? indices[j] : -1;
+                w[u] = j < seg1 ? data[j] : 0.0;
+            }
+            double v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) v[u] = col[u] >= 0 ? ld_src(source, (int64_t)col[u]) : 0.0;
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (col[u] >= 0) win[u * 64 + lane] = make_double2(w[u], v[u]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int a = s > c0 ? s : c0, b = e < c0 + W1_CAP ? e : c0 + W1_CAP;
+        for (int j = a; j < b; j++) {
+            const double2 wv = win[j - c0];
+            red.add(wv.y, wv.x, normsum);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the window is overwritten by the next chunk)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (t < T && !skip) {
+        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+        double r = NAN; // regridder.py:44,62: rows without entries stay NaN
+        if (e > s) {
+            r = red.fin();
+            if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
+        }
+        out[t_out] = r;
     }
 }
 
@@ -1437,7 +1570,16 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         SideScope side;
         launch_long_rows(false);
     }
-    if (K == 1) {
+    static const bool k1_block_kernel = getenv("XR_APPLY_K1") && !strcmp(getenv("XR_APPLY_K1"), "block"); // A/B switch
+    if (K == 1 && !k1_block_kernel) {
+        // one launch: long-row blocks in front, then one wave per 64 stored rows
+        const int n_long_blocks = csr->has_long ? engine().num_cu / 2 : 0;
+        const bool any_huge = csr->has_long && !(csr->max_row_len >= 0 && csr->max_row_len <= APPLY_WAVE);
+        dim3 grid((unsigned)(div_up(csr->n, AP_BLOCK) + n_long_blocks), 1);
+        XR_LAUNCH("apply_rows1", (k_apply_rows1<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(), csr->indices.get(),
+                  csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(), n_long_blocks, any_huge,
+                  csr->n, csr->m, src, out);
+    } else if (K == 1) {
         dim3 grid(div_up(csr->n, AP_BLOCK), 1);
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
                   csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out,

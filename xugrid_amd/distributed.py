@@ -513,6 +513,40 @@ class ShardedOverlapRegridder:
         return self.backend.to_device(data[:, self.local_faces])
 
     # ---- the exchange step, one tile of variables
+    # ---- measurement of the exchange step (bench.py): device events around every collective
+    def start_timing(self):
+        """From now on every tile's collective is bracketed by two events on the current stream: the first behind the
+        partial-state kernel that feeds it, the second behind the wait for its completion."""
+        self._timing = []
+
+    def stop_timing(self):
+        """-> (milliseconds spent in collectives since ``start_timing``, number of collectives); synchronises."""
+        events, self._timing = getattr(self, "_timing", None) or [], None
+        total = 0.0
+        for a, b in events:
+            b.synchronize()
+            total += a.elapsed_time(b)
+        return total, len(events)
+
+    def exchange_bytes(self, K=1):
+        """Bytes this rank hands to the collective per apply of K variables, and the part of them that leaves the GPU
+        (the slice it owns itself stays local): float64 states of C components."""
+        C = self.backend.n_components(self.method.method_id)
+        if self.exchange == "sparse":
+            rows, own = sum(self._send_counts), self._send_counts[self.rank]
+        else:
+            rows, own = self.t_chunk * self.world, self.t_chunk
+        return {"handed": 8 * C * K * rows, "sent_off_gpu": 8 * C * K * (rows - own)}
+
+    def _mark(self):
+        if getattr(self, "_timing", None) is None:
+            return None
+        import torch
+
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        return ev
+
     def _start_tile(self, src_tile):
         import torch
 
@@ -522,9 +556,10 @@ class ShardedOverlapRegridder:
             # one row of C * kt values per touched target, rows grouped by owner rank
             send = be.partial(self.weights, src_tile, mid, True)  # (T_local, C * kt)
             recv = torch.empty((sum(self._recv_counts), send.shape[1]), dtype=send.dtype, device=send.device)
+            t_begin = self._mark()
             work = self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
                                                input_split_sizes=self._send_counts, group=self.group, async_op=True)
-            return ("sparse", work, recv, send, kt)
+            return ("sparse", work, recv, send, kt, t_begin)
         part = be.partial(self.weights, src_tile, mid, False)  # (C, kt, T_local)
         t_pad = self.t_chunk * W
         nd = be.identity(mid, kt, t_pad)  # dense exchange buffer, the combine step's identity elsewhere
@@ -532,13 +567,16 @@ class ShardedOverlapRegridder:
         C = nd.shape[0]
         # (C, kt, world, chunk) -> (world, C, kt, chunk): slice w of the target axis goes to rank w
         send = nd.view(C, kt, W, self.t_chunk).permute(2, 0, 1, 3).contiguous()
+        t_begin = self._mark()
         out, work, full = _combine(self.dist, send, W, be.combine_is_max(mid), self.group, async_op=True)
-        return ("dense", work, out, (full, send), kt)
+        return ("dense", work, out, (full, send), kt, t_begin)
 
     def _finish_tile(self, pending):
-        kind, work, buf, aux, kt = pending
+        kind, work, buf, aux, kt, t_begin = pending
         if work is not None:
             work.wait()
+        if t_begin is not None:
+            self._timing.append((t_begin, self._mark()))
         be, mid = self.backend, self.method.method_id
         if kind == "sparse":
             return be.reduce_rows(mid, buf, self._recv_indptr, self._recv_order, self.t_chunk, kt)

@@ -101,16 +101,27 @@ class UnstructuredGrid2d:
         voronoi_grid = Ugrid2d(vertices[:, 0], vertices[:, 1], -1, faces)
         return voronoi_grid, vertices, faces, node_to_face_index, node_to_node_map
 
+    def _voronoi_device(self):
+        """The device-resident centroidal Voronoi tessellation of this grid, built once per ``Ugrid2d`` and kept on it
+        (as ``Ugrid2d.celltree`` is, ugrid2d.py:908-921): a second interpolator on the same source -- another target,
+        another tolerance -- skips the pre-step (its mesh, prepared arrays and index included)."""
+        from .. import voronoi
+
+        grid = self.ugrid_topology
+        cached = getattr(grid, "_voronoi_device_cache", None)
+        if cached is None:
+            cached = voronoi.voronoi_topology_device(grid, compact=True)
+            grid._voronoi_device_cache = cached
+        return cached
+
     def barycentric_device(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None,
                            tree_order: bool = False):
         """The barycentric weights as a device CSR (rows = faces of ``other``): everything after the Voronoi
         pre-step -- locate + weights, exterior-vertex replacement, masking, compaction -- runs in HBM.
         ``tree_order``: see ``barycentric``."""
-        from .. import engine, voronoi
+        from .. import engine
 
-        voronoi_mesh, face_index_tail, node_to_node_map = voronoi.voronoi_topology_device(
-            self.ugrid_topology, compact=True
-        )
+        voronoi_mesh, face_index_tail, node_to_node_map = self._voronoi_device()
         return engine.barycentric_csr(
             voronoi_mesh,
             self.ugrid_topology.device_mesh,

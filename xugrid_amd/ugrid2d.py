@@ -38,6 +38,7 @@ class Ugrid2d:
         self.start_index = 0
         self.name = name
         self._celltree = None
+        self._voronoi_device_cache = None  # (UnstructuredGrid2d._voronoi_device)
         self._area = None
         self._centroids = None
         self._edge_node_connectivity = None
