@@ -34,6 +34,13 @@ def small_data(sxy, sf):
     return data7
 
 
+def wide_data(sxy, sf):
+    data = np.concatenate([small_data(sxy, sf), np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), 40 + k, 0.02) for k in range(12)])])
+    data[9] = np.abs(data[9]) + 0.3
+    data[17, ::5] = 0.0
+    return data
+
+
 def small(out_dir):
     sxy, sf = meshgen.triangle_mesh(3000, 0)
     txy, tf = meshgen.triangle_mesh(2503, 1, 30.0, 0.7)  # T not divisible by 2 or 8
@@ -70,6 +77,25 @@ def small(out_dir):
                 results[f"{tag}_{methods[0]}_f32_1d"] = per_rank[0]["f32_1d"]
                 results[f"{tag}_{methods[0]}_n_local"] = np.array([o["n_local"] for o in per_rank])
                 results[f"{tag}_{methods[0]}_max_senders"] = np.array([o["max_senders"] for o in per_rank])
+    # K = 19 variables in tiles of 8 (two full tiles + a short one): the K-tiled partial-state kernel, both layouts
+    data19 = wide_data(sxy, sf)
+
+    def tiled_body(dist, rank):
+        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, HipBackend(0), partition="balanced", method="mean", k_tile=8, dist=dist)
+        out = {}
+        for method in ("mean", "geometric_mean", "minimum", "harmonic_mean"):
+            rg.set_method(method)
+            for exchange in ("sparse", "dense"):
+                rg.exchange = exchange
+                out[f"{method}_{exchange}"] = rg.regrid(data19)
+        rg.set_method("mean")
+        rg.exchange = "sparse"
+        out["f32"] = rg.regrid(data19.astype(np.float32))
+        return out
+
+    per_rank, _ = run_ranks(3, tiled_body)
+    for key, value in per_rank[0].items():
+        results["K19_" + key] = value
     np.savez(os.path.join(out_dir, "loopback_small.npz"), **results)
 
 
@@ -90,7 +116,8 @@ def full(out_dir, n_points):
             out["mean_" + exchange] = rg.regrid(data) if rank == 0 else rg.regrid(data)[:, :1]
         rg.exchange = "sparse"
         rg.set_method("maximum")
-        out["maximum"] = rg.regrid(data) if rank == 0 else None
+        full_max = rg.regrid(data)  # (a collective: every rank takes part)
+        out["maximum"] = full_max if rank == 0 else None
         return out
 
     per_rank, world = run_ranks(W, rank_body)

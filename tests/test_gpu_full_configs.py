@@ -154,7 +154,7 @@ def test_bench_multi_gpu_path_10m_one_rank():
         if "--k" in extra:
             assert line["config"]["variables"] == 256 and line["unit"] == "target cell-variables/s"
             assert line["config"]["per_rank"]["collectives_per_step"] == 8  # 256 variables in tiles of 32
-            assert line["value"] > 1e10
+            assert line["value"] > 2e9  # (one rank: the partial-state kernels + the exchange of 256 variables in 8 tiles)
         else:
             assert line["config"]["target_faces"] > 9_900_000 and "config 4" in line["config"]["workload"]
 

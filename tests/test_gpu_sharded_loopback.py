@@ -64,6 +64,25 @@ def test_every_shard_reducer_with_several_contributions_per_target(hip, oracle, 
             np.testing.assert_allclose(out[f"{tag}_mean_f32_1d"], exp32, rtol=1e-12, equal_nan=True)
 
 
+    # 19 variables in tiles of 8, three ranks: the K-tiled partial-state kernel (whole tiles and a short one)
+    from loopback_worker_gpu import wide_data
+
+    data19 = wide_data(sxy, sf)
+    for method in ("mean", "geometric_mean", "minimum", "harmonic_mean"):
+        expected = oracle.regrid_csr(method, data19, a, s_, indptr, T)
+        for exchange in ("sparse", "dense"):
+            got = out[f"K19_{method}_{exchange}"]
+            assert np.array_equal(np.isnan(got), np.isnan(expected)), (method, exchange)
+            if method == "minimum":
+                assert np.array_equal(got, expected, equal_nan=True)
+            else:
+                np.testing.assert_allclose(got, expected, rtol=1e-9 if method == "harmonic_mean" else 1e-12,
+                                           atol=1e-14 if method != "harmonic_mean" else 0, equal_nan=True,
+                                           err_msg=f"K19 {method} {exchange}")
+    exp32 = oracle.regrid_csr("mean", data19.astype(np.float32), a, s_, indptr, T)
+    np.testing.assert_allclose(out["K19_f32"], exp32, rtol=1e-12, atol=1e-14, equal_nan=True)
+
+
 def test_sharded_w8_at_10m_faces_properties(hip, tmp_path):
     """BASELINE config 4's shape (10M -> 10M triangles, 8 source shards) on one GPU: properties only."""
     _run([str(tmp_path), "full", "5000000"], 3000)

@@ -1455,6 +1455,47 @@ k_apply_partial(int method, const int32_t *__restrict__ indptr, const int32_t *_
 
 // the listed long rows (hull slivers: thousands of entries): one wave per (row, variable), lanes stride the row,
 // butterfly combine of the states (fixed order)
+// KT variables per thread (K >= KT): the row's entries are read once per tile instead of once per variable, the KT
+// gathers of an entry are independent loads in flight, and in the rows layout a thread writes KT consecutive doubles per
+// component (whole 64-byte lines) where the one-variable kernel scatters single doubles C * K apart.  Same additions in
+// the same order per variable.  (One rank, 1M x 1M matrix, 32 variables per call: see DESIGN section 6.)
+template <typename SRC, int KT>
+__global__ void __launch_bounds__(256)
+k_apply_partial_kt(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                   const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
+                   const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool rows_layout, bool skip_long) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    if (t >= T) return;
+    const int s = indptr[t], e = indptr[t + 1];
+    if (skip_long && e - s > APPLY_LONG) return; // reduced by one wave each (k_apply_partial_long)
+    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
+    PartialState st[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; kk++) st[kk] = partial_identity(method);
+    const SRC *src = source + k0 * S;
+    for (int j = s; j < e; j++) {
+        const int64_t col = indices[j];
+        const double w = data[j];
+        double v[KT];
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++) v[kk] = kk < kn ? ld_src(src, (int64_t)kk * S + col) : 0.0;
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++)
+            if (kk < kn) partial_add(method, st[kk], v[kk], w);
+    }
+    const int C = partial_components(method);
+    const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+    for (int c = 0; c < C; c++) {
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++) {
+            if (kk < kn) {
+                if (rows_layout) out[t_out * (C * K) + c * K + k0 + kk] = st[kk].c[c];
+                else out[((int64_t)c * K + k0 + kk) * T + t_out] = st[kk].c[c];
+            }
+        }
+    }
+}
 template <typename SRC>
 __global__ void __launch_bounds__(256)
 k_apply_partial_long(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
@@ -2506,6 +2547,19 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
         XR_REQUIRE(source_dev || csr->m == 0, XR_ERR_INVALID, "xr_apply_partial_dev: NULL source");
         DevBuf<char> permuted;
         source_dev = stored_source(csr, source_dev, source_dtype, K, permuted);
+        constexpr int PKT = 8;
+        static const bool one_var = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
+        if (K >= PKT && !one_var) {
+            dim3 grid(div_up(csr->n, 256), (unsigned)div_up(K, PKT));
+            if (source_dtype == XR_F64)
+                XR_LAUNCH("apply_partial", (k_apply_partial_kt<double, PKT>), grid, dim3(256), 0, method, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                          static_cast<const double *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
+            else
+                XR_LAUNCH("apply_partial", (k_apply_partial_kt<float, PKT>), grid, dim3(256), 0, method, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                          static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
+        } else {
         dim3 grid(div_up(csr->n, 256), (unsigned)K);
         if (source_dtype == XR_F64)
             XR_LAUNCH("apply_partial", k_apply_partial<double>, grid, dim3(256), 0, method, csr->indptr.get(),
@@ -2515,6 +2569,7 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
             XR_LAUNCH("apply_partial", k_apply_partial<float>, grid, dim3(256), 0, method, csr->indptr.get(),
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                       static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
+        }
         if (csr->has_long) {
             dim3 lgrid(64, (unsigned)K);
             if (source_dtype == XR_F64)

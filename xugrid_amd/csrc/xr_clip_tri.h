@@ -128,7 +128,7 @@ __device__ __forceinline__ void tri_stage_generic(const P2 (&v)[TRI_MAXV], int &
 // One stage.  NIN = number of vertices the fast path is unrolled for (3, 4, 5 for the three edges of a triangle
 // clipper: a regular stage adds at most one vertex).  The lane's LDS column holds the current polygon before and
 // after; registers are only a per-stage copy.
-template <int NIN>
+template <int NIN, bool LAST = false>
 __device__ __forceinline__ void tri_stage(int &n, P2 &r, const P2 s, bool &alive, bool &dirty, bool &overflow,
                                           double2 *col, const uint2 *lut) {
     const P2 U{s.x - r.x, s.y - r.y};
@@ -169,7 +169,8 @@ __device__ __forceinline__ void tri_stage(int &n, P2 &r, const P2 s, bool &alive
         if (!irregular) {
             // a crossing point that coincides with a neighbour in the output is a repeated vertex for later stages
             // (x first: the y comparisons only run when some lane has an equal x)
-            if (pt1.x == a1.x || pt1.x == b1.x || pt2.x == a2.x || pt2.x == b2.x || pt1.x == pt2.x)
+            // (the last stage has no successor: a repeated vertex only adds an empty fan triangle to the area)
+            if (!LAST && (pt1.x == a1.x || pt1.x == b1.x || pt2.x == a2.x || pt2.x == b2.x || pt1.x == pt2.x))
                 dirty = p2_eq(pt1, a1) || p2_eq(pt1, b1) || p2_eq(pt2, a2) || p2_eq(pt2, b2) || p2_eq(pt1, pt2);
             // compaction in the oracle's emission order; vertices outside land in the trash slot
             *tri_slot(col, e.x & 0xffu) = make_double2(v[0].x, v[0].y);
@@ -215,7 +216,7 @@ __device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv
     P2 r = sv[2];
     tri_stage<3>(n, r, sv[0], alive, dirty, overflow, col, lut);
     tri_stage<4>(n, r, sv[1], alive, dirty, overflow, col, lut);
-    tri_stage<5>(n, r, sv[2], alive, dirty, overflow, col, lut);
+    tri_stage<5, true>(n, r, sv[2], alive, dirty, overflow, col, lut);
     if (overflow) return TRI_AREA_OVERFLOW;
     double area = 0.0;
     if (alive) {

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <functional>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -150,6 +151,10 @@ void dev_call_done(); // end of a *_dev entry point: stream_sync() unless the ca
 // between the caller's pages and the staging buffer (page faults of a fresh result array included) while the DMA
 // engine moves the previous piece -- 2-3x the rate of a plain hipMemcpy on pageable memory.  Synchronous.
 void h2d_big(void *dst, const void *src, size_t bytes);
+// pieces of a host array through the pinned staging buffers, filled by the host thread pool while the previous piece is on
+// its way (fill(pinned_dst, first_byte_of_the_device_data, n_bytes)); does NOT wait for the last DMA
+void h2d_staged(void *dst, size_t bytes, const std::function<void(char *, size_t, size_t)> &fill);
+void parallel_ranges(size_t n, size_t align, const std::function<void(size_t, size_t)> &fn);
 void d2h_big(void *dst, const void *src, size_t bytes);
 template <typename T> T read_scalar(const T *dev) {
     T v;

@@ -15,6 +15,8 @@
 
 #include <memory>
 
+#include <atomic>
+
 #include "xr_objects.h"
 
 namespace xr {
@@ -767,10 +769,14 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
                "xr_mesh_create: mesh exceeds the int32 index range");
     XR_REQUIRE((node_xy && faces) || n_face == 0, XR_ERR_INVALID, "xr_mesh_create: NULL arrays");
     engine();
-    // ingest on the device: the raw connectivity (int32 or int64, caller's fill value) is uploaded as it is; one kernel
-    // maps the fill value to -1, narrows to int32 and validates (every face has at least three nodes, every node id
-    // is inside [0, n_node)); the first offending face is reported
+    // Ingest on the way to the device.  Both arrays go through the pinned staging buffers in pieces, filled by the host
+    // thread pool while the previous piece is in flight (pageable numpy arrays handed to hipMemcpy move at a third of the
+    // link rate).  The connectivity is NARROWED while it is copied: fill value -> -1, int64 -> int32 (half the bytes over
+    // PCIe), validated (every face has at least three nodes, every node id is inside [0, n_node)); the first offending
+    // face is reported.  Nothing waits for the last DMA: the arrays are consumed, later work is stream-ordered behind it.
+    // (XR_INGEST=device: raw upload + k_ingest_faces on the device, as until round 3 -- measurement switch.)
     const size_t cnt = (size_t)n_face * (size_t)n_max_node;
+    static const bool device_ingest = getenv("XR_INGEST") && !strcmp(getenv("XR_INGEST"), "device");
     xr_mesh *mesh = new xr_mesh();
     try {
         mesh->n_node = n_node;
@@ -778,8 +784,50 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
         mesh->m = (int)n_max_node;
         mesh->node_xy.alloc((size_t)n_node * 2);
         mesh->faces_raw.alloc(cnt);
-        h2d_big(mesh->node_xy.get(), node_xy, sizeof(double) * 2 * (size_t)n_node);
-        if (cnt > 0) {
+        if (device_ingest) {
+            h2d_big(mesh->node_xy.get(), node_xy, sizeof(double) * 2 * (size_t)n_node);
+        } else {
+            const char *xy_bytes = reinterpret_cast<const char *>(node_xy);
+            h2d_staged(mesh->node_xy.get(), sizeof(double) * 2 * (size_t)n_node, [=](char *dst, size_t off, size_t n) {
+                parallel_ranges(n, 64, [=](size_t b, size_t e) { memcpy(dst + b, xy_bytes + off + b, e - b); });
+            });
+        }
+        if (cnt > 0 && !device_ingest) {
+            std::atomic<int64_t> bad_short(INT64_MAX), bad_node(INT64_MAX);
+            const int m = (int)n_max_node;
+            auto narrow = [&](auto *raw) {
+                h2d_staged(mesh->faces_raw.get(), cnt * sizeof(int32_t), [&, raw](char *dst, size_t off, size_t n) {
+                    int32_t *out32 = reinterpret_cast<int32_t *>(dst);
+                    const size_t k0 = off / sizeof(int32_t), nk = n / sizeof(int32_t);
+                    parallel_ranges(nk, 16, [&, raw, out32, k0](size_t b, size_t e) {
+                        int64_t first_short = INT64_MAX, first_node = INT64_MAX;
+                        for (size_t i = b; i < e; i++) {
+                            const size_t k = k0 + i;
+                            const int64_t v = (int64_t)raw[k];
+                            if (v == fill_value || v == -1) {
+                                if ((int)(k % (size_t)m) < 3 && first_short == INT64_MAX) first_short = (int64_t)(k / (size_t)m);
+                                out32[i] = -1;
+                            } else {
+                                if ((v < 0 || v >= n_node) && first_node == INT64_MAX) first_node = (int64_t)(k / (size_t)m);
+                                out32[i] = (int32_t)v;
+                            }
+                        }
+                        int64_t cur = bad_short.load();
+                        while (first_short < cur && !bad_short.compare_exchange_weak(cur, first_short)) {}
+                        cur = bad_node.load();
+                        while (first_node < cur && !bad_node.compare_exchange_weak(cur, first_node)) {}
+                    });
+                });
+            };
+            if (faces_itemsize == 8) narrow(static_cast<const int64_t *>(faces));
+            else narrow(static_cast<const int32_t *>(faces));
+            if (bad_short.load() != INT64_MAX || bad_node.load() != INT64_MAX) stream_sync(); // (the handle is dropped below)
+            XR_REQUIRE(bad_short.load() == INT64_MAX, XR_ERR_INVALID, "xr_mesh_create: face %lld has fewer than 3 nodes",
+                       (long long)bad_short.load());
+            XR_REQUIRE(bad_node.load() == INT64_MAX, XR_ERR_INVALID,
+                       "xr_mesh_create: face %lld references a node outside [0,%lld)", (long long)bad_node.load(),
+                       (long long)n_node);
+        } else if (cnt > 0) {
             DevBuf<char> raw(cnt * (size_t)faces_itemsize);
             DevBuf<int64_t> err(2); // [0] first face with fewer than 3 nodes, [1] first face with a node id out of range
             const int64_t none[2] = {INT64_MAX, INT64_MAX};

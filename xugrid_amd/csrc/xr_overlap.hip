@@ -1229,13 +1229,23 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     int32_t *blk_surv = ctl.get() + 16 + 2 * (size_t)grid, *blk_rows = blk_surv + grid;
     DevBuf<int32_t> blk_base(2 * (size_t)grid); // first stored row / CSR base of every hardware block (k_assemble_scan)
     // XR_ASSEMBLE_SCAN=0: the assembly finds its bases by the decoupled look-back instead (measurement / fallback switch)
+    // (default 2: every assembly block sums the counts of the blocks in front of it itself; 1: a one-block scan kernel
+    // between clip and assembly, as until round 3)
     const char *scan_env = getenv("XR_ASSEMBLE_SCAN");
-    const bool scan_bases = !(scan_env && atoi(scan_env) == 0);
+    const int scan_mode = scan_env ? atoi(scan_env) : 2;
+    const bool scan_bases = scan_mode != 0;
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T), pending((size_t)T), nnz_row((size_t)T),
         slot_face((size_t)T), big_indptr((size_t)T + 1);
     DevBuf<uint8_t> is_big((size_t)T);
     DevBuf<int2> block_seg((size_t)n_blocks);
-    DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)reg_capacity);
+    // XR_CLIP_COMPACT=1: the clip writes only its survivors, compacted in place over the queue (16 B per survivor at the
+    // front of every 64-pair stretch), and k_assemble_packed reads only those.  Measured on the 1M x 1M benchmark (round 3,
+    // A/B on one box): the HBM bytes drop as intended, but the assembly becomes three passes of dependent loads (stretch
+    // count -> survivors) with returning LDS atomics -- 0.066 -> 0.087 ms -- and the clip pays 2 us for the ranking:
+    // step 0.582 -> 0.603 ms.  Kept as a switch, off by default.
+    const bool compact = scan_bases && getenv("XR_CLIP_COMPACT") && atoi(getenv("XR_CLIP_COMPACT")) == 1;
+    DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)(compact ? 1 : reg_capacity));
+    DevBuf<int32_t> wave_surv((size_t)(compact ? reg_capacity / 64 + 1 : 1));
     DevBuf<double> cand_area((size_t)reg_capacity);
     csr->n_long.alloc(1);
     csr->row_order.alloc((size_t)T);
@@ -1293,21 +1303,31 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, blk_surv);
+                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr);
         else
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 0>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, (int32_t *)nullptr);
-        if (scan_bases)
+        if (scan_mode == 1)
             XR_LAUNCH("assemble_scan", k_assemble_scan, dim3(1), dim3(1024), 0, blk_rows, blk_surv, (int64_t)n_blocks, (int)grid,
                       remap, blk_base.get(), blk_base.get() + grid, fc, csr->indptr.get());
+        if (compact)
+            XR_LAUNCH("assemble", k_assemble_packed, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
+                      cand_src.get(), cand_area.get(), wave_surv.get(), block_seg.get(), is_big.get(), tree_area, relative, tile,
+                      csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, status, csr->indptr.get(),
+                      csr->indices.get(), csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, remap,
+                      scan_mode == 1 ? blk_base.get() : (const int32_t *)nullptr,
+                      scan_mode == 1 ? blk_base.get() + grid : (const int32_t *)nullptr,
+                      scan_mode == 2 ? blk_rows : (const int32_t *)nullptr, scan_mode == 2 ? blk_surv : (const int32_t *)nullptr);
+        else
         XR_LAUNCH("assemble", k_assemble, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
                   cand_off.get(), cand_count.get(), block_seg.get(), is_big.get(), cand_area.get(), cand_sid.get(),
                   tree_area, relative, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc,
                   status, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
-                  csr->long_rows.get(), cap, remap, scan_bases ? blk_base.get() : (const int32_t *)nullptr,
-                  scan_bases ? blk_base.get() + grid : (const int32_t *)nullptr);
+                  csr->long_rows.get(), cap, remap, scan_mode == 1 ? blk_base.get() : (const int32_t *)nullptr,
+                  scan_mode == 1 ? blk_base.get() + grid : (const int32_t *)nullptr,
+                  scan_mode == 2 ? blk_rows : (const int32_t *)nullptr, scan_mode == 2 ? blk_surv : (const int32_t *)nullptr);
         side_join();
         XR_LAUNCH("place_big", k_place_big, dim3(64), dim3(256), 0, ctl.get() + 2, slot_face.get(), big_indptr.get(),
                   big_indices.get(), big_data.get(), T, query->qo_perm(), query->qo_bbox(), tile,
@@ -1343,7 +1363,11 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     // (the query side on the side stream next to the tree side was measured: the prepare kernels are bandwidth bound and
     // just slow each other down, 0.684 -> 0.706 ms per step)
-    mesh_prepare(tree, false); // the tree side only needs its records (built from the raw mesh)
+    // the tree side only needs its records (built from the raw mesh).  Its statistics go to the host through a one-block
+    // kernel that ends with writes to pinned memory (~20 us): on the side stream as well, beside the preparation of the
+    // query mesh, which is what the host waits behind anyway (XR_STATS_INLINE=1: in line, measurement hook)
+    static const bool stats_inline = getenv("XR_STATS_INLINE") && atoi(getenv("XR_STATS_INLINE")) != 0;
+    mesh_prepare(tree, false, /*stats_on_side=*/!stats_inline);
     mesh_prepare(query, true, /*stats_on_side=*/true); // (its statistics are first read by mesh_query_order below)
     mesh_build_index(tree);
     mesh_query_order(query);

@@ -142,12 +142,15 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/,
 template <int BLOCK, int COUNT>
 __global__ void __launch_bounds__(BLOCK)
 k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
-                 const int32_t *__restrict__ rec_face, const int32_t *__restrict__ cand_tgt,
-                 const int32_t *__restrict__ cand_src, const int32_t *__restrict__ n_cand_dev, int64_t capacity,
+                 const int32_t *__restrict__ rec_face, const int32_t *cand_tgt /* (rewritten in place when compacting) */,
+                 const int32_t *cand_src, const int32_t *__restrict__ n_cand_dev, int64_t capacity,
                  double *__restrict__ cand_area, int32_t *__restrict__ cand_sid, int32_t *__restrict__ error_bits,
                  int32_t *__restrict__ nnz_row /* optional: survivors per target face, counted by atomics */,
                  const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */,
-                 int32_t *__restrict__ blk_surv = nullptr /* optional: survivors per BLOCK of 256 target faces (k_assemble_scan) */) {
+                 int32_t *__restrict__ blk_surv = nullptr /* optional: survivors per BLOCK of 256 target faces (k_assemble_scan) */,
+                 int32_t *__restrict__ wave_surv = nullptr /* COUNT == 1: survivors per 64-pair stretch; the output is then
+                 COMPACTED: the survivors of stretch w are written to the front of the stretch, IN PLACE over the queue --
+                 (target face, caller's source id, area) in cand_tgt / cand_src / cand_area at w * 64 + rank */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
     __shared__ uint2 sh_lut[TRI_LUT];
@@ -201,7 +204,22 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
         load_idx(slot + stride, n_tq, n_s);
         const double area = tri_clip_area(tv, sv, col, sh_lut, active);
         const int tq_now = active ? cur_tq : -1;
-        if (active) {
+        if (COUNT == 1 && wave_surv) {
+            // Only the pairs that survive (60 % on the benchmark) are written, packed at the front of the wave's own
+            // 64-pair stretch of the queue: 16 bytes per survivor into lines the wave has just read, no holes for the
+            // assembly to fetch.  (All 64 inputs of the stretch were loaded an iteration ago: overwriting is safe.)
+            overflow = overflow || (active && area == TRI_AREA_OVERFLOW);
+            const bool keep = active && area > 0;
+            const unsigned long long surv = __ballot(keep);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(surv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)surv, 0));
+            const int64_t w0 = c & ~(int64_t)63;
+            if (keep) {
+                cand_area[w0 + rank] = area;
+                const_cast<int32_t *>(cand_tgt)[w0 + rank] = cur_tq;
+                const_cast<int32_t *>(cand_src)[w0 + rank] = sid;
+            }
+            if ((tid & 63) == 0 && w0 < n_cand) wave_surv[w0 >> 6] = __popcll(surv);
+        } else if (active) {
             overflow = overflow || area == TRI_AREA_OVERFLOW;
             cand_area[c] = area;
             cand_sid[c] = area > 0 ? sid : 0x7fffffff;
@@ -311,7 +329,8 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
            int32_t *__restrict__ tile_key, FusedCounters *__restrict__ counters, unsigned long long *__restrict__ status,
            int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ row_order,
            int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap,
-           const int32_t *__restrict__ base_rows = nullptr, const int32_t *__restrict__ base_nnz = nullptr) {
+           const int32_t *__restrict__ base_rows = nullptr, const int32_t *__restrict__ base_nnz = nullptr,
+           const int32_t *__restrict__ blk_rows = nullptr, const int32_t *__restrict__ blk_surv = nullptr) {
     __shared__ int32_t sh_stage[SLOTS * FB];
     __shared__ int32_t sh_nnz[FB];     // survivors of the face (LDS atomics)
     __shared__ uint16_t sh_lo[FB];     // offset of the face's pairs inside the stretch
@@ -367,7 +386,29 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
     const int rowidx = block_excl_scan(regular ? 1 : 0, sh_wave, &block_rows);
     sh_rowoff[tid] = (uint16_t)rowoff;
     const int b = (int)blockIdx.x, n_chain = (int)gridDim.x;
-    if (base_nnz) { // scanned beforehand (k_assemble_scan)
+    if (blk_surv) {
+        // The search left the regular faces, the clip the surviving pairs of every block of FB target faces: this block
+        // sums the (rows, entries) of the blocks in front of it itself -- in the order the assembly assigns stored rows,
+        // i.e. hardware block order.  A few thousand pairs of words that all blocks read from L2 (b / 256 loads per thread,
+        // issued together, while the block's own entry loads are in flight): no scan kernel, no launch in between.
+        const int64_t per_xcd = (n_blocks + 7) >> 3;
+        long long acc = 0;
+        for (int hb = tid; hb < b; hb += FB) {
+            const int64_t plb = remap ? (int64_t)(hb & 7) * per_xcd + (hb >> 3) : hb;
+            if (plb < n_blocks) acc += ((long long)blk_rows[plb] << 31) | (long long)blk_surv[plb];
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        __shared__ long long sh_part[FWAVES];
+        if ((tid & 63) == 0) sh_part[tid >> 6] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            long long tot = 0;
+#pragma unroll
+            for (int w = 0; w < FWAVES; w++) tot += sh_part[w];
+            sh_base = tot;
+        }
+    } else if (base_nnz) { // scanned beforehand (k_assemble_scan)
         if (tid == 0) sh_base = ((long long)base_rows[b] << 31) | (long long)base_nnz[b];
     } else if (tid < 64) {
         const long long packed = lookback_exclusive(status, b, ((long long)block_rows << 31) | (long long)block_nnz, tid, &counters->error);
@@ -376,7 +417,7 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
     __syncthreads();
     if (sh_base < 0) return; // aborted (the host falls back)
     const long long base = sh_base & 0x7fffffffll, row_base = sh_base >> 31;
-    if (!base_nnz && b == n_chain - 1 && tid == 0) {
+    if (!base_nnz && b == n_chain - 1 && tid == 0) { // (look-back or own prefix: the last block of the chain knows the totals)
         const long long entries = base + block_nnz, rows = row_base + block_rows;
         counters->p_regular = (int32_t)entries; // entries of all regular rows
         counters->rows_regular = (int32_t)rows;
@@ -419,6 +460,169 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
             if (pos < csr_capacity) {
                 indices[pos] = s;
                 data[pos] = relative ? area[u] / src_area[s] : area[u];
+            } else {
+                overflow_cap = true;
+            }
+        }
+    }
+    if (overflow_cap) atomicOr(&counters->error, 4);
+}
+
+// The same assembly on the COMPACTED clip output (k_clip_tri_queue with wave_surv): the block's stretch of the queue is a
+// run of 64-pair wave stretches, each holding its survivors -- (target face, source id, area) -- packed at its front.  The
+// block's four waves take the wave stretches in turn, 64 lanes on (up to) 64 survivors: nothing of the 40 % of the pairs
+// that clipped to nothing is fetched.  Three passes over the survivors (the second and third hit L2): count per row ->
+// [scan of the rows, base of the block] -> source ids into per-row lists in LDS (order of arrival) -> rank of every
+// survivor among its row's list = its position in the row, ascending in the source id; written with its area.
+// (A wave stretch at either end of the block's stretch is shared with the neighbouring block: each takes its own rows.)
+__global__ void __launch_bounds__(FB, 2)
+k_assemble_packed(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm, int64_t n_query,
+                  const int32_t *__restrict__ surv_tgt, const int32_t *__restrict__ surv_sid,
+                  const double *__restrict__ surv_area, const int32_t *__restrict__ wave_surv,
+                  const int2 *__restrict__ block_seg, const uint8_t *__restrict__ is_big,
+                  const double *__restrict__ src_area, bool relative, MortonParams tile, int32_t *__restrict__ tile_key,
+                  FusedCounters *__restrict__ counters, unsigned long long *__restrict__ status,
+                  int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
+                  int32_t *__restrict__ row_order, int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap,
+                  const int32_t *__restrict__ base_rows, const int32_t *__restrict__ base_nnz,
+                  const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ blk_surv) {
+    __shared__ int32_t sh_list[SLOTS * FB]; // source ids, row by row (a row's list: [sh_rowoff[row], + sh_nnz[row]))
+    __shared__ int32_t sh_nnz[FB];          // survivors of the face
+    __shared__ int32_t sh_cur[FB];          // fill cursor of the face's list
+    __shared__ uint16_t sh_rowoff[FB];      // offset of the face's row inside the block
+    __shared__ int32_t sh_wave[FWAVES];
+    __shared__ long long sh_part[FWAVES];
+    __shared__ long long sh_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n_blocks = (n_query + FB - 1) / FB;
+    const int64_t lb = xcd_block(n_blocks, remap); // (blocks beyond n_blocks carry no faces but stay in the chain)
+    const bool valid_block = lb < n_blocks;
+    sh_nnz[tid] = 0;
+    sh_cur[tid] = 0;
+    const int64_t t0 = lb * FB;
+    const int64_t t = t0 + tid;
+    const bool in_range = valid_block && t < n_query;
+    const int2 seg = valid_block ? block_seg[lb] : make_int2(0, 0);
+    const int total = seg.y;
+    const bool regular = in_range && !is_big[t];
+    // wave stretches that overlap the block's stretch of the queue
+    const int wc0 = seg.x >> 6, wc1 = total > 0 ? (seg.x + total - 1) >> 6 : wc0 - 1;
+    __syncthreads();
+    // ---- pass 1: survivors per row (four wave stretches in flight per wave)
+    for (int wc = wc0 + wave; wc <= wc1; wc += 4 * FWAVES) {
+        int n[4], row[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = wc + u * FWAVES;
+            n[u] = w <= wc1 ? wave_surv[w] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = wc + u * FWAVES;
+            row[u] = lane < n[u] ? surv_tgt[(int64_t)w * 64 + lane] - (int)t0 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (row[u] >= 0 && row[u] < FB) atomicAdd(&sh_nnz[row[u]], 1);
+    }
+    __syncthreads();
+    const int my_nnz = regular ? sh_nnz[tid] : 0;
+    int block_nnz = 0, block_rows = 0;
+    const int rowoff = block_excl_scan(my_nnz, sh_wave, &block_nnz);
+    const int rowidx = block_excl_scan(regular ? 1 : 0, sh_wave, &block_rows);
+    sh_rowoff[tid] = (uint16_t)rowoff;
+    const int b = (int)blockIdx.x, n_chain = (int)gridDim.x;
+    if (blk_surv) { // own prefix over the blocks in front (see k_assemble)
+        const int64_t per_xcd = (n_blocks + 7) >> 3;
+        long long acc = 0;
+        for (int hb = tid; hb < b; hb += FB) {
+            const int64_t plb = remap ? (int64_t)(hb & 7) * per_xcd + (hb >> 3) : hb;
+            if (plb < n_blocks) acc += ((long long)blk_rows[plb] << 31) | (long long)blk_surv[plb];
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+        if (lane == 0) sh_part[wave] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            long long tot = 0;
+#pragma unroll
+            for (int w = 0; w < FWAVES; w++) tot += sh_part[w];
+            sh_base = tot;
+        }
+    } else if (base_nnz) {
+        if (tid == 0) sh_base = ((long long)base_rows[b] << 31) | (long long)base_nnz[b];
+    } else if (tid < 64) {
+        const long long packed = lookback_exclusive(status, b, ((long long)block_rows << 31) | (long long)block_nnz, tid, &counters->error);
+        if (tid == 0) sh_base = packed;
+    }
+    __syncthreads();
+    if (sh_base < 0) return; // aborted (the host falls back)
+    const long long base = sh_base & 0x7fffffffll, row_base = sh_base >> 31;
+    if (!base_nnz && b == n_chain - 1 && tid == 0) {
+        const long long entries = base + block_nnz, rows = row_base + block_rows;
+        counters->p_regular = (int32_t)entries; // entries of all regular rows
+        counters->rows_regular = (int32_t)rows;
+        indptr[rows] = (int32_t)entries;        // (= indptr[T] when there are no big faces)
+    }
+    if (regular) {
+        const long long r = row_base + rowidx; // stored row of the face
+        indptr[r] = (int32_t)(base + rowoff);
+        row_order[r] = q_perm ? q_perm[t] : (int32_t)t;
+        if (tile_key) {
+            const int64_t mid = (t & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
+            tile_key[r] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
+        }
+        if (my_nnz > XR_APPLY_LONG_ROW) {
+            apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
+            atomicMax(&counters->max_row, my_nnz); // (long rows only: the apply asks whether any row exceeds its wave kernel)
+        }
+    }
+    // ---- pass 2: the rows' source ids into their lists (order of arrival)
+    for (int wc = wc0 + wave; wc <= wc1; wc += 4 * FWAVES) {
+        int n[4], row[4], sid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = wc + u * FWAVES;
+            n[u] = w <= wc1 ? wave_surv[w] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = (int64_t)(wc + u * FWAVES) * 64 + lane;
+            row[u] = lane < n[u] ? surv_tgt[i] - (int)t0 : -1;
+            sid[u] = lane < n[u] ? surv_sid[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (row[u] >= 0 && row[u] < FB) sh_list[sh_rowoff[row[u]] + atomicAdd(&sh_cur[row[u]], 1)] = sid[u];
+    }
+    __syncthreads();
+    // ---- pass 3: rank within the row, final position
+    bool overflow_cap = false;
+    for (int wc = wc0 + wave; wc <= wc1; wc += 4 * FWAVES) {
+        int n[4], row[4], sid[4];
+        double area[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int w = wc + u * FWAVES;
+            n[u] = w <= wc1 ? wave_surv[w] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int64_t i = (int64_t)(wc + u * FWAVES) * 64 + lane;
+            row[u] = lane < n[u] ? surv_tgt[i] - (int)t0 : -1;
+            sid[u] = lane < n[u] ? surv_sid[i] : 0;
+            area[u] = lane < n[u] ? surv_area[i] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (row[u] < 0 || row[u] >= FB) continue;
+            const int a0 = sh_rowoff[row[u]], a1 = a0 + sh_nnz[row[u]];
+            int rank = 0;
+            for (int j = a0; j < a1; j++) rank += sh_list[j] < sid[u] ? 1 : 0;
+            const long long pos = base + a0 + rank;
+            if (pos < csr_capacity) {
+                indices[pos] = sid[u];
+                data[pos] = relative ? area[u] / src_area[sid[u]] : area[u];
             } else {
                 overflow_cap = true;
             }
