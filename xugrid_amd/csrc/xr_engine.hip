@@ -261,7 +261,8 @@ void pool_trim() {
 }
 
 static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
-static constexpr size_t BIG_COPY_BYTES = 2 * STAGE_BYTES; // copies of this size and more are staged
+static constexpr size_t BIG_COPY_BYTES = (size_t)1 << 20; // copies of this size and more go through the pinned staging buffers
+static constexpr size_t SMALL_COPY_BYTES = BIG_COPY_BYTES;
 
 void h2d(void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
@@ -389,16 +390,19 @@ static void parallel_memcpy(char *dst, const char *src, size_t n) {
     parallel_ranges(n, 64, [=](size_t b, size_t e) { memcpy(dst + b, src + b, e - b); });
 }
 
-// Host array -> device through the pinned staging buffers in pieces of UP_PIECE bytes OF DEVICE DATA, double-buffered: the
+// Host array -> device through the pinned staging buffers in pieces (4 or 16 MiB OF DEVICE DATA), double-buffered: the
 // pool threads fill piece i + 1 (fill(dst_pinned, first_byte, n_bytes): a copy, or a narrowing conversion of the caller's
 // array) while the DMA engine moves piece i.  Returns without waiting for the last DMA: the caller's array has been
 // consumed, everything later on the stream is ordered behind the copies.
-static constexpr size_t UP_PIECE = (size_t)4 << 20;
+static inline size_t up_piece(size_t bytes) { // small pieces start the pipeline early; big copies amortise the per-piece cost
+    return bytes >= ((size_t)128 << 20) ? ((size_t)16 << 20) : ((size_t)4 << 20);
+}
 void h2d_staged(void *dst, size_t bytes, const std::function<void(char *, size_t, size_t)> &fill) {
     if (!bytes) return;
     Lane &sl = stage_init();
     hipStream_t st = launch_stream();
     // the two 64 MiB staging buffers as a ring of pieces
+    const size_t UP_PIECE = up_piece(bytes);
     const size_t per_buf = STAGE_BYTES / UP_PIECE;
     size_t off = 0;
     for (size_t k = 0; off < bytes; k++) {
@@ -415,50 +419,49 @@ void h2d_staged(void *dst, size_t bytes, const std::function<void(char *, size_t
 }
 
 void h2d_big(void *dst, const void *src, size_t bytes) {
-    if (bytes < BIG_COPY_BYTES) {
+    if (bytes < SMALL_COPY_BYTES) {
         XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, launch_stream()));
         XR_HIP(hipStreamSynchronize(launch_stream()));
         return;
     }
-    Lane &sl = stage_init();
-    char **g_stage = sl.stage;
-    hipEvent_t *g_stage_ev = sl.stage_ev;
-    hipStream_t st = launch_stream();
-    size_t off = 0;
-    for (int i = 0; off < bytes; i ^= 1) {
-        const size_t c = std::min(STAGE_BYTES, bytes - off);
-        XR_HIP(hipEventSynchronize(g_stage_ev[i])); // the DMA that last read this staging buffer is done
-        parallel_memcpy(g_stage[i], static_cast<const char *>(src) + off, c);
-        XR_HIP(hipMemcpyAsync(static_cast<char *>(dst) + off, g_stage[i], c, hipMemcpyHostToDevice, st));
-        XR_HIP(hipEventRecord(g_stage_ev[i], st));
-        off += c;
-    }
-    XR_HIP(hipStreamSynchronize(st));
+    // pieces through the pinned staging buffers, filled by the host thread pool while the previous piece is in flight
+    const char *bytes_src = static_cast<const char *>(src);
+    h2d_staged(dst, bytes, [=](char *pinned, size_t off, size_t n) { parallel_memcpy(pinned, bytes_src + off, n); });
+    XR_HIP(hipStreamSynchronize(launch_stream()));
 }
 
+// Device -> pageable host array: DMA into the pinned staging buffers in pieces, each copied out by the
+// host thread pool while the next pieces are on their way (D2H_DEPTH pieces in flight, one event per piece).
+static constexpr int D2H_DEPTH = 8;
 void d2h_big(void *dst, const void *src, size_t bytes) {
-    if (bytes < BIG_COPY_BYTES) {
+    if (bytes < SMALL_COPY_BYTES) {
         XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, launch_stream()));
         XR_HIP(hipStreamSynchronize(launch_stream()));
         return;
     }
     Lane &sl = stage_init();
-    char **g_stage = sl.stage;
-    hipEvent_t *g_stage_ev = sl.stage_ev;
+    static thread_local hipEvent_t piece_ev[D2H_DEPTH] = {};
+    if (!piece_ev[0])
+        for (int i = 0; i < D2H_DEPTH; i++) XR_HIP(hipEventCreateWithFlags(&piece_ev[i], hipEventDisableTiming));
     hipStream_t st = launch_stream();
-    const size_t n_piece = (bytes + STAGE_BYTES - 1) / STAGE_BYTES;
-    auto piece = [&](size_t k) { return std::min(STAGE_BYTES, bytes - k * STAGE_BYTES); };
-    XR_HIP(hipMemcpyAsync(g_stage[0], src, piece(0), hipMemcpyDeviceToHost, st));
-    XR_HIP(hipEventRecord(g_stage_ev[0], st));
+    // (the staging buffers may still be read by un-awaited uploads of h2d_staged: same stream, so the DMAs below are
+    // ordered behind them)
+    const size_t UP_PIECE = up_piece(bytes), per_buf = STAGE_BYTES / UP_PIECE; // (16 or 4 pieces per buffer: 8 slots fit)
+    const size_t n_piece = (bytes + UP_PIECE - 1) / UP_PIECE;
+    auto piece_bytes = [&](size_t k) { return std::min(UP_PIECE, bytes - k * UP_PIECE); };
+    auto pinned_of = [&](size_t k) {
+        const size_t slot = k % D2H_DEPTH;
+        return sl.stage[slot / per_buf] + (slot % per_buf) * UP_PIECE;
+    };
+    auto issue = [&](size_t k) {
+        XR_HIP(hipMemcpyAsync(pinned_of(k), static_cast<const char *>(src) + k * UP_PIECE, piece_bytes(k), hipMemcpyDeviceToHost, st));
+        XR_HIP(hipEventRecord(piece_ev[k % D2H_DEPTH], st));
+    };
+    for (size_t k = 0; k < n_piece && k < (size_t)D2H_DEPTH; k++) issue(k);
     for (size_t k = 0; k < n_piece; k++) {
-        const int i = (int)(k & 1);
-        if (k + 1 < n_piece) { // next piece into the other buffer while this one is copied out
-            XR_HIP(hipMemcpyAsync(g_stage[i ^ 1], static_cast<const char *>(src) + (k + 1) * STAGE_BYTES, piece(k + 1),
-                                  hipMemcpyDeviceToHost, st));
-            XR_HIP(hipEventRecord(g_stage_ev[i ^ 1], st));
-        }
-        XR_HIP(hipEventSynchronize(g_stage_ev[i]));
-        parallel_memcpy(static_cast<char *>(dst) + k * STAGE_BYTES, g_stage[i], piece(k));
+        XR_HIP(hipEventSynchronize(piece_ev[k % D2H_DEPTH]));
+        parallel_memcpy(static_cast<char *>(dst) + k * UP_PIECE, pinned_of(k), piece_bytes(k));
+        if (k + D2H_DEPTH < n_piece) issue(k + D2H_DEPTH); // (its slot has just been copied out)
     }
     XR_HIP(hipStreamSynchronize(st));
 }

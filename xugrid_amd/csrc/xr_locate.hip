@@ -313,9 +313,10 @@ k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
 // replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) on the point's own row, then the
 // masking of unstructured.py:188-191 (points outside the source grid; weights > 0), counted per point.
 // Same statement order as oracle/xr_oracle.c:xo_replace_interpolated_weights.
+template <typename FI> // int64_t: a normalised table (tree order); int32_t: the mesh's own connectivity (caller's order)
 __global__ void __launch_bounds__(256)
 k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__ weights, int m,
-                 const int64_t *__restrict__ faces_ccw, const double *__restrict__ vxy,
+                 const FI *__restrict__ faces_ccw, const double *__restrict__ vxy,
                  const int64_t *__restrict__ node_to_node_map, int64_t threshold,
                  const uint8_t *__restrict__ inside, int64_t n, int32_t *__restrict__ count) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -324,7 +325,7 @@ k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__
     int c = 0;
     if (f >= 0 && inside[i]) { // (a point outside the source grid keeps no weight, unstructured.py:189-190)
         double *w = weights + i;
-        const int64_t *face = faces_ccw + f * m;
+        const FI *face = faces_ccw + f * m;
         int len = 0;
         while (len < m && face[len] >= 0) len++; // (-1 fill behind the cell's corners)
         for (int j = 0; j < len; j++) {
@@ -356,9 +357,10 @@ k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__
 // (one thread writing its own 4- and 8-byte pieces cost 1.45 GB of HBM writes for 300 MB of entries, PMC).
 static constexpr int FILL_STAGE = 3072; // entries one block stages (36 KiB); fuller blocks write directly
 
+template <typename FI>
 __global__ void __launch_bounds__(256)
 k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict__ weights, int m,
-            const int64_t *__restrict__ faces_ccw, const int64_t *__restrict__ vertex_face,
+            const FI *__restrict__ faces_ccw, const int64_t *__restrict__ vertex_face,
             const int32_t *__restrict__ indptr, int64_t n, int32_t *__restrict__ indices,
             double *__restrict__ data) {
     __shared__ int32_t sh_idx[FILL_STAGE];
@@ -370,7 +372,7 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
     if (i < n) {
         int pos = indptr[i];
         if (indptr[i + 1] != pos) {
-            const int64_t *face = faces_ccw + face_of_point[i] * m;
+            const FI *face = faces_ccw + face_of_point[i] * m;
             const double *w = weights + i;
             for (int j = 0; j < m && face[j] >= 0; j++) {
                 const double wj = w[(int64_t)j * n];
@@ -439,7 +441,7 @@ __global__ void k_iota_i64(int64_t *__restrict__ p, int64_t n) {
 
 static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
     if (tolerance >= 0) return tolerance;
-    mesh_read_stats(mesh);
+    mesh_read_stats(mesh, /*need_exact=*/true); // (the largest bbox diagonal over ALL faces)
     return 1e-12 * mesh->h_stats[6]; // ugridbase.py:1165-1170
 }
 
@@ -575,7 +577,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             DevBuf<double> pts((size_t)n * 2), w((size_t)n * m);
             if (query) mesh_centroids_dev(query, pts.get());
             else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
-            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)voronoi->n_face * m), vface((size_t)nv),
+            // the vertex table the weight slots are paired with: the caller's order as the reference does
+            // (unstructured.py:175,193) = the mesh's own int32 connectivity, read as it is; or -- tree_order -- the tree's
+            // counter-clockwise-normalised copy, materialised as a table first
+            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)(reference_order ? 1 : voronoi->n_face * m)), vface((size_t)nv),
                 n2n((size_t)(n_extra > 0 ? 2 * n_extra : 1));
             DevBuf<uint8_t> inside((size_t)n);
             DevBuf<int32_t> count((size_t)n);
@@ -584,24 +589,29 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             if (nv > n_identity)
                 h2d(vface.get() + n_identity, vertex_face, sizeof(int64_t) * (size_t)(nv - n_identity));
             if (n_extra > 0) h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_extra);
-            // the vertex table the weight slots are paired with: the tree's own counter-clockwise order, or -- to reproduce
-            // the reference's indexing (unstructured.py:175,193) also for the cells the tree reversed -- the caller's
-            mesh_faces_ccw_dev(voronoi, faces_ccw.get(), reference_order);
+            if (!reference_order) mesh_faces_ccw_dev(voronoi, faces_ccw.get(), false);
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
                       voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get());
             XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
                       source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
                       source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
-            XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                      faces_ccw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
+            if (reference_order)
+                XR_LAUNCH("bary_fix_count", k_bary_fix_count<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                          voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
+            else
+                XR_LAUNCH("bary_fix_count", k_bary_fix_count<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                          faces_ccw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
             exclusive_scan_i32(count.get(), csr->indptr.get(), n);
             const int64_t nnz = read_scalar(csr->indptr.get() + n);
             csr->nnz = nnz;
             csr->indices.alloc((size_t)nnz);
             csr->data.alloc((size_t)nnz);
-            if (nnz > 0)
-                XR_LAUNCH("bary_fill", k_bary_fill, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+            if (nnz > 0 && reference_order)
+                XR_LAUNCH("bary_fill", k_bary_fill<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                          voronoi->faces_raw.get(), vface.get(), csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+            else if (nnz > 0)
+                XR_LAUNCH("bary_fill", k_bary_fill<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                           faces_ccw.get(), vface.get(), csr->indptr.get(), n, csr->indices.get(), csr->data.get());
             stream_sync();
         }
@@ -664,7 +674,7 @@ int xr_replace_interpolated_weights(const double *vertices, int64_t n_vertex, co
     h2d(fc.get(), faces, sizeof(int64_t) * (size_t)n_face * m);
     h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_map);
     XR_HIP(hipMemsetAsync(inside.get(), 1, (size_t)n, launch_stream()));
-    XR_LAUNCH("bary_fix_count", k_bary_fix_count, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), (int)m,
+    XR_LAUNCH("bary_fix_count", k_bary_fix_count<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), (int)m,
               fc.get(), vxy.get(), n2n.get(), n_vertex - n_map, inside.get(), n, count.get());
     d2h(cm.data(), w.get(), sizeof(double) * cm.size());
     stream_sync();

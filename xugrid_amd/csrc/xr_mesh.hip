@@ -162,6 +162,75 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
     }
 }
 
+// Statistics of a mesh that is only ever the TREE, from a SAMPLE of its faces: the index only needs the bounds (exact:
+// taken from the node array, a coalesced stream) and the mean bbox extent (to choose the cell size: every `stride`-th block
+// of 256 faces is looked at).  Block b reads faces [b * stride * 256, + 256) and its slice of the nodes; partials in the
+// layout of k_prepare_faces with [7] = faces sampled.  Nothing the RESULTS depend on comes from the sample: the grid is an
+// accelerator (any cell size gives the same pairs), the number of levels is then derived from the domain size, and the one
+// statistic with a meaning outside the index -- the largest bbox diagonal behind the default tolerance -- is recomputed over
+// all faces when somebody asks for it (mesh_read_stats(need_exact)).
+template <int MC>
+__global__ void __launch_bounds__(PREP_BLOCK)
+k_sample_stats(const double *__restrict__ node_xy, int64_t n_node, const int32_t *__restrict__ faces_raw, int64_t n_face,
+               int m_rt, int stride, double *__restrict__ partials) {
+    constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
+    const int m = MC > 0 ? MC : m_rt;
+    const int64_t f = ((int64_t)blockIdx.x * stride) * PREP_BLOCK + threadIdx.x;
+    double ext = 0.0, diag = 0.0, cnt = 0.0;
+    if (f < n_face) {
+        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        bool open = true;
+#pragma unroll
+        for (int j = 0; j < MA; j++) {
+            if (j < m) {
+                const int v = faces_raw[f * m + j];
+                open = open && !(j >= 3 && v < 0);
+                if (open) {
+                    const P2 p = load_p2(node_xy, v);
+                    xmin = fmin(xmin, p.x);
+                    xmax = fmax(xmax, p.x);
+                    ymin = fmin(ymin, p.y);
+                    ymax = fmax(ymax, p.y);
+                }
+            }
+        }
+        const double dx = xmax - xmin, dy = ymax - ymin;
+        ext = fmax(dx, dy);
+        diag = sqrt(dx * dx + dy * dy);
+        cnt = 1.0;
+    }
+    // this block's slice of the node array
+    double nx0 = INFINITY, nx1 = -INFINITY, ny0 = INFINITY, ny1 = -INFINITY;
+    const int64_t per = (n_node + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * per, i1 = i0 + per < n_node ? i0 + per : n_node;
+    const double2 *nodes = reinterpret_cast<const double2 *>(node_xy);
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += PREP_BLOCK) {
+        const double2 p = nodes[i];
+        nx0 = fmin(nx0, p.x);
+        nx1 = fmax(nx1, p.x);
+        ny0 = fmin(ny0, p.y);
+        ny1 = fmax(ny1, p.y);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double lds[8][PREP_BLOCK / 64];
+    double r0 = wave_min(nx0), r1 = wave_max(nx1), r2 = wave_min(ny0), r3 = wave_max(ny1);
+    double r4 = wave_sum(ext), r5 = wave_max(ext), r6 = wave_max(diag), r7 = wave_sum(cnt);
+    if (lane == 0) {
+        lds[0][wave] = r0; lds[1][wave] = r1; lds[2][wave] = r2;
+        lds[3][wave] = r3; lds[4][wave] = r4; lds[5][wave] = r5; lds[6][wave] = r6; lds[7][wave] = r7;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a0 = lds[0][0], a1 = lds[1][0], a2 = lds[2][0], a3 = lds[3][0], a4 = lds[4][0], a5 = lds[5][0], a6 = lds[6][0], a7 = lds[7][0];
+        for (int w = 1; w < PREP_BLOCK / 64; w++) {
+            a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
+            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]); a7 += lds[7][w];
+        }
+        double *p = partials + (int64_t)blockIdx.x * 8;
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6; p[7] = a7;
+    }
+}
+
 // ingest of the caller's connectivity (xr_mesh_create): fill -> -1, narrow to int32, validate
 template <typename I>
 __global__ void __launch_bounds__(256)
@@ -272,12 +341,51 @@ void mesh_face_coords(xr_mesh *mesh) {
     mesh->fxy_valid = true;
 }
 
-void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side) {
+static constexpr int64_t SAMPLE_MIN_FACES = 1 << 17; // smaller meshes: the full pass costs a launch either way
+static constexpr int SAMPLE_STRIDE = 8;              // every 8th block of 256 faces
+
+void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_sampled) {
     // two depths: statistics only (want_fxy = false: the mesh is used as a tree) or statistics + the caller-order
-    // len / bbox / vertex blocks a query needs.  A mesh prepared light and later used as a query is prepared again.
-    if (mesh->prepared && (mesh->has_attrs || !want_fxy)) return;
+    // len / bbox / vertex blocks a query needs.  A mesh prepared light and later used as a query is prepared again;
+    // so is one whose statistics come from a sample when exact ones are asked for.
+    if (mesh->prepared && (mesh->has_attrs || !want_fxy) && (!mesh->stats_sampled || allow_sampled)) return;
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
+    static const bool sampling_off = getenv("XR_STATS_SAMPLE") && atoi(getenv("XR_STATS_SAMPLE")) == 0; // measurement switch
+    if (!want_fxy && allow_sampled && !sampling_off && F >= SAMPLE_MIN_FACES && !mesh->has_attrs) {
+        mesh->stats.alloc(8);
+        const int64_t nb_all = (F + PREP_BLOCK - 1) / PREP_BLOCK;
+        const int64_t nb = (nb_all + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
+        DevBuf<double> partials((size_t)nb * 8);
+        dim3 grid((unsigned)nb), block(PREP_BLOCK);
+        if (m == 3)
+            XR_LAUNCH("sample_stats", k_sample_stats<3>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
+                      F, m, SAMPLE_STRIDE, partials.get());
+        else if (m == 4)
+            XR_LAUNCH("sample_stats", k_sample_stats<4>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
+                      F, m, SAMPLE_STRIDE, partials.get());
+        else
+            XR_LAUNCH("sample_stats", k_sample_stats<0>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
+                      F, m, SAMPLE_STRIDE, partials.get());
+        if (!mesh->stats_host) {
+            void *p = nullptr;
+            XR_HIP(hipHostMalloc(&p, sizeof(double) * 8, hipHostMallocCoherent));
+            mesh->stats_host = static_cast<double *>(p);
+            XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
+        }
+        {
+            std::unique_ptr<SideScope> side;
+            if (stats_on_side) side.reset(new SideScope);
+            XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
+                      mesh->stats_host);
+            XR_HIP(hipEventRecord(mesh->stats_event, launch_stream()));
+        }
+        mesh->prepared = true;
+        mesh->stats_valid = false;
+        mesh->stats_sampled = true;
+        return;
+    }
+    mesh->stats_sampled = false;
     const bool dense_fxy = want_fxy && !mesh->ragged(); // (ragged: flat blocks, filled on demand by mesh_face_coords)
     if (want_fxy) {
         if (dense_fxy) mesh->fxy.alloc((size_t)F * m * 2);
@@ -343,8 +451,9 @@ const double *mesh_area(xr_mesh *mesh) {
     return mesh->area.get();
 }
 
-void mesh_read_stats(xr_mesh *mesh) {
-    mesh_prepare(mesh, false);
+void mesh_read_stats(xr_mesh *mesh, bool need_exact) {
+    if (!mesh->prepared) mesh_prepare(mesh, false);
+    else if (need_exact && mesh->stats_sampled) mesh_prepare(mesh, mesh->has_attrs, false, false); // over all faces this time
     if (mesh->stats_valid) return;
     XR_HIP(hipEventSynchronize(mesh->stats_event));
     for (int i = 0; i < 8; i++) mesh->h_stats[i] = mesh->stats_host[i];
@@ -591,7 +700,11 @@ void mesh_build_index(xr_mesh *mesh) {
     const int m = mesh->m;
     XR_REQUIRE(F < (int64_t)1 << 31, XR_ERR_LIMIT, "mesh has too many faces for int32 indices");
     const double xmin = mesh->h_stats[0], xmax = mesh->h_stats[1], ymin = mesh->h_stats[2], ymax = mesh->h_stats[3];
-    const double sum_ext = mesh->h_stats[4], max_ext = mesh->h_stats[5];
+    // (sampled statistics: [7] = faces looked at; the largest extent is then only bounded by the domain)
+    const bool sampled = mesh->stats_sampled;
+    const double n_ext = sampled ? std::max(mesh->h_stats[7], 1.0) : (double)F;
+    const double sum_ext = mesh->h_stats[4] * ((double)F / n_ext);
+    const double max_ext = sampled ? std::max(xmax - xmin, ymax - ymin) : mesh->h_stats[5];
     GridParams g{};
     double W = F > 0 ? xmax - xmin : 1.0, H = F > 0 ? ymax - ymin : 1.0;
     if (!(W > 0)) W = 1.0;

@@ -31,6 +31,7 @@ struct xr_mesh {
     xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order (mesh_area, on demand)
     xr::DevBuf<double> stats; // [8] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal,sum_jump (device)
     bool stats_valid = false;
+    bool stats_sampled = false; // h_stats[4..6] come from a sample of the faces ([7] = faces sampled): enough to size a grid, NOT for the default tolerance
     double h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // the reduction kernel also deposits the statistics in pinned host memory; the host waits on an event
     // recorded right behind it, so kernels queued later (the other mesh's prepare) keep the GPU busy meanwhile
@@ -136,13 +137,13 @@ struct xr_outer {
 };
 
 namespace xr {
-void mesh_prepare(xr_mesh *mesh, bool want_fxy = true, bool stats_on_side = false); // stats_on_side: the reduction of the
+void mesh_prepare(xr_mesh *mesh, bool want_fxy = true, bool stats_on_side = false, bool allow_sampled = false); // stats_on_side: the reduction of the
     // statistics (only the HOST reads them) leaves the main stream: kernels queued behind the prepare pass do not wait for it
 const double *mesh_area(xr_mesh *mesh); // connectivity.area in the caller's face order (computed on first use)
 void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex blocks exist
 void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
-void mesh_read_stats(xr_mesh *mesh);
+void mesh_read_stats(xr_mesh *mesh, bool need_exact = false); // need_exact: statistics over ALL faces (sampled ones are redone)
 void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev);    // connectivity.centroids into device memory [n_face*2]
 void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order = false); // CCW-normalised (or the caller's) connectivity [n_face*m]
 } // namespace xr

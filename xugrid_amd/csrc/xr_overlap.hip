@@ -1367,7 +1367,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     // kernel that ends with writes to pinned memory (~20 us): on the side stream as well, beside the preparation of the
     // query mesh, which is what the host waits behind anyway (XR_STATS_INLINE=1: in line, measurement hook)
     static const bool stats_inline = getenv("XR_STATS_INLINE") && atoi(getenv("XR_STATS_INLINE")) != 0;
-    mesh_prepare(tree, false, /*stats_on_side=*/!stats_inline);
+    mesh_prepare(tree, false, /*stats_on_side=*/!stats_inline, /*allow_sampled=*/true); // (bounds exact, mean extent sampled)
     mesh_prepare(query, true, /*stats_on_side=*/true); // (its statistics are first read by mesh_query_order below)
     mesh_build_index(tree);
     mesh_query_order(query);
