@@ -79,6 +79,8 @@ def kernel_model_bytes(S, T, Ns, Nt, C, P, Ms=3, Mt=3):
         "clip_tri": 8 * C + vt * T + vs * S + 4 * S + 12 * C,
         "assemble": 16 * C + 8 * T + 8 * T + 12 * P + 4 * T,
         "apply_stream": 12 * P + 4 * (T + 1) + 4 * T + 8 * (S + T),
+        "apply_rows1": 12 * P + 4 * (T + 1) + 4 * T + 8 * (S + T),   # (the one-launch K = 1 apply: same bytes)
+        "sample_stats": (4 * Ms * S + 16 * Ns) // 8 + 16 * Ns,        # tree side: every 8th block of faces + all nodes
     }
 
 
@@ -286,7 +288,8 @@ def run_single(args):
                  "big_rank": "k_big_rank", "big_scan": "k_big_scan", "row_fill_long": "k_row_fill_long",
                  "place_big": "k_place_big", "publish": "k_publish_all", "scan_reduce": "k_scan_reduce",
                  "scan_apply": "k_scan_apply_fused", "apply_stream": "k_apply_stream", "apply_wave": "k_apply_wave",
-                 "apply_long": "k_apply_long"}
+                 "apply_long": "k_apply_long", "apply_rows1": "k_apply_rows1", "sample_stats": "k_sample_stats",
+                 "prepare_stats": "k_prepare_faces"}
     if pmc:
         def per_step_bytes(name):
             e = pmc.get("k_clip_tri_queue@65536" if name == "clip_big" else pmc_names.get(name, name))
@@ -595,7 +598,8 @@ def run_multi(args):
     import torch.distributed as dist
 
     from xugrid_amd import meshgen
-    from xugrid_amd.distributed import HipBackend, ShardedOverlapRegridder, init_process_group_from_env
+    from xugrid_amd.distributed import (HipBackend, ShardedOverlapRegridder, TargetPartitionedRegridder,
+                                        init_process_group_from_env)
 
     init_process_group_from_env("nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -631,11 +635,21 @@ def run_multi(args):
         phase = 2.0 * np.pi * torch.arange(K, device=backend.device, dtype=torch.float64)[:, None] / K
         return (torch.sin(6.0 * np.pi * cen[None, :, 0] + phase) * torch.cos(4.0 * np.pi * cen[None, :, 1])).contiguous()
 
+    # K > 1 (cached weights, many variables): by default the TARGETS are partitioned -- every rank owns a slice of the rows
+    # with all their entries, applies with the single-GPU many-variable kernels and needs NO data-path collective (SURVEY
+    # 8e "not shardable over sources": the same layout serves any reducer).  Sharding the SOURCES for an apply-only job
+    # moves C x K x T partial states through the exchange, more bytes than the apply itself reads (--k-mode source keeps
+    # that path measurable: one rank, K = 256: 19.7 ms per step against 1.8 ms).
+    target_partitioned = K > 1 and args.k_mode == "target"
+
     def measure(exchange):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=exchange,
-                                     k_tile=args.k_tile)
+        if target_partitioned:
+            rg = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method="mean")
+        else:
+            rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=exchange,
+                                         k_tile=args.k_tile)
         torch.cuda.synchronize()
         setup_s = time.perf_counter() - t0
         local = local_block(rg)
@@ -660,11 +674,14 @@ def run_multi(args):
         elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=backend.device)
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         # the exchange step by itself: the same steps again with device events around every collective (untimed leg)
-        rg.start_timing()
-        for _ in range(args.steps):
-            step()
-        exch_ms, n_coll = rg.stop_timing()
-        eb = rg.exchange_bytes(K)
+        if target_partitioned:
+            exch_ms, n_coll, eb = 0.0, 0, {"sent_off_gpu": 0}
+        else:
+            rg.start_timing()
+            for _ in range(args.steps):
+                step()
+            exch_ms, n_coll = rg.stop_timing()
+            eb = rg.exchange_bytes(K)
         per_rank = torch.tensor([mine / args.steps * 1e3, exch_ms / args.steps, float(eb["sent_off_gpu"]),
                                  float(rg.local_faces.size), float(rg.local_targets.size), float(rg.weights.nnz)],
                                 dtype=torch.float64, device=backend.device)
@@ -687,7 +704,10 @@ def run_multi(args):
 
     rg, step, elapsed, stats, setup_s = measure(args.exchange)
     other = "dense" if args.exchange == "sparse" else "sparse"
-    _, _, elapsed_other, stats_other, _ = measure(other)
+    if target_partitioned:
+        elapsed_other, stats_other = elapsed, stats  # (no exchange step: nothing to compare)
+    else:
+        _, _, elapsed_other, stats_other, _ = measure(other)
     # rank 0's kernels of a few more steps (hipEvents around every launch): roofline of its dominant kernel
     roofline = None
     from xugrid_amd import engine as E
@@ -723,8 +743,9 @@ def run_multi(args):
         units = T * K
         if K > 1:
             metric = f"target cell-variables regridded/s (cached OverlapRegridder weights, K={K} stacked variables, mean apply)"
-            workload = (f"BASELINE config 5 at {world} GPU(s) ({mesh_kind}): {S} source -> {T} target triangles, cached sharded "
-                        f"weights, K={K} variables exchanged in tiles of {args.k_tile}")
+            workload = (f"BASELINE config 5 at {world} GPU(s) ({mesh_kind}): {S} source -> {T} target triangles, cached weights, "
+                        + (f"K={K} variables; target rows partitioned over the ranks (complete rows on their owner: no collective)"
+                           if target_partitioned else f"source-sharded, K={K} variables exchanged in tiles of {args.k_tile}"))
             unit = "target cell-variables/s"
         elif args.strong:
             metric = "target cells regridded/s (OverlapRegridder 10M->10M tri, source faces sharded, weights + mean apply)"
@@ -755,11 +776,13 @@ def run_multi(args):
                 "target_faces": T,
                 "variables": K,
                 "nnz": stats["nnz"],
-                "parallelism": f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
-                + exchange_name[args.exchange],
+                "parallelism": (f"target rows partitioned over {world} GPUs (contiguous slices + the source faces near them), "
+                                "no data-path collective" if target_partitioned else
+                                f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
+                                + exchange_name[args.exchange]),
                 "rccl_ranks": world,
                 "collective_backend": dist.get_backend(),
-                "exchange": args.exchange,
+                "exchange": "none" if target_partitioned else args.exchange,
                 "exchange_ms": stats["exchange_ms"],
                 "exchange_ms_note": "device events around every collective of a step (behind the partial-state kernel that feeds "
                 "it / behind the wait for it), max over ranks; measured on a further, untimed set of steps",
@@ -801,6 +824,8 @@ def main():
     ap.add_argument("--k", type=int, default=1,
                     help="multi-GPU: K > 1 = BASELINE config 5 at N GPUs (cached sharded weights, K stacked variables per step)")
     ap.add_argument("--k-tile", type=int, default=32, help="variables per collective of the K-tiled exchange")
+    ap.add_argument("--k-mode", default="target", choices=["target", "source"],
+                    help="K > 1: partition the target rows (no collective; default) or shard the source faces (exchange of partial states)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.force_dist:

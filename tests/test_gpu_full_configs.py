@@ -143,18 +143,25 @@ def test_bench_multi_gpu_path_10m_one_rank():
         assert line["n_gpus"] == 1 and line["config"]["target_faces"] > 9_900_000
         assert line["value"] > 1e8 and line["config"]["nnz"] > 40_000_000
         _check_scale_fields(line, exchange, 1)
-    # the two other workloads of the SCALE line: config 4 as a strong-scaling pair, config 5 (K = 256) on cached weights
-    for extra, scaling in ((["--strong", "--strong-points", "5000000"], "strong"), (["--k", "256", "--points", "500000", "--no-delaunay"], "weak")):
+    # the other workloads of the SCALE line: config 4 as a strong-scaling pair; config 5 (K = 256) on cached weights --
+    # target rows partitioned (default: no collective) and source-sharded (partial states exchanged in 8 tiles of 32)
+    runs = ((["--strong", "--strong-points", "5000000"], "strong", "sparse"),
+            (["--k", "256", "--points", "500000", "--no-delaunay"], "weak", "none"),
+            (["--k", "256", "--k-mode", "source", "--points", "500000", "--no-delaunay"], "weak", "sparse"))
+    for extra, scaling, exchange in runs:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--steps", "3", "--warmup", "1"] + extra
         proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
         assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
         line = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
         assert line["scaling"] == scaling and line["n_gpus"] == 1
-        _check_scale_fields(line, "sparse", 1)
+        _check_scale_fields(line, exchange, 1)
         if "--k" in extra:
             assert line["config"]["variables"] == 256 and line["unit"] == "target cell-variables/s"
-            assert line["config"]["per_rank"]["collectives_per_step"] == 8  # 256 variables in tiles of 32
-            assert line["value"] > 2e9  # (one rank: the partial-state kernels + the exchange of 256 variables in 8 tiles)
+            if exchange == "none":
+                assert line["config"]["per_rank"]["collectives_per_step"] == 0 and line["value"] > 5e10
+            else:
+                assert line["config"]["per_rank"]["collectives_per_step"] == 8  # 256 variables in tiles of 32
+                assert line["value"] > 2e9
         else:
             assert line["config"]["target_faces"] > 9_900_000 and "config 4" in line["config"]["workload"]
 
@@ -164,13 +171,16 @@ def _check_scale_fields(line, exchange, world):
     spread of the ranks' step times, the size of the RCCL group."""
     cfg = line["config"]
     assert cfg["exchange"] == exchange and cfg["rccl_ranks"] == world and cfg["collective_backend"] == "nccl"
-    assert 0.0 < cfg["exchange_ms"] < line["ms_per_step"]
+    if exchange == "none":
+        assert cfg["exchange_ms"] == 0.0
+    else:
+        assert 0.0 < cfg["exchange_ms"] < line["ms_per_step"]
     pr = cfg["per_rank"]
     assert len(pr["step_ms_per_rank"]["all"]) == world
     assert 0 < pr["step_ms_per_rank"]["min"] <= pr["step_ms_per_rank"]["max"] <= line["ms_per_step"] * 1.001
     assert pr["exchange_bytes_sent_per_rank"]["max"] >= 0  # (one rank: everything stays on the GPU)
     assert pr["source_faces_per_rank"]["min"] > 0 and pr["target_faces_per_rank"]["min"] > 0
-    assert cfg["other_exchange"]["exchange_ms"] > 0
+    assert cfg["other_exchange"]["exchange_ms"] > 0 or exchange == "none"
     assert line["roofline"]["frac"] > 0
 
 

@@ -226,6 +226,39 @@ def test_overlap_graded_mesh_many_levels(hip, oracle):
     assert_overlap_parity(hip, oracle, txy, tf, pts, sf)
 
 
+def test_overlap_sampled_tree_statistics(hip, oracle):
+    """From 131072 source faces on, the tree side's grid is sized from a SAMPLE of the faces (every 8th block of 256;
+    bounds exact from the nodes, number of levels from the domain).  A graded mesh whose sampled blocks misrepresent the
+    mean -- fine faces first, coarse ones last, the few huge ones in blocks the sample skips -- must give the oracle's
+    pairs and areas all the same (the grid is an accelerator only), and the default tolerance of a later locate on the
+    same handle must still be the one of the exact statistics (largest bbox diagonal over ALL faces)."""
+    from scipy.spatial import Delaunay
+
+    rng = np.random.default_rng(19)
+    n = 80_000
+    r = 10.0 ** rng.uniform(-3, 0, n)
+    th = rng.uniform(0, 2 * np.pi, n)
+    pts = np.column_stack([r * np.cos(th), r * np.sin(th)])
+    sf = Delaunay(pts).simplices.astype(np.int64)
+    # faces ordered by size: the strided sample sees a biased mix, the largest faces sit in the last (partly unsampled) blocks
+    p = pts[sf]
+    ext = np.maximum(np.ptp(p[:, :, 0], axis=1), np.ptp(p[:, :, 1], axis=1))
+    sf = sf[np.argsort(ext, kind="stable")]
+    assert sf.shape[0] >= 131072
+    txy, tf = meshgen.triangle_mesh(20_000, 4, 15.0, 1.6)
+    txy = txy - 0.5
+    csr, _ = assert_overlap_parity(hip, oracle, pts, sf, txy, tf)
+    assert csr.nnz > tf.shape[0]
+    # the same handle as a locate tree afterwards: tolerance from exact statistics, results as on a fresh handle
+    E = hip.engine
+    ms = E.DeviceMesh(pts, sf)
+    ms.overlap(E.DeviceMesh(txy, tf))
+    q = rng.uniform(-0.8, 0.8, (50_000, 2))
+    q[:200] = pts[sf[:200, 0]]  # points ON vertices: decided by the tolerance
+    assert np.array_equal(ms.locate_points(q), E.DeviceMesh(pts, sf).locate_points(q))
+    assert np.array_equal(ms.locate_points(q), oracle.CellTree2d(pts, sf).locate_points(q))
+
+
 def test_overlap_degenerate_inputs(hip, oracle):
     sxy, sf = meshgen.triangle_mesh(100, 1)
     # disjoint meshes -> empty matrix, apply gives NaN everywhere

@@ -1496,6 +1496,93 @@ k_apply_partial_kt(int method, const int32_t *__restrict__ indptr, const int32_t
         }
     }
 }
+// The same for the ROWS layout (T, C * K) of the sparse exchange.  There a row's states lie C * K doubles apart from the
+// next row's: a thread that stores its own doubles makes every store instruction of the wave touch 64 different lines, 8
+// bytes each (measured: 2.2 ms for 32 variables x 1M rows, one rank -- 7 x what the bytes cost).  The block therefore
+// parks its 128 rows x C x KT states in LDS and writes them out with 8 lanes per (row, component): whole 64-byte lines.
+template <typename SRC, int KT>
+__global__ void __launch_bounds__(128)
+k_apply_partial_rows(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                     const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
+                     const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool skip_long) {
+    static_assert(KT == 8, "one 64-byte line per (row, component)");
+    __shared__ double sh_state[128][4 * KT + 1];
+    __shared__ int32_t sh_tout[128];
+    const int64_t t = (int64_t)blockIdx.x * 128 + threadIdx.x;
+    const int64_t k0 = (int64_t)blockIdx.y * KT;
+    const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
+    const int C = partial_components(method);
+    int s = 0, e = 0;
+    bool mine = false;
+    if (t < T) {
+        s = indptr[t];
+        e = indptr[t + 1];
+        mine = !(skip_long && e - s > APPLY_LONG); // (long rows: one wave each, k_apply_partial_long)
+    }
+    PartialState st[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; kk++) st[kk] = partial_identity(method);
+    const SRC *src = source + k0 * S;
+    if (mine) {
+        for (int j = s; j < e; j++) {
+            const int64_t col = indices[j];
+            const double w = data[j];
+            double v[KT];
+#pragma unroll
+            for (int kk = 0; kk < KT; kk++) v[kk] = kk < kn ? ld_src(src, (int64_t)kk * S + col) : 0.0;
+#pragma unroll
+            for (int kk = 0; kk < KT; kk++)
+                if (kk < kn) partial_add(method, st[kk], v[kk], w);
+        }
+    }
+    sh_tout[threadIdx.x] = mine ? (int32_t)(row_order ? row_order[t] : t) : -1;
+    for (int c = 0; c < C; c++)
+#pragma unroll
+        for (int kk = 0; kk < KT; kk++) sh_state[threadIdx.x][c * KT + kk] = st[kk].c[c];
+    __syncthreads();
+    // 8 lanes per (row, component) line
+    const int n_lines = 128 * C;
+    for (int line = threadIdx.x >> 3; line < n_lines; line += 16) {
+        const int r = line / C, c = line - r * C, kk = threadIdx.x & 7;
+        const int t_out = sh_tout[r];
+        if (t_out >= 0 && kk < kn) out[(int64_t)t_out * (C * K) + (int64_t)c * K + k0 + kk] = sh_state[r][c * KT + kk];
+    }
+}
+
+// Combination + finalisation of the received rows (sparse exchange), coalesced both ways: a block takes 64 owned targets
+// x a chunk of 32 variables; a thread reads the states of ITS (target, variable) with the variable running fastest across
+// the lanes -- 256-byte runs of the (R, C * K) rows -- and the finalised values cross LDS so that the (K, n_targets)
+// output is written with the target running fastest.  (One thread per output element read one double per 64-byte line
+// and line 8 times over: 1.4 ms for 32 variables x 1M targets.)
+__global__ void __launch_bounds__(256)
+k_reduce_partial_rows_t(int method, const double *__restrict__ rows, const int64_t *__restrict__ indptr,
+                        const int64_t *__restrict__ order, int64_t n_targets, int64_t K, double *__restrict__ out) {
+    constexpr int TT = 64, KC = 32;
+    __shared__ double sh_val[KC][TT + 1];
+    const int C = partial_components(method);
+    const int64_t t0 = (int64_t)blockIdx.x * TT;
+    for (int64_t kc0 = (int64_t)blockIdx.y * KC; kc0 < K; kc0 += (int64_t)gridDim.y * KC) {
+        const int kk = threadIdx.x & (KC - 1);
+        const int64_t k = kc0 + kk;
+        for (int tl = threadIdx.x / KC; tl < TT; tl += 256 / KC) {
+            const int64_t t = t0 + tl;
+            double v = NAN;
+            if (t < n_targets && k < K) {
+                PartialState st = partial_identity(method);
+                for (int64_t j = indptr[t]; j < indptr[t + 1]; j++) partial_combine(method, st, rows + order[j] * (C * K) + k, K, C);
+                v = partial_finalize(method, st);
+            }
+            sh_val[kk][tl] = v;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < KC * TT; q += 256) {
+            const int kq = q / TT, tl = q - kq * TT;
+            if (t0 + tl < n_targets && kc0 + kq < K) out[(kc0 + kq) * n_targets + t0 + tl] = sh_val[kq][tl];
+        }
+        __syncthreads();
+    }
+}
+
 template <typename SRC>
 __global__ void __launch_bounds__(256)
 k_apply_partial_long(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
@@ -2549,7 +2636,17 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
         source_dev = stored_source(csr, source_dev, source_dtype, K, permuted);
         constexpr int PKT = 8;
         static const bool one_var = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
-        if (K >= PKT && !one_var) {
+        if (K >= PKT && !one_var && rows_layout != 0) {
+            dim3 grid(div_up(csr->n, 128), (unsigned)div_up(K, PKT));
+            if (source_dtype == XR_F64)
+                XR_LAUNCH("apply_partial", (k_apply_partial_rows<double, PKT>), grid, dim3(128), 0, method, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                          static_cast<const double *>(source_dev), K, out_dev, csr->has_long);
+            else
+                XR_LAUNCH("apply_partial", (k_apply_partial_rows<float, PKT>), grid, dim3(128), 0, method, csr->indptr.get(),
+                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
+                          static_cast<const float *>(source_dev), K, out_dev, csr->has_long);
+        } else if (K >= PKT && !one_var) {
             dim3 grid(div_up(csr->n, 256), (unsigned)div_up(K, PKT));
             if (source_dtype == XR_F64)
                 XR_LAUNCH("apply_partial", (k_apply_partial_kt<double, PKT>), grid, dim3(256), 0, method, csr->indptr.get(),
@@ -2619,8 +2716,13 @@ int xr_reduce_partial_rows_dev(int method, const double *rows_dev, const int64_t
     XR_REQUIRE(n_targets >= 0 && K >= 0, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: negative size");
     if (n_targets * K > 0) {
         XR_REQUIRE(indptr_dev && out_dev, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: NULL argument");
-        XR_LAUNCH("reduce_partial_rows", k_reduce_partial_rows, dim3(div_up(n_targets * K, 256)), dim3(256), 0, method,
-                  rows_dev, indptr_dev, order_dev, n_targets, K, out_dev);
+        static const bool plain = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
+        if (K >= 8 && !plain)
+            XR_LAUNCH("reduce_partial_rows", k_reduce_partial_rows_t, dim3(div_up(n_targets, 64), (unsigned)std::min<int64_t>(div_up(K, 32), 64)),
+                      dim3(256), 0, method, rows_dev, indptr_dev, order_dev, n_targets, K, out_dev);
+        else
+            XR_LAUNCH("reduce_partial_rows", k_reduce_partial_rows, dim3(div_up(n_targets * K, 256)), dim3(256), 0, method,
+                      rows_dev, indptr_dev, order_dev, n_targets, K, out_dev);
     }
     dev_call_done();
     XR_API_END
