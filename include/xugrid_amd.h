@@ -199,6 +199,19 @@ int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                             double tolerance, int64_t n_identity, const int64_t *vertex_face_tail,
                             const int64_t *node_to_node_map, int64_t n_extra, int tree_order, xr_csr **out);
 
+/* The source-side half of UnstructuredGrid2d.barycentric -- the query points (points, or the face centroids of `query`,
+ * unstructured.py:147) and `grid.locate_points(points) == -1` with the default tolerance (:188-190) -- as a device-resident
+ * handle, ENQUEUED WITHOUT WAITING: it needs nothing of the Voronoi tessellation, so a caller that starts it first overlaps
+ * its kernels (index of the source grid, centroids, point location: 0.7 ms at 1M faces / 4M points) with the host part of
+ * the Voronoi pre-step (the O(boundary) cells, 0.5 ms).  xr_barycentric_csr_points is xr_barycentric_csr_tail on such a
+ * handle (same stream: ordered behind it). */
+typedef struct xr_points xr_points;
+int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, xr_points **out);
+int xr_points_destroy(xr_points *points);
+int xr_barycentric_csr_points(xr_mesh *voronoi, xr_mesh *source, xr_points *points, double tolerance, int64_t n_identity,
+                              const int64_t *vertex_face_tail, const int64_t *node_to_node_map, int64_t n_extra,
+                              int tree_order, xr_csr **out);
+
 /* ---- Voronoi pre-step of BarycentricInterpolator (xugrid/ugrid/voronoi.py:330-458 as called from
  * xugrid/regrid/unstructured.py:151-165: add_exterior, add_vertices, skip_concave) ---------------------
  * xr_voronoi_create does the O(n) part on the device: the node -> face inversion

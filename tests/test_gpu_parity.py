@@ -400,6 +400,72 @@ def test_apply_long_rows(hip, oracle):
     assert np.array_equal(tr.apply(src, 0), csr.apply(src, 0), equal_nan=True)
 
 
+def test_apply_single_variable_one_launch(hip, oracle, monkeypatch):
+    """K = 1 takes the one-launch kernel (wave-private staging windows, the long rows by blocks in front of the same
+    grid): every reducer, float64 and float32 sources, on a matrix with empty rows, short rows, rows of 33 ... 2048
+    entries (lane groups / waves) and rows beyond 2048 entries (a block each); windows that overflow their 320 entries;
+    an uploaded copy of the same matrix (no stored row order) gives the same numbers; so does the block-wide kernel it
+    replaced (XR_APPLY_K1=block cannot be flipped inside one process: compared through K = 2, which takes the direct
+    kernel, row for row)."""
+    rng = np.random.default_rng(23)
+    T, S = 6000, 5000
+    counts = rng.integers(0, 9, T)
+    counts[rng.choice(T, 300, replace=False)] = 0            # empty rows -> NaN
+    counts[rng.choice(T, 64, replace=False)] = rng.integers(20, 33, 64)     # long-ish rows: windows of > 320 entries per 64 rows
+    counts[100:164] = 32                                       # a whole wave of 32-entry rows: 2048 entries, seven chunks
+    counts[rng.choice(T, 40, replace=False)] = rng.integers(33, 600, 40)    # lane groups
+    counts[rng.choice(T, 12, replace=False)] = rng.integers(600, 2049, 12)  # whole waves
+    counts[[7, 4001]] = [2500, 3100]                           # beyond the wave kernel's reach: one block each
+    indptr = np.concatenate([[0], np.cumsum(counts)])
+    idx = np.concatenate([np.sort(rng.choice(S, c, replace=False)) for c in counts]) if indptr[-1] else np.zeros(0, int)
+    data = rng.uniform(0.1, 2.0, indptr[-1])
+    data[rng.random(indptr[-1]) < 0.02] = 0.0                  # zero weights
+    csr = hip.engine.DeviceCSR.from_arrays(data, idx, indptr, T, S)
+    v = rng.normal(size=S)
+    v[rng.random(S) < 0.05] = np.nan
+    sources = {"mixed": v, "positive": np.abs(v) + 0.1, "ties": np.round(2 * v), "all_nan": np.full(S, np.nan)}
+    short = counts <= LONG_ROW
+    for name, mid, p in METHODS:
+        m = ("percentile", p) if mid == 7 else name
+        for tag, vec in sources.items():
+            for dtype in (np.float64, np.float32):
+                one = vec.astype(dtype)[None, :]
+                got = csr.apply(one, mid, p)
+                exp = oracle.regrid_csr(m, one.astype(np.float64), data, idx, indptr, T)
+                assert got.shape == (1, T)
+                assert np.array_equal(np.isnan(got), np.isnan(exp)), (name, tag, dtype)
+                if name == "geometric_mean":
+                    np.testing.assert_allclose(got, exp, rtol=RTOL_GEOMETRIC, equal_nan=True)
+                    continue
+                # rows of up to 32 entries: the reference loop's additions in its order -> bit for bit
+                assert same_or_nan(got[:, short], exp[:, short]).all(), (name, tag, dtype)
+                if mid in (6, 7, 4, 5, 9):
+                    assert same_or_nan(got, exp).all(), (name, tag, dtype)
+                else:
+                    # (sums of mixed sign cancel: the cooperative order of the long rows then shows beyond 1e-13 relative
+                    # to the -- small -- result: an absolute floor of 1e-12 x the row's scale; 1e-6 for sums of w / v)
+                    signed = tag in ("mixed", "ties")
+                    loose = name == "harmonic_mean" and signed
+                    np.testing.assert_allclose(got, exp, rtol=1e-6 if loose else (1e-9 if name == "harmonic_mean" else RTOL_LONG),
+                                               atol=1e-9 if loose else (1e-11 if signed else 0.0), equal_nan=True,
+                                               err_msg=f"{name} {tag}")
+                # the two-variable path (another kernel family) agrees row for row on the short rows
+                two = csr.apply(np.concatenate([one, one]), mid, p)
+                assert same_or_nan(two[:1, short], got[:, short]).all() and same_or_nan(two[1:, short], got[:, short]).all()
+    # a matrix BUILT on the device (stored row order, big rows last) through the same kernel: covered against the oracle
+    sxy, sf = meshgen.triangle_mesh(30000, 3)
+    txy, tf = meshgen.quad_mesh(np.linspace(-0.1, 1.1, 40), np.linspace(0.0, 1.0, 3))
+    built, _, bidx, bdata, bindptr = gpu_triplets(hip, sxy, sf, txy, tf)
+    bv = meshgen.smooth_field(oracle.centroids(sxy, sf), 1, nan_fraction=0.03)[None, :]
+    for name, mid, p in (("mean", 0, 0.0), ("sum", 3, 0.0), ("maximum", 5, 0.0), ("max_overlap", 9, 0.0)):
+        got = built.apply(bv, mid, p)
+        exp = oracle.regrid_csr(name, bv, bdata, bidx, bindptr, built.n)
+        if mid in (5, 9):
+            assert same_or_nan(got, exp).all(), name
+        else:
+            np.testing.assert_allclose(got, exp, rtol=RTOL_LONG, atol=1e-11, equal_nan=True, err_msg=name)
+
+
 def grid2d():
     xy = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0], [0.0, 1.0], [1.0, 1.0], [2.0, 1.0], [1.0, 2.0]])
     faces = np.array([[0, 1, 4, 3], [1, 2, 5, 4], [3, 4, 6, -1], [4, 5, 6, -1]])

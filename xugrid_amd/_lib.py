@@ -76,6 +76,9 @@ SIGNATURES = {
     "xr_replace_interpolated_weights": (c_int, [vp, c_i64, vp, c_i64, c_i64, vp, vp, c_i64, vp, c_i64]),
     "xr_barycentric_csr": (c_int, [vp, vp, vp, vp, c_i64, c_f64, vp, vp, c_i64, p_vp]),
     "xr_barycentric_csr_tail": (c_int, [vp, vp, vp, vp, c_i64, c_f64, c_i64, vp, vp, c_i64, c_int, p_vp]),
+    "xr_locate_flags_begin": (c_int, [vp, vp, vp, c_i64, p_vp]),
+    "xr_points_destroy": (c_int, [vp]),
+    "xr_barycentric_csr_points": (c_int, [vp, vp, vp, c_f64, c_i64, vp, vp, c_i64, c_int, p_vp]),
     "xr_csr_info": (c_int, [vp, p_i64, p_i64, p_i64]),
     "xr_csr_download": (c_int, [vp, vp, vp, vp]),
     "xr_csr_upload": (c_int, [vp, vp, vp, c_i64, c_i64, c_i64, p_vp]),

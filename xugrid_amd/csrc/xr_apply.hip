@@ -1506,12 +1506,13 @@ k_apply_partial_rows(int method, const int32_t *__restrict__ indptr, const int32
                      const double *__restrict__ data, const int32_t *__restrict__ row_order, int64_t T, int64_t S,
                      const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool skip_long) {
     static_assert(KT == 8, "one 64-byte line per (row, component)");
-    __shared__ double sh_state[128][4 * KT + 1];
+    extern __shared__ double sh_dyn[]; // [128][C * KT + 1] states (sized for the reducer's C: 17 KB for two components)
     __shared__ int32_t sh_tout[128];
     const int64_t t = (int64_t)blockIdx.x * 128 + threadIdx.x;
     const int64_t k0 = (int64_t)blockIdx.y * KT;
     const int kn = (int)((K - k0) < KT ? (K - k0) : KT);
     const int C = partial_components(method);
+    const int ld = C * KT + 1;
     int s = 0, e = 0;
     bool mine = false;
     if (t < T) {
@@ -1538,14 +1539,14 @@ k_apply_partial_rows(int method, const int32_t *__restrict__ indptr, const int32
     sh_tout[threadIdx.x] = mine ? (int32_t)(row_order ? row_order[t] : t) : -1;
     for (int c = 0; c < C; c++)
 #pragma unroll
-        for (int kk = 0; kk < KT; kk++) sh_state[threadIdx.x][c * KT + kk] = st[kk].c[c];
+        for (int kk = 0; kk < KT; kk++) sh_dyn[threadIdx.x * ld + c * KT + kk] = st[kk].c[c];
     __syncthreads();
     // 8 lanes per (row, component) line
     const int n_lines = 128 * C;
     for (int line = threadIdx.x >> 3; line < n_lines; line += 16) {
         const int r = line / C, c = line - r * C, kk = threadIdx.x & 7;
         const int t_out = sh_tout[r];
-        if (t_out >= 0 && kk < kn) out[(int64_t)t_out * (C * K) + (int64_t)c * K + k0 + kk] = sh_state[r][c * KT + kk];
+        if (t_out >= 0 && kk < kn) out[(int64_t)t_out * (C * K) + (int64_t)c * K + k0 + kk] = sh_dyn[r * ld + c * KT + kk];
     }
 }
 
@@ -2638,12 +2639,13 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
         static const bool one_var = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
         if (K >= PKT && !one_var && rows_layout != 0) {
             dim3 grid(div_up(csr->n, 128), (unsigned)div_up(K, PKT));
+            const size_t rows_shmem = sizeof(double) * 128 * (size_t)(partial_components(method) * PKT + 1);
             if (source_dtype == XR_F64)
-                XR_LAUNCH("apply_partial", (k_apply_partial_rows<double, PKT>), grid, dim3(128), 0, method, csr->indptr.get(),
+                XR_LAUNCH("apply_partial", (k_apply_partial_rows<double, PKT>), grid, dim3(128), rows_shmem, method, csr->indptr.get(),
                           csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                           static_cast<const double *>(source_dev), K, out_dev, csr->has_long);
             else
-                XR_LAUNCH("apply_partial", (k_apply_partial_rows<float, PKT>), grid, dim3(128), 0, method, csr->indptr.get(),
+                XR_LAUNCH("apply_partial", (k_apply_partial_rows<float, PKT>), grid, dim3(128), rows_shmem, method, csr->indptr.get(),
                           csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                           static_cast<const float *>(source_dev), K, out_dev, csr->has_long);
         } else if (K >= PKT && !one_var) {

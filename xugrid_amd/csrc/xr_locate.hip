@@ -537,16 +537,50 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 
 // vertex v of the tessellation belongs to source face v for v < n_identity (the face centroids come first) and to
 // vertex_face[v - n_identity] beyond (projections: their face; substitute vertices: -1)
+} // namespace xr (the handle type is a global name, like xr_mesh / xr_csr)
+
+// query points of a barycentric construction + "inside the source grid" flags, resident in HBM (xr_locate_flags_begin)
+struct xr_points {
+    int64_t n = 0;
+    xr_mesh *source = nullptr;
+    xr::DevBuf<double> pts;
+    xr::DevBuf<uint8_t> inside;
+};
+
+namespace xr {
+
+// the source-side part of UnstructuredGrid2d.barycentric (unstructured.py:147, 188-190) -- the query points and
+// `grid.locate_points(points) == -1` -- enqueued WITHOUT a final wait: it needs nothing of the Voronoi tessellation
+static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, DevBuf<double> &pts,
+                         DevBuf<uint8_t> &inside) {
+    mesh_prepare(source, false);
+    mesh_build_index(source);
+    const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
+    pts.alloc((size_t)n * 2);
+    inside.alloc((size_t)n);
+    if (query) mesh_centroids_dev(query, pts.get());
+    else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+    XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
+              source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
+              source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
+}
+
 static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
                             double tolerance, int64_t n_identity, const int64_t *vertex_face,
-                            const int64_t *node_to_node_map, int64_t n_extra, bool reference_order, xr_csr **out) {
+                            const int64_t *node_to_node_map, int64_t n_extra, bool reference_order, xr_csr **out,
+                            xr_points *pre = nullptr) {
     {
     XR_REQUIRE(voronoi && source && out, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
+    if (pre) {
+        XR_REQUIRE(pre->source == source && !query && !points, XR_ERR_INVALID,
+                   "xr_barycentric_csr: the prepared points belong to another source grid (or points were given twice)");
+        n = pre->n;
+    }
+    XR_REQUIRE(pre || ((query != nullptr) != (points != nullptr)), XR_ERR_INVALID,
+               "xr_barycentric_csr: give either a query mesh (its face centroids are the points) or points");
     XR_REQUIRE(n_identity >= 0 && n_identity <= voronoi->n_node && n_identity <= source->n_face &&
                    (vertex_face || n_identity == voronoi->n_node),
                XR_ERR_INVALID, "xr_barycentric_csr: bad vertex_face");
-    XR_REQUIRE((query != nullptr) != (points != nullptr), XR_ERR_INVALID,
-               "xr_barycentric_csr: give either a query mesh (its face centroids are the points) or points");
     if (query) n = query->n_face;
     XR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "xr_barycentric_csr: too many points");
     XR_REQUIRE(n_extra >= 0 && n_extra <= voronoi->n_node && (n_extra == 0 || node_to_node_map), XR_ERR_INVALID,
@@ -571,18 +605,17 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             stream_sync();
         } else {
             mesh_prepare(voronoi, false); mesh_build_index(voronoi);
-            mesh_prepare(source, false); mesh_build_index(source);
             const double tol = resolve_tolerance(voronoi, tolerance);
-            const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
-            DevBuf<double> pts((size_t)n * 2), w((size_t)n * m);
-            if (query) mesh_centroids_dev(query, pts.get());
-            else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            DevBuf<double> own_pts, w((size_t)n * m);
+            DevBuf<uint8_t> own_inside;
+            if (!pre) locate_flags(source, query, points, n, own_pts, own_inside); // (else: enqueued earlier, same stream)
+            DevBuf<double> &pts = pre ? pre->pts : own_pts;
+            DevBuf<uint8_t> &inside = pre ? pre->inside : own_inside;
             // the vertex table the weight slots are paired with: the caller's order as the reference does
             // (unstructured.py:175,193) = the mesh's own int32 connectivity, read as it is; or -- tree_order -- the tree's
             // counter-clockwise-normalised copy, materialised as a table first
             DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)(reference_order ? 1 : voronoi->n_face * m)), vface((size_t)nv),
                 n2n((size_t)(n_extra > 0 ? 2 * n_extra : 1));
-            DevBuf<uint8_t> inside((size_t)n);
             DevBuf<int32_t> count((size_t)n);
             if (n_identity > 0)
                 XR_LAUNCH("iota", k_iota_i64, dim3(div_up(n_identity, 256)), dim3(256), 0, vface.get(), n_identity);
@@ -593,9 +626,6 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
                       voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get());
-            XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
-                      source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
-                      source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
             if (reference_order)
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                           voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
@@ -638,6 +668,52 @@ int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
     XR_API_BEGIN
     barycentric_csr(voronoi, source, query, points, n, tolerance, n_identity, vertex_face_tail, node_to_node_map, n_extra,
                     tree_order == 0, out);
+    XR_API_END
+}
+
+int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, xr_points **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(source && out, XR_ERR_INVALID, "xr_locate_flags_begin: NULL argument");
+    XR_REQUIRE((query != nullptr) != (points != nullptr), XR_ERR_INVALID,
+               "xr_locate_flags_begin: give either a query mesh (its face centroids are the points) or points");
+    if (query) n = query->n_face;
+    XR_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "xr_locate_flags_begin: too many points");
+    xr_points *h = new xr_points();
+    try {
+        h->n = n;
+        h->source = source;
+        if (n > 0 && source->n_face > 0) locate_flags(source, query, points, n, h->pts, h->inside);
+        else if (n > 0) { // (no source faces: every point is outside)
+            h->pts.alloc((size_t)n * 2);
+            h->inside.alloc((size_t)n);
+            XR_HIP(hipMemsetAsync(h->inside.get(), 0, (size_t)n, launch_stream()));
+            if (query) mesh_centroids_dev(query, h->pts.get());
+            else h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+        }
+    } catch (...) {
+        delete h;
+        throw;
+    }
+    *out = h; // (no wait: the kernels run while the caller goes on -- e.g. builds the Voronoi tessellation's boundary cells)
+    XR_API_END
+}
+
+int xr_points_destroy(xr_points *points) {
+    XR_API_BEGIN
+    if (points) {
+        stream_sync();
+        delete points;
+    }
+    XR_API_END
+}
+
+int xr_barycentric_csr_points(xr_mesh *voronoi, xr_mesh *source, xr_points *points, double tolerance, int64_t n_identity,
+                              const int64_t *vertex_face_tail, const int64_t *node_to_node_map, int64_t n_extra,
+                              int tree_order, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(points, XR_ERR_INVALID, "xr_barycentric_csr_points: NULL argument");
+    barycentric_csr(voronoi, source, nullptr, nullptr, 0, tolerance, n_identity, vertex_face_tail, node_to_node_map, n_extra,
+                    tree_order == 0, out, points);
     XR_API_END
 }
 
