@@ -39,6 +39,11 @@ static std::mutex g_pool_mutex; // the block pool and the kernel-timer tables ar
 
 Lane *current_lane() { return t_lane; }
 
+static thread_local hipStream_t t_stream_override = nullptr;
+hipStream_t stream_override() { return t_stream_override; }
+StreamOverride::StreamOverride(hipStream_t s) : prev(t_stream_override) { t_stream_override = s; }
+StreamOverride::~StreamOverride() { t_stream_override = prev; }
+
 ExclusiveScope::ExclusiveScope() {
     if (t_exclusive_depth++ == 0) {
         engine_mutex().lock();
@@ -506,7 +511,7 @@ ProfScope::ProfScope(const char *n) : name(n) {
     e1 = get_event();
     (void)hipEventRecord(e0, launch_stream());
     on_side = g_engine.on_side;
-    lane_stream = t_lane ? t_lane->stream : nullptr;
+    lane_stream = t_stream_override ? t_stream_override : (t_lane ? t_lane->stream : nullptr);
 }
 
 ProfScope::~ProfScope() {

@@ -197,10 +197,18 @@ struct Lane {
 };
 Lane *current_lane(); // the calling thread's lane, nullptr on the engine's own (exclusive) path
 
+hipStream_t stream_override(); // a stream the calling thread has redirected its launches to (StreamOverride), or nullptr
 inline hipStream_t launch_stream() {
+    if (hipStream_t s = stream_override()) return s;
     if (Lane *l = current_lane()) return l->on_side ? l->side : l->stream;
     return engine().on_side ? engine().side : engine().stream;
 }
+// RAII: launches of the calling thread go to `s` (a stream the caller owns and orders itself with events)
+struct StreamOverride {
+    explicit StreamOverride(hipStream_t s);
+    ~StreamOverride();
+    hipStream_t prev;
+};
 
 // RAII: launches inside the scope go to the side stream, which first waits for everything enqueued on the main
 // stream so far; join() makes the main stream wait for the side stream's work

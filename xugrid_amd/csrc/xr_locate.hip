@@ -6,6 +6,8 @@
 // One thread per query point walks the hierarchical grid of the mesh; the arithmetic mirrors
 // oracle/xr_oracle.c (point_in_poly_or_on_edge / bary_weights) operation for operation.
 // A point matched by several faces (within tolerance of a shared edge) gets the LOWEST face id.
+#include <memory>
+
 #include "xr_objects.h"
 
 namespace xr {
@@ -537,32 +539,54 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 
 // vertex v of the tessellation belongs to source face v for v < n_identity (the face centroids come first) and to
 // vertex_face[v - n_identity] beyond (projections: their face; substitute vertices: -1)
-} // namespace xr (the handle type is a global name, like xr_mesh / xr_csr)
-
 // query points of a barycentric construction + "inside the source grid" flags, resident in HBM (xr_locate_flags_begin)
 struct xr_points {
     int64_t n = 0;
     xr_mesh *source = nullptr;
     xr::DevBuf<double> pts;
     xr::DevBuf<uint8_t> inside;
+    // The kernels that fill the two buffers run on a stream of the handle's own: the engine's stream is synchronised by the
+    // calls the caller makes next (the Voronoi pre-step reads its boundary rows back), and a kernel queued there would be
+    // waited for -- on its own stream it keeps running while the host computes.  `ready`: recorded behind them.
+    // (ONE auxiliary stream per process, created on first use: creating and destroying a HIP stream costs milliseconds)
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr;
+    ~xr_points() {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (ready) (void)hipEventDestroy(ready);
+    }
 };
 
-namespace xr {
+static hipStream_t aux_stream() {
+    static hipStream_t s = nullptr; // (callers hold the engine's exclusive lock)
+    if (!s) XR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    return s;
+}
 
 // the source-side part of UnstructuredGrid2d.barycentric (unstructured.py:147, 188-190) -- the query points and
 // `grid.locate_points(points) == -1` -- enqueued WITHOUT a final wait: it needs nothing of the Voronoi tessellation
 static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, DevBuf<double> &pts,
-                         DevBuf<uint8_t> &inside) {
+                         DevBuf<uint8_t> &inside, xr_points *own_stream = nullptr) {
     mesh_prepare(source, false);
     mesh_build_index(source);
     const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
     pts.alloc((size_t)n * 2);
     inside.alloc((size_t)n);
+    if (!query) h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n); // (synchronous, engine stream)
+    std::unique_ptr<StreamOverride> redirect;
+    if (own_stream) {
+        // the handle's stream starts behind everything enqueued so far (index of the source, pool blocks in stream order)
+        own_stream->stream = aux_stream();
+        XR_HIP(hipEventCreateWithFlags(&own_stream->ready, hipEventDisableTiming));
+        XR_HIP(hipEventRecord(own_stream->ready, launch_stream()));
+        XR_HIP(hipStreamWaitEvent(own_stream->stream, own_stream->ready, 0));
+        redirect.reset(new StreamOverride(own_stream->stream));
+    }
     if (query) mesh_centroids_dev(query, pts.get());
-    else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
     XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
               source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
               source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
+    if (own_stream) XR_HIP(hipEventRecord(own_stream->ready, own_stream->stream));
 }
 
 static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
@@ -608,7 +632,8 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             const double tol = resolve_tolerance(voronoi, tolerance);
             DevBuf<double> own_pts, w((size_t)n * m);
             DevBuf<uint8_t> own_inside;
-            if (!pre) locate_flags(source, query, points, n, own_pts, own_inside); // (else: enqueued earlier, same stream)
+            if (!pre) locate_flags(source, query, points, n, own_pts, own_inside);
+            else if (pre->ready) XR_HIP(hipStreamWaitEvent(launch_stream(), pre->ready, 0)); // (filled on the handle's stream)
             DevBuf<double> &pts = pre ? pre->pts : own_pts;
             DevBuf<uint8_t> &inside = pre ? pre->inside : own_inside;
             // the vertex table the weight slots are paired with: the caller's order as the reference does
@@ -682,7 +707,7 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
     try {
         h->n = n;
         h->source = source;
-        if (n > 0 && source->n_face > 0) locate_flags(source, query, points, n, h->pts, h->inside);
+        if (n > 0 && source->n_face > 0) locate_flags(source, query, points, n, h->pts, h->inside, h);
         else if (n > 0) { // (no source faces: every point is outside)
             h->pts.alloc((size_t)n * 2);
             h->inside.alloc((size_t)n);

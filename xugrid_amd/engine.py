@@ -371,8 +371,36 @@ def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_n
     return weights
 
 
+class DevicePoints:
+    """Query points of a barycentric construction and their "inside the source grid" flags, in HBM
+    (include/xugrid_amd.h: xr_locate_flags_begin).  Creating one ENQUEUES the source-side kernels and returns at once."""
+
+    def __init__(self, source: DeviceMesh, query: DeviceMesh = None, points=None):
+        if (query is None) == (points is None):
+            raise ValueError("give either a query mesh or points")
+        handle = ctypes.c_void_p()
+        if points is not None:
+            pts = _as_xy(points)
+            check(_lib.load().xr_locate_flags_begin(source._h, None, _ptr(pts), pts.shape[0], ctypes.byref(handle)))
+            self.n = pts.shape[0]
+        else:
+            check(_lib.load().xr_locate_flags_begin(source._h, query._h, None, 0, ctypes.byref(handle)))
+            self.n = query.n_face
+        self._h = handle
+        self._source = source  # (keeps the mesh alive as long as its flags)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().xr_points_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+
 def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_to_node_map, query: DeviceMesh = None,
-                    points=None, tolerance=None, n_identity=0, reference_order=True) -> "DeviceCSR":
+                    points=None, tolerance=None, n_identity=0, reference_order=True, prepared: "DevicePoints" = None) -> "DeviceCSR":
     """UnstructuredGrid2d.barycentric after the Voronoi pre-step, on the device (see include/xugrid_amd.h).
     ``n_identity`` > 0: ``vertex_face`` holds only the entries of the vertices ``>= n_identity`` (the first
     ``n_identity`` vertices are the source face centroids, in face order).  ``reference_order`` (default): pair the
@@ -388,6 +416,19 @@ def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_t
     tol = -1.0 if tolerance is None else float(tolerance)
     if tolerance is not None and tol < 0:
         raise ValueError("tolerance must be non-negative")
+    handle = ctypes.c_void_p()
+    if prepared is not None:
+        # ``prepared``: a DevicePoints started earlier for the same source and query (its kernels ran beside whatever the
+        # host did in between, e.g. the boundary cells of the Voronoi pre-step)
+        if query is not None or points is not None:
+            raise ValueError("prepared points replace the query mesh / points")
+        check(
+            _lib.load().xr_barycentric_csr_points(
+                voronoi._h, source._h, prepared._h, tol, int(n_identity), _ptr(vertex_face), _ptr(n2n), n2n.shape[0],
+                0 if reference_order else 1, ctypes.byref(handle),
+            )
+        )
+        return DeviceCSR(handle)
     if (query is None) == (points is None):
         raise ValueError("give either a query mesh or points")
     if points is not None:
@@ -395,7 +436,6 @@ def barycentric_csr(voronoi: DeviceMesh, source: DeviceMesh, vertex_face, node_t
         p_arg, n, q_arg = _ptr(pts), pts.shape[0], None
     else:
         p_arg, n, q_arg = None, query.n_face, query._h
-    handle = ctypes.c_void_p()
     if n_identity or not reference_order:
         check(
             _lib.load().xr_barycentric_csr_tail(

@@ -121,16 +121,21 @@ class UnstructuredGrid2d:
         ``tree_order``: see ``barycentric``."""
         from .. import engine
 
+        # the source-side half (index of this grid, the target's centroids, which of them lie inside this grid) needs
+        # nothing of the tessellation: enqueued first, it runs while the host builds the boundary cells of the Voronoi
+        # pre-step (0.5 ms at 1M faces) -- nothing to overlap when the tessellation is cached
+        source_mesh = self.ugrid_topology.device_mesh
+        prepared = engine.DevicePoints(source_mesh, query=other.ugrid_topology.device_mesh)
         voronoi_mesh, face_index_tail, node_to_node_map = self._voronoi_device()
         return engine.barycentric_csr(
             voronoi_mesh,
-            self.ugrid_topology.device_mesh,
+            source_mesh,
             face_index_tail,
             node_to_node_map,
-            query=other.ugrid_topology.device_mesh,
             tolerance=tolerance,
             n_identity=self.ugrid_topology.n_face,
             reference_order=not tree_order,
+            prepared=prepared,
         )
 
     def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None, tree_order: bool = False):
