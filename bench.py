@@ -306,11 +306,23 @@ def run_single(args):
     ppath = os.path.join(ROOT, "profiles", "pmc_per_launch.json")
     if pmc and os.path.exists(ppath):
         try:
-            insts = json.load(open(ppath))["k_clip_tri_queue"]["SQ_INSTS_VALU"]
+            ctr = json.load(open(ppath))["k_clip_tri_queue"]
+            insts = ctr["SQ_INSTS_VALU"]
             floor_ms = insts * 4 / (256 * 4) / 2.4e9 * 1e3
             clip_ms = kernels["clip_tri"][1] if "clip_tri" in kernels else None
             valu = {"kernel": "clip_tri", "wave_instructions_per_launch": insts, "issue_floor_ms": floor_ms,
                     "frac_of_issue_limit": floor_ms / clip_ms if clip_ms else None, "source": "profiles/pmc_per_launch.json"}
+            if all(k in ctr for k in ("SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAVES")) and ctr["SQ_WAVES"] > 0:
+                # The persistent clip's waves live for the whole launch: SQ_WAVE_CYCLES (quad-cycles) / waves = the launch in
+                # shader cycles, i.e. the clock the chip really ran this FP64-dense kernel at; the VALU pipes' busy cycles
+                # per SIMD against that lifetime = how VALU-bound the kernel is, whatever the clock.
+                life_cycles = 4.0 * ctr["SQ_WAVE_CYCLES"] / ctr["SQ_WAVES"]
+                busy_cycles = 4.0 * ctr["SQ_ACTIVE_INST_VALU"] / (256 * 4)
+                valu["valu_busy_frac"] = busy_cycles / life_cycles
+                valu["wave_lifetime_cycles"] = life_cycles
+                valu["effective_clock_ghz_under_pmc"] = life_cycles / (clip_ms * 1e-3) / 1e9 if clip_ms else None
+                valu["note"] = ("frac_of_issue_limit prices the instructions at 2.4 GHz; valu_busy_frac = VALU-active cycles per SIMD / "
+                                "wave lifetime is clock-independent: the kernel is VALU-bound (DESIGN section 5)")
         except Exception:
             valu = None
     km = kernel_model_bytes(S, T, Ns, Nt, C, P)

@@ -124,14 +124,19 @@ class UnstructuredGrid2d:
         # the source-side half (index of this grid, the target's centroids, which of them lie inside this grid) needs
         # nothing of the tessellation: enqueued first, it runs while the host builds the boundary cells of the Voronoi
         # pre-step (0.5 ms at 1M faces) -- nothing to overlap when the tessellation is cached
+        import os
+
         source_mesh = self.ugrid_topology.device_mesh
-        prepared = engine.DevicePoints(source_mesh, query=other.ugrid_topology.device_mesh)
+        query_mesh = other.ugrid_topology.device_mesh
+        overlap = os.environ.get("XR_BARY_OVERLAP", "1") != "0"  # (measurement switch: 0 = both halves in one call)
+        prepared = engine.DevicePoints(source_mesh, query=query_mesh) if overlap else None
         voronoi_mesh, face_index_tail, node_to_node_map = self._voronoi_device()
         return engine.barycentric_csr(
             voronoi_mesh,
             source_mesh,
             face_index_tail,
             node_to_node_map,
+            query=None if overlap else query_mesh,
             tolerance=tolerance,
             n_identity=self.ugrid_topology.n_face,
             reference_order=not tree_order,
