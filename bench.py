@@ -403,11 +403,12 @@ def run_single(args):
         "cpu_baseline": cpu,
     }
     if not args.no_extras:
-        result["other_configs"] = other_configs(E, lib, _lib, csr, S, T, ms, sxy, sf, delaunay=not args.no_delaunay)
+        result["other_configs"] = other_configs(E, lib, _lib, csr, S, T, ms, sxy, sf, delaunay=not args.no_delaunay,
+                                                 target_centroids=mt.centroids())
     print(json.dumps(result), flush=True)
 
 
-def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaunay=True):
+def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaunay=True, target_centroids=None):
     """BASELINE configs 5 and 3, a structured pair and a network, measured beside the headline (rank 0, N = 1): informative
     extras of the JSON line, never part of `value`.  Bounded to a few seconds each."""
     import ctypes
@@ -468,6 +469,27 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
             dt2 = (time.perf_counter() - t0) / n
             out["config5_apply_K256"]["morton_columns_" + tag] = {
                 "ms": 1e3 * dt2, "algorithmic_GBps": nbytes / dt2 / 1e9, "frac_of_hbm_peak": nbytes / dt2 / 1e9 / HBM_PEAK_GBS}
+        # ... and with BOTH sides in the engine's order: rows regrouped at the finest granularity (every row to its own Morton
+        # tile: the output is delivered in stored order, so it no longer needs runs of consecutive caller ids), source
+        # block in stored column order.  For data that lives on the device across many applies.
+        rkeys, rrange = E.morton_row_keys(target_centroids, faces_per_tile=4)
+        csr.set_row_keys(rkeys, rrange)
+        csr.expect_permuted(True)
+        csr.output_stored_order(True)
+        for _ in range(2):
+            csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+        E.dev_sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+        E.dev_sync()
+        dt3 = (time.perf_counter() - t0) / n
+        out["config5_apply_K256"]["engine_order_in_and_out"] = {
+            "ms": 1e3 * dt3, "algorithmic_GBps": nbytes / dt3 / 1e9, "frac_of_hbm_peak": nbytes / dt3 / 1e9 / HBM_PEAK_GBS,
+            "note": "source block in the stored (Morton) column order, result in the stored (Morton-tiled) row order: "
+                    "DeviceCSR.engine_order / xr_csr_set_row_keys + xr_csr_set_col_keys + xr_csr_expect_permuted + "
+                    "xr_csr_output_stored_order"}
+        csr.output_stored_order(False)
         csr.expect_permuted(False)
         lib.xr_dev_free(d_src)
         lib.xr_dev_free(d_out)

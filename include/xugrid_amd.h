@@ -314,7 +314,9 @@ int xr_edge_pieces(xr_mesh *tree, const xr_csr *csr, const double *edge_xy, int6
  * from_weights path): one small integer per row such that rows with equal keys are spatial neighbours (e.g. the
  * Morton code of a coarse cell holding the target face's centroid).  With many source variables (K >= 8) the apply
  * regroups the STORED rows by key once -- results and xr_csr_download are unaffected.  xr_overlap attaches such
- * keys itself. */
+ * keys itself (runs of 16 consecutive target ids share a key, so that a variable's outputs leave in 128-byte pieces);
+ * keys given for such a matrix are per CALLER row and replace that grouping -- worth it with xr_csr_output_stored_order,
+ * where the output no longer cares about the caller's numbering and every row can go to its own tile. */
 int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range);
 /* The same for the COLUMNS (source cells): one small integer per column such that columns with equal keys are spatial
  * neighbours.  The columns are renumbered once by key (stable), so that the source values a block of target rows
@@ -328,6 +330,13 @@ int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range);
 int xr_csr_set_col_keys(xr_csr *csr, const int64_t *keys, int64_t key_range);
 int xr_csr_col_order(const xr_csr *csr, int64_t *order_out);
 int xr_csr_expect_permuted(xr_csr *csr, int permuted);
+/* The mirror image for the OUTPUT: after xr_csr_output_stored_order(csr, 1) the applies write stored row r to out[k, r]
+ * (fully coalesced whatever the caller's numbering) instead of out[k, row_order[r]]; xr_csr_row_order returns the permutation
+ * (stored row r = caller's row order[r]; K_hint: the number of variables of the coming applies -- from 8 on the rows are
+ * regrouped into 2-D tiles once, which is part of the stored order).  With columns AND rows in the engine's order a pipeline
+ * that keeps its blocks on the device pays the caller's numbering once, not per apply. */
+int xr_csr_output_stored_order(xr_csr *csr, int stored);
+int xr_csr_row_order(const xr_csr *csr, int64_t K_hint, int64_t *order_out);
 int xr_csr_destroy(xr_csr *csr);
 
 /* ---- seam 2: apply ---------------------------------------------------------------------- */

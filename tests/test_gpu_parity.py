@@ -615,8 +615,12 @@ def test_apply_many_variables_row_tiling(hip, oracle):
     assert_apply_equal(up.apply(v, 0), oracle.regrid_csr("mean", v, oa, os_, indptr, csr.n), indptr, "uploaded")
     d, i, p = up.download()
     assert np.array_equal(d, oa) and np.array_equal(i, os_) and np.array_equal(p, indptr)
-    with pytest.raises(ValueError):
-        up.set_row_keys(keys, key_range)  # rows are already stored in a spatial order
+    # keys for rows that are already stored in a spatial order: per CALLER row, the permutations compose (finer tiles here)
+    keys2, key_range2 = E.morton_row_keys(oracle.centroids(txy, tf), faces_per_tile=4)
+    up.set_row_keys(keys2, key_range2)
+    assert_apply_equal(up.apply(v, 0), oracle.regrid_csr("mean", v, oa, os_, indptr, csr.n), indptr, "re-keyed")
+    d, i, p = up.download()
+    assert np.array_equal(d, oa) and np.array_equal(i, os_) and np.array_equal(p, indptr)
     with pytest.raises(ValueError):
         E.DeviceCSR.from_arrays(oa, os_, indptr, csr.n, csr.m).set_row_keys(keys + key_range, key_range)
 
@@ -765,3 +769,41 @@ def test_apply_columns_renumbered_by_spatial_key(hip, oracle):
     assert same_or_nan(csr.apply(v.astype(np.float32), 0), csr.apply(v.astype(np.float32).astype(np.float64), 0)).all()
     with pytest.raises(ValueError):
         csr.set_col_keys(keys, key_range)  # already renumbered
+
+
+@pytest.mark.parametrize("kind", ["built", "uploaded"])
+def test_apply_in_engine_order(hip, oracle, kind):
+    """Both sides of the apply in the engine's own order (DeviceCSR.engine_order: xr_csr_set_row_keys on the caller's rows
+    -- also for a matrix xr_overlap built, where it replaces the runs-of-16 grouping --, xr_csr_set_col_keys,
+    xr_csr_expect_permuted, xr_csr_output_stored_order): ``out[:, r]`` is the caller's row ``row_order[r]``, for every
+    kernel family (K = 1 one-launch, direct, planned, long rows, workspace reducers); downloads stay in the caller's
+    ids; switching the stored-order output off again gives the caller's rows back."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.triangle_mesh(20000, 3)
+    txy, tf = meshgen.triangle_mesh(24000, 4, 30.0, 0.8)
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    csr = ms.overlap(mt)
+    data, idx, indptr = csr.download()
+    if kind == "uploaded":
+        csr = E.DeviceCSR.from_arrays(data, idx, indptr, csr.n, csr.m)
+    rng = np.random.default_rng(16)
+    v = rng.normal(size=(40, csr.m))
+    v[3, ::5] = np.nan
+    cases = [(0, 0.0, 1), (0, 0.0, 3), (0, 0.0, 9), (0, 0.0, 40), (3, 0.0, 40), (5, 0.0, 9), (9, 0.0, 2), (7, 50.0, 4), (6, 0.0, 2)]
+    ref = {c: csr.apply(v[: c[2]], c[0], c[1]) for c in cases}
+    col_order, row_order = csr.engine_order(ms.centroids(), mt.centroids(), K=40, row_tile=4, col_tile=8)
+    assert np.array_equal(np.sort(row_order), np.arange(csr.n)) and not np.array_equal(row_order, np.arange(csr.n))
+    assert np.array_equal(np.sort(col_order), np.arange(csr.m))
+    vp = np.ascontiguousarray(v[:, col_order])
+    for c in cases:
+        got = csr.apply(vp[: c[2]], c[0], c[1])
+        back = np.empty_like(got)
+        back[:, row_order] = got
+        assert same_or_nan(back, ref[c]).all(), (kind, c)
+    d2, i2, p2 = csr.download()
+    assert np.array_equal(d2, data) and np.array_equal(i2, idx) and np.array_equal(p2, indptr)
+    csr.output_stored_order(False)
+    csr.expect_permuted(False)
+    for c in cases[:4]:
+        assert same_or_nan(csr.apply(v[: c[2]], c[0], c[1]), ref[c]).all(), (kind, c, "caller order again")

@@ -96,6 +96,8 @@ SIGNATURES = {
     "xr_csr_set_col_keys": (c_int, [vp, vp, c_i64]),
     "xr_csr_col_order": (c_int, [vp, vp]),
     "xr_csr_expect_permuted": (c_int, [vp, c_int]),
+    "xr_csr_output_stored_order": (c_int, [vp, c_int]),
+    "xr_csr_row_order": (c_int, [vp, c_i64, vp]),
     "xr_csr_destroy": (c_int, [vp]),
     "xr_apply_csr": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
     "xr_apply_csr_dev": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),

@@ -1657,7 +1657,7 @@ __global__ void k_apply_coo(const int32_t *__restrict__ row, const int32_t *__re
 }
 
 static inline const int32_t *row_order_of(const xr_csr *csr) {
-    return csr->has_row_order ? csr->row_order.get() : nullptr;
+    return (csr->has_row_order && !csr->output_stored) ? csr->row_order.get() : nullptr;
 }
 
 template <int METHOD, typename SRC>
@@ -2447,15 +2447,23 @@ int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range) {
     XR_REQUIRE(csr && (keys || csr->n == 0), XR_ERR_INVALID, "xr_csr_set_row_keys: NULL argument");
     XR_REQUIRE(key_range >= 1 && key_range <= ((int64_t)1 << 24), XR_ERR_INVALID,
                "xr_csr_set_row_keys: key_range must be in [1, 2^24]");
-    XR_REQUIRE(!csr->has_row_order, XR_ERR_INVALID,
-               "xr_csr_set_row_keys: the rows of this matrix are already stored in a spatial order");
     for (int64_t i = 0; i < csr->n; i++)
         XR_REQUIRE(keys[i] >= 0 && keys[i] < key_range, XR_ERR_INVALID, "xr_csr_set_row_keys: key %lld outside [0,%lld)",
                    (long long)keys[i], (long long)key_range);
     if (csr->n > 0) {
         csr->tile_key.alloc((size_t)csr->n);
-        upload_narrow(keys, csr->n, csr->tile_key.get());
+        if (csr->has_row_order) {
+            // rows already stored in another order (built by xr_overlap, or tiled before): the keys are per CALLER row, the
+            // regrouping works on stored rows -- key of stored row r = keys[row_order[r]]; the permutations compose
+            DevBuf<int32_t> by_caller((size_t)csr->n);
+            upload_narrow(keys, csr->n, by_caller.get());
+            XR_LAUNCH("gather_keys", k_gather_i32, dim3(div_up(csr->n, 256)), dim3(256), 0, by_caller.get(),
+                      csr->row_order.get(), csr->n, csr->tile_key.get());
+        } else {
+            upload_narrow(keys, csr->n, csr->tile_key.get());
+        }
         stream_sync();
+        csr->plan_ready = false;
         csr->tile_key_range = key_range;
         csr->has_tile_key = key_range > 1;
     }
@@ -2513,6 +2521,32 @@ int xr_csr_expect_permuted(xr_csr *csr, int permuted) {
     XR_API_BEGIN
     XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_expect_permuted: NULL argument");
     csr->source_permuted = permuted != 0;
+    XR_API_END
+}
+
+static int prepare_for_apply(const xr_csr *csr, int64_t K);
+
+int xr_csr_output_stored_order(xr_csr *csr, int stored) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_output_stored_order: NULL argument");
+    csr->output_stored = stored != 0;
+    XR_API_END
+}
+
+int xr_csr_row_order(const xr_csr *csr, int64_t K_hint, int64_t *order_out) {
+    {
+        // (the row tiling of the many-variable apply is part of the stored order: settle it first)
+        const int rc = prepare_for_apply(csr, K_hint);
+        if (rc != XR_OK) return rc;
+    }
+    XR_API_BEGIN
+    XR_REQUIRE(csr && (order_out || csr->n == 0), XR_ERR_INVALID, "xr_csr_row_order: NULL argument");
+    if (csr->has_row_order) {
+        download_widen(csr->row_order.get(), csr->n, order_out);
+        stream_sync();
+    } else {
+        for (int64_t i = 0; i < csr->n; i++) order_out[i] = i;
+    }
     XR_API_END
 }
 

@@ -112,6 +112,7 @@ struct xr_csr {
     xr::DevBuf<int32_t> col_of; // [m]
     bool has_col_perm = false;
     bool source_permuted = false;
+    bool output_stored = false; // applies write row r of the STORED order to out[k, r] (xr_csr_output_stored_order)
     // "apply plan" for many source variables (built lazily, xr_apply.hip): per block of 256 stored
     // rows the sorted list of DISTINCT column ids and, per entry, its 16-bit position in that list
     bool plan_ready = false;
