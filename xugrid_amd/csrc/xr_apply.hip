@@ -1000,6 +1000,9 @@ static void ensure_tiled(const xr_csr *ccsr) {
     if (!csr->has_tile_key) return;
     static const bool no_tile = getenv("XR_APPLY_NO_TILING") != nullptr; // measurement switch
     if (no_tile) return;
+    // (a re-layout of the matrix: only under the exclusive scope -- the apply entry points call prepare_for_apply first,
+    // so that the concurrent, shared part of an apply finds this done)
+    XR_REQUIRE(exclusive_held(), XR_ERR_INVALID, "internal: row tiling requested outside the exclusive scope");
     csr->has_tile_key = false;
     const int64_t n = csr->n, R = csr->tile_key_range;
     if (n == 0 || R <= 1) {
@@ -1041,6 +1044,7 @@ static void ensure_tiled(const xr_csr *ccsr) {
 static void ensure_plan(const xr_csr *ccsr) {
     xr_csr *csr = const_cast<xr_csr *>(ccsr); // the plan is a cache attached to the weights
     if (csr->plan_ready) return;
+    XR_REQUIRE(exclusive_held(), XR_ERR_INVALID, "internal: apply plan requested outside the exclusive scope");
     const int64_t nb = (csr->n + AP_BLOCK - 1) / AP_BLOCK;
     csr->plan_ucol.alloc((size_t)nb * PLAN_UMAX);
     csr->plan_nuniq.alloc((size_t)nb);

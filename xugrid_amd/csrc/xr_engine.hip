@@ -38,6 +38,7 @@ static Lane g_lanes[N_LANES];
 static std::mutex g_pool_mutex; // the block pool and the kernel-timer tables are shared by all threads
 
 Lane *current_lane() { return t_lane; }
+bool exclusive_held() { return t_exclusive_depth > 0; }
 
 static thread_local hipStream_t t_stream_override = nullptr;
 hipStream_t stream_override() { return t_stream_override; }

@@ -196,6 +196,7 @@ struct Lane {
     std::mutex busy;
 };
 Lane *current_lane(); // the calling thread's lane, nullptr on the engine's own (exclusive) path
+bool exclusive_held(); // the calling thread is inside an entry point that holds the engine exclusively
 
 hipStream_t stream_override(); // a stream the calling thread has redirected its launches to (StreamOverride), or nullptr
 inline hipStream_t launch_stream() {
