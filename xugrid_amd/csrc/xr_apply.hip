@@ -419,11 +419,25 @@ k_apply_rows1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ in
         const int nl = *n_long;
         apply_wave_rows<METHOD, SRC, 1>(indptr, indices, data, row_order, long_rows, nl, (int)blockIdx.x * (AP_BLOCK / 64) + wib,
                                         n_long_blocks * (AP_BLOCK / 64), T, S, source, 1, out, nullptr);
-        if (any_huge) { // (uniform per block: every thread walks the list)
-            for (int li = blockIdx.x; li < nl; li += n_long_blocks) {
-                const int t = long_rows[li];
-                if (indptr[t + 1] - indptr[t] > APPLY_WAVE)
-                    apply_row_block<METHOD, SRC>(indptr, indices, data, row_order, t, T, S, source, 1, out, sh_merge);
+        if (any_huge) {
+            // rows beyond the wave kernel's reach, a block each.  The block's share of the list is looked at by all its
+            // threads AT ONCE (entry li = block + n_long_blocks * thread: two dependent loads per thread, in flight
+            // together) and the few hits are parked in LDS -- walking the share entry by entry was a chain of ~9 x 2
+            // dependent round trips that made these blocks the last to finish (the kernel's 28 us on the benchmark).
+            int *sh_list = reinterpret_cast<int *>(&sh_win[1][0]), *sh_cnt = reinterpret_cast<int *>(&sh_win[2][0]);
+            for (int base = 0; base < nl; base += n_long_blocks * AP_BLOCK) {
+                if (threadIdx.x == 0) *sh_cnt = 0;
+                __syncthreads();
+                const int li = base + (int)blockIdx.x + n_long_blocks * (int)threadIdx.x;
+                if (li < nl) {
+                    const int t = long_rows[li];
+                    if (indptr[t + 1] - indptr[t] > APPLY_WAVE) sh_list[atomicAdd(sh_cnt, 1)] = t; // (at most one per thread)
+                }
+                __syncthreads();
+                const int n_hit = *sh_cnt;
+                for (int i = 0; i < n_hit; i++) // (uniform: every thread of the block works on the row)
+                    apply_row_block<METHOD, SRC>(indptr, indices, data, row_order, sh_list[i], T, S, source, 1, out, sh_merge);
+                __syncthreads();
             }
         }
         return;
