@@ -10,6 +10,26 @@
 
 #include "xr_objects.h"
 
+// query points of a barycentric construction + "inside the source grid" flags, resident in HBM (xr_locate_flags_begin)
+struct xr_points {
+    int64_t n = 0;
+    xr_mesh *source = nullptr;
+    xr::DevBuf<double> pts;
+    xr::DevBuf<uint8_t> inside;
+    // The kernels that fill the two buffers (centroids of the query, point location in the source grid) go to the engine's
+    // SIDE stream -- the high-priority stream the big faces of xr_overlap use, known to run beside the main one -- as soon as
+    // the handle is made; the construction that consumes the handle joins the side stream first.  They then run beside the
+    // latency-bound kernels of the Voronoi pre-step instead of in front of them.  (Versions that did not survive: a stream
+    // per handle -- creating and destroying a HIP stream costs 1-3 ms; one extra plain stream -- whether it really runs
+    // beside the engine's depends on how the runtime maps streams onto its few hardware queues: it did in a small script,
+    // not in bench.py; launching them on the main stream right before the host computes the boundary cells -- that host
+    // part turned out too short to hide anything, the gain had come from kernel-beside-kernel.)
+    xr_mesh *query = nullptr;
+    double tol_source = 0.0;
+    bool on_side = false; // launched on the side stream: join before use
+};
+
+
 namespace xr {
 
 // crossing-number test + "strictly within tol of an edge's line, projection on the segment"
@@ -447,6 +467,16 @@ static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
     return 1e-12 * mesh->h_stats[6]; // ugridbase.py:1165-1170
 }
 
+static void launch_points(xr_points *h) {
+    if (h->query) mesh_centroids_dev(h->query, h->pts.get());
+    xr_mesh *source = h->source;
+    XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(h->n, 256)), dim3(256), 0, source->rec_fxy.get(),
+              source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
+              source->rec_face.get(), source->n_face, h->pts.get(), h->n, h->tol_source, h->inside.get());
+}
+
+void flush_pending_points() {} // (kept for the Voronoi pre-step's call site: nothing is deferred any more)
+
 } // namespace xr
 
 using namespace xr;
@@ -539,54 +569,21 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 
 // vertex v of the tessellation belongs to source face v for v < n_identity (the face centroids come first) and to
 // vertex_face[v - n_identity] beyond (projections: their face; substitute vertices: -1)
-// query points of a barycentric construction + "inside the source grid" flags, resident in HBM (xr_locate_flags_begin)
-struct xr_points {
-    int64_t n = 0;
-    xr_mesh *source = nullptr;
-    xr::DevBuf<double> pts;
-    xr::DevBuf<uint8_t> inside;
-    // The kernels that fill the two buffers run on a stream of the handle's own: the engine's stream is synchronised by the
-    // calls the caller makes next (the Voronoi pre-step reads its boundary rows back), and a kernel queued there would be
-    // waited for -- on its own stream it keeps running while the host computes.  `ready`: recorded behind them.
-    // (ONE auxiliary stream per process, created on first use: creating and destroying a HIP stream costs milliseconds)
-    hipStream_t stream = nullptr;
-    hipEvent_t ready = nullptr;
-    ~xr_points() {
-        if (stream) (void)hipStreamSynchronize(stream);
-        if (ready) (void)hipEventDestroy(ready);
-    }
-};
-
-static hipStream_t aux_stream() {
-    static hipStream_t s = nullptr; // (callers hold the engine's exclusive lock)
-    if (!s) XR_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    return s;
-}
 
 // the source-side part of UnstructuredGrid2d.barycentric (unstructured.py:147, 188-190) -- the query points and
 // `grid.locate_points(points) == -1` -- enqueued WITHOUT a final wait: it needs nothing of the Voronoi tessellation
 static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, DevBuf<double> &pts,
-                         DevBuf<uint8_t> &inside, xr_points *own_stream = nullptr) {
+                         DevBuf<uint8_t> &inside) {
     mesh_prepare(source, false);
     mesh_build_index(source);
     const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
     pts.alloc((size_t)n * 2);
     inside.alloc((size_t)n);
-    if (!query) h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n); // (synchronous, engine stream)
-    std::unique_ptr<StreamOverride> redirect;
-    if (own_stream) {
-        // the handle's stream starts behind everything enqueued so far (index of the source, pool blocks in stream order)
-        own_stream->stream = aux_stream();
-        XR_HIP(hipEventCreateWithFlags(&own_stream->ready, hipEventDisableTiming));
-        XR_HIP(hipEventRecord(own_stream->ready, launch_stream()));
-        XR_HIP(hipStreamWaitEvent(own_stream->stream, own_stream->ready, 0));
-        redirect.reset(new StreamOverride(own_stream->stream));
-    }
     if (query) mesh_centroids_dev(query, pts.get());
+    else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
     XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
               source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
               source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
-    if (own_stream) XR_HIP(hipEventRecord(own_stream->ready, own_stream->stream));
 }
 
 static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, const double *points, int64_t n,
@@ -633,7 +630,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             DevBuf<double> own_pts, w((size_t)n * m);
             DevBuf<uint8_t> own_inside;
             if (!pre) locate_flags(source, query, points, n, own_pts, own_inside);
-            else if (pre->ready) XR_HIP(hipStreamWaitEvent(launch_stream(), pre->ready, 0)); // (filled on the handle's stream)
+            else if (pre->on_side) { // (filled on the side stream: the main stream waits for it here)
+                side_join();
+                pre->on_side = false;
+            }
             DevBuf<double> &pts = pre ? pre->pts : own_pts;
             DevBuf<uint8_t> &inside = pre ? pre->inside : own_inside;
             // the vertex table the weight slots are paired with: the caller's order as the reference does
@@ -707,7 +707,20 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
     try {
         h->n = n;
         h->source = source;
-        if (n > 0 && source->n_face > 0) locate_flags(source, query, points, n, h->pts, h->inside, h);
+        if (n > 0 && source->n_face > 0) {
+            mesh_prepare(source, false);
+            mesh_build_index(source);
+            h->tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
+            h->pts.alloc((size_t)n * 2);
+            h->inside.alloc((size_t)n);
+            h->query = query;
+            if (!query) h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            {
+                SideScope side; // (forks behind everything enqueued so far: the index of the source grid, the points)
+                launch_points(h);
+            }
+            h->on_side = true;
+        }
         else if (n > 0) { // (no source faces: every point is outside)
             h->pts.alloc((size_t)n * 2);
             h->inside.alloc((size_t)n);
@@ -719,7 +732,7 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
         delete h;
         throw;
     }
-    *out = h; // (no wait: the kernels run while the caller goes on -- e.g. builds the Voronoi tessellation's boundary cells)
+    *out = h; // (no wait: the kernels run on the side stream beside whatever the caller does next)
     XR_API_END
 }
 

@@ -144,6 +144,7 @@ const double *mesh_area(xr_mesh *mesh); // connectivity.area in the caller's fac
 void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex blocks exist
 void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
+void flush_pending_points(); // launch the deferred source-side kernels of pending xr_points handles (xr_locate.hip)
 void mesh_read_stats(xr_mesh *mesh, bool need_exact = false); // need_exact: statistics over ALL faces (sampled ones are redone)
 void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev);    // connectivity.centroids into device memory [n_face*2]
 void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order = false); // CCW-normalised (or the caller's) connectivity [n_face*m]

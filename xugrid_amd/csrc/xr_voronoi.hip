@@ -316,6 +316,9 @@ static double np_pairwise_sum(const double *a, int64_t n) { // numpy's DOUBLE_pa
 static void voronoi_boundary_cells(xr_voronoi *v) {
     if (v->cells_ready) return;
     voronoi_boundary(v);
+    // (the boundary rows are on the host now; whatever device work is waiting for a good moment -- the source-side half of a
+    // barycentric construction -- goes out here, and runs while the host builds the boundary cells below)
+    flush_pending_points();
     const auto tk0 = std::chrono::steady_clock::now();
     const int64_t nb = (int64_t)v->b_nodes.size(), ne = (int64_t)v->edge_face.size(), n_face = v->n_face;
     v->c_extra_xy.clear(); v->c_cells.clear(); v->c_tail.clear(); v->c_interp.clear();
