@@ -205,3 +205,16 @@ def test_g10_replace_interpolated_weights(golden, oracle, tag):
     w = g[f"{tag}_weights_in"].copy()
     host_replace(*args, w, node_map, threshold)
     assert np.array_equal(w, exp)
+
+
+def test_oracle_runs_clean_under_sanitizers():
+    """the C oracle under AddressSanitizer + UndefinedBehaviorSanitizer on small seeded inputs --
+    every entry point of xr_oracle.h (tree, overlap incl. SAT and brute force, every reducer, COO, area / centroids,
+    locate with and without tolerance, barycentric weights, network edges); any finding aborts the driver."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run(["make", "-C", os.path.join(root, "oracle"), "sanitize"], capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    assert "sanitize_driver ok" in proc.stdout
