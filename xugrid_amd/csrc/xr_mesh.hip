@@ -889,7 +889,11 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
     // face is reported.  Nothing waits for the last DMA: the arrays are consumed, later work is stream-ordered behind it.
     // (XR_INGEST=device: raw upload + k_ingest_faces on the device, as until round 3 -- measurement switch.)
     const size_t cnt = (size_t)n_face * (size_t)n_max_node;
-    static const bool device_ingest = getenv("XR_INGEST") && !strcmp(getenv("XR_INGEST"), "device");
+    // (Meshes of less than 1 MB take the device-side ingest: two plain copies and a kernel, no pinned staging buffers --
+    // those are 2 x 64 MiB of pinned host memory, allocated on first use.)
+    static const bool device_ingest_env = getenv("XR_INGEST") && !strcmp(getenv("XR_INGEST"), "device");
+    const bool device_ingest =
+        device_ingest_env || cnt * (size_t)faces_itemsize + sizeof(double) * 2 * (size_t)n_node < ((size_t)1 << 20);
     xr_mesh *mesh = new xr_mesh();
     try {
         mesh->n_node = n_node;
