@@ -402,17 +402,18 @@ k_apply_wave(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
 // stages the CSR segment of its 64 consecutive rows -- contiguous -- in a private LDS window in chunks of W1_CAP entries
 // (column and weight loaded coalesced, the source value gathered by the same lane and parked next to the weight), then every
 // lane reduces ITS row from the window, sequentially in CSR order (bit-identical to the reference loop,
-// regridder.py:52-62).  No block barrier anywhere and 5 KB of LDS per wave: 32 waves per CU keep three dependent
+// regridder.py:52-62).  No block barrier anywhere and 6 KB of LDS per wave: 24 waves per CU keep three dependent
 // round trips (row pointers -> entries -> source values) in flight, where the block-wide version (k_apply_stream, 32 KB
 // and four barriers per block) held 20 (MI355X, 1M x 1M benchmark: 42.6 -> see DESIGN section 5).
-static constexpr int W1_CAP = 320; // entries per wave window: 64 rows x 4 entries (the mean of a triangle pair) + slack
+static constexpr int W1_CAP = 384; // entries per wave window: 64 rows x 4 entries (the mean of a triangle pair) + slack for the tail
+                                   // (measured on the 1M x 1M matrix: 256 / 320 / 384 / 448 entries -> kernel 31 / 30 / 27 / 27 us)
 template <int METHOD, typename SRC>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_rows1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
               const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
               const int32_t *__restrict__ n_long, int n_long_blocks, bool any_huge, int64_t T, int64_t S,
               const SRC *__restrict__ source, double *__restrict__ out) {
-    __shared__ double2 sh_win[AP_BLOCK / 64][W1_CAP]; // (.x = weight, .y = source value); 20 KB: 8 blocks per CU
+    __shared__ double2 sh_win[AP_BLOCK / 64][W1_CAP]; // (.x = weight, .y = source value); 24 KB: 6 blocks per CU
     double(*sh_merge)[3] = reinterpret_cast<double(*)[3]>(&sh_win[0][0]); // (long-row blocks stage nothing)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_long_blocks) {
