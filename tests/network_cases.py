@@ -22,6 +22,36 @@ def reference_case():
     return raster, node_xy, edge_nodes, data, (x_loc, y_loc, expected)
 
 
+def line_selection_cases():
+    """Known answers of the reference's line selections, which are numba_celltree.intersect_edges results
+    post-processed by selection_utils.py:27-32 / ugridbase.py:1371-1450 (piece midpoints, distance along the line):
+    tests/test_ugrid2d.py:1153-1190 and tests/test_ugrid_dataset.py:255-281 on the seven-node mesh of two unit
+    quads below two triangles.  Returns (nodes, faces, cases); a case is (segments (n, 2, 2), face ids, mid x,
+    mid y, s) in the order of increasing s."""
+    nodes = np.array([[0.0, 0.0], [1.0, 0.0], [2.0, 0.0], [0.0, 1.0], [1.0, 1.0], [2.0, 1.0], [1.0, 2.0]])
+    faces = np.array([[0, 1, 4, 3], [1, 2, 5, 4], [3, 4, 6, -1], [4, 5, 6, -1]])
+    r2 = np.sqrt(2.0)
+    diagonal = (np.array([[[0.0, 0.0], [2.0, 2.0]]]), [0, 3], [0.5, 1.25], [0.5, 1.25], [0.5 * r2, 1.25 * r2])
+    # faces 1 and 2 are touched at the corner (1, 1) only: no piece.  The bend (1.5, 1.5) lies ON the hypotenuse of face 3.
+    bend = (np.array([[[0.5, 0.5], [1.5, 0.5]], [[1.5, 0.5], [1.5, 1.5]]]), [0, 1, 1, 3], [0.75, 1.25, 1.5, 1.5],
+            [0.5, 0.5, 0.75, 1.25], [0.25, 0.75, 1.25, 1.75])
+    # ugrid2d.sel with a full slice in x and y = 0.5 (and x = 0.5, all y): tests/test_ugrid2d.py:1120-1145; the line
+    # spans the bounding box of the mesh
+    along_x = (np.array([[[0.0, 0.5], [2.0, 0.5]]]), [0, 1], [0.5, 1.5], [0.5, 0.5], [0.5, 1.5])
+    along_y = (np.array([[[0.5, 0.0], [0.5, 2.0]]]), [0, 2], [0.5, 0.5], [0.5, 1.25], [0.5, 1.25])
+    return nodes, faces, (diagonal, bend, along_x, along_y)
+
+
+def line_selection_of_pairs(segments, edge_idx, face_idx, intersections):
+    """selection_utils.py:27-32 + ugridbase.py:1412-1450 on intersect_edges output: (faces, mid x, mid y, s) by s."""
+    mid = 0.5 * (intersections[:, 0, :] + intersections[:, 1, :])
+    seg_len = np.hypot(*(segments[:, 1] - segments[:, 0]).T)
+    before = np.concatenate(([0.0], np.cumsum(seg_len)[:-1]))
+    s = np.hypot(*(mid - segments[edge_idx, 0]).T) + before[edge_idx]
+    order = np.argsort(s, kind="stable")
+    return face_idx[order], mid[order, 0], mid[order, 1], s[order]
+
+
 def raster_quads(x_edges, y_edges):
     """node_xy, faces (row-major over y then x) of the rectilinear grid with the given cell edges."""
     nx, ny = len(x_edges) - 1, len(y_edges) - 1

@@ -4,7 +4,8 @@ NetworkGridder path."""
 import numpy as np
 import pytest
 
-from network_cases import csr_from_pairs, random_network, raster_quads, reference_case
+from network_cases import (csr_from_pairs, line_selection_cases, line_selection_of_pairs, random_network, raster_quads,
+                           reference_case)
 
 
 def test_reference_known_answer(oracle):
@@ -23,6 +24,27 @@ def test_reference_known_answer(oracle):
     # transient data: twice the values -> twice the means (:107-131)
     out2 = oracle.regrid_csr("mean", np.stack([data, 2 * data]), w, cols, indptr, 16)
     np.testing.assert_allclose(out2[1, cells], 2 * expected)
+
+
+def test_reference_line_selection_known_answers(oracle):
+    """The intersect_edges results behind the reference's intersect_line / intersect_linestring / sel(x=slice, y=c)
+    tests (tests/test_ugrid2d.py:1120-1190, tests/test_ugrid_dataset.py:255-281): faces crossed, midpoints and
+    distance along the line of every piece, in both directions of travel."""
+    nodes, faces, cases = line_selection_cases()
+    tree = oracle.CellTree2d(nodes, faces)
+    for segments, exp_faces, exp_x, exp_y, exp_s in cases:
+        e, f, xy = tree.intersect_edges(segments)
+        got_f, got_x, got_y, got_s = line_selection_of_pairs(segments, e, f, xy)
+        assert np.array_equal(got_f, exp_faces)
+        np.testing.assert_allclose(got_x, exp_x, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(got_y, exp_y, rtol=0, atol=1e-15)
+        np.testing.assert_allclose(got_s, exp_s, rtol=1e-15)
+        back = segments[::-1, ::-1]  # the same line walked from its end (test_ugrid2d.py:1165-1166)
+        e, f, xy = tree.intersect_edges(back)
+        got_f, _, _, got_s = line_selection_of_pairs(back, e, f, xy)
+        assert np.array_equal(got_f, exp_faces[::-1])
+        total = np.hypot(*(segments[:, 1] - segments[:, 0]).T).sum()
+        np.testing.assert_allclose(got_s, total - np.asarray(exp_s)[::-1], rtol=1e-15)
 
 
 def test_pieces_tile_the_edge(oracle):

@@ -258,9 +258,44 @@ static void pool_release_deferred() {
     g_side_active = false;
 }
 
+// ---------------------------------------------------------------------------------------------
+// "zero at rest" scratch words (see xr_internal.h)
+// ---------------------------------------------------------------------------------------------
+static int32_t *g_zero_buf[ZERO_SLOTS] = {nullptr, nullptr};
+static size_t g_zero_cap[ZERO_SLOTS] = {0, 0};
+static bool g_zero_dirty[ZERO_SLOTS] = {false, false};
+
+int32_t *zero_scratch(int slot, size_t n_words) {
+    if (!exclusive_held() || stream_override() || engine().on_side || n_words > ZERO_SCRATCH_MAX_WORDS) return nullptr;
+    if (n_words > g_zero_cap[slot]) {
+        if (g_zero_buf[slot]) pool_free(g_zero_buf[slot]);
+        g_zero_buf[slot] = nullptr;
+        g_zero_cap[slot] = 0;
+        const size_t cap = n_words < 1024 ? 1024 : n_words + n_words / 4; // (meshes of about one size keep their buffer)
+        g_zero_buf[slot] = static_cast<int32_t *>(pool_alloc(cap * sizeof(int32_t)));
+        g_zero_cap[slot] = cap;
+        g_zero_dirty[slot] = true;
+    }
+    if (g_zero_dirty[slot]) XR_HIP(hipMemsetAsync(g_zero_buf[slot], 0, g_zero_cap[slot] * sizeof(int32_t), engine().stream));
+    g_zero_dirty[slot] = true; // until the caller has enqueued the kernel that restores the zeros
+    return g_zero_buf[slot];
+}
+
+void zero_scratch_done(int slot) { g_zero_dirty[slot] = false; }
+
+static void zero_scratch_drop() {
+    for (int s = 0; s < ZERO_SLOTS; s++) {
+        if (g_zero_buf[s]) pool_free(g_zero_buf[s]);
+        g_zero_buf[s] = nullptr;
+        g_zero_cap[s] = 0;
+        g_zero_dirty[s] = false;
+    }
+}
+
 void pool_trim() {
     if (g_engine.stream) (void)hipStreamSynchronize(g_engine.stream);
     pool_release_deferred();
+    zero_scratch_drop();
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &kv : g_free) (void)hipFree(kv.second);
     g_free.clear();

@@ -143,6 +143,18 @@ template <typename T> struct DevBuf {
     size_t bytes() const { return n * sizeof(T); }
 };
 
+// "Zero at rest" scratch words: int32 arrays the engine keeps between calls and that are ALL ZERO whenever no call is
+// using them -- so the hot path has no memset (a hipMemsetAsync is a 4-5 us kernel plus its launch gap; an odd length
+// even two).  The user's own kernels restore the zeros: a histogram that is counted up and handed out down to zero
+// (mesh index build), counters that the kernel publishing them clears (xr_overlap).  zero_scratch() -> the words (all
+// zero in stream order), or nullptr when the cache does not apply (not the engine's own stream, too large): the caller
+// then allocates and clears as before.  zero_scratch_done() says the restoring kernel has been enqueued; a call that
+// fails before that leaves the slot marked dirty and the next user clears it.  Exclusive calls only.
+static constexpr int ZERO_SLOTS = 2;                                     // 0: bucket histogram, 1: overlap counters
+static constexpr size_t ZERO_SCRATCH_MAX_WORDS = (size_t)16 << 20;       // 64 MB; larger histograms are not kept
+int32_t *zero_scratch(int slot, size_t n_words);
+void zero_scratch_done(int slot);
+
 void h2d(void *dst, const void *src, size_t bytes);       // synchronous w.r.t. the host
 void d2h(void *dst, const void *src, size_t bytes);       // stream-ordered, then synchronised
 void stream_sync();

@@ -623,35 +623,45 @@ static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams 
                          int32_t *bucket_start, int32_t *perm, double *o_fxy, uint8_t *o_len, double *o_bbox,
                          float *o_recbb) {
     const int64_t F = mesh->n_face;
-    DevBuf<int32_t> key((size_t)F), count((size_t)n_buckets);
-    XR_HIP(hipMemsetAsync(count.get(), 0, sizeof(int32_t) * (size_t)n_buckets, launch_stream()));
+    // The histogram lives in the engine's zero-at-rest scratch: the count pass raises it, the scatter pass hands the slots
+    // out from the top down -- every bucket is back at zero when the scatter has run, so the next build needs no memset
+    // (one launch, or two when the length is odd: 9 us + gaps of a 0.56 ms step).
+    DevBuf<int32_t> key((size_t)F), count_own;
+    int32_t *count = zero_scratch(0, (size_t)n_buckets);
+    const bool cached = count != nullptr;
+    if (!cached) {
+        count_own.alloc((size_t)n_buckets);
+        count = count_own.get();
+        XR_HIP(hipMemsetAsync(count, 0, sizeof(int32_t) * (((size_t)n_buckets + 3) & ~(size_t)3), launch_stream())); // (blocks are >= 4 KB: one fill kernel)
+    }
     if (F > 0) {
         const char *name = INDEX ? "index_count" : "order_count";
         const dim3 grid(div_up(F, 256)), block(256);
         if (mesh->m == 3)
             XR_LAUNCH(name, (k_spatial_count<INDEX, 3>), grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F,
-                      mesh->m, g, mp, key.get(), count.get());
+                      mesh->m, g, mp, key.get(), count);
         else if (mesh->m == 4)
             XR_LAUNCH(name, (k_spatial_count<INDEX, 4>), grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F,
-                      mesh->m, g, mp, key.get(), count.get());
+                      mesh->m, g, mp, key.get(), count);
         else
             XR_LAUNCH(name, (k_spatial_count<INDEX, 0>), grid, block, 0, mesh->node_xy.get(), mesh->faces_raw.get(), F,
-                      mesh->m, g, mp, key.get(), count.get());
+                      mesh->m, g, mp, key.get(), count);
     }
-    exclusive_scan_i32(count.get(), bucket_start, n_buckets);
+    exclusive_scan_i32(count, bucket_start, n_buckets);
     if (F > 0) {
         const char *name = INDEX ? "index_scatter" : "order_scatter";
         const dim3 grid(div_up(F, 256)), block(256);
         if (mesh->m == 3)
-            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 3>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count.get(),
+            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 3>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count,
                       mesh->node_xy.get(), mesh->faces_raw.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
         else if (mesh->m == 4)
-            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 4>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count.get(),
+            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 4>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count,
                       mesh->node_xy.get(), mesh->faces_raw.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
         else
-            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 0>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count.get(),
+            XR_LAUNCH(name, (k_spatial_scatter<INDEX, 0>), grid, block, 0, key.get(), F, mesh->m, bucket_start, count,
                       mesh->node_xy.get(), mesh->faces_raw.get(), perm, o_fxy, o_len, o_bbox, o_recbb, g.x0, g.y0);
     }
+    if (cached) zero_scratch_done(0);
 }
 
 void mesh_query_order(xr_mesh *mesh) {

@@ -69,6 +69,10 @@ __device__ __forceinline__ int64_t xcd_block(int64_t n_blocks, bool remap) {
 static constexpr int BIGREC_MAX = 1024;  // records of the upper grid levels handled as a list
 static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may touch one block's bounding box
 
+// PACK: the owning thread of a parked candidate rides in the top 8 bits of the record id (trees of at most 2^24 faces) instead
+// of a byte array of its own: 19.5 instead of 23.5 KB of LDS per block = 8 instead of 6 resident blocks per CU for a
+// kernel that is a chain of dependent loads.
+template <bool PACK>
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
          const int32_t *__restrict__ cell_start,
@@ -76,9 +80,10 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
          int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
          int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key, int32_t *__restrict__ nnz_row,
-         bool remap, int32_t *__restrict__ blk_rows = nullptr /* optional: regular (non-big) faces per block, written */) {
+         bool remap, int32_t *__restrict__ blk_rows = nullptr /* optional: regular (non-big) faces per block, written */,
+         int32_t *__restrict__ blk_surv = nullptr /* optional: the clip's survivor count of the block, cleared here */) {
     __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
-    __shared__ uint8_t sh_owner[SLOTS * 256];
+    __shared__ uint8_t sh_owner[PACK ? 1 : SLOTS * 256];
     __shared__ __attribute__((aligned(16))) float4 sh_bigbb[BIGREC_BLOCK];
     __shared__ int32_t sh_bigrec[BIGREC_BLOCK];
     __shared__ float sh_box[4][4];
@@ -87,7 +92,11 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
     __shared__ int32_t sh_base;
     const int64_t n_blocks = (n_query + 255) / 256;
     const int64_t lb = xcd_block(n_blocks, remap);
-    if (lb >= n_blocks) return;
+    if (threadIdx.x == 0 && blk_surv) blk_surv[lb] = 0; // (every hardware block owns one word, also the idle ones of the rounded grid)
+    if (lb >= n_blocks) {
+        if (threadIdx.x == 0 && blk_rows) blk_rows[lb] = 0;
+        return;
+    }
     const int64_t t = lb * 256 + threadIdx.x;
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     // ---- level split (uniform: scalar loads)
@@ -253,8 +262,8 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
 #pragma unroll
     for (int j = 0; j < SLOTS; j++) {
         if (j < mine) {
-            flat[lo + j] = own[j];
-            sh_owner[lo + j] = (uint8_t)threadIdx.x;
+            flat[lo + j] = PACK ? (own[j] | (int32_t)(threadIdx.x << 24)) : own[j];
+            if (!PACK) sh_owner[lo + j] = (uint8_t)threadIdx.x;
         }
     }
     __syncthreads();
@@ -266,8 +275,9 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
     if (threadIdx.x == 0) block_seg[lb] = make_int2(base, total);
     const int32_t t0 = (int32_t)(lb * 256);
     for (int i = threadIdx.x; i < total; i += 256) {
-        cand_tgt[base + i] = t0 + sh_owner[i];
-        cand_src[base + i] = flat[i];
+        const int32_t v = flat[i];
+        cand_tgt[base + i] = t0 + (PACK ? (int32_t)((uint32_t)v >> 24) : (int32_t)sh_owner[i]);
+        cand_src[base + i] = PACK ? (v & 0xffffff) : v;
     }
 }
 
@@ -309,7 +319,15 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
 // not fit the queue as currently allocated are listed and filled by a second launch (FUSED = false) after the host
 // regrew it.  (The two-walk version -- count, reserve, fill -- took twice as long per face, and a big face is a
 // chain of dependent phases: the kernel's duration is the slowest face's.)
-static constexpr int BIG_STAGE = 5120;
+static constexpr int BIG_STAGE = 5120; // default size of the stage (dynamic LDS; XR_BIG_STAGE overrides: tuning hook)
+static int big_stage_entries() {
+    static const int n = [] {
+        const char *e = getenv("XR_BIG_STAGE");
+        const int v = e ? atoi(e) : BIG_STAGE;
+        return v < 64 ? 64 : (v > 12288 ? 12288 : v);
+    }();
+    return n;
+}
 static constexpr int BIG_RANK_MAX = 1 << 16; // big faces ranked by id (all-pairs, inside k_search_big); longer lists keep their order
 
 template <bool FUSED>
@@ -321,13 +339,14 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
              const int32_t *__restrict__ n_big, int32_t *__restrict__ cand_off, int32_t *__restrict__ cand_count,
              int32_t *__restrict__ cand_tgt, int32_t *__restrict__ cand_src, int32_t *__restrict__ queue_cursor,
              int64_t capacity, int32_t *__restrict__ pending_list, int32_t *__restrict__ n_pending,
+             int big_stage /* entries of the LDS stage (FUSED) */,
              int32_t *__restrict__ slot_face = nullptr /* optional: the listed faces in ascending id order, written */) {
     __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     // one BLOCK per big face: its four waves take the 64-row batches round-robin; candidates are
     // appended through a per-face cursor in LDS (their order inside the row is irrelevant: rows are
     // ranked by tree face id afterwards)
     __shared__ double2 sh_poly[XR_MAX_FACE_NODES];
-    __shared__ int32_t sh_stage[FUSED ? BIG_STAGE : 1];
+    extern __shared__ int32_t sh_stage[]; // [big_stage] (FUSED) / [1]
     __shared__ int sh_cursor;
     __shared__ int sh_out0;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -378,7 +397,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                 __syncthreads();
                 const int out = sh_out0;
                 if (out < 0) break;
-                if (n <= BIG_STAGE) { // everything is parked: copy it out, no second walk
+                if (n <= big_stage) { // everything is parked: copy it out, no second walk
                     for (int i = threadIdx.x; i < n; i += 256) {
                         cand_tgt[out + i] = t;
                         cand_src[out + i] = sh_stage[i];
@@ -454,7 +473,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                             if (hit) {
                                 const int slot = slot0 + __popcll(mask & lt_mask);
                                 if (STAGE) {
-                                    if (slot < BIG_STAGE) sh_stage[FUSED ? slot : 0] = r;
+                                    if (slot < big_stage) sh_stage[FUSED ? slot : 0] = r;
                                 } else {
                                     cand_tgt[out0 + slot] = t;
                                     cand_src[out0 + slot] = r;
@@ -477,7 +496,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                     for (int r = r0; r < my_r1; r++) {
                         if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
                             if (STAGE) {
-                                if (pos < BIG_STAGE) sh_stage[FUSED ? pos : 0] = r;
+                                if (pos < big_stage) sh_stage[FUSED ? pos : 0] = r;
                             } else {
                                 cand_tgt[out0 + pos] = t;
                                 cand_src[out0 + pos] = r;
@@ -1223,10 +1242,12 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     // ctl: [0] regular queue cursor, [1] big queue cursor, [2] big faces, [3] big faces that did not fit, [4] clip
     // overflows among the big pairs | FusedCounters | look-back status words
     // | per block of 256 target faces: survivors (clip), regular faces (search)
-    DevBuf<int32_t> ctl(8 + sizeof(FusedCounters) / 4 + 4 * (size_t)grid);
-    FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl.get() + 8);
-    unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl.get() + 16);
-    int32_t *blk_surv = ctl.get() + 16 + 2 * (size_t)grid, *blk_rows = blk_surv + grid;
+    // The 16 counter words come from the engine's zero-at-rest scratch (k_publish_all clears them again after copying them
+    // to the mailbox) and k_search clears its block's survivor count: no memset in front of the search.
+    constexpr size_t CTL_HEAD = 8 + sizeof(FusedCounters) / 4;
+    DevBuf<int32_t> ctl_tail(4 * (size_t)grid), ctl_own;
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl_tail.get());
+    int32_t *blk_surv = ctl_tail.get() + 2 * (size_t)grid, *blk_rows = blk_surv + grid;
     DevBuf<int32_t> blk_base(2 * (size_t)grid); // first stored row / CSR base of every hardware block (k_assemble_scan)
     // XR_ASSEMBLE_SCAN=0: the assembly finds its bases by the decoupled look-back instead (measurement / fallback switch)
     // (default 2: every assembly block sums the counts of the blocks in front of it itself; 1: a one-block scan kernel
@@ -1272,27 +1293,43 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         DevBuf<int32_t> big_tgt((size_t)big_capacity), big_src((size_t)big_capacity), big_sid((size_t)big_capacity),
             big_indices((size_t)big_capacity);
         DevBuf<double> big_area((size_t)big_capacity), big_data((size_t)big_capacity);
-        XR_HIP(hipMemsetAsync(ctl.get(), 0, ctl.bytes(), st));
-        XR_LAUNCH("search", k_search, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
-                  tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl.get() + 0,
-                  block_seg.get(), is_big.get(), big_list.get(), ctl.get() + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                  remap, scan_bases ? blk_rows : (int32_t *)nullptr);
+        int32_t *ctl_head = zero_scratch(1, CTL_HEAD);
+        const bool ctl_cached = ctl_head != nullptr;
+        if (!ctl_cached) {
+            ctl_own.alloc(CTL_HEAD);
+            ctl_head = ctl_own.get();
+            XR_HIP(hipMemsetAsync(ctl_head, 0, CTL_HEAD * sizeof(int32_t), st));
+        }
+        FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl_head + 8);
+        if (!scan_bases) XR_HIP(hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)grid, st)); // (look-back words: XR_ASSEMBLE_SCAN=0 only)
+        static const bool pack_ok = !(getenv("XR_SEARCH_PACK") && atoi(getenv("XR_SEARCH_PACK")) == 0); // (A/B switch)
+        if (pack_ok && tree->n_face <= ((int64_t)1 << 24))
+            XR_LAUNCH("search", k_search<true>, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
+                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
+                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
+                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
+        else
+            XR_LAUNCH("search", k_search<false>, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
+                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
+                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
+                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
         {
             // ---- side stream: everything about the big faces except their final placement
             SideScope side;
-            XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
+            XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), sizeof(int32_t) * (size_t)big_stage_entries(),
+                      query->qo_bbox(), query->qo_fxy(),
                       query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
-                      big_list.get(), ctl.get() + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
-                      ctl.get() + 1, big_capacity, pending.get(), ctl.get() + 3, slot_face.get());
+                      big_list.get(), ctl_head + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
+                      ctl_head + 1, big_capacity, pending.get(), ctl_head + 3, big_stage_entries(), slot_face.get());
             // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
             XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
-                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl.get() + 1,
-                      big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl.get() + 3);
+                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
+                      big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3);
             // (rows in face order: ranked inside search_big; their offsets: scanned inside row_fill_long -- two launches less
             // in what is the critical path of the whole weight build)
             XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
                       cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
-                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl.get() + 2, (int64_t)0, ctl.get() + 3,
+                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
                       nnz_row.get(), big_indptr.get(), &fc->p_big);
         }
         // Persistent blocks per CU: five fill the LDS and the register files (best for the clip alone).  The big faces' chain
@@ -1304,12 +1341,12 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         if (scan_bases)
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                      ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr);
         else
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 0>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                      ctl.get() + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, (int32_t *)nullptr);
         if (scan_mode == 1)
             XR_LAUNCH("assemble_scan", k_assemble_scan, dim3(1), dim3(1024), 0, blk_rows, blk_surv, (int64_t)n_blocks, (int)grid,
@@ -1331,11 +1368,12 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                   scan_mode == 1 ? blk_base.get() + grid : (const int32_t *)nullptr,
                   scan_mode == 2 ? blk_rows : (const int32_t *)nullptr, scan_mode == 2 ? blk_surv : (const int32_t *)nullptr);
         side_join();
-        XR_LAUNCH("place_big", k_place_big, dim3(64), dim3(256), 0, ctl.get() + 2, slot_face.get(), big_indptr.get(),
+        XR_LAUNCH("place_big", k_place_big, dim3(64), dim3(256), 0, ctl_head + 2, slot_face.get(), big_indptr.get(),
                   big_indices.get(), big_data.get(), T, query->qo_perm(), query->qo_bbox(), tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, csr->indptr.get(), csr->indices.get(),
-                  csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, ctl.get() + 3);
-        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl.get(), fc, csr->n_long.get(), mail);
+                  csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, ctl_head + 3);
+        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl_head, fc, csr->n_long.get(), mail);
+        if (ctl_cached) zero_scratch_done(1); // (the counters are zero again behind k_publish_all)
         mailbox_wait();
         const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], n_pending = mail[3], big_overflow = mail[4];
         const int32_t err = mail[5], rows_regular = mail[6], p_regular = mail[8], p_big = mail[9];
@@ -1437,15 +1475,22 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
     XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
     DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     const bool remap_search = xcd_remap_mask() & 2, remap_rows = xcd_remap_mask() & 4;
-    XR_LAUNCH("search", k_search, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
-              tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
-              cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
-              csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
+    if (tree->n_face <= ((int64_t)1 << 24))
+        XR_LAUNCH("search", k_search<true>, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
+                  tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
+                  cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
+                  csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
+    else
+        XR_LAUNCH("search", k_search<false>, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
+                  tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
+                  cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
+                  csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
     DevBuf<int32_t> pending((size_t)T);
-    XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
+    XR_LAUNCH("search_big", k_search_big<true>, dim3(big_grid), dim3(256), sizeof(int32_t) * (size_t)big_stage_entries(),
+              query->qo_bbox(), query->qo_fxy(),
               query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
               big_list.get(), counters.get() + 2, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
-              counters.get() + 3, capacity, pending.get(), counters.get() + 1);
+              counters.get() + 3, capacity, pending.get(), counters.get() + 1, big_stage_entries());
     // queue length and number of big faces still to be filled -> host
     int32_t *mail = const_cast<int32_t *>(engine().mailbox);
     XR_LAUNCH("publish", k_publish, dim3(1), dim3(64), 0, counters.get() + 3, mail + 0, counters.get() + 1, mail + 3);
@@ -1464,10 +1509,10 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         cand_src = std::move(bigger_src);
         capacity = C;
         h2d(counters.get() + 1, &n_pending, sizeof(int32_t)); // (k_publish zeroed the device copy)
-        XR_LAUNCH("search_big_fill", k_search_big<false>, dim3(big_grid), dim3(256), 0, query->qo_bbox(), query->qo_fxy(),
+        XR_LAUNCH("search_big_fill", k_search_big<false>, dim3(big_grid), dim3(256), sizeof(int32_t), query->qo_bbox(), query->qo_fxy(),
                   query->qo_len(), query->qo_off(), query->m, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_face.get(),
                   pending.get(), counters.get() + 1, cand_off.get(), cand_count.get(), cand_tgt.get(), cand_src.get(),
-                  (int32_t *)nullptr, capacity, (int32_t *)nullptr, (int32_t *)nullptr);
+                  (int32_t *)nullptr, capacity, (int32_t *)nullptr, (int32_t *)nullptr, 0);
         XR_HIP(hipMemsetAsync(counters.get() + 1, 0, sizeof(int32_t), st));
     }
     // (counters[1], zeroed again by k_publish, is reused below as the number of long rows)

@@ -43,6 +43,9 @@ struct FusedCounters {                    // device words, zeroed before the lau
     int32_t max_row;                      // entries of the longest row (atomicMax)
     int32_t pad2;
 };
+static_assert(offsetof(FusedCounters, error) == 4 && offsetof(FusedCounters, p_regular) == 8 && offsetof(FusedCounters, rows_regular) == 12 &&
+                  offsetof(FusedCounters, p_big) == 16 && offsetof(FusedCounters, max_row) == 24,
+              "k_publish_all addresses the fields by word");
 
 // Decoupled look-back: one 64-bit status word per block -- nothing yet / the block's own aggregate / its inclusive prefix.
 // Value: rows in bits 31..61, entries in bits 0..30 (both totals stay below 2^31, so sums never carry across).  Blocks
@@ -677,18 +680,29 @@ k_place_big(const int32_t *__restrict__ n_big_dev, const int32_t *__restrict__ s
 }
 
 // sizes, error bits and the long-row count -> host mailbox / device word of the matrix (after everything else)
-__global__ void k_publish_all(const int32_t *__restrict__ c /* search counters */, const FusedCounters *__restrict__ fc,
+// ... and clears all of them behind itself: the counter words are the engine's zero-at-rest scratch (the next xr_overlap
+// starts without a memset).  One wave.
+__global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right behind them (c + 8) */, FusedCounters *fc,
                               int32_t *__restrict__ n_apply_long_out, int32_t *mail) {
-    if (threadIdx.x < 5) mail[threadIdx.x] = c[threadIdx.x]; // regular pairs, big pairs, big faces, not fitting, (unused)
-    if (threadIdx.x == 0) {
-        mail[5] = fc->error;
-        mail[6] = fc->rows_regular;
-        mail[7] = fc->n_apply_long;
-        mail[8] = fc->p_regular;
-        mail[9] = fc->p_big;
-        mail[10] = fc->max_row;
-        *n_apply_long_out = fc->n_apply_long;
-    }
+    // one load per lane (the 16 words are one line), so the host's wait is one round trip long
+    const int t = threadIdx.x;
+    int32_t w = 0;
+    if (t < 16) w = c[t];
+    // mailbox slot of word t: [0..4] regular pairs, big pairs, big faces, not fitting, (unused); then the FusedCounters
+    // fields in the order the host reads them: error, rows_regular, n_apply_long, p_regular, p_big, max_row
+    int slot = -1;
+    if (t < 5) slot = t;
+    else if (t == 8 + 1) slot = 5;
+    else if (t == 8 + 3) slot = 6;
+    else if (t == 8 + 0) slot = 7;
+    else if (t == 8 + 2) slot = 8;
+    else if (t == 8 + 4) slot = 9;
+    else if (t == 8 + 6) slot = 10;
+    if (slot >= 0) mail[slot] = w;
+    if (t == 8) *n_apply_long_out = w;
+    __builtin_amdgcn_s_waitcnt(0); // (every load above has returned before the words are cleared)
+    if (t < 16) c[t] = 0;
+    (void)fc;
 }
 
 } // namespace xr
