@@ -9,6 +9,7 @@
 #include <memory>
 
 #include "xr_objects.h"
+#include "xr_point_in_face.h"
 
 // query points of a barycentric construction + "inside the source grid" flags, resident in HBM (xr_locate_flags_begin)
 struct xr_points {
@@ -32,30 +33,9 @@ struct xr_points {
 
 namespace xr {
 
-// crossing-number test + "strictly within tol of an edge's line, projection on the segment"
-__device__ bool point_in_face(const double *__restrict__ poly, int n, P2 p, double tol) {
-    bool c = false;
-    P2 v0 = load_p2(poly, n - 1);
-    for (int i = 0; i < n; i++) {
-        const P2 v1 = load_p2(poly, i);
-        const double wx = v1.x - v0.x, wy = v1.y - v0.y;
-        const double len2 = wx * wx + wy * wy;
-        if (len2 > 0) {
-            const double ux = p.x - v0.x, uy = p.y - v0.y;
-            const double twice_area = fabs(wx * uy - wy * ux);
-            const double len = sqrt(len2);
-            if (twice_area < tol * len) {
-                const double tpar = ux * wx + uy * wy;
-                if (tpar >= 0 && tpar <= len2) return true;
-            }
-            if ((v0.y > p.y) != (v1.y > p.y)) {
-                const double xint = wx * (p.y - v0.y) / wy + v0.x;
-                if (p.x < xint) c = !c;
-            }
-        }
-        v0 = v1;
-    }
-    return c;
+// crossing-number test + "strictly within tol of an edge's line, projection on the segment" (xr_point_in_face.h)
+__device__ __forceinline__ bool point_in_face(const double *__restrict__ poly, int n, P2 p, double tol) {
+    return point_in_face_impl([&](int i) { return load_p2(poly, i); }, n, p, tol);
 }
 
 // Level split (as in xr_overlap.hip:k_search): the records of the upper grid levels -- the hull slivers of a Delaunay
@@ -72,6 +52,8 @@ static constexpr int LOC_CAND = 8;        // parked candidates per point; furthe
 
 struct LocateBig { // per block, in LDS
     int32_t cand[LOC_CAND][256];
+    unsigned long long best[256];       // per point: (face id << 32) | record of the lowest matching face so far; ~0: none
+    uint16_t owner[4][64 * LOC_CAND];   // per wave: the parked candidates of its lanes as one list, lane | slot << 8
     float4 bb[LOC_BIG_BLOCK];
     int32_t rec[LOC_BIG_BLOCK];
     float box[4][4];
@@ -135,47 +117,86 @@ __device__ int locate_prepare(LocateBig &sh, const GridParams &g, const int32_t 
     return l_split;
 }
 
-// -> record index of the matching face with the LOWEST caller face id, or -1
-__device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
-                            const GridParams &g, const int32_t *__restrict__ cell_start,
-                            const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, P2 p, double tol,
-                            LocateBig &big, int l_split) {
+// record r passed the f32 bbox test of point q: exact bbox, then the polygon test; a match lowers *best = (face id << 32) | record
+__device__ __forceinline__ void consider_record(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+                                                const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int r,
+                                                P2 q, double tol, unsigned long long *best) {
+    const int f = rec_face[r];
+    if ((uint32_t)(*best >> 32) < (uint32_t)f) return; // a lower face already holds the point
+    const double *poly = rec_fxy + 2 * face_vertex_base(rec_off, r, m);
+    const int n = rec_len[r];
+    // exact bbox of the face (the same min/max the prepare kernel stored)
+    double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+    for (int j = 0; j < n; j++) {
+        const P2 v = load_p2(poly, j);
+        xmin = fmin(xmin, v.x);
+        xmax = fmax(xmax, v.x);
+        ymin = fmin(ymin, v.y);
+        ymax = fmax(ymax, v.y);
+    }
+    if (q.x < xmin - tol || q.x > xmax + tol || q.y < ymin - tol || q.y > ymax + tol) return;
+    if (point_in_face(poly, n, q, tol))
+        atomicMin(best, ((unsigned long long)(uint32_t)f << 32) | (unsigned long long)(uint32_t)r);
+}
+
+// The plain walk -- every record whose f32 box holds the point is tested on the spot -- for the rare point with more
+// candidates than LOC_CAND parking slots (stacked or sliver faces).  Kept apart from the fast path below, which then holds ONE copy
+// of the exact test in its loop (a called function would cost scratch and 50 registers: 3 instead of 5 waves per SIMD).
+__device__ __forceinline__ void locate_point_slow(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+                                               const int32_t *__restrict__ rec_off, int m, const GridParams &g,
+                                               const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
+                                               const int32_t *__restrict__ rec_face, P2 p, double tol, LocateBig &big, int l_split,
+                                               unsigned long long *best) {
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const float qx0 = f32_below(p.x - tol - g.x0), qx1 = f32_above(p.x + tol - g.x0);
     const float qy0 = f32_below(p.y - tol - g.y0), qy1 = f32_above(p.y + tol - g.y0);
-    int best = -1, best_rec = -1;
-    // record r passed the f32 bbox test: exact bbox, then the polygon test; the lowest face id wins
-    auto consider = [&](int r) {
-        const int f = rec_face[r];
-        if (best >= 0 && f > best) return;
-        const double *poly = rec_fxy + 2 * face_vertex_base(rec_off, r, m);
-        const int n = rec_len[r];
-        // exact bbox of the face (the same min/max the prepare kernel stored)
-        double xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
-        for (int j = 0; j < n; j++) {
-            const P2 v = load_p2(poly, j);
-            xmin = fmin(xmin, v.x);
-            xmax = fmax(xmax, v.x);
-            ymin = fmin(ymin, v.y);
-            ymax = fmax(ymax, v.y);
-        }
-        if (p.x < xmin - tol || p.x > xmax + tol || p.y < ymin - tol || p.y > ymax + tol) return;
-        if (point_in_face(poly, n, p, tol)) {
-            best = f;
-            best_rec = r;
-        }
-    };
-    int nc = 0;
-    auto park = [&](int r) {
-        if (nc < LOC_CAND) big.cand[nc][threadIdx.x] = r;
-        else consider(r);
-        nc++;
-    };
     for (int l = 0; l < l_split; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
         const int cx0 = cell_coord(p.x - tol - h, g.x0, inv_h, nx), cx1 = cell_coord(p.x + tol, g.x0, inv_h, nx);
         const int cy0 = cell_coord(p.y - tol - h, g.y0, inv_h, ny), cy1 = cell_coord(p.y + tol, g.y0, inv_h, ny);
+        for (int cy = cy0; cy <= cy1; cy++) {
+            const int r0 = cell_start[base + cy * nx + cx0], r1 = cell_start[base + cy * nx + cx1 + 1];
+            for (int r = r0; r < r1; r++)
+                if (box_gap(rbb[r], qx0, qx1, qy0, qy1) <= 0.0f) consider_record(rec_fxy, rec_len, rec_off, m, rec_face, r, p, tol, best);
+        }
+    }
+    const int nb = big.n;
+    for (int k = 0; k < nb; k++)
+        if (box_gap(big.bb[k], qx0, qx1, qy0, qy1) <= 0.0f) consider_record(rec_fxy, rec_len, rec_off, m, rec_face, big.rec[k], p, tol, best);
+}
+
+// -> record index of the matching face with the LOWEST caller face id, or -1.  BLOCK-cooperative: call with all 256
+// threads (`valid` = the thread has a point).
+// The walk PARKS the records whose f32 box holds the point; the exact tests are then dealt out evenly over the lanes of the
+// wave.  Per point the walk parks ~2 candidates (triangles) but the fullest lane of a wave has 4-5, and a loop over "my
+// candidates" makes all 64 lanes step through that many exact tests -- the kernels are VALU-bound on them (PMC: 2200-3500
+// vector instructions per wave, vector ALUs busy 57-63 %).  Instead every wave lists the parked candidates of its lanes
+// in LDS, lane i takes items i, i + 64, ... (the point comes from its owner by a cross-lane read), and a match lowers the
+// owner's (face id, record) word by an LDS atomic min.
+// Cells: the level-0 cells of the point's box, once; the level-l cell is that >> l exactly and the cell of x - h_l is one
+// less (as in k_search, xr_overlap.hip): no per-level floating-point cell arithmetic.
+__device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
+                            const GridParams &g, const int32_t *__restrict__ cell_start,
+                            const float *__restrict__ rec_bb, const int32_t *__restrict__ rec_face, P2 p, bool valid, double tol,
+                            LocateBig &big, int l_split) {
+    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float qx0 = f32_below(p.x - tol - g.x0), qx1 = f32_above(p.x + tol - g.x0);
+    const float qy0 = f32_below(p.y - tol - g.y0), qy1 = f32_above(p.y + tol - g.y0);
+    big.best[tid] = ~0ull;
+    int nc = 0;
+    auto park = [&](int r) {
+        big.cand[nc < LOC_CAND ? nc : LOC_CAND - 1][tid] = r; // (beyond the slots: the point takes the plain walk below)
+        nc++;
+    };
+    const int c_x0 = cell_coord(p.x - tol, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(p.x + tol, g.x0, g.inv_h0, g.nx[0]);
+    const int c_y0 = cell_coord(p.y - tol, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(p.y + tol, g.y0, g.inv_h0, g.ny[0]);
+    for (int l = 0; l < l_split && valid; l++) {
+        const int nx = g.nx[l], base = g.base[l];
+        const int sh = l * LEVEL_SHIFT;
+        const int cx0 = max((c_x0 >> sh) - 1, 0), cx1 = c_x1 >> sh;
+        const int cy0 = max((c_y0 >> sh) - 1, 0), cy1 = c_y1 >> sh;
         for (int cy = cy0; cy <= cy1; cy++) {
             const int r0 = cell_start[base + cy * nx + cx0];
             const int r1 = cell_start[base + cy * nx + cx1 + 1];
@@ -197,14 +218,35 @@ __device__ int locate_point(const double *__restrict__ rec_fxy, const uint8_t *_
             }
         }
     }
-    const int nb = big.n;
+    const int nb = valid ? big.n : 0;
     for (int k = 0; k < nb; k++) { // the upper-level records that touch this block (from LDS)
         const float4 b = big.bb[k];
         if (box_gap(b, qx0, qx1, qy0, qy1) <= 0.0f) park(big.rec[k]);
     }
-    const int parked = nc < LOC_CAND ? nc : LOC_CAND;
-    for (int k = 0; k < parked; k++) consider(big.cand[k][threadIdx.x]);
-    return best_rec;
+    // the wave's list of parked candidates
+    const bool overflow = nc > LOC_CAND;
+    const int parked = overflow ? 0 : nc;
+    int incl = parked;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    const int total = __shfl(incl, 63, 64), excl = incl - parked;
+    for (int k = 0; k < parked; k++) big.owner[wv][excl + k] = (uint16_t)(lane | (k << 8));
+    __syncthreads(); // (the list, the candidates and every point's `best` word are in LDS)
+    for (int first = 0; first < total; first += 64) { // (wave-uniform)
+        const int item = first + lane;
+        const bool has = item < total;
+        const int ow = has ? big.owner[wv][item] : 0;
+        const int ol = ow & 63, slot = ow >> 8;
+        const P2 q{__shfl(p.x, ol, 64), __shfl(p.y, ol, 64)};
+        if (has) consider_record(rec_fxy, rec_len, rec_off, m, rec_face, big.cand[slot][wv * 64 + ol], q, tol, &big.best[wv * 64 + ol]);
+    }
+    if (overflow) locate_point_slow(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, big, l_split, &big.best[tid]);
+    __syncthreads();
+    const unsigned long long b = big.best[tid];
+    return b == ~0ull ? -1 : (int)(uint32_t)b;
 }
 
 __global__ void __launch_bounds__(256)
@@ -217,8 +259,8 @@ k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len
     const bool valid = i < n;
     const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
     if (!valid) return;
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     out[i] = r >= 0 ? rec_face[r] : -1;
 }
 
@@ -227,36 +269,43 @@ k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len
 // weights are aligned with the CCW-normalised vertex order of the face (as numba_celltree's).
 __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, double tol, double *__restrict__ w,
                              int64_t ws = 1) {
+    // (vertices roll through registers and indices wrap by a compare: `% n` with a run-time n is a ~40-instruction integer
+    // division, and the loops below had five of them per vertex)
     // pass 1: on-edge detection
-    for (int i = 0; i < n; i++) {
-        const P2 v0 = load_p2(poly, i), v1 = load_p2(poly, (i + 1) % n);
-        const double wx = v1.x - v0.x, wy = v1.y - v0.y;
-        const double ux = p.x - v0.x, uy = p.y - v0.y;
-        const double a = wx * uy - wy * ux;
-        const double len2 = wx * wx + wy * wy;
-        if (len2 > 0) {
-            const double len = sqrt(len2);
-            if (fabs(a) < tol * len) {
-                const double tpar = ux * wx + uy * wy;
-                if (tpar >= 0 && tpar <= len2) {
-                    double tt = tpar / len2;
-                    if (tt < 0) tt = 0;
-                    if (tt > 1) tt = 1;
-                    w[(i) * ws] = 1.0 - tt;
-                    w[((i + 1) % n) * ws] = tt;
-                    return;
+    {
+        P2 v0 = load_p2(poly, 0);
+        for (int i = 0; i < n; i++) {
+            const int in = i + 1 == n ? 0 : i + 1;
+            const P2 v1 = load_p2(poly, in);
+            const double wx = v1.x - v0.x, wy = v1.y - v0.y;
+            const double ux = p.x - v0.x, uy = p.y - v0.y;
+            const double a = wx * uy - wy * ux;
+            const double len2 = wx * wx + wy * wy;
+            if (len2 > 0 && !edge_certainly_far(fabs(a), len2, tol)) { // (xr_point_in_face.h: the square root only where it decides)
+                const double len = sqrt(len2);
+                if (fabs(a) < tol * len) {
+                    const double tpar = ux * wx + uy * wy;
+                    if (tpar >= 0 && tpar <= len2) {
+                        double tt = tpar / len2;
+                        if (tt < 0) tt = 0;
+                        if (tt > 1) tt = 1;
+                        w[(i) * ws] = 1.0 - tt;
+                        w[(in) * ws] = tt;
+                        return;
+                    }
                 }
             }
+            v0 = v1;
         }
     }
-    auto A = [&](int i) { // cross(v_i - p, v_{i+1} - p) in the oracle's form
-        const P2 v0 = load_p2(poly, i), v1 = load_p2(poly, (i + 1) % n);
+    auto cross_at = [&](P2 v0, P2 v1) { // cross(v_i - p, v_{i+1} - p) in the oracle's form
         const double wx = v1.x - v0.x, wy = v1.y - v0.y;
         const double ux = p.x - v0.x, uy = p.y - v0.y;
         return wx * uy - wy * ux;
     };
     if (n == 3) {
-        const double a0 = A(0), a1 = A(1), a2 = A(2);
+        const P2 v0 = load_p2(poly, 0), v1 = load_p2(poly, 1), v2 = load_p2(poly, 2);
+        const double a0 = cross_at(v0, v1), a1 = cross_at(v1, v2), a2 = cross_at(v2, v0);
         const double s = a0 + a1 + a2;
         w[(0) * ws] = a1 / s;
         w[(1) * ws] = a2 / s;
@@ -264,13 +313,18 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
         return;
     }
     double wsum = 0.0;
+    P2 vp = load_p2(poly, n - 1), vi = load_p2(poly, 0);
+    double a_prev = cross_at(vp, vi); // A(n - 1)
     for (int i = 0; i < n; i++) {
-        const int ip = (i + n - 1) % n, in = (i + 1) % n;
-        const P2 vp = load_p2(poly, ip), vi = load_p2(poly, i), vn = load_p2(poly, in);
+        const P2 vn = load_p2(poly, i + 1 == n ? 0 : i + 1);
+        const double a_i = cross_at(vi, vn);
         const double cx = (vi.x - vp.x) * (vn.y - vi.y) - (vi.y - vp.y) * (vn.x - vi.x);
-        const double wi = cx / (A(ip) * A(i));
+        const double wi = cx / (a_prev * a_i);
         w[(i) * ws] = wi;
         wsum += wi;
+        vp = vi;
+        vi = vn;
+        a_prev = a_i;
     }
     for (int i = 0; i < n; i++) w[(i) * ws] = w[(i) * ws] / wsum;
 }
@@ -285,8 +339,8 @@ k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
     const bool valid = i < n;
     const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
     if (!valid) return;
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     face_out[i] = r >= 0 ? rec_face[r] : -1;
     double *w = weights + i * m;
     for (int j = 0; j < m; j++) w[j] = 0.0;
@@ -308,8 +362,8 @@ k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__
     const bool valid = i < n;
     const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
     if (!valid) return;
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     face_out[i] = r >= 0 ? rec_face[r] : -1;
     if (r < 0) return;
     double *w = weights + i;
@@ -328,8 +382,8 @@ k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
     const bool valid = i < n;
     const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
-    if (!valid) return;
-    inside[i] = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split) >= 0;
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
+    if (valid) inside[i] = r >= 0;
 }
 
 // replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) on the point's own row, then the
@@ -431,8 +485,8 @@ k_locate_col(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec
     const bool valid = i < n;
     const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
+    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
     if (!valid) return;
-    const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, tol, sh_big, l_split);
     col[i] = r >= 0 ? rec_face[r] : -1;
     found[i] = r >= 0;
 }

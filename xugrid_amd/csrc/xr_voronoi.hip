@@ -105,7 +105,7 @@ k_vor_exterior(const int32_t *__restrict__ faces, int64_t n_face, int m, const i
     const int32_t *face = faces + f * m;
     const int n = face_len(face, m);
     if (j >= n) return;
-    const int a = face[j], b = face[(j + 1) % n];
+    const int a = face[j], b = face[j + 1 == n ? 0 : j + 1]; // (wrap by compare: `% n` with a run-time n is an integer division)
     if (a == b) return;
     bool shared = false;
     for (int r = indptr[a]; r < indptr[a + 1] && !shared; r++) {
@@ -115,7 +115,7 @@ k_vor_exterior(const int32_t *__restrict__ faces, int64_t n_face, int m, const i
         const int k = face_len(other, m);
         for (int t = 0; t < k; t++) {
             if (other[t] != a) continue;
-            if (other[(t + 1) % k] == b || other[(t + k - 1) % k] == b) shared = true;
+            if (other[t + 1 == k ? 0 : t + 1] == b || other[t == 0 ? k - 1 : t - 1] == b) shared = true;
         }
     }
     if (shared) return;
