@@ -531,6 +531,16 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
         # B_bary = 16 n + 4 sum(M_v) + 16 N_vv + 4 sum(M_s) + 16 Ns + 16 nnz_b  with sum(M_v) ~ 3 S, N_vv ~ S
         b_bary = 16 * n_pts + 12 * S3 + 16 * S3 + 12 * S3 + 16 * Ns3 + 16 * nnz_b
         med_first, med_cached = float(np.median(first)), float(np.median(cached))
+        # the centroid locator on the same pair: locate the 4M target centroids in the source + CSR of (row, face, 1.0)
+        loc_ms = []
+        for _ in range(5):
+            E.dev_sync()
+            t0 = time.perf_counter()
+            loc = xa.CentroidLocatorRegridder(src_g, tgt_g)
+            E.dev_sync()
+            loc_ms.append(1e3 * (time.perf_counter() - t0))
+        loc_nnz = loc._device_weights.nnz
+        del loc
         out["config3_barycentric_1M_to_4M"] = {
             "workload": f"BASELINE config 3: {'Delaunay' if delaunay else 'lattice-split'} source S={S3} (seed 0) -> "
                         f"{n_pts} query points = centroids of a {'Delaunay' if delaunay else 'lattice-split'} target (2M points, "
@@ -538,6 +548,8 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
             "construct_ms": 1e3 * med_first, "construct_ms_min": 1e3 * min(first), "construct_ms_max": 1e3 * max(first),
             "construct_ms_voronoi_cached": 1e3 * med_cached,
             "target_points_per_s": n_pts / med_first, "nnz": nnz_b,
+            "centroid_locator_construct_ms": float(np.median(loc_ms)), "centroid_locator_points_per_s": n_pts / (1e-3 * float(np.median(loc_ms))),
+            "centroid_locator_nnz": loc_nnz,
             "roofline": {
                 "bound": "hbm", "kernel": dominant3, "algorithmic_bytes": b_bary,
                 "avg_launch_ms": dom3_ms, "launches": kt.records[dominant3][0],
