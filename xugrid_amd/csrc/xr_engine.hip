@@ -142,6 +142,7 @@ void engine_init(int device) {
     }
     XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, hipEventDisableTiming));
     XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, hipEventDisableTiming));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.aux_event, hipEventDisableTiming));
     g_engine.device = device;
 }
 

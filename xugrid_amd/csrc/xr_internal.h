@@ -102,6 +102,7 @@ struct Engine {
     // forked / joined with events, never synchronised with the host on its own
     hipStream_t side = nullptr;
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    hipEvent_t aux_event = nullptr; // a point INSIDE the side stream's work the main stream may wait for before the full join
     bool on_side = false; // XR_LAUNCH and the kernel timer go to the side stream while set
 };
 inline hipStream_t launch_stream();

@@ -28,6 +28,7 @@ struct xr_points {
     xr_mesh *query = nullptr;
     double tol_source = 0.0;
     bool on_side = false; // launched on the side stream: join before use
+    bool pts_marked = false; // the engine's aux_event was recorded behind the kernel that fills `pts` (before locate_flag)
 };
 
 
@@ -523,6 +524,13 @@ static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
 
 static void launch_points(xr_points *h) {
     if (h->query) mesh_centroids_dev(h->query, h->pts.get());
+    if (engine().on_side && !current_lane()) {
+        // the consumer needs the points long before it needs the flags: it waits for this mark first and joins the side
+        // stream only in front of the kernel that reads `inside` (on a cached tessellation locate_flag then runs BESIDE the
+        // barycentric kernel instead of in front of it)
+        XR_HIP(hipEventRecord(engine().aux_event, engine().side));
+        h->pts_marked = true;
+    }
     xr_mesh *source = h->source;
     XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(h->n, 256)), dim3(256), 0, source->rec_fxy.get(),
               source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
@@ -684,9 +692,15 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             DevBuf<double> own_pts, w((size_t)n * m);
             DevBuf<uint8_t> own_inside;
             if (!pre) locate_flags(source, query, points, n, own_pts, own_inside);
-            else if (pre->on_side) { // (filled on the side stream: the main stream waits for it here)
-                side_join();
-                pre->on_side = false;
+            bool join_later = false;
+            if (pre && pre->on_side) { // (filled on the side stream)
+                if (pre->pts_marked) { // the points now, the flags in front of bary_fix_count
+                    XR_HIP(hipStreamWaitEvent(engine().stream, engine().aux_event, 0));
+                    join_later = true;
+                } else {
+                    side_join();
+                    pre->on_side = false;
+                }
             }
             DevBuf<double> &pts = pre ? pre->pts : own_pts;
             DevBuf<uint8_t> &inside = pre ? pre->inside : own_inside;
@@ -705,6 +719,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
                       voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get());
+            if (join_later) {
+                side_join();
+                pre->on_side = false;
+            }
             if (reference_order)
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                           voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());

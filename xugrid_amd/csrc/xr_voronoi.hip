@@ -97,7 +97,7 @@ __device__ __forceinline__ int face_len(const int32_t *__restrict__ face, int m)
 __global__ void __launch_bounds__(256)
 k_vor_exterior(const int32_t *__restrict__ faces, int64_t n_face, int m, const int32_t *__restrict__ indptr,
                const int32_t *__restrict__ rows, uint8_t *__restrict__ on_boundary, int32_t *__restrict__ n_edges,
-               int32_t *__restrict__ e_lo, int32_t *__restrict__ e_hi, int32_t *__restrict__ e_face) {
+               int32_t *__restrict__ e_all /* (lo, hi, face) per exterior edge: one download */) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n_face * m) return;
     const int64_t f = i / m;
@@ -144,9 +144,19 @@ k_vor_exterior(const int32_t *__restrict__ faces, int64_t n_face, int m, const i
     on_boundary[a] = 1;
     on_boundary[b] = 1;
     const int at = atomicAdd(n_edges, 1);
-    e_lo[at] = a < b ? a : b;
-    e_hi[at] = a < b ? b : a;
-    e_face[at] = (int32_t)f;
+    e_all[3 * (int64_t)at] = a < b ? a : b;
+    e_all[3 * (int64_t)at + 1] = a < b ? b : a;
+    e_all[3 * (int64_t)at + 2] = (int32_t)f;
+}
+
+__global__ void k_vor_init_counters(int32_t *__restrict__ c) {
+    if (threadIdx.x < 8) c[threadIdx.x] = threadIdx.x == 1 ? INT32_MAX : 0;
+}
+__global__ void k_vor_totals(const int32_t *__restrict__ n_interior, const int32_t *__restrict__ nnz, int32_t *__restrict__ c) {
+    if (threadIdx.x == 0) {
+        c[3] = *n_interior;
+        c[4] = *nnz;
+    }
 }
 
 // angle class of a direction in arctan2's order (-pi, pi]: 0: dy < 0, 1: dy == 0 & dx >= 0, 2: dy > 0,
@@ -285,37 +295,69 @@ __global__ void __launch_bounds__(256) k_vor_widen(const int32_t *__restrict__ i
     if (i < n) out[i] = in[i];
 }
 
-// rows of selected nodes: degree, then faces + their centroids
-__global__ void k_vor_row_degree(const int32_t *__restrict__ indptr, const int64_t *__restrict__ nodes, int64_t n,
-                                 int64_t *__restrict__ deg) {
+// everything the host needs about the boundary except the rows themselves, in ONE launch: per boundary node its degree and
+// coordinates, per exterior edge the centroid of its face.  `in` = [nodes (nb) | edge faces (ne)]; `out` (8-byte words) =
+// [degree (nb, int64) | node xy (2 nb) | edge-face xy (2 ne)]
+__global__ void __launch_bounds__(256)
+k_vor_boundary_info(const int32_t *__restrict__ indptr, const double *__restrict__ node_xy, const double *__restrict__ centroids,
+                    const int64_t *__restrict__ in, int64_t nb, int64_t ne, int64_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) deg[i] = indptr[nodes[i] + 1] - indptr[nodes[i]];
+    double *out_d = reinterpret_cast<double *>(out);
+    if (i < nb) {
+        const int64_t v = in[i];
+        out[i] = indptr[v + 1] - indptr[v];
+        out_d[nb + 2 * i] = node_xy[2 * v];
+        out_d[nb + 2 * i + 1] = node_xy[2 * v + 1];
+    }
+    if (i < ne) {
+        const int64_t f = in[nb + i];
+        out_d[3 * nb + 2 * i] = centroids[2 * f];
+        out_d[3 * nb + 2 * i + 1] = centroids[2 * f + 1];
+    }
 }
 
+// exclusive scan of the degrees by one block (a few thousand boundary nodes): ptr[0..n]
+__global__ void __launch_bounds__(1024) k_vor_scan_deg(const int64_t *__restrict__ deg, int64_t n, int64_t *__restrict__ ptr) {
+    __shared__ long long sh[1024];
+    const int t = threadIdx.x;
+    const int64_t chunk = (n + 1023) / 1024, i0 = (int64_t)t * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    long long sum = 0;
+    for (int64_t i = i0; i < i1; i++) sum += deg[i];
+    sh[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const long long add = t >= d ? sh[t - d] : 0;
+        __syncthreads();
+        sh[t] += add;
+        __syncthreads();
+    }
+    long long run = sh[t] - sum; // exclusive prefix of this thread's chunk
+    for (int64_t i = i0; i < i1; i++) {
+        ptr[i] = run;
+        run += deg[i];
+    }
+    if (t == 1023) ptr[n] = sh[1023];
+}
+
+// rows of the boundary nodes: `out` (8-byte words) = [faces (total, int64) | their centroids (2 total)]
 __global__ void k_vor_row_gather(const int32_t *__restrict__ indptr, const int32_t *__restrict__ faces_asc,
                                  const double *__restrict__ centroids, const int64_t *__restrict__ nodes,
-                                 const int64_t *__restrict__ ptr, int64_t n, int64_t *__restrict__ faces,
-                                 double *__restrict__ xy) {
+                                 const int64_t *__restrict__ ptr, int64_t n, int64_t total, int64_t *__restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    double *xy = reinterpret_cast<double *>(out) + total;
     const int s = indptr[nodes[i]], e = indptr[nodes[i] + 1];
     for (int r = s; r < e; r++) {
         const int f = faces_asc[r];
         const int64_t o = ptr[i] + (r - s);
-        faces[o] = f;
+        out[o] = f;
         xy[2 * o] = centroids[2 * f];
         xy[2 * o + 1] = centroids[2 * f + 1];
     }
 }
 
-__global__ void k_vor_face_xy(const double *__restrict__ centroids, const int64_t *__restrict__ faces, int64_t n,
-                              double *__restrict__ xy) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    xy[2 * i] = centroids[2 * faces[i]];
-    xy[2 * i + 1] = centroids[2 * faces[i] + 1];
-}
-
+// Three host <-> device round trips (one upload, two downloads of packed buffers) instead of the nine single-array copies
+// this used to make: each is a stream synchronisation, ~20 us with the device idle in between.
 static void voronoi_boundary(xr_voronoi *v) {
     if (v->boundary_ready) return;
     std::vector<int64_t> nodes(v->edge_lo);
@@ -328,43 +370,32 @@ static void voronoi_boundary(xr_voronoi *v) {
     v->b_faces.clear();
     v->b_face_xy.clear();
     v->b_edge_face_xy.assign((size_t)ne * 2, 0.0);
-    if (nb > 0) {
-        DevBuf<int64_t> d_nodes((size_t)nb), d_deg((size_t)nb), d_ptr((size_t)nb + 1);
-        h2d(d_nodes.get(), nodes.data(), sizeof(int64_t) * (size_t)nb);
-        XR_LAUNCH("vor_row_degree", k_vor_row_degree, dim3(div_up(nb, 256)), dim3(256), 0, v->indptr.get(), d_nodes.get(), nb,
-                  d_deg.get());
-        std::vector<int64_t> deg((size_t)nb);
-        d2h(deg.data(), d_deg.get(), sizeof(int64_t) * (size_t)nb);
-        for (int64_t i = 0; i < nb; i++) v->b_ptr[(size_t)i + 1] = v->b_ptr[(size_t)i] + deg[(size_t)i];
+    v->b_node_xy.assign((size_t)nb * 2, 0.0);
+    if (nb + ne > 0) {
+        std::vector<int64_t> in(nodes);
+        in.insert(in.end(), v->edge_face.begin(), v->edge_face.end());
+        DevBuf<int64_t> d_in((size_t)(nb + ne)), d_info((size_t)(3 * nb + 2 * ne)), d_ptr((size_t)nb + 1);
+        h2d(d_in.get(), in.data(), sizeof(int64_t) * (size_t)(nb + ne));
+        XR_LAUNCH("vor_boundary_info", k_vor_boundary_info, dim3(div_up(std::max(nb, ne), 256)), dim3(256), 0, v->indptr.get(),
+                  v->mesh->node_xy.get(), v->centroids.get(), d_in.get(), nb, ne, d_info.get());
+        if (nb > 0) XR_LAUNCH("vor_scan_deg", k_vor_scan_deg, dim3(1), dim3(1024), 0, d_info.get(), nb, d_ptr.get());
+        std::vector<int64_t> info((size_t)(3 * nb + 2 * ne));
+        d2h(info.data(), d_info.get(), sizeof(int64_t) * info.size());
+        for (int64_t i = 0; i < nb; i++) v->b_ptr[(size_t)i + 1] = v->b_ptr[(size_t)i] + info[(size_t)i];
+        if (nb > 0) memcpy(v->b_node_xy.data(), info.data() + nb, sizeof(double) * 2 * (size_t)nb);
+        if (ne > 0) memcpy(v->b_edge_face_xy.data(), info.data() + 3 * nb, sizeof(double) * 2 * (size_t)ne);
         const int64_t total = v->b_ptr[(size_t)nb];
         v->b_faces.resize((size_t)total);
         v->b_face_xy.resize((size_t)total * 2);
         if (total > 0) {
-            DevBuf<int64_t> d_faces((size_t)total);
-            DevBuf<double> d_xy((size_t)total * 2);
-            h2d(d_ptr.get(), v->b_ptr.data(), sizeof(int64_t) * (size_t)(nb + 1));
+            DevBuf<int64_t> d_rows((size_t)(3 * total));
             XR_LAUNCH("vor_row_gather", k_vor_row_gather, dim3(div_up(nb, 256)), dim3(256), 0, v->indptr.get(),
-                      v->faces_asc.get(), v->centroids.get(), d_nodes.get(), d_ptr.get(), nb, d_faces.get(), d_xy.get());
-            d2h(v->b_faces.data(), d_faces.get(), sizeof(int64_t) * (size_t)total);
-            d2h(v->b_face_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)total);
+                      v->faces_asc.get(), v->centroids.get(), d_in.get(), d_ptr.get(), nb, total, d_rows.get());
+            std::vector<int64_t> rows((size_t)(3 * total));
+            d2h(rows.data(), d_rows.get(), sizeof(int64_t) * rows.size());
+            memcpy(v->b_faces.data(), rows.data(), sizeof(int64_t) * (size_t)total);
+            memcpy(v->b_face_xy.data(), rows.data() + total, sizeof(double) * 2 * (size_t)total);
         }
-    }
-    v->b_node_xy.assign((size_t)nb * 2, 0.0);
-    if (nb > 0) {
-        DevBuf<int64_t> d_nodes((size_t)nb);
-        DevBuf<double> d_xy((size_t)nb * 2);
-        h2d(d_nodes.get(), nodes.data(), sizeof(int64_t) * (size_t)nb);
-        XR_LAUNCH("vor_node_xy", k_vor_face_xy, dim3(div_up(nb, 256)), dim3(256), 0, v->mesh->node_xy.get(), d_nodes.get(), nb,
-                  d_xy.get());
-        d2h(v->b_node_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)nb);
-    }
-    if (ne > 0) {
-        DevBuf<int64_t> d_ef((size_t)ne);
-        DevBuf<double> d_xy((size_t)ne * 2);
-        h2d(d_ef.get(), v->edge_face.data(), sizeof(int64_t) * (size_t)ne);
-        XR_LAUNCH("vor_face_xy", k_vor_face_xy, dim3(div_up(ne, 256)), dim3(256), 0, v->centroids.get(), d_ef.get(), ne,
-                  d_xy.get());
-        d2h(v->b_edge_face_xy.data(), d_xy.get(), sizeof(double) * 2 * (size_t)ne);
     }
     v->boundary_ready = true;
 }
@@ -586,25 +617,25 @@ int xr_voronoi_create(xr_mesh *mesh, xr_voronoi **out) {
         if (total > 0)
             XR_LAUNCH("vor_count", k_vor_count, dim3(div_up(total, 256)), dim3(256), 0, mesh->faces_raw.get(), total, count.get());
         exclusive_scan_i32(count.get(), v->indptr.get(), N);
-        v->nnz = read_scalar(v->indptr.get() + N);
-        v->faces_asc.alloc((size_t)v->nnz);
-        v->faces_ccw.alloc((size_t)v->nnz);
+        // (sized by the slot count, an upper bound of the entries: their number is read at the end with the other counters --
+        // the whole construction has TWO host round trips, counters and exterior edges, instead of seven)
+        v->faces_asc.alloc((size_t)std::max<int64_t>(total, 1));
+        v->faces_ccw.alloc((size_t)std::max<int64_t>(total, 1));
         v->interior.alloc((size_t)N);
         v->cell_rank.alloc((size_t)N + 1);
         v->centroids.alloc((size_t)F * 2);
         DevBuf<uint8_t> on_boundary((size_t)N);
-        DevBuf<int32_t> flag32((size_t)N), counters(4), e_lo((size_t)total), e_hi((size_t)total), e_face((size_t)total);
+        DevBuf<int32_t> flag32((size_t)N), counters(8), e_all((size_t)std::max<int64_t>(3 * total, 1));
         XR_HIP(hipMemsetAsync(on_boundary.get(), 0, (size_t)(N > 0 ? N : 1), launch_stream()));
-        const int32_t init[4] = {0, INT32_MAX, 0, 0}; // n_edges, min degree, max degree
-        h2d(counters.get(), init, sizeof(init));
+        // counters: [0] exterior edges, [1] min / [2] max interior degree, [3] interior nodes, [4] entries of the node -> face rows
+        XR_LAUNCH("vor_init", k_vor_init_counters, dim3(1), dim3(64), 0, counters.get());
         if (total > 0) {
             XR_LAUNCH("vor_scatter", k_vor_scatter, dim3(div_up(total, 256)), dim3(256), 0, mesh->faces_raw.get(), total, m,
                       v->indptr.get(), cursor.get(), v->faces_asc.get());
             XR_LAUNCH("vor_sort_rows", k_vor_sort_rows, dim3(div_up(N, 256)), dim3(256), 0, v->indptr.get(), N,
                       v->faces_asc.get());
             XR_LAUNCH("vor_exterior", k_vor_exterior, dim3(div_up(total, 256)), dim3(256), 0, mesh->faces_raw.get(), F, m,
-                      v->indptr.get(), v->faces_asc.get(), on_boundary.get(), counters.get(), e_lo.get(), e_hi.get(),
-                      e_face.get());
+                      v->indptr.get(), v->faces_asc.get(), on_boundary.get(), counters.get(), e_all.get());
         }
         mesh_centroids_dev(mesh, v->centroids.get());
         if (N > 0)
@@ -612,17 +643,23 @@ int xr_voronoi_create(xr_mesh *mesh, xr_voronoi **out) {
                       v->centroids.get(), v->indptr.get(), v->faces_asc.get(), on_boundary.get(), N, v->faces_ccw.get(),
                       v->interior.get(), flag32.get(), counters.get() + 1);
         exclusive_scan_i32(flag32.get(), v->cell_rank.get(), N);
-        int32_t h[4];
+        XR_LAUNCH("vor_totals", k_vor_totals, dim3(1), dim3(64), 0, v->cell_rank.get() + N, v->indptr.get() + N, counters.get());
+        int32_t h[8];
         d2h(h, counters.get(), sizeof(h));
-        v->n_interior = read_scalar(v->cell_rank.get() + N);
+        v->n_interior = h[3];
+        v->nnz = h[4];
         v->min_degree = v->n_interior > 0 ? h[1] : 0;
         v->max_degree = h[2];
         const int64_t ne = h[0];
         std::vector<int32_t> lo((size_t)ne), hi((size_t)ne), fc((size_t)ne);
         if (ne > 0) {
-            d2h(lo.data(), e_lo.get(), sizeof(int32_t) * (size_t)ne);
-            d2h(hi.data(), e_hi.get(), sizeof(int32_t) * (size_t)ne);
-            d2h(fc.data(), e_face.get(), sizeof(int32_t) * (size_t)ne);
+            std::vector<int32_t> all((size_t)(3 * ne));
+            d2h(all.data(), e_all.get(), sizeof(int32_t) * all.size());
+            for (int64_t i = 0; i < ne; i++) {
+                lo[(size_t)i] = all[3 * (size_t)i];
+                hi[(size_t)i] = all[3 * (size_t)i + 1];
+                fc[(size_t)i] = all[3 * (size_t)i + 2];
+            }
         }
         std::vector<int64_t> order((size_t)ne);
         for (int64_t i = 0; i < ne; i++) order[(size_t)i] = i;
