@@ -707,14 +707,20 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             // the vertex table the weight slots are paired with: the caller's order as the reference does
             // (unstructured.py:175,193) = the mesh's own int32 connectivity, read as it is; or -- tree_order -- the tree's
             // counter-clockwise-normalised copy, materialised as a table first
-            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)(reference_order ? 1 : voronoi->n_face * m)), vface((size_t)nv),
-                n2n((size_t)(n_extra > 0 ? 2 * n_extra : 1));
+            // (vertex -> face table and the interpolation map behind it in ONE buffer: their host parts are adjacent, one upload)
+            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)(reference_order ? 1 : voronoi->n_face * m)),
+                ids((size_t)(nv + 2 * n_extra + 1));
+            int64_t *const vface = ids.get(), *const n2n = ids.get() + nv;
             DevBuf<int32_t> count((size_t)n);
             if (n_identity > 0)
-                XR_LAUNCH("iota", k_iota_i64, dim3(div_up(n_identity, 256)), dim3(256), 0, vface.get(), n_identity);
-            if (nv > n_identity)
-                h2d(vface.get() + n_identity, vertex_face, sizeof(int64_t) * (size_t)(nv - n_identity));
-            if (n_extra > 0) h2d(n2n.get(), node_to_node_map, sizeof(int64_t) * 2 * (size_t)n_extra);
+                XR_LAUNCH("iota", k_iota_i64, dim3(div_up(n_identity, 256)), dim3(256), 0, vface, n_identity);
+            {
+                const size_t n_tail = (size_t)(nv - n_identity), n_map = (size_t)(2 * n_extra);
+                std::vector<int64_t> host(n_tail + n_map);
+                if (n_tail > 0) memcpy(host.data(), vertex_face, sizeof(int64_t) * n_tail);
+                if (n_map > 0) memcpy(host.data() + n_tail, node_to_node_map, sizeof(int64_t) * n_map);
+                if (!host.empty()) h2d(vface + n_identity, host.data(), sizeof(int64_t) * host.size());
+            }
             if (!reference_order) mesh_faces_ccw_dev(voronoi, faces_ccw.get(), false);
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
@@ -725,10 +731,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             }
             if (reference_order)
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
+                          voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get());
             else
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          faces_ccw.get(), voronoi->node_xy.get(), n2n.get(), nv - n_extra, inside.get(), n, count.get());
+                          faces_ccw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get());
             exclusive_scan_i32(count.get(), csr->indptr.get(), n);
             const int64_t nnz = read_scalar(csr->indptr.get() + n);
             csr->nnz = nnz;
@@ -736,10 +742,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             csr->data.alloc((size_t)nnz);
             if (nnz > 0 && reference_order)
                 XR_LAUNCH("bary_fill", k_bary_fill<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          voronoi->faces_raw.get(), vface.get(), csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+                          voronoi->faces_raw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get());
             else if (nnz > 0)
                 XR_LAUNCH("bary_fill", k_bary_fill<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          faces_ccw.get(), vface.get(), csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+                          faces_ccw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get());
             stream_sync();
         }
     } catch (...) {
