@@ -268,8 +268,10 @@ k_locate(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len
 // Wachspress coordinates with the on-edge special case; triangles use plain area coordinates.
 // w points at this point's row of the (n, m) weight table (global memory, zero-initialised);
 // weights are aligned with the CCW-normalised vertex order of the face (as numba_celltree's).
-__device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, double tol, double *__restrict__ w,
-                             int64_t ws = 1) {
+// -> the number of weights > 0 among the n it wrote (what the masking of unstructured.py:188-191 keeps for a point
+// inside the source grid whose cell has no substitute vertex)
+__device__ int bary_weights(const double *__restrict__ poly, int n, P2 p, double tol, double *__restrict__ w,
+                            int64_t ws = 1) {
     // (vertices roll through registers and indices wrap by a compare: `% n` with a run-time n is a ~40-instruction integer
     // division, and the loops below had five of them per vertex)
     // pass 1: on-edge detection
@@ -292,7 +294,7 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
                         if (tt > 1) tt = 1;
                         w[(i) * ws] = 1.0 - tt;
                         w[(in) * ws] = tt;
-                        return;
+                        return (1.0 - tt > 0 ? 1 : 0) + (tt > 0 ? 1 : 0);
                     }
                 }
             }
@@ -308,10 +310,11 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
         const P2 v0 = load_p2(poly, 0), v1 = load_p2(poly, 1), v2 = load_p2(poly, 2);
         const double a0 = cross_at(v0, v1), a1 = cross_at(v1, v2), a2 = cross_at(v2, v0);
         const double s = a0 + a1 + a2;
-        w[(0) * ws] = a1 / s;
-        w[(1) * ws] = a2 / s;
-        w[(2) * ws] = a0 / s;
-        return;
+        const double w0 = a1 / s, w1 = a2 / s, w2 = a0 / s;
+        w[(0) * ws] = w0;
+        w[(1) * ws] = w1;
+        w[(2) * ws] = w2;
+        return (w0 > 0 ? 1 : 0) + (w1 > 0 ? 1 : 0) + (w2 > 0 ? 1 : 0);
     }
     double wsum = 0.0;
     P2 vp = load_p2(poly, n - 1), vi = load_p2(poly, 0);
@@ -327,7 +330,13 @@ __device__ void bary_weights(const double *__restrict__ poly, int n, P2 p, doubl
         vi = vn;
         a_prev = a_i;
     }
-    for (int i = 0; i < n; i++) w[(i) * ws] = w[(i) * ws] / wsum;
+    int n_pos = 0;
+    for (int i = 0; i < n; i++) {
+        const double wi = w[(i) * ws] / wsum;
+        w[(i) * ws] = wi;
+        n_pos += wi > 0 ? 1 : 0;
+    }
+    return n_pos;
 }
 
 __global__ void __launch_bounds__(256)
@@ -348,6 +357,8 @@ k_barycentric(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
     if (r >= 0) bary_weights(rec_fxy + 2 * face_vertex_base(rec_off, r, m), rec_len[r], p, tol, w);
 }
 
+static constexpr uint8_t NPOS_FIX = 255;
+
 // ---- BarycentricInterpolator weights assembled on the device (xr_barycentric_csr) ----------------
 // The (n, m) weight table of this pipeline is kept COLUMN-major (weight j of point i at [j * n + i]): the lanes of a
 // wave are neighbouring points, so every access is coalesced, and only the first len(cell) slots of a point are ever
@@ -357,7 +368,9 @@ __global__ void __launch_bounds__(256)
 k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
                  const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
                  const int32_t *__restrict__ rec_face, int64_t n_tree, const double *__restrict__ pts, int64_t n, double tol,
-                 int64_t *__restrict__ face_out, double *__restrict__ weights) {
+                 int64_t *__restrict__ face_out, double *__restrict__ weights,
+                 const uint8_t *__restrict__ cell_flag /* cells with a substitute vertex: their weights are rewritten later */,
+                 uint8_t *__restrict__ n_pos /* weights > 0 of the point; NPOS_FIX: read the weights (flagged cell) */) {
     __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool valid = i < n;
@@ -365,12 +378,29 @@ k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
     const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
     if (!valid) return;
-    face_out[i] = r >= 0 ? rec_face[r] : -1;
-    if (r < 0) return;
+    const int cell = r >= 0 ? rec_face[r] : -1;
+    face_out[i] = cell;
+    if (r < 0) {
+        n_pos[i] = 0;
+        return;
+    }
     double *w = weights + i;
     const int len = rec_len[r];
     for (int j = 0; j < len; j++) w[(int64_t)j * n] = 0.0;
-    bary_weights(rec_fxy + 2 * face_vertex_base(rec_off, r, m), len, p, tol, w, n);
+    const int c = bary_weights(rec_fxy + 2 * face_vertex_base(rec_off, r, m), len, p, tol, w, n);
+    n_pos[i] = cell_flag[cell] ? NPOS_FIX : (uint8_t)c;
+}
+
+// cells of the tessellation that hold a substitute vertex (id >= threshold): only their points go through the weight
+// replacement of bary_fix_count; for all others the barycentric kernel already knows how many weights are positive
+__global__ void __launch_bounds__(256)
+k_bary_cell_flag(const int32_t *__restrict__ faces_raw, int64_t n_cell, int m, int64_t threshold, uint8_t *__restrict__ flag) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_cell) return;
+    const int32_t *face = faces_raw + c * m;
+    bool any = false;
+    for (int j = 0; j < m && face[j] >= 0; j++) any = any || face[j] >= threshold;
+    flag[c] = any;
 }
 
 __global__ void __launch_bounds__(256)
@@ -395,9 +425,16 @@ __global__ void __launch_bounds__(256)
 k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__ weights, int m,
                  const FI *__restrict__ faces_ccw, const double *__restrict__ vxy,
                  const int64_t *__restrict__ node_to_node_map, int64_t threshold,
-                 const uint8_t *__restrict__ inside, int64_t n, int32_t *__restrict__ count) {
+                 const uint8_t *__restrict__ inside, int64_t n, int32_t *__restrict__ count,
+                 const uint8_t *__restrict__ n_pos = nullptr /* optional: see k_barycentric_cm */) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (n_pos && n_pos[i] != NPOS_FIX) {
+        // (no substitute vertex in the point's cell: nothing to rewrite, and the count is known -- 2 bytes read per point
+        // instead of its weights, vertex ids and face id: 0.157 -> see DESIGN ms for 4M points)
+        count[i] = inside[i] ? n_pos[i] : 0;
+        return;
+    }
     const int64_t f = face_of_point[i];
     int c = 0;
     if (f >= 0 && inside[i]) { // (a point outside the source grid keeps no weight, unstructured.py:189-190)
@@ -722,19 +759,22 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                 if (!host.empty()) h2d(vface + n_identity, host.data(), sizeof(int64_t) * host.size());
             }
             if (!reference_order) mesh_faces_ccw_dev(voronoi, faces_ccw.get(), false);
+            DevBuf<uint8_t> cell_flag((size_t)voronoi->n_face), n_pos((size_t)n);
+            XR_LAUNCH("bary_cell_flag", k_bary_cell_flag, dim3(div_up(voronoi->n_face, 256)), dim3(256), 0, voronoi->faces_raw.get(),
+                      voronoi->n_face, m, nv - n_extra, cell_flag.get());
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
-                      voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get());
+                      voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get(), cell_flag.get(), n_pos.get());
             if (join_later) {
                 side_join();
                 pre->on_side = false;
             }
             if (reference_order)
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get());
+                          voronoi->faces_raw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get(), n_pos.get());
             else
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          faces_ccw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get());
+                          faces_ccw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get(), n_pos.get());
             exclusive_scan_i32(count.get(), csr->indptr.get(), n);
             const int64_t nnz = read_scalar(csr->indptr.get() + n);
             csr->nnz = nnz;
