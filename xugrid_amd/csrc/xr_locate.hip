@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256)
 k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict__ weights, int m,
             const FI *__restrict__ faces_ccw, const int64_t *__restrict__ vertex_face,
             const int32_t *__restrict__ indptr, int64_t n, int32_t *__restrict__ indices,
-            double *__restrict__ data) {
+            double *__restrict__ data, int64_t n_identity = 0 /* vertices below it ARE their face (the centroids): no table gather */) {
     __shared__ int32_t sh_idx[FILL_STAGE];
     __shared__ double sh_val[FILL_STAGE];
     const int64_t i0 = (int64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
@@ -491,7 +491,8 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
             for (int j = 0; j < m && face[j] >= 0; j++) {
                 const double wj = w[(int64_t)j * n];
                 if (wj > 0) {
-                    const int32_t col = (int32_t)vertex_face[face[j]];
+                    const int64_t vtx = face[j];
+                    const int32_t col = vtx < n_identity ? (int32_t)vtx : (int32_t)vertex_face[vtx];
                     if (staged) {
                         sh_idx[pos - base] = col;
                         sh_val[pos - base] = wj;
@@ -546,11 +547,6 @@ k_raster_points(const double *__restrict__ x, const double *__restrict__ y, int6
     if (v >= n) return;
     const int64_t j = v / nx, i = v - j * nx;
     reinterpret_cast<double2 *>(pts)[v] = make_double2(x[i], y[j]);
-}
-
-__global__ void k_iota_i64(int64_t *__restrict__ p, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) p[i] = i;
 }
 
 static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
@@ -749,8 +745,7 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                 ids((size_t)(nv + 2 * n_extra + 1));
             int64_t *const vface = ids.get(), *const n2n = ids.get() + nv;
             DevBuf<int32_t> count((size_t)n);
-            if (n_identity > 0)
-                XR_LAUNCH("iota", k_iota_i64, dim3(div_up(n_identity, 256)), dim3(256), 0, vface, n_identity);
+            // (vertices below n_identity are their own face -- the centroids --: bary_fill never reads their table entries)
             {
                 const size_t n_tail = (size_t)(nv - n_identity), n_map = (size_t)(2 * n_extra);
                 std::vector<int64_t> host(n_tail + n_map);
@@ -782,10 +777,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             csr->data.alloc((size_t)nnz);
             if (nnz > 0 && reference_order)
                 XR_LAUNCH("bary_fill", k_bary_fill<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          voronoi->faces_raw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+                          voronoi->faces_raw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity);
             else if (nnz > 0)
                 XR_LAUNCH("bary_fill", k_bary_fill<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          faces_ccw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get());
+                          faces_ccw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity);
             stream_sync();
         }
     } catch (...) {
