@@ -253,7 +253,11 @@ def run_single(args):
     del hs, ht, h_out
     host_to_host_ms = 1e3 * float(np.median(host_times[1:]))  # (the first pass warms the pinned staging path)
 
-    # per-kernel durations: the same K steps with hipEvents around every launch (engine stream)
+    # per-kernel durations: the same K steps with hipEvents around every launch (engine stream); the W warm-up steps again
+    # first (the host-array passes above ran other kernels and released their buffers)
+    for _ in range(args.warmup):
+        step()
+    E.dev_sync()
     with E.KernelTimer() as kt:
         for _ in range(args.steps):
             step()
