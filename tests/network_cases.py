@@ -42,6 +42,21 @@ def line_selection_cases():
     return nodes, faces, (diagonal, bend, along_x, along_y)
 
 
+def burn_lines_case():
+    """tests/test_burn.py:20-27,44-62,135-141 of the reference: _burn_lines (burn.py:153-181) writes ``values[line]`` into every
+    face ``intersect_edges`` reports for a segment of the line, on a 3 x 3 grid of unit quads (face id = 3 row + column).
+    Returns (nodes, faces, segments (5, 2, 2), value per segment, expected output with -1 for untouched faces)."""
+    gy, gx = np.meshgrid(np.arange(4.0), np.arange(4.0), indexing="ij")
+    nodes = np.column_stack([gx.ravel(), gy.ravel()])
+    v = (4 * np.arange(3)[:, None] + np.arange(3)[None, :]).ravel()
+    faces = np.column_stack([v, v + 1, v + 5, v + 4])
+    xy = np.array([[0.5, 0.5], [2.5, 0.5], [1.2, 1.5], [1.8, 1.5], [0.2, 2.2], [0.8, 2.8], [1.2, 2.2], [1.8, 2.8]])
+    segments = np.array([[xy[0], xy[1]], [xy[2], xy[3]], [xy[4], xy[5]], [xy[5], xy[6]], [xy[6], xy[7]]])
+    values = np.array([0.0, 1.0, 2.0, 2.0, 2.0])
+    expected = np.array([0.0, 0.0, 0.0, -1.0, 1.0, -1.0, 2.0, 2.0, -1.0])
+    return nodes, faces, segments, values, expected
+
+
 def line_selection_of_pairs(segments, edge_idx, face_idx, intersections):
     """selection_utils.py:27-32 + ugridbase.py:1412-1450 on intersect_edges output: (faces, mid x, mid y, s) by s."""
     mid = 0.5 * (intersections[:, 0, :] + intersections[:, 1, :])

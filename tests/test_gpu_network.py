@@ -9,8 +9,8 @@ import pytest
 
 import xugrid_amd as xa
 from conftest import same_or_nan
-from network_cases import (csr_from_pairs, line_selection_cases, line_selection_of_pairs, random_network, raster_quads,
-                           reference_case)
+from network_cases import (burn_lines_case, csr_from_pairs, line_selection_cases, line_selection_of_pairs, random_network,
+                           raster_quads, reference_case)
 from xugrid_amd import engine, meshgen
 
 pytestmark = pytest.mark.gpu
@@ -189,6 +189,15 @@ def test_reference_line_selection_known_answers(hip, oracle):
                 np.testing.assert_allclose(got_x, exp_x, rtol=0, atol=1e-15)
                 np.testing.assert_allclose(got_y, exp_y, rtol=0, atol=1e-15)
                 np.testing.assert_allclose(got_s, es, rtol=1e-15)
+
+
+def test_reference_burn_lines_known_answer(hip):
+    """tests/test_burn.py:135-141 through the device path (CellTree2d.intersect_edges)."""
+    nodes, faces, segments, values, expected = burn_lines_case()
+    e, f, _ = xa.CellTree2d(nodes, faces, -1).intersect_edges(segments)
+    out = np.full(faces.shape[0], -1.0)
+    out[f] = values[e]
+    assert np.array_equal(out, expected)
 
 
 def test_intersection_length_relative_reproduces_reference_formula(hip):

@@ -478,6 +478,11 @@ def test_locate_and_barycentric_known_answers(hip):
     assert np.array_equal(mesh.locate_points(mesh.centroids()), [0, 1, 2, 3])
     off = np.array([[-0.01, 1.0], [-0.01, 0.5]])
     assert np.array_equal(mesh.locate_points(off, 0.011), [0, 0])  # tests/test_ugrid2d.py:724-730
+    # tests/test_ugrid2d.py:835-885, 1085-1108: the reference's point selections (locate_points results)
+    oob = np.array([[-10.0, -10.0], [0.5, 0.5], [-20.0, -20.0], [1.5, 1.25], [-30.0, -30.0]])
+    assert np.array_equal(mesh.locate_points(oob), [-1, 0, -1, 3, -1])
+    gx, gy = np.meshgrid([0.4, 0.8, 1.2], [0.5, 1.1])
+    assert np.array_equal(mesh.locate_points(np.column_stack([gx.ravel(), gy.ravel()])), [0, 0, 1, 2, 2, 3])
     pts = np.array([[0.0, 0.0], [0.5, 0.5], [1.5, 0.5], [0.5, 1.5], [2.0, 2.0]])
     face, w = mesh.compute_barycentric_weights(pts)  # tests/test_ugrid2d.py:751-791
     assert np.array_equal(face, [0, 0, 1, 2, -1])

@@ -4,8 +4,8 @@ NetworkGridder path."""
 import numpy as np
 import pytest
 
-from network_cases import (csr_from_pairs, line_selection_cases, line_selection_of_pairs, random_network, raster_quads,
-                           reference_case)
+from network_cases import (burn_lines_case, csr_from_pairs, line_selection_cases, line_selection_of_pairs, random_network,
+                           raster_quads, reference_case)
 
 
 def test_reference_known_answer(oracle):
@@ -45,6 +45,16 @@ def test_reference_line_selection_known_answers(oracle):
         assert np.array_equal(got_f, exp_faces[::-1])
         total = np.hypot(*(segments[:, 1] - segments[:, 0]).T).sum()
         np.testing.assert_allclose(got_s, total - np.asarray(exp_s)[::-1], rtol=1e-15)
+
+
+def test_reference_burn_lines_known_answer(oracle):
+    """tests/test_burn.py:135-141: the faces intersect_edges reports for the segments of three lines on a 3 x 3 grid."""
+    nodes, faces, segments, values, expected = burn_lines_case()
+    e, f, _ = oracle.CellTree2d(nodes, faces).intersect_edges(segments)
+    out = np.full(faces.shape[0], -1.0)
+    out[f] = values[e]
+    assert np.array_equal(out, expected)
+    assert sorted(zip(e.tolist(), f.tolist())) == [(0, 0), (0, 1), (0, 2), (1, 4), (2, 6), (3, 6), (3, 7), (4, 7)]
 
 
 def test_pieces_tile_the_edge(oracle):

@@ -123,6 +123,13 @@ def test_locate_points_known_answers(oracle):
     off = np.array([[-0.01, 1.0], [-0.01, 0.5]])
     assert np.array_equal(tree.locate_points(off, 0.011), [0, 0])
     assert np.array_equal(tree.locate_points(off), [-1, -1])
+    # the point selections of the reference's own tests, which are locate_points results (ugridbase.py:1323):
+    # tests/test_ugrid2d.py:835-859 (sel_points), :862-885 (out of bounds -> -1), :1085-1108 (sel on an outer product of x and y)
+    assert np.array_equal(tree.locate_points(np.array([[0.5, 0.5], [1.5, 1.25]])), [0, 3])
+    oob = np.array([[-10.0, -10.0], [0.5, 0.5], [-20.0, -20.0], [1.5, 1.25], [-30.0, -30.0]])
+    assert np.array_equal(tree.locate_points(oob), [-1, 0, -1, 3, -1])
+    gx, gy = np.meshgrid([0.4, 0.8, 1.2], [0.5, 1.1])
+    assert np.array_equal(tree.locate_points(np.column_stack([gx.ravel(), gy.ravel()])), [0, 0, 1, 2, 2, 3])
 
 
 def test_barycentric_known_answers(oracle):
