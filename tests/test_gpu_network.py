@@ -92,6 +92,28 @@ def test_many_edges_through_few_faces(hip, oracle):
     np.testing.assert_allclose(got, exp, rtol=1e-12)
 
 
+def test_every_edge_kernel_path_equals_oracle(hip, oracle, monkeypatch):
+    """The thread-per-edge passes deal the exact clips out over the wave (default: 48 parking slots per edge); edges with
+    more candidate faces than slots go to the wave-per-edge kernels.  Shallow parking (24) sends many edges there, a tiny
+    big-box threshold nearly all of them, XR_EDGE_KERNEL=old runs the previous kernels: the CSR is the oracle's each time.
+    Edge lengths from far below a cell to a third of the mesh, so that the candidate lists range from 1 to hundreds."""
+    rng = np.random.default_rng(31)
+    nodes, faces = meshgen.triangle_mesh(4000, 4)
+    lo, hi = nodes.min(), nodes.max()
+    span = hi - lo
+    edges = np.concatenate([random_network(rng, 3000, lo, hi, 0.01 * span), random_network(rng, 2000, lo, hi, 0.06 * span),
+                            random_network(rng, 400, lo, hi, 0.3 * span)])
+    edges = edges[rng.permutation(edges.shape[0])]
+    settings = [{}, {"XR_EDGE_DEAL": "24"}, {"XR_EDGE_DEAL": "32", "XR_EDGE_BIG": "8"}, {"XR_EDGE_DEAL": "40", "XR_EDGE_BIG": "100000"},
+                {"XR_EDGE_KERNEL": "old"}, {"XR_EDGE_WALK": "major"}]
+    for env in settings:
+        for k in ("XR_EDGE_DEAL", "XR_EDGE_BIG", "XR_EDGE_KERNEL", "XR_EDGE_WALK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        device_vs_oracle(oracle, nodes, faces, edges)
+
+
 def _sample(grid_values, shape, x_loc, y_loc, y_descending):
     ny, nx = shape
     i = np.floor(x_loc).astype(int)

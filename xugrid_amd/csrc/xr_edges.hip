@@ -298,6 +298,113 @@ k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, 
     if (live) edge_hits[e] = redo ? 0 : nh;
 }
 
+// ---- thread-per-edge passes with the exact clips dealt out over the wave ------------------------------------------
+// Diagnosis (1M edges of exponentially distributed length over 1M triangles, variants of k_edges_count): the walk alone
+// takes 0.35 of the count pass's 0.98 ms; the rest are the Cyrus-Beck clips (~135 vector instructions each).  An edge has
+// ~10 candidate faces on average but the longest of a wave 30-40, and a loop "clip my candidates" -- worse, the clips
+// made on the spot once an edge's 16 parking slots were full -- makes the whole wave step through the longest lists one
+// after the other.  Here the walk only PARKS (EDGE_DEAL slots per edge); the wave then treats the parked candidates of its
+// 64 edges as ONE list and lane i clips items i, i + 64, ... (owner lane by a binary search over the wave's running
+// counts, its edge by a cross-lane read; a hit takes the owner's next slot by an LDS atomic).  Edges with more candidates
+// than slots go to the wave-per-edge kernels (big_list), which deal an edge's candidates over the lanes by construction.
+// FILL = false: count pass; FILL = true: the listed (redo) edges write their rows.  EDGE_DEAL: parking slots per edge.
+template <bool FILL, int EDGE_DEAL>
+__global__ void __launch_bounds__(256)
+k_edges_deal(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const int32_t *__restrict__ cell_start,
+             const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+             const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
+             int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
+             int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
+             double *__restrict__ side_len, int big_cells, const int32_t *__restrict__ indptr, int32_t *__restrict__ indices,
+             double *__restrict__ data, const int32_t *__restrict__ todo_list, const int32_t *__restrict__ n_todo) {
+    __shared__ int32_t sh_park[EDGE_DEAL][256];
+    __shared__ int32_t sh_hits[256];
+    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
+    const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
+    const int64_t n_items = FILL ? (int64_t)*n_todo : n_edge;
+    const int64_t n_rounded = (n_items + 255) / 256 * 256; // (every lane of a wave takes part in the cross-lane reads)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n_rounded; i += (int64_t)gridDim.x * 256) {
+        const bool live = i < n_items;
+        const int64_t e = live ? (FILL ? (int64_t)todo_list[i] : i) : 0;
+        EdgeBox q{};
+        bool walk = false, big = false;
+        if (live) {
+            q = load_edge(edge_xy, e, g);
+            const bool finite = q.xmin == q.xmin && q.ymin == q.ymin && q.xmax == q.xmax && q.ymax == q.ymax; // no NaN
+            big = !FILL && finite && edge_cells(q, g) > big_cells;
+            walk = finite && !big;
+        }
+        sh_hits[tid] = 0;
+        int np = 0;
+        if (walk) {
+            auto park = [&](int r) {
+                sh_park[np < EDGE_DEAL ? np : EDGE_DEAL - 1][tid] = r;
+                np++;
+            };
+            edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
+        }
+        // (FILL: the listed edges had at most EDGE_DEAL candidates in the count pass -- the same walk)
+        if (np > EDGE_DEAL) {
+            big = !FILL;
+            np = 0;
+        }
+        int incl = np;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const int total = __shfl(incl, 63, 64);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int first = 0; first < total; first += 64) { // (wave-uniform)
+            const int item = first + lane;
+            const bool has = item < total;
+            int lo = 0, hi = 63; // owner = first lane whose running count exceeds the item
+#pragma unroll
+            for (int step = 0; step < 6; step++) {
+                const int mid = (lo + hi) >> 1;
+                const int v = __shfl(incl, mid, 64);
+                if (v > item) hi = mid;
+                else lo = mid + 1;
+            }
+            const int ol = has ? lo : 0;
+            const int slot = item - (__shfl(incl, ol, 64) - __shfl(np, ol, 64));
+            const P2 a{__shfl(q.a.x, ol, 64), __shfl(q.a.y, ol, 64)}, b{__shfl(q.b.x, ol, 64), __shfl(q.b.y, ol, 64)};
+            const long long e_owner = __shfl((long long)e, ol, 64);
+            if (has) {
+                const int rr = sh_park[slot][wbase + ol];
+                const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, rr, m), rec_len[rr], a, b);
+                if (len > 0.0) { // (a degenerate piece of zero length is no intersection)
+                    const int face = rec_face[rr];
+                    const int k_row = atomicAdd(row_count + face, 1);
+                    if (FILL) {
+                        indices[indptr[face] + k_row] = (int32_t)e_owner;
+                        data[indptr[face] + k_row] = len;
+                    } else {
+                        const int k_edge = atomicAdd(&sh_hits[wbase + ol], 1);
+                        if (k_edge < EDGE_SLOTS) {
+                            side_face[(int64_t)k_edge * n_edge + e_owner] = face;
+                            side_len[(int64_t)k_edge * n_edge + e_owner] = len;
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!FILL) {
+            const int nh = sh_hits[tid];
+            const bool redo = nh > EDGE_SLOTS;
+            wave_append(big, (int32_t)e, big_list, n_big);
+            wave_append(redo, (int32_t)e, redo_list, n_redo);
+            if (live) edge_hits[e] = redo ? 0 : nh;
+        }
+    }
+}
+
 // pass 2a: the kept hits go to their rows (arbitrary order within a row)
 __global__ void __launch_bounds__(256)
 k_edges_replay(int64_t n_edge, const int32_t *__restrict__ edge_hits, const int32_t *__restrict__ side_face,
@@ -497,7 +604,22 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     const int big_grid = engine().num_cu * 8;
     const int big_cells = getenv("XR_EDGE_BIG") ? atoi(getenv("XR_EDGE_BIG")) : EDGE_BIG_CELLS; // tuning hook
     const bool major = getenv("XR_EDGE_WALK") ? !strcmp(getenv("XR_EDGE_WALK"), "major") : false; // tuning hook
-    if (major)
+    const bool deal = !major && !(getenv("XR_EDGE_KERNEL") && !strcmp(getenv("XR_EDGE_KERNEL"), "old")); // (A/B switch)
+    const int deal_slots = getenv("XR_EDGE_DEAL") ? atoi(getenv("XR_EDGE_DEAL")) : 48; // tuning hook: parking slots per edge (24 / 32 / 40 / 48)
+#define XR_DEAL_COUNT(P)                                                                                                              \
+    XR_LAUNCH("edges_count", (k_edges_deal<false, P>), dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,              \
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,      \
+              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,             \
+              edge_hits.get(), side_face.get(), side_len.get(), big_cells, (const int32_t *)nullptr, (int32_t *)nullptr,              \
+              (double *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr)
+    if (deal) {
+        if (deal_slots <= 24) XR_DEAL_COUNT(24);
+        else if (deal_slots <= 32) XR_DEAL_COUNT(32);
+        else if (deal_slots <= 40) XR_DEAL_COUNT(40);
+        else XR_DEAL_COUNT(48);
+    }
+#undef XR_DEAL_COUNT
+    else if (major)
     XR_LAUNCH("edges_count", k_edges_count<true>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
@@ -521,7 +643,20 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
     XR_LAUNCH("edges_replay", k_edges_replay, dim3(div_up(n_edge, 256)), dim3(256), 0, n_edge, edge_hits.get(),
               side_face.get(), side_len.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
-    if (major)
+#define XR_DEAL_FILL(P)                                                                                                               \
+    XR_LAUNCH("edges_redo", (k_edges_deal<true, P>), dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),     \
+              dim3(256), 0, edge_xy.get(), n_edge, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),                \
+              tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), (int32_t *)nullptr,            \
+              (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,  \
+              big_cells, csr->indptr.get(), csr->indices.get(), csr->data.get(), redo_list.get(), counters.get() + 2)
+    if (deal) {
+        if (deal_slots <= 24) XR_DEAL_FILL(24);
+        else if (deal_slots <= 32) XR_DEAL_FILL(32);
+        else if (deal_slots <= 40) XR_DEAL_FILL(40);
+        else XR_DEAL_FILL(48);
+    }
+#undef XR_DEAL_FILL
+    else if (major)
     XR_LAUNCH("edges_redo", k_edges_redo<true>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
               dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
               tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
