@@ -104,10 +104,13 @@ def test_every_edge_kernel_path_equals_oracle(hip, oracle, monkeypatch):
     edges = np.concatenate([random_network(rng, 3000, lo, hi, 0.01 * span), random_network(rng, 2000, lo, hi, 0.06 * span),
                             random_network(rng, 400, lo, hi, 0.3 * span)])
     edges = edges[rng.permutation(edges.shape[0])]
+    # (the wave-per-edge count pass keeps its hits in a pool that the fill pass replays: off, and with a pool far too small --
+    # the edges that are refused, or have more hits than a wave's stage, walk again)
     settings = [{}, {"XR_EDGE_DEAL": "24"}, {"XR_EDGE_DEAL": "32", "XR_EDGE_BIG": "8"}, {"XR_EDGE_DEAL": "40", "XR_EDGE_BIG": "100000"},
-                {"XR_EDGE_KERNEL": "old"}, {"XR_EDGE_WALK": "major"}]
+                {"XR_EDGE_KERNEL": "old"}, {"XR_EDGE_WALK": "major"}, {"XR_EDGE_POOL": "0", "XR_EDGE_BIG": "8"},
+                {"XR_EDGE_POOL": "700", "XR_EDGE_BIG": "8"}, {"XR_EDGE_POOL": "1", "XR_EDGE_DEAL": "24"}]
     for env in settings:
-        for k in ("XR_EDGE_DEAL", "XR_EDGE_BIG", "XR_EDGE_KERNEL", "XR_EDGE_WALK"):
+        for k in ("XR_EDGE_DEAL", "XR_EDGE_BIG", "XR_EDGE_KERNEL", "XR_EDGE_WALK", "XR_EDGE_POOL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -477,6 +477,80 @@ k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__r
     }
 }
 
+// Count pass of the wave-per-edge kernels that KEEPS its hits: the lanes append (face, length) to a stage of their wave in
+// LDS; when the edge is done the wave reserves a stretch of the hit pool with one atomic and copies the stage out.  The
+// fill pass is then a replay of the pool (one thread per hit) instead of a second walk over the long edges.  Edges with
+// more hits than the stage holds, or that find the pool full, are listed for the walking fill pass (k_edges_big<true>).
+static constexpr int BIG_STAGE_HITS = 256;
+struct EdgeHit {
+    int32_t edge, face;
+    double len;
+};
+
+__global__ void __launch_bounds__(256)
+k_edges_big_pool(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
+                 const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+                 const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
+                 const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big, EdgeHit *__restrict__ pool,
+                 int32_t *__restrict__ pool_cursor /* [0] cursor, [1] capacity - first refused base (0: none refused) */, int pool_cap,
+                 int32_t *__restrict__ walk_list, int32_t *__restrict__ n_walk) {
+    __shared__ int32_t sh_face[4][BIG_STAGE_HITS];
+    __shared__ double sh_len[4][BIG_STAGE_HITS];
+    __shared__ int32_t sh_n[4];
+    const int nb = *n_big, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = blockIdx.x * 4 + wv; i < nb; i += gridDim.x * 4) { // (wave-uniform)
+        const int64_t e = big_list[i];
+        const EdgeBox q = load_edge(edge_xy, e, g);
+        if (lane == 0) sh_n[wv] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        auto hit = [&](int face, double len) {
+            atomicAdd(row_count + face, 1);
+            const int k = atomicAdd(&sh_n[wv], 1);
+            if (k < BIG_STAGE_HITS) {
+                sh_face[wv][k] = face;
+                sh_len[wv][k] = len;
+            }
+        };
+        auto cand = [&](int r) { edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit); };
+        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, rec_off, m, rec_face, cand);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = sh_n[wv];
+        int base = -1;
+        if (lane == 0) {
+            if (n <= BIG_STAGE_HITS && n > 0) {
+                const int b = atomicAdd(pool_cursor, n);
+                if (b >= 0 && b <= pool_cap - n) base = b;
+                else if (b >= 0 && b < pool_cap) atomicMax(pool_cursor + 1, pool_cap - b); // (the cursor only grows: every later stretch is refused too)
+            }
+            if (n > 0 && base < 0) walk_list[atomicAdd(n_walk, 1)] = (int32_t)e;
+        }
+        base = __shfl(base, 0, 64);
+        if (base >= 0)
+            for (int k = lane; k < n; k += 64) pool[base + k] = EdgeHit{(int32_t)e, sh_face[wv][k], sh_len[wv][k]};
+    }
+}
+
+// fill pass of the pooled hits: the granted stretches are exactly [0, end), end = the base of the first refused stretch
+// (the cursor only grows, so nothing behind a refused stretch is granted) or the cursor itself
+__global__ void __launch_bounds__(256)
+k_edges_pool_replay(const EdgeHit *__restrict__ pool, const int32_t *__restrict__ pool_cursor, int pool_cap,
+                    int32_t *__restrict__ row_count, const int32_t *__restrict__ indptr, int32_t *__restrict__ indices,
+                    double *__restrict__ data) {
+    const int end = pool_cap - (pool_cursor[1] > 0 ? pool_cursor[1] : 0);
+    const int cur = pool_cursor[0] < 0 ? 0 : pool_cursor[0]; // (a wrapped cursor: nothing was granted after the wrap)
+    const int n = cur < end ? cur : end;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const EdgeHit h = pool[i];
+        const int pos = indptr[h.face] + atomicAdd(row_count + h.face, 1);
+        indices[pos] = h.edge;
+        data[pos] = h.len;
+    }
+}
+
 // rows ordered by edge id: short rows by one thread each, the others are queued
 __global__ void __launch_bounds__(256)
 k_edge_rows_sort(const int32_t *__restrict__ indptr, int64_t n_face, int32_t *__restrict__ indices,
@@ -595,11 +669,11 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     mesh_build_index(tree);
     DevBuf<double> edge_xy((size_t)n_edge * 4);
     h2d(edge_xy.get(), edge_xy_host, sizeof(double) * 4 * (size_t)n_edge);
-    DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters(4);
+    DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters(8); // [0] big, [1] rows to sort, [2] redo, [4] pool cursor, [5] its refusal mark, [6] big edges that walk again
     DevBuf<int32_t> edge_hits((size_t)n_edge), side_face((size_t)n_edge * EDGE_SLOTS), redo_list((size_t)n_edge);
     DevBuf<double> side_len((size_t)n_edge * EDGE_SLOTS);
     XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
-    XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 4, st));
+    XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 8, st));
     const GridParams &g = tree->grid;
     const int big_grid = engine().num_cu * 8;
     const int big_cells = getenv("XR_EDGE_BIG") ? atoi(getenv("XR_EDGE_BIG")) : EDGE_BIG_CELLS; // tuning hook
@@ -629,6 +703,20 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
               edge_hits.get(), side_face.get(), side_len.get(), big_cells);
+    // the wave-per-edge count pass keeps its hits in a pool (16 B each; 4 per edge of the network, at least 1M): the fill pass
+    // replays them instead of walking the long edges again (XR_EDGE_POOL=0: both passes walk, as before)
+    // (XR_EDGE_POOL = n > 0: a pool of n hits -- test hook for the refusal path)
+    const int pool_env = getenv("XR_EDGE_POOL") ? atoi(getenv("XR_EDGE_POOL")) : -1;
+    const bool pooled = pool_env != 0;
+    const int pool_cap = !pooled ? 1 : pool_env > 0 ? pool_env : (int)std::min<int64_t>(std::max<int64_t>(4 * n_edge, (int64_t)1 << 20), (int64_t)1 << 28);
+    DevBuf<EdgeHit> pool((size_t)pool_cap);
+    DevBuf<int32_t> walk_list((size_t)(pooled ? n_edge : 1));
+    if (pooled)
+    XR_LAUNCH("edges_big_count", k_edges_big_pool, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
+              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
+              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), pool.get(), counters.get() + 4, pool_cap,
+              walk_list.get(), counters.get() + 6);
+    else
     XR_LAUNCH("edges_big_count", k_edges_big<false>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
@@ -666,6 +754,14 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
               dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
               tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
               csr->data.get(), redo_list.get(), counters.get() + 2);
+    if (pooled) {
+        XR_LAUNCH("edges_pool_replay", k_edges_pool_replay, dim3(engine().num_cu * 8), dim3(256), 0, pool.get(), counters.get() + 4,
+                  pool_cap, row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
+        XR_LAUNCH("edges_big_fill", k_edges_big<true>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
+                  tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
+                  tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
+                  walk_list.get(), counters.get() + 6);
+    } else
     XR_LAUNCH("edges_big_fill", k_edges_big<true>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
               tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
