@@ -20,7 +20,8 @@ namespace xr {
 
 static constexpr int EDGE_BIG_CELLS = 64;  // edges whose box covers more grid cells (all levels) get a wave of their own
 static constexpr int EDGE_SLOTS = 6;       // hits per edge the count pass keeps for the fill pass (slot-major side buffer)
-static constexpr int ROW_SORT_SMALL = 48;  // rows up to this length are insertion-sorted by one thread
+static constexpr int ROW_SORT_SMALL = 16;  // rows up to this length are insertion-sorted by one thread (in global memory: every step waits for the
+                                           // store before it -- at 48 the few rows of 30-48 entries WERE the kernel, 0.23 ms; 16: 0.10)
 static constexpr int ROW_SORT_LDS = 4096;  // rows up to this length are sorted in LDS by one block
 
 // a + t (b - a), t in [0, 1], against every half-plane of the CCW polygon.  -> length of the clipped piece, or -1;
