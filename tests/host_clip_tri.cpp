@@ -25,3 +25,25 @@ extern "C" double host_tri_clip_area(const double *tv_, const double *sv_) {
 extern "C" void host_tri_clip_many(const double *tv, const double *sv, long n, double *out) {
     for (long i = 0; i < n; i++) out[i] = host_tri_clip_area(tv + 6 * i, sv + 6 * i);
 }
+
+// quadrilateral (or triangular: n0 = 3) subject against a triangle: the MAXV = 7 instantiation
+extern "C" void host_quad_clip_many(const double *tv_, const int *n0, const double *sv_, long n, double *out) {
+    static uint2 lut[xr::QUAD_LUT];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < xr::QUAD_LUT; i++) {
+            threadIdx.x = i;
+            xr::poly_lut_init<xr::QUAD_MAXV>(lut);
+        }
+        threadIdx.x = 0;
+        init = true;
+    }
+    for (long i = 0; i < n; i++) {
+        xr::P2 tv[4], sv[3];
+        for (int j = 0; j < 4; j++) tv[j] = xr::P2{tv_[8 * i + 2 * j], tv_[8 * i + 2 * j + 1]};
+        for (int j = 0; j < 3; j++) sv[j] = xr::P2{sv_[6 * i + 2 * j], sv_[6 * i + 2 * j + 1]};
+        double2 col[xr::QUAD_MAXV + 2];
+        for (auto &c : col) c = double2{NAN, NAN};
+        out[i] = xr::poly_clip_area<xr::QUAD_MAXV, 4>(tv, n0[i], sv, col, lut, true);
+    }
+}

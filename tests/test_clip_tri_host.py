@@ -24,6 +24,7 @@ def host_clip(tmp_path_factory):
          "-I", os.path.join(ROOT, "xugrid_amd", "csrc"), os.path.join(ROOT, "tests", "host_clip_tri.cpp"), "-o", so])
     lib = ctypes.CDLL(so)
     lib.host_tri_clip_many.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    lib.host_quad_clip_many.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
 
     def many(tv, sv):
         tv = np.ascontiguousarray(tv, dtype=np.float64)
@@ -32,6 +33,15 @@ def host_clip(tmp_path_factory):
         lib.host_tri_clip_many(tv.ctypes.data, sv.ctypes.data, tv.shape[0], out.ctypes.data)
         return out
 
+    def quads(tv, n0, sv):
+        tv = np.ascontiguousarray(tv, dtype=np.float64)
+        sv = np.ascontiguousarray(sv, dtype=np.float64)
+        n0 = np.ascontiguousarray(n0, dtype=np.int32)
+        out = np.empty(tv.shape[0])
+        lib.host_quad_clip_many(tv.ctypes.data, n0.ctypes.data, sv.ctypes.data, tv.shape[0], out.ctypes.data)
+        return out
+
+    many.quads = quads
     return many
 
 
@@ -94,3 +104,46 @@ def test_shared_vertex_mesh_pairs(host_clip, oracle):
     owner = np.tile(np.arange(faces.shape[0]), 4)
     fj = near[owner][:, :6].ravel()
     check(host_clip, oracle, ccw(fine[fi].copy()), tri[fj], fine.shape[0])
+
+
+def check_quads(host_clip, oracle, tv, n0, sv, min_positive):
+    got = host_clip.quads(tv, n0, sv)
+    exp = np.array([oracle.clip_area(tv[i, : n0[i]], sv[i]) for i in range(tv.shape[0])])
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (bad.size, tv[bad[0]].tolist(), int(n0[bad[0]]), sv[bad[0]].tolist(), got[bad[0]], exp[bad[0]])
+    assert (exp > 0).sum() >= min_positive
+
+
+def convex_quads(rng, n, centre, size):
+    ang = np.sort(rng.uniform(0, 2 * np.pi, (n, 4)), axis=1)
+    return centre + size * np.stack([np.cos(ang), np.sin(ang)], axis=2)
+
+
+def test_quadrilateral_subjects(host_clip, oracle):
+    """The MAXV = 7 instantiation (faces of a raster / quadrilateral target against source triangles): random convex quads,
+    axis-aligned cells against a triangle mesh's own triangles (vertices ON cell lines: lattice coordinates), cells that are
+    triangles with a fill slot (n0 = 3), repeated vertices, UTM-sized offsets."""
+    rng = np.random.default_rng(4)
+    n = 60_000
+    c = rng.random((n, 1, 2))
+    tv = convex_quads(rng, n, c, 0.15)
+    sv = ccw(c + 0.3 * (rng.random((n, 3, 2)) - 0.5))
+    check_quads(host_clip, oracle, tv, np.full(n, 4), sv, 30_000)
+    # raster cells on an integer lattice against lattice triangles: every degenerate contact is exact
+    n = 120_000
+    x0 = rng.integers(0, 4, (n, 1)).astype(np.float64); y0 = rng.integers(0, 4, (n, 1)).astype(np.float64)
+    w = rng.integers(1, 3, (n, 1)).astype(np.float64); h = rng.integers(1, 3, (n, 1)).astype(np.float64)
+    cells = np.stack([np.hstack([x0, y0]), np.hstack([x0 + w, y0]), np.hstack([x0 + w, y0 + h]), np.hstack([x0, y0 + h])], axis=1)
+    tris = ccw(rng.integers(0, 6, size=(n, 3, 2)).astype(np.float64))
+    n0 = np.full(n, 4)
+    check_quads(host_clip, oracle, cells, n0, tris, 20_000)
+    check_quads(host_clip, oracle, cells[:30_000] * 25.0 + np.array([5.0e5, 6.0e6]), n0[:30_000], tris[:30_000] * 25.0 + np.array([5.0e5, 6.0e6]), 4_000)
+    # half of the "cells" are triangles (fill slot): the fourth vertex is never read
+    tri_cells = cells.copy()
+    n0 = np.where(rng.random(n) < 0.5, 3, 4)
+    tri_cells[n0 == 3, 3] = np.nan
+    check_quads(host_clip, oracle, tri_cells, n0, tris, 15_000)
+    # repeated vertices (a quad with a zero-length side) and general lattice quads, not all convex-regular
+    rep = cells.copy()
+    rep[::3, 2] = rep[::3, 1]
+    check_quads(host_clip, oracle, rep, np.full(n, 4), tris, 10_000)

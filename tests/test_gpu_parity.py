@@ -95,6 +95,33 @@ def test_overlap_clockwise_and_fill_values(hip, oracle):
     assert_overlap_parity(hip, oracle, sxy, sf5, txy, tf5, relative=True, fill=-999)
 
 
+def test_overlap_quadrilateral_targets_on_triangles(hip, oracle, monkeypatch):
+    """The shape of the reference's unstructured -> raster regridding: quadrilateral targets against a triangle source go
+    through the flag / compaction clip with a four-vertex subject (k_clip_quad_tri).  A raster whose cell lines pass through
+    source vertices (a lattice-split triangulation: exact contacts), a rotated and sheared quad mesh, clockwise quads,
+    and a target that mixes quads with triangles (fill slot); bit-equal to the oracle and to the slot-loop kernel
+    (XR_CLIP_QUAD=0), absolute and relative."""
+    sxy, sf = meshgen.triangle_mesh(2500, 5, delaunay=False)
+    lo, hi = sxy.min(), sxy.max()
+    rxy, rf = meshgen.quad_mesh(np.linspace(lo, hi, 41), np.linspace(lo, hi, 33))
+    ang = np.deg2rad(17.0)
+    shear = np.array([[np.cos(ang), -np.sin(ang)], [np.sin(ang) + 0.3, np.cos(ang)]])
+    qxy = (rxy - rxy.mean(0)) @ shear.T * 0.8 + rxy.mean(0)
+    mixed = rf.copy()
+    mixed[::3, 3] = -1  # every third cell: the triangle of its first three corners
+    dxy, df = meshgen.triangle_mesh(2500, 6)  # a Delaunay source for the general-position cases
+    cases = [(sxy, sf, rxy, rf), (dxy, df, qxy, rf), (dxy, df, rxy, rf[:, ::-1].copy()), (sxy, sf, rxy, mixed), (dxy, df, qxy, mixed)]
+    for src_xy, src_f, txy, tf in cases:
+        results = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("XR_CLIP_QUAD", flag)
+            csr, _ = assert_overlap_parity(hip, oracle, src_xy, src_f, txy, tf)
+            results.append(csr.download())
+            assert_overlap_parity(hip, oracle, src_xy, src_f, txy, tf, relative=True)
+        assert all(np.array_equal(a, b) for a, b in zip(*results))
+    monkeypatch.delenv("XR_CLIP_QUAD")
+
+
 def test_overlap_polygons_up_to_hexagons(hip, oracle):
     """mixed 3..6-gons (voronoi cells of a Delaunay mesh) against triangles: MAXV = 16 clip kernel."""
     from xugrid_amd import connectivity as C, voronoi

@@ -38,10 +38,14 @@ static constexpr int TRI_LUT = 64;                // compaction table entries (u
 // Compaction table: entry (1 << n) + F, n = 3..5 vertices, F = inside mask.  .x bytes 0..3: output offset of vertex
 // 0..3; .y byte 0: vertex 4, byte 1 / 2: the crossing points of the first / second transition slot.  A vertex that is
 // outside (or beyond the polygon) goes to the trash slot.  Call with all threads of the block, then __syncthreads().
-__device__ __forceinline__ void tri_lut_init(uint2 *lut) {
+// MAXV = 6: triangle subjects (entries (1 << n) + F, n = 3..5); MAXV = 7: subjects of up to four vertices (n = 3..6, 128
+// entries; vertex 5 in .y byte 3).  The trash slot is slot MAXV.
+template <int MAXV>
+__device__ __forceinline__ void poly_lut_init(uint2 *lut) {
+    constexpr int N_LUT = 1 << MAXV;
     const int i = threadIdx.x;
-    if (i >= TRI_LUT) return;
-    uint32_t pos[7] = {6, 6, 6, 6, 6, 6, 6}; // vertex 0..4, crossing point 1, 2
+    if (i >= N_LUT) return;
+    uint32_t pos[8] = {MAXV, MAXV, MAXV, MAXV, MAXV, MAXV, MAXV, MAXV}; // vertex 0..4, crossing point 1, 2, vertex 5
     if (i >= 8) {
         const int n = 31 - __clz(i);
         const uint32_t F = (uint32_t)i - (1u << n);
@@ -53,14 +57,15 @@ __device__ __forceinline__ void tri_lut_init(uint2 *lut) {
                 n_t++;
                 before++;
             }
-            if (fj) pos[j] = (uint32_t)(before++);
+            if (fj) pos[j < 5 ? j : 7] = (uint32_t)(before++);
         }
     }
     uint2 e;
     e.x = (pos[0] << 4) | (pos[1] << 12) | (pos[2] << 20) | (pos[3] << 28);
-    e.y = (pos[4] << 4) | (pos[5] << 12) | (pos[6] << 20);
+    e.y = (pos[4] << 4) | (pos[5] << 12) | (pos[6] << 20) | (pos[7] << 28);
     lut[i] = e;
 }
+__device__ __forceinline__ void tri_lut_init(uint2 *lut) { poly_lut_init<TRI_MAXV>(lut); }
 
 __device__ __forceinline__ bool p2_eq(P2 a, P2 b) { return a.x == b.x && a.y == b.y; }
 __device__ __forceinline__ bool p2_eq(P2 a, double2 b) { return a.x == b.x && a.y == b.y; }
@@ -70,17 +75,18 @@ __device__ __forceinline__ double2 *tri_slot(double2 *col, uint32_t byte_offset)
 
 // The oracle's stage loop on a register polygon (static indexing, predicated on the current length); output
 // pushed into the lane's LDS column (slot TRI_MAXV = trash for clamped pushes).
-__device__ __forceinline__ void tri_stage_generic(const P2 (&v)[TRI_MAXV], int &n, const P2 r, const P2 U, bool &alive,
-                                                  bool &overflow, double2 *col) {
+template <int MAXV>
+__device__ __forceinline__ void poly_stage_generic(const P2 (&v)[MAXV], int &n, const P2 r, const P2 U, bool &alive,
+                                                   bool &overflow, double2 *col) {
     const P2 N{-U.y, U.x};
     int n_output = 0;
     P2 a = v[0];
 #pragma unroll
-    for (int j = 1; j < TRI_MAXV; j++)
+    for (int j = 1; j < MAXV; j++)
         if (j < n) a = v[j];
     bool a_inside = U.x * (a.y - r.y) > U.y * (a.x - r.x);
 #pragma unroll
-    for (int j = 0; j < TRI_MAXV; j++) {
+    for (int j = 0; j < MAXV; j++) {
         if (j < n) {
             const P2 b = v[j];
             const P2 V{b.x - a.x, b.y - a.y};
@@ -102,12 +108,12 @@ __device__ __forceinline__ void tri_stage_generic(const P2 (&v)[TRI_MAXV], int &
             }
             const bool quirk = cross && !b_inside && !have_pt; // parallel edge: keep b, which then counts as inside
             if (cross && have_pt) {
-                col[n_output < TRI_MAXV ? n_output : TRI_MAXV] = make_double2(pt.x, pt.y);
+                col[n_output < MAXV ? n_output : MAXV] = make_double2(pt.x, pt.y);
                 n_output++;
             }
             b_inside = b_inside || quirk;
             if (live && b_inside) {
-                col[n_output < TRI_MAXV ? n_output : TRI_MAXV] = make_double2(b.x, b.y);
+                col[n_output < MAXV ? n_output : MAXV] = make_double2(b.x, b.y);
                 n_output++;
             }
             if (live) {
@@ -116,7 +122,7 @@ __device__ __forceinline__ void tri_stage_generic(const P2 (&v)[TRI_MAXV], int &
             }
         }
     }
-    if (n_output > TRI_MAXV) {
+    if (n_output > MAXV) {
         overflow = true;
         alive = false;
     } else if (n_output < 3) {
@@ -128,14 +134,14 @@ __device__ __forceinline__ void tri_stage_generic(const P2 (&v)[TRI_MAXV], int &
 // One stage.  NIN = number of vertices the fast path is unrolled for (3, 4, 5 for the three edges of a triangle
 // clipper: a regular stage adds at most one vertex).  The lane's LDS column holds the current polygon before and
 // after; registers are only a per-stage copy.
-template <int NIN, bool LAST = false>
-__device__ __forceinline__ void tri_stage(int &n, P2 &r, const P2 s, bool &alive, bool &dirty, bool &overflow,
-                                          double2 *col, const uint2 *lut) {
+template <int MAXV, int NIN, bool LAST = false>
+__device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &alive, bool &dirty, bool &overflow,
+                                           double2 *col, const uint2 *lut) {
     const P2 U{s.x - r.x, s.y - r.y};
     const bool work = alive && !(U.x == 0 && U.y == 0); // zero-length clipper edge: the oracle skips the stage, r stays
-    P2 v[TRI_MAXV];
+    P2 v[MAXV];
 #pragma unroll
-    for (int j = 0; j < TRI_MAXV; j++) {
+    for (int j = 0; j < MAXV; j++) {
         if (j < NIN) {
             const double2 q = col[j]; // (slots >= n: stale values, masked below)
             v[j] = P2{q.x, q.y};
@@ -178,6 +184,7 @@ __device__ __forceinline__ void tri_stage(int &n, P2 &r, const P2 s, bool &alive
             *tri_slot(col, (e.x >> 16) & 0xffu) = make_double2(v[2].x, v[2].y);
             if (NIN > 3) *tri_slot(col, e.x >> 24) = make_double2(v[3].x, v[3].y);
             if (NIN > 4) *tri_slot(col, e.y & 0xffu) = make_double2(v[4].x, v[4].y);
+            if (NIN > 5) *tri_slot(col, e.y >> 24) = make_double2(v[5].x, v[5].y);
             *tri_slot(col, (e.y >> 8) & 0xffu) = make_double2(pt1.x, pt1.y);
             *tri_slot(col, (e.y >> 16) & 0xffu) = make_double2(pt2.x, pt2.y);
             n = __popc(F) + 2; // (>= 3: a transition implies an inside vertex)
@@ -189,34 +196,42 @@ __device__ __forceinline__ void tri_stage(int &n, P2 &r, const P2 s, bool &alive
     if (irregular) {
         if (n > NIN) { // (only after an earlier generic stage: fetch the vertices the fast path does not unroll)
 #pragma unroll
-            for (int j = NIN; j < TRI_MAXV; j++) {
+            for (int j = NIN; j < MAXV; j++) {
                 if (j < n) {
                     const double2 q = col[j];
                     v[j] = P2{q.x, q.y};
                 }
             }
         }
-        tri_stage_generic(v, n, r, U, alive, overflow, col);
+        poly_stage_generic<MAXV>(v, n, r, U, alive, overflow, col);
         dirty = true; // (the generic loop may emit repeated vertices)
     }
     if (work) r = s;
 }
 
-// area of (target triangle tv) clipped by (source triangle sv, counter-clockwise), or TRI_AREA_OVERFLOW.
-// col: the lane's LDS column, col[0 .. TRI_MAXV] (TRI_MAXV + 1 double2 slots, contiguous); lut: tri_lut_init's table.
-__device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv)[3], double2 *col, const uint2 *lut,
-                                                bool active) {
-    int n = 3;
+// area of (subject polygon tv, n0 <= N0 vertices: a target face) clipped by (source triangle sv, counter-clockwise), or
+// TRI_AREA_OVERFLOW.  col: the lane's LDS column, col[0 .. MAXV] (MAXV + 1 double2 slots, contiguous); lut: poly_lut_init<MAXV>'s
+// table.  N0 = 3, MAXV = 6: triangle x triangle; N0 = 4, MAXV = 7: the faces of a quadrilateral (raster) target, which may
+// be triangles with a fill slot (n0 = 3).
+template <int MAXV, int N0>
+__device__ __forceinline__ double poly_clip_area(const P2 (&tv)[N0], int n0, const P2 (&sv)[3], double2 *col, const uint2 *lut,
+                                                 bool active) {
+    int n = n0;
     bool alive = active, overflow = false;
-    bool dirty = p2_eq(tv[0], tv[1]) || p2_eq(tv[1], tv[2]) || p2_eq(tv[2], tv[0]);
+    bool dirty = false;
+#pragma unroll
+    for (int j = 0; j < N0; j++)
+        if (j < n0) dirty = dirty || p2_eq(tv[j], tv[j + 1 < n0 ? j + 1 : 0]);
+    if (N0 > 3 && n0 > 3) dirty = dirty || p2_eq(tv[0], tv[2]) || p2_eq(tv[1], tv[3 < N0 ? 3 : 0]);
     if (active) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) col[j] = make_double2(tv[j].x, tv[j].y);
+        for (int j = 0; j < N0; j++)
+            if (j < n0) col[j] = make_double2(tv[j].x, tv[j].y);
     }
     P2 r = sv[2];
-    tri_stage<3>(n, r, sv[0], alive, dirty, overflow, col, lut);
-    tri_stage<4>(n, r, sv[1], alive, dirty, overflow, col, lut);
-    tri_stage<5, true>(n, r, sv[2], alive, dirty, overflow, col, lut);
+    poly_stage<MAXV, N0>(n, r, sv[0], alive, dirty, overflow, col, lut);
+    poly_stage<MAXV, N0 + 1>(n, r, sv[1], alive, dirty, overflow, col, lut);
+    poly_stage<MAXV, N0 + 2, true>(n, r, sv[2], alive, dirty, overflow, col, lut);
     if (overflow) return TRI_AREA_OVERFLOW;
     double area = 0.0;
     if (alive) {
@@ -225,7 +240,7 @@ __device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv
         const P2 a0{q0.x, q0.y};
         double ux = q1.x - a0.x, uy = q1.y - a0.y;
 #pragma unroll
-        for (int i = 2; i < TRI_MAXV; i++) {
+        for (int i = 2; i < MAXV; i++) {
             if (i < n) {
                 const double2 q = col[i];
                 const double vx = a0.x - q.x, vy = a0.y - q.y;
@@ -238,5 +253,13 @@ __device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv
     }
     return area;
 }
+
+__device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv)[3], double2 *col, const uint2 *lut,
+                                                bool active) {
+    return poly_clip_area<TRI_MAXV, 3>(tv, 3, sv, col, lut, active);
+}
+
+static constexpr int QUAD_MAXV = 7;              // quadrilateral subject: up to 7 vertices after three clip edges
+static constexpr int QUAD_LUT = 1 << QUAD_MAXV;  // compaction table entries
 
 } // namespace xr

@@ -853,6 +853,73 @@ k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__
     }
 }
 
+// Quadrilateral (raster / quad mesh) targets against a triangle source -- the shape of the reference's unstructured ->
+// raster regridding: the same flag / compaction clip with a subject of up to four vertices (xr_clip_tri.h, MAXV = 7);
+// target faces may be triangles with a fill slot (q_len).  Replaces k_clip_small<8> for this pair of shapes.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_clip_quad_tri(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, const double *__restrict__ s_fxy,
+                const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
+                double *__restrict__ cand_area, const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
+                int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (QUAD_MAXV + 2 slots per lane: 144 bytes -- 128 would put the 16-byte accesses of all lanes on the same banks)
+    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (QUAD_MAXV + 2);
+    __shared__ uint2 sh_lut[QUAD_LUT];
+    const int64_t n_blocks = (n_cand + BLOCK - 1) / BLOCK;
+    const int64_t lb = xcd_block(n_blocks, remap);
+    if (lb >= n_blocks) return;
+    poly_lut_init<QUAD_MAXV>(sh_lut);
+    __syncthreads();
+    const int64_t c = lb * BLOCK + threadIdx.x;
+    const bool active = c < n_cand;
+    int t = -1, n0 = 3;
+    P2 tv[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
+    if (active) {
+        t = cand_tgt[c];
+        const int s = cand_src[c];
+        cand_sid[c] = rec_face[s];
+        n0 = q_len[t];
+        const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * 4;
+        const double2 *sf = reinterpret_cast<const double2 *>(s_fxy) + (int64_t)s * 3;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (j < n0) {
+                const double2 a = tf[j];
+                tv[j] = P2{a.x, a.y};
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const double2 b = sf[j];
+            sv[j] = P2{b.x, b.y};
+        }
+    }
+    double area = poly_clip_area<QUAD_MAXV, 4>(tv, n0, sv, col, sh_lut, active);
+    if (active) {
+        if (area == TRI_AREA_OVERFLOW) {
+            area = AREA_OVERFLOW;
+            atomicAdd(overflow_count, 1);
+        }
+        cand_area[c] = area;
+    }
+    {
+        const int lane = threadIdx.x & 63;
+        const int t_prev = __shfl_up(t, 1, 64);
+        const bool head = lane == 0 || t_prev != t;
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long surv = __ballot(active && area > 0);
+        if (head && t >= 0) {
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+            const int next = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+            unsigned long long run = next == 64 ? ~0ull : ((1ull << next) - 1);
+            run &= ~((1ull << lane) - 1);
+            const int n = __popcll(surv & run);
+            if (n > 0) atomicAdd(&nnz_row[t], n);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // CSR assembly
 // ---------------------------------------------------------------------------------------------
@@ -1209,6 +1276,13 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
             XR_LAUNCH("clip_tri", (k_clip_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
                       query->qo_fxy(), query->m, tree->rec_fxy.get(), tree->m, cand_tgt, cand_src, C, cand_area,
                       tree->rec_face.get(), cand_sid, overflow_count, nnz_row, remap);
+    } else if (query->m == 4 && tree->m == 3 && !(getenv("XR_CLIP_QUAD") && atoi(getenv("XR_CLIP_QUAD")) == 0)) {
+        // quadrilateral targets (a raster) x triangle source (XR_CLIP_QUAD=0: the slot-loop kernel, A/B switch)
+        constexpr int BLOCK = 256;
+        const size_t shmem = (size_t)(QUAD_MAXV + 2) * BLOCK * sizeof(double2);
+        XR_LAUNCH("clip_quad_tri", (k_clip_quad_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
+                  query->qo_fxy(), query->qo_len(), tree->rec_fxy.get(), cand_tgt, cand_src, C, cand_area, tree->rec_face.get(),
+                  cand_sid, overflow_count, nnz_row, remap);
     } else if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
