@@ -3,8 +3,10 @@
 Benchmark of the regridding hot path on MI355X.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (launches itself under torch.distributed.run, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --project-shards 8 [--strong]          (ONE GPU: per-shard table + projected 8-GPU step)
 
 Metric (BASELINE.json): target cells regridded / s for an OverlapRegridder, area-weighted mean.
 Workload at N = 1: BASELINE config 2 -- a ~1M-triangle Delaunay source mesh (500k jittered-lattice
@@ -186,6 +188,19 @@ def cpu_baseline(sxy, sf, txy, tf, data):
     }, out[0]
 
 
+def make_step(E, ms, mt, d_src, d_out, state):
+    """One step of the headline: nothing cached (both meshes lose their derived state), then the whole weight build and the
+    mean apply of one variable, from HBM-resident raw arrays to an HBM-resident result."""
+    def step():
+        ms.invalidate()
+        mt.invalidate()
+        csr = ms.overlap(mt)  # prepare x2 + index + search + clip + CSR
+        csr.apply_dev(d_src, E.XR_F64, 1, d_out, 0)
+        state["csr"] = csr
+
+    return step
+
+
 def run_single(args):
     import ctypes
 
@@ -205,13 +220,7 @@ def run_single(args):
     _lib.check(lib.xr_dev_upload(d_src, data.ctypes.data_as(ctypes.c_void_p), 8 * S))
 
     state = {}
-
-    def step():
-        ms.invalidate()
-        mt.invalidate()
-        csr = ms.overlap(mt)  # prepare x2 + index + search + clip + CSR
-        csr.apply_dev(d_src.value, E.XR_F64, 1, d_out.value, 0)
-        state["csr"] = csr
+    step = make_step(E, ms, mt, d_src.value, d_out.value, state)
 
     for _ in range(args.warmup):
         step()
@@ -252,6 +261,44 @@ def run_single(args):
         host_times.append(time.perf_counter() - t0)
     del hs, ht, h_out
     host_to_host_ms = 1e3 * float(np.median(host_times[1:]))  # (the first pass warms the pinned staging path)
+    # ... and through the PUBLIC API, as a user of the reference would write it (regridder.py:505-512, :212-262):
+    # OverlapRegridder(Ugrid2d(...), Ugrid2d(...), "mean").regrid(data) from host arrays to a host result -- everything the
+    # Python layer adds (constructor checks, grid wrappers, result allocation) is inside.  Median of 5 after one warm-up,
+    # with a phase split taken on further passes.
+    def api_once(split=None):
+        t = [time.perf_counter()]
+        src_g = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+        tgt_g = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+        t.append(time.perf_counter())
+        if split is not None:
+            src_g.device_mesh, tgt_g.device_mesh  # (uploads on their own; otherwise they happen inside the constructor below)
+            E.dev_sync()
+            t.append(time.perf_counter())
+        rg = xa.OverlapRegridder(src_g, tgt_g, method="mean")
+        if split is not None:
+            E.dev_sync()
+        t.append(time.perf_counter())
+        res = rg.regrid(data)
+        t.append(time.perf_counter())
+        if split is not None:
+            for k, v in zip(("grid_wrappers", "uploads", "constructor_weights", "regrid_apply_download"), np.diff(t)):
+                split.setdefault(k, []).append(1e3 * v)
+        return t[-1] - t[0], (src_g, tgt_g, rg, res)
+
+    api_times, keep = [], None
+    for _ in range(6):
+        del keep
+        E.dev_sync()
+        dt, keep = api_once()
+        api_times.append(dt)
+    api_ms = 1e3 * float(np.median(api_times[1:]))
+    api_split = {}
+    for _ in range(3):
+        del keep
+        E.dev_sync()
+        _, keep = api_once(api_split)
+    del keep
+    api_phases = {k: round(float(np.median(v)), 4) for k, v in api_split.items()}
 
     # per-kernel durations: the same K steps with hipEvents around every launch (engine stream); the W warm-up steps again
     # first (the host-array passes above ran other kernels and released their buffers)
@@ -402,6 +449,12 @@ def run_single(args):
             "host_to_host_note": "mesh uploads (pageable host arrays; the int64 connectivity is narrowed to int32 while it is "
             "copied into the pinned staging buffers) + weights + apply + download of the result vector over PCIe, median of 5; "
             "not part of `value`",
+            "api_ms": api_ms,
+            "api_phases_ms": api_phases,
+            "api_note": "xa.OverlapRegridder(xa.Ugrid2d(x, y, -1, faces), xa.Ugrid2d(...), method='mean').regrid(data): host arrays "
+            "in, host result out, through the reference-shaped Python classes; median of 5 after a warm-up.  api_phases_ms "
+            "(further passes with a synchronisation between the phases): grid wrappers / uploads / constructor = weights / "
+            "regrid = apply + download",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
@@ -635,6 +688,42 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
     return out
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run (no WORLD_SIZE in the environment): re-exec this very
+    command line under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N` on a free local port, one rank per
+    GPU.  Rank 0's JSON line passes through on stdout; the exit code is non-zero if any rank failed."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (the host driver only supports dmabuf IPC: RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={max(1, args.gpus)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] launching", " ".join(cmd))
+    return subprocess.call(cmd, env=env)
+
+
+def make_backend(args, local_rank):
+    """HipBackend (the product).  --compute-backend module:attr is a TEST hook: tests/test_distributed_cpu.py runs this
+    file end to end on CPU (gloo, world size 2) with the oracle-backed stand-in that lives under tests/."""
+    if args.compute_backend:
+        import importlib
+
+        mod, attr = args.compute_backend.split(":")
+        return getattr(importlib.import_module(mod), attr)()
+    from xugrid_amd.distributed import HipBackend
+
+    return HipBackend(local_rank)
+
+
 def run_multi(args):
     """One rank per GPU (RCCL).  Three workloads, all reported as whole-job throughput over max-over-ranks time:
       default    WEAK scaling of the headline: N tiles of BASELINE config 2 (N x 1M source and target triangles); a step
@@ -643,24 +732,57 @@ def run_multi(args):
                  the N ranks, so that N = 8 IS config 4
       --k 256    BASELINE config 5 at N GPUs: cached sharded weights, K stacked variables; a step = the apply of the K
                  variables (partial states in tiles + the tile-pipelined exchange), no weight build
+    The default invocation at N > 1 carries the other two as `other_configs` of the same JSON line (fewer steps), so that
+    ONE run per N yields the three multi-GPU numbers of the north star.
     """
     import torch
     import torch.distributed as dist
 
-    from xugrid_amd import meshgen
-    from xugrid_amd.distributed import (HipBackend, ShardedOverlapRegridder, TargetPartitionedRegridder,
-                                        init_process_group_from_env)
+    from xugrid_amd.distributed import init_process_group_from_env
 
-    init_process_group_from_env("nccl")
+    dist_backend = args.dist_backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    init_process_group_from_env(dist_backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
-    backend = HipBackend(local_rank)
+    backend = make_backend(args, local_rank)
     K = max(1, int(args.k))
+    result = multi_workload(args, backend, strong=args.strong, K=K, steps=args.steps, warmup=args.warmup,
+                            both_exchanges=True, setup_leg=True)
+    if K == 1 and not args.strong and not args.no_extras and (world > 1 or args.multi_extras):
+        few, few_w = max(1, min(args.steps, 10)), max(1, min(args.warmup, 3))
+        others = {}
+        for name, kw in (("config4_strong_10M", dict(strong=True, K=1)),
+                         ("config5_apply_K%d" % args.extras_k, dict(strong=False, K=max(2, args.extras_k)))):
+            try:
+                others[name] = multi_workload(args, backend, steps=few, warmup=few_w, both_exchanges=False,
+                                              setup_leg=False, **kw)
+            except Exception as e:  # noqa: BLE001 -- (the headline line must survive a failing extra; all ranks see the same error)
+                others[name] = {"error": repr(e)}
+        if rank == 0:
+            result["other_configs"] = others
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def multi_workload(args, backend, strong, K, steps, warmup, both_exchanges, setup_leg):
+    """One of the three multi-GPU workloads on the initialised process group -> the JSON object (rank 0; None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+
+    from xugrid_amd import meshgen
+    from xugrid_amd.distributed import HipBackend, ShardedOverlapRegridder, TargetPartitionedRegridder
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = getattr(backend, "device", None)
+    on_gpu = dev is not None and dev.type == "cuda"
+    dsync = torch.cuda.synchronize if on_gpu else (lambda: None)
     # Weak scaling: N tiles of the single-GPU benchmark pair (the same Delaunay meshes, hull slivers included, side by
     # side), N x 1M faces per mesh.  One qhull run serves any N; with --points > 600k (config 4's 10M faces on one box)
     # or --no-delaunay the lattice-split triangulation is used so that set-up stays within seconds.
     t_gen = time.perf_counter()
-    if args.strong:
+    if strong:
         sxy, sf, txy, tf = make_meshes(args.strong_points, delaunay=False)
         mesh_kind = "BASELINE config 4, fixed size (lattice-split triangulation)"
     elif args.no_delaunay or args.points > 600_000:
@@ -681,8 +803,8 @@ def run_multi(args):
         (K, S) block -- 2 GB per 1M faces -- is never built)."""
         if K == 1:
             return rg.local_source(data)
-        cen = torch.as_tensor(sxy[sf[rg.local_faces]].mean(axis=1), device=backend.device)
-        phase = 2.0 * np.pi * torch.arange(K, device=backend.device, dtype=torch.float64)[:, None] / K
+        cen = torch.as_tensor(sxy[sf[rg.local_faces]].mean(axis=1), device=dev)
+        phase = 2.0 * np.pi * torch.arange(K, device=dev, dtype=torch.float64)[:, None] / K
         return (torch.sin(6.0 * np.pi * cen[None, :, 0] + phase) * torch.cos(4.0 * np.pi * cen[None, :, 1])).contiguous()
 
     # K > 1 (cached weights, many variables): by default the TARGETS are partitioned -- every rank owns a slice of the rows
@@ -692,15 +814,31 @@ def run_multi(args):
     # that path measurable: one rank, K = 256: 19.7 ms per step against 1.8 ms).
     target_partitioned = K > 1 and args.k_mode == "target"
 
+    def timed(fn, n):
+        """n calls of fn bracketed by barrier + device synchronisation on both sides -> (max-over-ranks seconds, own seconds)"""
+        dsync()
+        dist.barrier()
+        dsync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        dsync()
+        mine = time.perf_counter() - t0  # this rank's own time to finish (before the closing barrier)
+        dist.barrier()
+        dsync()
+        elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        return float(elapsed.item()), mine
+
     def measure(exchange):
-        torch.cuda.synchronize()
+        dsync()
         t0 = time.perf_counter()
         if target_partitioned:
             rg = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method="mean")
         else:
             rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=exchange,
                                          k_tile=args.k_tile)
-        torch.cuda.synchronize()
+        dsync()
         setup_s = time.perf_counter() - t0
         local = local_block(rg)
 
@@ -709,32 +847,22 @@ def run_multi(args):
                 rg.rebuild()
             return rg.regrid_local(local)
 
-        for _ in range(args.warmup):
+        for _ in range(warmup):
             step()
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        mine = time.perf_counter() - t0  # this rank's own time to finish its K steps (before the closing barrier)
-        dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=backend.device)
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        elapsed, mine = timed(step, steps)
         # the exchange step by itself: the same steps again with device events around every collective (untimed leg)
-        if target_partitioned:
-            exch_ms, n_coll, eb = 0.0, 0, {"sent_off_gpu": 0}
+        if target_partitioned or not on_gpu:
+            exch_ms, n_coll = 0.0, 0
+            eb = {"sent_off_gpu": 0} if target_partitioned else rg.exchange_bytes(K)
         else:
             rg.start_timing()
-            for _ in range(args.steps):
+            for _ in range(steps):
                 step()
             exch_ms, n_coll = rg.stop_timing()
             eb = rg.exchange_bytes(K)
-        per_rank = torch.tensor([mine / args.steps * 1e3, exch_ms / args.steps, float(eb["sent_off_gpu"]),
+        per_rank = torch.tensor([mine / steps * 1e3, exch_ms / steps, float(eb["sent_off_gpu"]),
                                  float(rg.local_faces.size), float(rg.local_targets.size), float(rg.weights.nnz)],
-                                dtype=torch.float64, device=backend.device)
+                                dtype=torch.float64, device=dev)
         gathered = [torch.empty_like(per_rank) for _ in range(world)]
         dist.all_gather(gathered, per_rank)
         table = torch.stack(gathered).cpu().numpy()
@@ -743,115 +871,339 @@ def run_multi(args):
                                  "all": [round(float(v), 4) for v in table[:, 0]]},
             "exchange_ms": float(table[:, 1].max()),
             "exchange_ms_per_rank": {"min": float(table[:, 1].min()), "max": float(table[:, 1].max())},
-            "collectives_per_step": n_coll / max(1, args.steps),
+            "collectives_per_step": n_coll / max(1, steps),
             "exchange_bytes_sent_per_rank": {"min": int(table[:, 2].min()), "max": int(table[:, 2].max()),
                                              "total": int(table[:, 2].sum())},
             "source_faces_per_rank": {"min": int(table[:, 3].min()), "max": int(table[:, 3].max())},
             "target_faces_per_rank": {"min": int(table[:, 4].min()), "max": int(table[:, 4].max())},
             "nnz": int(table[:, 5].sum()),
         }
-        return rg, step, float(elapsed.item()), stats, setup_s
+        return rg, step, local, elapsed, stats, setup_s
 
-    rg, step, elapsed, stats, setup_s = measure(args.exchange)
+    rg, step, local, elapsed, stats, setup_s = measure(args.exchange)
     other = "dense" if args.exchange == "sparse" else "sparse"
-    if target_partitioned:
-        elapsed_other, stats_other = elapsed, stats  # (no exchange step: nothing to compare)
+    if target_partitioned or not both_exchanges:
+        elapsed_other, stats_other = None, None
     else:
-        _, _, elapsed_other, stats_other, _ = measure(other)
+        _, _, _, elapsed_other, stats_other, _ = measure(other)
+    # Like for like with N = 1, whose step starts from the raw arrays of the whole mesh: here the raw arrays of the SHARD
+    # have to be cut out of the replicated mesh first -- partition of the source faces, near-shard filter of the targets,
+    # the shard's two mesh handles (device to device), the exchange lists -- all of it device code from HBM-resident
+    # tensors (ShardedOverlapRegridder.setup).  A "step including set-up" = setup() [which builds the weights] + the apply
+    # + the exchange; reported beside the headline, which keeps the partition across steps as a real job would.
+    including = None
+    if setup_leg and K == 1 and not target_partitioned:
+        def full_step():
+            rg.setup()
+            return rg.regrid_local(local)
+
+        full_step()
+        n_full = max(1, min(steps, 10))
+        el_full, _ = timed(full_step, n_full)
+        ms_full = 1e3 * el_full / n_full
+        including = {"ms_per_step_including_setup": ms_full,
+                     "setup_ms_per_rebuild": ms_full - 1e3 * elapsed / steps,
+                     "value_including_setup": T * K / (el_full / n_full), "steps": n_full,
+                     "what": "partition of the source faces + near-shard target filter + the shard's mesh handles (device to "
+                             "device) + exchange lists, redone every step from the HBM-resident replicated meshes, then "
+                             "weight build + apply + exchange: what N = 1 counts from its raw arrays"}
     # rank 0's kernels of a few more steps (hipEvents around every launch): roofline of its dominant kernel
     roofline = None
-    from xugrid_amd import engine as E
+    if on_gpu and isinstance(backend, HipBackend):
+        from xugrid_amd import engine as E
 
-    with E.KernelTimer() as kt:
-        for _ in range(3):
-            step()
-    dist.barrier()
-    if rank == 0:
-        try:
-            kernels = {k: (n, t / n) for k, (n, t) in kt.records.items()}
-            per_step = {k: n * avg / 3 for k, (n, avg) in kernels.items()}
-            side = {"search_big", "clip_big", "big_rank", "big_scan", "row_fill_long"}
-            dominant = max((k for k in per_step if k not in side), key=per_step.get)
-            s_loc, t_loc = rg.local_faces.size, rg.local_targets.size
-            ab = algorithmic_bytes(s_loc, t_loc, sxy.shape[0] // world, txy.shape[0] // world, rg.weights.nnz, K=K)
-            # K = 1: SURVEY 8(d) B_build of the rank's shard / its dominant kernel; K > 1 (cached weights): B_apply of the shard
-            dom_bytes, dom_ms = (ab["build"] if K == 1 else ab["apply"]), kernels[dominant][1]
-            launches = kernels[dominant][0] / 3
-            achieved = dom_bytes / (dom_ms * launches * 1e-3) / 1e9 if dom_bytes else None
-            roofline = {
-                "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
-                "algorithmic_bytes_per_step": dom_bytes, "avg_launch_ms": dom_ms, "launches_per_step": launches, "rank": 0,
-                "local_source_faces": int(s_loc), "local_target_faces": int(t_loc),
-                "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
-            }
-        except Exception as e:  # noqa: BLE001
-            roofline = {"error": repr(e)}
-    if rank == 0:
-        exchange_name = {"sparse": "RCCL sparse all-to-all (the reduce-scatter restricted to the touched targets) of per-target partial sums",
-                         "dense": "RCCL reduce-scatter of per-target partial sums"}
-        units = T * K
-        if K > 1:
-            metric = f"target cell-variables regridded/s (cached OverlapRegridder weights, K={K} stacked variables, mean apply)"
-            workload = (f"BASELINE config 5 at {world} GPU(s) ({mesh_kind}): {S} source -> {T} target triangles, cached weights, "
-                        + (f"K={K} variables; target rows partitioned over the ranks (complete rows on their owner: no collective)"
-                           if target_partitioned else f"source-sharded, K={K} variables exchanged in tiles of {args.k_tile}"))
-            unit = "target cell-variables/s"
-        elif args.strong:
-            metric = "target cells regridded/s (OverlapRegridder 10M->10M tri, source faces sharded, weights + mean apply)"
-            workload = (f"{mesh_kind}: {S} source -> {T} target triangles sharded over {world} GPU(s), "
-                        "OverlapRegridder mean, K=1")
-            unit = "target cells/s"
+        with E.KernelTimer() as kt:
+            for _ in range(3):
+                step()
+        dist.barrier()
+        if rank == 0:
+            try:
+                kernels = {k: (n, t / n) for k, (n, t) in kt.records.items()}
+                per_step = {k: n * avg / 3 for k, (n, avg) in kernels.items()}
+                side = {"search_big", "clip_big", "big_rank", "big_scan", "row_fill_long"}
+                dominant = max((k for k in per_step if k not in side), key=per_step.get)
+                s_loc, t_loc = rg.local_faces.size, rg.local_targets.size
+                ab = algorithmic_bytes(s_loc, t_loc, sxy.shape[0] // world, txy.shape[0] // world, rg.weights.nnz, K=K)
+                # K = 1: SURVEY 8(d) B_build of the rank's shard / its dominant kernel; K > 1 (cached weights): B_apply of the shard
+                dom_bytes, dom_ms = (ab["build"] if K == 1 else ab["apply"]), kernels[dominant][1]
+                launches = kernels[dominant][0] / 3
+                achieved = dom_bytes / (dom_ms * launches * 1e-3) / 1e9 if dom_bytes else None
+                roofline = {
+                    "bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS if achieved else None, "traffic": None,
+                    "algorithmic_bytes_per_step": dom_bytes, "avg_launch_ms": dom_ms, "launches_per_step": launches, "rank": 0,
+                    "local_source_faces": int(s_loc), "local_target_faces": int(t_loc),
+                    "kernel_ms_per_step": {k: round(v, 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1])},
+                }
+            except Exception as e:  # noqa: BLE001
+                roofline = {"error": repr(e)}
+    del rg, step, local
+    if rank != 0:
+        return None
+    exchange_name = {"sparse": "RCCL sparse all-to-all (the reduce-scatter restricted to the touched targets) of per-target partial sums",
+                     "dense": "RCCL reduce-scatter of per-target partial sums"}
+    units = T * K
+    if K > 1:
+        metric = f"target cell-variables regridded/s (cached OverlapRegridder weights, K={K} stacked variables, mean apply)"
+        workload = (f"BASELINE config 5 at {world} GPU(s) ({mesh_kind}): {S} source -> {T} target triangles, cached weights, "
+                    + (f"K={K} variables; target rows partitioned over the ranks (complete rows on their owner: no collective)"
+                       if target_partitioned else f"source-sharded, K={K} variables exchanged in tiles of {args.k_tile}"))
+        unit = "target cell-variables/s"
+    elif strong:
+        metric = "target cells regridded/s (OverlapRegridder 10M->10M tri, source faces sharded, weights + mean apply)"
+        workload = (f"{mesh_kind}: {S} source -> {T} target triangles sharded over {world} GPU(s), "
+                    "OverlapRegridder mean, K=1")
+        unit = "target cells/s"
+    else:
+        metric = "target cells regridded/s (OverlapRegridder 1M->1M tri per GPU, weights + mean apply)"
+        workload = (f"{world} x BASELINE config 2 ({mesh_kind}): {S} source -> {T} target triangles, "
+                    "OverlapRegridder mean, K=1")
+        unit = "target cells/s"
+    config = {
+        "workload": workload,
+        "source_faces": S,
+        "target_faces": T,
+        "variables": K,
+        "nnz": stats["nnz"],
+        "parallelism": (f"target rows partitioned over {world} GPUs (contiguous slices + the source faces near them), "
+                        "no data-path collective" if target_partitioned else
+                        f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
+                        + exchange_name[args.exchange]),
+        "rccl_ranks": world,
+        "collective_backend": dist.get_backend(),
+        "exchange": "none" if target_partitioned else args.exchange,
+        "exchange_ms": stats["exchange_ms"],
+        "exchange_ms_note": "device events around every collective of a step (behind the partial-state kernel that feeds "
+        "it / behind the wait for it), max over ranks; measured on a further, untimed set of steps",
+        "per_rank": stats,
+        "setup_s_untimed": {"mesh_generation": t_gen, "partition_filter_first_build": setup_s,
+                            "note": "first construction (host meshes uploaded once, first-use allocations, first weight "
+                            "build, exchange lists); what it costs per rebuild from resident meshes is "
+                            "`including_setup.setup_ms_per_rebuild`"},
+    }
+    if elapsed_other is not None:
+        config["other_exchange"] = {"exchange": other, "ms_per_step": 1e3 * elapsed_other / steps,
+                                    "value": units / (elapsed_other / steps), "what": exchange_name[other],
+                                    "exchange_ms": stats_other["exchange_ms"],
+                                    "exchange_bytes_sent_per_rank": stats_other["exchange_bytes_sent_per_rank"]}
+    elif target_partitioned:
+        config["other_exchange"] = {"exchange": "none", "exchange_ms": 0.0}
+    if including is not None:
+        config["including_setup"] = including
+    return {
+        "metric": metric,
+        "value": units / (elapsed / steps),
+        "unit": unit,
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / steps,
+        "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": config,
+        "roofline": roofline,
+        "cpu_baseline": None,
+    }
+
+
+XGMI_LINK_GBS = 153.0   # per direct xGMI link and direction (7 links x ~153 GB/s per GPU)
+EXCHANGE_LATENCY_MS = 0.03  # launch + hand-shake of one small all-to-all (assumption of the projection)
+
+
+class ProjectionDist:
+    """Stand-in for the few torch.distributed calls of ShardedOverlapRegridder, for ONE "rank" at a time on ONE GPU
+    (`bench.py --project-shards W`): the exchange LISTS are the real ones (computed from all W shards beforehand), the
+    data path of a collective is a device copy of the right shape -- its time is measured and taken out of the
+    projection, which prices the exchange from the bytes and the xGMI link rate instead."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, rank, world, counts, ids_to):
+        self.rank, self.world, self.counts, self.ids_to = rank, world, counts, ids_to
+        self._cycle = {}
+
+    def get_rank(self, group=None):
+        return self.rank
+
+    def get_world_size(self, group=None):
+        return self.world
+
+    def get_backend(self, group=None):
+        return "nccl"
+
+    def barrier(self, group=None):
+        pass
+
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
+        import torch
+
+        if input.dtype == torch.int64 and input_split_sizes is None:      # set-up: how many rows every sender has for me
+            output.copy_(torch.as_tensor(self.counts[:, self.rank], device=output.device))
+        elif input.dtype == torch.int64:                                   # set-up: which of my targets they are
+            parts = [self.ids_to[s][self.rank] for s in range(self.world)]
+            output.copy_(torch.cat(parts) if parts else input[:0])
+        else:                                                              # a step: rows of partial states (values: my own, cycled)
+            n_out, n_in = output.shape[0], input.shape[0]
+            if n_out and n_in:
+                key = (n_out, n_in)
+                if key not in self._cycle:
+                    self._cycle[key] = torch.arange(n_out, device=output.device) % n_in
+                torch.index_select(input, 0, self._cycle[key], out=output)
+            elif n_out:
+                output.zero_()
+        return self._Done() if async_op else None
+
+    def reduce_scatter_tensor(self, output, input, op="sum", group=None, async_op=False):
+        output.copy_(input[self.rank])
+        return self._Done() if async_op else None
+
+    def all_gather(self, tensor_list, tensor, group=None):
+        for dst in tensor_list:
+            dst.copy_(tensor)
+
+
+def run_projection(args):
+    """ONE GPU, W shards one after another: the real ShardedOverlapRegridder + HipBackend per shard (its own partition,
+    near-shard filter, weight build, partial states, multi-sender combination with the real receive lists), collectives
+    looped back.  Prints the per-shard table, the max / mean imbalance and a PROJECTED W-GPU step: max over shards of the
+    measured compute time + an exchange time modelled from the bytes a rank sends to one peer over one xGMI link.
+    Projected, not measured -- the multi-GPU curve itself is the driver's (bench.py --gpus N)."""
+    import torch
+
+    from xugrid_amd import engine as E, meshgen
+    from xugrid_amd.distributed import HipBackend, ShardedOverlapRegridder, _t, shard_lists
+
+    W = int(args.project_shards)
+    backend = HipBackend(0)
+    dev = backend.device
+    t_gen = time.perf_counter()
+    if args.strong:
+        sxy, sf, txy, tf = make_meshes(args.strong_points, delaunay=False)
+        mesh_kind = f"BASELINE config 4: fixed {sf.shape[0]} -> {tf.shape[0]} lattice-split triangles over {W} shards (strong)"
+    elif args.no_delaunay or args.points > 600_000:
+        sxy, sf, txy, tf = make_meshes(args.points * W, delaunay=False)
+        mesh_kind = f"{W} x config-2 size, lattice-split triangulation (weak)"
+    else:
+        sxy, sf, txy, tf = make_meshes(args.points, delaunay=True)
+        sxy, sf = meshgen.tiled_mesh(sxy, sf, W)
+        txy, tf = meshgen.tiled_mesh(txy, tf, W)
+        mesh_kind = f"{W} tiles of the Delaunay benchmark pair (weak)"
+    t_gen = time.perf_counter() - t_gen
+    S, T = sf.shape[0], tf.shape[0]
+    data = meshgen.smooth_field(sxy[sf].mean(axis=1), 0)
+    steps, warmup = max(1, min(args.steps, 20)), max(1, min(args.warmup, 5))
+
+    def shard_tables(world):
+        """the real exchange lists of all `world` shards: counts[s, o] rows of sender s for owner o, and the ids"""
+        full = (_t(sxy, dev), _t(sf.astype(np.int64), dev), _t(txy, dev), _t(tf.astype(np.int64), dev))
+        t_chunk = -(-T // world)
+        counts = np.zeros((world, world), dtype=np.int64)
+        ids_to = []
+        for r in range(world):
+            _, lt = shard_lists(full, world, r, args.partition)
+            owner = torch.div(lt, t_chunk, rounding_mode="floor")
+            counts[r] = torch.bincount(owner, minlength=world).cpu().numpy()
+            local = lt - owner * t_chunk
+            ids_to.append(list(torch.split(local, [int(c) for c in counts[r]])))
+        del full
+        return counts, ids_to
+
+    def run_shards(world):
+        counts, ids_to = shard_tables(world)
+        rows = []
+        for r in range(world):
+            pd = ProjectionDist(r, world, counts, ids_to)
+            rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=args.exchange,
+                                         k_tile=args.k_tile, dist=pd)
+            local = rg.local_source(data)
+
+            def step():
+                rg.rebuild()
+                return rg.regrid_local(local)
+
+            for _ in range(warmup):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            step_ms = 1e3 * (time.perf_counter() - t0) / steps
+            rg.start_timing()
+            for _ in range(steps):
+                step()
+            loop_ms, _ = rg.stop_timing()
+            loop_ms /= steps
+            with E.KernelTimer() as kt:
+                for _ in range(3):
+                    step()
+            kms = {k: round(t / 3, 4) for k, (n, t) in kt.records.items()}
+            C = backend.n_components(rg.method.method_id)
+            sent = counts[r].copy()
+            sent[r] = 0
+            rows.append({
+                "shard": r, "source_faces": int(rg.local_faces.size), "target_faces": int(rg.local_targets.size),
+                "nnz": int(rg.weights.nnz), "step_ms": step_ms, "loopback_copy_ms": loop_ms, "compute_ms": step_ms - loop_ms,
+                "rows_sent_off_gpu": int(sent.sum()), "bytes_sent_off_gpu": int(8 * C * sent.sum()),
+                "bytes_to_busiest_peer": int(8 * C * sent.max()),
+                "rows_received": int(counts[:, r].sum()),
+                "side_chain_ms": round(sum(kms.get(k, 0.0) for k in ("search_big", "clip_big", "row_fill_long")), 4),
+                "kernel_ms": dict(sorted(kms.items(), key=lambda kv: -kv[1])[:8]),
+            })
+            del rg, local, step
+            log(f"[project] W={world} shard {r}: step {step_ms:.3f} ms (loop-back copy {loop_ms:.3f}), "
+                f"S_loc {rows[-1]['source_faces']} T_loc {rows[-1]['target_faces']} nnz {rows[-1]['nnz']}")
+        comp = np.array([x["compute_ms"] for x in rows])
+        exch_ms = max(x["bytes_to_busiest_peer"] for x in rows) / (XGMI_LINK_GBS * 1e9) * 1e3 + (EXCHANGE_LATENCY_MS if world > 1 else 0.0)
+        return rows, comp, exch_ms
+
+    rows, comp, exch_ms = run_shards(W)
+    projected_ms = float(comp.max() + exch_ms)
+    # the 1-GPU point of the same curve through the same code (one shard = the whole problem of ONE GPU's share)
+    if args.strong:
+        base_rows, base_comp, _ = run_shards(1)
+        base_ms, base_cells = float(base_comp.max()), T
+    else:  # weak: one tile on one GPU
+        keep = (sxy, sf, txy, tf, data, S, T)
+        if args.no_delaunay or args.points > 600_000:
+            sxy, sf, txy, tf = make_meshes(args.points, delaunay=False)
         else:
-            metric = "target cells regridded/s (OverlapRegridder 1M->1M tri per GPU, weights + mean apply)"
-            workload = (f"{world} x BASELINE config 2 ({mesh_kind}): {S} source -> {T} target triangles, "
-                        "OverlapRegridder mean, K=1")
-            unit = "target cells/s"
-        result = {
-            "metric": metric,
-            "value": units / (elapsed / args.steps),
-            "unit": unit,
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True,
-            "scaling": "strong" if args.strong else "weak",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": workload,
-                "source_faces": S,
-                "target_faces": T,
-                "variables": K,
-                "nnz": stats["nnz"],
-                "parallelism": (f"target rows partitioned over {world} GPUs (contiguous slices + the source faces near them), "
-                                "no data-path collective" if target_partitioned else
-                                f"source faces sharded over {world} GPUs ({args.partition} blocks), target replicated, "
-                                + exchange_name[args.exchange]),
-                "rccl_ranks": world,
-                "collective_backend": dist.get_backend(),
-                "exchange": "none" if target_partitioned else args.exchange,
-                "exchange_ms": stats["exchange_ms"],
-                "exchange_ms_note": "device events around every collective of a step (behind the partial-state kernel that feeds "
-                "it / behind the wait for it), max over ranks; measured on a further, untimed set of steps",
-                "per_rank": stats,
-                "other_exchange": {"exchange": other, "ms_per_step": 1e3 * elapsed_other / args.steps,
-                                   "value": units / (elapsed_other / args.steps), "what": exchange_name[other],
-                                   "exchange_ms": stats_other["exchange_ms"],
-                                   "exchange_bytes_sent_per_rank": stats_other["exchange_bytes_sent_per_rank"]},
-                "setup_s_untimed": {"mesh_generation": t_gen, "partition_filter_first_build": setup_s,
-                                    "note": "set-up (torch ops on the device: centroids, Morton partition, work estimate, "
-                                    "near-shard filter, mesh upload, first weight build, exchange lists) is done once "
-                                    "per regridder and is not part of the step"},
-            },
-            "roofline": roofline,
-            "cpu_baseline": None,
-        }
-        print(json.dumps(result), flush=True)
-    dist.barrier()
-    dist.destroy_process_group()
+            sxy, sf, txy, tf = make_meshes(args.points, delaunay=True)
+        S, T = sf.shape[0], tf.shape[0]
+        data = meshgen.smooth_field(sxy[sf].mean(axis=1), 0)
+        base_rows, base_comp, _ = run_shards(1)
+        base_ms, base_cells = float(base_comp.max()), T
+        sxy, sf, txy, tf, data, S, T = keep
+    value_1 = base_cells / (base_ms * 1e-3)
+    value_w = T / (projected_ms * 1e-3)
+    out = {
+        "what": "PROJECTED, NOT MEASURED: W shards of the multi-GPU workload run one after another on ONE MI355X (real "
+                "ShardedOverlapRegridder + HipBackend per shard, collectives looped back); projected step = max over shards of "
+                "the measured compute time + modelled exchange",
+        "workload": mesh_kind, "shards": W, "partition": args.partition, "exchange": args.exchange,
+        "source_faces": S, "target_faces": T, "steps": steps, "warmup": warmup,
+        "per_shard": rows,
+        "imbalance_max_over_mean": float(comp.max() / comp.mean()),
+        "compute_ms": {"max": float(comp.max()), "mean": float(comp.mean()), "min": float(comp.min())},
+        "modelled_exchange_ms": exch_ms,
+        "exchange_model": f"bytes a rank sends to its busiest peer / {XGMI_LINK_GBS} GB/s (one direct xGMI link per peer, all "
+                          f"links in parallel) + {EXCHANGE_LATENCY_MS} ms latency; no overlap with compute assumed",
+        "projected_step_ms": projected_ms, "projected_value_cells_per_s": value_w,
+        "one_gpu_step_ms_same_code": base_ms, "one_gpu_value_cells_per_s": value_1,
+        "projected_speedup_1_to_W": value_w / value_1,
+        "projected_efficiency_1_to_W": value_w / value_1 / W,
+        "scaling": "strong" if args.strong else "weak",
+        "mesh_generation_s": t_gen,
+    }
+    print(json.dumps(out), flush=True)
 
 
 def main():
@@ -876,9 +1228,22 @@ def main():
     ap.add_argument("--k-tile", type=int, default=32, help="variables per collective of the K-tiled exchange")
     ap.add_argument("--k-mode", default="target", choices=["target", "source"],
                     help="K > 1: partition the target rows (no collective; default) or shard the source faces (exchange of partial states)")
+    ap.add_argument("--multi-extras", action="store_true",
+                    help="multi-GPU path with ONE rank: also run the config-4 strong and config-5 K=256 workloads as "
+                    "`other_configs` (done by default when N > 1)")
+    ap.add_argument("--extras-k", type=int, default=256, help="stacked variables of the config-5 extra of the multi-GPU line")
+    ap.add_argument("--project-shards", type=int, default=0,
+                    help="ONE GPU: run each of W shards of the multi-GPU workload one after another (real sharded regridder, "
+                    "looped-back collectives) and print the per-shard table + a projected W-GPU step -- projected, not measured")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"], help=argparse.SUPPRESS)
+    ap.add_argument("--compute-backend", default=None, help=argparse.SUPPRESS)  # test hook: module:attr of a backend class
     args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or args.force_dist:
+    in_group = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.project_shards > 1:
+        run_projection(args)
+    elif (args.gpus > 1 or args.force_dist) and not in_group:
+        sys.exit(self_launch(args))
+    elif in_group and (args.gpus > 1 or args.force_dist or int(os.environ["WORLD_SIZE"]) > 1):
         run_multi(args)
     else:
         run_single(args)

@@ -104,6 +104,14 @@ int xr_set_stream(void *hip_stream, int external, int async_dev);
  * xr_mesh_build_index. */
 int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int faces_itemsize,
                    int64_t n_face, int64_t n_max_node, int64_t fill_value, xr_mesh **out);
+/* The same from arrays that are ALREADY in HBM of the engine's device (a multi-GPU rank that cut its shard out of the
+ * replicated mesh on the device, xugrid_amd/distributed.py; any pipeline that produced the mesh there).  node_xy_dev:
+ * float64[n_node,2]; faces_dev: int32 or int64 [n_face, n_max_node].  Both are COPIED (the handle owns its arrays; the
+ * copy of the connectivity is the same fill -> -1 / narrowing / validation pass xr_mesh_create runs).  The caller's arrays
+ * must be complete in the engine's stream order (xr_set_stream: the caller's own stream) or on the host's view
+ * (after a device synchronisation). */
+int xr_mesh_create_dev(const double *node_xy_dev, int64_t n_node, const void *faces_dev, int faces_itemsize,
+                       int64_t n_face, int64_t n_max_node, int64_t fill_value, xr_mesh **out);
 /* The quad mesh of a rectilinear grid, generated on the device: Ugrid2d.from_structured_bounds ->
  * _from_intervals_helper (xugrid/ugrid/ugrid2d.py:1973-2034, :1894-1912), which is how a raster enters the polygon
  * path when the other grid is unstructured (StructuredGrid2d.convert_to, regrid/structured.py:489-501).
@@ -332,9 +340,12 @@ int xr_csr_col_order(const xr_csr *csr, int64_t *order_out);
 int xr_csr_expect_permuted(xr_csr *csr, int permuted);
 /* The mirror image for the OUTPUT: after xr_csr_output_stored_order(csr, 1) the applies write stored row r to out[k, r]
  * (fully coalesced whatever the caller's numbering) instead of out[k, row_order[r]]; xr_csr_row_order returns the permutation
- * (stored row r = caller's row order[r]; K_hint: the number of variables of the coming applies -- from 8 on the rows are
- * regrouped into 2-D tiles once, which is part of the stored order).  With columns AND rows in the engine's order a pipeline
- * that keeps its blocks on the device pays the caller's numbering once, not per apply. */
+ * (stored row r = caller's row order[r]; K_hint is ignored and kept for binary compatibility).  The regrouping of the rows
+ * into 2-D tiles -- otherwise deferred to the first apply with 8 or more variables -- is part of the stored order: both calls
+ * settle it at once, and from xr_csr_output_stored_order(csr, 1) on the order is FROZEN: xr_csr_set_row_keys refuses
+ * (XR_ERR_INVALID) until the stored-order output is switched off again, so no apply can ever write rows in a permutation
+ * the caller has not read.  With columns AND rows in the engine's order a pipeline that keeps its blocks on the device pays
+ * the caller's numbering once, not per apply. */
 int xr_csr_output_stored_order(xr_csr *csr, int stored);
 int xr_csr_row_order(const xr_csr *csr, int64_t K_hint, int64_t *order_out);
 int xr_csr_destroy(xr_csr *csr);

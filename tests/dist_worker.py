@@ -24,6 +24,10 @@ class OracleWeights:
     def __init__(self, data, indices, indptr, n, m=None):
         self.data, self.indices, self.indptr, self.n, self.m = data, indices, indptr, n, m
 
+    @property
+    def nnz(self):
+        return int(np.asarray(self.data).size)
+
 
 COMPONENTS = {0: 2, 8: 2, 3: 2, 1: 2, 2: 4, 4: 2, 5: 2}  # method id -> partial-state components (include/xugrid_amd.h)
 NAMES = {0: "mean", 1: "harmonic_mean", 2: "geometric_mean", 3: "sum", 4: "minimum", 5: "maximum", 6: "mode",
@@ -38,11 +42,15 @@ class OracleBackend:
     device = None
 
     def build_weights(self, src_xy, src_faces, tgt_xy, tgt_faces, relative=False):
+        self._last = (src_xy, src_faces, tgt_xy, tgt_faces, relative)
         q, s, a = O.CellTree2d(src_xy, src_faces).intersect_faces(tgt_xy, tgt_faces)
         if relative:
             a = a / O.area(src_xy, src_faces)[s]
         T = np.asarray(tgt_faces).shape[0]
         return OracleWeights(a, s, O.to_csr_indptr(q, T), T, np.asarray(src_faces).shape[0])
+
+    def rebuild_weights(self):
+        return self.build_weights(*self._last)
 
     def download_weights(self, w):
         return w.data, w.indices, w.indptr, w.n, w.m

@@ -179,3 +179,38 @@ def test_sharded_regridder_world3_and_8_loopback(oracle):
         return True
 
     assert run_ranks(2, refuse)[0] == [True, True]
+
+
+def test_bench_self_launches_two_ranks_on_gloo(tmp_path):
+    """`python bench.py --gpus 2` with no torch.distributed environment: bench.py re-execs itself under
+    torch.distributed.run (free port, one rank per "GPU"), rank 0 prints ONE JSON line, the exit code is that of the job.
+    On CPU the collectives are gloo and the compute backend is the oracle-backed stand-in of tests/dist_worker.py (a test
+    hook of bench.py); what runs is bench.py's own launcher, workload set-up, timing protocol and reporting."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--points", "1500",
+           "--no-delaunay", "--dist-backend", "gloo", "--compute-backend", "tests.dist_worker:OracleBackend",
+           "--multi-extras", "--strong-points", "1200", "--extras-k", "3"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line (rank 0)"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    cfg = line["config"]
+    assert cfg["rccl_ranks"] == 2 and cfg["collective_backend"] == "gloo"
+    assert len(cfg["per_rank"]["step_ms_per_rank"]["all"]) == 2
+    inc = cfg["including_setup"]  # like for like with N = 1: the set-up a step from raw arrays would count
+    assert inc["ms_per_step_including_setup"] > 0 and inc["value_including_setup"] > 0
+    assert cfg["other_exchange"]["exchange"] == "dense"
+    others = line["other_configs"]
+    strong = others["config4_strong_10M"]
+    assert strong["scaling"] == "strong" and strong["n_gpus"] == 2 and strong["value"] > 0
+    k3 = others["config5_apply_K3"]
+    assert k3["config"]["variables"] == 3 and k3["unit"] == "target cell-variables/s" and k3["config"]["exchange"] == "none"
+    # a failing rank makes the launcher's exit code non-zero
+    bad = subprocess.run(cmd[:-6] + ["--compute-backend", "tests.dist_worker:NoSuchBackend"], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert bad.returncode != 0

@@ -129,13 +129,11 @@ def test_config4_10m_single_gpu(hip, oracle):
 
 def test_bench_multi_gpu_path_10m_one_rank():
     """The SCALE path of bench.py at config 4's size through a one-rank RCCL group (the box has one GPU)."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (no torch.distributed variables in the environment: bench.py launches itself under torch.distributed.run, the way the
+    # driver's plain `python bench.py --gpus N` would)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     for exchange in ("dense", "sparse"):
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--points", "5000000", "--steps", "3",
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--points", "5000000", "--steps", "3",
                "--warmup", "1", "--exchange", exchange]
         proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
         assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
@@ -143,6 +141,14 @@ def test_bench_multi_gpu_path_10m_one_rank():
         assert line["n_gpus"] == 1 and line["config"]["target_faces"] > 9_900_000
         assert line["value"] > 1e8 and line["config"]["nnz"] > 40_000_000
         _check_scale_fields(line, exchange, 1)
+        inc = line["config"]["including_setup"]  # the set-up N = 1 counts, from HBM-resident meshes
+        assert inc["ms_per_step_including_setup"] > line["ms_per_step"] and inc["value_including_setup"] > 1e7
+    # the same through an explicit environment (how torch.distributed.run starts the ranks)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
     # the other workloads of the SCALE line: config 4 as a strong-scaling pair; config 5 (K = 256) on cached weights --
     # target rows partitioned (default: no collective) and source-sharded (partial states exchanged in 8 tiles of 32)
     runs = ((["--strong", "--strong-points", "5000000"], "strong", "sparse"),
@@ -164,6 +170,39 @@ def test_bench_multi_gpu_path_10m_one_rank():
                 assert line["value"] > 2e9
         else:
             assert line["config"]["target_faces"] > 9_900_000 and "config 4" in line["config"]["workload"]
+
+
+def test_bench_one_invocation_three_multi_gpu_numbers():
+    """`bench.py --gpus N` (N > 1 by default; one rank here with --multi-extras) carries the config-4 strong and the
+    config-5 K-variable workloads as `other_configs` of the ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--multi-extras", "--steps", "3",
+           "--warmup", "1", "--points", "200000", "--no-delaunay", "--strong-points", "400000", "--extras-k", "32"]
+    proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    line = json.loads(lines[-1])
+    _check_scale_fields(line, "sparse", 1)
+    strong = line["other_configs"]["config4_strong_10M"]
+    assert strong["scaling"] == "strong" and strong["config"]["target_faces"] > 700_000 and strong["value"] > 1e8
+    k32 = line["other_configs"]["config5_apply_K32"]
+    assert k32["config"]["variables"] == 32 and k32["config"]["exchange"] == "none" and k32["value"] > 1e10
+
+
+def test_bench_projection_of_eight_shards():
+    """`bench.py --project-shards 8`: the eight shards of the multi-GPU workload one after another on the one GPU."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in ([], ["--strong", "--strong-points", "800000"]):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--project-shards", "8", "--steps", "3", "--warmup", "1",
+               "--points", "100000", "--no-delaunay"] + extra
+        proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-3000:]
+        out = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+        assert out["shards"] == 8 and len(out["per_shard"]) == 8 and "PROJECTED" in out["what"]
+        assert sum(r["source_faces"] for r in out["per_shard"]) == out["source_faces"]  # disjoint and complete
+        assert all(r["nnz"] > 0 and r["compute_ms"] > 0 for r in out["per_shard"])
+        assert 1.0 <= out["imbalance_max_over_mean"] < 2.0
+        assert out["projected_step_ms"] > 0 and 0 < out["projected_efficiency_1_to_W"] < 1.5
 
 
 def _check_scale_fields(line, exchange, world):

@@ -882,3 +882,45 @@ def test_apply_in_engine_order(hip, oracle, kind):
     csr.expect_permuted(False)
     for c in cases[:4]:
         assert same_or_nan(csr.apply(v[: c[2]], c[0], c[1]), ref[c]).all(), (kind, c, "caller order again")
+
+
+def test_stored_row_order_is_frozen_once_handed_out(hip):
+    """The stored row order is settled by the call that hands it out, whatever the number of variables of the later
+    applies: read the order FIRST (the old default was K = 1, which left the row tiling pending), then apply 1 and 16
+    variables -- both come out in the order that was read.  While the output is delivered in stored order new row keys
+    are refused; after switching it off they are accepted and the order read afterwards is the new one."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.triangle_mesh(20000, 3)
+    txy, tf = meshgen.triangle_mesh(24000, 4, 30.0, 0.8)
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    for kind in ("built", "uploaded"):
+        csr = ms.overlap(mt)
+        if kind == "uploaded":
+            data, idx, indptr = csr.download()
+            csr = E.DeviceCSR.from_arrays(data, idx, indptr, csr.n, csr.m)
+            csr.set_row_keys(*E.morton_row_keys(mt.centroids(), faces_per_tile=64))
+        v = np.random.default_rng(3).normal(size=(16, csr.m))
+        ref = csr.apply(v[:1]), None
+        csr_ref = ms.overlap(mt)
+        ref16 = csr_ref.apply(v)
+        csr.output_stored_order(True)
+        order = csr.row_order()  # (no K: the tiling is settled here)
+        for K in (1, 16, 3, 16):
+            got = csr.apply(v[:K])
+            back = np.empty_like(got)
+            back[:, order] = got
+            assert same_or_nan(back, ref16[:K]).all(), (kind, K)
+        assert np.array_equal(csr.row_order(), order)
+        with pytest.raises(ValueError, match="frozen"):
+            csr.set_row_keys(*E.morton_row_keys(mt.centroids(), faces_per_tile=4))
+        csr.output_stored_order(False)
+        assert same_or_nan(csr.apply(v), ref16).all()
+        csr.set_row_keys(*E.morton_row_keys(mt.centroids(), faces_per_tile=4))
+        csr.output_stored_order(True)
+        order2 = csr.row_order()
+        assert not np.array_equal(order2, order)
+        got = csr.apply(v)
+        back = np.empty_like(got)
+        back[:, order2] = got
+        assert same_or_nan(back, ref16).all(), kind

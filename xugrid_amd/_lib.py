@@ -45,6 +45,7 @@ SIGNATURES = {
     "xr_version": (c_int, []),
     "xr_set_stream": (c_int, [vp, c_int, c_int]),
     "xr_mesh_create": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),
+    "xr_mesh_create_dev": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),
     "xr_mesh_create_rectilinear": (c_int, [vp, c_i64, vp, c_i64, p_vp]),
     "xr_mesh_destroy": (c_int, [vp]),
     "xr_mesh_info": (c_int, [vp, p_i64, p_i64, p_i64]),

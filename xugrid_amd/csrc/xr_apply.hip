@@ -2466,6 +2466,11 @@ int xr_csr_set_row_keys(xr_csr *csr, const int64_t *keys, int64_t key_range) {
     XR_REQUIRE(csr && (keys || csr->n == 0), XR_ERR_INVALID, "xr_csr_set_row_keys: NULL argument");
     XR_REQUIRE(key_range >= 1 && key_range <= ((int64_t)1 << 24), XR_ERR_INVALID,
                "xr_csr_set_row_keys: key_range must be in [1, 2^24]");
+    // With the output in stored order the stored order is part of what the caller has been told (xr_csr_row_order): new
+    // keys would regroup the rows under every result that is read through the old permutation.
+    XR_REQUIRE(!csr->output_stored, XR_ERR_INVALID,
+               "xr_csr_set_row_keys: the matrix delivers its output in stored order -- its row order is frozen; call "
+               "xr_csr_output_stored_order(csr, 0) first, set the keys, switch it on again and re-read xr_csr_row_order");
     for (int64_t i = 0; i < csr->n; i++)
         XR_REQUIRE(keys[i] >= 0 && keys[i] < key_range, XR_ERR_INVALID, "xr_csr_set_row_keys: key %lld outside [0,%lld)",
                    (long long)keys[i], (long long)key_range);
@@ -2545,21 +2550,30 @@ int xr_csr_expect_permuted(xr_csr *csr, int permuted) {
 
 static int prepare_for_apply(const xr_csr *csr, int64_t K);
 
+// The row tiling of the many-variable apply is PART of the stored order.  It is normally deferred to the first apply with
+// K >= 8; whoever is told the stored order (xr_csr_row_order) or asks for results in it (xr_csr_output_stored_order) gets
+// it settled right away, whatever K the coming applies have -- otherwise a later apply would regroup the rows under a
+// permutation the caller has already read, and every result after that would be silently mis-ordered.
+static void settle_row_layout(const xr_csr *csr) {
+    if (csr && csr->n > 0 && csr->has_tile_key) {
+        ensure_tiled(csr);
+        stream_sync();
+    }
+}
+
 int xr_csr_output_stored_order(xr_csr *csr, int stored) {
     XR_API_BEGIN
     XR_REQUIRE(csr, XR_ERR_INVALID, "xr_csr_output_stored_order: NULL argument");
+    if (stored) settle_row_layout(csr); // from here on the order is frozen (xr_csr_set_row_keys refuses)
     csr->output_stored = stored != 0;
     XR_API_END
 }
 
 int xr_csr_row_order(const xr_csr *csr, int64_t K_hint, int64_t *order_out) {
-    {
-        // (the row tiling of the many-variable apply is part of the stored order: settle it first)
-        const int rc = prepare_for_apply(csr, K_hint);
-        if (rc != XR_OK) return rc;
-    }
     XR_API_BEGIN
+    (void)K_hint; // (kept in the signature; the layout is settled whatever K is)
     XR_REQUIRE(csr && (order_out || csr->n == 0), XR_ERR_INVALID, "xr_csr_row_order: NULL argument");
+    settle_row_layout(csr);
     if (csr->has_row_order) {
         download_widen(csr->row_order.get(), csr->n, order_out);
         stream_sync();

@@ -1033,6 +1033,60 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
     XR_API_END
 }
 
+int xr_mesh_create_dev(const double *node_xy_dev, int64_t n_node, const void *faces_dev, int faces_itemsize, int64_t n_face,
+                       int64_t n_max_node, int64_t fill_value, xr_mesh **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(out != nullptr, XR_ERR_INVALID, "xr_mesh_create_dev: out is NULL");
+    XR_REQUIRE(n_node >= 0 && n_face >= 0, XR_ERR_INVALID, "xr_mesh_create_dev: negative sizes");
+    XR_REQUIRE(n_max_node >= 3 && n_max_node <= XR_MAX_FACE_NODES, XR_ERR_LIMIT,
+               "xr_mesh_create_dev: n_max_node_per_face must be in [3, %d], got %lld", XR_MAX_FACE_NODES,
+               (long long)n_max_node);
+    XR_REQUIRE(faces_itemsize == 4 || faces_itemsize == 8, XR_ERR_INVALID, "xr_mesh_create_dev: faces_itemsize must be 4 or 8");
+    XR_REQUIRE(n_node < ((int64_t)1 << 31) && n_face * n_max_node < ((int64_t)1 << 31), XR_ERR_LIMIT,
+               "xr_mesh_create_dev: mesh exceeds the int32 index range");
+    XR_REQUIRE((node_xy_dev && faces_dev) || n_face == 0, XR_ERR_INVALID, "xr_mesh_create_dev: NULL arrays");
+    engine();
+    const size_t cnt = (size_t)n_face * (size_t)n_max_node;
+    xr_mesh *mesh = new xr_mesh();
+    try {
+        mesh->n_node = n_node;
+        mesh->n_face = n_face;
+        mesh->m = (int)n_max_node;
+        mesh->node_xy.alloc((size_t)n_node * 2);
+        mesh->faces_raw.alloc(cnt);
+        if (n_node > 0)
+            XR_HIP(hipMemcpyAsync(mesh->node_xy.get(), node_xy_dev, sizeof(double) * 2 * (size_t)n_node, hipMemcpyDeviceToDevice,
+                                  launch_stream()));
+        if (cnt > 0) {
+            // [0] first face with fewer than 3 nodes, [1] first face with a node id out of range
+            DevBuf<int64_t> err(2);
+            XR_HIP(hipMemsetAsync(err.get(), 0xff, 2 * sizeof(int64_t), launch_stream())); // (all ones: "none" for the unsigned atomicMin)
+            if (faces_itemsize == 8)
+                XR_LAUNCH("ingest_faces", k_ingest_faces<int64_t>, dim3(div_up((int64_t)cnt, 256)), dim3(256), 0,
+                          reinterpret_cast<const int64_t *>(faces_dev), (int64_t)cnt, (int)n_max_node, fill_value, n_node,
+                          mesh->faces_raw.get(), err.get());
+            else
+                XR_LAUNCH("ingest_faces", k_ingest_faces<int32_t>, dim3(div_up((int64_t)cnt, 256)), dim3(256), 0,
+                          reinterpret_cast<const int32_t *>(faces_dev), (int64_t)cnt, (int)n_max_node, fill_value, n_node,
+                          mesh->faces_raw.get(), err.get());
+            uint64_t h_err[2];
+            d2h(h_err, err.get(), sizeof(h_err));
+            XR_REQUIRE(h_err[0] == UINT64_MAX, XR_ERR_INVALID, "xr_mesh_create_dev: face %lld has fewer than 3 nodes",
+                       (long long)h_err[0]);
+            XR_REQUIRE(h_err[1] == UINT64_MAX, XR_ERR_INVALID,
+                       "xr_mesh_create_dev: face %lld references a node outside [0,%lld)", (long long)h_err[1],
+                       (long long)n_node);
+        } else {
+            stream_sync();
+        }
+    } catch (...) {
+        delete mesh;
+        throw;
+    }
+    *out = mesh;
+    XR_API_END
+}
+
 int xr_mesh_destroy(xr_mesh *mesh) {
     XR_API_BEGIN
     if (mesh) {

@@ -254,6 +254,22 @@ class HipBackend:
         self._relative = bool(relative)
         return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
 
+    def build_weights_t(self, src_xy, src_faces, tgt_xy, tgt_faces, relative=False):
+        """The same from torch tensors on this rank's device (float64 (N, 2) coordinates, int64 (F, M) connectivity): the
+        handles copy them device-to-device (xr_mesh_create_dev) -- a shard cut out of the replicated mesh never visits
+        the host."""
+        E = self.engine
+        self._handover()
+
+        def mesh(xy, faces):
+            xy, faces = xy.contiguous(), faces.contiguous()
+            return E.DeviceMesh.from_device(xy.data_ptr(), xy.shape[0], faces.data_ptr(), faces.element_size(),
+                                            faces.shape[0], faces.shape[1])
+
+        self._src_mesh, self._tgt_mesh = mesh(src_xy, src_faces), mesh(tgt_xy, tgt_faces)
+        self._relative = bool(relative)
+        return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
+
     def rebuild_weights(self):
         """Benchmark hook: redo prepare + index + overlap from the HBM-resident raw meshes."""
         self._src_mesh.invalidate()
@@ -351,6 +367,26 @@ def _method(method):
     return table[method], method in RELATIVE_OVERLAP_METHODS
 
 
+def shard_lists(full, world, rank, partition="balanced"):
+    """(sxy, sfa, txy, tfa) tensors of the replicated meshes -> (global ids of rank's source faces, global ids of the
+    target faces it can give weight to), both ascending, on the tensors' device.  Every rank computes the same owner
+    array (exact integer arithmetic), so the shards are disjoint and complete without communication."""
+    import torch
+
+    sxy, sfa, txy, tfa = full
+    cen = _centroids_t(sxy, sfa)
+    if partition == "balanced":
+        # Morton blocks of equal estimated WORK: where the target mesh is denser than the source mesh (or covers
+        # only a part of it) equal source counts would leave some ranks with several times the targets of others
+        owner = _partition_faces_t(cen, world, "morton", weights=_work_weights_t(cen, _centroids_t(txy, tfa)))
+    else:
+        owner = _partition_faces_t(cen, world, partition)
+    local_faces = torch.nonzero(owner == rank)[:, 0]  # global ids of this rank's sources
+    # only targets whose bbox overlaps the occupancy raster of this rank's source shard can receive weight
+    local_targets = _targets_near_shard_t(_face_boxes_t(sxy, sfa[local_faces]), _face_boxes_t(txy, tfa))
+    return local_faces, local_targets
+
+
 class ShardedOverlapRegridder:
     """
     ``OverlapRegridder(source, target, method)`` / ``RelativeOverlapRegridder`` with the source faces sharded over the
@@ -382,48 +418,71 @@ class ShardedOverlapRegridder:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.backend = backend
+        self.partition = partition
         dev = getattr(backend, "device", None)
         source_xy = np.asarray(source_xy, dtype=np.float64)
         target_xy = np.asarray(target_xy, dtype=np.float64)
         source_faces, target_faces = np.asarray(source_faces), np.asarray(target_faces)
-        sxy, sfa = _t(source_xy, dev), _t(source_faces.astype(np.int64), dev)
-        txy, tfa = _t(target_xy, dev), _t(target_faces.astype(np.int64), dev)
-        self.n_source, self.n_target = int(sfa.shape[0]), int(tfa.shape[0])
-        cen = _centroids_t(sxy, sfa)
-        if partition == "balanced":
-            # Morton blocks of equal estimated WORK: where the target mesh is denser than the source mesh (or covers
-            # only a part of it) equal source counts would leave some ranks with several times the targets of others
-            owner = _partition_faces_t(cen, self.world, "morton", weights=_work_weights_t(cen, _centroids_t(txy, tfa)))
-        else:
-            owner = _partition_faces_t(cen, self.world, partition)
-        local_faces = torch.nonzero(owner == self.rank)[:, 0]  # global ids of this rank's sources
-        # only targets whose bbox overlaps the occupancy raster of this rank's source shard can receive weight
-        local_targets = _targets_near_shard_t(_face_boxes_t(sxy, sfa[local_faces]), _face_boxes_t(txy, tfa))
-        self.local_faces = local_faces.cpu().numpy()
-        self.local_targets = local_targets.cpu().numpy()
+        # the FULL meshes, resident on the rank's device from here on: everything below starts from these tensors
+        self._full = (_t(source_xy, dev), _t(source_faces.astype(np.int64), dev),
+                      _t(target_xy, dev), _t(target_faces.astype(np.int64), dev))
+        self._host_meshes = (source_xy, source_faces, target_xy, target_faces)  # (backends without a device path)
+        self.n_source, self.n_target = int(source_faces.shape[0]), int(target_faces.shape[0])
         # target rows are cut into `world` equal slices (padded): rank r finalises slice r
         self.t_chunk = -(-self.n_target // self.world)
-        self.weights = backend.build_weights(source_xy, source_faces[self.local_faces], target_xy,
-                                             target_faces[self.local_targets], relative=self.relative)
-        self._local_targets_dev = backend.to_device(self.local_targets.astype(np.int64))
+        self.setup()
+
+    def setup(self):
+        """Everything between the replicated raw meshes (device tensors) and a regridder that can step: the partition of
+        the source faces, the near-shard filter of the targets, the shard's two meshes, its weights and the exchange
+        lists.  Called by the constructor; ``bench.py`` calls it again to price what the single-GPU step counts too
+        (there, a step starts from the raw arrays: here the raw arrays of the shard have to be cut out first)."""
+        import torch
+
+        sxy, sfa, txy, tfa = self._full
+        local_faces, local_targets = shard_lists(self._full, self.world, self.rank, self.partition)
+        sfa_local = sfa[local_faces]
+        self._local_faces_t, self._local_targets_t = local_faces, local_targets
+        self._local_np = [None, None]
+        if hasattr(self.backend, "build_weights_t"):  # device tensors in, nothing crosses PCIe
+            self.weights = self.backend.build_weights_t(sxy, sfa_local, txy, tfa[local_targets], relative=self.relative)
+        else:
+            hsxy, hsf, htxy, htf = self._host_meshes
+            self.weights = self.backend.build_weights(hsxy, hsf[self.local_faces], htxy, htf[self.local_targets],
+                                                      relative=self.relative)
+        self._local_targets_dev = local_targets
         self._setup_sparse_exchange()
+
+    @property
+    def local_faces(self):
+        """global ids of this rank's source faces (ascending), host array"""
+        if self._local_np[0] is None:
+            self._local_np[0] = self._local_faces_t.cpu().numpy()
+        return self._local_np[0]
+
+    @property
+    def local_targets(self):
+        """global ids of the target faces this rank can give weight to (ascending), host array"""
+        if self._local_np[1] is None:
+            self._local_np[1] = self._local_targets_t.cpu().numpy()
+        return self._local_np[1]
 
     def _setup_sparse_exchange(self):
         """Who gets which of my partial rows: exchanged once (the weights are fixed)."""
         import torch
 
         dist, W = self.dist, self.world
-        owner = self.local_targets // self.t_chunk  # local_targets is ascending -> grouped by owner
-        send_counts = np.bincount(owner, minlength=W).astype(np.int64)
-        cnt_in = torch.as_tensor(send_counts)
-        cnt_out = torch.empty(W, dtype=torch.int64)
-        dev = self._local_targets_dev.device
-        if dist.get_backend(self.group) == "nccl":
-            cnt_in, cnt_out = cnt_in.to(dev), cnt_out.to(dev)
+        lt = self._local_targets_dev
+        dev = lt.device
+        owner = torch.div(lt, self.t_chunk, rounding_mode="floor")  # local targets are ascending -> grouped by owner
+        cnt_in = torch.bincount(owner, minlength=W)
+        cnt_out = torch.empty(W, dtype=torch.int64, device=dev)
+        if dist.get_backend(self.group) != "nccl":
+            cnt_in, cnt_out = cnt_in.cpu(), cnt_out.cpu()
         dist.all_to_all_single(cnt_out, cnt_in, group=self.group)
-        self._send_counts = [int(c) for c in send_counts]
+        self._send_counts = [int(c) for c in cnt_in.cpu()]
         self._recv_counts = [int(c) for c in cnt_out.cpu()]
-        ids_in = self.backend.to_device((self.local_targets - owner * self.t_chunk).astype(np.int64))
+        ids_in = lt - owner * self.t_chunk
         ids_out = torch.empty(sum(self._recv_counts), dtype=torch.int64, device=dev)
         dist.all_to_all_single(ids_out, ids_in, output_split_sizes=self._recv_counts,
                                input_split_sizes=self._send_counts, group=self.group)
@@ -486,8 +545,7 @@ class ShardedOverlapRegridder:
             if self.relative != _method(stored)[1]:
                 raise ValueError("relative and absolute overlap weights are not interchangeable")
             self.n_source, self.n_target = int(f["__n_source"]), int(f["__n_target"])
-            self.local_faces = f["__shard_source_faces"].astype(np.int64)
-            self.local_targets = f["__shard_target_faces"].astype(np.int64)
+            self._local_np = [f["__shard_source_faces"].astype(np.int64), f["__shard_target_faces"].astype(np.int64)]
             n, m = int(f["__regrid_n"]), int(f["__regrid_m"])
             if n != self.local_targets.size or m != self.local_faces.size:
                 raise ValueError("shard id lists do not match the stored matrix")
@@ -497,7 +555,8 @@ class ShardedOverlapRegridder:
         if self.method.name not in SHARD_METHODS:
             raise ValueError(f"{self.method.name!r} needs whole rows: use TargetPartitionedRegridder")
         self.t_chunk = -(-self.n_target // self.world)
-        self._local_targets_dev = backend.to_device(self.local_targets)
+        self._local_faces_t = backend.to_device(self.local_faces)
+        self._local_targets_t = self._local_targets_dev = backend.to_device(self.local_targets)
         self._setup_sparse_exchange()
         return self
 

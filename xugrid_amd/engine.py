@@ -95,6 +95,23 @@ class DeviceMesh:
         check(_lib.load().xr_mesh_create_rectilinear(_ptr(xv), xv.size - 1, _ptr(yv), yv.size - 1, ctypes.byref(handle)))
         return cls._from_handle(handle)
 
+    @classmethod
+    def from_device(cls, node_xy_ptr, n_node, faces_ptr, faces_itemsize, n_face, n_max_node, fill_value=-1):
+        """A mesh from arrays that already live in the engine's HBM (device pointers as integers, e.g.
+        ``tensor.data_ptr()``): float64 (n_node, 2) coordinates, int32 / int64 (n_face, n_max_node) connectivity.
+        The handle copies both (include/xugrid_amd.h: xr_mesh_create_dev)."""
+        handle = ctypes.c_void_p()
+        check(
+            _lib.load().xr_mesh_create_dev(
+                ctypes.c_void_p(int(node_xy_ptr)), int(n_node), ctypes.c_void_p(int(faces_ptr)), int(faces_itemsize),
+                int(n_face), int(n_max_node), int(fill_value), ctypes.byref(handle),
+            )
+        )
+        self = cls.__new__(cls)
+        self._h = handle
+        self.n_node, self.n_face, self.n_max_node = int(n_node), int(n_face), int(n_max_node)
+        return self
+
     def download(self):
         """-> (node_xy float64[n_node, 2], faces int64[n_face, n_max_node]) as uploaded / assembled."""
         xy = np.empty((self.n_node, 2), dtype=np.float64)
@@ -581,17 +598,18 @@ class DeviceCSR:
         self.set_col_keys(ck, cr)
         self.expect_permuted(True)
         self.output_stored_order(True)
-        return self.col_order(), self.row_order(K)
+        return self.col_order(), self.row_order()
 
     def output_stored_order(self, stored=True):
         """The following applies write their rows in the STORED order (``out[:, r]`` = caller's row ``row_order()[r]``)."""
         check(_lib.load().xr_csr_output_stored_order(self._h, 1 if stored else 0))
 
-    def row_order(self, K=1):
-        """stored row r holds the caller's row ``row_order(K)[r]`` (K: variables of the coming applies; from 8 on the
-        rows are regrouped into tiles once)"""
+    def row_order(self, K=None):
+        """stored row r holds the caller's row ``row_order()[r]``.  The pending regrouping of the rows into tiles (the
+        many-variable apply) is settled by this call whatever the number of variables of the coming applies (``K`` is
+        accepted and ignored), so the permutation returned here stays valid."""
         out = np.empty(self.n, dtype=np.int64)
-        check(_lib.load().xr_csr_row_order(self._h, int(K), _ptr(out)))
+        check(_lib.load().xr_csr_row_order(self._h, 0, _ptr(out)))
         return out
 
     def download(self):
