@@ -191,11 +191,18 @@ def cpu_baseline(sxy, sf, txy, tf, data):
 def make_step(E, ms, mt, d_src, d_out, state):
     """One step of the headline: nothing cached (both meshes lose their derived state), then the whole weight build and the
     mean apply of one variable, from HBM-resident raw arrays to an HBM-resident result."""
+    two_calls = os.environ.get("XR_BENCH_TWO_CALLS", "") not in ("", "0")  # A/B: weights and apply as two entry points
+
     def step():
         ms.invalidate()
         mt.invalidate()
-        csr = ms.overlap(mt)  # prepare x2 + index + search + clip + CSR
-        csr.apply_dev(d_src, E.XR_F64, 1, d_out, 0)
+        if two_calls:
+            csr = ms.overlap(mt)  # prepare x2 + index + search + clip + CSR
+            csr.apply_dev(d_src, E.XR_F64, 1, d_out, 0)
+        else:
+            # the same through ONE entry point (OverlapRegridder(...).regrid(data) on first use): the apply is enqueued
+            # before the host has read the matrix' sizes back
+            csr = ms.overlap_apply_dev(mt, d_src, E.XR_F64, 1, d_out, 0)
         state["csr"] = csr
 
     return step
@@ -222,6 +229,11 @@ def run_single(args):
     state = {}
     step = make_step(E, ms, mt, d_src.value, d_out.value, state)
 
+    # The K steps are issued back to back on the engine's stream (xr_set_async: no host synchronisation inside a step
+    # beyond the one read-back of the matrix' sizes every weight build needs); the timed region is bracketed by device
+    # synchronisations on both sides.  XR_BENCH_SYNC=1: every call synchronous, as until round 3 (A/B).
+    sync_steps = os.environ.get("XR_BENCH_SYNC", "") not in ("", "0")
+    E.set_async(not sync_steps)
     for _ in range(args.warmup):
         step()
     E.dev_sync()
@@ -230,6 +242,7 @@ def run_single(args):
         step()
     E.dev_sync()
     elapsed = time.perf_counter() - t0
+    E.set_async(False)
     ms_per_step = 1e3 * elapsed / args.steps
     csr = state["csr"]
     C, P = ms.last_candidates(), csr.nnz
@@ -302,12 +315,14 @@ def run_single(args):
 
     # per-kernel durations: the same K steps with hipEvents around every launch (engine stream); the W warm-up steps again
     # first (the host-array passes above ran other kernels and released their buffers)
+    E.set_async(not sync_steps)
     for _ in range(args.warmup):
         step()
     E.dev_sync()
     with E.KernelTimer() as kt:
         for _ in range(args.steps):
             step()
+    E.set_async(False)
     kernels = {k: (n, t / n) for k, (n, t) in kt.records.items()}  # name -> (launches, avg ms)
     per_step = {k: n * avg / args.steps for k, (n, avg) in kernels.items()}
     # the dominant kernel of the MAIN stream chain (the big faces' kernels run beside it on the side stream)

@@ -94,6 +94,11 @@ int xr_version(void);
  * async_dev != 0 the *_dev entry points return as soon as their kernels are enqueued.  external == 0 restores the
  * engine's own stream.  The multi-GPU layer uses this between its kernels and the RCCL collectives. */
 int xr_set_stream(void *hip_stream, int external, int async_dev);
+/* Asynchronous mode on the engine's OWN stream (on != 0): the *_dev entry points, xr_overlap_apply_dev and
+ * xr_mesh_invalidate return with their kernels still in flight; results are complete after xr_dev_sync() or any call that
+ * returns data to the host.  All work then stays on the one engine stream (no per-thread lanes).  For pipelines that keep
+ * their data on the device and issue many calls back to back (a time loop; bench.py's step). */
+int xr_set_async(int on);
 
 /* ---- seam 1: mesh handle = CellTree2d(vertices, faces, fill_value) --------------------- */
 /* ugrid2d.py:915-921.  node_xy: float64[n_node,2] (node_coordinates, ugridbase.py:576-579);
@@ -150,6 +155,13 @@ int xr_mesh_download(xr_mesh *mesh, double *node_xy_out, int64_t *faces_out);
 int xr_overlap(xr_mesh *tree, xr_mesh *query, int relative, xr_csr **out);
 /* Statistics of the last xr_overlap on this tree: bbox candidate pairs tested by the clipper. */
 int xr_overlap_stats(const xr_mesh *tree, int64_t *n_candidates);
+/* Weights AND their first use in one call: OverlapRegridder(source, target, method).regrid(data) -- constructor
+ * (regridder.py:505-512 -> _compute_weights :428-436) followed by regrid (:212-262 -> _regrid :41-67).  Same results as
+ * xr_overlap + xr_apply_csr_dev; the matrix is returned for further applies.  For one variable and a streaming reducer the
+ * apply is enqueued before the host has read the sizes of the matrix back, so the build's one host round trip hides behind
+ * the apply kernel instead of separating the two.  source_dev (K, S) / out_dev (K, T) are device pointers. */
+int xr_overlap_apply_dev(xr_mesh *tree, xr_mesh *query, int relative, int method, double percentile,
+                         const void *source_dev, int source_dtype, int64_t K, double *out_dev, xr_csr **out);
 
 /* CellTree2d.locate_points(points, tolerance) (unstructured.py:139,189; ugridbase.py:1323).
  * points float64[n,2] -> face index int64[n], -1 = not found.  tolerance < 0 selects the

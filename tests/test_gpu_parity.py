@@ -924,3 +924,71 @@ def test_stored_row_order_is_frozen_once_handed_out(hip):
         back = np.empty_like(got)
         back[:, order2] = got
         assert same_or_nan(back, ref16).all(), kind
+
+
+def test_overlap_apply_in_one_call_matches_two_calls(hip, monkeypatch):
+    """xr_overlap_apply_dev (weights + their first use in one entry point; for K = 1 the apply is enqueued before the host
+    has read the matrix' sizes back) == xr_overlap followed by xr_apply_csr_dev, bit for bit: every reducer family, K = 1
+    and K = 3, synchronous and asynchronous mode (xr_set_async), the regrow path (a tiny pair-queue margin makes the first
+    attempt fail AFTER its apply was enqueued: the result must come from the final attempt), polling and event mailbox."""
+    import ctypes
+
+    from xugrid_amd import _lib, engine as E
+
+    lib = _lib.load()
+    sxy, sf = meshgen.triangle_mesh(30000, 5)
+    txy, tf = meshgen.triangle_mesh(26000, 6, 30.0, 0.7)
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    S, T = sf.shape[0], tf.shape[0]
+    v = np.random.default_rng(8).normal(size=(3, S))
+    v[1, ::7] = np.nan
+    d_src, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.xr_dev_alloc(8 * 3 * S, ctypes.byref(d_src)))
+    _lib.check(lib.xr_dev_alloc(8 * 3 * T, ctypes.byref(d_out)))
+    _lib.check(lib.xr_dev_upload(d_src, v.ctypes.data_as(ctypes.c_void_p), 8 * 3 * S))
+    ref_csr = ms.overlap(mt)
+    ref_w = ref_csr.download()
+
+    def fetch(K):
+        out = np.empty((K, T))
+        _lib.check(lib.xr_dev_download(out.ctypes.data_as(ctypes.c_void_p), d_out, 8 * K * T))
+        return out
+
+    def check_all(tag):
+        for method_id, pct, K in ((0, 0.0, 1), (3, 0.0, 1), (5, 0.0, 1), (9, 0.0, 1), (0, 0.0, 3), (6, 0.0, 1), (7, 50.0, 1)):
+            ref = ref_csr.apply(v[:K], method_id, pct)
+            for a in (False, True):
+                E.set_async(a)
+                try:
+                    ms.invalidate()
+                    mt.invalidate()
+                    csr = ms.overlap_apply_dev(mt, d_src.value, E.XR_F64, K, d_out.value, method_id, pct)
+                    E.dev_sync()
+                    got = fetch(K)
+                finally:
+                    E.set_async(False)
+                assert same_or_nan(got, ref).all(), (tag, method_id, K, a)
+                assert csr.nnz == ref_csr.nnz
+                w = csr.download()
+                assert all(np.array_equal(x, y) for x, y in zip(w, ref_w)), (tag, method_id, K, a)
+                # the matrix is a normal one afterwards
+                assert same_or_nan(csr.apply(v[:K], method_id, pct), ref).all()
+
+    check_all("default")
+    monkeypatch.setenv("XR_QUEUE_MARGIN", "64")  # the big faces do not fit the first time: redo, apply enqueued again
+    check_all("regrow")
+    monkeypatch.delenv("XR_QUEUE_MARGIN")
+    # many steps back to back without a host synchronisation in between (the benchmark's loop)
+    E.set_async(True)
+    try:
+        for _ in range(20):
+            ms.invalidate()
+            mt.invalidate()
+            keep = ms.overlap_apply_dev(mt, d_src.value, E.XR_F64, 1, d_out.value, 0)
+        E.dev_sync()
+    finally:
+        E.set_async(False)
+    assert same_or_nan(fetch(1), ref_csr.apply(v[:1], 0)).all()
+    del keep
+    lib.xr_dev_free(d_src)
+    lib.xr_dev_free(d_out)

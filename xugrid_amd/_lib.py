@@ -44,6 +44,7 @@ SIGNATURES = {
     "xr_trim_pool": (c_int, []),
     "xr_version": (c_int, []),
     "xr_set_stream": (c_int, [vp, c_int, c_int]),
+    "xr_set_async": (c_int, [c_int]),
     "xr_mesh_create": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),
     "xr_mesh_create_dev": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),
     "xr_mesh_create_rectilinear": (c_int, [vp, c_i64, vp, c_i64, p_vp]),
@@ -70,6 +71,7 @@ SIGNATURES = {
     "xr_voronoi_destroy": (c_int, [vp]),
     "xr_overlap": (c_int, [vp, vp, c_int, p_vp]),
     "xr_overlap_stats": (c_int, [vp, p_i64]),
+    "xr_overlap_apply_dev": (c_int, [vp, vp, c_int, c_int, c_f64, vp, c_int, c_i64, vp, p_vp]),
     "xr_locate_points": (c_int, [vp, vp, c_i64, c_f64, vp]),
     "xr_locate_raster": (c_int, [vp, vp, c_i64, vp, c_i64, c_f64, vp]),
     "xr_barycentric": (c_int, [vp, vp, c_i64, c_f64, vp, vp]),

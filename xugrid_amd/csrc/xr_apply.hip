@@ -1876,6 +1876,10 @@ static void apply_dev(const xr_csr *csr, int method, double p, const void *src, 
     else apply_dispatch<float>(csr, method, p, static_cast<const float *>(src), K, out);
 }
 
+void csr_apply_dev(const xr_csr *csr, int method, double percentile, const void *src_dev, int dtype, int64_t K, double *out_dev) {
+    apply_dev(csr, method, percentile, src_dev, dtype, K, out_dev);
+}
+
 __global__ void k_narrow_i64(const int64_t *__restrict__ in, int32_t *__restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = (int32_t)in[i];
@@ -2586,7 +2590,7 @@ int xr_csr_row_order(const xr_csr *csr, int64_t K_hint, int64_t *order_out) {
 int xr_csr_destroy(xr_csr *csr) {
     XR_API_BEGIN
     if (csr) {
-        stream_sync();
+        release_point();
         delete csr;
     }
     XR_API_END

@@ -2,6 +2,8 @@
 #include <cstdarg>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <map>
 #include <cstring>
 #include <thread>
@@ -66,6 +68,7 @@ SharedScope::SharedScope() {
     leased = true;
     Engine &e = engine();
     if (e.stream != e.own_stream) return; // bound to the caller's stream (xr_set_stream): ordered there, no lane
+    if (e.own_async) return; // asynchronous mode: everything stays on the ONE main stream (stream-ordered pool), no lanes
     // a free lane, else wait for "this thread's" one
     const size_t h = std::hash<std::thread::id>()(std::this_thread::get_id());
     Lane *lane = nullptr;
@@ -335,10 +338,24 @@ void d2h(void *dst, const void *src, size_t bytes) {
 
 void stream_sync() {
     XR_HIP(hipStreamSynchronize(launch_stream()));
+    if (!t_lane && !t_stream_override && !g_engine.on_side) g_engine.main_busy = false;
     pool_release_deferred();
 }
+void release_point() {
+    Engine &e = engine();
+    if (e.own_async && e.stream == e.own_stream && !t_lane && !t_stream_override) return;
+    stream_sync();
+}
 void dev_call_done() {
-    if (!engine().async_dev) stream_sync();
+    Engine &e = engine();
+    if (e.async_dev) return;
+    // xr_set_async(1): calls on the engine's own main stream return with their kernels in flight (blocks they freed are
+    // reused in stream order on that one stream; a thread that takes a lane waits for the main stream first)
+    if (e.own_async && !t_lane && !t_stream_override && e.stream == e.own_stream) {
+        e.main_busy = true;
+        return;
+    }
+    stream_sync();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,6 +531,55 @@ void mailbox_wait() {
     pool_release_deferred();
 }
 
+static bool mail_poll_enabled() {
+    static const bool on = !(getenv("XR_MAIL_POLL") && atoi(getenv("XR_MAIL_POLL")) == 0);
+    return on;
+}
+
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#endif
+}
+
+int32_t mailbox_next_seq() {
+    Engine &e = engine();
+    e.mail_seq = e.mail_seq >= (1 << 30) ? 1 : e.mail_seq + 1;
+    return e.mail_seq;
+}
+
+void mailbox_wait_seq(int32_t seq) {
+    Engine &e = engine();
+    if (!mail_poll_enabled() || e.stream != e.own_stream) { // (a caller's stream: its events order things, keep the event path)
+        mailbox_wait();
+        XR_REQUIRE(e.mailbox[MAIL_SEQ_SLOT] == seq, XR_ERR_HIP, "mailbox sequence word missing after synchronisation");
+        return;
+    }
+    const volatile int32_t *word = e.mailbox + MAIL_SEQ_SLOT;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *word != seq; spins++) {
+        cpu_relax();
+        if ((spins & 0x3fff) == 0x3fff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) {
+            XR_HIP(hipStreamSynchronize(e.stream)); // (slow or failed kernel: the error, if any, surfaces here)
+            XR_REQUIRE(*word == seq, XR_ERR_HIP, "mailbox sequence word missing after synchronisation");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    pool_release_deferred();
+}
+
+bool poll_pinned_f64(const volatile double *word, double expected) {
+    if (!mail_poll_enabled()) return false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spins = 0; *word != expected; spins++) {
+        cpu_relax();
+        if ((spins & 0x3fff) == 0x3fff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return false;
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // kernel timing
 // ---------------------------------------------------------------------------------------------
@@ -664,6 +730,15 @@ int xr_set_stream(void *hip_stream, int external, int async_dev) {
     XR_HIP(hipStreamSynchronize(e.stream)); // nothing of the engine may still be in flight on the old stream
     e.stream = external ? static_cast<hipStream_t>(hip_stream) : e.own_stream;
     e.async_dev = external && async_dev;
+    XR_API_END
+}
+
+int xr_set_async(int on) {
+    XR_API_BEGIN
+    Engine &e = engine();
+    XR_HIP(hipStreamSynchronize(e.stream));
+    e.main_busy = false;
+    e.own_async = on != 0;
     XR_API_END
 }
 

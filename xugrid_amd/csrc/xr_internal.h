@@ -104,9 +104,23 @@ struct Engine {
     hipEvent_t fork_event = nullptr, join_event = nullptr;
     hipEvent_t aux_event = nullptr; // a point INSIDE the side stream's work the main stream may wait for before the full join
     bool on_side = false; // XR_LAUNCH and the kernel timer go to the side stream while set
+    int32_t mail_seq = 0; // sequence number of the last mailbox publication the host asked for (mailbox_wait_seq)
+    // xr_set_async(1): the *_dev entry points, xr_mesh_invalidate and xr_overlap_apply_dev return with their kernels
+    // still in flight on the engine's own stream; the caller orders itself with xr_dev_sync (or any synchronous call)
+    bool own_async = false;
+    bool main_busy = false; // an asynchronous call returned: the main stream may hold work the host has not waited for
 };
 inline hipStream_t launch_stream();
 void mailbox_wait(); // everything enqueued so far has executed and its mailbox writes are visible
+// The same without an event: the publishing kernel stores `seq` in mailbox[MAIL_SEQ_SLOT] (system scope) BEHIND its other
+// mailbox words and the host polls that word -- no event record / barrier packet on the stream, no interrupt-driven wake-up
+// (an event costs ~5 us of stream time and ~10 us of host latency per wait; XR_MAIL_POLL=0 restores it).  Bounded: after
+// ~20 ms without the word the stream is synchronised and the word checked once more (a failed kernel raises the HIP error).
+static constexpr int MAIL_SEQ_SLOT = 1023;
+int32_t mailbox_next_seq();
+void mailbox_wait_seq(int32_t seq);
+// host side of the same protocol for any pinned word a kernel publishes (the mesh statistics)
+bool poll_pinned_f64(const volatile double *word, double expected);
 Engine &engine();      // initialises device 0 on first use
 void engine_init(int device);
 
@@ -160,6 +174,9 @@ void h2d(void *dst, const void *src, size_t bytes);       // synchronous w.r.t. 
 void d2h(void *dst, const void *src, size_t bytes);       // stream-ordered, then synchronised
 void stream_sync();
 void dev_call_done(); // end of a *_dev entry point: stream_sync() unless the caller shares the engine's stream
+// before a handle's blocks go back to the pool: wait for the device -- unless the engine runs asynchronously on its one
+// own stream (xr_set_async), where the pool's stream-ordered reuse already orders every later user behind the last one
+void release_point();
 // Large host <-> device copies of pageable memory through two pinned staging buffers: worker threads move the data
 // between the caller's pages and the staging buffer (page faults of a fresh result array included) while the DMA
 // engine moves the previous piece -- 2-3x the rate of a plain hipMemcpy on pageable memory.  Synchronous.

@@ -95,13 +95,81 @@ k_face_area(const double *__restrict__ node_xy, const int32_t *__restrict__ face
     area[f] = 0.5 * fabs(det);
 }
 
+// Tail of the two statistics kernels: the block's partial goes to HBM with agent-scope (sc1) stores, a counter says how
+// many blocks have done so, and the LAST block to arrive reduces all partials -- in the fixed order of k_reduce_stats, so the
+// result does not depend on which block that is -- and publishes the eight numbers: device copy, pinned host copy and,
+// behind them, the host's sequence word (system scope), which the host polls (mesh_read_stats).  One launch and one
+// cross-queue hop less per mesh than a separate one-block reduction kernel, and no event on the stream.
+// Hand-off: 8-byte agent-scope atomics on both sides (MI355X_MICROARCH.md, inter-workgroup visibility) + an agent acquire
+// in the one reducing block; the counter is zero at rest (the last block clears it).
+struct StatsTail {
+    double *partials;     // [nb][8]
+    unsigned *done;       // zero at rest
+    double *stats;        // [8] device copy
+    double *stats_host;   // [9] pinned: 8 statistics + the sequence word
+    double seq;
+};
+
+__device__ __forceinline__ void stats_tail(const StatsTail &t, const double (&a)[8], double (*lds)[PREP_BLOCK / 64]) {
+    __shared__ int s_last;
+    const int64_t nb = gridDim.x;
+    if (threadIdx.x == 0) {
+        double *p = t.partials + (int64_t)blockIdx.x * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) __hip_atomic_store(&p[i], a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned prev = __hip_atomic_fetch_add(t.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = prev == (unsigned)(nb - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(t.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    double a0 = INFINITY, a1 = -INFINITY, a2 = INFINITY, a3 = -INFINITY, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+    for (int64_t i = threadIdx.x; i < nb; i += PREP_BLOCK) {
+        const double *p = t.partials + i * 8;
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __hip_atomic_load(&p[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a0 = fmin(a0, v[0]); a1 = fmax(a1, v[1]); a2 = fmin(a2, v[2]);
+        a3 = fmax(a3, v[3]); a4 += v[4]; a5 = fmax(a5, v[5]); a6 = fmax(a6, v[6]); a7 += v[7];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    a0 = wave_min(a0); a1 = wave_max(a1); a2 = wave_min(a2); a3 = wave_max(a3); a4 = wave_sum(a4); a5 = wave_max(a5);
+    a6 = wave_max(a6);
+    a7 = wave_sum(a7);
+    __syncthreads(); // (lds still holds the block's own wave partials for thread 0 above)
+    if (lane == 0) {
+        lds[0][wave] = a0; lds[1][wave] = a1; lds[2][wave] = a2;
+        lds[3][wave] = a3; lds[4][wave] = a4; lds[5][wave] = a5; lds[6][wave] = a6; lds[7][wave] = a7;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < PREP_BLOCK / 64; w++) {
+            a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
+            a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]); a7 += lds[7][w];
+        }
+        const double r[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            t.stats[k] = r[k];
+            t.stats_host[k] = r[k];
+        }
+        __threadfence_system();
+        __hip_atomic_store(&t.stats_host[8], t.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // LIGHT: statistics only (a mesh that is only ever the TREE: its records are built from the raw mesh by
 // k_spatial_scatter, nothing reads caller-order per-face arrays)
 template <int MC, bool LIGHT>
 __global__ void __launch_bounds__(PREP_BLOCK)
 k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face,
                 int m_rt, double *__restrict__ fxy, uint8_t *__restrict__ len_out, double *__restrict__ bbox,
-                double *__restrict__ partials) {
+                double *__restrict__ partials, StatsTail tail) {
     constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * PREP_BLOCK + threadIdx.x;
@@ -151,15 +219,20 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
         lds[3][wave] = r3; lds[4][wave] = r4; lds[5][wave] = r5; lds[6][wave] = r6; lds[7][wave] = r7;
     }
     __syncthreads();
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x == 0) {
         double a0 = lds[0][0], a1 = lds[1][0], a2 = lds[2][0], a3 = lds[3][0], a4 = lds[4][0], a5 = lds[5][0], a6 = lds[6][0], a7 = lds[7][0];
         for (int w = 1; w < PREP_BLOCK / 64; w++) {
             a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
             a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]); a7 += lds[7][w];
         }
-        double *p = partials + (int64_t)blockIdx.x * 8;
-        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6; p[7] = a7;
+        if (tail.done == nullptr) { // (separate reduction kernel behind this one: XR_STATS_TAIL=0)
+            double *p = partials + (int64_t)blockIdx.x * 8;
+            p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6; p[7] = a7;
+        }
+        a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3; a[4] = a4; a[5] = a5; a[6] = a6; a[7] = a7;
     }
+    if (tail.done != nullptr) stats_tail(tail, a, lds);
 }
 
 // Statistics of a mesh that is only ever the TREE, from a SAMPLE of its faces: the index only needs the bounds (exact:
@@ -172,7 +245,7 @@ k_prepare_faces(const double *__restrict__ node_xy, const int32_t *__restrict__ 
 template <int MC>
 __global__ void __launch_bounds__(PREP_BLOCK)
 k_sample_stats(const double *__restrict__ node_xy, int64_t n_node, const int32_t *__restrict__ faces_raw, int64_t n_face,
-               int m_rt, int stride, double *__restrict__ partials) {
+               int m_rt, int stride, double *__restrict__ partials, StatsTail tail) {
     constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = ((int64_t)blockIdx.x * stride) * PREP_BLOCK + threadIdx.x;
@@ -220,15 +293,20 @@ k_sample_stats(const double *__restrict__ node_xy, int64_t n_node, const int32_t
         lds[3][wave] = r3; lds[4][wave] = r4; lds[5][wave] = r5; lds[6][wave] = r6; lds[7][wave] = r7;
     }
     __syncthreads();
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (threadIdx.x == 0) {
         double a0 = lds[0][0], a1 = lds[1][0], a2 = lds[2][0], a3 = lds[3][0], a4 = lds[4][0], a5 = lds[5][0], a6 = lds[6][0], a7 = lds[7][0];
         for (int w = 1; w < PREP_BLOCK / 64; w++) {
             a0 = fmin(a0, lds[0][w]); a1 = fmax(a1, lds[1][w]); a2 = fmin(a2, lds[2][w]);
             a3 = fmax(a3, lds[3][w]); a4 += lds[4][w]; a5 = fmax(a5, lds[5][w]); a6 = fmax(a6, lds[6][w]); a7 += lds[7][w];
         }
-        double *p = partials + (int64_t)blockIdx.x * 8;
-        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6; p[7] = a7;
+        if (tail.done == nullptr) { // (separate reduction kernel behind this one: XR_STATS_TAIL=0)
+            double *p = partials + (int64_t)blockIdx.x * 8;
+            p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5; p[6] = a6; p[7] = a7;
+        }
+        a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3; a[4] = a4; a[5] = a5; a[6] = a6; a[7] = a7;
     }
+    if (tail.done != nullptr) stats_tail(tail, a, lds);
 }
 
 // ingest of the caller's connectivity (xr_mesh_create): fill -> -1, narrow to int32, validate
@@ -367,6 +445,30 @@ void mesh_face_coords(xr_mesh *mesh) {
 static constexpr int64_t SAMPLE_MIN_FACES = 1 << 17; // smaller meshes: the full pass costs a launch either way
 static constexpr int SAMPLE_STRIDE = 8;              // every 8th block of 256 faces
 
+// pinned statistics page + (unless XR_STATS_TAIL=0) the hand-off words of the in-kernel reduction
+static StatsTail stats_tail_for(xr_mesh *mesh, double *partials) {
+    if (!mesh->stats_host) {
+        void *p = nullptr;
+        XR_HIP(hipHostMalloc(&p, sizeof(double) * 16, hipHostMallocCoherent));
+        mesh->stats_host = static_cast<double *>(p);
+        memset(mesh->stats_host, 0, sizeof(double) * 16);
+        XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
+    }
+    static const bool tail_on = !(getenv("XR_STATS_TAIL") && atoi(getenv("XR_STATS_TAIL")) == 0); // A/B switch
+    // (the hand-off needs the host's polling view of ONE stream: not on a caller's stream, not under a stream override)
+    if (!tail_on || stream_override() || current_lane() || engine().on_side) {
+        mesh->stats_polled = false;
+        return StatsTail{partials, nullptr, nullptr, nullptr, 0.0};
+    }
+    if (!mesh->stats_done.get()) {
+        mesh->stats_done.alloc(1);
+        XR_HIP(hipMemsetAsync(mesh->stats_done.get(), 0, sizeof(unsigned), launch_stream()));
+    }
+    mesh->stats_seq += 1.0;
+    mesh->stats_polled = true;
+    return StatsTail{partials, mesh->stats_done.get(), mesh->stats.get(), mesh->stats_host, mesh->stats_seq};
+}
+
 void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_sampled) {
     // two depths: statistics only (want_fxy = false: the mesh is used as a tree) or statistics + the caller-order
     // len / bbox / vertex blocks a query needs.  A mesh prepared light and later used as a query is prepared again;
@@ -385,22 +487,17 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
         const int64_t nb = (nb_all + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
         DevBuf<double> partials((size_t)nb * 8);
         dim3 grid((unsigned)nb), block(PREP_BLOCK);
+        const StatsTail tail = stats_tail_for(mesh, partials.get());
         if (m == 3)
             XR_LAUNCH("sample_stats", k_sample_stats<3>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
-                      F, m, SAMPLE_STRIDE, partials.get());
+                      F, m, SAMPLE_STRIDE, partials.get(), tail);
         else if (m == 4)
             XR_LAUNCH("sample_stats", k_sample_stats<4>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
-                      F, m, SAMPLE_STRIDE, partials.get());
+                      F, m, SAMPLE_STRIDE, partials.get(), tail);
         else
             XR_LAUNCH("sample_stats", k_sample_stats<0>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
-                      F, m, SAMPLE_STRIDE, partials.get());
-        if (!mesh->stats_host) {
-            void *p = nullptr;
-            XR_HIP(hipHostMalloc(&p, sizeof(double) * 8, hipHostMallocCoherent));
-            mesh->stats_host = static_cast<double *>(p);
-            XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
-        }
-        {
+                      F, m, SAMPLE_STRIDE, partials.get(), tail);
+        if (!tail.done) {
             std::unique_ptr<SideScope> side;
             if (stats_on_side) side.reset(new SideScope);
             XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
@@ -425,28 +522,23 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
     const int64_t nb = std::max<int64_t>(1, (F + PREP_BLOCK - 1) / PREP_BLOCK);
     DevBuf<double> partials((size_t)nb * 8);
     dim3 grid((unsigned)nb), block(PREP_BLOCK);
+    const StatsTail tail = stats_tail_for(mesh, partials.get());
 #define XR_PREP(MC)                                                                                                    \
     do {                                                                                                               \
         if (want_fxy)                                                                                                  \
             XR_LAUNCH("prepare_faces", (k_prepare_faces<MC, false>), grid, block, 0, mesh->node_xy.get(),              \
                       mesh->faces_raw.get(), F, m, dense_fxy ? mesh->fxy.get() : (double *)nullptr, mesh->len.get(),  \
-                      mesh->bbox.get(), partials.get());                                                               \
+                      mesh->bbox.get(), partials.get(), tail);                                                         \
         else                                                                                                           \
             XR_LAUNCH("prepare_stats", (k_prepare_faces<MC, true>), grid, block, 0, mesh->node_xy.get(),               \
                       mesh->faces_raw.get(), F, m, (double *)nullptr, (uint8_t *)nullptr, (double *)nullptr,           \
-                      partials.get());                                                                                 \
+                      partials.get(), tail);                                                                           \
     } while (0)
     if (m == 3) XR_PREP(3);
     else if (m == 4) XR_PREP(4);
     else XR_PREP(0);
 #undef XR_PREP
-    if (!mesh->stats_host) {
-        void *p = nullptr;
-        XR_HIP(hipHostMalloc(&p, sizeof(double) * 8, hipHostMallocCoherent));
-        mesh->stats_host = static_cast<double *>(p);
-        XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
-    }
-    {
+    if (!tail.done) {
         // (a one-block kernel that ends with writes to pinned host memory: ~10 us, which only the host waits for)
         std::unique_ptr<SideScope> side;
         if (stats_on_side) side.reset(new SideScope);
@@ -482,7 +574,15 @@ void mesh_read_stats(xr_mesh *mesh, bool need_exact) {
     if (!mesh->prepared) mesh_prepare(mesh, false);
     else if (need_exact && mesh->stats_sampled) mesh_prepare(mesh, mesh->has_attrs, false, false); // over all faces this time
     if (mesh->stats_valid) return;
-    XR_HIP(hipEventSynchronize(mesh->stats_event));
+    if (mesh->stats_polled) {
+        // the reducing block stores the sequence word behind the statistics: poll it (bounded), else drain the stream
+        if (!poll_pinned_f64(mesh->stats_host + 8, mesh->stats_seq)) {
+            XR_HIP(hipStreamSynchronize(engine().stream));
+            XR_REQUIRE(mesh->stats_host[8] == mesh->stats_seq, XR_ERR_HIP, "mesh statistics did not arrive");
+        }
+    } else {
+        XR_HIP(hipEventSynchronize(mesh->stats_event));
+    }
     for (int i = 0; i < 8; i++) mesh->h_stats[i] = mesh->stats_host[i];
     mesh->stats_valid = true;
 }
@@ -1090,7 +1190,7 @@ int xr_mesh_create_dev(const double *node_xy_dev, int64_t n_node, const void *fa
 int xr_mesh_destroy(xr_mesh *mesh) {
     XR_API_BEGIN
     if (mesh) {
-        stream_sync();
+        release_point();
         delete mesh;
     }
     XR_API_END
@@ -1136,7 +1236,9 @@ int xr_mesh_build_index(xr_mesh *mesh) {
 int xr_mesh_invalidate(xr_mesh *mesh) {
     XR_API_BEGIN
     XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_invalidate: NULL mesh");
-    stream_sync();
+    // (the blocks go back to the pool, which hands them out again in stream order on the one main stream: in asynchronous
+    // mode nothing has to wait here)
+    release_point();
     mesh->prepared = false;
     mesh->has_attrs = false;
     mesh->area_valid = false;

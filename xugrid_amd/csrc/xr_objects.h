@@ -35,8 +35,11 @@ struct xr_mesh {
     double h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // the reduction kernel also deposits the statistics in pinned host memory; the host waits on an event
     // recorded right behind it, so kernels queued later (the other mesh's prepare) keep the GPU busy meanwhile
-    double *stats_host = nullptr; // [8] pinned
+    double *stats_host = nullptr; // [9] pinned: the statistics + the sequence word the publishing block stores last
     hipEvent_t stats_event = nullptr;
+    xr::DevBuf<unsigned> stats_done; // [1] blocks that have delivered their partial (zero at rest; stats_tail, xr_mesh.hip)
+    double stats_seq = 0.0;          // sequence number of the last statistics launch (what stats_host[8] must show)
+    bool stats_polled = false;       // the statistics of the last launch arrive through the sequence word (no event recorded)
     xr_mesh() = default;
     xr_mesh(const xr_mesh &) = delete;
     xr_mesh &operator=(const xr_mesh &) = delete;
@@ -146,6 +149,8 @@ void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
 void flush_pending_points(); // launch the deferred source-side kernels of pending xr_points handles (xr_locate.hip)
 void mesh_read_stats(xr_mesh *mesh, bool need_exact = false); // need_exact: statistics over ALL faces (sampled ones are redone)
+// the apply of a finished (or, K = 1, of a just-enqueued) matrix on the calling thread's launch stream (xr_apply.hip)
+void csr_apply_dev(const xr_csr *csr, int method, double percentile, const void *src_dev, int dtype, int64_t K, double *out_dev);
 void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev);    // connectivity.centroids into device memory [n_face*2]
 void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order = false); // CCW-normalised (or the caller's) connectivity [n_face*m]
 } // namespace xr

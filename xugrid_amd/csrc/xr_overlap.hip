@@ -1299,8 +1299,16 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
 // faces of the search (hull slivers ...) on a side stream, their rows stored behind the regular ones; ONE host round
 // trip at the very end (sizes + error bits).  -> false if the pair has to go through the general pipeline after all
 // (a clip that needs more than 6 vertices: floating-point degenerate input; or the look-back chain gave up).
+// An apply the caller wants right behind the weight build (xr_overlap_apply_dev).  The triangle pipeline enqueues it BEFORE
+// the host has read the sizes back -- the K = 1 apply kernel takes everything it needs from device memory -- so the one host
+// round trip of the build is hidden behind the apply instead of standing between the two.
+struct EarlyApply {
+    std::function<void(const xr_csr *)> fn;
+    bool done = false;
+};
+
 static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, bool relative, xr_csr *csr,
-                        const MortonParams &tile) {
+                        const MortonParams &tile, EarlyApply *early) {
     const int64_t T = query->n_face;
     const GridParams &g = tree->grid;
     hipStream_t st = launch_stream();
@@ -1446,9 +1454,18 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                   big_indices.get(), big_data.get(), T, query->qo_perm(), query->qo_bbox(), tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, csr->indptr.get(), csr->indices.get(),
                   csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, ctl_head + 3);
-        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl_head, fc, csr->n_long.get(), mail);
+        const int32_t seq = mailbox_next_seq();
+        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl_head, fc, csr->n_long.get(), mail, seq);
         if (ctl_cached) zero_scratch_done(1); // (the counters are zero again behind k_publish_all)
-        mailbox_wait();
+        if (early) {
+            // sizes unknown on the host yet: pessimistic flags (long rows possible, of any length) -- they only add blocks
+            // that look at the device-side list of long rows and find it short or empty; results do not depend on them
+            csr->nnz = 0;
+            csr->has_long = true;
+            csr->max_row_len = -1;
+            early->fn(csr);
+        }
+        mailbox_wait_seq(seq);
         const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], n_pending = mail[3], big_overflow = mail[4];
         const int32_t err = mail[5], rows_regular = mail[6], p_regular = mail[8], p_big = mail[9];
         XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
@@ -1470,11 +1487,12 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         csr->nnz = (int64_t)p_regular + p_big;
         csr->has_long = mail[7] > 0;   // rows of more than XR_APPLY_LONG_ROW entries (none: the apply skips their kernels)
         csr->max_row_len = mail[7] > 0 ? mail[10] : XR_APPLY_LONG_ROW;
+        if (early) early->done = true; // (the apply enqueued in THIS attempt saw the final matrix)
         return true;
     }
 }
 
-static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
+static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, EarlyApply *early = nullptr) {
     // (the query side on the side stream next to the tree side was measured: the prepare kernels are bandwidth bound and
     // just slow each other down, 0.684 -> 0.706 ms per step)
     // the tree side only needs its records (built from the raw mesh).  Its statistics go to the host through a one-block
@@ -1528,7 +1546,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr) {
         const char *fused_env = getenv("XR_OVERLAP_FUSED");
         const bool fused_on = !(fused_env && atoi(fused_env) == 0);
         if (fused_on && tree->m == 3 && query->m == 3 && T * SLOTS < ((int64_t)1 << 31)) {
-            if (overlap_tri(tree, query, tree_area, relative, csr, tile)) return;
+            if (overlap_tri(tree, query, tree_area, relative, csr, tile, early)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
         }
     }
@@ -1664,6 +1682,33 @@ int xr_overlap(xr_mesh *tree, xr_mesh *query, int relative, xr_csr **out) {
         overlap(tree, query, relative != 0, csr);
         stream_sync();
     } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_overlap_apply_dev(xr_mesh *tree, xr_mesh *query, int relative, int method, double percentile, const void *source_dev,
+                         int source_dtype, int64_t K, double *out_dev, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && query && out, XR_ERR_INVALID, "xr_overlap_apply_dev: NULL argument");
+    XR_REQUIRE(K >= 0 && (source_dev || tree->n_face == 0 || K == 0) && (out_dev || query->n_face == 0 || K == 0), XR_ERR_INVALID,
+               "xr_overlap_apply_dev: NULL data argument");
+    XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", source_dtype);
+    xr_csr *csr = new xr_csr();
+    try {
+        EarlyApply early;
+        early.fn = [&](const xr_csr *c) { csr_apply_dev(c, method, percentile, source_dev, source_dtype, K, out_dev); };
+        // one variable and a streaming reducer: the apply is one launch that needs no size on the host
+        static const bool early_off = getenv("XR_EARLY_APPLY") && atoi(getenv("XR_EARLY_APPLY")) == 0; // A/B switch
+        const bool can_early = !early_off && K == 1 && method != XR_MODE && method != XR_PERCENTILE &&
+                               !(getenv("XR_APPLY_K1") && !strcmp(getenv("XR_APPLY_K1"), "block"));
+        overlap(tree, query, relative != 0, csr, can_early ? &early : nullptr);
+        if (!early.done && K > 0) csr_apply_dev(csr, method, percentile, source_dev, source_dtype, K, out_dev);
+        dev_call_done(); // (xr_set_async(1): returns with the apply in flight)
+    } catch (...) {
+        stream_sync();
         delete csr;
         throw;
     }

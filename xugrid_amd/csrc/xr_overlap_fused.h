@@ -683,7 +683,7 @@ k_place_big(const int32_t *__restrict__ n_big_dev, const int32_t *__restrict__ s
 // ... and clears all of them behind itself: the counter words are the engine's zero-at-rest scratch (the next xr_overlap
 // starts without a memset).  One wave.
 __global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right behind them (c + 8) */, FusedCounters *fc,
-                              int32_t *__restrict__ n_apply_long_out, int32_t *mail) {
+                              int32_t *__restrict__ n_apply_long_out, int32_t *mail, int32_t seq) {
     // one load per lane (the 16 words are one line), so the host's wait is one round trip long
     const int t = threadIdx.x;
     int32_t w = 0;
@@ -703,6 +703,10 @@ __global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right
     __builtin_amdgcn_s_waitcnt(0); // (every load above has returned before the words are cleared)
     if (t < 16) c[t] = 0;
     (void)fc;
+    // the host polls the sequence word (mailbox_wait_seq): it goes out BEHIND the words above (one wave: a system-scope
+    // release covers the stores of all its lanes)
+    __threadfence_system();
+    if (t == 0) __hip_atomic_store(&mail[MAIL_SEQ_SLOT], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 } // namespace xr

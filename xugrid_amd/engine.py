@@ -52,6 +52,12 @@ def set_stream(handle=None, async_dev=False):
         check(_lib.load().xr_set_stream(ctypes.c_void_p(int(handle)), 1, int(bool(async_dev))))
 
 
+def set_async(on=True):
+    """Asynchronous mode on the engine's own stream (include/xugrid_amd.h: xr_set_async): ``*_dev`` calls,
+    ``DeviceMesh.overlap_apply_dev`` and ``invalidate`` return with their kernels in flight; ``dev_sync()`` completes them."""
+    check(_lib.load().xr_set_async(1 if on else 0))
+
+
 def _as_xy(vertices):
     xy = np.ascontiguousarray(vertices, dtype=np.float64)
     if xy.ndim != 2 or xy.shape[1] != 2:
@@ -177,6 +183,16 @@ class DeviceMesh:
         """All (query face, self face) pairs with positive intersection area, as CSR rows=query."""
         handle = ctypes.c_void_p()
         check(_lib.load().xr_overlap(self._h, query._h, int(bool(relative)), ctypes.byref(handle)))
+        return DeviceCSR(handle)
+
+    def overlap_apply_dev(self, query: "DeviceMesh", source_ptr, source_dtype, K, out_ptr, method_id=0, percentile=0.0,
+                          relative=False) -> "DeviceCSR":
+        """``overlap(query)`` and the apply of ``K`` variables in one call (device pointers in and out): the weights'
+        first use rides on their construction (include/xugrid_amd.h: xr_overlap_apply_dev).  -> the matrix."""
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_overlap_apply_dev(self._h, query._h, int(bool(relative)), int(method_id), float(percentile),
+                                               ctypes.c_void_p(int(source_ptr)), int(source_dtype), int(K),
+                                               ctypes.c_void_p(int(out_ptr)), ctypes.byref(handle)))
         return DeviceCSR(handle)
 
     def last_candidates(self):
