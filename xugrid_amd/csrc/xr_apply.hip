@@ -412,8 +412,9 @@ __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_rows1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
               const int32_t *__restrict__ row_order, const int32_t *__restrict__ long_rows,
               const int32_t *__restrict__ n_long, int n_long_blocks, bool any_huge, int64_t T, int64_t S,
-              const SRC *__restrict__ source, double *__restrict__ out) {
+              const SRC *__restrict__ source, double *__restrict__ out, const int32_t *__restrict__ gate) {
     __shared__ double2 sh_win[AP_BLOCK / 64][W1_CAP]; // (.x = weight, .y = source value); 24 KB: 6 blocks per CU
+    if (gate && *gate == 0) return; // (enqueued behind a weight build whose attempt failed: the host redoes both)
     double(*sh_merge)[3] = reinterpret_cast<double(*)[3]>(&sh_win[0][0]); // (long-row blocks stage nothing)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     if ((int)blockIdx.x < n_long_blocks) {
@@ -1726,7 +1727,7 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         dim3 grid((unsigned)(div_up(csr->n, AP_BLOCK) + n_long_blocks), 1);
         XR_LAUNCH("apply_rows1", (k_apply_rows1<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(), csr->indices.get(),
                   csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(), n_long_blocks, any_huge,
-                  csr->n, csr->m, src, out);
+                  csr->n, csr->m, src, out, csr->apply_gated ? csr->n_long.get() + 1 : (const int32_t *)nullptr);
     } else if (K == 1) {
         dim3 grid(div_up(csr->n, AP_BLOCK), 1);
         XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),

@@ -143,9 +143,14 @@ void engine_init(int device) {
         XR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, hi));
     }
-    XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, hipEventDisableTiming));
-    XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, hipEventDisableTiming));
-    XR_HIP(hipEventCreateWithFlags(&g_engine.aux_event, hipEventDisableTiming));
+    // fork / join between two streams of the one device: a device-scope release is all the waiting stream needs (the default,
+    // a system-scope release, writes the caches back to host visibility at every record: ~7 us between two dependent kernels
+    // on the main stream, rocprofv3 timeline of round 4).  XR_EVENT_SCOPE=system restores the default (A/B switch).
+    const bool dev_scope = !(getenv("XR_EVENT_SCOPE") && !strcmp(getenv("XR_EVENT_SCOPE"), "system"));
+    const unsigned ev_flags = hipEventDisableTiming | (dev_scope ? hipEventReleaseToDevice : 0u);
+    XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, ev_flags));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, ev_flags));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.aux_event, ev_flags));
     g_engine.device = device;
 }
 
@@ -253,9 +258,13 @@ static void lane_release_blocks(Lane *lane) {
 }
 
 // called after the main stream has been synchronised with the host
-static void pool_release_deferred() {
+static void pool_release_deferred(bool may_block = true) {
     if (!g_side_active || t_lane) return;
-    (void)hipStreamSynchronize(g_engine.side);
+    if (may_block) (void)hipStreamSynchronize(g_engine.side);
+    else if (hipStreamQuery(g_engine.side) != hipSuccess) { // (still busy: the blocks stay parked until a later host sync)
+        (void)hipGetLastError();
+        return;
+    }
     std::lock_guard<std::mutex> lock(g_pool_mutex);
     for (auto &kv : g_deferred) g_free.emplace(kv.first, kv.second);
     g_deferred.clear();
@@ -566,7 +575,7 @@ void mailbox_wait_seq(int32_t seq) {
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
-    pool_release_deferred();
+    pool_release_deferred(/*may_block=*/false); // (the publisher ran behind the join: the side stream is normally drained)
 }
 
 bool poll_pinned_f64(const volatile double *word, double expected) {

@@ -102,9 +102,10 @@ k_face_area(const double *__restrict__ node_xy, const int32_t *__restrict__ face
 // cross-queue hop less per mesh than a separate one-block reduction kernel, and no event on the stream.
 // Hand-off: 8-byte agent-scope atomics on both sides (MI355X_MICROARCH.md, inter-workgroup visibility) + an agent acquire
 // in the one reducing block; the counter is zero at rest (the last block clears it).
+static constexpr int STATS_SHARDS = 64;
 struct StatsTail {
     double *partials;     // [nb][8]
-    unsigned *done;       // zero at rest
+    unsigned *done;       // [16 * (1 + STATS_SHARDS)] arrival counters, one per 64-byte line, zero at rest
     double *stats;        // [8] device copy
     double *stats_host;   // [9] pinned: 8 statistics + the sequence word
     double seq;
@@ -118,8 +119,19 @@ __device__ __forceinline__ void stats_tail(const StatsTail &t, const double (&a)
 #pragma unroll
         for (int i = 0; i < 8; i++) __hip_atomic_store(&p[i], a[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned prev = __hip_atomic_fetch_add(t.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = prev == (unsigned)(nb - 1);
+        // Two-level arrival count: thousands of returning atomics on ONE address serialise (~10 ns each: 3900 blocks that
+        // finish together = 40 us, measured); STATS_SHARDS counters on lines of their own take 1/STATS_SHARDS of the blocks
+        // each, and only the last arrival of a shard goes on to the second-level word.
+        const int shard = (int)(blockIdx.x % STATS_SHARDS);
+        const unsigned in_shard = (unsigned)((nb - shard + STATS_SHARDS - 1) / STATS_SHARDS);
+        unsigned *first = t.done + 16 * (1 + shard);
+        bool last = false;
+        if (__hip_atomic_fetch_add(first, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == in_shard - 1) {
+            __hip_atomic_store(first, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned shards = (unsigned)(nb < STATS_SHARDS ? nb : STATS_SHARDS);
+            last = __hip_atomic_fetch_add(t.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == shards - 1;
+        }
+        s_last = last;
     }
     __syncthreads();
     if (!s_last) return;
@@ -344,7 +356,7 @@ __global__ void __launch_bounds__(256) k_faces_ccw(const double *__restrict__ no
 }
 
 __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__ partials, int64_t nb,
-                                                     double *__restrict__ stats, double *stats_host) {
+                                                     double *__restrict__ stats, double *stats_host, double seq) {
     double a0 = INFINITY, a1 = -INFINITY, a2 = INFINITY, a3 = -INFINITY, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
     for (int64_t i = threadIdx.x; i < nb; i += 256) {
         const double *p = partials + i * 8;
@@ -370,6 +382,9 @@ __global__ void __launch_bounds__(256) k_reduce_stats(const double *__restrict__
         stats[7] = a7;
         stats_host[0] = a0; stats_host[1] = a1; stats_host[2] = a2; stats_host[3] = a3; stats_host[4] = a4;
         stats_host[5] = a5; stats_host[6] = a6; stats_host[7] = a7;
+        // the host polls the sequence word (mesh_read_stats): behind the statistics, system scope
+        __threadfence_system();
+        __hip_atomic_store(&stats_host[8], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -446,7 +461,8 @@ static constexpr int64_t SAMPLE_MIN_FACES = 1 << 17; // smaller meshes: the full
 static constexpr int SAMPLE_STRIDE = 8;              // every 8th block of 256 faces
 
 // pinned statistics page + (unless XR_STATS_TAIL=0) the hand-off words of the in-kernel reduction
-static StatsTail stats_tail_for(xr_mesh *mesh, double *partials) {
+static constexpr int64_t STATS_TAIL_MAX_BLOCKS = 1024;
+static StatsTail stats_tail_for(xr_mesh *mesh, double *partials, int64_t nb) {
     if (!mesh->stats_host) {
         void *p = nullptr;
         XR_HIP(hipHostMalloc(&p, sizeof(double) * 16, hipHostMallocCoherent));
@@ -454,18 +470,22 @@ static StatsTail stats_tail_for(xr_mesh *mesh, double *partials) {
         memset(mesh->stats_host, 0, sizeof(double) * 16);
         XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
     }
-    static const bool tail_on = !(getenv("XR_STATS_TAIL") && atoi(getenv("XR_STATS_TAIL")) == 0); // A/B switch
-    // (the hand-off needs the host's polling view of ONE stream: not on a caller's stream, not under a stream override)
-    if (!tail_on || stream_override() || current_lane() || engine().on_side) {
-        mesh->stats_polled = false;
-        return StatsTail{partials, nullptr, nullptr, nullptr, 0.0};
-    }
-    if (!mesh->stats_done.get()) {
-        mesh->stats_done.alloc(1);
-        XR_HIP(hipMemsetAsync(mesh->stats_done.get(), 0, sizeof(unsigned), launch_stream()));
-    }
+    // XR_STATS_TAIL: 0 = never (a separate reduction kernel, as until round 3), 1 = always, default = grids of up to
+    // STATS_TAIL_MAX_BLOCKS blocks.  Every block pays ~3 us at its end for the hand-off (agent-scope stores, their
+    // acknowledgement, a returning atomic): nothing for the 490 blocks of sample_stats, whose result the host is waiting
+    // for (16 instead of 12 + 10 + 20 us until the tree's statistics are there), but +15 us for the 3900 blocks of
+    // prepare_faces, whose statistics are only read after the index build -- those keep the one-block kernel on the side
+    // stream (measured, 1M x 1M step: never 0.507, always 0.520, default see DESIGN section 5).
+    static const int tail_mode = getenv("XR_STATS_TAIL") ? atoi(getenv("XR_STATS_TAIL")) : 2;
     mesh->stats_seq += 1.0;
-    mesh->stats_polled = true;
+    mesh->stats_polled = true; // (both forms end with the sequence word)
+    // (the in-kernel form is for the engine's own main stream)
+    if (tail_mode == 0 || (tail_mode == 2 && nb > STATS_TAIL_MAX_BLOCKS) || stream_override() || current_lane() || engine().on_side)
+        return StatsTail{partials, nullptr, nullptr, nullptr, mesh->stats_seq};
+    if (!mesh->stats_done.get()) {
+        mesh->stats_done.alloc(16 * (1 + STATS_SHARDS));
+        XR_HIP(hipMemsetAsync(mesh->stats_done.get(), 0, sizeof(unsigned) * 16 * (1 + STATS_SHARDS), launch_stream()));
+    }
     return StatsTail{partials, mesh->stats_done.get(), mesh->stats.get(), mesh->stats_host, mesh->stats_seq};
 }
 
@@ -487,7 +507,7 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
         const int64_t nb = (nb_all + SAMPLE_STRIDE - 1) / SAMPLE_STRIDE;
         DevBuf<double> partials((size_t)nb * 8);
         dim3 grid((unsigned)nb), block(PREP_BLOCK);
-        const StatsTail tail = stats_tail_for(mesh, partials.get());
+        const StatsTail tail = stats_tail_for(mesh, partials.get(), nb);
         if (m == 3)
             XR_LAUNCH("sample_stats", k_sample_stats<3>, grid, block, 0, mesh->node_xy.get(), mesh->n_node, mesh->faces_raw.get(),
                       F, m, SAMPLE_STRIDE, partials.get(), tail);
@@ -501,9 +521,10 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
             std::unique_ptr<SideScope> side;
             if (stats_on_side) side.reset(new SideScope);
             XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
-                      mesh->stats_host);
+                      mesh->stats_host, tail.seq);
             XR_HIP(hipEventRecord(mesh->stats_event, launch_stream()));
         }
+        mesh->stats_event_pending = !tail.done;
         mesh->prepared = true;
         mesh->stats_valid = false;
         mesh->stats_sampled = true;
@@ -522,7 +543,7 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
     const int64_t nb = std::max<int64_t>(1, (F + PREP_BLOCK - 1) / PREP_BLOCK);
     DevBuf<double> partials((size_t)nb * 8);
     dim3 grid((unsigned)nb), block(PREP_BLOCK);
-    const StatsTail tail = stats_tail_for(mesh, partials.get());
+    const StatsTail tail = stats_tail_for(mesh, partials.get(), nb);
 #define XR_PREP(MC)                                                                                                    \
     do {                                                                                                               \
         if (want_fxy)                                                                                                  \
@@ -543,9 +564,10 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
         std::unique_ptr<SideScope> side;
         if (stats_on_side) side.reset(new SideScope);
         XR_LAUNCH("reduce_stats", k_reduce_stats, dim3(1), dim3(256), 0, partials.get(), nb, mesh->stats.get(),
-                  mesh->stats_host);
+                  mesh->stats_host, tail.seq);
         XR_HIP(hipEventRecord(mesh->stats_event, launch_stream()));
     }
+    mesh->stats_event_pending = !tail.done;
     mesh->prepared = true;
     mesh->stats_valid = false;
 }
@@ -574,14 +596,12 @@ void mesh_read_stats(xr_mesh *mesh, bool need_exact) {
     if (!mesh->prepared) mesh_prepare(mesh, false);
     else if (need_exact && mesh->stats_sampled) mesh_prepare(mesh, mesh->has_attrs, false, false); // over all faces this time
     if (mesh->stats_valid) return;
-    if (mesh->stats_polled) {
-        // the reducing block stores the sequence word behind the statistics: poll it (bounded), else drain the stream
-        if (!poll_pinned_f64(mesh->stats_host + 8, mesh->stats_seq)) {
-            XR_HIP(hipStreamSynchronize(engine().stream));
-            XR_REQUIRE(mesh->stats_host[8] == mesh->stats_seq, XR_ERR_HIP, "mesh statistics did not arrive");
-        }
-    } else {
-        XR_HIP(hipEventSynchronize(mesh->stats_event));
+    // the reducing block / kernel stores the sequence word behind the statistics: poll it (bounded), else wait for the
+    // event behind the reduction kernel or drain the stream
+    if (!(mesh->stats_polled && poll_pinned_f64(mesh->stats_host + 8, mesh->stats_seq))) {
+        if (mesh->stats_event_pending) XR_HIP(hipEventSynchronize(mesh->stats_event));
+        else XR_HIP(hipStreamSynchronize(engine().stream));
+        XR_REQUIRE(!mesh->stats_polled || mesh->stats_host[8] == mesh->stats_seq, XR_ERR_HIP, "mesh statistics did not arrive");
     }
     for (int i = 0; i < 8; i++) mesh->h_stats[i] = mesh->stats_host[i];
     mesh->stats_valid = true;

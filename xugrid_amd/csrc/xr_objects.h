@@ -39,6 +39,7 @@ struct xr_mesh {
     hipEvent_t stats_event = nullptr;
     xr::DevBuf<unsigned> stats_done; // [1] blocks that have delivered their partial (zero at rest; stats_tail, xr_mesh.hip)
     double stats_seq = 0.0;          // sequence number of the last statistics launch (what stats_host[8] must show)
+    bool stats_event_pending = false; // a reduction kernel + event were enqueued for the last launch (fallback of the poll)
     bool stats_polled = false;       // the statistics of the last launch arrive through the sequence word (no event recorded)
     xr_mesh() = default;
     xr_mesh(const xr_mesh &) = delete;
@@ -101,7 +102,8 @@ struct xr_csr {
     bool has_row_order = false;
     // stored rows with more than XR_APPLY_LONG_ROW entries (reduced by one wave or block each in the apply)
     xr::DevBuf<int32_t> long_rows; // [<= n]
-    xr::DevBuf<int32_t> n_long;    // [1] device-side count
+    xr::DevBuf<int32_t> n_long;    // [1] device-side count ([2] for matrices of the triangle pipeline: [1] = apply gate)
+    bool apply_gated = false;      // the K = 1 apply being enqueued must check n_long[1] (matrix not yet confirmed by the host)
     int64_t max_row_len = -1;      // entries of the longest row if the builder reported it (-1: unknown)
     bool has_long = false;
     // Coarse Morton key per STORED row (tile of ~12 target extents).  Set by xr_overlap when the rows are kept

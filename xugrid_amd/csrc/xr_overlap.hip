@@ -1352,7 +1352,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)(compact ? 1 : reg_capacity));
     DevBuf<int32_t> wave_surv((size_t)(compact ? reg_capacity / 64 + 1 : 1));
     DevBuf<double> cand_area((size_t)reg_capacity);
-    csr->n_long.alloc(1);
+    csr->n_long.alloc(2); // [0] rows of more than XR_APPLY_LONG_ROW entries, [1] gate of an apply enqueued behind the build
     csr->row_order.alloc((size_t)T);
     csr->has_row_order = true;
     const int big_grid = engine().num_cu * 8;
@@ -1455,7 +1455,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, csr->indptr.get(), csr->indices.get(),
                   csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, ctl_head + 3);
         const int32_t seq = mailbox_next_seq();
-        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl_head, fc, csr->n_long.get(), mail, seq);
+        XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl_head, fc, csr->n_long.get(), mail, seq, cap, big_capacity);
         if (ctl_cached) zero_scratch_done(1); // (the counters are zero again behind k_publish_all)
         if (early) {
             // sizes unknown on the host yet: pessimistic flags (long rows possible, of any length) -- they only add blocks
@@ -1463,7 +1463,9 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             csr->nnz = 0;
             csr->has_long = true;
             csr->max_row_len = -1;
+            csr->apply_gated = true; // (the kernel looks at the gate k_publish_all has just set: a failed attempt is skipped)
             early->fn(csr);
+            csr->apply_gated = false;
         }
         mailbox_wait_seq(seq);
         const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], n_pending = mail[3], big_overflow = mail[4];

@@ -683,7 +683,8 @@ k_place_big(const int32_t *__restrict__ n_big_dev, const int32_t *__restrict__ s
 // ... and clears all of them behind itself: the counter words are the engine's zero-at-rest scratch (the next xr_overlap
 // starts without a memset).  One wave.
 __global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right behind them (c + 8) */, FusedCounters *fc,
-                              int32_t *__restrict__ n_apply_long_out, int32_t *mail, int32_t seq) {
+                              int32_t *__restrict__ n_apply_long_out, int32_t *mail, int32_t seq, int64_t cap,
+                              int64_t big_capacity) {
     // one load per lane (the 16 words are one line), so the host's wait is one round trip long
     const int t = threadIdx.x;
     int32_t w = 0;
@@ -700,6 +701,15 @@ __global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right
     else if (t == 8 + 6) slot = 10;
     if (slot >= 0) mail[slot] = w;
     if (t == 8) *n_apply_long_out = w;
+    if (t == 0) {
+        // gate of an apply enqueued right behind this kernel (xr_overlap_apply_dev): open only if THIS attempt produced the
+        // final matrix -- the very conditions the host checks after its read-back (overlap_tri); a failed attempt leaves
+        // row pointers no kernel may follow
+        const int32_t c_reg = c[0], c_big = c[1], n_pending = c[3], err = c[8 + 1], p_reg = c[8 + 2], p_big = c[8 + 4];
+        const bool ok = c_reg >= 0 && c_big >= 0 && !(err & (1 | 4 | 8)) && n_pending == 0 && (int64_t)c_big <= big_capacity &&
+                        (int64_t)p_reg + p_big <= cap;
+        n_apply_long_out[1] = ok ? 1 : 0;
+    }
     __builtin_amdgcn_s_waitcnt(0); // (every load above has returned before the words are cleared)
     if (t < 16) c[t] = 0;
     (void)fc;
