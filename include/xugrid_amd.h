@@ -99,6 +99,11 @@ int xr_set_stream(void *hip_stream, int external, int async_dev);
  * returns data to the host.  All work then stays on the one engine stream (no per-thread lanes).  For pipelines that keep
  * their data on the device and issue many calls back to back (a time loop; bench.py's step). */
 int xr_set_async(int on);
+/* Host-only helpers of the Python layer (no device, usable without one): the copies xugrid's constructors make
+ * (Ugrid2d.__init__, xugrid/ugrid/ugrid2d.py:86-96: contiguous node_x / node_y, face_node_connectivity.copy()) done by the
+ * library's host thread pool.  xr_host_interleave2: out_xy[i] = (x[i * x_stride], y[i * y_stride]), strides in elements. */
+int xr_host_copy(void *dst, const void *src, int64_t bytes);
+int xr_host_interleave2(const double *x, int64_t x_stride, const double *y, int64_t y_stride, int64_t n, double *out_xy);
 
 /* ---- seam 1: mesh handle = CellTree2d(vertices, faces, fill_value) --------------------- */
 /* ugrid2d.py:915-921.  node_xy: float64[n_node,2] (node_coordinates, ugridbase.py:576-579);

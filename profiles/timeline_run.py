@@ -29,6 +29,7 @@ _lib.check(lib.xr_dev_upload(d_src, data.ctypes.data_as(ctypes.c_void_p), 8 * S)
 import bench  # noqa: E402  (the step itself lives there)
 
 step = bench.make_step(E, ms, mt, d_src.value, d_out.value, {})
+E.set_async(os.environ.get("XR_BENCH_SYNC", "") in ("", "0"))  # (as bench.py's timed loop)
 for _ in range(20):
     step()
 E.dev_sync()

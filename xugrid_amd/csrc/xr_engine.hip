@@ -742,6 +742,36 @@ int xr_set_stream(void *hip_stream, int external, int async_dev) {
     XR_API_END
 }
 
+// ---- host-side helpers of the Python layer (no device involved): the copies the reference's constructors make
+// (Ugrid2d.__init__: face_node_connectivity.copy(), contiguous node coordinates) through the library's host thread pool --
+// a 24 MB numpy copy into a fresh array is 2-3 ms of single-threaded page faults, eight threads do it in 0.5 ms.
+int xr_host_copy(void *dst, const void *src, int64_t bytes) {
+    try {
+        XR_REQUIRE(bytes >= 0 && ((dst && src) || bytes == 0), XR_ERR_INVALID, "xr_host_copy: bad arguments");
+        char *d = static_cast<char *>(dst);
+        const char *c = static_cast<const char *>(src);
+        parallel_ranges((size_t)bytes, 4096, [=](size_t b, size_t e) { memcpy(d + b, c + b, e - b); });
+        return XR_OK;
+    } catch (const Failure &f) {
+        return f.code;
+    }
+}
+
+int xr_host_interleave2(const double *x, int64_t x_stride, const double *y, int64_t y_stride, int64_t n, double *out_xy) {
+    try {
+        XR_REQUIRE(n >= 0 && ((x && y && out_xy) || n == 0), XR_ERR_INVALID, "xr_host_interleave2: bad arguments");
+        parallel_ranges((size_t)n, 512, [=](size_t b, size_t e) {
+            for (size_t i = b; i < e; i++) {
+                out_xy[2 * i] = x[(int64_t)i * x_stride];
+                out_xy[2 * i + 1] = y[(int64_t)i * y_stride];
+            }
+        });
+        return XR_OK;
+    } catch (const Failure &f) {
+        return f.code;
+    }
+}
+
 int xr_set_async(int on) {
     XR_API_BEGIN
     Engine &e = engine();

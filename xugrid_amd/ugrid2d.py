@@ -8,22 +8,48 @@ Minimal ``Ugrid2d``: exactly the slice of xugrid/ugrid/ugrid2d.py the regridding
 """
 import numpy as np
 
-from . import connectivity
+import ctypes
+
+from . import _lib, connectivity
 from .celltree import CellTree2d
 from .engine import FloatDType, IntDType
 
 FILL_VALUE = -1
 
 
+def _node_table(node_x, node_y):
+    """(n, 2) C-contiguous float64 table of the node coordinates: the layout the device wants, written once -- by the
+    library's host threads when the inputs are float64 (any stride, e.g. the two columns of an (n, 2) array)."""
+    x, y = np.asarray(node_x), np.asarray(node_y)
+    if x.shape != y.shape or x.ndim != 1:
+        raise ValueError("node_x and node_y must be 1-D arrays of equal length")
+    n = x.size
+    if n >= 65536 and x.dtype == np.float64 and y.dtype == np.float64 and x.strides[0] % 8 == 0 and y.strides[0] % 8 == 0:
+        out = np.empty((n, 2), dtype=np.float64)
+        _lib.check(_lib.load().xr_host_interleave2(ctypes.c_void_p(x.ctypes.data), x.strides[0] // 8, ctypes.c_void_p(y.ctypes.data),
+                                                   y.strides[0] // 8, n, ctypes.c_void_p(out.ctypes.data)))
+        return out
+    return np.column_stack([np.asarray(x, dtype=FloatDType), np.asarray(y, dtype=FloatDType)])
+
+
+def _copy_connectivity(faces):
+    """face_node_connectivity.copy() as IntDType (ugrid2d.py:94-96): a private copy the constructor may rewrite."""
+    if faces.dtype == IntDType and faces.flags.c_contiguous and faces.nbytes >= (1 << 20):
+        out = np.empty(faces.shape, dtype=IntDType)
+        _lib.check(_lib.load().xr_host_copy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(faces.ctypes.data), faces.nbytes))
+        return out
+    return faces.astype(IntDType, copy=True)
+
+
 class Ugrid2d:
     def __init__(self, node_x, node_y, fill_value, face_node_connectivity, name="mesh2d", start_index=0):
-        self.node_x = np.ascontiguousarray(node_x, dtype=FloatDType)
-        self.node_y = np.ascontiguousarray(node_y, dtype=FloatDType)
-        if self.node_x.shape != self.node_y.shape or self.node_x.ndim != 1:
-            raise ValueError("node_x and node_y must be 1-D arrays of equal length")
+        # (n, 2) node table, contiguous: what node_coordinates returns and the device mesh uploads; node_x / node_y
+        # (contiguous, as the reference keeps them, ugrid2d.py:86-87) are cut out of it on first use
+        self._node_xy = _node_table(node_x, node_y)
+        self._node_x = self._node_y = None
         if not isinstance(face_node_connectivity, np.ndarray):
             raise TypeError("face_node_connectivity should be an array of integers")
-        faces = face_node_connectivity.astype(IntDType, copy=True)
+        faces = _copy_connectivity(face_node_connectivity)
         if faces.ndim != 2:
             raise ValueError("face_node_connectivity must be 2-D (n_face, n_max_node_per_face)")
         # fill -> -1 and 0-based, as ugrid2d.py:105-110
@@ -46,10 +72,22 @@ class Ugrid2d:
         self._edge_face_connectivity = None
         self._node_face_connectivity = None
 
+    @property
+    def node_x(self):
+        if self._node_x is None:
+            self._node_x = np.ascontiguousarray(self._node_xy[:, 0])
+        return self._node_x
+
+    @property
+    def node_y(self):
+        if self._node_y is None:
+            self._node_y = np.ascontiguousarray(self._node_xy[:, 1])
+        return self._node_y
+
     # ---- sizes / names
     @property
     def n_node(self):
-        return self.node_x.size
+        return self._node_xy.shape[0]
 
     @property
     def n_face(self):
@@ -73,15 +111,16 @@ class Ugrid2d:
 
     @property
     def node_coordinates(self):
-        return np.column_stack([self.node_x, self.node_y])
+        return self._node_xy
 
     @property
     def bounds(self):
-        return (self.node_x.min(), self.node_y.min(), self.node_x.max(), self.node_y.max())
+        lo, hi = self._node_xy.min(axis=0), self._node_xy.max(axis=0)
+        return (lo[0], lo[1], hi[0], hi[1])
 
     def node_coordinates_of(self, nodes):
         """(len(nodes), 2) coordinates of the given node ids."""
-        return np.column_stack([self.node_x[nodes], self.node_y[nodes]])
+        return self._node_xy[nodes]
 
     # ---- device-backed geometry
     @property
@@ -263,6 +302,7 @@ class RectilinearUgrid2d(Ugrid2d):
 
     node_x = property(lambda self: self._materialise().node_x)
     node_y = property(lambda self: self._materialise().node_y)
+    node_coordinates = property(lambda self: self._materialise().node_coordinates)
     face_node_connectivity = property(lambda self: self._materialise().face_node_connectivity)
 
     @property
