@@ -29,6 +29,7 @@ def main():
     main_queue = ker[ends[-1]][3]
     out_steps = []
     gap_by_pair = defaultdict(list)
+    gantt = defaultdict(list)  # kernel name (+ occurrence within the step) -> [(start - t0, end - t0, on main queue)]
     for a, b in zip(ends[:-1], ends[1:]):
         t0, t1 = ker[a][1], ker[b][1]
         ks = ker[a + 1:b + 1]
@@ -44,6 +45,10 @@ def main():
                 busy += e - max(s, last_end)
                 last_end = e
                 prev_name = n
+        seen = defaultdict(int)
+        for s, e, n, q, st in ks:
+            seen[n] += 1
+            gantt[(n, seen[n])].append(((s - t0) / 1e3, (e - t0) / 1e3, q == main_queue))
         main_sum = sum(e - s for s, e, n, q, st in ks if q == main_queue)
         side_sum = sum(e - s for s, e, n, q, st in ks if q != main_queue)
         # what the host was inside during each idle gap
@@ -81,6 +86,9 @@ def main():
         "mean": {k: sum(s[k] for s in out_steps) / n for k in ("wall_us", "device_busy_us", "idle_us", "kernels", "launch_calls",
                                                                "main_queue_kernel_sum_us", "side_queue_kernel_sum_us", "n_gaps")},
         "idle_by_gap_us_per_step": [{"after": a, "before": b, "us": round(v, 2)} for (a, b), v in pairs[:30]],
+        "gantt_us": [{"kernel": k[0] + ("" if k[1] == 1 else "#%d" % k[1]), "queue": "main" if v[0][2] else "side",
+                      "start": round(sum(x[0] for x in v) / len(v), 2), "end": round(sum(x[1] for x in v) / len(v), 2)}
+                     for k, v in sorted(gantt.items(), key=lambda kv: sum(x[0] for x in kv[1]) / len(kv[1]))],
         "per_step": out_steps,
     }
     print(json.dumps(summary, indent=1))

@@ -69,13 +69,14 @@ __device__ __forceinline__ void tri_lut_init(uint2 *lut) { poly_lut_init<TRI_MAX
 
 __device__ __forceinline__ bool p2_eq(P2 a, P2 b) { return a.x == b.x && a.y == b.y; }
 __device__ __forceinline__ bool p2_eq(P2 a, double2 b) { return a.x == b.x && a.y == b.y; }
+template <int STRIDE>
 __device__ __forceinline__ double2 *tri_slot(double2 *col, uint32_t byte_offset) {
-    return reinterpret_cast<double2 *>(reinterpret_cast<char *>(col) + byte_offset);
+    return reinterpret_cast<double2 *>(reinterpret_cast<char *>(col) + byte_offset * STRIDE);
 }
 
 // The oracle's stage loop on a register polygon (static indexing, predicated on the current length); output
 // pushed into the lane's LDS column (slot TRI_MAXV = trash for clamped pushes).
-template <int MAXV>
+template <int MAXV, int STRIDE>
 __device__ __forceinline__ void poly_stage_generic(const P2 (&v)[MAXV], int &n, const P2 r, const P2 U, bool &alive,
                                                    bool &overflow, double2 *col) {
     const P2 N{-U.y, U.x};
@@ -108,12 +109,12 @@ __device__ __forceinline__ void poly_stage_generic(const P2 (&v)[MAXV], int &n, 
             }
             const bool quirk = cross && !b_inside && !have_pt; // parallel edge: keep b, which then counts as inside
             if (cross && have_pt) {
-                col[n_output < MAXV ? n_output : MAXV] = make_double2(pt.x, pt.y);
+                col[(n_output < MAXV ? n_output : MAXV) * STRIDE] = make_double2(pt.x, pt.y);
                 n_output++;
             }
             b_inside = b_inside || quirk;
             if (live && b_inside) {
-                col[n_output < MAXV ? n_output : MAXV] = make_double2(b.x, b.y);
+                col[(n_output < MAXV ? n_output : MAXV) * STRIDE] = make_double2(b.x, b.y);
                 n_output++;
             }
             if (live) {
@@ -134,7 +135,7 @@ __device__ __forceinline__ void poly_stage_generic(const P2 (&v)[MAXV], int &n, 
 // One stage.  NIN = number of vertices the fast path is unrolled for (3, 4, 5 for the three edges of a triangle
 // clipper: a regular stage adds at most one vertex).  The lane's LDS column holds the current polygon before and
 // after; registers are only a per-stage copy.
-template <int MAXV, int NIN, bool LAST = false>
+template <int MAXV, int NIN, int STRIDE, bool LAST = false>
 __device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &alive, bool &dirty, bool &overflow,
                                            double2 *col, const uint2 *lut) {
     const P2 U{s.x - r.x, s.y - r.y};
@@ -143,7 +144,7 @@ __device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &aliv
 #pragma unroll
     for (int j = 0; j < MAXV; j++) {
         if (j < NIN) {
-            const double2 q = col[j]; // (slots >= n: stale values, masked below)
+            const double2 q = col[j * STRIDE]; // (slots >= n: stale values, masked below)
             v[j] = P2{q.x, q.y};
         } else {
             v[j] = P2{0.0, 0.0};
@@ -163,7 +164,7 @@ __device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &aliv
         // end points of the two crossing edges from the lane's LDS column
         const int j1 = __ffs(Tm) - 1, j2 = 31 - __clz(Tm);
         const int p1 = j1 == 0 ? n - 1 : j1 - 1, p2 = j2 - 1;
-        const double2 a1 = col[p1], b1 = col[j1], a2 = col[p2], b2 = col[j2];
+        const double2 a1 = col[p1 * STRIDE], b1 = col[j1 * STRIDE], a2 = col[p2 * STRIDE], b2 = col[j2 * STRIDE];
         const uint2 e = lut[F + (1u << n)];
         const P2 N{-U.y, U.x};
         const P2 V1{b1.x - a1.x, b1.y - a1.y}, V2{b2.x - a2.x, b2.y - a2.y};
@@ -179,14 +180,14 @@ __device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &aliv
             if (!LAST && (pt1.x == a1.x || pt1.x == b1.x || pt2.x == a2.x || pt2.x == b2.x || pt1.x == pt2.x))
                 dirty = p2_eq(pt1, a1) || p2_eq(pt1, b1) || p2_eq(pt2, a2) || p2_eq(pt2, b2) || p2_eq(pt1, pt2);
             // compaction in the oracle's emission order; vertices outside land in the trash slot
-            *tri_slot(col, e.x & 0xffu) = make_double2(v[0].x, v[0].y);
-            *tri_slot(col, (e.x >> 8) & 0xffu) = make_double2(v[1].x, v[1].y);
-            *tri_slot(col, (e.x >> 16) & 0xffu) = make_double2(v[2].x, v[2].y);
-            if (NIN > 3) *tri_slot(col, e.x >> 24) = make_double2(v[3].x, v[3].y);
-            if (NIN > 4) *tri_slot(col, e.y & 0xffu) = make_double2(v[4].x, v[4].y);
-            if (NIN > 5) *tri_slot(col, e.y >> 24) = make_double2(v[5].x, v[5].y);
-            *tri_slot(col, (e.y >> 8) & 0xffu) = make_double2(pt1.x, pt1.y);
-            *tri_slot(col, (e.y >> 16) & 0xffu) = make_double2(pt2.x, pt2.y);
+            *tri_slot<STRIDE>(col, e.x & 0xffu) = make_double2(v[0].x, v[0].y);
+            *tri_slot<STRIDE>(col, (e.x >> 8) & 0xffu) = make_double2(v[1].x, v[1].y);
+            *tri_slot<STRIDE>(col, (e.x >> 16) & 0xffu) = make_double2(v[2].x, v[2].y);
+            if (NIN > 3) *tri_slot<STRIDE>(col, e.x >> 24) = make_double2(v[3].x, v[3].y);
+            if (NIN > 4) *tri_slot<STRIDE>(col, e.y & 0xffu) = make_double2(v[4].x, v[4].y);
+            if (NIN > 5) *tri_slot<STRIDE>(col, e.y >> 24) = make_double2(v[5].x, v[5].y);
+            *tri_slot<STRIDE>(col, (e.y >> 8) & 0xffu) = make_double2(pt1.x, pt1.y);
+            *tri_slot<STRIDE>(col, (e.y >> 16) & 0xffu) = make_double2(pt2.x, pt2.y);
             n = __popc(F) + 2; // (>= 3: a transition implies an inside vertex)
         }
     } else if (work && !irregular && !(F & 1u)) {
@@ -198,12 +199,12 @@ __device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &aliv
 #pragma unroll
             for (int j = NIN; j < MAXV; j++) {
                 if (j < n) {
-                    const double2 q = col[j];
+                    const double2 q = col[j * STRIDE];
                     v[j] = P2{q.x, q.y};
                 }
             }
         }
-        poly_stage_generic<MAXV>(v, n, r, U, alive, overflow, col);
+        poly_stage_generic<MAXV, STRIDE>(v, n, r, U, alive, overflow, col);
         dirty = true; // (the generic loop may emit repeated vertices)
     }
     if (work) r = s;
@@ -213,7 +214,7 @@ __device__ __forceinline__ void poly_stage(int &n, P2 &r, const P2 s, bool &aliv
 // TRI_AREA_OVERFLOW.  col: the lane's LDS column, col[0 .. MAXV] (MAXV + 1 double2 slots, contiguous); lut: poly_lut_init<MAXV>'s
 // table.  N0 = 3, MAXV = 6: triangle x triangle; N0 = 4, MAXV = 7: the faces of a quadrilateral (raster) target, which may
 // be triangles with a fill slot (n0 = 3).
-template <int MAXV, int N0>
+template <int MAXV, int N0, int STRIDE = 1>
 __device__ __forceinline__ double poly_clip_area(const P2 (&tv)[N0], int n0, const P2 (&sv)[3], double2 *col, const uint2 *lut,
                                                  bool active) {
     int n = n0;
@@ -226,23 +227,23 @@ __device__ __forceinline__ double poly_clip_area(const P2 (&tv)[N0], int n0, con
     if (active) {
 #pragma unroll
         for (int j = 0; j < N0; j++)
-            if (j < n0) col[j] = make_double2(tv[j].x, tv[j].y);
+            if (j < n0) col[j * STRIDE] = make_double2(tv[j].x, tv[j].y);
     }
     P2 r = sv[2];
-    poly_stage<MAXV, N0>(n, r, sv[0], alive, dirty, overflow, col, lut);
-    poly_stage<MAXV, N0 + 1>(n, r, sv[1], alive, dirty, overflow, col, lut);
-    poly_stage<MAXV, N0 + 2, true>(n, r, sv[2], alive, dirty, overflow, col, lut);
+    poly_stage<MAXV, N0, STRIDE>(n, r, sv[0], alive, dirty, overflow, col, lut);
+    poly_stage<MAXV, N0 + 1, STRIDE>(n, r, sv[1], alive, dirty, overflow, col, lut);
+    poly_stage<MAXV, N0 + 2, STRIDE, true>(n, r, sv[2], alive, dirty, overflow, col, lut);
     if (overflow) return TRI_AREA_OVERFLOW;
     double area = 0.0;
     if (alive) {
         // fan area from the first clipped vertex (local origin)
-        const double2 q0 = col[0], q1 = col[1];
+        const double2 q0 = col[0], q1 = col[STRIDE];
         const P2 a0{q0.x, q0.y};
         double ux = q1.x - a0.x, uy = q1.y - a0.y;
 #pragma unroll
         for (int i = 2; i < MAXV; i++) {
             if (i < n) {
-                const double2 q = col[i];
+                const double2 q = col[i * STRIDE];
                 const double vx = a0.x - q.x, vy = a0.y - q.y;
                 area += fabs(ux * vy - uy * vx);
                 ux = vx;
@@ -254,9 +255,10 @@ __device__ __forceinline__ double poly_clip_area(const P2 (&tv)[N0], int n0, con
     return area;
 }
 
+template <int STRIDE = 1>
 __device__ __forceinline__ double tri_clip_area(const P2 (&tv)[3], const P2 (&sv)[3], double2 *col, const uint2 *lut,
                                                 bool active) {
-    return poly_clip_area<TRI_MAXV, 3>(tv, 3, sv, col, lut, active);
+    return poly_clip_area<TRI_MAXV, 3, STRIDE>(tv, 3, sv, col, lut, active);
 }
 
 static constexpr int QUAD_MAXV = 7;              // quadrilateral subject: up to 7 vertices after three clip edges

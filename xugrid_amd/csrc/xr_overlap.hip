@@ -421,6 +421,12 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                 if (((batch_id + l) & 3) != wv) continue;
                 const int cy = cyb + lane;
                 int r0 = 0, r1 = 0;
+                // (the record test uses the polygon's x-extent INSIDE the row's slab, not the face's whole box: a record of this
+                // row lies inside the slab in y, so a common point with the polygon has its x inside that extent -- the same
+                // argument that lets the walk skip the cells beside it.  For a diagonal sliver this is the difference between
+                // "every record of every visited cell" and the records along the sliver: the longest face of the 1M benchmark
+                // went from ~4000 candidates, 763 of them real, to a third.)
+                float rx0 = qx0, rx1 = qx1;
                 if (cy <= cy1) {
                     // polygon x-extent inside the slab [ya, yb] of this grid row
                     const double ya = g.y0 + (double)cy * h - eps, yb = g.y0 + (double)(cy + 2) * h + eps;
@@ -452,6 +458,8 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                         const int cx0 = cell_coord(xlo - h, g.x0, inv_h, nx), cx1 = cell_coord(xhi, g.x0, inv_h, nx);
                         r0 = cell_start[base + cy * nx + cx0];
                         r1 = cell_start[base + cy * nx + cx1 + 1];
+                        rx0 = fmaxf(qx0, f32_below(xlo - g.x0));
+                        rx1 = fminf(qx1, f32_above(xhi - g.x0));
                     }
                 }
                 const int len = r1 - r0;
@@ -461,9 +469,10 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                     const int src_lane = __ffsll((long long)long_mask) - 1;
                     long_mask &= long_mask - 1;
                     const int R0 = __shfl(r0, src_lane, 64), R1 = __shfl(r1, src_lane, 64);
+                    const float X0 = __shfl(rx0, src_lane, 64), X1 = __shfl(rx1, src_lane, 64);
                     for (int rb = R0; rb < R1; rb += 64) {
                         const int r = rb + lane;
-                        const bool hit = r < R1 && rec_hit(rbb[r], qx0, qx1, qy0, qy1);
+                        const bool hit = r < R1 && rec_hit(rbb[r], X0, X1, qy0, qy1);
                         const unsigned long long mask = __ballot(hit);
                         const int n = __popcll(mask);
                         if (n > 0) {
@@ -485,7 +494,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                 // (2) short runs: one lane per grid row
                 const int my_r1 = len > LONG_RUN ? r0 : r1;
                 int cnt = 0;
-                for (int r = r0; r < my_r1; r++) cnt += rec_hit(rbb[r], qx0, qx1, qy0, qy1) ? 1 : 0;
+                for (int r = r0; r < my_r1; r++) cnt += rec_hit(rbb[r], rx0, rx1, qy0, qy1) ? 1 : 0;
                 const int excl = wave_excl_scan_i32(cnt, lane);
                 const int batch = __shfl(excl + cnt, 63, 64);
                 if (batch > 0) {
@@ -494,7 +503,7 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
                     slot0 = __shfl(slot0, 0, 64);
                     int pos = slot0 + excl;
                     for (int r = r0; r < my_r1; r++) {
-                        if (rec_hit(rbb[r], qx0, qx1, qy0, qy1)) {
+                        if (rec_hit(rbb[r], rx0, rx1, qy0, qy1)) {
                             if (STAGE) {
                                 if (pos < big_stage) sh_stage[FUSED ? pos : 0] = r;
                             } else {
@@ -1420,8 +1429,14 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         // blocks per CU all give the same step (0.635 ms) -- measured after the chain lost two launches; before, 3 was
         // 4 % faster because the chain was the critical path.  XR_CLIP_BPC overrides (tuning hook).
         static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5;
-        if (scan_bases)
-            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
+        static const bool clip_soa = getenv("XR_CLIP_SOA") && atoi(getenv("XR_CLIP_SOA")) == 1; // A/B switch: slot-major LDS columns
+        if (scan_bases && clip_soa)
+            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, true>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
+                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
+                      ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr);
+        else if (scan_bases)
+            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, false>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr);

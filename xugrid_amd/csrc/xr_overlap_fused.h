@@ -142,7 +142,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/,
 // k_search wrote it in: the vertex blocks are in that XCD's L2).
 // COUNT: which survivor counts the kernel keeps (two instantiations: both paths in one kernel cost registers -> scratch)
 //   0 none, 1 per block of FB target faces (regular queue: blk_surv), 2 per target face (big faces' queue: nnz_row)
-template <int BLOCK, int COUNT>
+//   SOA: the LDS columns slot-major (slot s of lane l at s * BLOCK + l: every 16-byte access of a wave -- static or
+//   dynamic slot -- falls on the banks of its lane alone) instead of lane-major (7 consecutive slots per lane: the dynamic-index
+//   reads of a stage conflict, 18 % of the LDS cycles, round-3 PMC)
+template <int BLOCK, int COUNT, bool SOA = false>
 __global__ void __launch_bounds__(BLOCK)
 k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
                  const int32_t *__restrict__ rec_face, const int32_t *cand_tgt /* (rewritten in place when compacting) */,
@@ -155,7 +158,8 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
                  COMPACTED: the survivors of stretch w are written to the front of the stretch, IN PLACE over the queue --
                  (target face, caller's source id, area) in cand_tgt / cand_src / cand_area at w * 64 + rank */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
+    constexpr int CS = SOA ? BLOCK : 1;
+    double2 *col = reinterpret_cast<double2 *>(smem) + (SOA ? threadIdx.x : threadIdx.x * (TRI_MAXV + 1)); // the lane's TRI_MAXV + 1 slots
     __shared__ uint2 sh_lut[TRI_LUT];
     if (skip_if) __builtin_amdgcn_s_setprio(3); // (the big faces' queue, on the side stream: issue priority over the main clip)
     if (skip_if && *skip_if > 0) return; // (big faces that did not fit their queue: the host redoes everything)
@@ -205,7 +209,7 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
             sid = rec_face[n_s];
         }
         load_idx(slot + stride, n_tq, n_s);
-        const double area = tri_clip_area(tv, sv, col, sh_lut, active);
+        const double area = tri_clip_area<CS>(tv, sv, col, sh_lut, active);
         const int tq_now = active ? cur_tq : -1;
         if (COUNT == 1 && wave_surv) {
             // Only the pairs that survive (60 % on the benchmark) are written, packed at the front of the wave's own
