@@ -30,7 +30,7 @@ for _ in range(reps):
             res[v].append(json.loads(out.stdout.strip().splitlines()[-1]))
         except Exception:
             print(v, "FAILED", out.stderr[-400:])
-keys = ["search", "place_big", "clip_tri", "assemble", "search_big", "clip_big", "row_fill_long", "big_all", "index_scatter", "index_count", "prepare_faces", "apply_rows1"]
+keys = ["search", "place_big", "clip_tri", "assemble", "search_big", "clip_big", "row_fill_long", "row_fill_huge", "index_scatter", "index_count", "prepare_faces", "apply_rows1"]
 for v in variants:
     if not res[v]:
         continue

@@ -238,6 +238,60 @@ def test_overlap_fused_matches_general_chain(hip, monkeypatch):
             np.testing.assert_array_equal(x, y)
 
 
+def test_overlap_meshes_sharing_nodes(hip, oracle):
+    """The reference clips a pair only if the two faces' EXACT bounding boxes overlap strictly (numba_celltree
+    boxes_intersect, oracle/xr_oracle.c:530): faces that merely touch -- a mesh against itself: the neighbours across a
+    corner -- never reach its clip, which would return a sliver of ~1e-36 for some of them (23 pairs of 60 394 on the mesh
+    below; the engine's float boxes are supersets and used to let them through).  The search marks the pairs whose float boxes
+    overlap by their rounding only, the clip kernels repeat the box test on the float64 vertices for those.  Also: the same
+    mesh far from the origin (UTM-like coordinates), needle-thin and zero-area source triangles, big faces (side-stream chain)
+    and the general kernel chain."""
+    sxy, sf = meshgen.triangle_mesh(30000, 21)
+    txy, tf = meshgen.triangle_mesh(25000, 22, 25.0, 0.8)
+    assert_overlap_parity(hip, oracle, sxy, sf, sxy, sf)
+    off = np.array([6.5e5, 5.9e6])
+    assert_overlap_parity(hip, oracle, sxy * 3000.0 + off, sf, sxy * 3000.0 + off, sf)
+    assert_overlap_parity(hip, oracle, sxy * 3000.0 + off, sf, txy * 3000.0 + off, tf)
+    # a coarser mesh on a subset of the same nodes (every face of it a union of boundary-sharing fine faces is NOT
+    # required: any triangulation of a node subset shares vertices and many edge directions with the fine mesh)
+    from scipy.spatial import Delaunay
+
+    sub = np.sort(np.random.default_rng(3).choice(sxy.shape[0], 4000, replace=False))
+    cf = Delaunay(sxy[sub]).simplices.astype(np.int64)
+    p = sxy[sub]
+    u, v = p[cf[:, 1]] - p[cf[:, 0]], p[cf[:, 2]] - p[cf[:, 0]]
+    cw = (u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]) < 0
+    cf[cw] = cf[cw][:, ::-1]
+    assert_overlap_parity(hip, oracle, sxy, sf, p, cf)   # coarse targets: the big faces' chain
+    assert_overlap_parity(hip, oracle, p, cf, sxy, sf)
+    # degenerate sources: needles (height ~1e-16) and repeated nodes
+    rng = np.random.default_rng(5)
+    nxy = sxy.copy()
+    bad = rng.choice(sf.shape[0], 400, replace=False)
+    f2 = sf.copy()
+    for k, f in enumerate(bad):
+        a, b, c = f2[f]
+        if k % 2 == 0:
+            nxy = np.vstack([nxy, 0.5 * (nxy[a] + nxy[b]) + 1e-13 * (nxy[c] - nxy[a])])
+            f2[f] = [a, b, nxy.shape[0] - 1]
+        else:
+            f2[f] = [a, b, b]
+    assert_overlap_parity(hip, oracle, nxy, f2, txy, tf)
+    assert_overlap_parity(hip, oracle, nxy, f2, sxy, sf)
+
+
+def test_overlap_meshes_sharing_nodes_general_chain(hip, oracle, monkeypatch):
+    """... and through the general kernel chain (XR_OVERLAP_FUSED=0) and a quadrilateral mesh against itself."""
+    monkeypatch.setenv("XR_OVERLAP_FUSED", "0")
+    sxy, sf = meshgen.triangle_mesh(12000, 23)
+    assert_overlap_parity(hip, oracle, sxy, sf, sxy, sf)
+    monkeypatch.delenv("XR_OVERLAP_FUSED")
+    qxy, qf = meshgen.quad_mesh(np.linspace(0.0, 1.0, 71), np.linspace(0.0, 1.0, 53))
+    assert_overlap_parity(hip, oracle, qxy, qf, qxy, qf)
+    assert_overlap_parity(hip, oracle, sxy, sf, qxy, qf)
+    assert_overlap_parity(hip, oracle, qxy, qf, sxy, sf)
+
+
 def test_overlap_graded_mesh_many_levels(hip, oracle):
     """face sizes spanning 4 orders of magnitude -> many grid levels."""
     rng = np.random.default_rng(9)

@@ -73,7 +73,7 @@ static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may t
 // of a byte array of its own: 19.5 instead of 23.5 KB of LDS per block = 8 instead of 6 resident blocks per CU for a
 // kernel that is a chain of dependent loads.
 template <bool PACK>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PACK ? 8 : 4))) // (PACK: 8 blocks per CU -- 64 VGPRs)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
          const int32_t *__restrict__ cell_start,
          const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_off,
@@ -521,6 +521,68 @@ k_search_big(const double *__restrict__ q_bbox, const double *__restrict__ q_fxy
 }
 
 // ---------------------------------------------------------------------------------------------
+// What the reference does with a candidate pair BEFORE it clips (numba_celltree, restated in oracle/xr_oracle.c): the two
+// faces' exact boxes must overlap STRICTLY (boxes_intersect, :530) and the separating-axis test must not separate them
+// (sat_intersect, :757; touching counts as intersecting).  For faces that overlap properly both tests pass and the engine
+// skips them.  They matter where faces merely touch or are degenerate: there the clip returns slivers of 1e-20 ... 1e-36
+// that the reference never computes --
+//   * a mesh against itself (or a mesh sharing its nodes): neighbours across a corner have boxes that touch, not overlap
+//     (23 pairs of 60 394 on a 60k-face Delaunay mesh; the engine's float boxes are supersets and let them through),
+//   * zero-area and needle source faces: the clip of a target by a segment leaves rounding dust the SAT rejects.
+// A pair that fails either test has faces whose interiors are disjoint up to a penetration of a few ulp(coordinate), so the
+// clip's area for it is at most ~1e-15 * |coordinate| * perimeter.  overlap_dust_threshold() bounds that for EVERY pair of
+// the two meshes (largest coordinate x the smaller mesh's largest face extent, with a factor of four to spare); the clip kernels run the two
+// tests -- on the float64 vertices, fetched again -- only for the lanes whose area is positive and below it: a handful
+// per million pairs on unrelated meshes, the touching neighbours on related ones.  The tests' arithmetic is the oracle's
+// (order and orientation of the vertices do not enter: min / max of the same products).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool pair_passes_box_and_sat(const double2 *__restrict__ a, int na, const double2 *__restrict__ b, int nb) {
+    double ax0 = INFINITY, ax1 = -INFINITY, ay0 = INFINITY, ay1 = -INFINITY, bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY;
+    for (int j = 0; j < na; j++) {
+        const double2 q = a[j];
+        ax0 = fmin(ax0, q.x), ax1 = fmax(ax1, q.x), ay0 = fmin(ay0, q.y), ay1 = fmax(ay1, q.y);
+    }
+    for (int j = 0; j < nb; j++) {
+        const double2 q = b[j];
+        bx0 = fmin(bx0, q.x), bx1 = fmax(bx1, q.x), by0 = fmin(by0, q.y), by1 = fmax(by1, q.y);
+    }
+    if (!(ax0 < bx1 && bx0 < ax1 && ay0 < by1 && by0 < ay1)) return false;
+    for (int pass = 0; pass < 2; pass++) {
+        const double2 *p = pass ? b : a;
+        const int np = pass ? nb : na;
+        for (int i = 0; i < np; i++) {
+            const double2 v0 = p[i], v1 = p[i + 1 < np ? i + 1 : 0];
+            const double nx = -(v1.y - v0.y), ny = v1.x - v0.x; // edge normal
+            if (nx == 0 && ny == 0) continue;
+            double amin = INFINITY, amax = -INFINITY, bmin = INFINITY, bmax = -INFINITY;
+            for (int j = 0; j < na; j++) {
+                const double2 q = a[j];
+                const double d = nx * q.x + ny * q.y;
+                amin = d < amin ? d : amin;
+                amax = d > amax ? d : amax;
+            }
+            for (int j = 0; j < nb; j++) {
+                const double2 q = b[j];
+                const double d = nx * q.x + ny * q.y;
+                bmin = d < bmin ? d : bmin;
+                bmax = d > bmax ? d : bmax;
+            }
+            if (amax < bmin || bmax < amin) return false;
+        }
+    }
+    return true;
+}
+// -> the pair's area after the reference's pre-clip tests: unchanged, or 0 for rounding dust of a pair they reject
+__device__ __forceinline__ double confirm_dust(double area, double dust, bool active, const double2 *__restrict__ a, int na,
+                                               const double2 *__restrict__ b, int nb) {
+    const bool suspicious = active && area > 0 && area <= dust;
+    if (__any(suspicious)) {
+        if (suspicious && !pair_passes_box_and_sat(a, na, b, nb)) area = 0.0;
+    }
+    return area;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Sutherland-Hodgman clip + fan area.  LDS: two polygon buffers per thread, [vertex][thread].
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool sh_inside(P2 p, P2 r, P2 U) { return U.x * (p.y - r.y) > U.y * (p.x - r.x); }
@@ -546,7 +608,7 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, cons
        const int32_t *__restrict__ q_perm, const double *__restrict__ s_fxy, const uint8_t *__restrict__ s_len, const int32_t *__restrict__ s_off,
        int s_m, const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
        double *__restrict__ cand_area, bool redo_only, const int32_t *__restrict__ rec_face,
-       int32_t *__restrict__ cand_sid, int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row) {
+       int32_t *__restrict__ cand_sid, int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, double dust) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *sh = reinterpret_cast<double2 *>(smem);
     const int64_t c = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -640,6 +702,7 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, cons
         }
         area = 0.5 * area;
     }
+    if (area > 0 && area <= dust && !pair_passes_box_and_sat(tf, nt, reinterpret_cast<const double2 *>(sf), ns)) area = 0.0;
     cand_area[c] = area;
     } // active
     // per-row survivor counts: candidates of one query face are contiguous, so a wave holds a
@@ -673,7 +736,7 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
              const uint8_t *__restrict__ s_len, const int32_t *__restrict__ s_off, int s_m, const int32_t *__restrict__ cand_tgt,
              const int32_t *__restrict__ cand_src, int64_t n_cand, double *__restrict__ cand_area,
              const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
-             int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
+             int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap, double dust) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *out = reinterpret_cast<double2 *>(smem) + threadIdx.x; // out[j * BLOCK]
     const int64_t n_blocks = (n_cand + BLOCK - 1) / BLOCK;
@@ -785,6 +848,7 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
             }
             area = 0.5 * area;
         }
+        if (area > 0 && area <= dust && !pair_passes_box_and_sat(tf, nt, reinterpret_cast<const double2 *>(sf), ns)) area = 0.0;
         cand_area[c] = area;
     }
     {
@@ -811,7 +875,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__ s_fxy, int s_m,
            const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
            double *__restrict__ cand_area, const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
-           int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
+           int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap, double dust) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (TRI_MAXV + 1); // the lane's TRI_MAXV + 1 slots
     __shared__ uint2 sh_lut[TRI_LUT];
@@ -822,11 +886,11 @@ k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__
     __syncthreads();
     const int64_t c = lb * BLOCK + threadIdx.x;
     const bool active = c < n_cand;
-    int t = -1;
+    int t = -1, s = 0;
     P2 tv[3] = {{0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
     if (active) {
         t = cand_tgt[c];
-        const int s = cand_src[c];
+        s = cand_src[c];
         cand_sid[c] = rec_face[s];
         const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m;
         const double2 *sf = reinterpret_cast<const double2 *>(s_fxy) + (int64_t)s * s_m;
@@ -838,6 +902,8 @@ k_clip_tri(const double *__restrict__ q_fxy, int q_m, const double *__restrict__
         }
     }
     double area = tri_clip_area(tv, sv, col, sh_lut, active);
+    area = confirm_dust(area, dust, active, reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * q_m, 3,
+                        reinterpret_cast<const double2 *>(s_fxy) + (int64_t)s * s_m, 3);
     if (active) {
         if (area == TRI_AREA_OVERFLOW) {
             area = AREA_OVERFLOW;
@@ -870,7 +936,7 @@ __global__ void __launch_bounds__(BLOCK)
 k_clip_quad_tri(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, const double *__restrict__ s_fxy,
                 const int32_t *__restrict__ cand_tgt, const int32_t *__restrict__ cand_src, int64_t n_cand,
                 double *__restrict__ cand_area, const int32_t *__restrict__ rec_face, int32_t *__restrict__ cand_sid,
-                int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap) {
+                int32_t *__restrict__ overflow_count, int32_t *__restrict__ nnz_row, bool remap, double dust) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // (QUAD_MAXV + 2 slots per lane: 144 bytes -- 128 would put the 16-byte accesses of all lanes on the same banks)
     double2 *col = reinterpret_cast<double2 *>(smem) + threadIdx.x * (QUAD_MAXV + 2);
@@ -882,11 +948,11 @@ k_clip_quad_tri(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_
     __syncthreads();
     const int64_t c = lb * BLOCK + threadIdx.x;
     const bool active = c < n_cand;
-    int t = -1, n0 = 3;
+    int t = -1, n0 = 3, s = 0;
     P2 tv[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
     if (active) {
         t = cand_tgt[c];
-        const int s = cand_src[c];
+        s = cand_src[c];
         cand_sid[c] = rec_face[s];
         n0 = q_len[t];
         const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * 4;
@@ -905,6 +971,8 @@ k_clip_quad_tri(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_
         }
     }
     double area = poly_clip_area<QUAD_MAXV, 4>(tv, n0, sv, col, sh_lut, active);
+    area = confirm_dust(area, dust, active, reinterpret_cast<const double2 *>(q_fxy) + (int64_t)t * 4, n0,
+                        reinterpret_cast<const double2 *>(s_fxy) + (int64_t)s * 3, 3);
     if (active) {
         if (area == TRI_AREA_OVERFLOW) {
             area = AREA_OVERFLOW;
@@ -1066,6 +1134,7 @@ static constexpr int BM_WORDS = 32768;          // 128 KiB of bitmap
 static constexpr int BM_BITS = BM_WORDS * 32;   // ids per chunk
 static constexpr int BM_SEG = BM_WORDS / 256;   // words per thread segment
 static constexpr int BM_STAGE = 4096;           // candidates parked in LDS (16 KiB); longer rows re-read HBM
+static constexpr size_t ROW_FILL_LIGHT_LDS = sizeof(int32_t) * (8 + BM_STAGE); // LDS of a k_row_fill_long launch with row_class = 1
 
 __global__ void __launch_bounds__(256)
 k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict__ cand_count,
@@ -1078,14 +1147,18 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
                 const int32_t *__restrict__ scan_nnz = nullptr /* optional: row lengths per FACE; the offsets of the listed rows
                                                                   are then computed here (exclusive scan in list order) */,
                 int32_t *__restrict__ scan_indptr = nullptr /* [n_long + 1], written */,
-                int32_t *__restrict__ scan_total = nullptr /* total entries, written */) {
+                int32_t *__restrict__ scan_total = nullptr /* total entries, written */,
+                int row_class = 0 /* 0: every listed row; 1: only rows of at most ROW_BLOCK candidates -- the launch then needs
+                                     ROW_FILL_LIGHT_LDS bytes of LDS instead of 150 KB, so its blocks find room beside other
+                                     kernels and every row gets a block of its own; 2: only the rows beyond ROW_BLOCK */) {
     __builtin_amdgcn_s_setprio(3); // side-stream kernel: its waves go first in the SIMDs' issue arbitration (see overlap_tri)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *bm = reinterpret_cast<uint32_t *>(smem);          // [BM_WORDS]
-    uint32_t *tbase = bm + BM_WORDS;                            // [256] exclusive over thread segments
-    int32_t *red = reinterpret_cast<int32_t *>(tbase + 256);    // [8] scratch
+    // (scratch and stage first: a row_class = 1 launch allocates nothing behind them)
+    int32_t *red = reinterpret_cast<int32_t *>(smem);           // [8] scratch
     int32_t *stage = red + 8;                                   // [BM_STAGE]
-    uint16_t *gcnt = reinterpret_cast<uint16_t *>(stage + BM_STAGE); // [BM_WORDS / 8] bits per 8 words -> prefix in segment
+    uint32_t *tbase = reinterpret_cast<uint32_t *>(stage + BM_STAGE); // [256] exclusive over thread segments
+    uint32_t *bm = tbase + 256;                                 // [BM_WORDS]
+    uint16_t *gcnt = reinterpret_cast<uint16_t *>(bm + BM_WORDS); // [BM_WORDS / 8] bits per 8 words -> prefix in segment
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (skip_if && *skip_if > 0) return;
     const int nl = *n_long;
@@ -1129,6 +1202,7 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
             base = row_base >= 0 ? indptr[row_base + li] : indptr[t];
         }
         __syncthreads();
+        if (row_class != 0 && (row_class == 1) != (n <= ROW_BLOCK)) continue; // (uniform) the other launch's row
         // park the row: survivor id or -1 (four independent pairs of loads per thread and trip)
         for (int i0 = tid; i0 < n && i0 < BM_STAGE; i0 += 4 * 256) {
             double a[4];
@@ -1249,6 +1323,24 @@ static int xcd_remap_mask() {
 }
 static unsigned xcd_grid(int64_t n_blocks, bool remap) { return (unsigned)(remap ? (n_blocks + 7) / 8 * 8 : n_blocks); }
 
+// Upper bound, for every pair of faces of the two meshes, of the area the clip can return for a pair the reference's pre-clip
+// tests reject (pair_passes_box_and_sat).  Such a pair's true intersection is at most ~3 ulp(coordinate) deep (the SAT's
+// projections) and the clip's crossing points are off by a few ulp(coordinate) more: a sliver of width <= ~8 eps |coordinate|
+// along at most half the perimeter of the smaller face.  With perimeter <= 4 extents: 16 eps M ext; the threshold is four
+// times that (64 eps = 1.4e-14), M the largest coordinate magnitude, ext the smaller of the two meshes' largest face extents
+// (both statistics are on the host when the clip is launched; a sampled tree statistic is bounded by the domain).  The
+// smaller the threshold the fewer lanes fetch their vertices again: on the 1M benchmark 1e-12 M ext cost the clip 7 us.
+static double overlap_dust_threshold(const xr_mesh *tree, const xr_mesh *query) {
+    double mag = 0.0, ext = INFINITY;
+    for (const xr_mesh *m : {tree, query}) {
+        const double *h = m->h_stats;
+        mag = std::max(mag, std::max(std::max(fabs(h[0]), fabs(h[1])), std::max(fabs(h[2]), fabs(h[3]))));
+        ext = std::min(ext, m->stats_sampled ? std::max(h[1] - h[0], h[3] - h[2]) : h[5]);
+    }
+    static const bool off = getenv("XR_DUST") && atoi(getenv("XR_DUST")) == 0; // (measurement switch: no confirmation)
+    return off ? 0.0 : 5.7e-14 * mag * ext;
+}
+
 template <int MAXV, int BLOCK>
 static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
                         int64_t C, double *cand_area, bool redo_only, int32_t *cand_sid, int32_t *overflow_count,
@@ -1263,7 +1355,7 @@ static void launch_clip(const xr_mesh *tree, const xr_mesh *query, const int32_t
     XR_LAUNCH(MAXV == 8 ? "clip_v8" : (MAXV == 16 ? "clip_v16" : "clip_v64"), (k_clip<MAXV, BLOCK>),
               dim3(div_up(C, BLOCK)), dim3(BLOCK), shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m,
               query->qo_perm(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area,
-              redo_only, tree->rec_face.get(), cand_sid, overflow_count, nnz_row);
+              redo_only, tree->rec_face.get(), cand_sid, overflow_count, nnz_row, overlap_dust_threshold(tree, query));
 }
 
 static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int32_t *cand_tgt, const int32_t *cand_src,
@@ -1271,6 +1363,7 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
                             int32_t *nnz_row) {
     const int vmax = query->m + tree->m;
     const bool remap = xcd_remap_mask() & 1;
+    const double dust = overlap_dust_threshold(tree, query);
     if (vmax <= 6) {
         // triangle x triangle: the clipped polygon never has more than 6 vertices
         constexpr int MAXV = 6, BLOCK = 256;
@@ -1280,25 +1373,25 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
             XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
                       shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                       tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
-                      overflow_count, nnz_row, remap);
+                      overflow_count, nnz_row, remap, dust);
         else
             XR_LAUNCH("clip_tri", (k_clip_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
                       query->qo_fxy(), query->m, tree->rec_fxy.get(), tree->m, cand_tgt, cand_src, C, cand_area,
-                      tree->rec_face.get(), cand_sid, overflow_count, nnz_row, remap);
+                      tree->rec_face.get(), cand_sid, overflow_count, nnz_row, remap, dust);
     } else if (query->m == 4 && tree->m == 3 && !(getenv("XR_CLIP_QUAD") && atoi(getenv("XR_CLIP_QUAD")) == 0)) {
         // quadrilateral targets (a raster) x triangle source (XR_CLIP_QUAD=0: the slot-loop kernel, A/B switch)
         constexpr int BLOCK = 256;
         const size_t shmem = (size_t)(QUAD_MAXV + 2) * BLOCK * sizeof(double2);
         XR_LAUNCH("clip_quad_tri", (k_clip_quad_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
                   query->qo_fxy(), query->qo_len(), tree->rec_fxy.get(), cand_tgt, cand_src, C, cand_area, tree->rec_face.get(),
-                  cand_sid, overflow_count, nnz_row, remap);
+                  cand_sid, overflow_count, nnz_row, remap, dust);
     } else if (vmax <= 8) {
         constexpr int MAXV = 8, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
         XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, false>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
                   shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m, query->qo_perm(), tree->rec_fxy.get(),
                   tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
-                  overflow_count, nnz_row, remap);
+                  overflow_count, nnz_row, remap, dust);
     }
     else if (vmax <= 16) launch_clip<16, 128>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
     else launch_clip<64, 64>(tree, query, cand_tgt, cand_src, C, cand_area, false, cand_sid, overflow_count, nnz_row);
@@ -1367,6 +1460,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     const int big_grid = engine().num_cu * 8;
     constexpr int CLIP_BLOCK = 256;
     const size_t clip_shmem = (size_t)(TRI_MAXV + 1) * CLIP_BLOCK * sizeof(double2);
+    const double dust = overlap_dust_threshold(tree, query);
     const size_t fill_shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1415,13 +1509,30 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
             XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
-                      big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3);
+                      big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3, (int32_t *)nullptr,
+                      (int32_t *)nullptr, dust);
             // (rows in face order: ranked inside search_big; their offsets: scanned inside row_fill_long -- two launches less
             // in what is the critical path of the whole weight build)
-            XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
-                      cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
-                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
-                      nnz_row.get(), big_indptr.get(), &fc->p_big);
+            // Two launches: the rows of at most ROW_BLOCK candidates (all but a handful) with 16 KB of LDS per block -- a block
+            // per row, resident beside the clip and the assembly -- and the few longer ones with the bitmap (150 KB, a CU per
+            // block).  As ONE launch every block needed a whole CU: it could not start before the clip's blocks had left and
+            // then walked ~5 rows in turn -- 54-64 us, ending after the assembly (round-4 timeline).  XR_ROWFILL_SPLIT=0: one launch.
+            static const bool fill_split = !(getenv("XR_ROWFILL_SPLIT") && atoi(getenv("XR_ROWFILL_SPLIT")) == 0);
+            if (fill_split) {
+                XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu * 6), dim3(256), ROW_FILL_LIGHT_LDS, cand_off.get(),
+                          cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
+                          tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
+                          nnz_row.get(), big_indptr.get(), &fc->p_big, 1);
+                XR_LAUNCH("row_fill_huge", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
+                          cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
+                          tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
+                          nnz_row.get(), big_indptr.get(), &fc->p_big, 2);
+            } else {
+                XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
+                          cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
+                          tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
+                          nnz_row.get(), big_indptr.get(), &fc->p_big);
+            }
         }
         // Persistent blocks per CU: five fill the LDS and the register files (best for the clip alone).  The big faces' chain
         // on the side stream then gets few wave slots while the clip runs; with its kernels at raised wave priority and only
@@ -1434,17 +1545,17 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, true>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr);
+                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr, dust);
         else if (scan_bases)
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, false>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr);
+                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr, dust);
         else
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 0>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, (int32_t *)nullptr);
+                      (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, dust);
         if (scan_mode == 1)
             XR_LAUNCH("assemble_scan", k_assemble_scan, dim3(1), dim3(1024), 0, blk_rows, blk_surv, (int64_t)n_blocks, (int)grid,
                       remap, blk_base.get(), blk_base.get() + grid, fc, csr->indptr.get());

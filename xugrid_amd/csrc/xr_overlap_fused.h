@@ -156,7 +156,8 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
                  int32_t *__restrict__ blk_surv = nullptr /* optional: survivors per BLOCK of 256 target faces (k_assemble_scan) */,
                  int32_t *__restrict__ wave_surv = nullptr /* COUNT == 1: survivors per 64-pair stretch; the output is then
                  COMPACTED: the survivors of stretch w are written to the front of the stretch, IN PLACE over the queue --
-                 (target face, caller's source id, area) in cand_tgt / cand_src / cand_area at w * 64 + rank */) {
+                 (target face, caller's source id, area) in cand_tgt / cand_src / cand_area at w * 64 + rank */,
+                 double dust = 0.0 /* areas up to this are confirmed by the reference's pre-clip tests (xr_overlap.hip: confirm_dust) */) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CS = SOA ? BLOCK : 1;
     double2 *col = reinterpret_cast<double2 *>(smem) + (SOA ? threadIdx.x : threadIdx.x * (TRI_MAXV + 1)); // the lane's TRI_MAXV + 1 slots
@@ -209,7 +210,14 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
             sid = rec_face[n_s];
         }
         load_idx(slot + stride, n_tq, n_s);
-        const double area = tri_clip_area<CS>(tv, sv, col, sh_lut, active);
+        // (rounding dust of a pair the reference's pre-clip tests reject: the few lanes concerned fetch their vertices again)
+        double area = tri_clip_area<CS>(tv, sv, col, sh_lut, active);
+        {
+            const bool suspicious = active && area > 0 && area <= dust;
+            if (__any(suspicious)) {
+                if (suspicious && !pair_passes_box_and_sat(tfx + (int64_t)cur_tq * 3, 3, sfx + (int64_t)cand_src[c] * 3, 3)) area = 0.0;
+            }
+        }
         const int tq_now = active ? cur_tq : -1;
         if (COUNT == 1 && wave_surv) {
             // Only the pairs that survive (60 % on the benchmark) are written, packed at the front of the wave's own
