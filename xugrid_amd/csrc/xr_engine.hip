@@ -590,6 +590,38 @@ bool poll_pinned_f64(const volatile double *word, double expected) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// host stamps (XR_HOST_STAMPS=1)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct HostStamps {
+    bool on = getenv("XR_HOST_STAMPS") && atoi(getenv("XR_HOST_STAMPS")) != 0;
+    std::chrono::steady_clock::time_point last[16];
+    bool seen[16] = {};
+    double sum_us[16][16] = {}; // [from][to] accumulated interval from the latest stamp of `from` to a stamp of `to`
+    long n[16][16] = {};
+    int prev = -1;
+    ~HostStamps() {
+        if (!on) return;
+        for (int a = 0; a < 16; a++)
+            for (int b = 0; b < 16; b++)
+                if (n[a][b] > 20) fprintf(stderr, "[host stamps] %d -> %d: %.2f us (n = %ld)\n", a, b, sum_us[a][b] / n[a][b], n[a][b]);
+    }
+};
+HostStamps g_stamps;
+} // namespace
+void host_stamp(int point) {
+    if (!g_stamps.on) return;
+    const auto now = std::chrono::steady_clock::now();
+    if (g_stamps.prev >= 0) {
+        const int a = g_stamps.prev;
+        g_stamps.sum_us[a][point] += std::chrono::duration<double, std::micro>(now - g_stamps.last[a]).count();
+        g_stamps.n[a][point]++;
+    }
+    g_stamps.last[point] = now;
+    g_stamps.prev = point;
+}
+
+// ---------------------------------------------------------------------------------------------
 // kernel timing
 // ---------------------------------------------------------------------------------------------
 struct ProfRec {

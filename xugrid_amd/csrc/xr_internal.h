@@ -173,6 +173,9 @@ void zero_scratch_done(int slot);
 void h2d(void *dst, const void *src, size_t bytes);       // synchronous w.r.t. the host
 void d2h(void *dst, const void *src, size_t bytes);       // stream-ordered, then synchronised
 void stream_sync();
+// XR_HOST_STAMPS=1: wall-clock stamps at a few points of the host path, averaged per point and printed at exit (where the
+// host's time goes between the mailbox of one weight build and the first kernel of the next -- profiles/r04_host_stamps.txt)
+void host_stamp(int point);
 void dev_call_done(); // end of a *_dev entry point: stream_sync() unless the caller shares the engine's stream
 // before a handle's blocks go back to the pool: wait for the device -- unless the engine runs asynchronously on its one
 // own stream (xr_set_async), where the pool's stream-ordered reuse already orders every later user behind the last one

@@ -72,8 +72,8 @@ static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may t
 // PACK: the owning thread of a parked candidate rides in the top 8 bits of the record id (trees of at most 2^24 faces) instead
 // of a byte array of its own: 19.5 instead of 23.5 KB of LDS per block = 8 instead of 6 resident blocks per CU for a
 // kernel that is a chain of dependent loads.
-template <bool PACK>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PACK ? 8 : 4))) // (PACK: 8 blocks per CU -- 64 VGPRs)
+template <bool PACK, int WALK_LOADS = 4>
+__global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
          const int32_t *__restrict__ cell_start,
          const float *__restrict__ rec_bb, int32_t *__restrict__ cand_count, int32_t *__restrict__ cand_off,
@@ -193,27 +193,22 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
                     visited += r1[k] - r0[k];
                     if (visited > BIG_VISITS) big = true;
                     if (!big) {
-                        for (int r = r0[k]; r < r1[k]; r += 4) {
-                            // four independent 16-byte loads in flight per step
+                        for (int r = r0[k]; r < r1[k]; r += WALK_LOADS) {
+                            // WALK_LOADS independent 16-byte loads in flight per step (8: the walk is a chain of dependent
+                            // round trips -- 12 records per grid row on the benchmark pair, i.e. three steps of four -- and
+                            // one wave per SIMD less (72 registers) buys two steps less per row)
                             const int last = r1[k] - 1;
-                            const float4 b0 = rbb[r];
-                            const float4 b1 = rbb[r + 1 <= last ? r + 1 : last];
-                            const float4 b2 = rbb[r + 2 <= last ? r + 2 : last];
-                            const float4 b3 = rbb[r + 3 <= last ? r + 3 : last];
+                            float4 bx[WALK_LOADS];
+#pragma unroll
+                            for (int u = 0; u < WALK_LOADS; u++) bx[u] = rbb[r + u <= last ? r + u : last];
                             // branch-free parking: the slot is written unconditionally and only kept (count
                             // advances) on a hit; beyond SLOTS everything lands in a trash row
-                            const bool h0 = box_gap(b0, qx0, qx1, qy0, qy1) < 0.0f;
-                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r;
-                            count += h0 ? 1 : 0;
-                            const bool h1 = fmaxf(box_gap(b1, qx0, qx1, qy0, qy1), r + 1 <= last ? -INFINITY : 1.0f) < 0.0f;
-                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 1;
-                            count += h1 ? 1 : 0;
-                            const bool h2 = fmaxf(box_gap(b2, qx0, qx1, qy0, qy1), r + 2 <= last ? -INFINITY : 1.0f) < 0.0f;
-                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 2;
-                            count += h2 ? 1 : 0;
-                            const bool h3 = fmaxf(box_gap(b3, qx0, qx1, qy0, qy1), r + 3 <= last ? -INFINITY : 1.0f) < 0.0f;
-                            sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + 3;
-                            count += h3 ? 1 : 0;
+#pragma unroll
+                            for (int u = 0; u < WALK_LOADS; u++) {
+                                const bool h = fmaxf(box_gap(bx[u], qx0, qx1, qy0, qy1), r + u <= last ? -INFINITY : 1.0f) < 0.0f;
+                                sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + u;
+                                count += h ? 1 : 0;
+                            }
                         }
                     }
                 }
@@ -1488,7 +1483,18 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl_head + 8);
         if (!scan_bases) XR_HIP(hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)grid, st)); // (look-back words: XR_ASSEMBLE_SCAN=0 only)
         static const bool pack_ok = !(getenv("XR_SEARCH_PACK") && atoi(getenv("XR_SEARCH_PACK")) == 0); // (A/B switch)
-        if (pack_ok && tree->n_face <= ((int64_t)1 << 24))
+        static const int walk_loads = getenv("XR_WALK_LOADS") ? atoi(getenv("XR_WALK_LOADS")) : 4; // (A/B switch)
+        if (pack_ok && walk_loads == 8 && tree->n_face <= ((int64_t)1 << 24))
+            XR_LAUNCH("search", (k_search<true, 8>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
+                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
+                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
+                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
+        else if (pack_ok && walk_loads == 6 && tree->n_face <= ((int64_t)1 << 24))
+            XR_LAUNCH("search", (k_search<true, 6>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
+                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
+                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
+                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
+        else if (pack_ok && tree->n_face <= ((int64_t)1 << 24))
             XR_LAUNCH("search", k_search<true>, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
                       tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
                       block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
@@ -1580,6 +1586,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                   big_indices.get(), big_data.get(), T, query->qo_perm(), query->qo_bbox(), tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, csr->indptr.get(), csr->indices.get(),
                   csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, ctl_head + 3);
+        host_stamp(5);
         const int32_t seq = mailbox_next_seq();
         XR_LAUNCH("publish", k_publish_all, dim3(1), dim3(64), 0, ctl_head, fc, csr->n_long.get(), mail, seq, cap, big_capacity);
         if (ctl_cached) zero_scratch_done(1); // (the counters are zero again behind k_publish_all)
@@ -1593,7 +1600,9 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             early->fn(csr);
             csr->apply_gated = false;
         }
+        host_stamp(6);
         mailbox_wait_seq(seq);
+        host_stamp(7);
         const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], n_pending = mail[3], big_overflow = mail[4];
         const int32_t err = mail[5], rows_regular = mail[6], p_regular = mail[8], p_big = mail[9];
         XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
@@ -1628,9 +1637,13 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
     // query mesh, which is what the host waits behind anyway (XR_STATS_INLINE=1: in line, measurement hook)
     static const bool stats_inline = getenv("XR_STATS_INLINE") && atoi(getenv("XR_STATS_INLINE")) != 0;
     mesh_prepare(tree, false, /*stats_on_side=*/!stats_inline, /*allow_sampled=*/true); // (bounds exact, mean extent sampled)
+    host_stamp(1);
     mesh_prepare(query, true, /*stats_on_side=*/true); // (its statistics are first read by mesh_query_order below)
+    host_stamp(2);
     mesh_build_index(tree);
+    host_stamp(3);
     mesh_query_order(query);
+    host_stamp(4);
     const double *tree_area = relative ? mesh_area(tree) : nullptr;
     const int64_t T = query->n_face, S = tree->n_face;
     XR_REQUIRE(T < ((int64_t)1 << 31) - 1, XR_ERR_LIMIT, "too many query faces for int32 row offsets");
@@ -1824,6 +1837,7 @@ int xr_overlap_apply_dev(xr_mesh *tree, xr_mesh *query, int relative, int method
     XR_REQUIRE(K >= 0 && (source_dev || tree->n_face == 0 || K == 0) && (out_dev || query->n_face == 0 || K == 0), XR_ERR_INVALID,
                "xr_overlap_apply_dev: NULL data argument");
     XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", source_dtype);
+    host_stamp(0);
     xr_csr *csr = new xr_csr();
     try {
         EarlyApply early;
@@ -1833,8 +1847,10 @@ int xr_overlap_apply_dev(xr_mesh *tree, xr_mesh *query, int relative, int method
         const bool can_early = !early_off && K == 1 && method != XR_MODE && method != XR_PERCENTILE &&
                                !(getenv("XR_APPLY_K1") && !strcmp(getenv("XR_APPLY_K1"), "block"));
         overlap(tree, query, relative != 0, csr, can_early ? &early : nullptr);
+        host_stamp(8);
         if (!early.done && K > 0) csr_apply_dev(csr, method, percentile, source_dev, source_dtype, K, out_dev);
         dev_call_done(); // (xr_set_async(1): returns with the apply in flight)
+        host_stamp(9);
     } catch (...) {
         stream_sync();
         delete csr;
