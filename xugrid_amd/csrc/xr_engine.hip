@@ -424,6 +424,14 @@ struct HostPool {
     }
     void run(size_t total, size_t align, const std::function<void(size_t, size_t)> &f) {
         if (total == 0) return;
+        // (not re-entrant: a fill callback that called back into the pool would wait for the mutex it runs under)
+        static thread_local bool inside = false;
+        XR_REQUIRE(!inside, XR_ERR_INVALID, "host thread pool re-entered from one of its own jobs");
+        struct Flag {
+            bool &f;
+            explicit Flag(bool &b) : f(b) { f = true; }
+            ~Flag() { f = false; }
+        } flag(inside);
         std::lock_guard<std::mutex> job(job_mutex);
         size_t p = (total + STAGE_THREADS - 1) / STAGE_THREADS;
         p = (p + align - 1) / align * align;
@@ -512,8 +520,11 @@ void d2h_big(void *dst, const void *src, size_t bytes) {
     if (!piece_ev[0])
         for (int i = 0; i < D2H_DEPTH; i++) XR_HIP(hipEventCreateWithFlags(&piece_ev[i], hipEventDisableTiming));
     hipStream_t st = launch_stream();
-    // (the staging buffers may still be read by un-awaited uploads of h2d_staged: same stream, so the DMAs below are
-    // ordered behind them)
+    // The staging buffers may still be read by un-awaited uploads of h2d_staged.  On the same stream the DMAs below are
+    // ordered behind them; should the two calls ever run on different streams (a side scope or a stream override around
+    // one of them) only the events say so: the stream waits for both before the first piece is written.
+    for (int i = 0; i < 2; i++)
+        if (sl.stage_ev[i]) XR_HIP(hipStreamWaitEvent(st, sl.stage_ev[i], 0));
     const size_t UP_PIECE = up_piece(bytes), per_buf = STAGE_BYTES / UP_PIECE; // (16 or 4 pieces per buffer: 8 slots fit)
     const size_t n_piece = (bytes + UP_PIECE - 1) / UP_PIECE;
     auto piece_bytes = [&](size_t k) { return std::min(UP_PIECE, bytes - k * UP_PIECE); };

@@ -835,7 +835,7 @@ static void spatial_sort(xr_mesh *mesh, const GridParams &g, const MortonParams 
 
 void mesh_query_order(xr_mesh *mesh) {
     if (mesh->query_ready) return;
-    mesh_read_stats(mesh);
+    mesh_read_stats(mesh, /*need_exact=*/true); // (the ordering heuristic reads sums over ALL faces: sampled statistics are redone)
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
     // coherent numbering (consecutive faces are, on average, within a few face extents of each

@@ -129,6 +129,13 @@ class Ugrid2d:
             self._celltree = CellTree2d(self.node_coordinates, self.face_node_connectivity, FILL_VALUE)
         return self._celltree
 
+    def drop_device_caches(self):
+        """Release what this grid keeps in HBM beyond its mesh: the celltree index and the cached centroidal Voronoi
+        tessellation of the barycentric path (mesh, prepared arrays and index: several times ``n_face`` worth of memory that
+        the engine's pool cannot reclaim while the grid is alive).  The next regridder on this grid rebuilds them."""
+        self._celltree = None
+        self._voronoi_device_cache = None
+
     @property
     def device_mesh(self):
         return self.celltree.device_mesh
