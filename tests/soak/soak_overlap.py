@@ -9,6 +9,9 @@ from xugrid_amd import engine as E, meshgen
 from oracle import oracle as O
 
 
+RELATED = float(os.environ.get("XR_SOAK_RELATED", "0.35"))  # share of iterations with a target derived from the source
+
+
 def run(seed0, n_iter):
     E.init(0)
     def same(a, b): return ((a == b) | (np.isnan(a) & np.isnan(b)))
@@ -36,16 +39,48 @@ def run(seed0, n_iter):
                 v = f[r][f[r] >= 0][::-1]; g[r, :v.size] = v
             f = g
         return xy, f
+    def derive(rng, sxy, sf):
+        """a target RELATED to the source: the mesh itself, a re-triangulation of (a subset of) its nodes, a refinement
+        (every face fanned around its centroid), or a copy shifted by one node-to-node vector (coincident edges)"""
+        how = int(rng.integers(4))
+        tri = sf.shape[1] == 3 or (sf[:, 3:] < 0).all()
+        if how == 0 or not tri and how in (1, 2):
+            return sxy.copy(), sf.copy()
+        f3 = sf[:, :3]
+        if how == 1:
+            from scipy.spatial import Delaunay
+            keep = np.sort(rng.choice(sxy.shape[0], max(8, int(sxy.shape[0] * rng.uniform(0.2, 1.0))), replace=False))
+            p = sxy[keep]
+            t = Delaunay(p).simplices.astype(np.int64)
+            u, v = p[t[:, 1]] - p[t[:, 0]], p[t[:, 2]] - p[t[:, 0]]
+            cw = (u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]) < 0
+            t[cw] = t[cw][:, ::-1]
+            return p, t
+        if how == 2:
+            c = sxy[f3].mean(axis=1)
+            n0 = sxy.shape[0]
+            ids = n0 + np.arange(f3.shape[0])
+            t = np.vstack([np.column_stack([f3[:, 0], f3[:, 1], ids]), np.column_stack([f3[:, 1], f3[:, 2], ids]),
+                           np.column_stack([f3[:, 2], f3[:, 0], ids])])
+            return np.vstack([sxy, c]), t
+        a, b = rng.choice(sxy.shape[0], 2, replace=False)
+        return sxy + (sxy[b] - sxy[a]), sf.copy()
+
     bad = 0
     t_start = time.time()
     for it in range(n_iter):
         rng = np.random.default_rng(seed0 * 100003 + it)
         ns, nt = int(10 ** rng.uniform(1.5, 4.6)), int(10 ** rng.uniform(1.0, 4.6))
         sxy, sf = make(rng, int(rng.integers(3)), ns)
-        txy, tf = make(rng, int(rng.integers(3)), nt)
+        related = rng.random() < RELATED  # the target shares nodes / edges with the source: faces that TOUCH (round 4)
+        if related:
+            txy, tf = derive(rng, sxy, sf)
+        else:
+            txy, tf = make(rng, int(rng.integers(3)), nt)
         off = rng.uniform(-1, 1, 2) * 10.0 ** rng.uniform(-2, 6) * float(rng.random() < 0.3)
         rel = bool(rng.integers(2))
-        txy = txy * rng.uniform(0.3, 1.5) + rng.uniform(-0.2, 0.2, 2)
+        if not related:
+            txy = txy * rng.uniform(0.3, 1.5) + rng.uniform(-0.2, 0.2, 2)
         sxy, txy = sxy + off, txy + off
         try:
             tree = O.CellTree2d(sxy, sf, -1)
@@ -71,6 +106,11 @@ def run(seed0, n_iter):
                         break
             if ok:
                 pts = np.column_stack([rng.uniform(sxy[:, 0].min(), sxy[:, 0].max(), 3000), rng.uniform(sxy[:, 1].min(), sxy[:, 1].max(), 3000)])
+                if related:  # points ON nodes and on the midpoints of sides: the tie between the faces sharing them
+                    nodes = sxy[rng.choice(sxy.shape[0], min(1500, sxy.shape[0]), replace=False)]
+                    fa = sf[rng.choice(sf.shape[0], min(1500, sf.shape[0]), replace=False)]
+                    mids = 0.5 * (sxy[fa[:, 0]] + sxy[fa[:, 1]])
+                    pts = np.vstack([pts, nodes, mids])
                 if not np.array_equal(ms.locate_points(pts), tree.locate_points(pts)): ok = False; msg = "locate"
                 else:
                     fg, wg = ms.compute_barycentric_weights(pts); fo, wo = tree.compute_barycentric_weights(pts)
