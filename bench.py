@@ -281,7 +281,9 @@ def run_single(args):
     build_ms = 1e3 * (time.perf_counter() - t0) / args.steps
     host_times = []
     hs = ht = h_out = None
-    for _ in range(6):
+    # (--step-only: the passes from host arrays are skipped -- their freshly uploaded meshes meet cold caches, and a profiler's
+    # per-kernel AVERAGE over the whole process would mix those launches with the timed step's: profiles/collect.sh)
+    for _ in range(0 if args.step_only else 6):
         del hs, ht, h_out  # (the previous iteration's handles are released OUTSIDE the timed region)
         E.dev_sync()
         t0 = time.perf_counter()
@@ -289,7 +291,7 @@ def run_single(args):
         h_out = hs.overlap(ht).apply(data[None, :], 0)
         host_times.append(time.perf_counter() - t0)
     del hs, ht, h_out
-    host_to_host_ms = 1e3 * float(np.median(host_times[1:]))  # (the first pass warms the pinned staging path)
+    host_to_host_ms = 1e3 * float(np.median(host_times[1:])) if host_times else None  # (the first pass warms the pinned staging path)
     # ... and through the PUBLIC API, as a user of the reference would write it (regridder.py:505-512, :212-262):
     # OverlapRegridder(Ugrid2d(...), Ugrid2d(...), "mean").regrid(data) from host arrays to a host result -- everything the
     # Python layer adds (constructor checks, grid wrappers, result allocation) is inside.  Median of 5 after one warm-up,
@@ -315,14 +317,14 @@ def run_single(args):
         return t[-1] - t[0], (src_g, tgt_g, rg, res)
 
     api_times, keep = [], None
-    for _ in range(6):
+    for _ in range(0 if args.step_only else 6):
         del keep
         E.dev_sync()
         dt, keep = api_once()
         api_times.append(dt)
-    api_ms = 1e3 * float(np.median(api_times[1:]))
+    api_ms = 1e3 * float(np.median(api_times[1:])) if api_times else None
     api_split = {}
-    for _ in range(3):
+    for _ in range(0 if args.step_only else 3):
         del keep
         E.dev_sync()
         _, keep = api_once(api_split)
@@ -1248,6 +1250,8 @@ def main():
     ap.add_argument("--no-delaunay", action="store_true", help="lattice-split triangulation instead of qhull")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the informative extras (configs 3 and 5, structured pair)")
+    ap.add_argument("--step-only", action="store_true", help="skip the passes from host arrays (host_to_host_ms, api_ms): "
+                    "every launch of the process then belongs to the step's loops (profiler runs)")
     ap.add_argument("--partition", default="balanced", choices=["balanced", "morton", "hash"],
                     help="source shards: Morton blocks of equal estimated work (default) / equal face counts, or id mod N")
     ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],

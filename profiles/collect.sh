@@ -13,7 +13,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu --no-extras $*"
+BENCH="python $ROOT/bench.py --no-cpu --no-extras --step-only $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH --steps 10 > "$OUT/bench_under_rocprof.json" 2> "$OUT/stats.log"
 cp "$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)" "$OUT/kernel_stats.csv" 2>/dev/null
 for SET in "FETCH_SIZE" "WRITE_SIZE" \
