@@ -916,7 +916,7 @@ void mesh_build_index(xr_mesh *mesh) {
     mesh->grid = g;
 
     mesh->cell_start.alloc((size_t)total + 1);
-    mesh->rec_bb.alloc((size_t)F * 4);
+    mesh->rec_bb.alloc((size_t)F * 4 + 4 * 8); // (+ 8 records of padding: k_search reads up to WALK_LOADS - 1 records past a run, masked)
     mesh->rec_face.alloc((size_t)F);
     if (!mesh->ragged()) mesh->rec_fxy.alloc((size_t)F * m * 2);
     mesh->rec_len.alloc((size_t)F);

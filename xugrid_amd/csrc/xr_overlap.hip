@@ -66,13 +66,14 @@ __device__ __forceinline__ int64_t xcd_block(int64_t n_blocks, bool remap) {
 // concatenated); when that tail is short (<= BIGREC_MAX) every block filters it against its own bounding box once
 // (coalesced) and its faces test the few survivors from LDS, instead of every face walking 5-6 all but empty levels:
 // the dependent cell_start -> record round trips of those levels were most of the search time.
+static constexpr int WALK_PAD = 8;       // records of padding behind rec_bb (xr_mesh.hip allocates them): the walk's unclamped loads
 static constexpr int BIGREC_MAX = 1024;  // records of the upper grid levels handled as a list
 static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may touch one block's bounding box
 
 // PACK: the owning thread of a parked candidate rides in the top 8 bits of the record id (trees of at most 2^24 faces) instead
 // of a byte array of its own: 19.5 instead of 23.5 KB of LDS per block = 8 instead of 6 resident blocks per CU for a
 // kernel that is a chain of dependent loads.
-template <bool PACK, int WALK_LOADS = 4>
+template <bool PACK, int WALK_LOADS = 4, bool COOP_OFF = false>
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
          const int32_t *__restrict__ cell_start,
@@ -114,8 +115,19 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
         qx0 = f32_below(bb.x - g.x0), qx1 = f32_above(bb.y - g.x0);
         qy0 = f32_below(bb.z - g.y0), qy1 = f32_above(bb.w - g.y0);
     }
+    // Sparse levels in between (round 4): from the lowest level on whose tail holds at most 1/64 of the records (the 1M benchmark:
+    // levels 2-4, 0.6 % of the records, ~0.05 per face -- but every face paid their cell bounds: three of its ~15 dependent
+    // round trips and 11 % of its instructions), the levels [l_coop, l_split) are walked ONCE PER BLOCK: thread i takes grid
+    // row i of the block's box on one of those levels, and the records that touch the box join the LDS list below.
+    int l_coop = l_split;
+    for (int l = l_split - 1; l >= 1; l--) {
+        const int first = cell_start[g.base[l]];
+        if (((int64_t)big0 - first) * 64 > n_tree) break;
+        l_coop = l;
+    }
+    if (COOP_OFF) l_coop = l_split;
     if (threadIdx.x == 0) sh_nbig = 0;
-    if (big0 < (int)n_tree) {
+    if (big0 < (int)n_tree || l_coop < l_split) {
         // the block's bounding box, then one coalesced pass over the big records
         float bx0 = qx0, bx1 = qx1, by0 = qy0, by1 = qy1;
 #pragma unroll
@@ -145,9 +157,42 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
                 }
             }
         }
+        if (l_coop < l_split) {
+            // level-0 cells of the box's corners (the float box is a superset of every face's box; same monotone cell function
+            // and the same shifts as the per-thread walk below)
+            const int bcx0 = cell_coord((double)bx0 + g.x0, g.x0, g.inv_h0, g.nx[0]), bcx1 = cell_coord((double)bx1 + g.x0, g.x0, g.inv_h0, g.nx[0]);
+            const int bcy0 = cell_coord((double)by0 + g.y0, g.y0, g.inv_h0, g.ny[0]), bcy1 = cell_coord((double)by1 + g.y0, g.y0, g.inv_h0, g.ny[0]);
+            int n_items = 0;
+            for (int l = l_coop; l < l_split; l++) n_items += (bcy1 >> (l * LEVEL_SHIFT)) - max((bcy0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
+            if (n_items > 256) {
+                l_coop = l_split; // (a block spanning too many grid rows: its faces walk these levels themselves)
+            } else if ((int)threadIdx.x < n_items) {
+                int it = threadIdx.x, l = l_coop;
+                for (;; l++) {
+                    const int rows = (bcy1 >> (l * LEVEL_SHIFT)) - max((bcy0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
+                    if (it < rows) break;
+                    it -= rows;
+                }
+                const int sh = l * LEVEL_SHIFT, nx = g.nx[l], base = g.base[l];
+                const int cy = max((bcy0 >> sh) - 1, 0) + it;
+                const int cx0 = max((bcx0 >> sh) - 1, 0), cx1 = bcx1 >> sh;
+                const int r0 = cell_start[base + cy * nx + cx0], r1 = cell_start[base + cy * nx + cx1 + 1];
+                for (int r = r0; r < r1; r++) {
+                    const float4 rb = rbb[r];
+                    if (rec_hit(rb, bx0, bx1, by0, by1)) {
+                        const int k = atomicAdd(&sh_nbig, 1);
+                        if (k < BIGREC_BLOCK) {
+                            sh_bigrec[k] = r;
+                            sh_bigbb[k] = rb;
+                        }
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (sh_nbig > BIGREC_BLOCK) { // too many for the list: this block walks every level
             l_split = g.n_levels;
+            l_coop = l_split;
             __syncthreads();
             if (threadIdx.x == 0) sh_nbig = 0;
         }
@@ -171,10 +216,10 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
         const int c_x0 = cell_coord(bb.x, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(bb.y, g.x0, g.inv_h0, g.nx[0]);
         const int c_y0 = cell_coord(bb.z, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(bb.w, g.y0, g.inv_h0, g.ny[0]);
         int visited = 0, n_rows = 0;
-        for (int l = 0; l < l_split; l++)
+        for (int l = 0; l < l_coop; l++)
             n_rows += (c_y1 >> (l * LEVEL_SHIFT)) - max((c_y0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
-        big = n_rows > 8 * l_split + 8;
-        for (int l = 0; l < l_split && !big; l++) {
+        big = n_rows > 8 * l_coop + 8;
+        for (int l = 0; l < l_coop && !big; l++) {
             const int nx = g.nx[l], base = g.base[l];
             const int sh = l * LEVEL_SHIFT;
             const int cx0 = max((c_x0 >> sh) - 1, 0), cx1 = c_x1 >> sh;
@@ -199,8 +244,14 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
                             // one wave per SIMD less (72 registers) buys two steps less per row)
                             const int last = r1[k] - 1;
                             float4 bx[WALK_LOADS];
+                            static_assert(WALK_LOADS - 1 <= WALK_PAD, "rec_bb padding");
+                            // (no clamp of the index: rec_bb is padded by WALK_PAD records, a load beyond the run reads the next
+                            // run or the padding and is masked below; PACK: a 32-bit byte offset from the uniform base -- at most
+                            // 2^24 records of 16 bytes -- instead of a 64-bit address per load)
 #pragma unroll
-                            for (int u = 0; u < WALK_LOADS; u++) bx[u] = rbb[r + u <= last ? r + u : last];
+                            for (int u = 0; u < WALK_LOADS; u++)
+                                bx[u] = PACK ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rbb) + ((uint32_t)(r + u) << 4))
+                                             : rbb[r + u];
                             // branch-free parking: the slot is written unconditionally and only kept (count
                             // advances) on a hit; beyond SLOTS everything lands in a trash row
 #pragma unroll
@@ -1486,6 +1537,11 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         static const int walk_loads = getenv("XR_WALK_LOADS") ? atoi(getenv("XR_WALK_LOADS")) : 4; // (A/B switch)
         if (pack_ok && walk_loads == 8 && tree->n_face <= ((int64_t)1 << 24))
             XR_LAUNCH("search", (k_search<true, 8>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
+                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
+                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
+                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
+        else if (pack_ok && getenv("XR_SEARCH_COOP") && atoi(getenv("XR_SEARCH_COOP")) == 0 && tree->n_face <= ((int64_t)1 << 24))
+            XR_LAUNCH("search", (k_search<true, 4, true>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
                       tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
                       block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
                       remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
