@@ -83,6 +83,22 @@ def test_config5_cached_weights_k256(hip, oracle, monkeypatch):
     assert_apply_equal(cached.apply(v32, 5), exp, indptr, "maximum K=200 f32")
 
 
+def test_config2_mesh_onto_itself_full_size(hip, oracle):
+    """The 1M-triangle benchmark source regridded onto ITSELF, and onto a copy of itself shifted by one side of one of its faces
+    (one node lands exactly on another): every face touches ~12 neighbours without overlapping them -- the pairs the reference
+    drops before it clips (strict box test, SAT).  Pair set, order and areas bit for bit against the oracle
+    at full size; the diagonal of the self-overlap is the face areas' clip with themselves."""
+    from test_gpu_parity import assert_overlap_parity
+
+    sxy, sf = meshgen.triangle_mesh(500_000, 0)
+    _, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, sxy, sf)
+    assert indptr.size == sf.shape[0] + 1
+    rows = np.repeat(np.arange(sf.shape[0]), np.diff(indptr))
+    assert (np.bincount(rows[idx == rows], minlength=sf.shape[0]) == 1).all()  # every face overlaps itself
+    f = sf[sf.shape[0] // 2]
+    assert_overlap_parity(hip, oracle, sxy, sf, sxy + (sxy[f[1]] - sxy[f[0]]), sf)  # a copy shifted by one side of one face
+
+
 def test_config4_10m_single_gpu(hip, oracle):
     from xugrid_amd import engine as E
 
