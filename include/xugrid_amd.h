@@ -156,7 +156,10 @@ int xr_mesh_download(xr_mesh *mesh, double *node_xy_out, int64_t *faces_out);
  * + MatrixCSR.from_triplet (regridder.py:433-435): all (query face, tree face) pairs with
  * intersection area > 0, as a CSR matrix with one row per QUERY (= regridding target) face,
  * columns = TREE (= source) faces sorted ascending within a row, data = overlap area, or
- * area / tree-face area if relative != 0.  The result stays in HBM. */
+ * area / tree-face area if relative != 0.  The result stays in HBM.
+ * As in numba_celltree a pair only counts if the two faces' exact bounding boxes overlap strictly and the separating-axis
+ * test does not separate them: faces that merely touch (a mesh against itself, meshes sharing nodes) give no entry even
+ * where the clip's floating-point result is a sliver of rounding dust. */
 int xr_overlap(xr_mesh *tree, xr_mesh *query, int relative, xr_csr **out);
 /* Statistics of the last xr_overlap on this tree: bbox candidate pairs tested by the clipper. */
 int xr_overlap_stats(const xr_mesh *tree, int64_t *n_candidates);
