@@ -280,6 +280,23 @@ def test_overlap_meshes_sharing_nodes(hip, oracle):
     assert_overlap_parity(hip, oracle, nxy, f2, sxy, sf)
 
 
+def test_overlap_same_handle_as_tree_and_query(hip, oracle):
+    """A grid regridded onto itself through the public API hands the SAME device mesh in as tree and as query (prepared light
+    as a tree, then fully as a query, indexed and query-ordered on one handle): the oracle's matrix, and the mean of a field
+    comes back unchanged up to the rounding of the few rows that hold more than their own face."""
+    import xugrid_amd as xa
+
+    sxy, sf = meshgen.triangle_mesh(20000, 5)
+    ms = hip.DeviceMesh(sxy, sf)
+    data, idx, indptr = ms.overlap(ms).download()
+    oq, os_, oa = oracle.CellTree2d(sxy, sf, -1).intersect_faces(sxy, sf, -1)
+    assert np.array_equal(np.repeat(np.arange(indptr.size - 1), np.diff(indptr)), oq)
+    assert np.array_equal(idx, os_) and np.array_equal(data, oa)
+    g = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    v = np.random.default_rng(0).normal(size=sf.shape[0])
+    np.testing.assert_allclose(xa.OverlapRegridder(g, g, method="mean").regrid(v), v, rtol=0, atol=1e-13)
+
+
 def test_overlap_meshes_sharing_nodes_general_chain(hip, oracle, monkeypatch):
     """... and through the general kernel chain (XR_OVERLAP_FUSED=0) and a quadrilateral mesh against itself."""
     monkeypatch.setenv("XR_OVERLAP_FUSED", "0")
