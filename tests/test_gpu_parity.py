@@ -287,7 +287,7 @@ def test_overlap_same_handle_as_tree_and_query(hip, oracle):
     import xugrid_amd as xa
 
     sxy, sf = meshgen.triangle_mesh(20000, 5)
-    ms = hip.DeviceMesh(sxy, sf)
+    ms = hip.engine.DeviceMesh(sxy, sf)
     data, idx, indptr = ms.overlap(ms).download()
     oq, os_, oa = oracle.CellTree2d(sxy, sf, -1).intersect_faces(sxy, sf, -1)
     assert np.array_equal(np.repeat(np.arange(indptr.size - 1), np.diff(indptr)), oq)
