@@ -200,8 +200,10 @@ def make_step(E, ms, mt, d_src, d_out, state):
             csr = ms.overlap(mt)  # prepare x2 + index + search + clip + CSR
             csr.apply_dev(d_src, E.XR_F64, 1, d_out, 0)
         else:
-            # the same through ONE entry point (OverlapRegridder(...).regrid(data) on first use): the apply is enqueued
-            # before the host has read the matrix' sizes back
+            # the same through ONE entry point of the C ABI (xr_overlap_apply_dev under xr_set_async: the RAW library step --
+            # the apply is enqueued before the host has read the matrix' sizes back).  The reference-shaped classes build
+            # the weights in their constructor and apply in regrid(): that figure is `config.api_ms`, and the two-call form
+            # of this step is XR_BENCH_TWO_CALLS=1
             csr = ms.overlap_apply_dev(mt, d_src, E.XR_F64, 1, d_out, 0)
         state["csr"] = csr
 
@@ -475,6 +477,9 @@ def run_single(args):
             "candidate_pairs": C,
             "nnz": P,
             "parallelism": "1 GPU",
+            "step_entry_point": "xr_overlap_apply_dev under xr_set_async: the raw C-ABI step on HBM-resident arrays (weights + "
+            "apply enqueued as one call); the reference-shaped classes (weights in the constructor, apply in regrid(), host "
+            "arrays in and out) are `api_ms`",
             "apply_only_ms": apply_ms,
             "apply_only_cells_per_s": T / (apply_ms * 1e-3),
             "apply_only_back_to_back_ms": apply_async_ms,

@@ -96,8 +96,10 @@ int xr_version(void);
 int xr_set_stream(void *hip_stream, int external, int async_dev);
 /* Asynchronous mode on the engine's OWN stream (on != 0): the *_dev entry points, xr_overlap_apply_dev and
  * xr_mesh_invalidate return with their kernels still in flight; results are complete after xr_dev_sync() or any call that
- * returns data to the host.  All work then stays on the one engine stream (no per-thread lanes).  For pipelines that keep
- * their data on the device and issue many calls back to back (a time loop; bench.py's step). */
+ * returns data to the host.  All work then stays on the one engine stream (no per-thread lanes): calls from several host
+ * threads are safe but take turns -- each is enqueued whole before the next starts -- instead of running on streams of their
+ * own (the same holds after xr_set_stream).  For pipelines that keep their data on the device and issue many calls back to
+ * back (a time loop; bench.py's step). */
 int xr_set_async(int on);
 /* Host-only helpers of the Python layer (no device, usable without one): the copies xugrid's constructors make
  * (Ugrid2d.__init__, xugrid/ugrid/ugrid2d.py:86-96: contiguous node_x / node_y, face_node_connectivity.copy()) done by the

@@ -666,3 +666,46 @@ def test_concurrent_applies_from_threads(hip, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_concurrent_applies_in_async_mode(hip, oracle):
+    """Asynchronous mode (``xr_set_async``) keeps every call on the ONE main stream and hands out no lanes; the stream's fork / join
+    state is not atomic, so shared-scope calls from several host threads take turns (``SharedScope``, ``xr_engine.hip``).  Four
+    threads apply matrices WITH long rows (fine -> coarse: the many-variable path forks its long rows to the side stream) at K >= 8:
+    every result equals the single-threaded one bit for bit."""
+    import threading
+
+    from xugrid_amd import engine as E
+
+    rng = np.random.default_rng(21)
+    cases = []
+    for i in range(4):
+        sxy, sf = meshgen.triangle_mesh(30000 + 4000 * i, 60 + i)
+        txy, tf = meshgen.triangle_mesh(300 + 40 * i, 70 + i, 30.0, 0.7)  # ~100 source faces per target: rows beyond 32 entries
+        csr = E.DeviceMesh(sxy, sf).overlap(E.DeviceMesh(txy, tf))
+        K = (8, 12, 16, 40)[i]
+        v = rng.normal(size=(K, csr.m))
+        v[0, ::11] = np.nan
+        cases.append((csr, v, 0, csr.apply(v, 0)))
+    errors = []
+
+    def worker(i):
+        try:
+            csr, v, mid, exp = cases[i]
+            for it in range(20):
+                if not same_or_nan(csr.apply(v, mid), exp).all():
+                    errors.append((i, it))
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    E.set_async(True)
+    try:
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    finally:
+        E.set_async(False)
+    assert not errors, errors

@@ -215,3 +215,28 @@ def test_rectilinear_ugrid_host_side_is_lazy_and_equal():
             assert np.array_equal(again.face_node_connectivity, host.face_node_connectivity)
     with pytest.raises(ValueError):
         RectilinearUgrid2d(np.array([0.0]), np.array([0.0, 1.0]))
+
+
+def test_ugrid2d_coordinates_cannot_go_stale():
+    """``node_x`` / ``node_y`` are plain attributes in the reference (ugrid2d.py:86-87) and ``node_coordinates`` a fresh array per
+    call (ugridbase.py:576-579).  Here the interleaved table feeds the device: the public view is read-only (an in-place
+    write raises instead of corrupting the grid silently) and assigning an axis rebuilds the table and drops what was derived."""
+    import xugrid_amd as xa
+
+    xy, faces = xa.meshgen.triangle_mesh(100, 0)
+    g = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+    nc = g.node_coordinates
+    assert np.array_equal(nc, xy)
+    with pytest.raises(ValueError):
+        nc[0, 0] = 5.0
+    old_x = g.node_x.copy()
+    g._area = np.ones(3)  # (stand-ins for device results: no device in this test)
+    g._celltree = object()
+    g.node_x = old_x * 2.0
+    assert np.array_equal(g.node_x, old_x * 2.0) and np.array_equal(g.node_coordinates[:, 0], old_x * 2.0)
+    assert np.array_equal(g.node_coordinates[:, 1], xy[:, 1]) and np.array_equal(g.node_y, xy[:, 1])
+    assert g._area is None and g._celltree is None
+    g.node_y = xy[:, 1] + 1.0
+    assert np.array_equal(g.node_coordinates[:, 1], xy[:, 1] + 1.0)
+    with pytest.raises(ValueError):
+        g.node_x = np.zeros(3)

@@ -38,6 +38,7 @@ static thread_local Lane *t_lane = nullptr;
 static constexpr int N_LANES = 4;
 static Lane g_lanes[N_LANES];
 static std::mutex g_pool_mutex; // the block pool and the kernel-timer tables are shared by all threads
+static std::mutex g_main_turn;  // shared-scope calls that run on the main stream (no lane) take turns
 
 Lane *current_lane() { return t_lane; }
 bool exclusive_held() { return t_exclusive_depth > 0; }
@@ -67,8 +68,15 @@ SharedScope::SharedScope() {
     engine_rw().lock_shared();
     leased = true;
     Engine &e = engine();
-    if (e.stream != e.own_stream) return; // bound to the caller's stream (xr_set_stream): ordered there, no lane
-    if (e.own_async) return; // asynchronous mode: everything stays on the ONE main stream (stream-ordered pool), no lanes
+    // Bound to the caller's stream (xr_set_stream) or asynchronous mode (xr_set_async): everything stays on the ONE main
+    // stream (stream-ordered pool) and there are no lanes.  The main stream's state -- on_side, the fork / join / aux events,
+    // the deferred pool list -- is not atomic, so calls from several host threads take turns here instead of running
+    // concurrently: a second thread waits until the first one's call has been ENQUEUED (not finished: the stream orders them).
+    if (e.stream != e.own_stream || e.own_async) {
+        g_main_turn.lock();
+        serial = true;
+        return;
+    }
     // a free lane, else wait for "this thread's" one
     const size_t h = std::hash<std::thread::id>()(std::this_thread::get_id());
     Lane *lane = nullptr;
@@ -97,6 +105,7 @@ SharedScope::SharedScope() {
 }
 SharedScope::~SharedScope() {
     if (!leased) return;
+    if (serial) g_main_turn.unlock();
     if (t_lane) {
         (void)hipStreamSynchronize(t_lane->stream); // the call is over: nothing of it is in flight
         if (t_lane->side_active) { // (a call that failed between fork and join)
@@ -414,7 +423,10 @@ struct HostPool {
                     const size_t b = (size_t)(t + 1) * per, e = std::min(n, b + per);
                     auto f = fn;
                     lock.unlock();
-                    if (b < e) f(b, e);
+                    if (b < e) {
+                        JobFlag flag;
+                        f(b, e);
+                    }
                     lock.lock();
                     if (--pending == 0) cv_done.notify_one();
                 }
@@ -422,17 +434,26 @@ struct HostPool {
             workers[t].detach(); // (the pool lives as long as the process)
         }
     }
+    // set on EVERY thread while it runs a slice of a job (the caller's own slice and the workers' slices alike)
+    static bool &in_job() {
+        static thread_local bool inside = false;
+        return inside;
+    }
+    struct JobFlag {
+        bool &f;
+        JobFlag() : f(in_job()) { f = true; }
+        ~JobFlag() { f = false; }
+    };
     void run(size_t total, size_t align, const std::function<void(size_t, size_t)> &f) {
         if (total == 0) return;
-        // (not re-entrant: a fill callback that called back into the pool would wait for the mutex it runs under)
-        static thread_local bool inside = false;
-        XR_REQUIRE(!inside, XR_ERR_INVALID, "host thread pool re-entered from one of its own jobs");
-        struct Flag {
-            bool &f;
-            explicit Flag(bool &b) : f(b) { f = true; }
-            ~Flag() { f = false; }
-        } flag(inside);
+        // not re-entrant: a slice that called back into the pool would wait for the job mutex its own job holds -- from the
+        // caller's thread as well as from a worker's.  A nested call runs inline on the thread it came from.
+        if (in_job()) {
+            f(0, total);
+            return;
+        }
         std::lock_guard<std::mutex> job(job_mutex);
+        JobFlag flag;
         size_t p = (total + STAGE_THREADS - 1) / STAGE_THREADS;
         p = (p + align - 1) / align * align;
         if (total < (size_t)1 << 16) { // small: not worth a wake-up

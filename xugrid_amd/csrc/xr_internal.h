@@ -80,6 +80,7 @@ struct SharedScope {
     SharedScope();
     ~SharedScope();
     bool leased = false;
+    bool serial = false; // no lane (caller's stream / asynchronous mode): holds the main stream's turn
 };
 
 // ---------------------------------------------------------------------------------------------

@@ -259,16 +259,20 @@ class HipBackend:
         handles copy them device-to-device (xr_mesh_create_dev) -- a shard cut out of the replicated mesh never visits
         the host."""
         E = self.engine
+        # contiguous copies FIRST (a copy kernel of a strided tensor goes to torch's stream), then the hand-over that makes
+        # torch's work visible to the engine's stream; the copies stay referenced until both handles have read them
+        src_xy, src_faces, tgt_xy, tgt_faces = (a.contiguous() for a in (src_xy, src_faces, tgt_xy, tgt_faces))
         self._handover()
 
         def mesh(xy, faces):
-            xy, faces = xy.contiguous(), faces.contiguous()
             return E.DeviceMesh.from_device(xy.data_ptr(), xy.shape[0], faces.data_ptr(), faces.element_size(),
                                             faces.shape[0], faces.shape[1])
 
         self._src_mesh, self._tgt_mesh = mesh(src_xy, src_faces), mesh(tgt_xy, tgt_faces)
         self._relative = bool(relative)
-        return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
+        weights = self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
+        del src_xy, src_faces, tgt_xy, tgt_faces
+        return weights
 
     def rebuild_weights(self):
         """Benchmark hook: redo prepare + index + overlap from the HBM-resident raw meshes."""

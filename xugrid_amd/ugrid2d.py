@@ -84,6 +84,27 @@ class Ugrid2d:
             self._node_y = np.ascontiguousarray(self._node_xy[:, 1])
         return self._node_y
 
+    # plain attributes in the reference (ugrid2d.py:86-87): assigning new coordinates is legal there.  Here the interleaved
+    # buffer is what the device sees, so an assignment rebuilds it and drops everything derived from the old coordinates.
+    @node_x.setter
+    def node_x(self, value):
+        self._set_node_axis(0, value)
+
+    @node_y.setter
+    def node_y(self, value):
+        self._set_node_axis(1, value)
+
+    def _set_node_axis(self, axis, value):
+        value = np.asarray(value, dtype=np.float64)
+        if value.shape != (self.n_node,):
+            raise ValueError(f"expected {self.n_node} node coordinates, got shape {value.shape}")
+        xy = np.array(self._node_xy)  # (a fresh buffer: the old one may be in use by a device upload or a caller's view)
+        xy[:, axis] = value
+        self._node_xy = xy
+        self._node_x = self._node_y = None
+        self._area = self._centroids = None
+        self.drop_device_caches()
+
     # ---- sizes / names
     @property
     def n_node(self):
@@ -111,7 +132,12 @@ class Ugrid2d:
 
     @property
     def node_coordinates(self):
-        return self._node_xy
+        """(n_node, 2).  The reference returns a fresh ``column_stack`` per call (ugridbase.py:576-579); here it is a READ-ONLY
+        view of the grid's own buffer (the one the device mesh is uploaded from): an in-place modification raises instead of
+        silently leaving the device copy and the cached ``node_x`` / ``node_y`` stale.  Copy it to get a writable array."""
+        view = self._node_xy.view()
+        view.flags.writeable = False
+        return view
 
     @property
     def bounds(self):
@@ -126,7 +152,7 @@ class Ugrid2d:
     @property
     def celltree(self) -> CellTree2d:
         if self._celltree is None:
-            self._celltree = CellTree2d(self.node_coordinates, self.face_node_connectivity, FILL_VALUE)
+            self._celltree = CellTree2d(self._node_xy, self.face_node_connectivity, FILL_VALUE)
         return self._celltree
 
     def drop_device_caches(self):
