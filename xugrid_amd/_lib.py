@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxugrid_amd.so")
+# XUGRID_AMD_LIB: measurement hook only -- an A/B build of the same sources with other compiler flags (profiles/fma_ab.sh)
+LIB_PATH = os.environ.get("XUGRID_AMD_LIB") or os.path.join(_HERE, "libxugrid_amd.so")
 
 XR_OK = 0
 XR_ERR_INVALID = -1
