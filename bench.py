@@ -725,6 +725,36 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
         }
     except Exception as e:  # noqa: BLE001
         out["network_gridder_1M_edges"] = {"error": repr(e)}
+    try:  # BASELINE config 1 as SURVEY 8(d) words it, through the public API (tests/test_gpu_regridder_api.py checks the values)
+        g = np.load(os.path.join(ROOT, "tests", "golden", "g8_elevation_nl.npz"))
+        node_x, node_y, faces1, elev = g["node_x"], g["node_y"], g["face_nodes"].astype(np.int64), g["elevation"]
+        n1 = 200
+        dx1, dy1 = (node_x.max() - node_x.min()) / n1, (node_y.max() - node_y.min()) / n1
+        raster = Raster(x=node_x.min() + (np.arange(n1) + 0.5) * dx1, y=node_y.max() - (np.arange(n1) + 0.5) * dy1, dx=dx1, dy=-dy1)
+        grid1 = xa.Ugrid2d(node_x, node_y, -1, faces1)
+        t_con, t_reg = [], []
+        for i in range(6):
+            t0 = time.perf_counter()
+            rg = xa.OverlapRegridder(xa.Ugrid2d(node_x, node_y, -1, faces1) if i else grid1, raster, method="mean")
+            t1 = time.perf_counter()
+            res = rg.regrid(elev)
+            t2 = time.perf_counter()
+            if i:  # (first pass = warm-up)
+                t_con.append(t1 - t0)
+                t_reg.append(t2 - t1)
+        w1 = rg._ensure_host_weights()
+        out["config1_elevation_nl_to_200x200"] = {
+            "workload": "BASELINE config 1: elevation_nl Ugrid2d (5248 triangles, float32 elevation) -> 200 x 200 raster, x ascending, "
+                        "y descending, OverlapRegridder mean, host arrays in and out through the public API (a fresh Ugrid2d per pass)",
+            "construct_ms": 1e3 * float(np.median(t_con)), "regrid_ms": 1e3 * float(np.median(t_reg)),
+            "target_cells_per_s": n1 * n1 / float(np.median(t_con) + np.median(t_reg)), "nnz": int(w1.nnz),
+            "weight_sum_over_mesh_area": float(w1.data.sum() / 4.2169478944e10),
+            "value_range": [float(np.nanmin(res)), float(np.nanmax(res))], "nan_cells": int(np.isnan(res).sum()),
+            "note": "40,000 quadrilateral targets on 5,248 triangles: a problem this small is launch / host-latency bound; kept as "
+                    "the plumbing check it is in BASELINE.json",
+        }
+    except Exception as e:  # noqa: BLE001
+        out["config1_elevation_nl_to_200x200"] = {"error": repr(e)}
     return out
 
 

@@ -709,3 +709,54 @@ def test_concurrent_applies_in_async_mode(hip, oracle):
     finally:
         E.set_async(False)
     assert not errors, errors
+
+
+def test_config1_as_survey_words_it(hip, oracle, golden):
+    """BASELINE config 1 exactly as SURVEY 8(d) states it, through the public API: the committed elevation_nl arrays as a ``Ugrid2d``
+    -> a 200 x 200 raster with x ASCENDING and y DESCENDING (``dy`` negative, the ``fixture_regridder.py:94-104`` style),
+    ``OverlapRegridder(..., "mean").regrid(elevation float32)`` -> (200, 200) float64, NaN where nothing overlaps; sum of all
+    weights = the mesh area 4.2169478944e10 m2 (1e-10 rel), every row sum <= the cell area, values within [-60.66, 252.73], and
+    equal to the oracle on the same quads."""
+    g = golden("g8_elevation_nl.npz")
+    node_x, node_y, faces, elev = g["node_x"], g["node_y"], g["face_nodes"].astype(np.int64), g["elevation"]
+    assert elev.dtype == np.float32 and faces.shape == (5248, 3) and node_x.size == 2790
+    xmin, xmax, ymin, ymax = node_x.min(), node_x.max(), node_y.min(), node_y.max()
+    n = 200
+    dx, dy = (xmax - xmin) / n, (ymax - ymin) / n
+    x = xmin + (np.arange(n) + 0.5) * dx
+    y = ymax - (np.arange(n) + 0.5) * dy
+    assert (np.diff(x) > 0).all() and (np.diff(y) < 0).all()
+    source = xa.Ugrid2d(node_x, node_y, -1, faces)
+    target = xa.Raster(x=x, y=y, dx=dx, dy=-dy)
+    rg = xa.OverlapRegridder(source, target, method="mean")
+    out = rg.regrid(elev)
+    assert out.shape == (n, n) and out.dtype == np.float64
+    w = rg._ensure_host_weights()
+    assert w.n == n * n and w.m == 5248
+    # the documented checks
+    assert abs(w.data.sum() / 4.2169478944e10 - 1.0) < 1e-10
+    assert abs(w.data.sum() / source.area.sum() - 1.0) < 1e-10
+    row_sum = np.bincount(np.repeat(np.arange(w.n), np.diff(w.indptr)), weights=w.data, minlength=w.n)
+    assert (row_sum <= dx * dy * (1 + 1e-12)).all()
+    empty = np.diff(w.indptr) == 0
+    assert np.array_equal(np.isnan(out).ravel(), empty) and empty.any() and not empty.all()
+    assert np.nanmin(out) >= -60.67 and np.nanmax(out) <= 252.74
+    # the raster's cells as the quads the regridder clipped: row-major (y, x) numbering, y descending
+    quads = xa.regrid.StructuredGrid2d(target).convert_to(xa.regrid.UnstructuredGrid2d).ugrid_topology
+    qxy, qf = np.asarray(quads.node_coordinates), np.asarray(quads.face_node_connectivity)
+    cen = qxy[qf].mean(axis=1).reshape(n, n, 2)
+    np.testing.assert_allclose(cen[..., 0], np.broadcast_to(x[None, :], (n, n)), rtol=1e-12)
+    np.testing.assert_allclose(cen[..., 1], np.broadcast_to(y[:, None], (n, n)), rtol=1e-12)
+    # ... and the oracle on those quads
+    sxy = np.column_stack([node_x, node_y])
+    oq, os_, oa = oracle.CellTree2d(sxy, faces).intersect_faces(qxy, qf)
+    assert np.array_equal(np.repeat(np.arange(w.n), np.diff(w.indptr)), oq) and np.array_equal(w.indices, os_)
+    assert np.array_equal(w.data, oa)
+    exp = oracle.regrid_csr("mean", elev[None, :].astype(np.float64), w.data, w.indices, w.indptr, w.n)[0]
+    long_rows = np.diff(w.indptr) > 32
+    assert same_or_nan(out.ravel()[~long_rows], exp[~long_rows]).all()
+    np.testing.assert_allclose(out.ravel(), exp, rtol=1e-13, equal_nan=True)
+    # the value at a raster cell is the area-weighted mean of the triangles under it: spot-check the cell with the most entries
+    t = int(np.argmax(np.diff(w.indptr)))
+    sl = slice(w.indptr[t], w.indptr[t + 1])
+    np.testing.assert_allclose(out.ravel()[t], (w.data[sl] * elev[w.indices[sl]].astype(np.float64)).sum() / w.data[sl].sum(), rtol=1e-12)
