@@ -19,8 +19,14 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 delaunay = kind == "delaunay"
 lib = _lib.load()
-sxy, sf = xa.meshgen.triangle_mesh(500_000, 0, delaunay=delaunay)
-txy, tf = xa.meshgen.triangle_mesh(500_000, 1, 30.0, 0.7, delaunay=delaunay)
+cache = f"/tmp/apply_k256_meshes_{kind}.npz"  # (qhull takes ~10 s per run; the PMC script makes ~30 of them)
+if os.path.exists(cache):
+    z = np.load(cache)
+    sxy, sf, txy, tf = z["sxy"], z["sf"], z["txy"], z["tf"]
+else:
+    sxy, sf = xa.meshgen.triangle_mesh(500_000, 0, delaunay=delaunay)
+    txy, tf = xa.meshgen.triangle_mesh(500_000, 1, 30.0, 0.7, delaunay=delaunay)
+    np.savez(cache, sxy=sxy, sf=sf, txy=txy, tf=tf)
 src_m, tgt_m = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
 csr = src_m.overlap(tgt_m)
 S, T = sf.shape[0], tf.shape[0]

@@ -890,7 +890,8 @@ void mesh_build_index(xr_mesh *mesh) {
     if (!(H > 0)) H = 1.0;
     // level-0 cell size = 1.25 mean bbox extents (measured optimum of the search kernel on the 1M
     // benchmark: 0.75 -> 0.168 ms, 1.0 -> 0.155, 1.25 -> 0.137, 1.5 -> 0.134, 2.0 -> 0.144)
-    double h0 = F > 0 ? 1.25 * sum_ext / (double)F : 1.0;
+    static const double h0_factor = getenv("XR_H0_FACTOR") ? std::min(8.0, std::max(0.25, atof(getenv("XR_H0_FACTOR")))) : 1.25; // (tuning hook)
+    double h0 = F > 0 ? h0_factor * sum_ext / (double)F : 1.0;
     if (!(h0 > 0)) h0 = std::max(W, H);
     // bound the level-0 cell count by ~4 cells per face
     const double max_cells0 = std::max(4.0 * (double)F, 1024.0);

@@ -48,6 +48,7 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
 // hits, too many grid rows or too many visited records are "big" and go to the block-per-face
 // kernel instead.
 static constexpr int SLOTS = 16;
+static constexpr int SEARCH_HIT_DEFAULT = 0; // form of the walk's box test (see k_search)
 static constexpr int TILE_RUN = 16; // rows per run in the tiling hint (128-byte output stores per variable).  Measured, K = 256 on
                                     // the benchmark matrix: runs of 64 rows / tiles of 24 extents 2.10 ms, 16 / 12: 1.72 ms (a qhull-numbered
                                     // target: long runs of consecutive ids are not compact); a lattice-numbered pair 0.99 ms either way
@@ -73,7 +74,11 @@ static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may t
 // PACK: the owning thread of a parked candidate rides in the top 8 bits of the record id (trees of at most 2^24 faces) instead
 // of a byte array of its own: 19.5 instead of 23.5 KB of LDS per block = 8 instead of 6 resident blocks per CU for a
 // kernel that is a chain of dependent loads.
-template <bool PACK, int WALK_LOADS = 4, bool COOP_OFF = false>
+// HIT: the form of the f32 box test in the walk's step (all three give the same answer; XR_SEARCH_HIT is the A/B switch):
+//   0  one float through subtract / max (box_gap), range guard folded into the max: 62 vector instructions per step of four
+//   1  five compares, lane masks combined on the scalar unit, count += carry: 37 vector + ~28 scalar instructions
+//   2  the two gaps of an axis from ONE packed add (v_pk_add_f32 with per-half operand selection and negation), two v_max3: 47 + 10
+template <bool PACK, int HIT = 0>
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
          const int32_t *__restrict__ cell_start,
@@ -125,7 +130,6 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
         if (((int64_t)big0 - first) * 64 > n_tree) break;
         l_coop = l;
     }
-    if (COOP_OFF) l_coop = l_split;
     if (threadIdx.x == 0) sh_nbig = 0;
     if (big0 < (int)n_tree || l_coop < l_split) {
         // the block's bounding box, then one coalesced pass over the big records
@@ -215,6 +219,8 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
         // so its cell is >= cell(q.xmin) - 1 for the same monotone cell function the index was built with.)
         const int c_x0 = cell_coord(bb.x, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(bb.y, g.x0, g.inv_h0, g.nx[0]);
         const int c_y0 = cell_coord(bb.z, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(bb.w, g.y0, g.inv_h0, g.ny[0]);
+        constexpr int WALK_LOADS = 4;
+        const float2v qxp = {qx0, qx1}, qyp = {qy0, qy1};
         int visited = 0, n_rows = 0;
         for (int l = 0; l < l_coop; l++)
             n_rows += (c_y1 >> (l * LEVEL_SHIFT)) - max((c_y0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
@@ -239,26 +245,31 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
                     if (visited > BIG_VISITS) big = true;
                     if (!big) {
                         for (int r = r0[k]; r < r1[k]; r += WALK_LOADS) {
-                            // WALK_LOADS independent 16-byte loads in flight per step (8: the walk is a chain of dependent
-                            // round trips -- 12 records per grid row on the benchmark pair, i.e. three steps of four -- and
-                            // one wave per SIMD less (72 registers) buys two steps less per row)
+                            // WALK_LOADS independent 16-byte loads in flight per step (6 and 8 measured in round 4: no faster)
                             const int last = r1[k] - 1;
                             float4 bx[WALK_LOADS];
                             static_assert(WALK_LOADS - 1 <= WALK_PAD, "rec_bb padding");
                             // (no clamp of the index: rec_bb is padded by WALK_PAD records, a load beyond the run reads the next
-                            // run or the padding and is masked below; PACK: a 32-bit byte offset from the uniform base -- at most
-                            // 2^24 records of 16 bytes -- instead of a 64-bit address per load)
+                            // run or the padding and is masked below; PACK: ONE 32-bit byte offset from the uniform base per step --
+                            // at most 2^24 records of 16 bytes -- and the records behind it through the instruction's immediate offset)
+                            const char *step_base = reinterpret_cast<const char *>(rbb) + ((uint32_t)r << 4);
 #pragma unroll
                             for (int u = 0; u < WALK_LOADS; u++)
-                                bx[u] = PACK ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(rbb) + ((uint32_t)(r + u) << 4))
-                                             : rbb[r + u];
-                            // branch-free parking: the slot is written unconditionally and only kept (count
-                            // advances) on a hit; beyond SLOTS everything lands in a trash row
+                                bx[u] = PACK ? *reinterpret_cast<const float4 *>(step_base + 16 * u) : rbb[r + u];
+                            // branch-free parking: the slot is written unconditionally and only kept (count advances) on a hit;
+                            // beyond SLOTS everything lands in a trash row
 #pragma unroll
                             for (int u = 0; u < WALK_LOADS; u++) {
-                                const bool h = fmaxf(box_gap(bx[u], qx0, qx1, qy0, qy1), r + u <= last ? -INFINITY : 1.0f) < 0.0f;
                                 sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + u;
-                                count += h ? 1 : 0;
+                                if (HIT == 1) {
+                                    unsigned long long h = box_hit_mask(bx[u], qx0, qx1, qy0, qy1);
+                                    if (u > 0) h &= __builtin_amdgcn_ballot_w64(r + u <= last);
+                                    count = add_lane_mask(count, h);
+                                } else if (HIT == 2) {
+                                    count += box_gap_packed(bx[u], qxp, qyp, u > 0 ? (r + u <= last ? -INFINITY : 1.0f) : -INFINITY) < 0.0f ? 1 : 0;
+                                } else {
+                                    count += fmaxf(box_gap(bx[u], qx0, qx1, qy0, qy1), r + u <= last ? -INFINITY : 1.0f) < 0.0f ? 1 : 0;
+                                }
                             }
                         }
                     }
@@ -1534,32 +1545,17 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl_head + 8);
         if (!scan_bases) XR_HIP(hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)grid, st)); // (look-back words: XR_ASSEMBLE_SCAN=0 only)
         static const bool pack_ok = !(getenv("XR_SEARCH_PACK") && atoi(getenv("XR_SEARCH_PACK")) == 0); // (A/B switch)
-        static const int walk_loads = getenv("XR_WALK_LOADS") ? atoi(getenv("XR_WALK_LOADS")) : 4; // (A/B switch)
-        if (pack_ok && walk_loads == 8 && tree->n_face <= ((int64_t)1 << 24))
-            XR_LAUNCH("search", (k_search<true, 8>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
-                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
-                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
-        else if (pack_ok && getenv("XR_SEARCH_COOP") && atoi(getenv("XR_SEARCH_COOP")) == 0 && tree->n_face <= ((int64_t)1 << 24))
-            XR_LAUNCH("search", (k_search<true, 4, true>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
-                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
-                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
-        else if (pack_ok && walk_loads == 6 && tree->n_face <= ((int64_t)1 << 24))
-            XR_LAUNCH("search", (k_search<true, 6>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
-                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
-                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
-        else if (pack_ok && tree->n_face <= ((int64_t)1 << 24))
-            XR_LAUNCH("search", k_search<true>, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
-                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
-                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
-        else
-            XR_LAUNCH("search", k_search<false>, dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face, tree->cell_start.get(),
-                      tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(), ctl_head + 0,
-                      block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),
-                      remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr);
+        static const int hit_form = getenv("XR_SEARCH_HIT") ? atoi(getenv("XR_SEARCH_HIT")) : SEARCH_HIT_DEFAULT; // (A/B switch)
+#define XR_SEARCH_LAUNCH(PACKED, FORM)                                                                                              \
+    XR_LAUNCH("search", (k_search<PACKED, FORM>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face,                      \
+              tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(),          \
+              ctl_head + 0, block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),    \
+              remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr)
+        if (!(pack_ok && tree->n_face <= ((int64_t)1 << 24))) XR_SEARCH_LAUNCH(false, SEARCH_HIT_DEFAULT);
+        else if (hit_form == 1) XR_SEARCH_LAUNCH(true, 1);
+        else if (hit_form == 2) XR_SEARCH_LAUNCH(true, 2);
+        else XR_SEARCH_LAUNCH(true, 0);
+#undef XR_SEARCH_LAUNCH
         {
             // ---- side stream: everything about the big faces except their final placement
             SideScope side;
@@ -1765,12 +1761,12 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
     DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     const bool remap_search = xcd_remap_mask() & 2, remap_rows = xcd_remap_mask() & 4;
     if (tree->n_face <= ((int64_t)1 << 24))
-        XR_LAUNCH("search", k_search<true>, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
+        XR_LAUNCH("search", (k_search<true, SEARCH_HIT_DEFAULT>), dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
                   tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
                   cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
     else
-        XR_LAUNCH("search", k_search<false>, dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
+        XR_LAUNCH("search", (k_search<false, SEARCH_HIT_DEFAULT>), dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
                   tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
                   cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
