@@ -818,7 +818,7 @@ __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
              const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
              const int32_t *__restrict__ row_order, bool skip_long, int64_t T, int64_t S,
-             const SRC *__restrict__ source, int64_t K, double *__restrict__ out, int lmax) {
+             const SRC *__restrict__ source, int64_t K, double *__restrict__ out, int lmax, int super_blocks, int item_tiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][PLAN_UMAX]
     double *sh_w = vals + KTILE * PLAN_UMAX;                              // [lmax] = entries of the largest planned block
@@ -828,7 +828,27 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     // row blocks (= one spatial region), so that lines shared by neighbouring blocks stay in one L2
     const int64_t n_blocks = (T + AP_BLOCK - 1) / AP_BLOCK;
     const int64_t per_xcd = (n_blocks + 7) / 8;
-    const int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    int64_t k_begin = 0, k_end = K;
+    if (super_blocks > 0) {
+        // L2-blocked order (round 5).  A block of 256 rows uses ~4 of the 16 source values of every 128-byte line it touches
+        // (a qhull-numbered mesh: spatial neighbours are not id neighbours); the rest of the line belongs to NEIGHBOURING row
+        // blocks, and a block that walks all K variables on its own drifts away from them -- the line comes from HBM once per
+        // block (PMC, K = 128: 24 M fabric reads against 7 M for a lattice-numbered pair).  Here a work item is one row block x
+        // `item_tiles` variable tiles, and an XCD's items are ordered (super tile of `super_blocks` neighbouring row blocks) ->
+        // (variable item) -> (row block): the blocks resident on an XCD at any time share one super tile and one variable
+        // item, whose source lines (~1.4 MB for 64 blocks x 8 variables) stay in that XCD's 4 MB L2.
+        const int64_t n_items = (K + (int64_t)KTILE * item_tiles - 1) / ((int64_t)KTILE * item_tiles);
+        const int64_t i = blockIdx.x >> 3;
+        const int64_t per_super = (int64_t)super_blocks * n_items;
+        const int64_t sup = i / per_super, rem = i - sup * per_super;
+        const int64_t item = rem / super_blocks, b = rem - item * super_blocks;
+        const int64_t local = sup * super_blocks + b;
+        if (local >= per_xcd) return;
+        lb = (int64_t)(blockIdx.x & 7) * per_xcd + local;
+        k_begin = item * KTILE * item_tiles;
+        k_end = k_begin + (int64_t)KTILE * item_tiles < K ? k_begin + (int64_t)KTILE * item_tiles : K;
+    }
     if (lb >= n_blocks) return;
     const int64_t row0 = lb * AP_BLOCK;
     const int64_t t = row0 + threadIdx.x;
@@ -865,15 +885,16 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     // prologue: request tile 0
     double stage[UPT][KTILE];
     {
-        const int kn = (int)(K < KTILE ? K : KTILE);
+        const int kn = (int)(k_end - k_begin < KTILE ? k_end - k_begin : KTILE);
+        const SRC *src0 = source + k_begin * S;
 #pragma unroll
         for (int q = 0; q < UPT; q++)
 #pragma unroll
             for (int kk = 0; kk < KTILE; kk++)
-                stage[q][kk] = (mycol[q] >= 0 && kk < kn) ? ld_src(source, (int64_t)kk * S + mycol[q]) : 0.0;
+                stage[q][kk] = (mycol[q] >= 0 && kk < kn) ? ld_src(src0, (int64_t)kk * S + mycol[q]) : 0.0;
     }
-    for (int64_t k0 = 0; k0 < K; k0 += KTILE) {
-        const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
+    for (int64_t k0 = k_begin; k0 < k_end; k0 += KTILE) {
+        const int kn = (int)((k_end - k0) < KTILE ? (k_end - k0) : KTILE);
         __syncthreads(); // everybody finished reading the previous tile
         int my_nan = 0;
 #pragma unroll
@@ -891,8 +912,8 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         const bool tile_has_nan = __syncthreads_or(my_nan) != 0;
         // request the next tile while this one is reduced
         const int64_t k1 = k0 + KTILE;
-        if (k1 < K) {
-            const int kn1 = (int)((K - k1) < KTILE ? (K - k1) : KTILE);
+        if (k1 < k_end) {
+            const int kn1 = (int)((k_end - k1) < KTILE ? (k_end - k1) : KTILE);
             const SRC *src1 = source + k1 * S;
 #pragma unroll
             for (int q = 0; q < UPT; q++)
@@ -1753,10 +1774,19 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_max);
             });
             XR_HIP(attr_rc);
-            XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), dim3((div_up(csr->n, AP_BLOCK) + 7) / 8 * 8), dim3(AP_BLOCK),
+            // L2-blocked order (k_apply_plan): super tiles of `super_blocks` row blocks x items of `item_tiles` variable tiles
+            static const int super_blocks = getenv("XR_APPLY_SUPER") ? std::max(0, atoi(getenv("XR_APPLY_SUPER"))) : 0; // tuning hooks
+            static const int item_tiles = getenv("XR_APPLY_ITEM") ? std::max(1, atoi(getenv("XR_APPLY_ITEM"))) : 1;
+            int64_t plan_grid = (div_up(csr->n, AP_BLOCK) + 7) / 8 * 8;
+            if (super_blocks > 0) {
+                const int64_t per_xcd = (div_up(csr->n, AP_BLOCK) + 7) / 8;
+                const int64_t n_items = div_up(K, (int64_t)PLAN_KT * item_tiles);
+                plan_grid = 8 * div_up(per_xcd, super_blocks) * super_blocks * n_items;
+            }
+            XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), dim3((unsigned)plan_grid), dim3(AP_BLOCK),
                       shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(),
                       csr->plan_nuniq.get(), csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src,
-                      K, out, csr->plan_lmax);
+                      K, out, csr->plan_lmax, super_blocks, item_tiles);
             if (csr->plan_n_unplanned > 0) {
                 // the few blocks the plan could not take (hull slivers: too many entries or distinct columns): direct
                 // gathers, parallel over the variable tiles as well so that no thread walks a long row K / 8 times

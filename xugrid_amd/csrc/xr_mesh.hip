@@ -888,9 +888,11 @@ void mesh_build_index(xr_mesh *mesh) {
     double W = F > 0 ? xmax - xmin : 1.0, H = F > 0 ? ymax - ymin : 1.0;
     if (!(W > 0)) W = 1.0;
     if (!(H > 0)) H = 1.0;
-    // level-0 cell size = 1.25 mean bbox extents (measured optimum of the search kernel on the 1M
-    // benchmark: 0.75 -> 0.168 ms, 1.0 -> 0.155, 1.25 -> 0.137, 1.5 -> 0.134, 2.0 -> 0.144)
-    static const double h0_factor = getenv("XR_H0_FACTOR") ? std::min(8.0, std::max(0.25, atof(getenv("XR_H0_FACTOR")))) : 1.25; // (tuning hook)
+    // level-0 cell size = 1.4 mean bbox extents (measured on the 1M benchmark.  Round 1's search kernel: 0.75 -> 0.168 ms,
+    // 1.0 -> 0.155, 1.25 -> 0.137, 1.5 -> 0.134, 2.0 -> 0.144; round 5's, interleaved on one box: 1.25 -> 0.0924,
+    // 1.4 -> 0.0898, 1.5 -> 0.0976, 1.6 -> 0.111 -- at 1.5 the second level still holds more than 1/64 of the records, so every
+    // face walks it, yet it is too empty to pay for its cell bounds; XR_H0_FACTOR is the A/B switch)
+    static const double h0_factor = getenv("XR_H0_FACTOR") ? std::min(8.0, std::max(0.25, atof(getenv("XR_H0_FACTOR")))) : 1.4; // (tuning hook)
     double h0 = F > 0 ? h0_factor * sum_ext / (double)F : 1.0;
     if (!(h0 > 0)) h0 = std::max(W, H);
     // bound the level-0 cell count by ~4 cells per face
