@@ -719,6 +719,7 @@ k_apply_direct(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
 static constexpr int PLAN_LMAX = 4096; // entries of a block the builder can sort in LDS
 static constexpr int PLAN_UMAX = 512;  // distinct columns per block kept in the plan
 static constexpr int PLAN_KT = 8;      // source variables per pipeline stage (LDS: PLAN_KT * PLAN_UMAX doubles)
+static constexpr int PLAN_SUBS_DEFAULT = 1; // row blocks per workgroup of k_apply_plan
 
 __global__ void __launch_bounds__(AP_BLOCK)
 k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
@@ -813,22 +814,31 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
 // (global -> registers -> LDS): the distinct source values of tile i+1 are requested into registers
 // before tile i is reduced, and written to LDS after it -- HBM latency overlaps the reduction, so one
 // resident block per CU is enough to keep its share of the memory system busy.
-template <int METHOD, typename SRC, int KTILE>
-__global__ void __launch_bounds__(AP_BLOCK)
+// SUBS > 1 (round 5): one workgroup = SUBS neighbouring row blocks (SUBS x 256 threads, every sub-block with its own plan and its
+// own LDS region) that walk the variable tiles in LOCKSTEP -- the group's barriers are the workgroup's.  On a mesh whose
+// numbering is coherent but not compact (qhull) a row block uses ~4 of the 16 source values of a 128-byte line and its
+// neighbours use the rest: as separate workgroups they drift apart and every one of them fetches the line on its own -- the L1
+// of a CU holds 256 lines, the L2 of an XCD four microseconds of traffic --, in lockstep on ONE CU the requests for a line meet
+// in that CU's L1.
+template <int METHOD, typename SRC, int KTILE, int SUBS>
+__global__ void __launch_bounds__(AP_BLOCK * SUBS)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
              const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
              const int32_t *__restrict__ row_order, bool skip_long, int64_t T, int64_t S,
-             const SRC *__restrict__ source, int64_t K, double *__restrict__ out, int lmax, int super_blocks, int item_tiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+             const SRC *__restrict__ source, int64_t K, double *__restrict__ out, int lmax, int super_blocks, int item_tiles, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    const int sub = SUBS > 1 ? (int)threadIdx.x / AP_BLOCK : 0, tid = SUBS > 1 ? (int)threadIdx.x % AP_BLOCK : (int)threadIdx.x;
+    char *smem = smem_all + (size_t)sub * (((sizeof(double) * (KTILE * PLAN_UMAX + lmax) + sizeof(uint16_t) * lmax) + 15) / 16 * 16);
     double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][PLAN_UMAX]
     double *sh_w = vals + KTILE * PLAN_UMAX;                              // [lmax] = entries of the largest planned block
     uint16_t *sh_loc = reinterpret_cast<uint16_t *>(sh_w + lmax);         // [lmax]
     constexpr int UPT = PLAN_UMAX / AP_BLOCK;                             // distinct columns per thread
     // XCD-aware block order: hardware block b runs on XCD b % 8; give every XCD a CONTIGUOUS range of
     // row blocks (= one spatial region), so that lines shared by neighbouring blocks stay in one L2
-    const int64_t n_blocks = (T + AP_BLOCK - 1) / AP_BLOCK;
-    const int64_t per_xcd = (n_blocks + 7) / 8;
-    int64_t lb = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int64_t n_blocks = (T + AP_BLOCK - 1) / AP_BLOCK;           // row blocks
+    const int64_t n_groups = (n_blocks + SUBS - 1) / SUBS;            // workgroups' worth of them
+    const int64_t per_xcd = (n_groups + 7) / 8;
+    int64_t lg = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     int64_t k_begin = 0, k_end = K;
     if (super_blocks > 0) {
         // L2-blocked order (round 5).  A block of 256 rows uses ~4 of the 16 source values of every 128-byte line it touches
@@ -845,15 +855,20 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         const int64_t item = rem / super_blocks, b = rem - item * super_blocks;
         const int64_t local = sup * super_blocks + b;
         if (local >= per_xcd) return;
-        lb = (int64_t)(blockIdx.x & 7) * per_xcd + local;
+        lg = (int64_t)(blockIdx.x & 7) * per_xcd + local;
         k_begin = item * KTILE * item_tiles;
         k_end = k_begin + (int64_t)KTILE * item_tiles < K ? k_begin + (int64_t)KTILE * item_tiles : K;
     }
-    if (lb >= n_blocks) return;
-    const int64_t row0 = lb * AP_BLOCK;
-    const int64_t t = row0 + threadIdx.x;
+    if (lg >= n_groups) return; // (uniform over the workgroup)
+    const int64_t lb = lg * SUBS + sub;
+    // (a sub-block without work -- past the last row block, or unplanned: too many entries / distinct columns, k_apply_direct takes
+    // those over its block list -- stays for the workgroup's barriers; SUBS == 1: it leaves)
+    const int64_t row0 = (lb < n_blocks ? lb : 0) * AP_BLOCK;
+    const int nu = lb < n_blocks ? nuniq[lb] : -1;
+    if (SUBS == 1 && nu < 0) return;
+    const bool active = nu >= 0;
+    const int64_t t = active ? row0 + tid : T;
     const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
-    const int nu = nuniq[lb];
     int s = 0, e = 0;
     if (t < T) {
         s = indptr[t];
@@ -861,10 +876,9 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
     const bool is_long = skip_long && (e - s > APPLY_LONG); // reduced by k_apply_long
     const int64_t t_out = (t < T && row_order) ? (int64_t)row_order[t] : t;
-    if (nu < 0) return; // unplanned block (too many entries / distinct columns): k_apply_direct over the block list
     // stage the block's entries once
-    const int seg0 = indptr[row0], seg1 = indptr[row_end];
-    for (int j = seg0 + threadIdx.x; j < seg1; j += AP_BLOCK) {
+    const int seg0 = indptr[row0], seg1 = active ? indptr[row_end] : seg0;
+    for (int j = seg0 + tid; j < seg1; j += AP_BLOCK) {
         sh_w[j - seg0] = data[j];
         sh_loc[j - seg0] = loc[j];
     }
@@ -872,8 +886,8 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     int64_t mycol[UPT];
 #pragma unroll
     for (int q = 0; q < UPT; q++) {
-        const int u = q * AP_BLOCK + threadIdx.x;
-        mycol[q] = u < nu ? (int64_t)ucol[lb * PLAN_UMAX + u] : -1;
+        const int u = q * AP_BLOCK + tid;
+        mycol[q] = (u < nu && !(dbg & 1)) ? (int64_t)ucol[lb * PLAN_UMAX + u] : -1; // (dbg: measurement switches, XR_PLAN_DBG)
     }
     __syncthreads();
     double normsum = 0.0;
@@ -899,7 +913,7 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         int my_nan = 0;
 #pragma unroll
         for (int q = 0; q < UPT; q++) {
-            const int u = q * AP_BLOCK + threadIdx.x;
+            const int u = q * AP_BLOCK + tid;
             if (u < nu) {
 #pragma unroll
                 for (int kk = 0; kk < KTILE; kk++) {
@@ -943,13 +957,25 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                         else acc[kk] += v[kk] * w;
                     }
                 }
+                const bool defined = e > s && wsum_row != 0;
+                double *o = out + k0 * T + t_out;
+                if (dbg & 2) { // (measurement: no stores -- the compiler must not know)
+                    if (acc[0] != 12345.678) continue;
+                }
+                if (kn == KTILE && !(dbg & 4)) {
+                    // whole tile: no per-variable branch around the stores.  Non-temporal: the result is written once and not
+                    // read here -- it should not push the source lines that neighbouring row blocks still need out of the L2
+                    // (1M x 1M, K = 256: 1.52 -> 1.44 ms qhull-numbered, 1.04 -> 0.99 ms lattice-numbered; XR_PLAN_DBG=4: plain stores)
 #pragma unroll
-                for (int kk = 0; kk < KTILE; kk++) {
-                    if (kk < kn) {
-                        double r = NAN;
-                        if (e > s && wsum_row != 0) r = METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk];
-                        out[(k0 + kk) * T + t_out] = r;
-                    }
+                    for (int kk = 0; kk < KTILE; kk++)
+                        __builtin_nontemporal_store(defined ? (METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk]) : NAN, &o[kk * T]);
+                } else if (kn == KTILE) {
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++) o[kk * T] = defined ? (METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk]) : NAN;
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++)
+                        if (kk < kn) o[kk * T] = defined ? (METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk]) : NAN;
                 }
             }
         } else if (t < T && !is_long) {
@@ -1764,29 +1790,54 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             ensure_plan(csr);
             // LDS: one tile of distinct source values + the block's entries (weight + 16-bit local column); sized
             // for the largest planned block, so typical matrices run three blocks per CU instead of two
-            const size_t shmem_max = sizeof(double) * (PLAN_KT * PLAN_UMAX + PLAN_LMAX) + sizeof(uint16_t) * PLAN_LMAX;
-            const size_t shmem = sizeof(double) * (PLAN_KT * PLAN_UMAX + csr->plan_lmax) + sizeof(uint16_t) * csr->plan_lmax;
-            // (applies run concurrently under the shared scope: the one-time attribute is set behind a once_flag)
-            static std::once_flag attr_once;
-            hipError_t attr_rc = hipSuccess;
-            std::call_once(attr_once, [&] {
-                attr_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_max);
-            });
-            XR_HIP(attr_rc);
-            // L2-blocked order (k_apply_plan): super tiles of `super_blocks` row blocks x items of `item_tiles` variable tiles
-            static const int super_blocks = getenv("XR_APPLY_SUPER") ? std::max(0, atoi(getenv("XR_APPLY_SUPER"))) : 0; // tuning hooks
-            static const int item_tiles = getenv("XR_APPLY_ITEM") ? std::max(1, atoi(getenv("XR_APPLY_ITEM"))) : 1;
-            int64_t plan_grid = (div_up(csr->n, AP_BLOCK) + 7) / 8 * 8;
+            // (tuning hooks: row blocks per workgroup, variables per tile, the L2-blocked order of k_apply_plan: super tiles of
+            // `super_blocks` workgroups x items of `item_tiles` variable tiles)
+            static const int plan_subs = getenv("XR_PLAN_SUBS") ? (atoi(getenv("XR_PLAN_SUBS")) == 4 ? 4 : atoi(getenv("XR_PLAN_SUBS")) == 2 ? 2 : 1) : PLAN_SUBS_DEFAULT;
+            // default: items of 64 variables, super tile = the XCD's whole range of row blocks -- every XCD sweeps its row blocks
+            // once per 64 variables (the source planes in flight: 0.5 GB instead of all K of them; what the host-side split
+            // into groups of 128 variables did until round 4, without its extra launches, forks and joins)
+            static const int super_env = getenv("XR_APPLY_SUPER") ? std::max(0, atoi(getenv("XR_APPLY_SUPER"))) : -1;
+            static const int item_env = getenv("XR_APPLY_ITEM") ? std::max(1, atoi(getenv("XR_APPLY_ITEM"))) : 0;
+            const int plan_dbg = getenv("XR_PLAN_DBG") ? atoi(getenv("XR_PLAN_DBG")) : 0; // measurement: 1 no gathers, 2 no stores, 4 non-temporal stores
+            // LDS per row block: a tile of distinct source values + the block's entries (weight + 16-bit local column), sized for
+            // the largest planned block of the matrix.  4 row blocks per workgroup: tiles of 4 variables (4 x 34 KB)
+            const int plan_kt = plan_subs > 1 ? 4 : PLAN_KT;
+            auto sub_bytes = [&](int kt, int lmax) {
+                return ((sizeof(double) * ((size_t)kt * PLAN_UMAX + lmax) + sizeof(uint16_t) * lmax) + 15) / 16 * 16;
+            };
+            const size_t shmem = sub_bytes(plan_kt, csr->plan_lmax) * plan_subs;
+            XR_REQUIRE(shmem <= (size_t)160 * 1024, XR_ERR_LIMIT, "internal: apply plan needs %zu bytes of LDS", shmem);
+            // (dynamic LDS beyond 64 KB has to be allowed per kernel; applies run concurrently under the shared scope, so the
+            // high-water mark per instantiation sits behind a mutex)
+            auto allow_lds = [&](const void *kernel, size_t &granted) {
+                static std::mutex attr_mutex;
+                std::lock_guard<std::mutex> lock(attr_mutex);
+                if (shmem <= granted) return;
+                XR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+                granted = shmem;
+            };
+            static size_t granted1 = 0, granted2 = 0, granted4 = 0;
+            if (plan_subs == 4) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 4>), granted4);
+            else if (plan_subs == 2) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 2>), granted2);
+            else allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT, 1>), granted1);
+            const int64_t n_groups = div_up(div_up(csr->n, AP_BLOCK), plan_subs);
+            const int item_tiles = item_env > 0 ? item_env : 64 / plan_kt;
+            const int super_blocks = super_env >= 0 ? super_env : (K > (int64_t)plan_kt * item_tiles ? (int)std::min<int64_t>((n_groups + 7) / 8, 1 << 30) : 0);
+            int64_t plan_grid = (n_groups + 7) / 8 * 8;
             if (super_blocks > 0) {
-                const int64_t per_xcd = (div_up(csr->n, AP_BLOCK) + 7) / 8;
-                const int64_t n_items = div_up(K, (int64_t)PLAN_KT * item_tiles);
+                const int64_t per_xcd = (n_groups + 7) / 8;
+                const int64_t n_items = div_up(K, (int64_t)plan_kt * item_tiles);
                 plan_grid = 8 * div_up(per_xcd, super_blocks) * super_blocks * n_items;
             }
-            XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, PLAN_KT>), dim3((unsigned)plan_grid), dim3(AP_BLOCK),
-                      shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(),
-                      csr->plan_nuniq.get(), csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src,
-                      K, out, csr->plan_lmax, super_blocks, item_tiles);
+#define XR_PLAN_LAUNCH(KT, SUBS)                                                                                                     \
+    XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, KT, SUBS>), dim3((unsigned)plan_grid), dim3(AP_BLOCK * SUBS), shmem,            \
+              csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),                   \
+              csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out, csr->plan_lmax, super_blocks,      \
+              item_tiles, plan_dbg)
+            if (plan_subs == 4) XR_PLAN_LAUNCH(4, 4);
+            else if (plan_subs == 2) XR_PLAN_LAUNCH(4, 2);
+            else XR_PLAN_LAUNCH(PLAN_KT, 1);
+#undef XR_PLAN_LAUNCH
             if (csr->plan_n_unplanned > 0) {
                 // the few blocks the plan could not take (hull slivers: too many entries or distinct columns): direct
                 // gathers, parallel over the variable tiles as well so that no thread walks a long row K / 8 times
@@ -1840,7 +1891,9 @@ static void apply_dispatch(const xr_csr *csr, int method, double p, const SRC *s
     // time instead of from all K of them.  Measured at K = 256 on the 1M x 1M benchmark matrix: 2.21 -> 2.07 ms with
     // qhull-numbered (scattered) columns, 1.10 -> 1.13 ms with lattice-numbered ones; smaller groups lose more on
     // re-staging the entries than they gain.
-    static const int64_t kgroup = getenv("XR_APPLY_KGROUP") ? atoll(getenv("XR_APPLY_KGROUP")) : 128; // tuning hook
+    // (Round 5: the many-variable kernel orders its own work by groups of 64 variables -- k_apply_plan, L2-blocked order -- so the
+    // host-side split is off by default; XR_APPLY_KGROUP=128 restores it.)
+    static const int64_t kgroup = getenv("XR_APPLY_KGROUP") ? atoll(getenv("XR_APPLY_KGROUP")) : 0; // tuning hook
     if (kgroup > 0 && K > kgroup + kgroup / 2) {
         for (int64_t k0 = 0; k0 < K; k0 += kgroup) {
             const int64_t kc = (K - k0) < kgroup + kgroup / 2 ? (K - k0) : kgroup; // (no short tail group)
