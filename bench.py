@@ -914,7 +914,7 @@ def multi_workload(args, backend, strong, K, steps, warmup, both_exchanges, setu
 
         def step():
             if K == 1:
-                rg.rebuild()
+                return rg.rebuild_regrid_local(local)  # (weights + partial states: one engine call)
             return rg.regrid_local(local)
 
         for _ in range(warmup):
@@ -1196,8 +1196,7 @@ def run_projection(args):
             local = rg.local_source(data)
 
             def step():
-                rg.rebuild()
-                return rg.regrid_local(local)
+                return rg.rebuild_regrid_local(local)
 
             for _ in range(warmup):
                 step()

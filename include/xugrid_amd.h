@@ -409,6 +409,11 @@ int xr_partial_components(int method);
 int xr_partial_combine_is_max(int method);
 int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, int source_dtype, int64_t K,
                          double *out_dev, int rows_layout);
+/* Weight build + partial state of ONE call: what a rank of the sharded regridder does per rebuild (xugrid/regrid/regridder.py:386-398
+ * + the per-target reduction of :41-67 restricted to the rank's columns).  As xr_overlap_apply_dev: for K = 1 the partial-state
+ * kernel is enqueued before the host has read the matrix' sizes back, so the one host round trip of the build hides behind it. */
+int xr_overlap_partial_dev(xr_mesh *tree, xr_mesh *query, int relative, int method, const void *source_dev, int source_dtype,
+                           int64_t K, double *out_dev, int rows_layout, xr_csr **out);
 /* identity element of the combine step in the same layouts (buffers of targets a rank has no weight for) */
 int xr_partial_fill_identity_dev(int method, double *planes_dev, int64_t K, int64_t T);
 /* out_dev float64 [K, T] from combined planes [C, K, T] */

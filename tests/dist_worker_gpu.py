@@ -30,10 +30,14 @@ def main():
     data = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(3)])
     results = {}
     for exchange in ("sparse", "dense"):
-        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, exchange=exchange)
+        # (always_exchange: a one-rank group would otherwise skip the collective -- here the RCCL calls are the point)
+        rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, exchange=exchange, always_exchange=True)
         results["mean_" + exchange] = rg.regrid(data)
         rg.rebuild()
         results["mean_rebuilt_" + exchange] = rg.regrid(data.astype(np.float32))
+        # weight build + partial states as one engine call (xr_overlap_partial_dev): one variable rides on the build, three do not
+        for k in (1, 3):
+            results[f"mean_fused{k}_" + exchange] = rg.rebuild_regrid_local(rg.local_source(data[:k])).cpu().numpy()[:, : rg.n_target]
     rg.to_file(os.path.join(out_dir, "sharded"))  # (dense exchange stored; read back as sparse)
     dist.barrier()
     results["mean_from_file"] = ShardedOverlapRegridder.from_file(
@@ -47,6 +51,8 @@ def main():
         for exchange in ("sparse", "dense"):
             rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, exchange=exchange, method=method, k_tile=2)
             results[f"m_{method}_{exchange}"] = rg.regrid(data7)
+            # one variable at a time: the wave-window partial-state kernel, one specialisation per reducer
+            results[f"m1_{method}_{exchange}"] = np.stack([rg.regrid(data7[k]) for k in range(data7.shape[0])])
     results["int_source"] = ShardedOverlapRegridder(sxy, sf, txy, tf, backend).regrid(np.nan_to_num(10 * data).astype(np.int32))
     for method in ("mode", "median", "max_overlap", "minimum"):
         results["tp_" + method] = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method=method).regrid(data)

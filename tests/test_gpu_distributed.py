@@ -37,6 +37,8 @@ def test_sharded_and_target_partitioned_regridders_rccl(hip, oracle, tmp_path):
         # partial sums + finalise: same additions as the sequential loop on one rank
         np.testing.assert_allclose(out["mean_" + exchange], exp, rtol=1e-13, equal_nan=True)
         np.testing.assert_allclose(out["mean_rebuilt_" + exchange], exp32, rtol=1e-13, equal_nan=True)
+        for k in (1, 3):  # rebuild + regrid as one engine call
+            assert np.array_equal(out[f"mean_fused{k}_" + exchange], out["mean_" + exchange][:k], equal_nan=True)
     assert np.array_equal(out["mean_sparse"], out["mean_dense"], equal_nan=True)
     assert np.array_equal(out["mean_sparse"], out["mean_from_file"], equal_nan=True)  # shard files, no meshes
     data7 = np.stack([meshgen.smooth_field(sxy[sf].mean(axis=1), k, 0.05) for k in range(7)])
@@ -51,6 +53,8 @@ def test_sharded_and_target_partitioned_regridders_rccl(hip, oracle, tmp_path):
             assert np.array_equal(np.isnan(got), np.isnan(single)), (method, exchange)
             np.testing.assert_allclose(got, single, rtol=1e-9 if method == "harmonic_mean" else 1e-12, equal_nan=True,
                                        err_msg=f"{method} {exchange}")
+            # K = 1 (k_apply_partial_w1, specialised per reducer): the same additions in the same order as the K = 7 kernels
+            assert np.array_equal(out[f"m1_{method}_{exchange}"], got, equal_nan=True), (method, exchange)
     np.testing.assert_allclose(out["int_source"], oracle.regrid_csr("mean", np.nan_to_num(10 * data).astype(np.int32).astype(np.float64),
                                                                   a, s_, indptr, tf.shape[0]), rtol=1e-12, equal_nan=True)
     for method in ("mode", "median", "max_overlap", "minimum"):

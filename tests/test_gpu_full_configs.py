@@ -276,3 +276,27 @@ def test_config3_barycentric_4m_targets(hip, oracle):
     flat = np.repeat(indptr[sample] - (np.cumsum(cnt) - cnt), cnt) + np.arange(cnt.sum())
     assert np.array_equal(np.bincount(ot, minlength=sample.size), cnt), "row lengths differ from the oracle"
     assert np.array_equal(indices[flat], os_) and np.array_equal(data[flat], ow)
+
+
+def test_full_size_mixed_and_raster_pairs_bit_exact(hip, oracle):
+    """The one-round-trip pipeline for non-triangle pairs at full size (round 5): a ~1M-face mixed triangle / quadrilateral mesh
+    onto a rotated one, and the 1M-triangle benchmark source onto a 1000 x 1000 raster (BASELINE config 1's shape at scale:
+    quadrilateral targets) -- pair sets and areas equal to the oracle's bit for bit, row sums = target areas."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.mixed_mesh(660_000, 0)
+    txy, tf = meshgen.mixed_mesh(660_000, 1, 30.0, 0.7)
+    assert 950_000 < sf.shape[0] < 1_050_000
+    cases = [(sxy, sf, txy, tf)]
+    bxy, bf = meshgen.triangle_mesh(500_000, 0, delaunay=False)
+    edges = np.linspace(0.02, 0.98, 1001)
+    rxy, rf = meshgen.quad_mesh(edges, edges)
+    cases.append((bxy, bf, rxy, rf))
+    for s_xy, s_f, q_xy, q_f in cases:
+        ms, mq = E.DeviceMesh(s_xy, s_f, -1), E.DeviceMesh(q_xy, q_f, -1)
+        csr = ms.overlap(mq)
+        data, idx, indptr = csr.download()
+        oq, os_, oa = oracle.CellTree2d(s_xy, s_f, -1).intersect_faces(q_xy, q_f, -1)
+        assert np.array_equal(np.repeat(np.arange(csr.n), np.diff(indptr)), oq)
+        assert np.array_equal(idx, os_) and np.array_equal(data, oa)
+        np.testing.assert_allclose(np.bincount(oq, weights=data, minlength=csr.n), mq.area(), rtol=1e-9)

@@ -238,6 +238,30 @@ def test_overlap_fused_matches_general_chain(hip, monkeypatch):
             np.testing.assert_array_equal(x, y)
 
 
+def test_overlap_fused_pipeline_quads_and_mixed_meshes(hip, oracle, monkeypatch):
+    """Dense meshes of up to four nodes per face -- quadrilaterals, mixed triangle / quadrilateral meshes with -1 in the fourth slot
+    (the flexible-mesh case), a raster's quads against triangles -- take the one-round-trip pipeline of xr_overlap_fused.h with
+    the register / LDS clip of k_clip_small inside the persistent queue kernel (round 5).  Every pair: the oracle's matrix bit for
+    bit, and the identical CSR through the general kernel chain (XR_OVERLAP_FUSED=0); big faces (coarse targets), relative
+    weights, a mixed mesh against itself."""
+    mxy, mf = meshgen.mixed_mesh(9000, 3)
+    nxy, nf = meshgen.mixed_mesh(7000, 4, 25.0, 0.8)
+    txy, tf = meshgen.triangle_mesh(6000, 5, 30.0, 0.7)
+    qxy, qf = meshgen.quad_mesh(np.linspace(0.1, 0.9, 61), np.linspace(0.15, 0.85, 47))
+    cxy, cf = meshgen.mixed_mesh(150, 6, 10.0, 0.9)  # coarse: every target is a big face on the fine source
+    assert (mf[:, 3] >= 0).any() and (mf[:, 3] < 0).any()
+    pairs = [(mxy, mf, nxy, nf), (nxy, nf, mxy, mf), (mxy, mf, txy, tf), (txy, tf, mxy, mf), (txy, tf, qxy, qf), (qxy, qf, nxy, nf),
+             (mxy, mf, cxy, cf), (mxy, mf, mxy, mf)]
+    for sxy, sf, qx, qfc in pairs:
+        for relative in (False, True):
+            monkeypatch.delenv("XR_OVERLAP_FUSED", raising=False)
+            _, fused = assert_overlap_parity(hip, oracle, sxy, sf, qx, qfc, relative=relative)
+            monkeypatch.setenv("XR_OVERLAP_FUSED", "0")
+            general = gpu_triplets(hip, sxy, sf, qx, qfc, relative)
+            assert np.array_equal(fused[0], general[3]) and np.array_equal(fused[1], general[2]) and np.array_equal(fused[2], general[4])
+    monkeypatch.delenv("XR_OVERLAP_FUSED", raising=False)
+
+
 def test_overlap_meshes_sharing_nodes(hip, oracle):
     """The reference clips a pair only if the two faces' EXACT bounding boxes overlap strictly (numba_celltree
     boxes_intersect, oracle/xr_oracle.c:530): faces that merely touch -- a mesh against itself: the neighbours across a

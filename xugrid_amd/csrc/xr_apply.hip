@@ -1520,6 +1520,87 @@ k_apply_partial(int method, const int32_t *__restrict__ indptr, const int32_t *_
     }
 }
 
+// K = 1, one specialisation per decomposable reducer (round 5): the partial state of 64 stored rows per WAVE through the wave's
+// private LDS window, exactly as k_apply_rows1 reduces them -- the CSR segment of the 64 rows is contiguous: column and weight
+// loaded coalesced, the source value gathered by the same lane and parked next to the weight, then every lane walks ITS row in
+// CSR order (the same additions in the same order as k_apply_partial's thread-per-row loop, so the states are bit-identical).
+// With the reducer a run-time switch this form was slower than the plain kernel (73 against 61 us, round 4: four state
+// components and a switch per entry in the walk); as a template the walk of `mean` is two selects per entry.
+// Rows beyond APPLY_LONG entries are left to k_apply_partial_long.
+template <int METHOD, typename SRC>
+__global__ void __launch_bounds__(AP_BLOCK)
+k_apply_partial_w1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
+                   const int32_t *__restrict__ row_order, int64_t T, int64_t S, const SRC *__restrict__ source,
+                   double *__restrict__ out, bool rows_layout, bool skip_long, const int32_t *__restrict__ gate) {
+    __shared__ double2 sh_win[AP_BLOCK / 64][W1_CAP]; // (.x = weight, .y = source value)
+    if (gate && *gate == 0) return; // (enqueued behind a weight build whose attempt failed: the host redoes both)
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)(gridDim.x - 1 - blockIdx.x) * (AP_BLOCK / 64) + wib) * 64;
+    if (row0 >= T) return;
+    const int64_t t = row0 + lane;
+    int s = 0, e = 0;
+    if (t < T) {
+        s = indptr[t];
+        e = indptr[t + 1];
+    }
+    const bool skip = skip_long && (e - s > APPLY_LONG);
+    const int seg0 = __shfl(s, 0, 64);
+    int seg1 = e;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) seg1 = max(seg1, __shfl_xor(seg1, d, 64));
+    if (skip) e = s;
+    const bool jumpy = __any(skip);
+    double2 *win = sh_win[wib];
+    auto next_chunk = [&](int c0) -> int { // first entry any lane still needs at or behind c0 (skipped long rows are not streamed)
+        if (!jumpy) return c0;
+        int mine = (e > s && e > c0) ? (s > c0 ? s : c0) : INT_MAX;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) mine = min(mine, __shfl_xor(mine, d, 64));
+        return mine;
+    };
+    PartialState st = partial_identity(METHOD);
+    for (int c0 = seg0; c0 < seg1; c0 += W1_CAP) {
+        c0 = next_chunk(c0);
+        if (c0 >= seg1) break;
+        {
+            constexpr int PER = W1_CAP / 64;
+            int col[PER];
+            double w[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) {
+                const int j = c0 + u * 64 + lane;
+                col[u] = j < seg1 ? indices[j] : -1;
+                w[u] = j < seg1 ? data[j] : 0.0;
+            }
+            double v[PER];
+#pragma unroll
+            for (int u = 0; u < PER; u++) v[u] = col[u] >= 0 ? ld_src(source, (int64_t)col[u]) : 0.0;
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (col[u] >= 0) win[u * 64 + lane] = make_double2(w[u], v[u]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int a = s > c0 ? s : c0, b = e < c0 + W1_CAP ? e : c0 + W1_CAP;
+        for (int j = a; j < b; j++) {
+            const double2 wv = win[j - c0];
+            partial_add(METHOD, st, wv.y, wv.x); // (METHOD is a constant: the switch folds to the reducer's own lines)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // (the window is overwritten by the next chunk)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (t < T && !skip) {
+        constexpr int C = METHOD == XR_GEOMETRIC_MEAN ? 4 : 2;
+        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            if (rows_layout) out[t_out * C + c] = st.c[c];
+            else out[(int64_t)c * T + t_out] = st.c[c];
+        }
+    }
+}
+
 // the listed long rows (hull slivers: thousands of entries): one wave per (row, variable), lanes stride the row,
 // butterfly combine of the states (fixed order)
 // KT variables per thread (K >= KT): the row's entries are read once per tile instead of once per variable, the KT
@@ -1656,7 +1737,9 @@ __global__ void __launch_bounds__(256)
 k_apply_partial_long(int method, const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                      const double *__restrict__ data, const int32_t *__restrict__ row_order,
                      const int32_t *__restrict__ long_rows, const int32_t *__restrict__ n_long, int64_t T, int64_t S,
-                     const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool rows_layout) {
+                     const SRC *__restrict__ source, int64_t K, double *__restrict__ out, bool rows_layout,
+                     const int32_t *__restrict__ gate = nullptr) {
+    if (gate && *gate == 0) return; // (see k_apply_partial_w1)
     const int lane = threadIdx.x & 63;
     const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (int64_t)gridDim.x * 4;
     const int64_t k = blockIdx.y;
@@ -2779,13 +2862,17 @@ int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,
 int xr_partial_components(int method) { return partial_components(method); }
 int xr_partial_combine_is_max(int method) { return partial_is_max(method) ? 1 : 0; }
 
-int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, int source_dtype, int64_t K,
-                         double *out_dev, int rows_layout) {
-    XR_API_BEGIN
-    XR_REQUIRE(csr && out_dev, XR_ERR_INVALID, "xr_apply_partial_dev: NULL argument");
+} // extern "C"
+
+// the partial state of every stored row (xr_apply_partial_dev; also enqueued right behind a weight build by
+// xr_overlap_partial_dev, then gated like the early apply: csr->apply_gated)
+void xr::csr_partial_dev(const xr_csr *csr, int method, const void *source_dev, int source_dtype, int64_t K, double *out_dev,
+                         int rows_layout) {
     XR_REQUIRE(partial_components(method) > 0, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
     XR_REQUIRE(source_dtype == XR_F64 || source_dtype == XR_F32, XR_ERR_INVALID, "unsupported source dtype id %d", source_dtype);
     XR_REQUIRE(K >= 0 && K < 65536, XR_ERR_LIMIT, "xr_apply_partial_dev: K out of range (tile the variables)");
+    const int32_t *gate = csr->apply_gated ? csr->n_long.get() + 1 : (const int32_t *)nullptr;
+    XR_REQUIRE(!gate || K == 1, XR_ERR_INVALID, "internal: a gated partial apply is one variable");
     if (csr->n > 0 && K > 0) {
         XR_REQUIRE(source_dev || csr->m == 0, XR_ERR_INVALID, "xr_apply_partial_dev: NULL source");
         DevBuf<char> permuted;
@@ -2813,6 +2900,31 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
                 XR_LAUNCH("apply_partial", (k_apply_partial_kt<float, PKT>), grid, dim3(256), 0, method, csr->indptr.get(),
                           csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                           static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
+        } else if (K == 1 && !one_var) {
+            // one variable: the wave-window kernel, one specialisation per reducer
+            dim3 grid(div_up(csr->n, AP_BLOCK));
+#define XR_PARTIAL_W1(M)                                                                                                            \
+    case M:                                                                                                                         \
+        if (source_dtype == XR_F64)                                                                                                 \
+            XR_LAUNCH("apply_partial", (k_apply_partial_w1<M, double>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),                 \
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,                                       \
+                      static_cast<const double *>(source_dev), out_dev, rows_layout != 0, csr->has_long, gate);                     \
+        else                                                                                                                        \
+            XR_LAUNCH("apply_partial", (k_apply_partial_w1<M, float>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),                  \
+                      csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,                                       \
+                      static_cast<const float *>(source_dev), out_dev, rows_layout != 0, csr->has_long, gate);                      \
+        break;
+            switch (method) {
+                XR_PARTIAL_W1(XR_MEAN)
+                XR_PARTIAL_W1(XR_FIRST_ORDER_CONSERVATIVE)
+                XR_PARTIAL_W1(XR_SUM)
+                XR_PARTIAL_W1(XR_HARMONIC_MEAN)
+                XR_PARTIAL_W1(XR_GEOMETRIC_MEAN)
+                XR_PARTIAL_W1(XR_MINIMUM)
+                XR_PARTIAL_W1(XR_MAXIMUM)
+            default: XR_REQUIRE(false, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
+            }
+#undef XR_PARTIAL_W1
         } else {
         dim3 grid(div_up(csr->n, 256), (unsigned)K);
         if (source_dtype == XR_F64)
@@ -2829,13 +2941,22 @@ int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
             if (source_dtype == XR_F64)
                 XR_LAUNCH("apply_partial_long", k_apply_partial_long<double>, lgrid, dim3(256), 0, method, csr->indptr.get(),
                           csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
-                          csr->n, csr->m, static_cast<const double *>(source_dev), K, out_dev, rows_layout != 0);
+                          csr->n, csr->m, static_cast<const double *>(source_dev), K, out_dev, rows_layout != 0, gate);
             else
                 XR_LAUNCH("apply_partial_long", k_apply_partial_long<float>, lgrid, dim3(256), 0, method, csr->indptr.get(),
                           csr->indices.get(), csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(),
-                          csr->n, csr->m, static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0);
+                          csr->n, csr->m, static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, gate);
         }
     }
+}
+
+extern "C" {
+
+int xr_apply_partial_dev(const xr_csr *csr, int method, const void *source_dev, int source_dtype, int64_t K,
+                         double *out_dev, int rows_layout) {
+    XR_API_BEGIN
+    XR_REQUIRE(csr && out_dev, XR_ERR_INVALID, "xr_apply_partial_dev: NULL argument");
+    csr_partial_dev(csr, method, source_dev, source_dtype, K, out_dev, rows_layout);
     dev_call_done();
     XR_API_END
 }

@@ -153,6 +153,7 @@ void flush_pending_points(); // launch the deferred source-side kernels of pendi
 void mesh_read_stats(xr_mesh *mesh, bool need_exact = false); // need_exact: statistics over ALL faces (sampled ones are redone)
 // the apply of a finished (or, K = 1, of a just-enqueued) matrix on the calling thread's launch stream (xr_apply.hip)
 void csr_apply_dev(const xr_csr *csr, int method, double percentile, const void *src_dev, int dtype, int64_t K, double *out_dev);
+void csr_partial_dev(const xr_csr *csr, int method, const void *src_dev, int dtype, int64_t K, double *out_dev, int rows_layout);
 void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev);    // connectivity.centroids into device memory [n_face*2]
 void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order = false); // CCW-normalised (or the caller's) connectivity [n_face*m]
 } // namespace xr

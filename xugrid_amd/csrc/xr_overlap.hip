@@ -786,6 +786,107 @@ k_clip(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, cons
 // current length); only the output polygon, whose write index is data dependent, is staged in
 // LDS ([vertex][thread]).  Half the LDS of the generic kernel -> twice the resident waves.
 // The arithmetic and its order are those of k_clip / the oracle.
+// -> the pair's area (AREA_OVERFLOW: more than MAXV vertices; before the confirmation of rounding dust); `out` = the
+// thread's LDS column, out[j * BLOCK]
+template <int MAXV, int BLOCK, bool TRI>
+__device__ __forceinline__ double clip_small_pair(const double2 *__restrict__ tf, int nt, const double *__restrict__ sf, int ns,
+                                                  double2 *out) {
+    double area = 0.0;
+    P2 in[MAXV];
+    P2 last{0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < MAXV; j++) {
+        if (j < nt) {
+            const double2 v = tf[j];
+            in[j] = P2{v.x, v.y};
+            last = in[j];
+        }
+    }
+    int length = nt;
+    bool overflow = false, empty = false;
+    // all clipper vertices up front (three independent 16-byte loads for triangles)
+    P2 sv_all[TRI ? 3 : 1];
+    if (TRI) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) sv_all[i] = load_p2(sf, i);
+    }
+    P2 r = TRI ? sv_all[2] : load_p2(sf, ns - 1);
+#pragma unroll
+    for (int i = 0; i < (TRI ? 3 : XR_MAX_FACE_NODES); i++) {
+        if (!TRI && i >= ns) break;
+        const P2 sv = TRI ? sv_all[i] : load_p2(sf, i);
+        const P2 U{sv.x - r.x, sv.y - r.y};
+        if (U.x == 0 && U.y == 0) continue;
+        const P2 N{-U.y, U.x};
+        int n_output = 0;
+        P2 a = last;
+        bool a_inside = sh_inside(a, r, U);
+#pragma unroll
+        for (int j = 0; j < MAXV; j++) {
+            if (j < length) {
+                // flat body: the only nested divergent region is the division of a crossing
+                const P2 b = in[j];
+                const P2 V{b.x - a.x, b.y - a.y};
+                const bool live = !(V.x == 0 && V.y == 0);
+                bool b_inside = sh_inside(b, r, U);
+                const bool cross = live && (b_inside != a_inside);
+                P2 pt{0.0, 0.0};
+                bool have_pt = false;
+                if (cross) have_pt = sh_intersection(a, V, r, N, pt);
+                // S-H emission: entering -> [pt] b ; inside -> b ; leaving -> pt, or (parallel-edge
+                // quirk) b, which then counts as inside
+                const bool quirk = cross && !b_inside && !have_pt;
+                if (cross && have_pt) {
+                    out[(n_output < MAXV ? n_output : MAXV) * BLOCK] = make_double2(pt.x, pt.y);
+                    n_output++;
+                    last = pt;
+                }
+                b_inside = b_inside || quirk;
+                if (live && b_inside) {
+                    out[(n_output < MAXV ? n_output : MAXV) * BLOCK] = make_double2(b.x, b.y);
+                    n_output++;
+                    last = b;
+                }
+                if (live) {
+                    a = b;
+                    a_inside = b_inside;
+                }
+            }
+        }
+        overflow = n_output > MAXV;
+        if (overflow) break;
+        if (n_output < 3) {
+            empty = true;
+            break;
+        }
+        length = n_output;
+#pragma unroll
+        for (int j = 0; j < MAXV; j++) {
+            if (j < length) {
+                const double2 v = out[j * BLOCK];
+                in[j] = P2{v.x, v.y};
+            }
+        }
+        r = sv;
+    }
+    if (overflow) return AREA_OVERFLOW;
+    if (!empty) {
+        const P2 a0 = in[0];
+        double ux = in[1].x - a0.x, uy = in[1].y - a0.y;
+#pragma unroll
+        for (int i = 2; i < MAXV; i++) {
+            if (i < length) {
+                const double vx = a0.x - in[i].x, vy = a0.y - in[i].y;
+                area += fabs(ux * vy - uy * vx);
+                ux = vx;
+                uy = vy;
+            }
+        }
+        area = 0.5 * area;
+    }
+    return area;
+}
+
 template <int MAXV, int BLOCK, bool TRI>
 __global__ void __launch_bounds__(BLOCK)
 k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len, const int32_t *__restrict__ q_off, int q_m,
@@ -811,100 +912,8 @@ k_clip_small(const double *__restrict__ q_fxy, const uint8_t *__restrict__ q_len
         const int nt = TRI ? 3 : q_len[t], ns = TRI ? 3 : s_len[s];
         const double2 *tf = reinterpret_cast<const double2 *>(q_fxy) + face_vertex_base(q_off, t, q_m);
         const double *sf = s_fxy + 2 * face_vertex_base(s_off, s, s_m);
-        P2 in[MAXV];
-        P2 last{0.0, 0.0};
-#pragma unroll
-        for (int j = 0; j < MAXV; j++) {
-            if (j < nt) {
-                const double2 v = tf[j];
-                in[j] = P2{v.x, v.y};
-                last = in[j];
-            }
-        }
-        int length = nt;
-        bool overflow = false, empty = false;
-        // all clipper vertices up front (three independent 16-byte loads for triangles)
-        P2 sv_all[TRI ? 3 : 1];
-        if (TRI) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) sv_all[i] = load_p2(sf, i);
-        }
-        P2 r = TRI ? sv_all[2] : load_p2(sf, ns - 1);
-#pragma unroll
-        for (int i = 0; i < (TRI ? 3 : XR_MAX_FACE_NODES); i++) {
-            if (!TRI && i >= ns) break;
-            const P2 sv = TRI ? sv_all[i] : load_p2(sf, i);
-            const P2 U{sv.x - r.x, sv.y - r.y};
-            if (U.x == 0 && U.y == 0) continue;
-            const P2 N{-U.y, U.x};
-            int n_output = 0;
-            P2 a = last;
-            bool a_inside = sh_inside(a, r, U);
-#pragma unroll
-            for (int j = 0; j < MAXV; j++) {
-                if (j < length) {
-                    // flat body: the only nested divergent region is the division of a crossing
-                    const P2 b = in[j];
-                    const P2 V{b.x - a.x, b.y - a.y};
-                    const bool live = !(V.x == 0 && V.y == 0);
-                    bool b_inside = sh_inside(b, r, U);
-                    const bool cross = live && (b_inside != a_inside);
-                    P2 pt{0.0, 0.0};
-                    bool have_pt = false;
-                    if (cross) have_pt = sh_intersection(a, V, r, N, pt);
-                    // S-H emission: entering -> [pt] b ; inside -> b ; leaving -> pt, or (parallel-edge
-                    // quirk) b, which then counts as inside
-                    const bool quirk = cross && !b_inside && !have_pt;
-                    if (cross && have_pt) {
-                        out[(n_output < MAXV ? n_output : MAXV) * BLOCK] = make_double2(pt.x, pt.y);
-                        n_output++;
-                        last = pt;
-                    }
-                    b_inside = b_inside || quirk;
-                    if (live && b_inside) {
-                        out[(n_output < MAXV ? n_output : MAXV) * BLOCK] = make_double2(b.x, b.y);
-                        n_output++;
-                        last = b;
-                    }
-                    if (live) {
-                        a = b;
-                        a_inside = b_inside;
-                    }
-                }
-            }
-            overflow = n_output > MAXV;
-            if (overflow) break;
-            if (n_output < 3) {
-                empty = true;
-                break;
-            }
-            length = n_output;
-#pragma unroll
-            for (int j = 0; j < MAXV; j++) {
-                if (j < length) {
-                    const double2 v = out[j * BLOCK];
-                    in[j] = P2{v.x, v.y};
-                }
-            }
-            r = sv;
-        }
-        if (overflow) {
-            area = AREA_OVERFLOW;
-            atomicAdd(overflow_count, 1);
-        } else if (!empty) {
-            const P2 a0 = in[0];
-            double ux = in[1].x - a0.x, uy = in[1].y - a0.y;
-#pragma unroll
-            for (int i = 2; i < MAXV; i++) {
-                if (i < length) {
-                    const double vx = a0.x - in[i].x, vy = a0.y - in[i].y;
-                    area += fabs(ux * vy - uy * vx);
-                    ux = vx;
-                    uy = vy;
-                }
-            }
-            area = 0.5 * area;
-        }
+        area = clip_small_pair<MAXV, BLOCK, TRI>(tf, nt, sf, ns, out);
+        if (area == AREA_OVERFLOW) atomicAdd(overflow_count, 1);
         if (area > 0 && area <= dust && !pair_passes_box_and_sat(tf, nt, reinterpret_cast<const double2 *>(sf), ns)) area = 0.0;
         cand_area[c] = area;
     }
@@ -1507,7 +1516,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     // A/B on one box): the HBM bytes drop as intended, but the assembly becomes three passes of dependent loads (stretch
     // count -> survivors) with returning LDS atomics -- 0.066 -> 0.087 ms -- and the clip pays 2 us for the ranking:
     // step 0.582 -> 0.603 ms.  Kept as a switch, off by default.
-    const bool compact = scan_bases && getenv("XR_CLIP_COMPACT") && atoi(getenv("XR_CLIP_COMPACT")) == 1;
+    const bool compact = scan_bases && tree->m == 3 && query->m == 3 && getenv("XR_CLIP_COMPACT") && atoi(getenv("XR_CLIP_COMPACT")) == 1;
     DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)(compact ? 1 : reg_capacity));
     DevBuf<int32_t> wave_surv((size_t)(compact ? reg_capacity / 64 + 1 : 1));
     DevBuf<double> cand_area((size_t)reg_capacity);
@@ -1516,7 +1525,10 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     csr->has_row_order = true;
     const int big_grid = engine().num_cu * 8;
     constexpr int CLIP_BLOCK = 256;
-    const size_t clip_shmem = (size_t)(TRI_MAXV + 1) * CLIP_BLOCK * sizeof(double2);
+    // triangle x triangle: the flag / compaction clip of xr_clip_tri.h; any other pair of dense meshes (<= 4 nodes per face:
+    // quadrilaterals, mixed meshes with fill values, a raster against triangles): the register / LDS clip of k_clip_small<8>
+    const bool tri_pair = tree->m == 3 && query->m == 3;
+    const size_t clip_shmem = tri_pair ? (size_t)(TRI_MAXV + 1) * CLIP_BLOCK * sizeof(double2) : (size_t)(8 + 1) * CLIP_BLOCK * sizeof(double2);
     const double dust = overlap_dust_threshold(tree, query);
     const size_t fill_shmem = sizeof(uint32_t) * (BM_WORDS + 256) + sizeof(int32_t) * (8 + BM_STAGE) + sizeof(uint16_t) * (BM_WORDS / 8);
     static bool attr_set = false;
@@ -1565,10 +1577,16 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                       big_list.get(), ctl_head + 2, cand_off.get(), cand_count.get(), big_tgt.get(), big_src.get(),
                       ctl_head + 1, big_capacity, pending.get(), ctl_head + 3, big_stage_entries(), slot_face.get());
             // (pairs of a face that did not fit are missing: the error is seen at the end and everything is redone)
-            XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
-                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
-                      big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3, (int32_t *)nullptr,
-                      (int32_t *)nullptr, dust);
+            if (tri_pair)
+                XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
+                          query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
+                          big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3, (int32_t *)nullptr,
+                          (int32_t *)nullptr, dust);
+            else
+                XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2, false, 1>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
+                          query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
+                          big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3, (int32_t *)nullptr,
+                          (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
             // (rows in face order: ranked inside search_big; their offsets: scanned inside row_fill_long -- two launches less
             // in what is the critical path of the whole weight build)
             // Two launches: the rows of at most ROW_BLOCK candidates (all but a handful) with 16 KB of LDS per block -- a block
@@ -1599,7 +1617,20 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         // 4 % faster because the chain was the critical path.  XR_CLIP_BPC overrides (tuning hook).
         static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5;
         static const bool clip_soa = getenv("XR_CLIP_SOA") && atoi(getenv("XR_CLIP_SOA")) == 1; // A/B switch: slot-major LDS columns
-        if (scan_bases && clip_soa)
+        if (!tri_pair) {
+            // (k_clip_small's LDS columns: 36 KB per block, four persistent blocks per CU)
+            const int bpc = std::min(clip_bpc, 4);
+            if (scan_bases)
+                XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 1, false, 1>), dim3(engine().num_cu * bpc), dim3(CLIP_BLOCK), clip_shmem,
+                          query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
+                          ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                          (const int32_t *)nullptr, blk_surv, (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
+            else
+                XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 0, false, 1>), dim3(engine().num_cu * bpc), dim3(CLIP_BLOCK), clip_shmem,
+                          query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
+                          ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                          (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
+        } else if (scan_bases && clip_soa)
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, true>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
@@ -1738,7 +1769,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
         // measurement / test switch back to the general kernel chain)
         const char *fused_env = getenv("XR_OVERLAP_FUSED");
         const bool fused_on = !(fused_env && atoi(fused_env) == 0);
-        if (fused_on && tree->m == 3 && query->m == 3 && T * SLOTS < ((int64_t)1 << 31)) {
+        if (fused_on && tree->m <= DENSE_MAX_NODES && query->m <= DENSE_MAX_NODES && T * SLOTS < ((int64_t)1 << 31)) {
             if (overlap_tri(tree, query, tree_area, relative, csr, tile, early)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
         }
@@ -1903,6 +1934,30 @@ int xr_overlap_apply_dev(xr_mesh *tree, xr_mesh *query, int relative, int method
         if (!early.done && K > 0) csr_apply_dev(csr, method, percentile, source_dev, source_dtype, K, out_dev);
         dev_call_done(); // (xr_set_async(1): returns with the apply in flight)
         host_stamp(9);
+    } catch (...) {
+        stream_sync();
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_overlap_partial_dev(xr_mesh *tree, xr_mesh *query, int relative, int method, const void *source_dev, int source_dtype,
+                           int64_t K, double *out_dev, int rows_layout, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && query && out, XR_ERR_INVALID, "xr_overlap_partial_dev: NULL argument");
+    XR_REQUIRE(K >= 0 && (source_dev || tree->n_face == 0 || K == 0) && (out_dev || query->n_face == 0 || K == 0), XR_ERR_INVALID,
+               "xr_overlap_partial_dev: NULL data argument");
+    xr_csr *csr = new xr_csr();
+    try {
+        EarlyApply early;
+        early.fn = [&](const xr_csr *c) { csr_partial_dev(c, method, source_dev, source_dtype, K, out_dev, rows_layout); };
+        static const bool early_off = getenv("XR_EARLY_APPLY") && atoi(getenv("XR_EARLY_APPLY")) == 0; // A/B switch
+        const bool can_early = !early_off && K == 1; // (one variable: the wave-window kernel needs no size on the host)
+        overlap(tree, query, relative != 0, csr, can_early ? &early : nullptr);
+        if (!early.done && K > 0) csr_partial_dev(csr, method, source_dev, source_dtype, K, out_dev, rows_layout);
+        dev_call_done();
     } catch (...) {
         stream_sync();
         delete csr;

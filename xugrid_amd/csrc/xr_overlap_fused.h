@@ -145,7 +145,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/,
 //   SOA: the LDS columns slot-major (slot s of lane l at s * BLOCK + l: every 16-byte access of a wave -- static or
 //   dynamic slot -- falls on the banks of its lane alone) instead of lane-major (7 consecutive slots per lane: the dynamic-index
 //   reads of a stage conflict, 18 % of the LDS cycles, round-3 PMC)
-template <int BLOCK, int COUNT, bool SOA = false>
+// KIND 1 (round 5): dense meshes of up to 4 nodes per face on either side (quadrilaterals, mixed triangle / quadrilateral
+// meshes with fill values -- the usual D-Flow FM mesh, a raster paired with a triangle mesh): the register / LDS clip of
+// k_clip_small<8> (the oracle's arithmetic in the oracle's order) inside the same persistent loop, so that these pairs take
+// the one-round-trip pipeline too.  q_len / s_len / q_m / s_m are only read then.
+template <int BLOCK, int COUNT, bool SOA = false, int KIND = 0>
 __global__ void __launch_bounds__(BLOCK)
 k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
                  const int32_t *__restrict__ rec_face, const int32_t *cand_tgt /* (rewritten in place when compacting) */,
@@ -157,15 +161,19 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
                  int32_t *__restrict__ wave_surv = nullptr /* COUNT == 1: survivors per 64-pair stretch; the output is then
                  COMPACTED: the survivors of stretch w are written to the front of the stretch, IN PLACE over the queue --
                  (target face, caller's source id, area) in cand_tgt / cand_src / cand_area at w * 64 + rank */,
-                 double dust = 0.0 /* areas up to this are confirmed by the reference's pre-clip tests (xr_overlap.hip: confirm_dust) */) {
+                 double dust = 0.0 /* areas up to this are confirmed by the reference's pre-clip tests (xr_overlap.hip: confirm_dust) */,
+                 const uint8_t *__restrict__ q_len = nullptr, const uint8_t *__restrict__ s_len = nullptr, int q_m = 3, int s_m = 3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int CS = SOA ? BLOCK : 1;
-    double2 *col = reinterpret_cast<double2 *>(smem) + (SOA ? threadIdx.x : threadIdx.x * (TRI_MAXV + 1)); // the lane's TRI_MAXV + 1 slots
-    __shared__ uint2 sh_lut[TRI_LUT];
+    constexpr int SMALL_MAXV = 8;
+    double2 *col = reinterpret_cast<double2 *>(smem) + (KIND == 1 || SOA ? threadIdx.x : threadIdx.x * (TRI_MAXV + 1)); // the lane's slots
+    __shared__ uint2 sh_lut[KIND == 1 ? 1 : TRI_LUT];
     if (skip_if) __builtin_amdgcn_s_setprio(3); // (the big faces' queue, on the side stream: issue priority over the main clip)
     if (skip_if && *skip_if > 0) return; // (big faces that did not fit their queue: the host redoes everything)
-    tri_lut_init(sh_lut);
-    __syncthreads();
+    if (KIND == 0) {
+        tri_lut_init(sh_lut);
+        __syncthreads();
+    }
     const int64_t n_cand = *n_cand_dev < capacity ? *n_cand_dev : capacity; // (a queue that overflowed is redone by the host)
     const int64_t n_chunks = (n_cand + BLOCK - 1) / BLOCK;
     const int64_t per_xcd = (n_chunks + 7) >> 3;
@@ -197,22 +205,38 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
     for (; slot < n_slots; slot += stride) {
         const int64_t c = chunk_of(slot) * BLOCK + tid;
         const bool active = c < n_cand;
-        P2 tv[3] = {{0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
         int sid = 0;
         const int cur_tq = n_tq;
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const double2 a = tfx[(int64_t)n_tq * 3 + j], b2 = sfx[(int64_t)n_s * 3 + j];
-                tv[j] = P2{a.x, a.y};
-                sv[j] = P2{b2.x, b2.y};
+        double area = 0.0;
+        if (KIND == 1) {
+            const int cur_s = n_s;
+            int nt = 0, ns = 0;
+            if (active) {
+                sid = rec_face[cur_s];
+                nt = q_len[cur_tq];
+                ns = s_len[cur_s];
             }
-            sid = rec_face[n_s];
-        }
-        load_idx(slot + stride, n_tq, n_s);
-        // (rounding dust of a pair the reference's pre-clip tests reject: the few lanes concerned fetch their vertices again)
-        double area = tri_clip_area<CS>(tv, sv, col, sh_lut, active);
-        {
+            load_idx(slot + stride, n_tq, n_s);
+            if (active) {
+                const double2 *tf = tfx + (int64_t)cur_tq * q_m;
+                const double2 *sf = sfx + (int64_t)cur_s * s_m;
+                area = clip_small_pair<SMALL_MAXV, BLOCK, false>(tf, nt, reinterpret_cast<const double *>(sf), ns, col);
+                if (area > 0 && area <= dust && !pair_passes_box_and_sat(tf, nt, sf, ns)) area = 0.0;
+            }
+        } else {
+            P2 tv[3] = {{0, 0}, {0, 0}, {0, 0}}, sv[3] = {{0, 0}, {0, 0}, {0, 0}};
+            if (active) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    const double2 a = tfx[(int64_t)n_tq * 3 + j], b2 = sfx[(int64_t)n_s * 3 + j];
+                    tv[j] = P2{a.x, a.y};
+                    sv[j] = P2{b2.x, b2.y};
+                }
+                sid = rec_face[n_s];
+            }
+            load_idx(slot + stride, n_tq, n_s);
+            // (rounding dust of a pair the reference's pre-clip tests reject: the few lanes concerned fetch their vertices again)
+            area = tri_clip_area<CS>(tv, sv, col, sh_lut, active);
             const bool suspicious = active && area > 0 && area <= dust;
             if (__any(suspicious)) {
                 if (suspicious && !pair_passes_box_and_sat(tfx + (int64_t)cur_tq * 3, 3, sfx + (int64_t)cand_src[c] * 3, 3)) area = 0.0;

@@ -280,6 +280,21 @@ class HipBackend:
         self._tgt_mesh.invalidate()
         return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
 
+    def rebuild_partial(self, source, method_id, rows_layout):
+        """``rebuild_weights()`` + ``partial()`` as ONE engine call (xr_overlap_partial_dev): for one variable the partial-state
+        kernel is enqueued before the host has read the sizes of the new matrix.  -> (weights, state tensor)."""
+        torch = self.torch
+        K, C = source.shape[0], self.n_components(method_id)
+        source, dtype = self._typed(source)
+        self._src_mesh.invalidate()
+        self._tgt_mesh.invalidate()
+        n = self._tgt_mesh.n_face
+        out = torch.empty((n, C * K) if rows_layout else (C, K, n), dtype=torch.float64, device=self.device)
+        self._handover()
+        weights = self._src_mesh.overlap_partial_dev(self._tgt_mesh, source.data_ptr(), dtype, K, out.data_ptr(), method_id,
+                                                     rows_layout, relative=self._relative)
+        return weights, out
+
     def download_weights(self, weights):
         """-> (data, indices, indptr, n, m) host arrays of this rank's shard of the weights."""
         data, indices, indptr = weights.download()
@@ -404,7 +419,7 @@ class ShardedOverlapRegridder:
     """
 
     def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="balanced", group=None,
-                 exchange="sparse", method="mean", k_tile=32, dist=None):
+                 exchange="sparse", method="mean", k_tile=32, dist=None, always_exchange=False):
         import torch
 
         if dist is None:  # (tests inject a loop-back implementation of the four collectives used here)
@@ -417,6 +432,9 @@ class ShardedOverlapRegridder:
                              f"(source-sharded reducers: {', '.join(SHARD_METHODS)})")
         self.exchange = exchange
         self.k_tile = max(1, int(k_tile))
+        # a group of ONE rank needs no collective: every state already is where it is combined.  always_exchange=True makes
+        # the calls all the same (tests of the RCCL plumbing on a one-GPU box)
+        self.always_exchange = bool(always_exchange)
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
@@ -540,6 +558,7 @@ class ShardedOverlapRegridder:
         self.dist, self.group, self.backend = dist, group, backend
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.k_tile = max(1, int(k_tile))
+        self.always_exchange = False
         with np.load(cls.shard_path(prefix, self.rank, self.world)) as f:
             if int(f["__shard_world"]) != self.world or int(f["__shard_rank"]) != self.rank:
                 raise ValueError("sharded weights were written by a job of a different shape")
@@ -610,26 +629,43 @@ class ShardedOverlapRegridder:
         ev.record()
         return ev
 
-    def _start_tile(self, src_tile):
+    def rebuild_regrid_local(self, local_source):
+        """``rebuild()`` followed by ``regrid_local()``: a time step of a moving-mesh job, and the benchmark's step.  With a
+        backend that offers it (``rebuild_partial``: the HIP backend) the weight build and the partial states of the first tile
+        of variables are one engine call."""
+        K = local_source.shape[0]
+        if not hasattr(self.backend, "rebuild_partial") or K > self.k_tile:
+            self.rebuild()
+            return self.regrid_local(local_source)
+        self.weights, state = self.backend.rebuild_partial(local_source, self.method.method_id, self.exchange == "sparse")
+        return self._finish_tile(self._start_tile(local_source, state))
+
+    def _start_tile(self, src_tile, state=None):
         import torch
 
         be, mid, W = self.backend, self.method.method_id, self.world
         kt = src_tile.shape[0]
         if self.exchange == "sparse":
             # one row of C * kt values per touched target, rows grouped by owner rank
-            send = be.partial(self.weights, src_tile, mid, True)  # (T_local, C * kt)
+            send = state if state is not None else be.partial(self.weights, src_tile, mid, True)  # (T_local, C * kt)
+            if W == 1 and not self.always_exchange:
+                # a group of one rank: every state row already is where its owner combines it -- no collective call (a
+                # one-rank RCCL all-to-all is a device-to-device copy behind ~45 us of launch and bookkeeping)
+                return ("sparse", None, send, send, kt, None)
             recv = torch.empty((sum(self._recv_counts), send.shape[1]), dtype=send.dtype, device=send.device)
             t_begin = self._mark()
             work = self.dist.all_to_all_single(recv, send, output_split_sizes=self._recv_counts,
                                                input_split_sizes=self._send_counts, group=self.group, async_op=True)
             return ("sparse", work, recv, send, kt, t_begin)
-        part = be.partial(self.weights, src_tile, mid, False)  # (C, kt, T_local)
+        part = state if state is not None else be.partial(self.weights, src_tile, mid, False)  # (C, kt, T_local)
         t_pad = self.t_chunk * W
         nd = be.identity(mid, kt, t_pad)  # dense exchange buffer, the combine step's identity elsewhere
         nd.index_copy_(2, self._local_targets_dev, part)
         C = nd.shape[0]
         # (C, kt, world, chunk) -> (world, C, kt, chunk): slice w of the target axis goes to rank w
         send = nd.view(C, kt, W, self.t_chunk).permute(2, 0, 1, 3).contiguous()
+        if W == 1 and not self.always_exchange:
+            return ("dense", None, send[0], (None, send), kt, None)  # (the reduce-scatter of one contribution is that contribution)
         t_begin = self._mark()
         out, work, full = _combine(self.dist, send, W, be.combine_is_max(mid), self.group, async_op=True)
         return ("dense", work, out, (full, send), kt, t_begin)

@@ -195,6 +195,16 @@ class DeviceMesh:
                                                ctypes.c_void_p(int(out_ptr)), ctypes.byref(handle)))
         return DeviceCSR(handle)
 
+    def overlap_partial_dev(self, query: "DeviceMesh", source_ptr, source_dtype, K, out_ptr, method_id, rows_layout,
+                            relative=False) -> "DeviceCSR":
+        """``overlap(query)`` and the per-target partial STATE of ``K`` variables in one call (a rank of the sharded
+        regridder; include/xugrid_amd.h: xr_overlap_partial_dev).  -> the matrix."""
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_overlap_partial_dev(self._h, query._h, int(bool(relative)), int(method_id),
+                                                 ctypes.c_void_p(int(source_ptr)), int(source_dtype), int(K),
+                                                 ctypes.c_void_p(int(out_ptr)), int(bool(rows_layout)), ctypes.byref(handle)))
+        return DeviceCSR(handle)
+
     def last_candidates(self):
         n = ctypes.c_int64(0)
         check(_lib.load().xr_overlap_stats(self._h, ctypes.byref(n)))

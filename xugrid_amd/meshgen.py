@@ -74,6 +74,40 @@ def triangle_mesh(n_points, seed, rotate_deg=0.0, scale=1.0, delaunay=True):
     return np.ascontiguousarray(points), np.ascontiguousarray(faces)
 
 
+def mixed_mesh(n_points, seed, rotate_deg=0.0, scale=1.0, quad_fraction=0.5, jitter=0.25):
+    """A mixed triangle / quadrilateral mesh as flexible-mesh generators write them (dense (F, 4) connectivity, -1 in the
+    fourth slot of a triangle): the quads of a jittered m x m lattice, a seeded share of them kept as (convex, CCW)
+    quadrilaterals, the rest split into two CCW triangles along a valid diagonal.  -> (node_xy float64[n, 2], faces int64[F, 4]);
+    F ~ (2 - quad_fraction) * n_points."""
+    points, m = jittered_lattice_points(n_points, seed, jitter)
+    idx = np.arange(m * m).reshape(m, m)
+    a, b = idx[:-1, :-1].ravel(), idx[:-1, 1:].ravel()
+    c, d = idx[1:, 1:].ravel(), idx[1:, :-1].ravel()
+    p = points
+
+    def ccw(i, j, k):
+        u, v = p[j] - p[i], p[k] - p[i]
+        return (u[:, 0] * v[:, 1] - u[:, 1] * v[:, 0]) > 0
+
+    convex = ccw(a, b, c) & ccw(b, c, d) & ccw(c, d, a) & ccw(d, a, b)
+    rng = np.random.default_rng(seed + 7919)
+    keep = convex & (rng.random(a.size) < quad_fraction)
+    tri = _split_lattice(points, m)  # two triangles per lattice quad, in quad order
+    n_quad, n_split = int(keep.sum()), int((~keep).sum())
+    faces = np.full((n_quad + 2 * n_split, 4), -1, dtype=np.int64)
+    # faces in lattice order: a kept quad is one row, a split quad two
+    rows = np.cumsum(np.where(keep, 1, 2)) - np.where(keep, 1, 2)
+    faces[rows[keep]] = np.column_stack([a, b, c, d])[keep]
+    split = np.nonzero(~keep)[0]
+    faces[rows[split], :3] = tri[2 * split]
+    faces[rows[split] + 1, :3] = tri[2 * split + 1]
+    if rotate_deg != 0.0 or scale != 1.0:
+        th = math.radians(rotate_deg)
+        rot = np.array([[math.cos(th), -math.sin(th)], [math.sin(th), math.cos(th)]])
+        points = (points - 0.5) @ rot.T * scale + 0.5
+    return np.ascontiguousarray(points), np.ascontiguousarray(faces)
+
+
 def tiled_mesh(node_xy, faces, n_tiles):
     """n_tiles copies of a mesh side by side (tile t shifted by (t mod c, t div c) * 1.25 with c = ceil(sqrt(n_tiles))):
     the weak-scaling workload of the multi-GPU benchmark -- every tile is the single-GPU benchmark mesh, hull slivers
