@@ -1531,10 +1531,39 @@ template <int METHOD, typename SRC>
 __global__ void __launch_bounds__(AP_BLOCK)
 k_apply_partial_w1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
                    const int32_t *__restrict__ row_order, int64_t T, int64_t S, const SRC *__restrict__ source,
-                   double *__restrict__ out, bool rows_layout, bool skip_long, const int32_t *__restrict__ gate) {
+                   double *__restrict__ out, bool rows_layout, bool skip_long, const int32_t *__restrict__ gate,
+                   const int32_t *__restrict__ long_rows, const int32_t *__restrict__ n_long, int n_long_blocks) {
     __shared__ double2 sh_win[AP_BLOCK / 64][W1_CAP]; // (.x = weight, .y = source value)
     if (gate && *gate == 0) return; // (enqueued behind a weight build whose attempt failed: the host redoes both)
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    constexpr int C = METHOD == XR_GEOMETRIC_MEAN ? 4 : 2;
+    if ((int)blockIdx.x < n_long_blocks) {
+        // the listed long rows (hull slivers), one WAVE each, in the blocks dispatched first: beside the short rows instead of
+        // in a launch of their own behind them (as k_apply_rows1; the same strided walk and butterfly as k_apply_partial_long)
+        const int nl = *n_long;
+        for (int64_t li = (int64_t)blockIdx.x * (AP_BLOCK / 64) + wib; li < nl; li += (int64_t)n_long_blocks * (AP_BLOCK / 64)) {
+            const int t = long_rows[li];
+            PartialState st = partial_identity(METHOD);
+            for (int j = indptr[t] + lane; j < indptr[t + 1]; j += 64) partial_add(METHOD, st, ld_src(source, indices[j]), data[j]);
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const double o = __shfl_xor(st.c[c], d, 64);
+                    st.c[c] = partial_is_max(METHOD) ? fmax(st.c[c], o) : st.c[c] + o;
+                }
+            }
+            if (lane == 0) {
+                const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
+#pragma unroll
+                for (int c = 0; c < C; c++) {
+                    if (rows_layout) out[t_out * C + c] = st.c[c];
+                    else out[(int64_t)c * T + t_out] = st.c[c];
+                }
+            }
+        }
+        return;
+    }
     const int64_t row0 = ((int64_t)(gridDim.x - 1 - blockIdx.x) * (AP_BLOCK / 64) + wib) * 64;
     if (row0 >= T) return;
     const int64_t t = row0 + lane;
@@ -1591,7 +1620,6 @@ k_apply_partial_w1(const int32_t *__restrict__ indptr, const int32_t *__restrict
         __builtin_amdgcn_wave_barrier();
     }
     if (t < T && !skip) {
-        constexpr int C = METHOD == XR_GEOMETRIC_MEAN ? 4 : 2;
         const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
 #pragma unroll
         for (int c = 0; c < C; c++) {
@@ -2878,6 +2906,7 @@ void xr::csr_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
         DevBuf<char> permuted;
         source_dev = stored_source(csr, source_dev, source_dtype, K, permuted);
         constexpr int PKT = 8;
+        bool long_done = false; // (the long rows went with the short ones)
         static const bool one_var = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
         if (K >= PKT && !one_var && rows_layout != 0) {
             dim3 grid(div_up(csr->n, 128), (unsigned)div_up(K, PKT));
@@ -2901,18 +2930,22 @@ void xr::csr_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
                           csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                           static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
         } else if (K == 1 && !one_var) {
-            // one variable: the wave-window kernel, one specialisation per reducer
-            dim3 grid(div_up(csr->n, AP_BLOCK));
+            // one variable: the wave-window kernel, one specialisation per reducer; the long rows in its first blocks
+            const int n_long_blocks = csr->has_long ? engine().num_cu / 2 : 0;
+            dim3 grid((unsigned)(div_up(csr->n, AP_BLOCK) + n_long_blocks));
+            long_done = true;
 #define XR_PARTIAL_W1(M)                                                                                                            \
     case M:                                                                                                                         \
         if (source_dtype == XR_F64)                                                                                                 \
             XR_LAUNCH("apply_partial", (k_apply_partial_w1<M, double>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),                 \
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,                                       \
-                      static_cast<const double *>(source_dev), out_dev, rows_layout != 0, csr->has_long, gate);                     \
+                      static_cast<const double *>(source_dev), out_dev, rows_layout != 0, csr->has_long, gate,                      \
+                      csr->long_rows.get(), csr->n_long.get(), n_long_blocks);                                                      \
         else                                                                                                                        \
             XR_LAUNCH("apply_partial", (k_apply_partial_w1<M, float>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),                  \
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,                                       \
-                      static_cast<const float *>(source_dev), out_dev, rows_layout != 0, csr->has_long, gate);                      \
+                      static_cast<const float *>(source_dev), out_dev, rows_layout != 0, csr->has_long, gate,                       \
+                      csr->long_rows.get(), csr->n_long.get(), n_long_blocks);                                                      \
         break;
             switch (method) {
                 XR_PARTIAL_W1(XR_MEAN)
@@ -2936,7 +2969,7 @@ void xr::csr_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
                       csr->indices.get(), csr->data.get(), row_order_of(csr), csr->n, csr->m,
                       static_cast<const float *>(source_dev), K, out_dev, rows_layout != 0, csr->has_long);
         }
-        if (csr->has_long) {
+        if (csr->has_long && !long_done) {
             dim3 lgrid(64, (unsigned)K);
             if (source_dtype == XR_F64)
                 XR_LAUNCH("apply_partial_long", k_apply_partial_long<double>, lgrid, dim3(256), 0, method, csr->indptr.get(),
