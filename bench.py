@@ -718,8 +718,15 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
             w = E.edge_length_csr(mesh, edges)
             E.dev_sync()
             times.append(time.perf_counter() - t0)
+        # algorithmic bytes of the edge path, in the style of SURVEY 8(d): the edge coordinates once (32 B per edge), the mesh once
+        # (int32 connectivity + f64 nodes), the CSR once (12 B per entry + row offsets over the faces)
+        b_edges = 32 * n_edge + 4 * 3 * S + 16 * int(mesh_xy.shape[0]) + 12 * int(w.nnz) + 4 * (S + 1)
         out["network_gridder_1M_edges"] = {
             "weights_ms": 1e3 * min(times), "edges_per_s": n_edge / min(times), "nnz": w.nnz,
+            "roofline": {"bound": "hbm", "algorithmic_bytes": b_edges, "achieved_GBps": b_edges / min(times) / 1e9,
+                         "frac_of_hbm_peak": b_edges / min(times) / 1e9 / HBM_PEAK_GBS,
+                         "note": "whole call incl. the 32 MB host -> device copy of the edge coordinates (PCIe); the device part "
+                                 "is a grid walk per edge, latency / instruction bound like the face search"},
             "note": "1M random segments (exponential lengths, mean ~2 cell sizes) over the ~1M-triangle source mesh; "
             "includes the 32 MB upload of the edge coordinates",
         }
@@ -850,6 +857,11 @@ def run_multi(args):
 
     from xugrid_amd.distributed import init_process_group_from_env
 
+    # RCCL prints a version banner to the C-level stdout when its first communicator comes up: everything but the ONE JSON line
+    # goes to stderr (file descriptor 1 points at stderr for the whole run; the line is written to the saved descriptor)
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     dist_backend = args.dist_backend or ("nccl" if torch.cuda.is_available() else "gloo")
     init_process_group_from_env(dist_backend)
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -871,7 +883,8 @@ def run_multi(args):
         if rank == 0:
             result["other_configs"] = others
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     dist.barrier()
     dist.destroy_process_group()
 
