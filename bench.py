@@ -1231,7 +1231,7 @@ def run_projection(args):
         counts = np.zeros((world, world), dtype=np.int64)
         ids_to = []
         for r in range(world):
-            _, lt = shard_lists(full, world, r, args.partition)
+            _, lt = shard_lists(full, world, r, args.partition, backend)
             owner = torch.div(lt, t_chunk, rounding_mode="floor")
             counts[r] = torch.bincount(owner, minlength=world).cpu().numpy()
             local = lt - owner * t_chunk

@@ -390,6 +390,23 @@ int xr_apply_outer_dev(xr_outer *outer, int method, double percentile, const voi
 int xr_apply_coo(const int64_t *row, const int64_t *col, int64_t nnz, int64_t T,
                  const void *source, int source_dtype, int64_t K, int64_t S, double *out);
 
+/* ---- multi-GPU set-up: which source faces are mine, which targets can they reach ------------------
+ * The reference has no multi-device path (its only parallel loop is the dask map of regridder.py:167-185); SURVEY 8(e) shards
+ * the SOURCE faces over the ranks and replicates the target.  xr_shard_plan_dev evaluates the partition rule on the rank's
+ * device from the replicated raw meshes (float64 [N, 2] coordinates, int64 [F, m] connectivity with -1 fill, device pointers):
+ *   mode 0 "hash"      owner = face id mod world (the north star's wording)
+ *   mode 1 "morton"    cells of a 1024 x 1024 raster over the source centroids, ordered along the Morton curve, cut into
+ *                      `world` stretches of equal face COUNT (owner per cell: floor(faces in front of the cell * world / S))
+ *   mode 2 "balanced"  the same cut by estimated WORK, round(4096 (1 + 4 n_tgt / n_src)) per source face from a coarse raster
+ *                      both meshes are counted into
+ * and keeps the target faces whose box touches the 128 x 128 occupancy raster of the rank's own source faces.  Integer
+ * arithmetic decides every owner, so all ranks agree without communication.  Outputs: ascending global ids (device arrays of
+ * capacity n_src_face / n_tgt_face), their counts, optionally the owner of every source face (int32 [n_src_face]). */
+int xr_shard_plan_dev(const double *src_xy_dev, const int64_t *src_faces_dev, int64_t n_src_face, int src_m,
+                      const double *tgt_xy_dev, const int64_t *tgt_faces_dev, int64_t n_tgt_face, int tgt_m, int world, int rank,
+                      int mode, int64_t *local_faces_dev, int64_t *n_local_faces, int64_t *local_targets_dev,
+                      int64_t *n_local_targets, int32_t *owner_dev);
+
 /* Multi-GPU (source faces sharded over ranks).  For EVERY reducer that decomposes over source shards
  * (xugrid/regrid/reduce.py:16-123, 206-222) each rank reduces the entries of its own columns to a few partial STATE components per (target, variable),
  * the ranks combine the components element-wise with ONE collective (sum, or max for minimum / maximum), the owner of a

@@ -108,3 +108,13 @@ def test_sharded_w8_at_10m_faces_properties(hip, tmp_path):
     lin = 2.0 * out["target_cx"] - 3.0 * out["target_cy"] + 1.0
     assert np.abs(mean[1][ok] - lin[ok]).max() < 0.02
     assert np.array_equal(out["maximum"], out["single_max"], equal_nan=True)
+
+
+def test_shard_plan_on_the_device(hip):
+    """xr_shard_plan_dev (round 5: the set-up of a rank as HIP kernels instead of torch tensor operations) -- the checks live in
+    tests/shard_plan_worker_gpu.py (a process of its own: HipBackend puts the engine on torch's stream)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "shard_plan_worker_gpu.py")], env=env, capture_output=True,
+                          text=True, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-3000:] + proc.stderr[-6000:]
+    assert "shard plan ok" in proc.stdout

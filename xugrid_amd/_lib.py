@@ -76,6 +76,7 @@ SIGNATURES = {
     "xr_overlap_stats": (c_int, [vp, p_i64]),
     "xr_overlap_apply_dev": (c_int, [vp, vp, c_int, c_int, c_f64, vp, c_int, c_i64, vp, p_vp]),
     "xr_overlap_partial_dev": (c_int, [vp, vp, c_int, c_int, vp, c_int, c_i64, vp, c_int, p_vp]),
+    "xr_shard_plan_dev": (c_int, [vp, vp, c_i64, c_int, vp, vp, c_i64, c_int, c_int, c_int, c_int, vp, p_i64, vp, p_i64, vp]),
     "xr_locate_points": (c_int, [vp, vp, c_i64, c_f64, vp]),
     "xr_locate_raster": (c_int, [vp, vp, c_i64, vp, c_i64, c_f64, vp]),
     "xr_barycentric": (c_int, [vp, vp, c_i64, c_f64, vp, vp]),

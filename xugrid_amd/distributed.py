@@ -280,6 +280,22 @@ class HipBackend:
         self._tgt_mesh.invalidate()
         return self._src_mesh.overlap(self._tgt_mesh, relative=self._relative)
 
+    def shard_plan(self, full, world, rank, partition, want_owner=False):
+        """``shard_lists`` on the engine (xr_shard_plan_dev): -> (local source face ids, local target ids[, owner of every
+        source face]) as device tensors, ascending."""
+        torch = self.torch
+        sxy, sfa, txy, tfa = (a.contiguous() for a in full)
+        S, T = sfa.shape[0], tfa.shape[0]
+        faces = torch.empty(max(S, 1), dtype=torch.int64, device=self.device)
+        targets = torch.empty(max(T, 1), dtype=torch.int64, device=self.device)
+        owner = torch.empty(max(S, 1), dtype=torch.int32, device=self.device) if want_owner else None
+        self._handover()
+        n_f, n_t = self.engine.shard_plan_dev(sxy.data_ptr(), sfa.data_ptr(), S, sfa.shape[1], txy.data_ptr(), tfa.data_ptr(), T,
+                                              tfa.shape[1], world, rank, partition, faces.data_ptr(), targets.data_ptr(),
+                                              owner.data_ptr() if want_owner else 0)
+        out = (faces[:n_f], targets[:n_t])
+        return out + (owner[:S],) if want_owner else out
+
     def rebuild_partial(self, source, method_id, rows_layout):
         """``rebuild_weights()`` + ``partial()`` as ONE engine call (xr_overlap_partial_dev): for one variable the partial-state
         kernel is enqueued before the host has read the sizes of the new matrix.  -> (weights, state tensor)."""
@@ -386,12 +402,18 @@ def _method(method):
     return table[method], method in RELATIVE_OVERLAP_METHODS
 
 
-def shard_lists(full, world, rank, partition="balanced"):
+def shard_lists(full, world, rank, partition="balanced", backend=None):
     """(sxy, sfa, txy, tfa) tensors of the replicated meshes -> (global ids of rank's source faces, global ids of the
     target faces it can give weight to), both ascending, on the tensors' device.  Every rank computes the same owner
-    array (exact integer arithmetic), so the shards are disjoint and complete without communication."""
+    array (exact integer arithmetic), so the shards are disjoint and complete without communication.
+
+    A backend with ``shard_plan`` (the HIP backend: ``xr_shard_plan_dev``, a dozen O(S + T) kernels) evaluates ITS rule --
+    Morton cells instead of a sort of the faces, see include/xugrid_amd.h -- on the device; the torch rule below serves the
+    other backends (CPU tests).  The two cut the curve at slightly different faces; within one job every rank uses the same."""
     import torch
 
+    if backend is not None and hasattr(backend, "shard_plan") and partition in ("hash", "morton", "balanced"):
+        return backend.shard_plan(full, world, rank, partition)
     sxy, sfa, txy, tfa = full
     cen = _centroids_t(sxy, sfa)
     if partition == "balanced":
@@ -462,7 +484,7 @@ class ShardedOverlapRegridder:
         import torch
 
         sxy, sfa, txy, tfa = self._full
-        local_faces, local_targets = shard_lists(self._full, self.world, self.rank, self.partition)
+        local_faces, local_targets = shard_lists(self._full, self.world, self.rank, self.partition, self.backend)
         sfa_local = sfa[local_faces]
         self._local_faces_t, self._local_targets_t = local_faces, local_targets
         self._local_np = [None, None]

@@ -738,6 +738,22 @@ class DeviceOuter:
         )
 
 
+SHARD_MODES = {"hash": 0, "morton": 1, "balanced": 2}
+
+
+def shard_plan_dev(src_xy_ptr, src_faces_ptr, n_src_face, src_m, tgt_xy_ptr, tgt_faces_ptr, n_tgt_face, tgt_m, world, rank, mode,
+                   local_faces_ptr, local_targets_ptr, owner_ptr=0):
+    """The partition rule of a rank evaluated on the device (include/xugrid_amd.h: xr_shard_plan_dev): device pointers of the
+    replicated raw meshes in, ascending global id lists out.  -> (n_local_faces, n_local_targets)."""
+    n_f, n_t = ctypes.c_int64(0), ctypes.c_int64(0)
+    check(_lib.load().xr_shard_plan_dev(
+        ctypes.c_void_p(int(src_xy_ptr)), ctypes.c_void_p(int(src_faces_ptr)), int(n_src_face), int(src_m),
+        ctypes.c_void_p(int(tgt_xy_ptr)), ctypes.c_void_p(int(tgt_faces_ptr)), int(n_tgt_face), int(tgt_m), int(world), int(rank),
+        SHARD_MODES[mode], ctypes.c_void_p(int(local_faces_ptr)), ctypes.byref(n_f), ctypes.c_void_p(int(local_targets_ptr)),
+        ctypes.byref(n_t), ctypes.c_void_p(int(owner_ptr)) if owner_ptr else None))
+    return n_f.value, n_t.value
+
+
 def partial_components(method_id):
     """number of partial-state components of a shard-decomposable reducer (0: the reducer needs whole rows)"""
     return int(_lib.load().xr_partial_components(int(method_id)))
