@@ -39,19 +39,6 @@ __device__ __forceinline__ double dkey_inv(unsigned long long k) {
 struct Bounds { // [0..3] min x, min y, max x, max y as keys
     unsigned long long k[4];
 };
-__device__ __forceinline__ void bounds_add(Bounds *b, double x0, double y0, double x1, double y1) {
-    atomicMin(&b->k[0], dkey(x0));
-    atomicMin(&b->k[1], dkey(y0));
-    atomicMax(&b->k[2], dkey(x1));
-    atomicMax(&b->k[3], dkey(y1));
-}
-__global__ void k_shard_init(Bounds *b, int n) {
-    if (threadIdx.x < n) {
-        b[threadIdx.x].k[0] = b[threadIdx.x].k[1] = ~0ull;
-        b[threadIdx.x].k[2] = b[threadIdx.x].k[3] = 0ull;
-    }
-}
-
 // centroid + box of face f of a dense (F, m) int64 connectivity with -1 fill
 __device__ __forceinline__ void face_geometry(const double *__restrict__ xy, const int64_t *__restrict__ faces, int64_t f, int m,
                                               double &cx, double &cy, double &x0, double &y0, double &x1, double &y1) {
@@ -73,8 +60,11 @@ __device__ __forceinline__ void face_geometry(const double *__restrict__ xy, con
     cy = sy / (double)(n > 0 ? n : 1);
 }
 
-// wave-reduced bounds: one set of atomics per wave
-__device__ __forceinline__ void bounds_add_wave(Bounds *b, bool valid, double x0, double y0, double x1, double y1) {
+// Bounds of a set of boxes, two stages: every block reduces its boxes (waves by shuffles, the block through LDS) and writes ONE
+// partial (min x, min y, max x, max y) to its slot; a one-block kernel folds the partials.  (One set of same-address atomics
+// per wave -- 375 k of them for a 1M + 1M pair -- cost 3 ms: the L2 serves a contended word at a few hundred million a second.)
+__device__ __forceinline__ void bounds_block_partial(double4 *__restrict__ partial, bool valid, double x0, double y0, double x1, double y1) {
+    __shared__ double4 sh[4];
     double a = valid ? x0 : INFINITY, c = valid ? y0 : INFINITY, d = valid ? x1 : -INFINITY, e = valid ? y1 : -INFINITY;
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
@@ -83,14 +73,52 @@ __device__ __forceinline__ void bounds_add_wave(Bounds *b, bool valid, double x0
         d = fmax(d, __shfl_xor(d, s, 64));
         e = fmax(e, __shfl_xor(e, s, 64));
     }
-    if ((threadIdx.x & 63) == 0 && a <= d) bounds_add(b, a, c, d, e);
+    __syncthreads(); // (the LDS slots may still be read from an earlier call)
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = make_double4(a, c, d, e);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double4 r = sh[0];
+        for (int w = 1; w < 4; w++) {
+            r.x = fmin(r.x, sh[w].x); r.y = fmin(r.y, sh[w].y);
+            r.z = fmax(r.z, sh[w].z); r.w = fmax(r.w, sh[w].w);
+        }
+        partial[blockIdx.x] = r;
+    }
+}
+// partials [n_sets][n_blocks] -> Bounds[n_sets] (one block of 256 threads per set)
+__global__ void __launch_bounds__(256) k_shard_fold_bounds(const double4 *__restrict__ partial, int64_t n_blocks, Bounds *__restrict__ out) {
+    __shared__ double4 sh[4];
+    const double4 *p = partial + (int64_t)blockIdx.x * n_blocks;
+    double a = INFINITY, c = INFINITY, d = -INFINITY, e = -INFINITY;
+    for (int64_t i = threadIdx.x; i < n_blocks; i += 256) {
+        const double4 v = p[i];
+        a = fmin(a, v.x); c = fmin(c, v.y); d = fmax(d, v.z); e = fmax(e, v.w);
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        a = fmin(a, __shfl_xor(a, s, 64));
+        c = fmin(c, __shfl_xor(c, s, 64));
+        d = fmax(d, __shfl_xor(d, s, 64));
+        e = fmax(e, __shfl_xor(e, s, 64));
+    }
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = make_double4(a, c, d, e);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double4 r = sh[0];
+        for (int w = 1; w < 4; w++) {
+            r.x = fmin(r.x, sh[w].x); r.y = fmin(r.y, sh[w].y);
+            r.z = fmax(r.z, sh[w].z); r.w = fmax(r.w, sh[w].w);
+        }
+        out[blockIdx.x].k[0] = dkey(r.x); out[blockIdx.x].k[1] = dkey(r.y);
+        out[blockIdx.x].k[2] = dkey(r.z); out[blockIdx.x].k[3] = dkey(r.w);
+    }
 }
 
 // pass 1: centroids of both meshes (stored) and their bounds
 __global__ void __launch_bounds__(256)
 k_shard_centroids(const double *__restrict__ sxy, const int64_t *__restrict__ sf, int64_t S, int ms, const double *__restrict__ txy,
                   const int64_t *__restrict__ tf, int64_t T, int mt, double2 *__restrict__ scen, double2 *__restrict__ tcen,
-                  Bounds *__restrict__ b /* [0] source centroids, [1] target centroids */) {
+                  double4 *__restrict__ partial /* [2][gridDim.x]: source centroids, target centroids */) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool is_src = i < S, valid = i < S + T;
     double cx = 0, cy = 0, x0, y0, x1, y1;
@@ -99,8 +127,8 @@ k_shard_centroids(const double *__restrict__ sxy, const int64_t *__restrict__ sf
     if (is_src) scen[i] = make_double2(cx, cy);
     else if (valid) tcen[i - S] = make_double2(cx, cy);
     // (a block holds faces of one mesh except the one straddling S: the two reductions are masked per mesh)
-    bounds_add_wave(&b[0], is_src, cx, cy, cx, cy);
-    bounds_add_wave(&b[1], valid && !is_src, cx, cy, cx, cy);
+    bounds_block_partial(partial, is_src, cx, cy, cx, cy);
+    bounds_block_partial(partial + gridDim.x, valid && !is_src, cx, cy, cx, cy);
 }
 
 __device__ __forceinline__ int raster_cell(double v, double lo, double f, int n) {
@@ -238,7 +266,7 @@ k_shard_compact(const int32_t *__restrict__ flag, const int32_t *__restrict__ po
 // pass 5: bounds of the boxes of MY source faces and of all target faces
 __global__ void __launch_bounds__(256)
 k_shard_box_bounds(const double *__restrict__ sxy, const int64_t *__restrict__ sf, int64_t S, int ms, const int32_t *__restrict__ mine,
-                   const double *__restrict__ txy, const int64_t *__restrict__ tf, int64_t T, int mt, Bounds *__restrict__ b /* [2] */) {
+                   const double *__restrict__ txy, const int64_t *__restrict__ tf, int64_t T, int mt, double4 *__restrict__ partial) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     bool valid = false;
     double cx, cy, x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -251,7 +279,7 @@ k_shard_box_bounds(const double *__restrict__ sxy, const int64_t *__restrict__ s
         face_geometry(txy, tf, i - S, mt, cx, cy, x0, y0, x1, y1);
         valid = x0 <= x1;
     }
-    bounds_add_wave(&b[2], valid, x0, y0, x1, y1);
+    bounds_block_partial(partial, valid, x0, y0, x1, y1);
 }
 
 // pass 6: difference array of my source faces' boxes on the occupancy raster
@@ -273,43 +301,38 @@ k_shard_occupy(const double *__restrict__ sxy, const int64_t *__restrict__ sf, i
     atomicAdd(&diff[(cy1 + 1) * OCC_STRIDE + cx1 + 1], 1);
 }
 
-// difference array -> occupied cells -> integral image (one block; 129 x 129 words in place, then into `integral`)
-__global__ void __launch_bounds__(256) k_shard_integral(int32_t *__restrict__ diff, int32_t *__restrict__ integral) {
-    // prefix along x (a thread per row), then along y (a thread per column): coverage counts
-    for (int r = threadIdx.x; r < OCC_STRIDE; r += 256) {
-        int run = 0;
-        for (int c = 0; c < OCC_STRIDE; c++) {
-            run += diff[r * OCC_STRIDE + c];
-            diff[r * OCC_STRIDE + c] = run;
+// difference array -> occupied cells -> integral image (one block of 16 waves; a wave takes a line -- a row, then a column -- and
+// scans it 64 elements at a time by shuffles: four passes of 129 lines over the 129 x 129 words)
+__device__ __forceinline__ void scan_line(int32_t *line, int stride, int n, int lane) {
+    int carry = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int c = c0 + lane;
+        int v = c < n ? line[c * stride] : 0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(v, d, 64);
+            if (lane >= d) v += t;
         }
+        v += carry;
+        if (c < n) line[c * stride] = v;
+        carry = __shfl(v, 63, 64);
+    }
+}
+__global__ void __launch_bounds__(1024) k_shard_integral(int32_t *__restrict__ diff, int32_t *__restrict__ integral) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < OCC_STRIDE; r += 16) scan_line(diff + r * OCC_STRIDE, 1, OCC_STRIDE, lane); // along x
+    __syncthreads();
+    for (int c = wave; c < OCC_STRIDE; c += 16) scan_line(diff + c, OCC_STRIDE, OCC_STRIDE, lane);     // along y: coverage counts
+    __syncthreads();
+    // integral[r + 1][c + 1] = occupied(r, c); row 0 and column 0 stay zero; then the two prefix sums
+    for (int i = threadIdx.x; i < OCC_STRIDE * OCC_STRIDE; i += 1024) {
+        const int r = i / OCC_STRIDE, c = i - r * OCC_STRIDE;
+        integral[i] = (r > 0 && c > 0 && diff[(r - 1) * OCC_STRIDE + (c - 1)] > 0) ? 1 : 0;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < OCC_STRIDE; c += 256) {
-        int run = 0;
-        for (int r = 0; r < OCC_STRIDE; r++) {
-            run += diff[r * OCC_STRIDE + c];
-            diff[r * OCC_STRIDE + c] = run > 0 ? 1 : 0; // occupied
-        }
-    }
+    for (int r = wave; r < OCC_STRIDE; r += 16) scan_line(integral + r * OCC_STRIDE, 1, OCC_STRIDE, lane);
     __syncthreads();
-    // integral[r + 1][c + 1] = number of occupied cells in [0..r] x [0..c]
-    for (int r = threadIdx.x; r < OCC_STRIDE; r += 256) {
-        int run = 0;
-        integral[r * OCC_STRIDE] = 0;
-        for (int c = 0; c < OCC_GRID; c++) {
-            run += r < OCC_GRID ? diff[r * OCC_STRIDE + c] : 0;
-            if (r < OCC_GRID) integral[(r + 1) * OCC_STRIDE + c + 1] = run;
-        }
-    }
-    if (threadIdx.x < OCC_STRIDE) integral[threadIdx.x] = 0;
-    __syncthreads();
-    for (int c = threadIdx.x; c < OCC_STRIDE; c += 256) {
-        int run = 0;
-        for (int r = 1; r < OCC_STRIDE; r++) {
-            run += integral[r * OCC_STRIDE + c];
-            integral[r * OCC_STRIDE + c] = run;
-        }
-    }
+    for (int c = wave; c < OCC_STRIDE; c += 16) scan_line(integral + c, OCC_STRIDE, OCC_STRIDE, lane);
 }
 
 // pass 7: the target faces whose box touches an occupied cell
@@ -364,9 +387,11 @@ int xr_shard_plan_dev(const double *src_xy_dev, const int64_t *src_faces_dev, in
         spos((size_t)S + 1), tflag((size_t)T + 1), tpos((size_t)T + 1), diff((size_t)OCC_STRIDE * OCC_STRIDE),
         integral((size_t)OCC_STRIDE * OCC_STRIDE);
     DevBuf<unsigned long long> cell_work((size_t)SHARD_CELLS), part((size_t)SHARD_CELLS / S64_TILE + 1);
-    XR_LAUNCH("shard_init", k_shard_init, dim3(1), dim3(64), 0, bounds.get(), 3);
-    XR_LAUNCH("shard_centroids", k_shard_centroids, dim3(div_up(S + T, 256)), dim3(256), 0, src_xy_dev, src_faces_dev, S, src_m,
-              tgt_xy_dev, tgt_faces_dev, T, tgt_m, scen.get(), tcen.get(), bounds.get());
+    const int64_t nb_all = div_up(S + T, 256);
+    DevBuf<double4> partial((size_t)(2 * nb_all));
+    XR_LAUNCH("shard_centroids", k_shard_centroids, dim3(nb_all), dim3(256), 0, src_xy_dev, src_faces_dev, S, src_m,
+              tgt_xy_dev, tgt_faces_dev, T, tgt_m, scen.get(), tcen.get(), partial.get());
+    XR_LAUNCH("shard_bounds", k_shard_fold_bounds, dim3(2), dim3(256), 0, partial.get(), nb_all, bounds.get());
     const bool hash = mode == 0, balanced = mode == 2;
     if (!hash) {
         if (balanced) {
@@ -388,12 +413,13 @@ int xr_shard_plan_dev(const double *src_xy_dev, const int64_t *src_faces_dev, in
     exclusive_scan_i32(sflag.get(), spos.get(), S);
     XR_LAUNCH("shard_compact", k_shard_compact, dim3(div_up(S, 256)), dim3(256), 0, sflag.get(), spos.get(), S, local_faces_dev);
     if (T > 0) {
-        XR_LAUNCH("shard_box_bounds", k_shard_box_bounds, dim3(div_up(S + T, 256)), dim3(256), 0, src_xy_dev, src_faces_dev, S, src_m,
-                  sflag.get(), tgt_xy_dev, tgt_faces_dev, T, tgt_m, bounds.get());
+        XR_LAUNCH("shard_box_bounds", k_shard_box_bounds, dim3(nb_all), dim3(256), 0, src_xy_dev, src_faces_dev, S, src_m,
+                  sflag.get(), tgt_xy_dev, tgt_faces_dev, T, tgt_m, partial.get());
+        XR_LAUNCH("shard_bounds", k_shard_fold_bounds, dim3(1), dim3(256), 0, partial.get(), nb_all, bounds.get() + 2);
         fill_i32(diff.get(), 0, (int64_t)OCC_STRIDE * OCC_STRIDE);
         XR_LAUNCH("shard_occupy", k_shard_occupy, dim3(div_up(S, 256)), dim3(256), 0, src_xy_dev, src_faces_dev, S, src_m, sflag.get(),
                   bounds.get(), diff.get());
-        XR_LAUNCH("shard_integral", k_shard_integral, dim3(1), dim3(256), 0, diff.get(), integral.get());
+        XR_LAUNCH("shard_integral", k_shard_integral, dim3(1), dim3(1024), 0, diff.get(), integral.get());
         XR_LAUNCH("shard_targets", k_shard_targets, dim3(div_up(T, 256)), dim3(256), 0, tgt_xy_dev, tgt_faces_dev, T, tgt_m, bounds.get(),
                   integral.get(), tflag.get());
         exclusive_scan_i32(tflag.get(), tpos.get(), T);
