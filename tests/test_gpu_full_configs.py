@@ -182,7 +182,8 @@ def test_bench_multi_gpu_path_10m_one_rank():
             if exchange == "none":
                 assert line["config"]["per_rank"]["collectives_per_step"] == 0 and line["value"] > 5e10
             else:
-                assert line["config"]["per_rank"]["collectives_per_step"] == 8  # 256 variables in tiles of 32
+                # 256 variables in 8 tiles of 32 -- and a group of ONE rank makes no collective call for any of them
+                assert line["config"]["per_rank"]["collectives_per_step"] == 0
                 assert line["value"] > 2e9
         else:
             assert line["config"]["target_faces"] > 9_900_000 and "config 4" in line["config"]["workload"]
