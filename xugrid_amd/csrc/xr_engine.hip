@@ -327,11 +327,78 @@ static constexpr size_t STAGE_BYTES = (size_t)64 << 20;
 static constexpr size_t BIG_COPY_BYTES = (size_t)1 << 20; // copies of this size and more go through the pinned staging buffers
 static constexpr size_t SMALL_COPY_BYTES = BIG_COPY_BYTES;
 
+static bool mail_poll_enabled();
+static inline void cpu_relax();
+
+// ---- small copies without a stream synchronisation (round 5) -----------------------------------------------------------
+// A read-back of a few bytes to a few hundred KB used to be hipMemcpyAsync + hipStreamSynchronize: 35-55 us of host
+// latency each, with the device idle behind it (the Voronoi pre-step of the barycentric path makes eight of them, a small
+// regridder construction is little else).  On the engine's own main stream they now go the mailbox's way: a kernel copies
+// the bytes into a coherent pinned page and the LAST of its blocks stores a sequence number behind them, which the host
+// polls.  Uploads copy the host bytes into a pinned ring slot and enqueue the DMA without waiting for it (the slot is
+// reused after its event).  Anything else -- lanes, a caller's stream, the side stream, XR_MAIL_POLL=0 -- keeps the
+// synchronous path.
+static constexpr size_t FAST_D2H_MAX = (size_t)1 << 20;  // bytes of the pinned read-back page
+static constexpr size_t FAST_H2D_SLOT = (size_t)1 << 16, FAST_H2D_SLOTS = 16;
+struct FastCopy {
+    char *page = nullptr;          // coherent pinned: [0, FAST_D2H_MAX) data, then one sequence word
+    int32_t *done = nullptr;       // device word: blocks of the copy kernel that have finished
+    int32_t seq = 0;
+    char *ring = nullptr;          // pinned upload slots
+    hipEvent_t ring_ev[FAST_H2D_SLOTS] = {};
+    size_t ring_next = 0;
+};
+static FastCopy g_fast;
+
+__global__ void __launch_bounds__(256)
+k_copy_to_host(const uint32_t *__restrict__ src, uint32_t *dst, size_t n_words, const uint8_t *__restrict__ tail_src, uint8_t *tail_dst,
+               int n_tail, int32_t *done, volatile int32_t *seq_word, int32_t seq) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail_dst[threadIdx.x] = tail_src[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(done, 1) == (int)gridDim.x - 1) { // the last block: every other block's bytes are out
+            *done = 0;
+            __threadfence_system();
+            *seq_word = seq;
+        }
+    }
+}
+
+static bool fast_copy_allowed() {
+    Engine &e = engine();
+    return mail_poll_enabled() && !t_lane && !t_stream_override && !e.on_side && e.stream == e.own_stream;
+}
+static void fast_copy_init() {
+    if (g_fast.page) return;
+    void *p = nullptr;
+    XR_HIP(hipHostMalloc(&p, FAST_D2H_MAX + 64, hipHostMallocCoherent));
+    memset(p, 0, FAST_D2H_MAX + 64);
+    g_fast.page = static_cast<char *>(p);
+    XR_HIP(hipMalloc(reinterpret_cast<void **>(&g_fast.done), 64));
+    XR_HIP(hipMemset(g_fast.done, 0, 64));
+    XR_HIP(hipHostMalloc(&p, FAST_H2D_SLOT * FAST_H2D_SLOTS, hipHostMallocDefault));
+    g_fast.ring = static_cast<char *>(p);
+}
+
 void h2d(void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
     if (bytes >= BIG_COPY_BYTES) {
         h2d_big(dst, src, bytes);
         return;
+    }
+    if (bytes <= FAST_H2D_SLOT && fast_copy_allowed()) {
+        fast_copy_init();
+        const size_t slot = g_fast.ring_next++ % FAST_H2D_SLOTS;
+        if (g_fast.ring_ev[slot]) XR_HIP(hipEventSynchronize(g_fast.ring_ev[slot])); // (sixteen uploads ago: long done)
+        else XR_HIP(hipEventCreateWithFlags(&g_fast.ring_ev[slot], hipEventDisableTiming));
+        char *stage = g_fast.ring + slot * FAST_H2D_SLOT;
+        memcpy(stage, src, bytes);
+        XR_HIP(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, engine().stream));
+        XR_HIP(hipEventRecord(g_fast.ring_ev[slot], engine().stream));
+        engine().main_busy = true;
+        return; // (the caller's buffer is free again; the copy is ordered in front of everything enqueued after it)
     }
     XR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, launch_stream()));
     XR_HIP(hipStreamSynchronize(launch_stream()));
@@ -339,6 +406,36 @@ void h2d(void *dst, const void *src, size_t bytes) {
 
 void d2h(void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
+    if (bytes <= FAST_D2H_MAX && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && fast_copy_allowed()) {
+        fast_copy_init();
+        Engine &e = engine();
+        const size_t n_words = bytes / 4;
+        const int n_tail = (int)(bytes & 3);
+        g_fast.seq = g_fast.seq >= (1 << 30) ? 1 : g_fast.seq + 1;
+        volatile int32_t *seq_word = reinterpret_cast<volatile int32_t *>(g_fast.page + FAST_D2H_MAX);
+        const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>((n_words + 255) / 256, 1), 256);
+        hipLaunchKernelGGL(k_copy_to_host, dim3(grid), dim3(256), 0, e.stream, static_cast<const uint32_t *>(src),
+                           reinterpret_cast<uint32_t *>(g_fast.page), n_words, static_cast<const uint8_t *>(src) + 4 * n_words,
+                           reinterpret_cast<uint8_t *>(g_fast.page) + 4 * n_words, n_tail, g_fast.done, seq_word, g_fast.seq);
+        XR_HIP(hipGetLastError());
+        const auto t0 = std::chrono::steady_clock::now();
+        bool seen = true;
+        for (uint64_t spins = 0; *seq_word != g_fast.seq; spins++) {
+            cpu_relax();
+            if ((spins & 0x3fff) == 0x3fff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+                XR_HIP(hipStreamSynchronize(e.stream)); // (slow or failed kernel: the error, if any, surfaces here)
+                seen = *seq_word == g_fast.seq;
+                break;
+            }
+        }
+        XR_REQUIRE(seen, XR_ERR_HIP, "read-back sequence word missing after synchronisation");
+        std::atomic_thread_fence(std::memory_order_acquire);
+        memcpy(dst, g_fast.page, bytes);
+        // (everything in front of the copy kernel has executed: the stream is drained as far as pool blocks are concerned)
+        e.main_busy = false;
+        pool_release_deferred(/*may_block=*/false);
+        return;
+    }
     if (bytes <= 4096) {
         // scalar read-backs go through the pinned page: no pageable staging, one sync
         XR_HIP(hipMemcpyAsync(engine().pinned, src, bytes, hipMemcpyDeviceToHost, engine().stream));
