@@ -48,6 +48,8 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
 // hits, too many grid rows or too many visited records are "big" and go to the block-per-face
 // kernel instead.
 static constexpr int SLOTS = 16;
+static constexpr int QCUR_STRIDE = 32; // words between the cursors of the regular queue's eight regions: a 128-byte line each
+static constexpr int QCUR_BASE = 32;   // first of them in the control words of overlap_tri
 static constexpr int SEARCH_HIT_DEFAULT = 0; // form of the walk's box test (see k_search)
 static constexpr int TILE_RUN = 16; // rows per run in the tiling hint (128-byte output stores per variable).  Measured, K = 256 on
                                     // the benchmark matrix: runs of 64 rows / tiles of 24 extents 2.10 ms, 16 / 12: 1.72 ms (a qhull-numbered
@@ -87,7 +89,8 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
          int2 *__restrict__ block_seg, uint8_t *__restrict__ is_big, int32_t *__restrict__ big_list,
          int32_t *__restrict__ n_big, MortonParams tile, int32_t *__restrict__ tile_key, int32_t *__restrict__ nnz_row,
          bool remap, int32_t *__restrict__ blk_rows = nullptr /* optional: regular (non-big) faces per block, written */,
-         int32_t *__restrict__ blk_surv = nullptr /* optional: the clip's survivor count of the block, cleared here */) {
+         int32_t *__restrict__ blk_surv = nullptr /* optional: the clip's survivor count of the block, cleared here */,
+         int region_cap = 0 /* > 0: EIGHT queue regions of this many pairs with a cursor each (queue_cursor[0..7]), one per XCD */) {
     __shared__ __attribute__((aligned(16))) int32_t sh_slots[SLOTS + 1][256]; // [slot][thread]: conflict-free; + trash row
     __shared__ uint8_t sh_owner[PACK ? 1 : SLOTS * 256];
     __shared__ __attribute__((aligned(16))) float4 sh_bigbb[BIGREC_BLOCK];
@@ -314,7 +317,15 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
         total += sh_wave[w];
     }
     const int lo = woff + incl - mine;
-    if (threadIdx.x == 0) sh_base = total > 0 ? atomicAdd(queue_cursor, total) : 0;
+    // One returning atomic per block on ONE word is served at the memory side at ~10 M a second when thousands of blocks queue up
+    // for it (10 us of this kernel, measured by giving every block a fixed stretch instead).  With region_cap > 0 the queue is
+    // eight dense regions, one per XCD (hardware block b runs on XCD b mod 8, and with the XCD-aware block order that XCD owns a
+    // contiguous eighth of the target faces): eight words share the traffic, and the persistent clip deals its chunks per
+    // region anyway.
+    if (threadIdx.x == 0) {
+        const int x = region_cap > 0 ? (int)(blockIdx.x & 7) : 0;
+        sh_base = (total > 0 ? atomicAdd(&queue_cursor[x * QCUR_STRIDE], total) : 0) + x * region_cap;
+    }
     int32_t *flat = &sh_slots[0][0];
 #pragma unroll
     for (int j = 0; j < SLOTS; j++) {
@@ -1485,7 +1496,10 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     const unsigned grid = xcd_grid(n_blocks, remap);
     const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
     int64_t big_capacity = margin_env ? std::max<int64_t>((int64_t)atoll(margin_env), 1) : ((int64_t)4 << 20);
-    const int64_t reg_capacity = T * SLOTS;
+    // the regular pair queue: eight regions (one per XCD) of region_cap pairs each -- every block of 256 faces parks at most
+    // 256 x SLOTS pairs and an XCD takes ceil(n_blocks / 8) blocks
+    const int64_t region_cap = div_up(div_up(T, FB), 8) * FB * SLOTS;
+    const int64_t reg_capacity = 8 * region_cap;
     int64_t per_face = 8; // CSR entries reserved per target face (+ the big queue); regrown if the matrix is denser
     int32_t *mail = const_cast<int32_t *>(engine().mailbox);
     static_assert(sizeof(FusedCounters) == 32, "FusedCounters layout");
@@ -1494,7 +1508,7 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     // | per block of 256 target faces: survivors (clip), regular faces (search)
     // The 16 counter words come from the engine's zero-at-rest scratch (k_publish_all clears them again after copying them
     // to the mailbox) and k_search clears its block's survivor count: no memset in front of the search.
-    constexpr size_t CTL_HEAD = 8 + sizeof(FusedCounters) / 4;
+    constexpr size_t CTL_HEAD = QCUR_BASE + 8 * QCUR_STRIDE; // (the eight region cursors of the regular queue behind the 16 counters: a line each)
     DevBuf<int32_t> ctl_tail(4 * (size_t)grid), ctl_own;
     unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl_tail.get());
     int32_t *blk_surv = ctl_tail.get() + 2 * (size_t)grid, *blk_rows = blk_surv + grid;
@@ -1561,8 +1575,8 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
 #define XR_SEARCH_LAUNCH(PACKED, FORM)                                                                                              \
     XR_LAUNCH("search", (k_search<PACKED, FORM>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face,                      \
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(),          \
-              ctl_head + 0, block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),    \
-              remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr)
+              ctl_head + QCUR_BASE, block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),   \
+              remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr, (int)region_cap)
         if (!(pack_ok && tree->n_face <= ((int64_t)1 << 24))) XR_SEARCH_LAUNCH(false, SEARCH_HIT_DEFAULT);
         else if (hit_form == 1) XR_SEARCH_LAUNCH(true, 1);
         else if (hit_form == 2) XR_SEARCH_LAUNCH(true, 2);
@@ -1623,27 +1637,27 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             if (scan_bases)
                 XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 1, false, 1>), dim3(engine().num_cu * bpc), dim3(CLIP_BLOCK), clip_shmem,
                           query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                          ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                          ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                           (const int32_t *)nullptr, blk_surv, (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
             else
                 XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 0, false, 1>), dim3(engine().num_cu * bpc), dim3(CLIP_BLOCK), clip_shmem,
                           query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                          ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                          ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                           (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
         } else if (scan_bases && clip_soa)
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, true>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                      ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr, dust);
         else if (scan_bases)
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, false>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                      ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr, dust);
         else
             XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 0>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                      ctl_head + 0, reg_capacity, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
+                      ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
                       (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, dust);
         if (scan_mode == 1)
             XR_LAUNCH("assemble_scan", k_assemble_scan, dim3(1), dim3(1024), 0, blk_rows, blk_surv, (int64_t)n_blocks, (int)grid,
@@ -1690,8 +1704,9 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         const int32_t err = mail[5], rows_regular = mail[6], p_regular = mail[8], p_big = mail[9];
         XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
         if (getenv("XR_DEBUG_FUSED"))
-            fprintf(stderr, "[tri] T=%lld C=%d big: %d faces %d pairs (%d pending) p_regular=%d p_big=%d err=%d rows=%d long=%d\n",
-                    (long long)T, C_reg, n_big, C_big, n_pending, p_regular, p_big, err, rows_regular, mail[7]);
+            fprintf(stderr, "[tri] T=%lld C=%d big: %d faces %d pairs (%d pending) p_regular=%d p_big=%d err=%d rows=%d long=%d regions %d %d %d %d %d %d %d %d of %lld\n",
+                    (long long)T, C_reg, n_big, C_big, n_pending, p_regular, p_big, err, rows_regular, mail[7], mail[11], mail[12], mail[13],
+                    mail[14], mail[15], mail[16], mail[17], mail[18], (long long)region_cap);
         (void)big_overflow;
         if (err & (1 | 8)) return false;
         if (n_pending > 0 || C_big > big_capacity) { // some big faces needed more room than the margin
@@ -1769,7 +1784,7 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
         // measurement / test switch back to the general kernel chain)
         const char *fused_env = getenv("XR_OVERLAP_FUSED");
         const bool fused_on = !(fused_env && atoi(fused_env) == 0);
-        if (fused_on && tree->m <= DENSE_MAX_NODES && query->m <= DENSE_MAX_NODES && T * SLOTS < ((int64_t)1 << 31)) {
+        if (fused_on && tree->m <= DENSE_MAX_NODES && query->m <= DENSE_MAX_NODES && (T + 8 * FB) * SLOTS < ((int64_t)1 << 31)) {
             if (overlap_tri(tree, query, tree_area, relative, csr, tile, early)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
         }

@@ -149,8 +149,10 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/,
 // meshes with fill values -- the usual D-Flow FM mesh, a raster paired with a triangle mesh): the register / LDS clip of
 // k_clip_small<8> (the oracle's arithmetic in the oracle's order) inside the same persistent loop, so that these pairs take
 // the one-round-trip pipeline too.  q_len / s_len / q_m / s_m are only read then.
+// (waves per SIMD: the persistent grid is sized for five resident blocks per CU -- four for KIND 1 -- and a single register beyond
+// 96 would leave only four: the block that does not fit runs BEHIND the others, +40 % on the kernel -- measured when one crept in)
 template <int BLOCK, int COUNT, bool SOA = false, int KIND = 0>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(KIND == 0 ? 5 : 4)))
 k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
                  const int32_t *__restrict__ rec_face, const int32_t *cand_tgt /* (rewritten in place when compacting) */,
                  const int32_t *cand_src, const int32_t *__restrict__ n_cand_dev, int64_t capacity,
@@ -174,12 +176,35 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
         tri_lut_init(sh_lut);
         __syncthreads();
     }
-    const int64_t n_cand = *n_cand_dev < capacity ? *n_cand_dev : capacity; // (a queue that overflowed is redone by the host)
-    const int64_t n_chunks = (n_cand + BLOCK - 1) / BLOCK;
-    const int64_t per_xcd = (n_chunks + 7) >> 3;
-    const int64_t n_slots = per_xcd * 8; // chunk slots incl. the empty ones of the last eighths
-    auto chunk_of = [&](int64_t j) -> int64_t { // j-th slot -> logical chunk (>= n_chunks: nothing)
-        return (j & 7) * per_xcd + (j >> 3);
+    // capacity > 0: ONE dense queue of *n_cand_dev pairs, its chunks dealt so that every XCD works on a contiguous eighth;
+    // capacity < 0: EIGHT dense regions of -capacity pairs each (region x filled by the search blocks of XCD x, n_cand_dev[x] pairs):
+    // slot j is chunk j / 8 of region j mod 8 -- the same dealing, the regions' own lengths
+    const bool regions = capacity < 0;
+    const int64_t region_cap = regions ? -capacity : 0;
+    int64_t n_cand = 0, per_xcd;
+    auto region_len = [&](int x) -> int64_t { // (uniform: a scalar load; a region that overflowed is redone by the host)
+        const int64_t n = n_cand_dev[x * QCUR_STRIDE];
+        return n < region_cap ? n : region_cap;
+    };
+    if (regions) {
+        int64_t longest = 0;
+#pragma unroll
+        for (int x = 0; x < 8; x++) longest = region_len(x) > longest ? region_len(x) : longest;
+        per_xcd = (longest + BLOCK - 1) / BLOCK;
+    } else {
+        n_cand = *n_cand_dev < capacity ? *n_cand_dev : capacity; // (a queue that overflowed is redone by the host)
+        per_xcd = ((n_cand + BLOCK - 1) / BLOCK + 7) >> 3;
+    }
+    const int64_t n_slots = per_xcd * 8; // chunk slots incl. the empty ones of the shorter eighths
+    // j-th slot -> index of its first pair; *end = one behind the last pair the slot's stretch may hold
+    auto slot_first = [&](int64_t j, int64_t *end) -> int64_t {
+        if (regions) {
+            const int x = (int)(j & 7);
+            *end = (int64_t)x * region_cap + region_len(x);
+            return (int64_t)x * region_cap + (j >> 3) * BLOCK;
+        }
+        *end = n_cand;
+        return ((j & 7) * per_xcd + (j >> 3)) * BLOCK;
     };
     const double2 *tfx = reinterpret_cast<const double2 *>(q_fxy);
     const double2 *sfx = reinterpret_cast<const double2 *>(rec_fxy);
@@ -191,8 +216,9 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
         tq = 0;
         s = 0;
         if (slot < n_slots) {
-            const int64_t c = chunk_of(slot) * BLOCK + tid;
-            if (c < n_cand) {
+            int64_t end;
+            const int64_t c = slot_first(slot, &end) + tid;
+            if (c < end) {
                 tq = cand_tgt[c];
                 s = cand_src[c];
             }
@@ -203,8 +229,9 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
     load_idx(slot, n_tq, n_s);
     bool overflow = false;
     for (; slot < n_slots; slot += stride) {
-        const int64_t c = chunk_of(slot) * BLOCK + tid;
-        const bool active = c < n_cand;
+        int64_t c_end;
+        const int64_t c = slot_first(slot, &c_end) + tid;
+        const bool active = c < c_end;
         int sid = 0;
         const int cur_tq = n_tq;
         double area = 0.0;
@@ -257,7 +284,7 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
                 const_cast<int32_t *>(cand_tgt)[w0 + rank] = cur_tq;
                 const_cast<int32_t *>(cand_src)[w0 + rank] = sid;
             }
-            if ((tid & 63) == 0 && w0 < n_cand) wave_surv[w0 >> 6] = __popcll(surv);
+            if ((tid & 63) == 0 && w0 < c_end) wave_surv[w0 >> 6] = __popcll(surv);
         } else if (active) {
             overflow = overflow || area == TRI_AREA_OVERFLOW;
             cand_area[c] = area;
@@ -725,6 +752,13 @@ __global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right
     const int t = threadIdx.x;
     int32_t w = 0;
     if (t < 16) w = c[t];
+    // (the cursors of the eight regions of the regular pair queue, a line each: their sum is the number of regular pairs, which
+    // takes the place of the single cursor of word 0)
+    const int32_t cur = (t >= 16 && t < 24) ? c[QCUR_BASE + (t - 16) * QCUR_STRIDE] : 0;
+    int32_t c_reg_sum = cur;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c_reg_sum += __shfl_xor(c_reg_sum, d, 64);
+    if (t == 0) w = c_reg_sum;
     // mailbox slot of word t: [0..4] regular pairs, big pairs, big faces, not fitting, (unused); then the FusedCounters
     // fields in the order the host reads them: error, rows_regular, n_apply_long, p_regular, p_big, max_row
     int slot = -1;
@@ -736,18 +770,20 @@ __global__ void k_publish_all(int32_t *c /* search counters, FusedCounters right
     else if (t == 8 + 4) slot = 9;
     else if (t == 8 + 6) slot = 10;
     if (slot >= 0) mail[slot] = w;
+    if (t >= 16 && t < 24) mail[11 + (t - 16)] = cur; // (the regions' own lengths: XR_DEBUG_FUSED)
     if (t == 8) *n_apply_long_out = w;
     if (t == 0) {
         // gate of an apply enqueued right behind this kernel (xr_overlap_apply_dev): open only if THIS attempt produced the
         // final matrix -- the very conditions the host checks after its read-back (overlap_tri); a failed attempt leaves
         // row pointers no kernel may follow
-        const int32_t c_reg = c[0], c_big = c[1], n_pending = c[3], err = c[8 + 1], p_reg = c[8 + 2], p_big = c[8 + 4];
+        const int32_t c_reg = c_reg_sum, c_big = c[1], n_pending = c[3], err = c[8 + 1], p_reg = c[8 + 2], p_big = c[8 + 4];
         const bool ok = c_reg >= 0 && c_big >= 0 && !(err & (1 | 4 | 8)) && n_pending == 0 && (int64_t)c_big <= big_capacity &&
                         (int64_t)p_reg + p_big <= cap;
         n_apply_long_out[1] = ok ? 1 : 0;
     }
     __builtin_amdgcn_s_waitcnt(0); // (every load above has returned before the words are cleared)
     if (t < 16) c[t] = 0;
+    if (t >= 16 && t < 24) c[QCUR_BASE + (t - 16) * QCUR_STRIDE] = 0;
     (void)fc;
     // the host polls the sequence word (mailbox_wait_seq): it goes out BEHIND the words above (one wave: a system-scope
     // release covers the stores of all its lanes)
