@@ -761,7 +761,7 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
             b_build = 4 * (nodes_s + nodes_t) + 16 * (sxy2.shape[0] + txy2.shape[0]) + 12 * P2 + 4 * (T2 + 1)
             out[tag] = {
                 "source_faces": S2, "target_faces": T2, "candidate_pairs": C2, "nnz": P2, "weights_ms": 1e3 * dt,
-                "target_cells_per_s": T2 / dt, "us_per_million_candidate_pairs": 1e9 * dt / max(C2, 1) if C2 else None,
+                "target_cells_per_s": T2 / dt, "ns_per_candidate_pair": 1e9 * dt / max(C2, 1) if C2 else None,
                 "roofline": {"bound": "hbm", "algorithmic_bytes": b_build, "achieved_GBps_whole_build": b_build / dt / 1e9,
                              "frac_of_hbm_peak_whole_build": b_build / dt / 1e9 / HBM_PEAK_GBS,
                              "note": "B_build of SURVEY 8(d) over the WHOLE weight build (prepare x2, index, search, clip, assembly), "
