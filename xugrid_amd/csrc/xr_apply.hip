@@ -1825,6 +1825,38 @@ __global__ void k_reduce_partial_rows(int method, const double *__restrict__ row
     out[i] = partial_finalize(method, st);
 }
 
+// One variable: a thread per owned target, one specialisation per reducer (the components are compile-time registers, a row of
+// the (R, C) state table is one or two 16-byte loads) -- the run-time form above indexes the state by a loop over C and took
+// 40 us for 1M targets of one row each, 2.5 x what its 40 MB need.
+template <int METHOD>
+__global__ void __launch_bounds__(256)
+k_reduce_partial_rows_k1(const double *__restrict__ rows, const int64_t *__restrict__ indptr, const int64_t *__restrict__ order,
+                         int64_t n_targets, double *__restrict__ out) {
+    constexpr int C = METHOD == XR_GEOMETRIC_MEAN ? 4 : 2;
+    constexpr bool IS_MAX = METHOD == XR_MINIMUM || METHOD == XR_MAXIMUM;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_targets) return;
+    const int64_t j0 = indptr[t], j1 = indptr[t + 1];
+    PartialState st = partial_identity(METHOD);
+    for (int64_t j = j0; j < j1; j++) {
+        const double2 *row = reinterpret_cast<const double2 *>(rows + order[j] * C);
+        const double2 a = row[0];
+        if (IS_MAX) {
+            st.c[0] = fmax(st.c[0], a.x);
+            st.c[1] = fmax(st.c[1], a.y);
+        } else {
+            st.c[0] += a.x;
+            st.c[1] += a.y;
+        }
+        if (C == 4) {
+            const double2 b = row[1];
+            st.c[2] += b.x;
+            st.c[3] += b.y;
+        }
+    }
+    out[t] = partial_finalize(METHOD, st);
+}
+
 template <typename SRC>
 __global__ void k_apply_coo(const int32_t *__restrict__ row, const int32_t *__restrict__ col, int64_t nnz, int64_t T,
                             int64_t S, const SRC *__restrict__ source, double *__restrict__ out) {
@@ -3028,7 +3060,24 @@ int xr_reduce_partial_rows_dev(int method, const double *rows_dev, const int64_t
     if (n_targets * K > 0) {
         XR_REQUIRE(indptr_dev && out_dev, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: NULL argument");
         static const bool plain = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
-        if (K >= 8 && !plain)
+        if (K == 1 && !plain && (reinterpret_cast<uintptr_t>(rows_dev) & 15) == 0) {
+#define XR_REDUCE_K1(M)                                                                                                             \
+    case M:                                                                                                                         \
+        XR_LAUNCH("reduce_partial_rows", k_reduce_partial_rows_k1<M>, dim3(div_up(n_targets, 256)), dim3(256), 0, rows_dev,         \
+                  indptr_dev, order_dev, n_targets, out_dev);                                                                       \
+        break;
+            switch (method) {
+                XR_REDUCE_K1(XR_MEAN)
+                XR_REDUCE_K1(XR_FIRST_ORDER_CONSERVATIVE)
+                XR_REDUCE_K1(XR_SUM)
+                XR_REDUCE_K1(XR_HARMONIC_MEAN)
+                XR_REDUCE_K1(XR_GEOMETRIC_MEAN)
+                XR_REDUCE_K1(XR_MINIMUM)
+                XR_REDUCE_K1(XR_MAXIMUM)
+            default: XR_REQUIRE(false, XR_ERR_INVALID, "reducer %d does not decompose over source shards", method);
+            }
+#undef XR_REDUCE_K1
+        } else if (K >= 8 && !plain)
             XR_LAUNCH("reduce_partial_rows", k_reduce_partial_rows_t, dim3(div_up(n_targets, 64), (unsigned)std::min<int64_t>(div_up(K, 32), 64)),
                       dim3(256), 0, method, rows_dev, indptr_dev, order_dev, n_targets, K, out_dev);
         else

@@ -292,8 +292,7 @@ __device__ int bary_weights(const double *__restrict__ poly, int n, P2 p, double
                         double tt = tpar / len2;
                         if (tt < 0) tt = 0;
                         if (tt > 1) tt = 1;
-                        w[(i) * ws] = 1.0 - tt;
-                        w[(in) * ws] = tt;
+                        for (int j = 0; j < n; j++) w[(j) * ws] = j == i ? 1.0 - tt : j == in ? tt : 0.0;
                         return (1.0 - tt > 0 ? 1 : 0) + (tt > 0 ? 1 : 0);
                     }
                 }
@@ -386,7 +385,7 @@ k_barycentric_cm(const double *__restrict__ rec_fxy, const uint8_t *__restrict__
     }
     double *w = weights + i;
     const int len = rec_len[r];
-    for (int j = 0; j < len; j++) w[(int64_t)j * n] = 0.0;
+    // (bary_weights writes every one of the cell's len slots; nothing beyond them is ever read)
     const int c = bary_weights(rec_fxy + 2 * face_vertex_base(rec_off, r, m), len, p, tol, w, n);
     n_pos[i] = cell_flag[cell] ? NPOS_FIX : (uint8_t)c;
 }
@@ -488,20 +487,35 @@ k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict_
         if (indptr[i + 1] != pos) {
             const FI *face = faces_ccw + face_of_point[i] * m;
             const double *w = weights + i;
-            for (int j = 0; j < m && face[j] >= 0; j++) {
-                const double wj = w[(int64_t)j * n];
-                if (wj > 0) {
-                    const int64_t vtx = face[j];
-                    const int32_t col = vtx < n_identity ? (int32_t)vtx : (int32_t)vertex_face[vtx];
-                    if (staged) {
-                        sh_idx[pos - base] = col;
-                        sh_val[pos - base] = wj;
-                    } else {
-                        indices[pos] = col;
-                        data[pos] = wj;
-                    }
-                    pos++;
+            auto emit = [&](int64_t vtx, double wj) {
+                const int32_t col = vtx < n_identity ? (int32_t)vtx : (int32_t)vertex_face[vtx];
+                if (staged) {
+                    sh_idx[pos - base] = col;
+                    sh_val[pos - base] = wj;
+                } else {
+                    indices[pos] = col;
+                    data[pos] = wj;
                 }
+                pos++;
+            };
+            // the first eight slots (the typical cell has six corners) as two rounds of independent loads -- the corner ids,
+            // then the weights of the corners that exist -- instead of a chain of dependent (id, weight) pairs
+            constexpr int HEAD = 8;
+            FI id[HEAD];
+            double wv[HEAD];
+#pragma unroll
+            for (int j = 0; j < HEAD; j++) id[j] = j < m ? face[j] : (FI)-1;
+#pragma unroll
+            for (int j = 0; j < HEAD; j++) wv[j] = id[j] >= 0 ? w[(int64_t)j * n] : 0.0; // (-1 fill: nothing behind it either)
+            bool open = true;
+#pragma unroll
+            for (int j = 0; j < HEAD; j++) {
+                open = open && id[j] >= 0;
+                if (open && wv[j] > 0) emit((int64_t)id[j], wv[j]);
+            }
+            for (int j = HEAD; open && j < m && face[j] >= 0; j++) {
+                const double wj = w[(int64_t)j * n];
+                if (wj > 0) emit((int64_t)face[j], wj);
             }
         }
     }
@@ -741,25 +755,40 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             // (unstructured.py:175,193) = the mesh's own int32 connectivity, read as it is; or -- tree_order -- the tree's
             // counter-clockwise-normalised copy, materialised as a table first
             // (vertex -> face table and the interpolation map behind it in ONE buffer: their host parts are adjacent, one upload)
-            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)(reference_order ? 1 : voronoi->n_face * m)),
-                ids((size_t)(nv + 2 * n_extra + 1));
-            int64_t *const vface = ids.get(), *const n2n = ids.get() + nv;
+            DevBuf<int64_t> face((size_t)n), faces_ccw((size_t)(reference_order ? 1 : voronoi->n_face * m));
             DevBuf<int32_t> count((size_t)n);
             // (vertices below n_identity are their own face -- the centroids --: bary_fill never reads their table entries)
+            // The table and the flags of the cells with a substitute vertex stay on the tessellation: a second construction
+            // on it (another target, another tolerance) finds them there.
             {
                 const size_t n_tail = (size_t)(nv - n_identity), n_map = (size_t)(2 * n_extra);
                 std::vector<int64_t> host(n_tail + n_map);
                 if (n_tail > 0) memcpy(host.data(), vertex_face, sizeof(int64_t) * n_tail);
                 if (n_map > 0) memcpy(host.data() + n_tail, node_to_node_map, sizeof(int64_t) * n_map);
-                if (!host.empty()) h2d(vface + n_identity, host.data(), sizeof(int64_t) * host.size());
+                const bool same = voronoi->bary_ids.get() && voronoi->bary_n_identity == n_identity &&
+                                  voronoi->bary_n_extra == n_extra && voronoi->bary_ids_host == host;
+                if (!same) {
+                    voronoi->bary_flag_valid = false;
+                    voronoi->bary_ids.alloc((size_t)(nv + 2 * n_extra + 1));
+                    if (!host.empty()) h2d(voronoi->bary_ids.get() + n_identity, host.data(), sizeof(int64_t) * host.size());
+                    voronoi->bary_ids_host = std::move(host);
+                    voronoi->bary_n_identity = n_identity;
+                    voronoi->bary_n_extra = n_extra;
+                }
             }
+            int64_t *const vface = voronoi->bary_ids.get(), *const n2n = voronoi->bary_ids.get() + nv;
             if (!reference_order) mesh_faces_ccw_dev(voronoi, faces_ccw.get(), false);
-            DevBuf<uint8_t> cell_flag((size_t)voronoi->n_face), n_pos((size_t)n);
-            XR_LAUNCH("bary_cell_flag", k_bary_cell_flag, dim3(div_up(voronoi->n_face, 256)), dim3(256), 0, voronoi->faces_raw.get(),
-                      voronoi->n_face, m, nv - n_extra, cell_flag.get());
+            DevBuf<uint8_t> n_pos((size_t)n);
+            if (!voronoi->bary_flag_valid) {
+                voronoi->bary_cell_flag.alloc((size_t)voronoi->n_face);
+                XR_LAUNCH("bary_cell_flag", k_bary_cell_flag, dim3(div_up(voronoi->n_face, 256)), dim3(256), 0, voronoi->faces_raw.get(),
+                          voronoi->n_face, m, nv - n_extra, voronoi->bary_cell_flag.get());
+                voronoi->bary_flag_valid = true;
+            }
+            const uint8_t *const cell_flag_p = voronoi->bary_cell_flag.get();
             XR_LAUNCH("barycentric", k_barycentric_cm, dim3(div_up(n, 256)), dim3(256), 0, voronoi->rec_fxy.get(),
                       voronoi->rec_len.get(), voronoi->record_off(), m, voronoi->grid, voronoi->cell_start.get(), voronoi->rec_bb.get(),
-                      voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get(), cell_flag.get(), n_pos.get());
+                      voronoi->rec_face.get(), voronoi->n_face, pts.get(), n, tol, face.get(), w.get(), cell_flag_p, n_pos.get());
             if (join_later) {
                 side_join();
                 pre->on_side = false;

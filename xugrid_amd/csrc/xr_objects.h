@@ -1,5 +1,6 @@
 // xr_objects.h -- the two device-resident handle types behind the C ABI.
 #pragma once
+#include <vector>
 
 #include "xr_geom.h"
 #include "xr_internal.h"
@@ -71,6 +72,16 @@ struct xr_mesh {
     xr::DevBuf<uint8_t> rec_len;    // [n_face]
 
     int64_t last_candidates = 0;
+
+    // ---- kept by the barycentric construction when this mesh is a Voronoi tessellation (xr_locate.hip:barycentric_csr): the
+    // vertex -> face table with the interpolation map behind it, and the flags of the cells that hold a substitute vertex --
+    // a second interpolator on a cached tessellation uploads and recomputes nothing (its first kernel then runs BESIDE the
+    // source-side locate pass instead of behind a copy)
+    std::vector<int64_t> bary_ids_host;  // what was uploaded (tail of the vertex table, then the map)
+    xr::DevBuf<int64_t> bary_ids;        // [n_node + 2 n_extra + 1]
+    int64_t bary_n_identity = -1, bary_n_extra = -1;
+    xr::DevBuf<uint8_t> bary_cell_flag;  // [n_face], valid for bary_n_extra
+    bool bary_flag_valid = false;
 
     // vertex blocks flat + offsets instead of dense [n_face][m] (xr_geom.h)
     bool ragged() const { return m > xr::DENSE_MAX_NODES; }
