@@ -1477,10 +1477,15 @@ __device__ __forceinline__ void partial_add(int method, PartialState &st, double
     }
 }
 __device__ __forceinline__ void partial_combine(int method, PartialState &a, const double *b, int64_t stride, int C) {
+    // (static component indices: a loop over the run-time C puts the state into scratch memory)
     if (partial_is_max(method)) {
-        for (int c = 0; c < C; c++) a.c[c] = fmax(a.c[c], b[c * stride]);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (c < C) a.c[c] = fmax(a.c[c], b[c * stride]);
     } else {
-        for (int c = 0; c < C; c++) a.c[c] += b[c * stride];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+            if (c < C) a.c[c] += b[c * stride];
     }
 }
 __device__ __forceinline__ double partial_finalize(int method, const PartialState &st) {
@@ -1662,7 +1667,9 @@ k_apply_partial_kt(int method, const int32_t *__restrict__ indptr, const int32_t
     }
     const int C = partial_components(method);
     const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
-    for (int c = 0; c < C; c++) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) { // (static indices into the states: see partial_combine)
+        if (c >= C) break;
 #pragma unroll
         for (int kk = 0; kk < KT; kk++) {
             if (kk < kn) {
@@ -1713,9 +1720,12 @@ k_apply_partial_rows(int method, const int32_t *__restrict__ indptr, const int32
         }
     }
     sh_tout[threadIdx.x] = mine ? (int32_t)(row_order ? row_order[t] : t) : -1;
-    for (int c = 0; c < C; c++)
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        if (c >= C) break;
 #pragma unroll
         for (int kk = 0; kk < KT; kk++) sh_dyn[threadIdx.x * ld + c * KT + kk] = st[kk].c[c];
+    }
     __syncthreads();
     // 8 lanes per (row, component) line
     const int n_lines = 128 * C;
