@@ -1915,9 +1915,29 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                   csr->n, csr->m, src, K, out);
     };
     const bool long_on_side = csr->has_long && K >= PLAN_KT;
-    if (long_on_side) {
+    const bool use_plan = K > 1 && K >= PLAN_KT && getenv("XR_APPLY_NO_PLAN") == nullptr; // (measurement / test switch, read per call)
+    if (use_plan) { // (built once per matrix, on the main stream, in front of the fork)
+        ensure_tiled(csr);
+        ensure_plan(csr);
+    }
+    // the few blocks the plan could not take (hull slivers: too many entries or distinct columns): direct gathers, parallel
+    // over the variable tiles as well so that no thread walks a long row K / 8 times (tiles of 4 variables: these blocks hold
+    // rows of up to 256 entries that one thread walks alone).  Beside the planned blocks when the side stream is in use
+    // anyway (disjoint output rows; in line they were 0.07 ms behind the 1.5 ms of a K = 256 apply).
+    auto launch_unplanned = [&]() {
+        if (csr->plan_n_unplanned <= 0) return;
+        dim3 grid((unsigned)csr->plan_n_unplanned, div_up(K, 4));
+        XR_LAUNCH("apply_direct", (k_apply_direct<METHOD, SRC, 4>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
+                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out,
+                  csr->plan_unplanned.get());
+    };
+    // with a plan the side work is launched BEHIND the plan kernel but depends only on what precedes it (side_mark): the host
+    // reaches the long kernel's launch first, the three short side launches follow while it runs
+    const bool side_late = long_on_side && use_plan && side_mark();
+    if (long_on_side && !side_late) {
         SideScope side;
         launch_long_rows(false);
+        if (use_plan) launch_unplanned();
     }
     static const bool k1_block_kernel = getenv("XR_APPLY_K1") && !strcmp(getenv("XR_APPLY_K1"), "block"); // A/B switch
     if (K == 1 && !k1_block_kernel) {
@@ -1935,12 +1955,9 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                   csr->has_long ? huge.get() : (int32_t *)nullptr);
         if (csr->has_long) launch_long_rows(true);
     } else {
-        const bool no_plan = getenv("XR_APPLY_NO_PLAN") != nullptr; // measurement / test switch, read per call
-        if (K >= PLAN_KT && !no_plan) {
+        if (use_plan) {
             // many variables: rows regrouped into 2-D tiles, then a blocked CSR with per-block distinct-column
-            // lists (both built once per matrix)
-            ensure_tiled(csr);
-            ensure_plan(csr);
+            // lists (both built once per matrix, above)
             // LDS: one tile of distinct source values + the block's entries (weight + 16-bit local column); sized
             // for the largest planned block, so typical matrices run three blocks per CU instead of two
             // (tuning hooks: row blocks per workgroup, variables per tile, the L2-blocked order of k_apply_plan: super tiles of
@@ -1991,14 +2008,12 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             else if (plan_subs == 2) XR_PLAN_LAUNCH(4, 2);
             else XR_PLAN_LAUNCH(PLAN_KT, 1);
 #undef XR_PLAN_LAUNCH
-            if (csr->plan_n_unplanned > 0) {
-                // the few blocks the plan could not take (hull slivers: too many entries or distinct columns): direct
-                // gathers, parallel over the variable tiles as well so that no thread walks a long row K / 8 times
-                // (tiles of 4 variables: these blocks hold rows of up to 256 entries that one thread walks alone)
-                dim3 grid((unsigned)csr->plan_n_unplanned, div_up(K, 4));
-                XR_LAUNCH("apply_direct", (k_apply_direct<METHOD, SRC, 4>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                          csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K,
-                          out, csr->plan_unplanned.get());
+            if (side_late) {
+                SideScope side(true);
+                launch_long_rows(false);
+                launch_unplanned();
+            } else if (!long_on_side) {
+                launch_unplanned();
             }
         } else {
             // a few variables: register-resident k-tiles, direct gathers, no LDS

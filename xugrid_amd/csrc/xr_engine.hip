@@ -800,23 +800,37 @@ static bool side_disabled() {
     return v && atoi(v) != 0;
 }
 
-SideScope::SideScope() {
+static bool lane_side_ready(Lane *l) {
+    if (l->side) return true;
+    hipStream_t st = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return false; // (no side stream: in line)
+    }
+    l->side = st;
+    l->fork_event = a;
+    l->join_event = b;
+    return true;
+}
+bool side_mark() {
+    if (side_disabled()) return false;
+    if (Lane *l = current_lane()) {
+        if (!lane_side_ready(l)) return false;
+        XR_HIP(hipEventRecord(l->fork_event, l->stream));
+        return true;
+    }
+    if (t_exclusive_depth == 0) return false;
+    XR_HIP(hipEventRecord(engine().fork_event, engine().stream));
+    return true;
+}
+SideScope::SideScope(bool at_mark) {
     if (side_disabled()) return;
     if (Lane *l = current_lane()) {
-        if (!l->side) {
-            hipStream_t st = nullptr;
-            hipEvent_t a = nullptr, b = nullptr;
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) {
-                (void)hipGetLastError();
-                return; // (no side stream: in line)
-            }
-            l->side = st;
-            l->fork_event = a;
-            l->join_event = b;
-        }
-        XR_HIP(hipEventRecord(l->fork_event, l->stream));
+        if (!lane_side_ready(l)) return;
+        if (!at_mark) XR_HIP(hipEventRecord(l->fork_event, l->stream));
         XR_HIP(hipStreamWaitEvent(l->side, l->fork_event, 0));
         l->on_side = true;
         l->side_active = true;
@@ -825,7 +839,7 @@ SideScope::SideScope() {
     }
     if (t_exclusive_depth == 0) return; // a shared call on a caller's stream: several threads may be here, no common side stream
     Engine &e = engine();
-    XR_HIP(hipEventRecord(e.fork_event, e.stream));
+    if (!at_mark) XR_HIP(hipEventRecord(e.fork_event, e.stream));
     XR_HIP(hipStreamWaitEvent(e.side, e.fork_event, 0));
     e.on_side = true;
     g_side_active = true;

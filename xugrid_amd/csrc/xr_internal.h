@@ -250,11 +250,15 @@ struct StreamOverride {
 // Works on the engine's own (exclusive) path and inside a shared call that has a lane; elsewhere (a shared call bound to
 // a caller's stream) the scope is a no-op and the work simply runs in line.
 struct SideScope {
-    SideScope();
+    // at_mark: the side work depends on what was enqueued up to the last side_mark() of this thread, not on what followed it
+    // (a long kernel launched on the main stream first: the side work runs beside it, and the host reaches that launch
+    // without the side launches in front of it)
+    explicit SideScope(bool at_mark = false);
     ~SideScope();
     int mode = 0; // 0: in line, 1: engine side stream, 2: the lane's side stream
 };
 void side_join();
+bool side_mark(); // record the fork point now; false: no side stream here (SideScope(true) would run in line, i.e. BEHIND what follows)
 
 inline unsigned div_up(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
