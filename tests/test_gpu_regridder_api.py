@@ -189,8 +189,26 @@ def test_methods_and_errors(hip):
         xa.OverlapRegridder(grid, target, method="does_not_exist")
     with pytest.raises(ValueError):
         xa.OverlapRegridder.create_percentile_method(150.0)
+    # a caller's own reduction (regridder.py:136-137, examples/overlap_regridder.py:105-169): the weights are the engine's, the
+    # callable runs on the host over (values, weights, workspace) of every non-empty row
+    def own_mean(values, weights, workspace):
+        total = 0.0
+        weight_sum = 0.0
+        for value, weight in zip(values, weights):
+            if ~np.isnan(value):
+                total += value * weight
+                weight_sum += weight
+        if weight_sum == 0.0:
+            return np.nan
+        return total / weight_sum
+
+    zz = np.stack([z, np.where(np.arange(z.size) % 7 == 0, np.nan, z)])
+    mine = xa.OverlapRegridder(grid, target, method=own_mean).regrid(zz)
+    assert np.array_equal(mine, xa.OverlapRegridder(grid, target, method="mean").regrid(zz), equal_nan=True)
+    assert np.array_equal(xa.OverlapRegridder(grid, target, method=lambda v, w, ws: np.nanmax(v)).regrid(z),
+                          xa.OverlapRegridder(grid, target, method="maximum").regrid(z), equal_nan=True)
     with pytest.raises(TypeError):
-        xa.OverlapRegridder(grid, target, method=lambda v, w, ws: 0.0)  # needs a JIT CPU backend
+        xa.OverlapRegridder(grid, target, method=3.5)
     with pytest.raises(TypeError):
         xa.OverlapRegridder(1, target)
     with pytest.raises(TypeError):

@@ -240,3 +240,35 @@ def test_ugrid2d_coordinates_cannot_go_stale():
     assert np.array_equal(g.node_coordinates[:, 1], xy[:, 1] + 1.0)
     with pytest.raises(ValueError):
         g.node_x = np.zeros(3)
+
+
+def test_custom_reduction_callable_on_cached_weights():
+    """A caller's own reduction (regridder.py:136-137; examples/overlap_regridder.py:105-169) over cached weights: the loop of
+    make_regrid (regridder.py:41-67) -- NaN-initialised output, empty rows untouched, values in the order of the row's indices,
+    a workspace of the row's length -- needs no device."""
+    import xugrid_amd as xa
+
+    xy = np.array([[0.0, 0], [1, 0], [2, 0], [3, 0], [0, 1], [1, 1], [2, 1], [3, 1]])
+    quads = np.array([[0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6]])
+    src = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, quads)
+    txy = np.array([[0.0, 0], [1.5, 0], [3, 0], [0, 1], [1.5, 1], [3, 1], [4, 0], [4, 1]])
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, np.array([[0, 1, 4, 3], [1, 2, 5, 4], [2, 6, 7, 5]]))
+    ds = {"__regrid_data": np.array([1.0, 0.5, 0.5, 1.0]), "__regrid_indices": np.array([0, 1, 1, 2]),
+          "__regrid_indptr": np.array([0, 2, 4, 4]), "__regrid_n": np.array(3), "__regrid_m": np.array(3), "__regrid_nnz": np.array(4)}
+    ds.update(xa.regrid.UnstructuredGrid2d(src).to_dataset("__source"))
+    seen = []
+
+    def own(values, weights, workspace):
+        seen.append((values.copy(), weights.copy(), workspace.shape))
+        workspace[:] = values * weights
+        return workspace.sum() if not np.isnan(values).all() else np.nan
+
+    data = np.array([[1.0, 2.0, 4.0], [np.nan, 2.0, 4.0]])
+    out = xa.OverlapRegridder.from_weights(ds, tgt, method=own).regrid(data)
+    assert out.shape == (2, 3)
+    assert np.array_equal(out[0], [2.0, 5.0, np.nan], equal_nan=True)  # (row 2 is empty: stays NaN, the callable is not called)
+    assert np.isnan(out[1, 0]) and out[1, 1] == 5.0 and np.isnan(out[1, 2])
+    assert len(seen) == 4 and np.array_equal(seen[1][0], [2.0, 4.0]) and np.array_equal(seen[1][1], [0.5, 1.0]) and seen[1][2] == (2,)
+    assert xa.OverlapRegridder.from_weights(ds, tgt, method=lambda v, w, ws: float(v.size)).regrid(data[0]).tolist()[:2] == [2.0, 2.0]
+    with pytest.raises(TypeError):
+        xa.OverlapRegridder.from_weights(ds, tgt, method=3.5)

@@ -56,6 +56,39 @@ def convert_to_match(source, target):
     return source.convert_to(UnstructuredGrid2d), target.convert_to(UnstructuredGrid2d)
 
 
+def _make_host_regrid(func):
+    """make_regrid (regridder.py:34-69) for a caller-supplied reduction ``f(values, weights, workspace) -> float``: the same
+    loop -- output NaN-initialised, the row's source values copied into the first workspace row in the order of the row's
+    indices, the second workspace row handed over uninitialised, empty rows skipped -- run by the interpreter (the reference
+    compiles the callable with numba, which is used here too when it is importable).  O(nnz) Python calls: meant for what
+    the built-in reducers do not cover, not for million-cell grids."""
+    try:
+        import numba  # noqa: F401  (absent from this image; the reference's own path when present)
+
+        f = numba.njit(func)
+    except Exception:  # noqa: BLE001
+        f = func
+
+    def _regrid(source, A, size):
+        n_extra = source.shape[0]
+        out = np.full((n_extra, size), np.nan)
+        indptr = np.asarray(A.indptr)
+        n_work = int(np.diff(indptr).max()) if A.n > 0 else 0
+        workspace = np.empty((2, max(n_work, 1)), dtype=np.float64)
+        indices, data = np.asarray(A.indices), np.asarray(A.data, dtype=np.float64)
+        rows = np.flatnonzero(indptr[1:] > indptr[:-1])
+        for extra_index in range(n_extra):
+            source_flat = source[extra_index]
+            for target_index in rows:
+                s, e = int(indptr[target_index]), int(indptr[target_index + 1])
+                values = workspace[0, : e - s]
+                values[:] = source_flat[indices[s:e]]
+                out[extra_index, target_index] = f(values, data[s:e], workspace[1, : e - s])
+        return out
+
+    return _regrid
+
+
 class BaseRegridder(abc.ABC):
     _METHODS = {}
 
@@ -82,15 +115,23 @@ class BaseRegridder(abc.ABC):
         elif isinstance(func, Method):
             self._method = func
         elif callable(func):
-            raise TypeError(
-                "custom Python reduction callables need a JIT CPU backend; the HIP engine only runs the "
-                f"built-in reducers {sorted(self._METHODS)} and create_percentile_method(p)"
-            )
+            # the caller's OWN reduction (regridder.py:136-137; examples/overlap_regridder.py:105-169): Python code cannot run on
+            # the device.  The weights stay the engine's; the row loop of make_regrid (regridder.py:41-67) hands the callable
+            # (values, weights, workspace) per non-empty target row on the host -- not a fallback of any built-in reducer.
+            self._method = None
+            self._custom = _make_host_regrid(func)
         else:
             raise TypeError(f"method must be string or callable, received: {type(func).__name__}")
 
     # ---- apply
     def _regrid(self, source: np.ndarray, size: int) -> np.ndarray:
+        if self._method is None:
+            w = self._ensure_host_weights()
+            if isinstance(w, MatrixCOO):
+                w = w.to_csr()
+            if w.n != size:
+                raise ValueError(f"the weights have {w.n} rows, the target grid {size} cells")
+            return self._custom(np.asarray(source, dtype=np.float64), w, size)
         out = self._ensure_device_weights().apply(source, self._method.method_id, self._method.percentile)
         if out.shape[1] != size:
             raise ValueError(f"the weights have {out.shape[1]} rows, the target grid {size} cells")
