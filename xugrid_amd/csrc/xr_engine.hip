@@ -150,7 +150,9 @@ void engine_init(int device) {
         // the side stream carries short latency-bound kernels next to a long one on the main stream: highest priority
         int lo = 0, hi = 0;
         XR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, hi));
+        const char *pr = getenv("XR_SIDE_PRIORITY"); // (measurement switch: lo / normal instead of the highest)
+        const int prio = pr && !strcmp(pr, "lo") ? lo : pr && !strcmp(pr, "normal") ? (lo + hi) / 2 : hi;
+        XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, prio));
     }
     // fork / join between two streams of the one device: a device-scope release is all the waiting stream needs (the default,
     // a system-scope release, writes the caches back to host visibility at every record: ~7 us between two dependent kernels

@@ -468,7 +468,7 @@ k_bary_fix_count(const int64_t *__restrict__ face_of_point, double *__restrict__
 
 // The entries of a block's 256 points are contiguous in the CSR: they are collected in LDS and written out as whole lines
 // (one thread writing its own 4- and 8-byte pieces cost 1.45 GB of HBM writes for 300 MB of entries, PMC).
-static constexpr int FILL_STAGE = 3072; // entries one block stages (36 KiB); fuller blocks write directly
+static constexpr int FILL_STAGE = 2048; // entries one block stages (24 KiB: six blocks per CU; the typical block holds 1600); fuller blocks write directly
 
 template <typename FI>
 __global__ void __launch_bounds__(256)

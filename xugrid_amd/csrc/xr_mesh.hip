@@ -399,7 +399,7 @@ __global__ void __launch_bounds__(256) k_widen_len(const uint8_t *__restrict__ l
 // out as whole lines (a thread writing its own 16-byte vertices at a stride of ~100 bytes touched 64 lines per store
 // instruction: 0.15 ms for the 3M vertices of a Voronoi tessellation).  The node ids are read where they are needed
 // (no 32-entry private copy of the row); orientation as face_shape(): the first non-collinear vertex triple decides.
-static constexpr int RAGGED_STAGE = 3072; // vertices one block stages (48 KiB); fuller blocks write directly
+static constexpr int RAGGED_STAGE = 2048; // vertices one block stages (32 KiB: five blocks per CU; a tessellation's typical block holds 1536); fuller blocks write directly
 
 __global__ void __launch_bounds__(256)
 k_fill_ragged(const double *__restrict__ node_xy, const int32_t *__restrict__ faces_raw, int64_t n_face, int m,
@@ -425,9 +425,17 @@ k_fill_ragged(const double *__restrict__ node_xy, const int32_t *__restrict__ fa
             break;
         }
         double2 *dst = staged ? sh_xy + (off[r] - base) : reinterpret_cast<double2 *>(out_xy) + off[r];
-        for (int j = 0; j < n; j++) {
-            const P2 p = load_p2(node_xy, face[j]);
-            dst[flip ? n - 1 - j : j] = make_double2(p.x, p.y);
+        // eight corners at a time as two rounds of independent loads (ids, then coordinates) instead of a chain of dependent pairs
+        for (int j0 = 0; j0 < n; j0 += 8) {
+            int id[8];
+            P2 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) id[u] = face[j0 + u < n ? j0 + u : n - 1];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p[u] = load_p2(node_xy, id[u]);
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (j0 + u < n) dst[flip ? n - 1 - (j0 + u) : j0 + u] = make_double2(p[u].x, p[u].y);
         }
     }
     if (!staged) return; // (uniform)
@@ -726,11 +734,34 @@ k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m_rt, const in
     constexpr int MA = MC > 0 ? MC : XR_MAX_FACE_NODES;
     const int m = MC > 0 ? MC : m_rt;
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n) return;
-    if (MC == 0 && bbox_opt && len_opt && !o_fxy) {
+    // Slots: `cursor` still holds the bucket histogram of the count pass and is handed out from the top down (the order inside
+    // a bucket is unspecified anyway), which leaves every bucket at zero for the next build.  One returning atomic per DISTINCT
+    // key of the block, as in the count pass (device-scope atomics are executed at the memory side of the fabric, ~40 G/s: one
+    // per face was half of this kernel); a face's slot inside the block's stretch is its rank in the LDS table.
+    __shared__ KeyTable sh_tab;
+    agg_clear(sh_tab);
+    const bool valid = f < n;
+    const bool stored_only = MC == 0 && bbox_opt && len_opt && !o_fxy;
+    // (the face's node ids go out together with the key, in front of the barriers: their gathers follow the slot computation
+    // without a further round trip)
+    int face[MA];
+    if (valid && !stored_only) {
+#pragma unroll
+        for (int j = 0; j < MA; j++)
+            if (j < m) face[j] = faces_raw[f * m + j];
+    }
+    const int k = valid ? key[f] : -1;
+    __syncthreads();
+    int tab_slot = 0, rank = 0;
+    if (valid) tab_slot = agg_insert(sh_tab, k, rank);
+    __syncthreads();
+    for (int s = threadIdx.x; s < AGG_SLOTS; s += 256)
+        if (sh_tab.key[s] >= 0) sh_tab.base[s] = start[sh_tab.key[s]] + atomicSub(&cursor[sh_tab.key[s]], sh_tab.cnt[s]) - sh_tab.cnt[s];
+    __syncthreads();
+    if (!valid) return;
+    const int64_t r = (int64_t)sh_tab.base[tab_slot] + rank;
+    if (stored_only) {
         // a prepared polygon mesh (its vertex blocks are written by ragged_fill): the record is the stored box and length
-        const int k = key[f];
-        const int64_t r = start[k] + atomicSub(&cursor[k], 1) - 1;
         const double4 b = reinterpret_cast<const double4 *>(bbox_opt)[f];
         perm[r] = (int32_t)f;
         o_len[r] = len_opt[f];
@@ -740,17 +771,6 @@ k_spatial_scatter(const int32_t *__restrict__ key, int64_t n, int m_rt, const in
             reinterpret_cast<double4 *>(o_bbox)[r] = b;
         return;
     }
-    // Two round trips instead of three: the face's node ids and the key go out together; then the returning atomic, and
-    // behind it -- not waiting for it -- the node gathers.  (Written key, atomic, node ids, gathers, the compiler issues the
-    // node ids only with the atomic and the gathers after its wait.)
-    int face[MA];
-#pragma unroll
-    for (int j = 0; j < MA; j++)
-        if (j < m) face[j] = faces_raw[f * m + j];
-    const int k = key[f];
-    // `cursor` still holds the bucket histogram of the count pass: slots are handed out from the top down (the order
-    // inside a bucket is unspecified anyway), which saves re-zeroing the array between the two passes
-    const int64_t r = start[k] + atomicSub(&cursor[k], 1) - 1;
     int nl;
     bool flip;
     face_shape<MA>(node_xy, face, m, nl, flip);
