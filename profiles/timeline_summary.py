@@ -13,6 +13,12 @@ def short(name):
     return n.replace("void ", "").replace("xr::", "")
 
 
+def med(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])
+
+
 def main():
     kpath, hpath, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     rows = list(csv.DictReader(open(kpath)))
@@ -81,14 +87,16 @@ def main():
     summary = {
         "what": "rocprofv3 --hip-trace --kernel-trace of profiles/timeline_run.py: per step (end of one K=1 apply kernel to the "
                 "end of the next) wall, time with at least one kernel running on any queue, idle time, and the idle gaps by the "
-                "kernels on either side (mean us per step)",
+                "kernels on either side (mean us per step); `gantt_us` and `median`: medians over the steps (a step that catches a host hiccup moves a mean by tens of microseconds)",
         "steps": len(out_steps),
         "mean": {k: sum(s[k] for s in out_steps) / n for k in ("wall_us", "device_busy_us", "idle_us", "kernels", "launch_calls",
                                                                "main_queue_kernel_sum_us", "side_queue_kernel_sum_us", "n_gaps")},
         "idle_by_gap_us_per_step": [{"after": a, "before": b, "us": round(v, 2)} for (a, b), v in pairs[:30]],
         "gantt_us": [{"kernel": k[0] + ("" if k[1] == 1 else "#%d" % k[1]), "queue": "main" if v[0][2] else "side",
-                      "start": round(sum(x[0] for x in v) / len(v), 2), "end": round(sum(x[1] for x in v) / len(v), 2)}
-                     for k, v in sorted(gantt.items(), key=lambda kv: sum(x[0] for x in kv[1]) / len(kv[1]))],
+                      "start": round(med([x[0] for x in v]), 2), "end": round(med([x[1] for x in v]), 2)}
+                     for k, v in sorted(gantt.items(), key=lambda kv: med([x[0] for x in kv[1]]))],
+        "median": {k: med([s[k] for s in out_steps]) for k in ("wall_us", "device_busy_us", "idle_us", "main_queue_kernel_sum_us",
+                                                               "side_queue_kernel_sum_us")},
         "per_step": out_steps,
     }
     print(json.dumps(summary, indent=1))
