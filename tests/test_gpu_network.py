@@ -174,6 +174,19 @@ def test_network_gridder_large(hip, oracle):
     np.testing.assert_allclose(per_edge[inside], full[inside], rtol=1e-9)
 
 
+def test_network_gridder_pipelined_upload(hip, oracle):
+    """From 20 MB of edge coordinates on the upload goes in pieces and the count pass of what has arrived runs on the side stream
+    beside the DMA of the rest (xr_edges.hip: edge_length_csr; launches of 16 MB = 524288 edges): 700k edges = one such launch and a
+    remainder, the same matrix as the oracle's, bit for bit."""
+    nodes, faces = meshgen.triangle_mesh(60_000, 3)
+    lo, hi = nodes.min(axis=0), nodes.max(axis=0)
+    span = (hi - lo).max()
+    rng = np.random.default_rng(9)
+    edges = random_network(rng, 700_000, lo.min() - 0.02 * span, hi.max() + 0.02 * span, 0.006 * span)
+    assert edges.nbytes >= (20 << 20)
+    device_vs_oracle(oracle, nodes, faces, edges)
+
+
 def test_celltree_intersect_edges_adapter(hip, oracle):
     """CellTree2d.intersect_edges (numba_celltree's call shape, unstructured.py:203-215): edge ids, face ids and
     the end points of every piece equal the oracle's, bit for bit, ordered by (edge, face)."""

@@ -317,16 +317,20 @@ k_edges_deal(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, c
              int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
              int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
              double *__restrict__ side_len, int big_cells, const int32_t *__restrict__ indptr, int32_t *__restrict__ indices,
-             double *__restrict__ data, const int32_t *__restrict__ todo_list, const int32_t *__restrict__ n_todo) {
+             double *__restrict__ data, const int32_t *__restrict__ todo_list, const int32_t *__restrict__ n_todo,
+             int64_t e_base = 0 /* count pass over a PIECE of the edges: item i is edge e_base + i (n_edge = the piece's length; edge_xy
+                                  and every per-edge output stay indexed by the edge's own id) */,
+             int64_t n_edge_all = 0 /* ... and the number of ALL edges, the stride of the slot-major side buffers (0: n_edge) */) {
     __shared__ int32_t sh_park[EDGE_DEAL][256];
     __shared__ int32_t sh_hits[256];
     const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
     const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
     const int64_t n_items = FILL ? (int64_t)*n_todo : n_edge;
+    const int64_t side_stride = n_edge_all > 0 ? n_edge_all : n_edge;
     const int64_t n_rounded = (n_items + 255) / 256 * 256; // (every lane of a wave takes part in the cross-lane reads)
     for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n_rounded; i += (int64_t)gridDim.x * 256) {
         const bool live = i < n_items;
-        const int64_t e = live ? (FILL ? (int64_t)todo_list[i] : i) : 0;
+        const int64_t e = live ? (FILL ? (int64_t)todo_list[i] : e_base + i) : 0;
         EdgeBox q{};
         bool walk = false, big = false;
         if (live) {
@@ -386,8 +390,8 @@ k_edges_deal(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, c
                     } else {
                         const int k_edge = atomicAdd(&sh_hits[wbase + ol], 1);
                         if (k_edge < EDGE_SLOTS) {
-                            side_face[(int64_t)k_edge * n_edge + e_owner] = face;
-                            side_len[(int64_t)k_edge * n_edge + e_owner] = len;
+                            side_face[(int64_t)k_edge * side_stride + e_owner] = face;
+                            side_len[(int64_t)k_edge * side_stride + e_owner] = len;
                         }
                     }
                 }
@@ -669,31 +673,66 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     mesh_prepare(tree, false);
     mesh_build_index(tree);
     DevBuf<double> edge_xy((size_t)n_edge * 4);
-    h2d(edge_xy.get(), edge_xy_host, sizeof(double) * 4 * (size_t)n_edge);
     DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters(8); // [0] big, [1] rows to sort, [2] redo, [4] pool cursor, [5] its refusal mark, [6] big edges that walk again
     DevBuf<int32_t> edge_hits((size_t)n_edge), side_face((size_t)n_edge * EDGE_SLOTS), redo_list((size_t)n_edge);
     DevBuf<double> side_len((size_t)n_edge * EDGE_SLOTS);
     XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
     XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 8, st));
+    // The edge coordinates come from the host (32 bytes per edge: 0.86 ms of PCIe for 1M edges, a third of the whole call).  With the
+    // thread-per-edge count pass -- independent per edge -- the upload goes in the staging pipeline's pieces (4 MiB = 131072 edges)
+    // and the count kernel of what has arrived runs on the side stream while the next pieces are on their way: XR_EDGE_PIPE=0
+    // restores the single upload + single launch (A/B switch).
+    const size_t edge_bytes = sizeof(double) * 4 * (size_t)n_edge;
+    static const bool pipe_off = getenv("XR_EDGE_PIPE") && atoi(getenv("XR_EDGE_PIPE")) == 0;
     const GridParams &g = tree->grid;
     const int big_grid = engine().num_cu * 8;
     const int big_cells = getenv("XR_EDGE_BIG") ? atoi(getenv("XR_EDGE_BIG")) : EDGE_BIG_CELLS; // tuning hook
     const bool major = getenv("XR_EDGE_WALK") ? !strcmp(getenv("XR_EDGE_WALK"), "major") : false; // tuning hook
     const bool deal = !major && !(getenv("XR_EDGE_KERNEL") && !strcmp(getenv("XR_EDGE_KERNEL"), "old")); // (A/B switch)
     const int deal_slots = getenv("XR_EDGE_DEAL") ? atoi(getenv("XR_EDGE_DEAL")) : 48; // tuning hook: parking slots per edge (24 / 32 / 40 / 48)
+    // count pass of the edges [e0, e0 + ne) with the thread-per-edge kernel
+    auto deal_count = [&](int64_t e0, int64_t ne) {
 #define XR_DEAL_COUNT(P)                                                                                                              \
-    XR_LAUNCH("edges_count", (k_edges_deal<false, P>), dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,              \
+    XR_LAUNCH("edges_count", (k_edges_deal<false, P>), dim3(div_up(ne, 256)), dim3(256), 0, edge_xy.get(), ne, g,                      \
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,      \
               tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,             \
               edge_hits.get(), side_face.get(), side_len.get(), big_cells, (const int32_t *)nullptr, (int32_t *)nullptr,              \
-              (double *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr)
-    if (deal) {
+              (double *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, e0, n_edge)
         if (deal_slots <= 24) XR_DEAL_COUNT(24);
         else if (deal_slots <= 32) XR_DEAL_COUNT(32);
         else if (deal_slots <= 40) XR_DEAL_COUNT(40);
         else XR_DEAL_COUNT(48);
-    }
 #undef XR_DEAL_COUNT
+    };
+    static const size_t pipe_bytes = (size_t)(getenv("XR_EDGE_PIPE_MB") ? std::max(4, atoi(getenv("XR_EDGE_PIPE_MB"))) : 16) << 20; // tuning hook
+    const bool piped = deal && !pipe_off && edge_bytes >= pipe_bytes + ((size_t)4 << 20) && !current_lane() && !stream_override();
+    if (piped) {
+        // fill(pinned, off, n) is called for piece k BEFORE its DMA is enqueued, i.e. right after the DMA of piece k - 1 was: the
+        // count kernel of piece k - 1 is forked behind that DMA (SideScope) and runs beside the DMA of piece k
+        const char *src_bytes = reinterpret_cast<const char *>(edge_xy_host);
+        size_t done = 0; // bytes whose DMA has been enqueued
+        auto count_upto = [&](size_t upto, bool last = false) {
+            // (launches of pipe_bytes of coordinates: a launch ends with its slowest waves and at three 50 KB blocks per CU a small
+            // grid is a round and a third -- 131072 edges per launch took 142 us each against 95 us for an eighth of the single
+            // launch, 262144 took 265 us: what the overlap gained the tails lost.  Half a million edges per launch by default.)
+            if (upto <= done || (!last && upto - done < pipe_bytes)) return;
+            SideScope side;
+            deal_count((int64_t)(done / 32), (int64_t)((upto - done) / 32));
+            done = upto;
+        };
+        h2d_staged(edge_xy.get(), edge_bytes, [&](char *pinned, size_t off, size_t n) {
+            count_upto(off);
+            parallel_ranges(n, 64, [=](size_t b, size_t e) { memcpy(pinned + b, src_bytes + off + b, e - b); });
+        });
+        count_upto(edge_bytes, true);
+        side_join();
+    } else {
+        h2d(edge_xy.get(), edge_xy_host, edge_bytes);
+    }
+    if (piped) {
+    } else if (deal) {
+        deal_count(0, n_edge);
+    }
     else if (major)
     XR_LAUNCH("edges_count", k_edges_count<true>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
               tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
