@@ -29,6 +29,11 @@ struct xr_points {
     double tol_source = 0.0;
     bool on_side = false; // launched on the side stream: join before use
     bool pts_marked = false; // the engine's aux_event was recorded behind the kernel that fills `pts` (before locate_flag)
+    // round 5: the kernels are not launched when the handle is made but when somebody flushes the pending handles -- the Voronoi
+    // pre-step at the point where its host round trips begin (the device idles there for ~0.2 ms; launched at the start the
+    // locate pass only shared the vector ALUs with the pre-step's kernels, and the first of those that needs LDS waited for
+    // it to drain), or the construction that consumes the handle (a cached tessellation: no pre-step in between)
+    bool deferred = false;
 };
 
 
@@ -584,7 +589,28 @@ static void launch_points(xr_points *h) {
               source->rec_face.get(), source->n_face, h->pts.get(), h->n, h->tol_source, h->inside.get());
 }
 
-void flush_pending_points() {} // (kept for the Voronoi pre-step's call site: nothing is deferred any more)
+static std::vector<xr_points *> &pending_points() {
+    static std::vector<xr_points *> list; // (exclusive entry points only: no lock)
+    return list;
+}
+void flush_pending_points() {
+    auto &list = pending_points();
+    for (xr_points *h : list) {
+        if (!h->deferred) continue;
+        {
+            SideScope side; // (forks behind everything enqueued so far)
+            launch_points(h);
+        }
+        h->on_side = true;
+        h->deferred = false;
+    }
+    list.clear();
+}
+static void forget_pending_points(xr_points *h) {
+    auto &list = pending_points();
+    for (size_t i = 0; i < list.size(); i++)
+        if (list[i] == h) list[i] = list.back(), list.pop_back(), i--;
+}
 
 } // namespace xr
 
@@ -702,6 +728,7 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
     {
     XR_REQUIRE(voronoi && source && out, XR_ERR_INVALID, "xr_barycentric_csr: NULL argument");
     if (pre) {
+        if (pre->deferred) flush_pending_points(); // (nobody launched the source-side kernels yet: a cached tessellation)
         XR_REQUIRE(pre->source == source && !query && !points, XR_ERR_INVALID,
                    "xr_barycentric_csr: the prepared points belong to another source grid (or points were given twice)");
         n = pre->n;
@@ -857,11 +884,17 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
             h->inside.alloc((size_t)n);
             h->query = query;
             if (!query) h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
-            {
-                SideScope side; // (forks behind everything enqueued so far: the index of the source grid, the points)
-                launch_points(h);
+            static const bool defer = !(getenv("XR_POINTS_DEFER") && atoi(getenv("XR_POINTS_DEFER")) == 0); // (A/B switch)
+            if (defer) {
+                h->deferred = true; // launched by flush_pending_points
+                pending_points().push_back(h);
+            } else {
+                {
+                    SideScope side; // (forks behind everything enqueued so far: the index of the source grid, the points)
+                    launch_points(h);
+                }
+                h->on_side = true;
             }
-            h->on_side = true;
         }
         else if (n > 0) { // (no source faces: every point is outside)
             h->pts.alloc((size_t)n * 2);
@@ -881,6 +914,7 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
 int xr_points_destroy(xr_points *points) {
     XR_API_BEGIN
     if (points) {
+        forget_pending_points(points);
         stream_sync();
         delete points;
     }

@@ -172,6 +172,23 @@ k_vor_exterior(const int32_t *__restrict__ faces, int64_t n_face, int m, const i
         // gather of every neighbouring face's node list
         int ia = indptr[a], ib = indptr[b];
         const int ea = indptr[a + 1], eb = indptr[b + 1];
+        constexpr int ROW_REG = 8; // (a Delaunay node has ~6 faces)
+        if (ea - ia <= ROW_REG && eb - ib <= ROW_REG) {
+            // both rows in registers with ONE round of independent loads, then the intersection by all pairs: the merge below is a
+            // chain of ~10 dependent pairs of loads per half-edge (the kernel waited on memory for 57 % of its wave cycles)
+            int ra[ROW_REG], rb[ROW_REG];
+#pragma unroll
+            for (int u = 0; u < ROW_REG; u++) ra[u] = ia + u < ea ? rows[ia + u] : -1;
+#pragma unroll
+            for (int u = 0; u < ROW_REG; u++) rb[u] = ib + u < eb ? rows[ib + u] : -2;
+#pragma unroll
+            for (int u = 0; u < ROW_REG; u++) {
+                bool in_b = false;
+#pragma unroll
+                for (int w = 0; w < ROW_REG; w++) in_b = in_b || ra[u] == rb[w];
+                shared = shared || (in_b && ra[u] != (int)f);
+            }
+        } else
         while (ia < ea && ib < eb) {
             const int ga = rows[ia], gb = rows[ib];
             if (ga == gb) {
@@ -277,15 +294,15 @@ k_vor_interior(const double *__restrict__ node_xy, const double *__restrict__ cx
     const P2 p = load_p2(node_xy, (int)v);
     const int deg = e - s;
     if (deg <= VOR_CAP) {
-        for (int i0 = 0; i0 < deg; i0 += 4) {
-            int key[4];
-            P2 c[4];
+        for (int i0 = 0; i0 < deg; i0 += 8) { // (eight at a time: the typical row of six in ONE pair of dependent round trips)
+            int key[8];
+            P2 c[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) key[u] = rows_asc[s + (i0 + u < deg ? i0 + u : deg - 1)];
+            for (int u = 0; u < 8; u++) key[u] = rows_asc[s + (i0 + u < deg ? i0 + u : deg - 1)];
 #pragma unroll
-            for (int u = 0; u < 4; u++) c[u] = load_p2(cxy, key[u]);
+            for (int u = 0; u < 8; u++) c[u] = load_p2(cxy, key[u]);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < 8; u++) {
                 if (i0 + u < deg) {
                     sh_k[i0 + u][t] = key[u];
                     sh_d[i0 + u][t] = make_double2(c[u].x - p.x, c[u].y - p.y);
@@ -702,6 +719,9 @@ int xr_voronoi_create(xr_mesh *mesh, xr_voronoi **out) {
                       v->interior.get(), flag32.get(), counters.get() + 1);
         exclusive_scan_i32(flag32.get(), v->cell_rank.get(), N);
         XR_LAUNCH("vor_totals", k_vor_totals, dim3(1), dim3(64), 0, v->cell_rank.get() + N, v->indptr.get() + N, counters.get());
+        // (every kernel of the O(n) part is enqueued; from here on the host reads counters and lists back -- the device idles for
+        // most of the next 0.2-0.3 ms.  A pending source-side locate pass of a barycentric construction goes out here.)
+        flush_pending_points();
         int32_t h[8];
         d2h(h, counters.get(), sizeof(h));
         v->n_interior = h[3];
