@@ -795,6 +795,35 @@ def test_apply_many_variables_row_tiling(hip, oracle):
         E.DeviceCSR.from_arrays(oa, os_, indptr, csr.n, csr.m).set_row_keys(keys + key_range, key_range)
 
 
+def test_apply_plan_per_block_and_merged(hip, oracle, monkeypatch):
+    """The two forms of the many-variable apply plan (xr_apply.hip: ensure_plan) -- a distinct-column list per block of 256 rows,
+    or one per group of four blocks (chosen by itself when the blocks use the source lines poorly: qhull numberings) -- and the
+    automatic choice give the oracle's numbers, NaNs and a ragged last group included."""
+    from xugrid_amd import engine as E
+
+    sxy, sf = meshgen.triangle_mesh(30000, 5, delaunay=True)
+    txy, tf = meshgen.triangle_mesh(33000, 6, 30.0, 0.8, delaunay=True)
+    tree = oracle.CellTree2d(sxy, sf, -1)
+    oq, os_, oa = tree.intersect_faces(txy, tf, -1)
+    indptr = oracle.to_csr_indptr(oq, tf.shape[0])
+    rng = np.random.default_rng(11)
+    v = rng.normal(size=(20, sf.shape[0]))
+    v[5, ::13] = np.nan
+    v[11] = np.nan
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    for mode in ("0", "1", None):
+        if mode is None:
+            monkeypatch.delenv("XR_PLAN_MERGE", raising=False)
+        else:
+            monkeypatch.setenv("XR_PLAN_MERGE", mode)
+        csr = ms.overlap(mt)  # (a fresh matrix: the plan is built once per matrix, on its first many-variable apply)
+        for method, mid in (("mean", 0), ("maximum", 5), ("sum", 3), ("minimum", 4)):
+            assert_apply_equal(csr.apply(v, mid), oracle.regrid_csr(method, v, oa, os_, indptr, csr.n), indptr, f"{method} merge={mode}")
+        v32 = v[:9].astype(np.float32)
+        assert_apply_equal(csr.apply(v32, 0), oracle.regrid_csr("mean", v32, oa, os_, indptr, csr.n), indptr, f"f32 merge={mode}")
+    monkeypatch.delenv("XR_PLAN_MERGE", raising=False)
+
+
 def test_overlap_projected_coordinates(hip, oracle):
     """UTM-like coordinates (offsets of 5e5 / 6e6 m, 10-50 m cells): the f32 record bboxes are stored relative
     to the grid origin and rounded outwards, so nothing is lost against the f64 oracle."""

@@ -729,6 +729,7 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     __shared__ int32_t keys[PLAN_LMAX];
     __shared__ int32_t uniq[PLAN_UMAX];
     __shared__ int32_t sh_wave[4];
+    __shared__ int32_t sh_lines;
     const int64_t row0 = (int64_t)blockIdx.x * AP_BLOCK;
     const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
     const int seg0 = indptr[row0], seg1 = indptr[row_end];
@@ -794,10 +795,138 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
     __syncthreads();
     for (int u = threadIdx.x; u < total; u += AP_BLOCK) ucol[(int64_t)blockIdx.x * PLAN_UMAX + u] = uniq[u];
+    // how well the block uses the source lines it touches (16 values of 8 bytes per 128-byte line): the sums over all blocks
+    // decide whether a merged plan pays (ensure_plan)
+    if (threadIdx.x == 0) sh_lines = 0;
+    __syncthreads();
+    {
+        int mine = 0;
+        for (int u = threadIdx.x; u < total; u += AP_BLOCK) mine += (u == 0 || (uniq[u] >> 4) != (uniq[u - 1] >> 4)) ? 1 : 0;
+        if (mine) atomicAdd(&sh_lines, mine);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(max_entries + 2, total);
+        atomicAdd(max_entries + 3, sh_lines);
+    }
     if (threadIdx.x == 0) atomicMax(max_entries, n); // the apply kernel sizes its LDS stage for the largest planned block
     if (threadIdx.x == 0) nuniq[blockIdx.x] = total;
     // local index of every entry: binary search in the distinct list
     for (int i = threadIdx.x; i < n; i += AP_BLOCK) {
+        const int c = indices[seg0 + i];
+        int lo = 0, hi = total - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uniq[mid] < c) lo = mid + 1;
+            else hi = mid;
+        }
+        loc[seg0 + i] = (uint16_t)lo;
+    }
+}
+
+// MERGED plan (round 5, XR_PLAN_MERGE=1): ONE distinct-column list per GROUP of PLAN_GROUP neighbouring row blocks.  On a
+// qhull-numbered mesh a block of 256 rows uses ~4 of the 16 values of every source line it touches, a group of 1024 rows ~5
+// (52 lines per 256 rows instead of 85: profiles/r05_experiments/analysis_column_locality.*): the group's workgroup gathers every
+// line once for all its row blocks.  (Four blocks in lockstep with a list EACH -- XR_PLAN_SUBS=4 -- do not get there: the lines
+// in flight, 4 x 85 x 8 variables x 128 bytes, are ten times the L1, the siblings' requests miss again.)
+static constexpr int PLAN_GROUP = 4;
+static constexpr int PLAN_GUMAX = 2048; // distinct columns per group kept in the plan
+__global__ void __launch_bounds__(AP_BLOCK * PLAN_GROUP)
+k_plan_build_group(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
+                   int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc,
+                   int32_t *__restrict__ max_entries, int32_t *__restrict__ unplanned, int32_t *__restrict__ n_unplanned,
+                   int entry_cap) {
+    constexpr int NT = AP_BLOCK * PLAN_GROUP, KMAX = PLAN_LMAX * 2; // (8192 keys: four blocks of up to 2048 entries)
+    __shared__ int32_t keys[KMAX];
+    __shared__ int32_t uniq[PLAN_GUMAX];
+    __shared__ int32_t sh_wave[NT / 64];
+    __shared__ int32_t sh_bad;
+    const int64_t n_blocks = (T + AP_BLOCK - 1) / AP_BLOCK;
+    const int64_t b0 = (int64_t)blockIdx.x * PLAN_GROUP;
+    const int64_t row0 = b0 * AP_BLOCK;
+    const int64_t row_end = row0 + NT < T ? row0 + NT : T;
+    const int seg0 = indptr[row0], seg1 = indptr[row_end];
+    const int n = seg1 - seg0;
+    if (threadIdx.x == 0) sh_bad = 0;
+    __syncthreads();
+    // every block of the group has to fit the apply's per-block stage
+    if (threadIdx.x < PLAN_GROUP) {
+        const int64_t r0 = row0 + (int64_t)threadIdx.x * AP_BLOCK;
+        if (r0 < T) {
+            const int64_t r1 = r0 + AP_BLOCK < T ? r0 + AP_BLOCK : T;
+            const int nb_e = indptr[r1] - indptr[r0];
+            if (nb_e > entry_cap) sh_bad = 1;
+        }
+    }
+    __syncthreads();
+    auto give_up = [&]() {
+        if (threadIdx.x == 0) {
+            nuniq[blockIdx.x] = -1;
+            for (int g = 0; g < PLAN_GROUP; g++)
+                if (b0 + g < n_blocks) unplanned[atomicAdd(n_unplanned, 1)] = (int32_t)(b0 + g);
+        }
+    };
+    if (sh_bad || n > KMAX) {
+        give_up();
+        return;
+    }
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    for (int i = threadIdx.x; i < np2; i += NT) keys[i] = i < n ? indices[seg0 + i] : 0x7fffffff;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1) { // bitonic sort, ascending
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += NT) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int a = keys[i], b = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int per = (n + NT - 1) / NT;
+    const int a0 = threadIdx.x * per < n ? threadIdx.x * per : n, a1 = a0 + per < n ? a0 + per : n;
+    int cnt = 0;
+    for (int i = a0; i < a1; i++) cnt += (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
+    }
+    __syncthreads();
+    if (lane == 63) sh_wave[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+    for (int w = 0; w < NT / 64; w++) {
+        if (w < wave) woff += sh_wave[w];
+        total += sh_wave[w];
+    }
+    if (total > PLAN_GUMAX) {
+        give_up();
+        return;
+    }
+    int pos = woff + incl - cnt;
+    for (int i = a0; i < a1; i++)
+        if (i == 0 || keys[i] != keys[i - 1]) uniq[pos++] = keys[i];
+    __syncthreads();
+    for (int u = threadIdx.x; u < total; u += NT) ucol[(int64_t)blockIdx.x * PLAN_GUMAX + u] = uniq[u];
+    if (threadIdx.x < PLAN_GROUP) { // the apply kernel sizes its per-block stage for the largest planned block
+        const int64_t r0 = row0 + (int64_t)threadIdx.x * AP_BLOCK;
+        if (r0 < T) {
+            const int64_t r1 = r0 + AP_BLOCK < T ? r0 + AP_BLOCK : T;
+            atomicMax(max_entries, indptr[r1] - indptr[r0]);
+        }
+    }
+    if (threadIdx.x == 0) nuniq[blockIdx.x] = total;
+    for (int i = threadIdx.x; i < n; i += NT) { // local index of every entry: binary search in the group's list
         const int c = indices[seg0 + i];
         int lo = 0, hi = total - 1;
         while (lo < hi) {
@@ -820,7 +949,7 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
 // neighbours use the rest: as separate workgroups they drift apart and every one of them fetches the line on its own -- the L1
 // of a CU holds 256 lines, the L2 of an XCD four microseconds of traffic --, in lockstep on ONE CU the requests for a line meet
 // in that CU's L1.
-template <int METHOD, typename SRC, int KTILE, int SUBS>
+template <int METHOD, typename SRC, int KTILE, int SUBS, bool MERGE = false>
 __global__ void __launch_bounds__(AP_BLOCK * SUBS)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
              const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
@@ -828,11 +957,19 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
              const SRC *__restrict__ source, int64_t K, double *__restrict__ out, int lmax, int super_blocks, int item_tiles, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     const int sub = SUBS > 1 ? (int)threadIdx.x / AP_BLOCK : 0, tid = SUBS > 1 ? (int)threadIdx.x % AP_BLOCK : (int)threadIdx.x;
-    char *smem = smem_all + (size_t)sub * (((sizeof(double) * (KTILE * PLAN_UMAX + lmax) + sizeof(uint16_t) * lmax) + 15) / 16 * 16);
-    double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][PLAN_UMAX]
-    double *sh_w = vals + KTILE * PLAN_UMAX;                              // [lmax] = entries of the largest planned block
+    // MERGE: ONE value table for the workgroup (the group's distinct columns), the entries of every row block behind it
+    static_assert(!MERGE || SUBS == PLAN_GROUP, "a merged plan is built for groups of PLAN_GROUP row blocks");
+    constexpr int UMAX = MERGE ? PLAN_GUMAX : PLAN_UMAX;                  // columns of the value table
+    constexpr int GATHERERS = MERGE ? AP_BLOCK * SUBS : AP_BLOCK;         // threads that share a list
+    const size_t stage_bytes = ((sizeof(double) * (size_t)lmax + sizeof(uint16_t) * (size_t)lmax) + 15) / 16 * 16;
+    char *smem = MERGE ? smem_all
+                       : smem_all + (size_t)sub * (((sizeof(double) * (KTILE * PLAN_UMAX + lmax) + sizeof(uint16_t) * lmax) + 15) / 16 * 16);
+    double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][UMAX]
+    double *sh_w = MERGE ? reinterpret_cast<double *>(smem_all + sizeof(double) * KTILE * UMAX + (size_t)sub * stage_bytes)
+                         : vals + KTILE * PLAN_UMAX;                      // [lmax] = entries of the largest planned block
     uint16_t *sh_loc = reinterpret_cast<uint16_t *>(sh_w + lmax);         // [lmax]
-    constexpr int UPT = PLAN_UMAX / AP_BLOCK;                             // distinct columns per thread
+    constexpr int UPT = UMAX / GATHERERS;                                 // distinct columns per thread
+    const int gtid = MERGE ? (int)threadIdx.x : tid;                      // index among the threads that share the list
     // XCD-aware block order: hardware block b runs on XCD b % 8; give every XCD a CONTIGUOUS range of
     // row blocks (= one spatial region), so that lines shared by neighbouring blocks stay in one L2
     const int64_t n_blocks = (T + AP_BLOCK - 1) / AP_BLOCK;           // row blocks
@@ -864,9 +1001,9 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     // (a sub-block without work -- past the last row block, or unplanned: too many entries / distinct columns, k_apply_direct takes
     // those over its block list -- stays for the workgroup's barriers; SUBS == 1: it leaves)
     const int64_t row0 = (lb < n_blocks ? lb : 0) * AP_BLOCK;
-    const int nu = lb < n_blocks ? nuniq[lb] : -1;
-    if (SUBS == 1 && nu < 0) return;
-    const bool active = nu >= 0;
+    const int nu = MERGE ? nuniq[lg] : (lb < n_blocks ? nuniq[lb] : -1);
+    if ((SUBS == 1 || MERGE) && nu < 0) return; // (uniform over the workgroup)
+    const bool active = nu >= 0 && lb < n_blocks;
     const int64_t t = active ? row0 + tid : T;
     const int64_t row_end = row0 + AP_BLOCK < T ? row0 + AP_BLOCK : T;
     int s = 0, e = 0;
@@ -886,8 +1023,8 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     int64_t mycol[UPT];
 #pragma unroll
     for (int q = 0; q < UPT; q++) {
-        const int u = q * AP_BLOCK + tid;
-        mycol[q] = (u < nu && !(dbg & 1)) ? (int64_t)ucol[lb * PLAN_UMAX + u] : -1; // (dbg: measurement switches, XR_PLAN_DBG)
+        const int u = q * GATHERERS + gtid;
+        mycol[q] = (u < nu && !(dbg & 1)) ? (int64_t)ucol[(MERGE ? lg : lb) * UMAX + u] : -1; // (dbg: measurement switches, XR_PLAN_DBG)
     }
     __syncthreads();
     double normsum = 0.0;
@@ -913,11 +1050,11 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
         int my_nan = 0;
 #pragma unroll
         for (int q = 0; q < UPT; q++) {
-            const int u = q * AP_BLOCK + tid;
+            const int u = q * GATHERERS + gtid;
             if (u < nu) {
 #pragma unroll
                 for (int kk = 0; kk < KTILE; kk++) {
-                    vals[kk * PLAN_UMAX + u] = stage[q][kk];
+                    vals[kk * UMAX + u] = stage[q][kk];
                     my_nan |= (stage[q][kk] != stage[q][kk]) ? 1 : 0;
                 }
             }
@@ -949,7 +1086,7 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                     const double w = sh_w[j];
                     double v[KTILE];
 #pragma unroll
-                    for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * PLAN_UMAX + l];
+                    for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * UMAX + l];
 #pragma unroll
                     for (int kk = 0; kk < KTILE; kk++) {
                         if (METHOD == XR_MEAN) acc[kk] += w * v[kk];
@@ -985,7 +1122,7 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                 const double w = sh_w[j];
                 double v[KTILE];
 #pragma unroll
-                for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * PLAN_UMAX + l];
+                for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * UMAX + l];
 #pragma unroll
                 for (int kk = 0; kk < KTILE; kk++)
                     if (kk < kn) red[kk].add(v[kk], w, normsum);
@@ -1104,13 +1241,22 @@ static void ensure_tiled(const xr_csr *ccsr) {
     csr->tile_key.release();
 }
 
+// XR_PLAN_MERGE: 1 / 0 force a merged / per-block plan; unset: merged when the blocks use less than PLAN_MERGE_UTIL of the 16
+// values of the source lines they touch (measured by the per-block builder: ~4 on a qhull-numbered mesh, ~12 on a
+// lattice-numbered one -- there the lockstep of a group costs 7 % and saves nothing)
+static constexpr double PLAN_MERGE_UTIL = 6.0;
+static int plan_merge_mode() { // (read when a matrix' plan is built, once per matrix: a test can switch between matrices)
+    const char *e = getenv("XR_PLAN_MERGE");
+    return e ? (atoi(e) == 1 ? 1 : 0) : -1;
+}
+
 static void ensure_plan(const xr_csr *ccsr) {
     xr_csr *csr = const_cast<xr_csr *>(ccsr); // the plan is a cache attached to the weights
     if (csr->plan_ready) return;
     XR_REQUIRE(exclusive_held(), XR_ERR_INVALID, "internal: apply plan requested outside the exclusive scope");
     const int64_t nb = (csr->n + AP_BLOCK - 1) / AP_BLOCK;
-    csr->plan_ucol.alloc((size_t)nb * PLAN_UMAX);
-    csr->plan_nuniq.alloc((size_t)nb);
+    bool merged = plan_merge_mode() == 1;
+    int64_t n_lists = nb;
     csr->plan_loc.alloc((size_t)csr->nnz);
     csr->plan_lmax = 256;
     csr->plan_n_unplanned = 0;
@@ -1120,26 +1266,44 @@ static void ensure_plan(const xr_csr *ccsr) {
     // the direct kernel instead.
     static const int plan_cap = getenv("XR_PLAN_CAP") ? std::min(PLAN_LMAX, std::max(256, atoi(getenv("XR_PLAN_CAP")))) : 2048;
     if (nb > 0) {
-        DevBuf<int32_t> max_entries(2); // [0] largest planned block, [1] number of unplanned blocks
-        fill_i32(max_entries.get(), 0, 2);
+        DevBuf<int32_t> max_entries(4); // [0] largest planned block, [1] number of unplanned blocks, [2] distinct columns, [3] distinct lines (sums over the planned blocks)
         csr->plan_unplanned.alloc((size_t)nb);
-        XR_LAUNCH("plan_build", k_plan_build, dim3((unsigned)nb), dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get(),
-                  max_entries.get(), csr->plan_unplanned.get(), max_entries.get() + 1, plan_cap);
-        int32_t h[2];
+        auto build = [&](bool group) {
+            n_lists = group ? (nb + PLAN_GROUP - 1) / PLAN_GROUP : nb;
+            csr->plan_ucol.alloc((size_t)n_lists * (group ? PLAN_GUMAX : PLAN_UMAX));
+            csr->plan_nuniq.alloc((size_t)n_lists);
+            fill_i32(max_entries.get(), 0, 4);
+            if (group)
+                XR_LAUNCH("plan_build", k_plan_build_group, dim3((unsigned)n_lists), dim3(AP_BLOCK * PLAN_GROUP), 0, csr->indptr.get(),
+                          csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get(),
+                          max_entries.get(), csr->plan_unplanned.get(), max_entries.get() + 1, plan_cap);
+            else
+                XR_LAUNCH("plan_build", k_plan_build, dim3((unsigned)nb), dim3(AP_BLOCK), 0, csr->indptr.get(),
+                          csr->indices.get(), csr->n, csr->plan_ucol.get(), csr->plan_nuniq.get(), csr->plan_loc.get(),
+                          max_entries.get(), csr->plan_unplanned.get(), max_entries.get() + 1, plan_cap);
+        };
+        build(merged);
+        int32_t h[4];
         d2h(h, max_entries.get(), sizeof(h));
+        if (!merged && plan_merge_mode() < 0 && h[3] > 0 && nb >= 4 * PLAN_GROUP && (double)h[2] / (double)h[3] < PLAN_MERGE_UTIL) {
+            // (poor use of the source lines: the group plan gathers a line once for four row blocks)
+            merged = true;
+            build(true);
+            d2h(h, max_entries.get(), sizeof(h));
+        }
         const int m = h[0];
         csr->plan_n_unplanned = h[1];
         csr->plan_lmax = std::min(PLAN_LMAX, std::max(256, (m + 255) / 256 * 256));
         if (getenv("XR_DEBUG_PLAN")) {
-            std::vector<int32_t> nu((size_t)nb);
-            d2h(nu.data(), csr->plan_nuniq.get(), sizeof(int32_t) * (size_t)nb);
+            std::vector<int32_t> nu((size_t)n_lists);
+            d2h(nu.data(), csr->plan_nuniq.get(), sizeof(int32_t) * (size_t)n_lists);
             double sum = 0; int cnt = 0, mx = 0;
             for (auto v : nu) if (v >= 0) { sum += v; cnt++; mx = std::max(mx, (int)v); }
-            fprintf(stderr, "[plan] blocks %lld planned %d unplanned %d lmax %d avg distinct columns %.1f max %d nnz/block %.1f\n", (long long)nb, cnt,
+            fprintf(stderr, "[plan] %s blocks %lld planned %d unplanned %d lmax %d avg distinct columns %.1f max %d nnz/block %.1f\n", merged ? "merged (lists per group of 4 row blocks)" : "per block", (long long)nb, cnt,
                     csr->plan_n_unplanned, csr->plan_lmax, cnt ? sum / cnt : 0.0, mx, (double)csr->nnz / nb);
         }
     }
+    csr->plan_merged = merged;
     csr->plan_ready = true;
 }
 
@@ -1962,7 +2126,9 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             // for the largest planned block, so typical matrices run three blocks per CU instead of two
             // (tuning hooks: row blocks per workgroup, variables per tile, the L2-blocked order of k_apply_plan: super tiles of
             // `super_blocks` workgroups x items of `item_tiles` variable tiles)
-            static const int plan_subs = getenv("XR_PLAN_SUBS") ? (atoi(getenv("XR_PLAN_SUBS")) == 4 ? 4 : atoi(getenv("XR_PLAN_SUBS")) == 2 ? 2 : 1) : PLAN_SUBS_DEFAULT;
+            static const int plan_subs_env = getenv("XR_PLAN_SUBS") ? (atoi(getenv("XR_PLAN_SUBS")) == 4 ? 4 : atoi(getenv("XR_PLAN_SUBS")) == 2 ? 2 : 1) : PLAN_SUBS_DEFAULT;
+            const bool merged = csr->plan_merged;
+            const int plan_subs = merged ? PLAN_GROUP : plan_subs_env;
             // default: items of 64 variables, super tile = the XCD's whole range of row blocks -- every XCD sweeps its row blocks
             // once per 64 variables (the source planes in flight: 0.5 GB instead of all K of them; what the host-side split
             // into groups of 128 variables did until round 4, without its extra launches, forks and joins)
@@ -1975,7 +2141,9 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             auto sub_bytes = [&](int kt, int lmax) {
                 return ((sizeof(double) * ((size_t)kt * PLAN_UMAX + lmax) + sizeof(uint16_t) * lmax) + 15) / 16 * 16;
             };
-            const size_t shmem = sub_bytes(plan_kt, csr->plan_lmax) * plan_subs;
+            const size_t stage_bytes = ((sizeof(double) * (size_t)csr->plan_lmax + sizeof(uint16_t) * (size_t)csr->plan_lmax) + 15) / 16 * 16;
+            const size_t shmem = merged ? sizeof(double) * (size_t)plan_kt * PLAN_GUMAX + stage_bytes * PLAN_GROUP
+                                        : sub_bytes(plan_kt, csr->plan_lmax) * plan_subs;
             XR_REQUIRE(shmem <= (size_t)160 * 1024, XR_ERR_LIMIT, "internal: apply plan needs %zu bytes of LDS", shmem);
             // (dynamic LDS beyond 64 KB has to be allowed per kernel; applies run concurrently under the shared scope, so the
             // high-water mark per instantiation sits behind a mutex)
@@ -1986,8 +2154,9 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                 XR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                 granted = shmem;
             };
-            static size_t granted1 = 0, granted2 = 0, granted4 = 0;
-            if (plan_subs == 4) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 4>), granted4);
+            static size_t granted1 = 0, granted2 = 0, granted4 = 0, granted_m = 0;
+            if (merged) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, PLAN_GROUP, true>), granted_m);
+            else if (plan_subs == 4) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 4>), granted4);
             else if (plan_subs == 2) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 2>), granted2);
             else allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT, 1>), granted1);
             const int64_t n_groups = div_up(div_up(csr->n, AP_BLOCK), plan_subs);
@@ -2004,7 +2173,12 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
               csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),                   \
               csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out, csr->plan_lmax, super_blocks,      \
               item_tiles, plan_dbg)
-            if (plan_subs == 4) XR_PLAN_LAUNCH(4, 4);
+            if (merged)
+                XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, 4, PLAN_GROUP, true>), dim3((unsigned)plan_grid), dim3(AP_BLOCK * PLAN_GROUP), shmem,
+                          csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),
+                          csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out, csr->plan_lmax, super_blocks,
+                          item_tiles, plan_dbg);
+            else if (plan_subs == 4) XR_PLAN_LAUNCH(4, 4);
             else if (plan_subs == 2) XR_PLAN_LAUNCH(4, 2);
             else XR_PLAN_LAUNCH(PLAN_KT, 1);
 #undef XR_PLAN_LAUNCH

@@ -132,6 +132,7 @@ struct xr_csr {
     // "apply plan" for many source variables (built lazily, xr_apply.hip): per block of 256 stored
     // rows the sorted list of DISTINCT column ids and, per entry, its 16-bit position in that list
     bool plan_ready = false;
+    bool plan_merged = false;           // the lists are per GROUP of row blocks (k_plan_build_group), not per block
     xr::DevBuf<int32_t> plan_unplanned; // blocks the plan could not take (handled by the direct kernel)
     int plan_n_unplanned = 0;
     int plan_lmax = 0;               // entries of the largest planned block, rounded up to 256 (LDS stage of the apply)
