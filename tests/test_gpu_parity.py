@@ -797,7 +797,7 @@ def test_apply_many_variables_row_tiling(hip, oracle):
 
 def test_apply_plan_per_block_and_merged(hip, oracle, monkeypatch):
     """The two forms of the many-variable apply plan (xr_apply.hip: ensure_plan) -- a distinct-column list per block of 256 rows,
-    or one per group of four blocks (chosen by itself when the blocks use the source lines poorly: qhull numberings) -- and the
+    or one per group of neighbouring blocks (chosen by itself when the blocks use the source lines poorly: qhull numberings) -- and the
     automatic choice give the oracle's numbers, NaNs and a ragged last group included."""
     from xugrid_amd import engine as E
 

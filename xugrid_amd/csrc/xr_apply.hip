@@ -824,19 +824,21 @@ k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     }
 }
 
-// MERGED plan (round 5, XR_PLAN_MERGE=1): ONE distinct-column list per GROUP of PLAN_GROUP neighbouring row blocks.  On a
-// qhull-numbered mesh a block of 256 rows uses ~4 of the 16 values of every source line it touches, a group of 1024 rows ~5
-// (52 lines per 256 rows instead of 85: profiles/r05_experiments/analysis_column_locality.*): the group's workgroup gathers every
-// line once for all its row blocks.  (Four blocks in lockstep with a list EACH -- XR_PLAN_SUBS=4 -- do not get there: the lines
-// in flight, 4 x 85 x 8 variables x 128 bytes, are ten times the L1, the siblings' requests miss again.)
-static constexpr int PLAN_GROUP = 4;
-static constexpr int PLAN_GUMAX = 2048; // distinct columns per group kept in the plan
+// MERGED plan (round 5): ONE distinct-column list per GROUP of PLAN_GROUP neighbouring row blocks.  On a qhull-numbered mesh a
+// block of 256 rows uses ~4 of the 16 values of every source line it touches, a group of 512 rows 4.5, of 1024 rows 5 (66 / 52
+// lines per 256 rows instead of 85: profiles/r05_experiments/analysis_column_locality.*): the group's workgroup gathers every
+// line once for all its row blocks.  (Blocks in lockstep with a list EACH -- XR_PLAN_SUBS -- do not get there: the lines in
+// flight, 4 x 85 x 8 variables x 128 bytes, are ten times the L1, the siblings' requests miss again.)  Groups of two and of four
+// measured the same on the benchmark matrix (K = 256: 1.64 -> 1.53 / 1.56 ms: what the larger group saves in line fills its
+// 16-wave barriers cost); two blocks need 58 KB of LDS (two workgroups per CU) and cost a lattice-numbered matrix 2 %, four 7 %.
+static constexpr int PLAN_GROUP = 2;
+static constexpr int PLAN_GUMAX = 1024; // distinct columns per group kept in the plan
 __global__ void __launch_bounds__(AP_BLOCK * PLAN_GROUP)
 k_plan_build_group(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
                    int32_t *__restrict__ ucol, int32_t *__restrict__ nuniq, uint16_t *__restrict__ loc,
                    int32_t *__restrict__ max_entries, int32_t *__restrict__ unplanned, int32_t *__restrict__ n_unplanned,
                    int entry_cap) {
-    constexpr int NT = AP_BLOCK * PLAN_GROUP, KMAX = PLAN_LMAX * 2; // (8192 keys: four blocks of up to 2048 entries)
+    constexpr int NT = AP_BLOCK * PLAN_GROUP, KMAX = PLAN_LMAX * 2; // (8192 keys: the group's blocks of up to 2048 entries each)
     __shared__ int32_t keys[KMAX];
     __shared__ int32_t uniq[PLAN_GUMAX];
     __shared__ int32_t sh_wave[NT / 64];
@@ -1243,7 +1245,7 @@ static void ensure_tiled(const xr_csr *ccsr) {
 
 // XR_PLAN_MERGE: 1 / 0 force a merged / per-block plan; unset: merged when the blocks use less than PLAN_MERGE_UTIL of the 16
 // values of the source lines they touch (measured by the per-block builder: ~4 on a qhull-numbered mesh, ~12 on a
-// lattice-numbered one -- there the lockstep of a group costs 7 % and saves nothing)
+// lattice-numbered one -- there the lockstep of a group costs 2 % and saves nothing)
 static constexpr double PLAN_MERGE_UTIL = 6.0;
 static int plan_merge_mode() { // (read when a matrix' plan is built, once per matrix: a test can switch between matrices)
     const char *e = getenv("XR_PLAN_MERGE");
@@ -1286,7 +1288,7 @@ static void ensure_plan(const xr_csr *ccsr) {
         int32_t h[4];
         d2h(h, max_entries.get(), sizeof(h));
         if (!merged && plan_merge_mode() < 0 && h[3] > 0 && nb >= 4 * PLAN_GROUP && (double)h[2] / (double)h[3] < PLAN_MERGE_UTIL) {
-            // (poor use of the source lines: the group plan gathers a line once for four row blocks)
+            // (poor use of the source lines: the group plan gathers a line once for the group's row blocks)
             merged = true;
             build(true);
             d2h(h, max_entries.get(), sizeof(h));
@@ -1299,7 +1301,7 @@ static void ensure_plan(const xr_csr *ccsr) {
             d2h(nu.data(), csr->plan_nuniq.get(), sizeof(int32_t) * (size_t)n_lists);
             double sum = 0; int cnt = 0, mx = 0;
             for (auto v : nu) if (v >= 0) { sum += v; cnt++; mx = std::max(mx, (int)v); }
-            fprintf(stderr, "[plan] %s blocks %lld planned %d unplanned %d lmax %d avg distinct columns %.1f max %d nnz/block %.1f\n", merged ? "merged (lists per group of 4 row blocks)" : "per block", (long long)nb, cnt,
+            fprintf(stderr, "[plan] %s blocks %lld planned %d unplanned %d lmax %d avg distinct columns %.1f max %d nnz/block %.1f\n", merged ? "merged (a list per group of row blocks)" : "per block", (long long)nb, cnt,
                     csr->plan_n_unplanned, csr->plan_lmax, cnt ? sum / cnt : 0.0, mx, (double)csr->nnz / nb);
         }
     }
