@@ -341,7 +341,7 @@ static inline void cpu_relax();
 // reused after its event).  Anything else -- lanes, a caller's stream, the side stream, XR_MAIL_POLL=0 -- keeps the
 // synchronous path.
 static constexpr size_t FAST_D2H_MAX = (size_t)1 << 20;  // bytes of the pinned read-back page
-static constexpr size_t FAST_H2D_SLOT = (size_t)1 << 16, FAST_H2D_SLOTS = 16;
+static constexpr size_t FAST_H2D_SLOT = (size_t)1 << 18, FAST_H2D_SLOTS = 16; // (256 KB: the boundary lists of a Voronoi pre-step -- a pageable copy goes through a blit KERNEL, which waits for wave slots beside a kernel that fills the device)
 struct FastCopy {
     char *page = nullptr;          // coherent pinned: [0, FAST_D2H_MAX) data, then one sequence word
     int32_t *done = nullptr;       // device word: blocks of the copy kernel that have finished

@@ -391,16 +391,19 @@ k_vor_boundary_info(const int32_t *__restrict__ indptr, const double *__restrict
     }
 }
 
-// exclusive scan of the degrees by one block (a few thousand boundary nodes): ptr[0..n]
-__global__ void __launch_bounds__(1024) k_vor_scan_deg(const int64_t *__restrict__ deg, int64_t n, int64_t *__restrict__ ptr) {
-    __shared__ long long sh[1024];
+// exclusive scan of the degrees by one block (a few thousand boundary nodes): ptr[0..n].  256 threads, a wave per SIMD: a block
+// of 1024 threads needs four free wave slots on every SIMD of ONE CU, and beside a kernel that fills the device (the locate pass of
+// a barycentric construction runs on the side stream during this phase) it waited 200 us for them.
+__global__ void __launch_bounds__(256) k_vor_scan_deg(const int64_t *__restrict__ deg, int64_t n, int64_t *__restrict__ ptr) {
+    constexpr int NT = 256;
+    __shared__ long long sh[NT];
     const int t = threadIdx.x;
-    const int64_t chunk = (n + 1023) / 1024, i0 = (int64_t)t * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    const int64_t chunk = (n + NT - 1) / NT, i0 = (int64_t)t * chunk < n ? (int64_t)t * chunk : n, i1 = i0 + chunk < n ? i0 + chunk : n;
     long long sum = 0;
     for (int64_t i = i0; i < i1; i++) sum += deg[i];
     sh[t] = sum;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < NT; d <<= 1) {
         const long long add = t >= d ? sh[t - d] : 0;
         __syncthreads();
         sh[t] += add;
@@ -411,7 +414,7 @@ __global__ void __launch_bounds__(1024) k_vor_scan_deg(const int64_t *__restrict
         ptr[i] = run;
         run += deg[i];
     }
-    if (t == 1023) ptr[n] = sh[1023];
+    if (t == NT - 1) ptr[n] = sh[NT - 1];
 }
 
 // rows of the boundary nodes: `out` (8-byte words) = [faces (total, int64) | their centroids (2 total)]
@@ -453,7 +456,7 @@ static void voronoi_boundary(xr_voronoi *v) {
         h2d(d_in.get(), in.data(), sizeof(int64_t) * (size_t)(nb + ne));
         XR_LAUNCH("vor_boundary_info", k_vor_boundary_info, dim3(div_up(std::max(nb, ne), 256)), dim3(256), 0, v->indptr.get(),
                   v->mesh->node_xy.get(), v->centroids.get(), d_in.get(), nb, ne, d_info.get());
-        if (nb > 0) XR_LAUNCH("vor_scan_deg", k_vor_scan_deg, dim3(1), dim3(1024), 0, d_info.get(), nb, d_ptr.get());
+        if (nb > 0) XR_LAUNCH("vor_scan_deg", k_vor_scan_deg, dim3(1), dim3(256), 0, d_info.get(), nb, d_ptr.get());
         std::vector<int64_t> info((size_t)(3 * nb + 2 * ne));
         d2h(info.data(), d_info.get(), sizeof(int64_t) * info.size());
         for (int64_t i = 0; i < nb; i++) v->b_ptr[(size_t)i + 1] = v->b_ptr[(size_t)i] + info[(size_t)i];
