@@ -1389,8 +1389,13 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
 
 } // namespace xr
 #include "xr_overlap_fused.h"
+#include "xr_overlap_stream.h"
 namespace xr {
 
+static bool debug_fused() {
+    static const bool on = getenv("XR_DEBUG_FUSED") != nullptr;
+    return on;
+}
 static int xcd_remap_mask() {
     // bit 0 clip, bit 1 search, bit 2 row_fill.  Default: clip + search -- 15 % fewer HBM bytes fetched by both
     // (PMC: clip 161 -> 130 MB, search 56 -> 48 MB per launch) at an unchanged clip time and a 5 % shorter search;
@@ -1727,6 +1732,108 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     }
 }
 
+// Triangle x triangle pairs as ONE streamed kernel (xr_overlap_stream.h): a workgroup takes 256 target faces from the grid
+// walk to their finished CSR rows, big faces are listed and claimed by whichever block has finished its own rows.  One launch
+// + the publication; ONE host round trip.  -> false if the matrix has to go through the kernel chain (overlap_tri) after
+// all: a big face with more candidates than a block's stage, or a clip that needs more than 6 vertices.
+static bool overlap_stream(xr_mesh *tree, xr_mesh *query, const double *tree_area, bool relative, xr_csr *csr,
+                           const MortonParams &tile, EarlyApply *early) {
+    const int64_t T = query->n_face;
+    const GridParams &g = tree->grid;
+    hipStream_t st = launch_stream();
+    const int64_t n_blocks = div_up(T, FB);
+    const bool remap = xcd_remap_mask() & 2;
+    const unsigned grid = xcd_grid(n_blocks, remap);
+    int64_t per_face = 8; // CSR entries reserved per target face; regrown if the matrix is denser
+    int32_t *mail = const_cast<int32_t *>(engine().mailbox);
+    // the blocks' scratch stretches: pair words, (source id | dead), area -- SB_STRETCH per block, touched as far as the block's
+    // pairs go (1700 of 4096 on the benchmark) and read back by the block that wrote them
+    DevBuf<int32_t> sc_pair((size_t)grid * SB_STRETCH), sc_sid((size_t)grid * SB_STRETCH), ctl_own;
+    DevBuf<double> sc_area((size_t)grid * SB_STRETCH);
+    csr->n_long.alloc(2); // [0] rows of more than XR_APPLY_LONG_ROW entries, [1] gate of an apply enqueued behind the build
+    csr->row_order.alloc((size_t)T);
+    csr->has_row_order = true;
+    const size_t clip_shmem = (size_t)(TRI_MAXV + 1) * FB * sizeof(double2);
+    static_assert((size_t)(TRI_MAXV + 1) * FB * sizeof(double2) >= sizeof(int32_t) * (SLOTS + 1) * FB + (sizeof(float4) + sizeof(int32_t)) * BIGREC_BLOCK &&
+                      (size_t)(TRI_MAXV + 1) * FB * sizeof(double2) >= sizeof(int32_t) * SB_STRETCH,
+                  "the clip's columns are the largest of the three lives of the block's LDS region");
+    const double dust = overlap_dust_threshold(tree, query);
+    for (int attempt = 0;; attempt++) {
+        XR_REQUIRE(attempt < 8, XR_ERR_LIMIT, "xr_overlap: the weight matrix does not fit the device buffers");
+        const int64_t cap = per_face * T + ((int64_t)1 << 20);
+        XR_REQUIRE(cap < ((int64_t)1 << 31), XR_ERR_LIMIT, "nnz exceeds the int32 range");
+        csr->indices.alloc((size_t)cap);
+        csr->data.alloc((size_t)cap);
+        csr->long_rows.alloc((size_t)(cap / XR_APPLY_LONG_ROW + 1));
+        // control words + the list of big faces: zero at rest (k_publish_stream clears the words, a claimed list entry is cleared
+        // by the block that claimed it)
+        const size_t ctl_words = SC_HEAD + (size_t)T;
+        int32_t *ctl = zero_scratch(1, ctl_words);
+        const bool ctl_cached = ctl != nullptr;
+        if (!ctl_cached) {
+            ctl_own.alloc(ctl_words);
+            ctl = ctl_own.get();
+            XR_HIP(hipMemsetAsync(ctl, 0, ctl_words * sizeof(int32_t), st));
+        }
+        static const bool stream_debug = getenv("XR_STREAM_DEBUG") != nullptr; // phase clocks of the streamed kernel (measurement)
+        DevBuf<unsigned long long> dbg;
+        if (stream_debug) {
+            dbg.alloc(16);
+            XR_HIP(hipMemsetAsync(dbg.get(), 0, 16 * sizeof(unsigned long long), st));
+            XR_HIP(hipMemsetAsync(dbg.get() + 7, 0xff, sizeof(unsigned long long), st));
+        }
+        XR_LAUNCH("overlap_block", k_overlap_block, dim3(grid), dim3(FB), clip_shmem, query->qo_bbox(), query->qo_fxy(), query->qo_perm(), T,
+                  g, tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_face.get(), sc_pair.get(),
+                  sc_sid.get(), sc_area.get(), ctl, ctl + SC_HEAD, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr,
+                  tree_area, relative, dust, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
+                  csr->long_rows.get(), cap, remap, dbg.get());
+        host_stamp(5);
+        const int32_t seq = mailbox_next_seq();
+        XR_LAUNCH("publish", k_publish_stream, dim3(1), dim3(64), 0, ctl, csr->indptr.get(), T, csr->n_long.get(), mail, seq, cap);
+        if (ctl_cached) zero_scratch_done(1); // (words and list are zero again behind the two kernels)
+        if (early) {
+            // sizes unknown on the host yet: pessimistic flags (long rows possible, of any length) -- they only add blocks that
+            // look at the device-side list of long rows and find it short or empty; results do not depend on them
+            csr->nnz = 0;
+            csr->has_long = true;
+            csr->max_row_len = -1;
+            csr->apply_gated = true; // (the kernel looks at the gate k_publish_stream has just set: a failed attempt is skipped)
+            early->fn(csr);
+            csr->apply_gated = false;
+        }
+        host_stamp(6);
+        mailbox_wait_seq(seq);
+        host_stamp(7);
+        const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], err = mail[3], rows = mail[4], entries = mail[5];
+        XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
+        if (debug_fused())
+            fprintf(stderr, "[stream] T=%lld C=%d big: %d faces %d pairs rows=%d entries=%d err=%d long=%d max_row=%d\n", (long long)T, C_reg,
+                    n_big, C_big, rows, entries, err, mail[6], mail[7]);
+        if (stream_debug) {
+            unsigned long long h[16];
+            d2h(h, dbg.get(), sizeof(h));
+            const double us = 0.01; // 100 MHz
+            fprintf(stderr, "[stream clocks] per block (mean us): walk %.1f clip %.1f rows %.1f | big faces: %llu handled, mean %.1f us, longest %.1f us, most per block %llu | "
+                            "kernel span %.1f us, last block start %.1f us, longest block %.1f us\n",
+                    h[0] * us / n_blocks, h[1] * us / n_blocks, h[2] * us / n_blocks, h[4], h[4] ? h[3] * us / h[4] : 0.0, h[5] * us, h[6],
+                    (h[8] - h[7]) * us, (h[10] - h[7]) * us, h[9] * us);
+        }
+        XR_REQUIRE(!(err & 8), XR_ERR_INVALID, "xr_overlap: internal error (a listed face was never published)");
+        if (err & (1 | 2)) return false;
+        if ((err & 4) || entries < 0 || (int64_t)entries > cap) {
+            per_face *= 2;
+            continue;
+        }
+        XR_REQUIRE(rows == T, XR_ERR_INVALID, "xr_overlap: internal row count mismatch");
+        tree->last_candidates = (int64_t)C_reg + C_big;
+        csr->nnz = entries;
+        csr->has_long = mail[6] > 0; // rows of more than XR_APPLY_LONG_ROW entries (none: the apply skips their kernels)
+        csr->max_row_len = mail[6] > 0 ? mail[7] : XR_APPLY_LONG_ROW;
+        if (early) early->done = true; // (the apply enqueued in THIS attempt saw the final matrix)
+        return true;
+    }
+}
+
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, EarlyApply *early = nullptr) {
     // (the query side on the side stream next to the tree side was measured: the prepare kernels are bandwidth bound and
     // just slow each other down, 0.684 -> 0.706 ms per step)
@@ -1785,6 +1892,13 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
         const char *fused_env = getenv("XR_OVERLAP_FUSED");
         const bool fused_on = !(fused_env && atoi(fused_env) == 0);
         if (fused_on && tree->m <= DENSE_MAX_NODES && query->m <= DENSE_MAX_NODES && (T + 8 * FB) * SLOTS < ((int64_t)1 << 31)) {
+            // triangle x triangle on a tree of at most 2^24 faces (the pair word's record field): the streamed kernel;
+            // XR_OVERLAP_STREAM=0 (read per call: test / measurement switch) keeps the kernel chain
+            const char *stream_env = getenv("XR_OVERLAP_STREAM");
+            const bool stream_on = stream_env && atoi(stream_env) == 1; // (experiment: slower than the chain as ONE kernel, see DESIGN)
+            if (stream_on && tree->m == 3 && query->m == 3 && tree->n_face <= ((int64_t)1 << 24) &&
+                overlap_stream(tree, query, tree_area, relative, csr, tile, early))
+                return;
             if (overlap_tri(tree, query, tree_area, relative, csr, tile, early)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
         }
