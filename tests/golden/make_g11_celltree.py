@@ -29,6 +29,8 @@ Cases (names are the npz key prefixes):
                                   pins one)
   locate_ties                     points ON shared sides, ON nodes, ON the hull, just outside: which face wins a tie, the default
                                   tolerance and an explicit one
+  locate_tolform                  a long and a short hull side, probes at 0.9 / 1.1 x the tolerance outside them: tells
+                                  `cross < tol * length` (an absolute distance) from `cross < tol`
   bary_concave                    polygons incl. a concave one that STARTS at its reflex corner (the counter-clockwise
                                   normalisation by the first vertex triple) -- barycentric weights slot by slot
   edges_touch                     segments through a cell corner, along a shared side, ending on a side, outside along the hull
@@ -159,6 +161,30 @@ def main(path):
         out["locate_ties__default"] = np.asarray(tree.locate_points(pts))
         out["locate_ties__tolerances"] = np.array([])
     print("locate_ties:", pts.shape[0], "points")
+
+    # ---- locate_points: the FORM of the on-edge tolerance.  A point at distance d outside a hull side of length L counts as
+    # on the side if  |cross(side, point - start)| < tol * L  (d < tol: an absolute distance, what the oracle assumes,
+    # oracle/xr_oracle.c:point_in_poly_or_on_edge)  or if  |cross| < tol  (d < tol / L: the threshold scales with 1 / L).
+    # A long side (L = 100) and a short one (L = 0.01), probes at 0.9 tol and 1.1 tol (and far inside either threshold):
+    #   long side,  d = 0.9 tol:  absolute form -> face 0,  cross form -> -1 (0.9 tol > tol / 100)
+    #   short side, d = 1.1 tol:  absolute form -> -1,      cross form -> face 1 if the traversal reaches the face
+    tol = 1.0e-3
+    txy = np.array([[0.0, 0.0], [100.0, 0.0], [50.0, 40.0], [200.0, 0.0], [200.01, 0.0], [200.005, 0.008]])
+    tfaces = np.array([[0, 1, 2], [3, 4, 5]], dtype=np.int64)
+    d = np.array([0.005, 0.5, 0.9, 1.1, 2.0, 50.0, 150.0]) * tol
+    tpts = np.vstack([np.column_stack([np.full(d.size, 50.0), -d]),          # below the middle of the long side
+                      np.column_stack([np.full(d.size, 20.0), -d]),          # ... and off-centre
+                      np.column_stack([np.full(d.size, 200.005), -d]),       # below the middle of the short side
+                      [[50.0, 1.0], [200.005, 0.002]]])                      # interior points (sanity)
+    ttree = CellTree2d(txy, tfaces, -1)
+    out.update({"locate_tolform__xy": txy, "locate_tolform__faces": tfaces, "locate_tolform__points": tpts,
+                "locate_tolform__tol": np.array(tol), "locate_tolform__d": d})
+    try:
+        out["locate_tolform__result"] = np.asarray(ttree.locate_points(tpts, tol))
+    except TypeError:
+        out["locate_tolform__result"] = np.asarray(ttree.locate_points(tpts))
+        out["locate_tolform__tol"] = np.array(np.nan)
+    print("locate_tolform:", tpts.shape[0], "points ->", out["locate_tolform__result"].tolist())
 
     # ---- barycentric weights: convex polygons and a concave one starting at its reflex corner
     bxy = np.array([

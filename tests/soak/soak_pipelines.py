@@ -11,6 +11,7 @@ from xugrid_amd import engine as E, meshgen, voronoi
 from xugrid_amd.regrid.structured import Raster, StructuredGrid2d
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from structured_cases import random_raster
+from stepwise import host_barycentric_stepwise, host_locate_centroids_stepwise
 
 
 def run(seed0, n_iter):
@@ -47,12 +48,12 @@ def run(seed0, n_iter):
             if not (np.array_equal(v, hv) and np.array_equal(c, hc) and np.array_equal(fi, hfi) and np.array_equal(nm, hnm)): msg = "voronoi"
             if not msg:
                 d = us.barycentric_device(ut); dd, di, dp = d.download()
-                hs, ht, hw = us.barycentric(ut)
+                hs, ht, hw = host_barycentric_stepwise(us, ut)
                 rows = np.repeat(np.arange(d.n), np.diff(dp))
                 if not (np.array_equal(di, hs) and np.array_equal(rows, ht) and np.array_equal(dd, hw)): msg = "barycentric"
             if not msg:
                 d = us.locate_centroids_device(ut); dd, di, dp = d.download()
-                hs, ht, hw = us.locate_centroids(ut)
+                hs, ht, hw = host_locate_centroids_stepwise(us, ut)
                 rows = np.repeat(np.arange(d.n), np.diff(dp))
                 if not (np.array_equal(di, hs) and np.array_equal(rows, ht)): msg = "locator"
             if not msg:

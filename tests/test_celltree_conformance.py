@@ -69,6 +69,22 @@ def check_locate(z, make_tree):
         assert bad.size == 0, f"tolerance {tol:g}: {bad.size} points differ, first {bad[:5]}: {got[bad[:5]]} vs package {exp[bad[:5]]}"
 
 
+def check_locate_tolform(z, make_tree):
+    """The form of the on-edge tolerance (absolute distance vs. cross product): every probe, with a message that says which
+    reading the package's answer supports."""
+    if "locate_tolform__result" not in z.files:
+        pytest.skip("g11_celltree.npz predates the locate_tolform case: re-run tests/golden/make_g11_celltree.py")
+    tol = float(z["locate_tolform__tol"])
+    tree = make_tree(z["locate_tolform__xy"], z["locate_tolform__faces"], -1)
+    got = np.asarray(tree.locate_points(z["locate_tolform__points"], None if np.isnan(tol) else tol))
+    exp = z["locate_tolform__result"]
+    bad = np.nonzero(got != exp)[0]
+    assert bad.size == 0, (
+        f"on-edge tolerance form: {bad.size} probes differ from the package (probe rows {bad.tolist()}: got {got[bad].tolist()}, "
+        f"package {exp[bad].tolist()}; d / tol = {np.tile(z['locate_tolform__d'] / tol, 3)[bad[bad < 21]].tolist()}) -- the package "
+        "does not test `cross < tol * length`")
+
+
 def check_bary(z, make_tree, strict):
     for faces_key, suffix in (("bary_concave__faces", ""), ("bary_concave__faces_convex_start", "_convex_start")):
         tree = make_tree(z["bary_concave__xy"], z[faces_key], -1)
@@ -121,6 +137,7 @@ def _device_tree(hip):
 def test_package_vs_oracle(package_file, oracle, strict):
     check_faces(package_file, _oracle_tree(oracle), strict)
     check_locate(package_file, _oracle_tree(oracle))
+    check_locate_tolform(package_file, _oracle_tree(oracle))
     check_bary(package_file, _oracle_tree(oracle), strict)
     check_edges(package_file, _oracle_tree(oracle), strict)
 
@@ -130,6 +147,7 @@ def test_package_vs_oracle(package_file, oracle, strict):
 def test_package_vs_device(package_file, hip, strict):
     check_faces(package_file, _device_tree(hip), strict)
     check_locate(package_file, _device_tree(hip))
+    check_locate_tolform(package_file, _device_tree(hip))
     check_bary(package_file, _device_tree(hip), strict)
     check_edges(package_file, _device_tree(hip), strict)
 
@@ -176,8 +194,18 @@ def test_kit_runs_and_covers_the_assumption_table(selfcheck_file, oracle):
     # a file made by the stand-in compares equal with the oracle, by construction: the comparison code runs
     check_faces(z, _oracle_tree(oracle), True)
     check_locate(z, _oracle_tree(oracle))
+    check_locate_tolform(z, _oracle_tree(oracle))
     check_bary(z, _oracle_tree(oracle), True)
     check_edges(z, _oracle_tree(oracle), True)
+    # the tolerance-form probes do tell the two readings apart: under the oracle's reading (absolute distance < tol) the
+    # probes at d = 0.005 / 0.5 / 0.9 tol are on the side, those at 1.1 tol and beyond are outside -- for the long side (L = 100)
+    # AND the short one (L = 0.01); under `cross < tol` the long side would lose 0.5 and 0.9 tol (threshold tol / 100) and the
+    # short side would keep 1.1 ... 50 tol (threshold 100 tol, as far as the traversal's box inflation lets it)
+    res = z["locate_tolform__result"]
+    nd = z["locate_tolform__d"].size
+    assert nd == 7 and res.size == 3 * nd + 2
+    assert res[:nd].tolist() == [0, 0, 0, -1, -1, -1, -1] and res[nd:2 * nd].tolist() == [0, 0, 0, -1, -1, -1, -1]
+    assert res[2 * nd:3 * nd].tolist() == [1, 1, 1, -1, -1, -1, -1] and res[3 * nd:].tolist() == [0, 1]
 
 
 @pytest.mark.gpu
@@ -185,5 +213,6 @@ def test_device_equals_oracle_on_the_kit_cases(selfcheck_file, hip):
     """device == oracle, bit for bit, on every case the real package will be asked about."""
     check_faces(selfcheck_file, _device_tree(hip), True)
     check_locate(selfcheck_file, _device_tree(hip))
+    check_locate_tolform(selfcheck_file, _device_tree(hip))
     check_bary(selfcheck_file, _device_tree(hip), True)
     check_edges(selfcheck_file, _device_tree(hip), True)

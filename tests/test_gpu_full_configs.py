@@ -245,7 +245,7 @@ def test_config3_barycentric_4m_targets(hip, oracle):
     points, unstructured.py:147).  Size-independent properties of the whole weight matrix, and the oracle's
     step-by-step restatement on a 150k-point sample of the same points: identical triplets."""
     import xugrid_amd as xa
-    from test_gpu_regridder_api import _oracle_barycentric_triplets
+    from stepwise import oracle_barycentric_triplets
 
     sxy, sf = meshgen.triangle_mesh(500_000, 0, delaunay=False)
     txy, tf = meshgen.triangle_mesh(2_000_000, 2, 30.0, 0.7, delaunay=False)
@@ -272,11 +272,62 @@ def test_config3_barycentric_4m_targets(hip, oracle):
     # oracle on a sample of the query points
     rng = np.random.default_rng(3)
     sample = np.sort(rng.choice(n, 150_000, replace=False))
-    os_, ot, ow = _oracle_barycentric_triplets(oracle, src, cen_t[sample])
+    os_, ot, ow = oracle_barycentric_triplets(oracle, src, cen_t[sample])
     cnt = counts[sample]
     flat = np.repeat(indptr[sample] - (np.cumsum(cnt) - cnt), cnt) + np.arange(cnt.sum())
     assert np.array_equal(np.bincount(ot, minlength=sample.size), cnt), "row lengths differ from the oracle"
     assert np.array_equal(indices[flat], os_) and np.array_equal(data[flat], ow)
+
+
+def test_config3_barycentric_delaunay_source_as_benchmarked(hip, oracle):
+    """BASELINE config 3 on the workload bench.py TIMES: a 1M-triangle DELAUNAY source (node degree up to ~17, hull slivers,
+    concave exterior Voronoi cells) and the 4M centroids of a Delaunay target.  The other full-size tests use lattice-split
+    meshes (degree <= 8).  Properties of the whole matrix; the oracle's step-by-step restatement (unstructured.py:146-201) on
+    a 150k-point sample of the benchmark's points; and -- because the benchmark's target lies INSIDE the source hull and so
+    never meets the exterior cells -- on 60k extra points in and around the source's boundary layer."""
+    import xugrid_amd as xa
+    from stepwise import oracle_barycentric_triplets
+    from xugrid_amd import engine
+
+    sxy, sf = meshgen.triangle_mesh(500_000, 0, delaunay=True)
+    txy, tf = meshgen.triangle_mesh(2_000_000, 2, 30.0, 0.7, delaunay=True)
+    src = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    tgt = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    us = xa.regrid.UnstructuredGrid2d(src)
+    dcsr = us.barycentric_device(xa.regrid.UnstructuredGrid2d(tgt))
+    data, indices, indptr = dcsr.download()
+    n = tf.shape[0]
+    assert dcsr.n == n > 3_900_000 and dcsr.m == sf.shape[0] and data.size == dcsr.nnz > 20_000_000
+    counts = np.diff(indptr)
+    assert (counts >= 1).all()  # every target centroid lies inside the source mesh
+    assert (data > 0).all() and indices.min() >= 0 and indices.max() < dcsr.m
+    sums = np.add.reduceat(data, indptr[:-1])
+    assert (np.abs(sums - 1.0) < 1e-12).mean() > 0.999 and sums.min() > 0
+    cen_t = oracle.centroids(txy, tf)
+    rng = np.random.default_rng(5)
+    sample = np.sort(rng.choice(n, 150_000, replace=False))
+    os_, ot, ow = oracle_barycentric_triplets(oracle, src, cen_t[sample])
+    cnt = counts[sample]
+    flat = np.repeat(indptr[sample] - (np.cumsum(cnt) - cnt), cnt) + np.arange(cnt.sum())
+    assert np.array_equal(np.bincount(ot, minlength=sample.size), cnt), "row lengths differ from the oracle"
+    assert np.array_equal(indices[flat], os_) and np.array_equal(data[flat], ow)
+    del data, indices, indptr, dcsr
+    # the boundary layer: points within ~3 cells of the unit square's sides, half of them outside the hull
+    h = 1.0 / np.sqrt(500_000)
+    side = rng.integers(0, 4, 60_000)
+    along = rng.uniform(-2 * h, 1 + 2 * h, 60_000)
+    across = rng.uniform(-3 * h, 3 * h, 60_000)
+    px = np.where(side == 0, along, np.where(side == 1, along, np.where(side == 2, across, 1 - across)))
+    py = np.where(side == 0, across, np.where(side == 1, 1 - across, np.where(side == 2, along, along)))
+    pts = np.ascontiguousarray(np.column_stack([px, py]))
+    voronoi_mesh, face_index_tail, n2n = us._voronoi_device()
+    c2 = engine.barycentric_csr(voronoi_mesh, src.device_mesh, face_index_tail, n2n, points=pts, n_identity=src.n_face)
+    d2, i2, p2 = c2.download()
+    os2, ot2, ow2 = oracle_barycentric_triplets(oracle, src, pts)
+    rows2 = np.repeat(np.arange(c2.n), np.diff(p2))
+    empty = np.diff(p2) == 0
+    assert 0.2 < empty.mean() < 0.8  # a good share outside, a good share inside exterior cells
+    assert np.array_equal(i2, os2) and np.array_equal(rows2, ot2) and np.array_equal(d2, ow2)
 
 
 def test_full_size_mixed_and_raster_pairs_bit_exact(hip, oracle):

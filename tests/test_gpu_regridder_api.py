@@ -8,6 +8,7 @@ import pytest
 
 import xugrid_amd as xa
 from conftest import same_or_nan
+from stepwise import host_barycentric_stepwise, host_locate_centroids_stepwise, oracle_barycentric_triplets
 from xugrid_amd import meshgen
 
 pytestmark = pytest.mark.gpu
@@ -237,33 +238,6 @@ def test_celltree_adapter_matches_numba_celltree_call_shape(hip, oracle):
     assert (np.diff(i) >= 0).all()
 
 
-def _oracle_barycentric_triplets(oracle, grid, points, tolerance=None, tree_order=False):
-    """unstructured.py:146-201 step by step with the CPU oracle (Voronoi pre-step: xugrid_amd.voronoi, pinned by G6).
-    The weight slots are paired with the CALLER's vertex order of every Voronoi cell, as :175,193 do (default);
-    ``tree_order``: with the tree's counter-clockwise-normalised copy instead (the product's opt-in)."""
-    from xugrid_amd import voronoi
-
-    xy = grid.node_coordinates
-    faces = grid.face_node_connectivity
-    vertices, vfaces, node_to_face_index, n2n = voronoi.voronoi_topology(
-        grid.node_face_connectivity, xy, oracle.centroids(xy, faces),
-        edge_face_connectivity=grid.edge_face_connectivity, edge_node_connectivity=grid.edge_node_connectivity,
-        add_exterior=True, add_vertices=True, skip_concave=True,
-    )
-    vtree = oracle.CellTree2d(vertices, vfaces, -1)
-    face_index, weights = vtree.compute_barycentric_weights(points, tolerance)
-    pair_faces = vtree.faces if tree_order else np.asarray(vfaces)
-    assert pair_faces.shape == vtree.faces.shape
-    oracle.replace_interpolated_weights(vertices, pair_faces, face_index, weights, n2n, len(vertices) - len(n2n))
-    outside = oracle.CellTree2d(xy, faces, -1).locate_points(points) == -1
-    weights[outside] = 0
-    keep = weights.ravel() > 0
-    source_index = node_to_face_index[pair_faces[face_index]].ravel()[keep]
-    n, m = weights.shape
-    target_index = np.repeat(np.arange(n), m)[keep]
-    return source_index, target_index, weights.ravel()[keep]
-
-
 @pytest.mark.parametrize("kind", ["tri", "quad"])
 def test_barycentric_device_pipeline(hip, oracle, kind):
     """The device-assembled CSR (xr_barycentric_csr) == the step-by-step host path == the oracle, bit for bit;
@@ -283,10 +257,10 @@ def test_barycentric_device_pipeline(hip, oracle, kind):
         dcsr = us.barycentric_device(ut, tol)
         data, indices, indptr = dcsr.download()
         rows = np.repeat(np.arange(dcsr.n), np.diff(indptr))
-        hs, ht, hw = us.barycentric(ut, tol)
+        hs, ht, hw = host_barycentric_stepwise(us, ut, tol)
         assert (dcsr.n, dcsr.m) == (tgt.n_face, src.n_face)
         assert np.array_equal(indices, hs) and np.array_equal(rows, ht) and np.array_equal(data, hw)
-        os_, ot, ow = _oracle_barycentric_triplets(oracle, src, tgt.centroids, tol)
+        os_, ot, ow = oracle_barycentric_triplets(oracle, src, tgt.centroids, tol)
         assert np.array_equal(indices, os_) and np.array_equal(rows, ot) and np.array_equal(data, ow)
         outside_rows = np.diff(indptr) == 0
         assert 0 < outside_rows.sum() < tgt.n_face
@@ -307,6 +281,35 @@ def test_barycentric_device_pipeline(hip, oracle, kind):
     c2 = engine.barycentric_csr(vg.device_mesh, src.device_mesh, v2f, n2n, points=tgt.centroids)
     d2, i2, p2 = c2.download()
     assert np.array_equal(d2, data) and np.array_equal(i2, indices) and np.array_equal(p2, indptr)
+
+
+def test_barycentric_concave_reference_known_answer(hip, oracle):
+    """The reference's test_barycentric_concave (tests/test_regrid/test_regridder.py:334-369) through the public classes
+    on the device: BarycentricInterpolator(Ugrid2d, Raster) -> exactly 200 NaN cells, 0.5 <= v <= 2.0; and the device
+    weights == the oracle's step-by-step weights, bit for bit."""
+    from stepwise import CONCAVE_FACES, CONCAVE_VALUES, CONCAVE_VERTICES, concave_raster_axes
+
+    grid = xa.Ugrid2d(CONCAVE_VERTICES[:, 0], CONCAVE_VERTICES[:, 1], -1, CONCAVE_FACES)
+    x, y = concave_raster_axes()
+    regridder = xa.BarycentricInterpolator(source=grid, target=xa.Raster(x=x, y=y))
+    result = regridder.regrid(CONCAVE_VALUES)
+    assert result.shape == (y.size, x.size) == (20, 30)
+    assert np.nanmin(result) >= 0.5 and np.nanmax(result) <= 2.0
+    assert np.isnan(result).sum() == 200
+    # the query points are the centroids of the raster's cells as quadrilaterals (unstructured.py:147), row-major (y, x)
+    quads = xa.regrid.StructuredGrid2d(xa.Raster(x=x, y=y)).convert_to(xa.regrid.UnstructuredGrid2d).ugrid_topology
+    points = oracle.centroids(quads.node_coordinates, quads.face_node_connectivity)
+    yy, xx = np.meshgrid(y, x, indexing="ij")
+    assert np.allclose(points, np.column_stack([xx.ravel(), yy.ravel()]), rtol=0, atol=1e-12)
+    os_, ot, ow = oracle_barycentric_triplets(oracle, grid, points)
+    w = regridder._ensure_host_weights()
+    rows = np.repeat(np.arange(w.n), np.diff(w.indptr))
+    assert np.array_equal(w.indices, os_) and np.array_equal(rows, ot) and np.array_equal(w.data, ow)
+    expected = oracle.regrid_csr("mean", CONCAVE_VALUES[None, :], ow, os_, oracle.to_csr_indptr(ot, points.shape[0]), points.shape[0])[0]
+    assert same_or_nan(result.ravel(), expected).all()
+    # a descending-y raster (the usual DataArray orientation) is the same picture upside down
+    flipped = xa.BarycentricInterpolator(source=grid, target=xa.Raster(x=x, y=y[::-1].copy())).regrid(CONCAVE_VALUES)
+    assert same_or_nan(flipped, result[::-1]).all()
 
 
 @pytest.mark.parametrize("tag", ["a", "b", "c"])
@@ -473,7 +476,7 @@ def test_barycentric_full_size_vs_oracle(hip, oracle):
     dcsr = xa.regrid.UnstructuredGrid2d(src).barycentric_device(xa.regrid.UnstructuredGrid2d(tgt))
     data, indices, indptr = dcsr.download()
     rows = np.repeat(np.arange(dcsr.n), np.diff(indptr))
-    os_, ot, ow = _oracle_barycentric_triplets(oracle, src, oracle.centroids(txy, tf))
+    os_, ot, ow = oracle_barycentric_triplets(oracle, src, oracle.centroids(txy, tf))
     assert indices.size == os_.size > 4_000_000
     assert np.array_equal(indices, os_) and np.array_equal(rows, ot) and np.array_equal(data, ow)
 
@@ -604,12 +607,12 @@ def test_barycentric_tree_order_blast_radius(hip, oracle, golden, case):
     b = xa.regrid.UnstructuredGrid2d(tgt)
     trip = {}
     for ref in (False, True):
-        s_i, t_i, w = a.barycentric(b, tree_order=ref)
+        s_i, t_i, w = host_barycentric_stepwise(a, b, tree_order=ref)
         d = a.barycentric_device(b, tree_order=ref)
         data, idx, indptr = d.download()
         rows = np.repeat(np.arange(d.n), np.diff(indptr))
         assert np.array_equal(idx, s_i) and np.array_equal(rows, t_i) and np.array_equal(data, w), (case, ref)
-        o_s, o_t, o_w = _oracle_barycentric_triplets(oracle, src, tgt.centroids, tree_order=ref)
+        o_s, o_t, o_w = oracle_barycentric_triplets(oracle, src, tgt.centroids, tree_order=ref)
         assert np.array_equal(idx, o_s) and np.array_equal(rows, o_t) and np.array_equal(data, o_w), (case, ref)
         trip[ref] = (s_i, t_i, w)
     same = all(np.array_equal(x, y) for x, y in zip(trip[False], trip[True]))

@@ -149,6 +149,27 @@ def test_barycentric_known_answers(oracle):
     np.testing.assert_allclose(w, expected, atol=0.05)
 
 
+def test_barycentric_concave_reference_known_answer(oracle):
+    """The reference's test_barycentric_concave (tests/test_regrid/test_regridder.py:334-369), numbers transcribed: three
+    triangles around a reflex corner -> 30 x 20 raster of 0.1-wide cells; exactly 200 cells stay NaN (the gap right of the
+    reflex corner), every value lies in [0.5, 2.0].  One of the few reference tests that pin the external locate +
+    barycentric arithmetic.  Oracle step by step: unstructured.py:146-201, then the mean apply."""
+    import xugrid_amd as xa
+    from stepwise import CONCAVE_FACES, CONCAVE_VALUES, CONCAVE_VERTICES, concave_raster_axes, oracle_barycentric_triplets
+
+    grid = xa.Ugrid2d(CONCAVE_VERTICES[:, 0], CONCAVE_VERTICES[:, 1], -1, CONCAVE_FACES)
+    x, y = concave_raster_axes()
+    yy, xx = np.meshgrid(y, x, indexing="ij")
+    points = np.column_stack([xx.ravel(), yy.ravel()])
+    s, t, w = oracle_barycentric_triplets(oracle, grid, points)
+    out = oracle.regrid_csr("mean", CONCAVE_VALUES[None, :], w, s, oracle.to_csr_indptr(t, points.shape[0]), points.shape[0])[0]
+    out = out.reshape(y.size, x.size)
+    assert np.isnan(out).sum() == 200
+    assert np.nanmin(out) >= 0.5 and np.nanmax(out) <= 2.0
+    # the gap is the wedge between faces 0 and 2 right of the reflex corner (1, 1): nothing left of x = 1 is NaN
+    assert not np.isnan(out[:, x < 1.0]).any() and np.isnan(out[:, x > 1.0]).sum() == 200
+
+
 def test_self_overlap_identity(oracle):
     """tests/test_regrid/test_unstructured.py:32-45 on a seeded triangle mesh."""
     xy, faces = meshgen.triangle_mesh(400, 7)

@@ -74,13 +74,11 @@ class UnstructuredGrid2d:
         )
 
     def locate_centroids(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None):
-        tree = self.ugrid_topology.celltree
-        source_index = tree.locate_points(other.ugrid_topology.centroids, tolerance)
-        inside = source_index != -1
-        source_index = source_index[inside]
-        target_index = np.arange(other.size, dtype=IntDType)[inside]
-        weight_values = np.ones_like(source_index, dtype=FloatDType)
-        return source_index, target_index, weight_values
+        """-> (source_index, target_index, weights) as unstructured.py:137-144, read back from the device CSR."""
+        csr = self.locate_centroids_device(other, tolerance)
+        data, indices, indptr = csr.download()
+        target_index = np.repeat(np.arange(csr.n, dtype=IntDType), np.diff(indptr))
+        return indices.astype(IntDType, copy=False), target_index, data
 
     def _voronoi(self):
         """Centroidal Voronoi tessellation of this grid (unstructured.py:151-166) as a Ugrid2d, plus
@@ -144,7 +142,8 @@ class UnstructuredGrid2d:
         )
 
     def barycentric(self, other: "UnstructuredGrid2d", tolerance: Optional[float] = None, tree_order: bool = False):
-        """-> (source_index, target_index, weights) on the host, step by step as unstructured.py:146-201.
+        """-> (source_index, target_index, weights) as unstructured.py:146-201, read back from the device CSR of
+        ``barycentric_device`` (rows are target faces, so ``target_index`` is non-decreasing as ``to_csr`` needs).
 
         Default (``tree_order=False``): the weight of slot j of a Voronoi cell is paired with vertex j of the cell in
         the CALLER's vertex order -- exactly what the reference does (unstructured.py:175,193).
@@ -152,39 +151,12 @@ class UnstructuredGrid2d:
         counter-clockwise-normalised vertex order, the order the weights were computed in.  The two only differ for
         cells the tree stores reversed -- concave exterior cells that start at a reflex corner;
         tests/test_gpu_regridder_api.py::test_barycentric_tree_order_blast_radius counts them and the entries they
-        change."""
-        from .._replace import replace_interpolated_weights
-
-        points = other.ugrid_topology.centroids
-        grid = self.ugrid_topology
-        voronoi_grid, vertices, faces, node_to_face_index, node_to_node_map = self._voronoi()
-        face_index, weights = voronoi_grid.compute_barycentric_weights(points, tolerance)
-        # The weights come back aligned with the tree's own vertex order of each cell (the tree normalises its copy
-        # of the faces to counter-clockwise: the first non-collinear vertex triple decides, which reverses a concave
-        # cell that starts at a reflex corner).  The reference indexes them with the caller's order
-        # (unstructured.py:175,193) and so does the default here; ``tree_order`` re-aligns those cells instead.
-        if tree_order:
-            faces = voronoi_grid.device_mesh.faces_ccw()
-        replace_interpolated_weights(
-            vertices=vertices,
-            faces=faces,
-            face_index=face_index,
-            weights=weights,
-            node_to_node_map=node_to_node_map,
-            node_index_threshold=len(vertices) - len(node_to_node_map),
-        )
-        # discard zero weights and points outside of the source grid (unstructured.py:188-198)
-        outside = grid.locate_points(points) == -1
-        weights[outside] = 0
-        keep = weights.ravel() > 0
-        source_index = node_to_face_index[faces[face_index]].ravel()[keep]
-        n_points, n_max_node = weights.shape
-        target_index = np.repeat(np.arange(n_points, dtype=IntDType), n_max_node)[keep]
-        weights = weights.ravel()[keep]
-        # target_index is already non-decreasing; a stable sort keeps the reference's intent
-        # (its own argsort is non-stable, SURVEY appendix D)
-        order = np.argsort(target_index, kind="stable")
-        return source_index[order], target_index[order], weights[order]
+        change.  The reference's step-by-step host sequence lives in tests/stepwise.py, where
+        the device pass is compared with it."""
+        csr = self.barycentric_device(other, tolerance, tree_order)
+        data, indices, indptr = csr.download()
+        target_index = np.repeat(np.arange(csr.n, dtype=IntDType), np.diff(indptr))
+        return indices.astype(IntDType, copy=False), target_index, data
 
     def intersection_length_device(self, other):
         """unstructured.py:203-212 as a device CSR: rows = faces of this grid, columns = edges of the network
