@@ -153,6 +153,7 @@ void engine_init(int device) {
         const char *pr = getenv("XR_SIDE_PRIORITY"); // (measurement switch: lo / normal instead of the highest)
         const int prio = pr && !strcmp(pr, "lo") ? lo : pr && !strcmp(pr, "normal") ? (lo + hi) / 2 : hi;
         XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, prio));
+        XR_HIP(hipStreamCreateWithPriority(&g_engine.side2, hipStreamNonBlocking, prio));
     }
     // fork / join between two streams of the one device: a device-scope release is all the waiting stream needs (the default,
     // a system-scope release, writes the caches back to host visibility at every record: ~7 us between two dependent kernels
@@ -162,6 +163,8 @@ void engine_init(int device) {
     XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, ev_flags));
     XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, ev_flags));
     XR_HIP(hipEventCreateWithFlags(&g_engine.aux_event, ev_flags));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.fork2_event, ev_flags));
+    XR_HIP(hipEventCreateWithFlags(&g_engine.join2_event, ev_flags));
     g_engine.device = device;
 }
 
@@ -856,6 +859,27 @@ SideScope::~SideScope() {
         g_engine.on_side = false;
         (void)hipEventRecord(g_engine.join_event, g_engine.side);
     }
+}
+SideForkScope::SideForkScope() {
+    Engine &e = engine();
+    static const bool off = getenv("XR_SIDE_FORK") && atoi(getenv("XR_SIDE_FORK")) == 0; // (A/B switch: the tails one behind the other)
+    if (off || current_lane() || !e.on_side || t_stream_override || !e.side2) return;
+    XR_HIP(hipEventRecord(e.fork2_event, e.side));
+    XR_HIP(hipStreamWaitEvent(e.side2, e.fork2_event, 0));
+    prev = t_stream_override;
+    t_stream_override = e.side2;
+    active = launching = true;
+}
+void SideForkScope::end_launches() {
+    if (!launching) return;
+    launching = false;
+    t_stream_override = prev;
+    (void)hipEventRecord(g_engine.join2_event, g_engine.side2);
+}
+SideForkScope::~SideForkScope() {
+    if (!active) return;
+    end_launches();
+    (void)hipStreamWaitEvent(g_engine.side, g_engine.join2_event, 0);
 }
 void side_join() {
     if (side_disabled()) return;

@@ -103,6 +103,10 @@ struct Engine {
     // forked / joined with events, never synchronised with the host on its own
     hipStream_t side = nullptr;
     hipEvent_t fork_event = nullptr, join_event = nullptr;
+    // a second side stream, forked FROM the side stream and joined back into it (SideForkScope): two independent tails of the
+    // side chain (the light and the bitmap rows of the big faces) beside each other instead of one behind the other
+    hipStream_t side2 = nullptr;
+    hipEvent_t fork2_event = nullptr, join2_event = nullptr;
     hipEvent_t aux_event = nullptr; // a point INSIDE the side stream's work the main stream may wait for before the full join
     bool on_side = false; // XR_LAUNCH and the kernel timer go to the side stream while set
     int32_t mail_seq = 0; // sequence number of the last mailbox publication the host asked for (mailbox_wait_seq)
@@ -256,6 +260,16 @@ struct SideScope {
     explicit SideScope(bool at_mark = false);
     ~SideScope();
     int mode = 0; // 0: in line, 1: engine side stream, 2: the lane's side stream
+};
+// RAII, inside a SideScope of the engine's own path: launches go to a SECOND side stream that waits for what the side stream
+// holds so far; the destructor makes the side stream wait for them (so the one join of the SideScope covers both).  Anywhere
+// else (lanes, no side stream) the scope does nothing and the work runs in line on whatever stream is current.
+struct SideForkScope {
+    SideForkScope();
+    void end_launches(); // launches go to the side stream again (what follows there runs BESIDE the second stream's work)
+    ~SideForkScope();    // the side stream waits for the second stream's work
+    bool active = false, launching = false;
+    hipStream_t prev = nullptr;
 };
 void side_join();
 bool side_mark(); // record the fork point now; false: no side stream here (SideScope(true) would run in line, i.e. BEHIND what follows)
