@@ -101,6 +101,13 @@ int xr_set_stream(void *hip_stream, int external, int async_dev);
  * own (the same holds after xr_set_stream).  For pipelines that keep their data on the device and issue many calls back to
  * back (a time loop; bench.py's step). */
 int xr_set_async(int on);
+/* Run-time options of the library -- the switches tests and measurement scripts flip (no reference interface: xugrid has no
+ * such knobs).  None changes a result, except "apply_contract" (documented there).  Names and meanings: DESIGN.md section 8 /
+ * xugrid_amd/csrc/xr_internal.h (enum Option); the value an option starts with is read ONCE from the environment variable
+ * XR_<NAME IN CAPITALS> when the library is first used.  Unknown names are an error (XR_ERR_INVALID).  The calls are
+ * thread-safe; an option changed while another thread is inside a call takes effect for that call or the next. */
+int xr_set_option(const char *name, int64_t value);
+int xr_get_option(const char *name, int64_t *value);
 /* Host-only helpers of the Python layer (no device, usable without one): the copies xugrid's constructors make
  * (Ugrid2d.__init__, xugrid/ugrid/ugrid2d.py:86-96: contiguous node_x / node_y, face_node_connectivity.copy()) done by the
  * library's host thread pool.  xr_host_interleave2: out_xy[i] = (x[i * x_stride], y[i * y_stride]), strides in elements. */
@@ -231,10 +238,15 @@ int xr_barycentric_csr_tail(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
 
 /* The source-side half of UnstructuredGrid2d.barycentric -- the query points (points, or the face centroids of `query`,
  * unstructured.py:147) and `grid.locate_points(points) == -1` with the default tolerance (:188-190) -- as a device-resident
- * handle whose kernels are ENQUEUED ON THE ENGINE'S SIDE STREAM WITHOUT WAITING: they need nothing of the Voronoi
- * tessellation, so a caller that starts them first has them run beside the (latency-bound) kernels of the Voronoi pre-step
- * instead of behind them (1M faces / 4M points: construction 3.3 -> 2.96 ms).  xr_barycentric_csr_points is
- * xr_barycentric_csr_tail on such a handle; it joins the side stream before it reads the flags. */
+ * handle whose kernels run on the engine's side stream: they need nothing of the Voronoi tessellation, so they run beside
+ * the (latency-bound) kernels of the Voronoi pre-step instead of behind them (1M faces / 4M points: construction 3.3 -> 2.96
+ * ms).  Since round 5 they are DEFERRED: enqueued not by this call but by whichever call needs them or has the device idle
+ * next -- xr_voronoi_create / xr_voronoi_mesh_auto where their host round trips begin, xr_barycentric_csr_points at the
+ * latest.  LIFETIME: the handle keeps raw pointers to `source` and `query`; both meshes must stay alive until
+ * xr_barycentric_csr_points has consumed the handle or xr_points_destroy has released it.  xr_mesh_invalidate and
+ * xr_mesh_destroy of either mesh launch the deferred kernels first (they read the arrays as they are at that moment), so a
+ * mesh that is invalidated or destroyed in between is safe, a handle used AFTER its source was destroyed is not.
+ * xr_barycentric_csr_points is xr_barycentric_csr_tail on such a handle; it joins the side stream before it reads the flags. */
 typedef struct xr_points xr_points;
 int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, xr_points **out);
 int xr_points_destroy(xr_points *points);

@@ -53,6 +53,30 @@ def oracle():
     return O
 
 
+@pytest.fixture
+def xr_option():
+    """``xr_option(name, value)`` sets a run-time option of the library (include/xugrid_amd.h: xr_set_option) for the rest of the
+    test; ``value=None`` puts back what the option held when the test first touched it; everything is restored at teardown.
+    Strings are the words the environment variables of rounds 1-5 took ("old", "major", "free", "csr") or numerals."""
+    from xugrid_amd import engine
+
+    words = {"old": 1, "major": 1, "free": 1, "csr": 2, "device": 1}
+    initial = {}
+
+    def set_option(name, value):
+        if name not in initial:
+            initial[name] = engine.get_option(name)
+        if value is None:
+            value = initial[name]
+        elif isinstance(value, str):
+            value = words[value] if value in words else int(value)
+        engine.set_option(name, int(value))
+
+    yield set_option
+    for name, value in initial.items():
+        engine.set_option(name, value)
+
+
 @pytest.fixture(scope="session")
 def hip():
     """The HIP engine bound to device 0.  Fails (does not skip) without a device."""

@@ -63,9 +63,9 @@ def run(seed0, n_iter):
                 field = rng.normal(size=(K, s.size)) + 1.5
                 field[rng.random(field.shape) < 0.05] = np.nan
                 mid = int(rng.choice([0, 1, 2, 3, 4, 5, 8, 9]))
-                os.environ["XR_OUTER_APPLY"] = "free"
+                E.set_option("outer_apply", 1)  # matrix-free
                 free = dev.apply(field, mid)
-                os.environ.pop("XR_OUTER_APPLY")
+                E.set_option("outer_apply", 0)
                 ref = dev.csr().apply(field, mid)
                 data, indices, dip = dev.download()
                 short = np.diff(dip) <= 32

@@ -67,6 +67,39 @@ def test_work_balanced_partition():
     assert np.array_equal(partition_faces(cen, 8, "morton", weights=np.ones(cen.shape[0])), plain)
 
 
+def test_shard_lists_rules_are_explicit():
+    """shard_lists has two rules (the engine's Morton cells, the torch per-face cut) that cut the curve at different faces
+    (ADVICE round 5): which one runs is explicit -- ``rule="engine"`` without an engine backend is an error, ``rule="torch"``
+    ignores a backend's shard_plan, and ``"auto"`` with such a backend delegates."""
+    import pytest
+    import torch
+
+    from xugrid_amd.distributed import shard_lists
+
+    sxy, sf = meshgen.triangle_mesh(400, 0, delaunay=False)
+    txy, tf = meshgen.triangle_mesh(400, 1, 30.0, 0.7, delaunay=False)
+    full = tuple(torch.as_tensor(a) for a in (sxy, sf, txy, tf))
+
+    class EngineLike:
+        calls = 0
+
+        def shard_plan(self, full, world, rank, partition):
+            EngineLike.calls += 1
+            return torch.arange(3), torch.arange(5)
+
+    own = [shard_lists(full, 3, r, "balanced") for r in range(3)]
+    faces = torch.cat([o[0] for o in own]).sort().values
+    assert torch.equal(faces, torch.arange(sf.shape[0]))  # disjoint and complete
+    with pytest.raises(ValueError):
+        shard_lists(full, 3, 0, "balanced", rule="engine")
+    with pytest.raises(ValueError):
+        shard_lists(full, 3, 0, "balanced", rule="cells")
+    a = shard_lists(full, 3, 1, "balanced", backend=EngineLike(), rule="torch")
+    assert EngineLike.calls == 0 and torch.equal(a[0], own[1][0]) and torch.equal(a[1], own[1][1])
+    b = shard_lists(full, 3, 1, "balanced", backend=EngineLike())
+    assert EngineLike.calls == 1 and b[0].numel() == 3
+
+
 def test_sharded_regridder_world2_gloo(tmp_path, oracle):
     port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")

@@ -37,7 +37,7 @@ def _stacked_field(centroids, K, seed):
     return v
 
 
-def test_config5_cached_weights_k256(hip, oracle, monkeypatch):
+def test_config5_cached_weights_k256(hip, oracle, monkeypatch, xr_option):
     from xugrid_amd import engine as E
 
     K = 256
@@ -63,9 +63,9 @@ def test_config5_cached_weights_k256(hip, oracle, monkeypatch):
     d2, i2, p2 = cached.download()
     assert np.array_equal(d2, data) and np.array_equal(i2, idx) and np.array_equal(p2, indptr)
     # without the plan (direct gathers)
-    monkeypatch.setenv("XR_APPLY_NO_PLAN", "1")
+    xr_option("apply_plan", 0)
     got_np = cached.apply(v, 0)
-    monkeypatch.delenv("XR_APPLY_NO_PLAN")
+    xr_option("apply_plan", None)
     assert_apply_equal(got_np, exp, indptr, "mean K=256 no plan")
     del got_np, got_built
     # NaNs: 1 % in every fourth variable, one variable all-NaN (NaN-free tiles take the short path, the others not)

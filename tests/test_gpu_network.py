@@ -92,10 +92,10 @@ def test_many_edges_through_few_faces(hip, oracle):
     np.testing.assert_allclose(got, exp, rtol=1e-12)
 
 
-def test_every_edge_kernel_path_equals_oracle(hip, oracle, monkeypatch):
+def test_every_edge_kernel_path_equals_oracle(hip, oracle, xr_option):
     """The thread-per-edge passes deal the exact clips out over the wave (default: 48 parking slots per edge); edges with
     more candidate faces than slots go to the wave-per-edge kernels.  Shallow parking (24) sends many edges there, a tiny
-    big-box threshold nearly all of them, XR_EDGE_KERNEL=old runs the previous kernels: the CSR is the oracle's each time.
+    big-box threshold nearly all of them, option edge_kernel = 1 ("old") runs the previous kernels: the CSR is the oracle's each time.
     Edge lengths from far below a cell to a third of the mesh, so that the candidate lists range from 1 to hundreds."""
     rng = np.random.default_rng(31)
     nodes, faces = meshgen.triangle_mesh(4000, 4)
@@ -106,14 +106,14 @@ def test_every_edge_kernel_path_equals_oracle(hip, oracle, monkeypatch):
     edges = edges[rng.permutation(edges.shape[0])]
     # (the wave-per-edge count pass keeps its hits in a pool that the fill pass replays: off, and with a pool far too small --
     # the edges that are refused, or have more hits than a wave's stage, walk again)
-    settings = [{}, {"XR_EDGE_DEAL": "24"}, {"XR_EDGE_DEAL": "32", "XR_EDGE_BIG": "8"}, {"XR_EDGE_DEAL": "40", "XR_EDGE_BIG": "100000"},
-                {"XR_EDGE_KERNEL": "old"}, {"XR_EDGE_WALK": "major"}, {"XR_EDGE_POOL": "0", "XR_EDGE_BIG": "8"},
-                {"XR_EDGE_POOL": "700", "XR_EDGE_BIG": "8"}, {"XR_EDGE_POOL": "1", "XR_EDGE_DEAL": "24"}]
-    for env in settings:
-        for k in ("XR_EDGE_DEAL", "XR_EDGE_BIG", "XR_EDGE_KERNEL", "XR_EDGE_WALK", "XR_EDGE_POOL"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
+    settings = [{}, {"edge_deal": 24}, {"edge_deal": 32, "edge_big": 8}, {"edge_deal": 40, "edge_big": 100000},
+                {"edge_kernel": "old"}, {"edge_walk": "major"}, {"edge_pool": 0, "edge_big": 8},
+                {"edge_pool": 700, "edge_big": 8}, {"edge_pool": 1, "edge_deal": 24}]
+    for options in settings:
+        for k in ("edge_deal", "edge_big", "edge_kernel", "edge_walk", "edge_pool"):
+            xr_option(k, None)
+        for k, v in options.items():
+            xr_option(k, v)
         device_vs_oracle(oracle, nodes, faces, edges)
 
 

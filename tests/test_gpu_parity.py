@@ -95,7 +95,7 @@ def test_overlap_clockwise_and_fill_values(hip, oracle):
     assert_overlap_parity(hip, oracle, sxy, sf5, txy, tf5, relative=True, fill=-999)
 
 
-def test_overlap_quadrilateral_targets_on_triangles(hip, oracle, monkeypatch):
+def test_overlap_quadrilateral_targets_on_triangles(hip, oracle, monkeypatch, xr_option):
     """The shape of the reference's unstructured -> raster regridding: quadrilateral targets against a triangle source go
     through the flag / compaction clip with a four-vertex subject (k_clip_quad_tri).  A raster whose cell lines pass through
     source vertices (a lattice-split triangulation: exact contacts), a rotated and sheared quad mesh, clockwise quads,
@@ -114,12 +114,12 @@ def test_overlap_quadrilateral_targets_on_triangles(hip, oracle, monkeypatch):
     for src_xy, src_f, txy, tf in cases:
         results = []
         for flag in ("1", "0"):
-            monkeypatch.setenv("XR_CLIP_QUAD", flag)
+            xr_option("clip_quad", flag)
             csr, _ = assert_overlap_parity(hip, oracle, src_xy, src_f, txy, tf)
             results.append(csr.download())
             assert_overlap_parity(hip, oracle, src_xy, src_f, txy, tf, relative=True)
         assert all(np.array_equal(a, b) for a, b in zip(*results))
-    monkeypatch.delenv("XR_CLIP_QUAD")
+    xr_option("clip_quad", None)
 
 
 def test_overlap_polygons_up_to_hexagons(hip, oracle):
@@ -203,10 +203,10 @@ def test_overlap_long_rows_and_big_queries(hip, oracle):
         assert 128 < np.diff(indptr).max() < 2048
 
 
-def test_overlap_queue_regrow_path(hip, oracle, monkeypatch):
+def test_overlap_queue_regrow_path(hip, oracle, monkeypatch, xr_option):
     """big query faces whose candidates do not fit the pair queue's margin: the queue is regrown and the
-    pending faces are filled by the second launch (XR_QUEUE_MARGIN is a test hook)."""
-    monkeypatch.setenv("XR_QUEUE_MARGIN", "0")
+    pending faces are filled by the second launch (option "queue_margin" is a test hook)."""
+    xr_option("queue_margin", 1)
     sxy, sf = meshgen.triangle_mesh(30000, 3)
     txy, tf = meshgen.quad_mesh(np.linspace(-0.1, 1.1, 6), np.linspace(0.0, 1.0, 4))
     csr, (data, idx, indptr) = assert_overlap_parity(hip, oracle, sxy, sf, txy, tf)
@@ -220,7 +220,7 @@ def test_overlap_queue_regrow_path(hip, oracle, monkeypatch):
     assert_overlap_parity(hip, oracle, sxy, sf, mxy, mf)
 
 
-def test_overlap_fused_matches_general_chain(hip, monkeypatch):
+def test_overlap_fused_matches_general_chain(hip, monkeypatch, xr_option):
     """triangle x triangle pairs take the single-round-trip pipeline (persistent clip, look-back assembly, big faces on a
     side stream); XR_OVERLAP_FUSED=0 sends the same meshes through the general chain (search -> clip -> scan -> row_fill):
     identical CSR, absolute and relative weights."""
@@ -228,7 +228,7 @@ def test_overlap_fused_matches_general_chain(hip, monkeypatch):
     txy, tf = meshgen.triangle_mesh(30000, 12, 25.0, 0.8)
     results = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("XR_OVERLAP_FUSED", mode)
+        xr_option("overlap_fused", mode)
         for relative in (False, True):
             results[mode, relative] = gpu_triplets(hip, sxy, sf, txy, tf, relative)[2:]
     for relative in (False, True):
@@ -238,7 +238,7 @@ def test_overlap_fused_matches_general_chain(hip, monkeypatch):
             np.testing.assert_array_equal(x, y)
 
 
-def test_overlap_fused_pipeline_quads_and_mixed_meshes(hip, oracle, monkeypatch):
+def test_overlap_fused_pipeline_quads_and_mixed_meshes(hip, oracle, monkeypatch, xr_option):
     """Dense meshes of up to four nodes per face -- quadrilaterals, mixed triangle / quadrilateral meshes with -1 in the fourth slot
     (the flexible-mesh case), a raster's quads against triangles -- take the one-round-trip pipeline of xr_overlap_fused.h with
     the register / LDS clip of k_clip_small inside the persistent queue kernel (round 5).  Every pair: the oracle's matrix bit for
@@ -254,12 +254,12 @@ def test_overlap_fused_pipeline_quads_and_mixed_meshes(hip, oracle, monkeypatch)
              (mxy, mf, cxy, cf), (mxy, mf, mxy, mf)]
     for sxy, sf, qx, qfc in pairs:
         for relative in (False, True):
-            monkeypatch.delenv("XR_OVERLAP_FUSED", raising=False)
+            xr_option("overlap_fused", None)
             _, fused = assert_overlap_parity(hip, oracle, sxy, sf, qx, qfc, relative=relative)
-            monkeypatch.setenv("XR_OVERLAP_FUSED", "0")
+            xr_option("overlap_fused", "0")
             general = gpu_triplets(hip, sxy, sf, qx, qfc, relative)
             assert np.array_equal(fused[0], general[3]) and np.array_equal(fused[1], general[2]) and np.array_equal(fused[2], general[4])
-    monkeypatch.delenv("XR_OVERLAP_FUSED", raising=False)
+    xr_option("overlap_fused", None)
 
 
 def test_overlap_meshes_sharing_nodes(hip, oracle):
@@ -321,12 +321,12 @@ def test_overlap_same_handle_as_tree_and_query(hip, oracle):
     np.testing.assert_allclose(xa.OverlapRegridder(g, g, method="mean").regrid(v), v, rtol=0, atol=1e-13)
 
 
-def test_overlap_meshes_sharing_nodes_general_chain(hip, oracle, monkeypatch):
+def test_overlap_meshes_sharing_nodes_general_chain(hip, oracle, monkeypatch, xr_option):
     """... and through the general kernel chain (XR_OVERLAP_FUSED=0) and a quadrilateral mesh against itself."""
-    monkeypatch.setenv("XR_OVERLAP_FUSED", "0")
+    xr_option("overlap_fused", "0")
     sxy, sf = meshgen.triangle_mesh(12000, 23)
     assert_overlap_parity(hip, oracle, sxy, sf, sxy, sf)
-    monkeypatch.delenv("XR_OVERLAP_FUSED")
+    xr_option("overlap_fused", None)
     qxy, qf = meshgen.quad_mesh(np.linspace(0.0, 1.0, 71), np.linspace(0.0, 1.0, 53))
     assert_overlap_parity(hip, oracle, qxy, qf, qxy, qf)
     assert_overlap_parity(hip, oracle, sxy, sf, qxy, qf)
@@ -795,7 +795,7 @@ def test_apply_many_variables_row_tiling(hip, oracle):
         E.DeviceCSR.from_arrays(oa, os_, indptr, csr.n, csr.m).set_row_keys(keys + key_range, key_range)
 
 
-def test_apply_plan_per_block_and_merged(hip, oracle, monkeypatch):
+def test_apply_plan_per_block_and_merged(hip, oracle, monkeypatch, xr_option):
     """The two forms of the many-variable apply plan (xr_apply.hip: ensure_plan) -- a distinct-column list per block of 256 rows,
     or one per group of neighbouring blocks (chosen by itself when the blocks use the source lines poorly: qhull numberings) -- and the
     automatic choice give the oracle's numbers, NaNs and a ragged last group included."""
@@ -813,15 +813,15 @@ def test_apply_plan_per_block_and_merged(hip, oracle, monkeypatch):
     ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
     for mode in ("0", "1", None):
         if mode is None:
-            monkeypatch.delenv("XR_PLAN_MERGE", raising=False)
+            xr_option("plan_merge", None)
         else:
-            monkeypatch.setenv("XR_PLAN_MERGE", mode)
+            xr_option("plan_merge", mode)
         csr = ms.overlap(mt)  # (a fresh matrix: the plan is built once per matrix, on its first many-variable apply)
         for method, mid in (("mean", 0), ("maximum", 5), ("sum", 3), ("minimum", 4)):
             assert_apply_equal(csr.apply(v, mid), oracle.regrid_csr(method, v, oa, os_, indptr, csr.n), indptr, f"{method} merge={mode}")
         v32 = v[:9].astype(np.float32)
         assert_apply_equal(csr.apply(v32, 0), oracle.regrid_csr("mean", v32, oa, os_, indptr, csr.n), indptr, f"f32 merge={mode}")
-    monkeypatch.delenv("XR_PLAN_MERGE", raising=False)
+    xr_option("plan_merge", None)
 
 
 def test_overlap_projected_coordinates(hip, oracle):
@@ -916,7 +916,40 @@ def test_full_size_exact_vs_oracle(hip, oracle):
         assert_apply_equal(csr.apply(v, mid), oracle.regrid_csr(name, v, data, idx, indptr, csr.n), indptr, name)
 
 
-def test_apply_host_arrays_in_chunks(hip, oracle, monkeypatch):
+def test_apply_contracted_is_opt_in_and_within_its_bound(hip, oracle, xr_option):
+    """Option "apply_contract" (round 6): fused multiply-adds and one reciprocal per row in the many-variable kernel.  Off by
+    default -- the default is the reference's operation order, bit for bit.  On, every value differs from the oracle by at most
+    (n + 2) ulp of sum |w v| / sum w (n = entries of the row); NaN patterns are identical; both plans (per block, merged)."""
+    E = hip.engine
+    sxy, sf = meshgen.triangle_mesh(20000, 41)
+    txy, tf = meshgen.triangle_mesh(16000, 42, 30.0, 0.75)
+    oq, os_, oa = oracle.CellTree2d(sxy, sf).intersect_faces(txy, tf)
+    indptr = oracle.to_csr_indptr(oq, tf.shape[0])
+    rng = np.random.default_rng(9)
+    v = rng.normal(size=(24, sf.shape[0]))
+    v[3, ::17] = np.nan  # (a tile with NaNs takes the exact path in both modes)
+    ms, mt = E.DeviceMesh(sxy, sf), E.DeviceMesh(txy, tf)
+    eps = np.finfo(np.float64).eps
+    counts = np.diff(indptr)
+    for merge in (0, 1):
+        xr_option("plan_merge", merge)
+        csr = ms.overlap(mt)
+        for method, mid in (("mean", 0), ("first_order_conservative", 8)):
+            ref = oracle.regrid_csr(method, v, oa, os_, indptr, csr.n)
+            assert_apply_equal(csr.apply(v, mid), ref, indptr, f"{method} exact merge={merge}")
+            xr_option("apply_contract", 1)
+            got = csr.apply(v, mid)
+            xr_option("apply_contract", 0)
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            absw = oracle.regrid_csr(method, np.abs(np.nan_to_num(v)), oa, os_, indptr, csr.n)  # sum |w v| (/ sum w for the mean)
+            bound = (counts[None, :] + 2) * eps * np.nan_to_num(absw)
+            ok = ~np.isnan(ref)
+            assert (np.abs(got[ok] - ref[ok]) <= bound[ok]).all(), (method, merge, float(np.max(np.abs(got[ok] - ref[ok]) / np.maximum(bound[ok], 1e-300))))
+            assert (got[ok] != ref[ok]).any()  # (the switch does switch)
+    xr_option("plan_merge", None)
+
+
+def test_apply_host_arrays_in_chunks(hip, oracle, monkeypatch, xr_option):
     """xr_apply_csr stages the stacked variables through the device in chunks (any K fits): same result for any
     chunk size (XR_APPLY_CHUNK_BYTES is a test hook)."""
     from xugrid_amd import engine as E
@@ -928,7 +961,7 @@ def test_apply_host_arrays_in_chunks(hip, oracle, monkeypatch):
     whole = csr.apply(v, 0)
     per_k = csr.m * 8 + csr.n * 8
     for budget in (per_k, 5 * per_k + 1, 36 * per_k):
-        monkeypatch.setenv("XR_APPLY_CHUNK_BYTES", str(budget))
+        xr_option("apply_chunk_bytes", str(budget))
         assert np.array_equal(csr.apply(v, 0), whole, equal_nan=True)
         v32 = v.astype(np.float32)
         assert np.array_equal(csr.apply(v32, 7, 50.0), csr.apply(v32.astype(np.float64), 7, 50.0), equal_nan=True)
@@ -1050,7 +1083,7 @@ def test_stored_row_order_is_frozen_once_handed_out(hip):
         assert same_or_nan(back, ref16).all(), kind
 
 
-def test_overlap_apply_in_one_call_matches_two_calls(hip, monkeypatch):
+def test_overlap_apply_in_one_call_matches_two_calls(hip, monkeypatch, xr_option):
     """xr_overlap_apply_dev (weights + their first use in one entry point; for K = 1 the apply is enqueued before the host
     has read the matrix' sizes back) == xr_overlap followed by xr_apply_csr_dev, bit for bit: every reducer family, K = 1
     and K = 3, synchronous and asynchronous mode (xr_set_async), the regrow path (a tiny pair-queue margin makes the first
@@ -1099,9 +1132,9 @@ def test_overlap_apply_in_one_call_matches_two_calls(hip, monkeypatch):
                 assert same_or_nan(csr.apply(v[:K], method_id, pct), ref).all()
 
     check_all("default")
-    monkeypatch.setenv("XR_QUEUE_MARGIN", "64")  # the big faces do not fit the first time: redo, apply enqueued again
+    xr_option("queue_margin", "64")  # the big faces do not fit the first time: redo, apply enqueued again
     check_all("regrow")
-    monkeypatch.delenv("XR_QUEUE_MARGIN")
+    xr_option("queue_margin", None)
     # many steps back to back without a host synchronisation in between (the benchmark's loop)
     E.set_async(True)
     try:

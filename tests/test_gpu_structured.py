@@ -181,12 +181,12 @@ def _oracle_apply(oracle, name, field, data, indices, indptr, n):
 
 
 @pytest.mark.parametrize("engine_path", ["free", "csr", None])
-def test_factored_apply_vs_oracle(hip, oracle, monkeypatch, engine_path):
+def test_factored_apply_vs_oracle(hip, oracle, monkeypatch, engine_path, xr_option):
     """xr_apply_outer: the matrix-free kernel walks a target cell's entries in the order of the product's CSR row,
     so it equals the sequential oracle BIT FOR BIT whatever the row length (here up to ~600 entries); the stored
     product (forced, or chosen for long x-lists) follows the CSR contract: rows <= 32 entries exact, longer 1e-13."""
     if engine_path:
-        monkeypatch.setenv("XR_OUTER_APPLY", engine_path)
+        xr_option("outer_apply", engine_path)
     rng = np.random.default_rng(77)
     for case in range(8):
         ns = int(rng.integers(30, 260))
@@ -245,7 +245,7 @@ def test_device_outer_handle(hip):
     assert e.download()[2].tolist() == [0, 0, 0, 0, 0]
 
 
-def test_factored_apply_large_and_anisotropic(hip, oracle, monkeypatch):
+def test_factored_apply_large_and_anisotropic(hip, oracle, monkeypatch, xr_option):
     """2000 x 1500 source cells: coarsening by 40 along y only keeps x-lists short -> matrix-free with 80-entry rows,
     bit-identical to the sequential oracle; host chunking of many variables; float32 sources."""
     ns_x, ns_y = 2000, 1500
@@ -266,5 +266,5 @@ def test_factored_apply_large_and_anisotropic(hip, oracle, monkeypatch):
     exp = _oracle_apply(oracle, "mean", field, data, indices, indptr, t.size)
     assert same_or_nan(out.reshape(5, -1), exp).all()
     # host buffers larger than the device staging budget go through in chunks of variables (test hook)
-    monkeypatch.setenv("XR_APPLY_CHUNK_BYTES", str(2 * (s.size * 4 + t.size * 8) + 1))
+    xr_option("apply_chunk_bytes", str(2 * (s.size * 4 + t.size * 8) + 1))
     assert same_or_nan(w.apply(field, 0), exp).all()

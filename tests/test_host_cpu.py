@@ -217,18 +217,45 @@ def test_rectilinear_ugrid_host_side_is_lazy_and_equal():
         RectilinearUgrid2d(np.array([0.0]), np.array([0.0, 1.0]))
 
 
+def test_run_time_options_are_an_api_not_the_environment():
+    """The library's switches are options (xr_set_option / xr_get_option; read once from XR_<NAME> when the library is first
+    used): known names round-trip, unknown names are an error, and no compute path looks at the environment (round-5 review:
+    ~60 getenv reads, some per call, from threads that race with setenv)."""
+    import glob
+    import re
+
+    from xugrid_amd import engine
+
+    assert engine.get_option("overlap_fused") == 1 and engine.get_option("apply_contract") == 0
+    assert engine.set_option("plan_merge", 1) == -1 and engine.get_option("plan_merge") == 1
+    with engine.option("plan_merge", 0):
+        assert engine.get_option("plan_merge") == 0
+    assert engine.get_option("plan_merge") == 1
+    engine.set_option("plan_merge", -1)
+    with pytest.raises(ValueError):
+        engine.set_option("no_such_option", 1)
+    with pytest.raises(ValueError):
+        engine.get_option("XR_OVERLAP_FUSED")
+    # ONE getenv call site in the device library's sources
+    calls = []
+    for path in glob.glob(os.path.join(ROOT, "xugrid_amd", "csrc", "*.h*")):
+        text = re.sub(r"//[^\n]*", "", open(path).read())
+        calls += [path for _ in re.finditer(r"\bgetenv\s*\(", text)]
+    assert len(calls) == 1 and calls[0].endswith("xr_engine.hip"), calls
+
+
 def test_ugrid2d_coordinates_cannot_go_stale():
     """``node_x`` / ``node_y`` are plain attributes in the reference (ugrid2d.py:86-87) and ``node_coordinates`` a fresh array per
-    call (ugridbase.py:576-579).  Here the interleaved table feeds the device: the public view is read-only (an in-place
-    write raises instead of corrupting the grid silently) and assigning an axis rebuilds the table and drops what was derived."""
+    call (ugridbase.py:576-579).  Here the interleaved table feeds the device: ``node_coordinates`` is a copy as in the reference (an
+    in-place write changes nothing of the grid) and assigning an axis rebuilds the table and drops what was derived."""
     import xugrid_amd as xa
 
     xy, faces = xa.meshgen.triangle_mesh(100, 0)
     g = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
     nc = g.node_coordinates
     assert np.array_equal(nc, xy)
-    with pytest.raises(ValueError):
-        nc[0, 0] = 5.0
+    nc[0, 0] = 5.0  # (a fresh array, writable as the reference's: the grid does not see it)
+    assert np.array_equal(g.node_coordinates, xy) and g.node_x[0] == xy[0, 0]
     old_x = g.node_x.copy()
     g._area = np.ones(3)  # (stand-ins for device results: no device in this test)
     g._celltree = object()

@@ -46,6 +46,8 @@ SIGNATURES = {
     "xr_version": (c_int, []),
     "xr_set_stream": (c_int, [vp, c_int, c_int]),
     "xr_set_async": (c_int, [c_int]),
+    "xr_set_option": (c_int, [ctypes.c_char_p, ctypes.c_int64]),
+    "xr_get_option": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "xr_host_copy": (c_int, [vp, vp, c_i64]),
     "xr_host_interleave2": (c_int, [vp, c_i64, vp, c_i64, c_i64, vp]),
     "xr_mesh_create": (c_int, [vp, c_i64, vp, c_int, c_i64, c_i64, c_i64, p_vp]),

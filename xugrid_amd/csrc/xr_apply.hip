@@ -403,7 +403,7 @@ k_apply_wave(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
 // (column and weight loaded coalesced, the source value gathered by the same lane and parked next to the weight), then every
 // lane reduces ITS row from the window, sequentially in CSR order (bit-identical to the reference loop,
 // regridder.py:52-62).  No block barrier anywhere and 6 KB of LDS per wave: 24 waves per CU keep three dependent
-// round trips (row pointers -> entries -> source values) in flight, where the block-wide version (k_apply_stream, 32 KB
+// round trips (row pointers -> entries -> source values) in flight, where the block-wide version of rounds 1-2 (32 KB
 // and four barriers per block) held 20 (MI355X, 1M x 1M benchmark: 42.6 -> see DESIGN section 5).
 static constexpr int W1_CAP = 384; // entries per wave window: 64 rows x 4 entries (the mean of a triangle pair) + slack for the tail
                                    // (measured on the 1M x 1M matrix: 256 / 320 / 384 / 448 entries -> kernel 31 / 30 / 27 / 27 us)
@@ -527,119 +527,6 @@ k_apply_rows1(const int32_t *__restrict__ indptr, const int32_t *__restrict__ in
     }
 }
 
-// One block = AP_BLOCK consecutive rows.  The block's CSR segment [indptr[row0], indptr[row0+B)) is
-// contiguous: it is streamed through LDS in chunks of CH entries -- column index and weight are
-// loaded coalesced (one entry per thread), the source values are gathered by the same thread and
-// parked next to the weight -- then every thread reduces ITS row's entries of the chunk from LDS,
-// sequentially in CSR order (bit-identical to the reference loop).  Reducer state lives in
-// registers across chunks.  KTILE source variables are reduced per pass so the CSR is re-read only
-// K / KTILE times.
-template <int METHOD, typename SRC, int KTILE, int CH>
-__global__ void __launch_bounds__(AP_BLOCK)
-k_apply_stream(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-               const double *__restrict__ data, const int32_t *__restrict__ row_order, bool skip_long, int64_t T,
-               int64_t S, const SRC *__restrict__ source, int64_t K, double *__restrict__ out,
-               int32_t *__restrict__ zero_word = nullptr /* optional: counter of the long-row kernels queued behind */) {
-    __shared__ double sh_w[CH];
-    if (zero_word && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *zero_word = 0;
-    __shared__ double sh_v[KTILE][CH];
-    // (last row blocks first: weights built by xr_overlap keep the rows of the big target faces -- the long ones --
-    // at the end, and a kernel should start with its heaviest blocks)
-    const int64_t row0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * AP_BLOCK;
-    const int64_t t = row0 + threadIdx.x;
-    const int64_t row_end = (row0 + AP_BLOCK < T) ? row0 + AP_BLOCK : T;
-    const int64_t k0 = (int64_t)blockIdx.y * KTILE;
-    const int kn = (int)((K - k0) < KTILE ? (K - k0) : KTILE);
-    const int seg0 = indptr[row0], seg1 = indptr[row_end];
-    int s = 0, e = 0;
-    if (t < T) {
-        s = indptr[t];
-        e = indptr[t + 1];
-    }
-    const bool is_long = skip_long && (e - s > APPLY_LONG); // reduced by k_apply_long instead
-    if (is_long) e = s;
-    // A block that holds long rows must not stream their entries: the chunk loop then jumps to the
-    // first entry of the next row that still has work (block-wide minimum), skipping whole long rows.
-    __shared__ int sh_next;
-    const bool jumpy = skip_long && __syncthreads_or(is_long);
-    auto next_chunk = [&](int c0) -> int {
-        if (!jumpy) {
-            __syncthreads();
-            return c0;
-        }
-        int mine = (e > s && e > c0) ? (s > c0 ? s : c0) : INT_MAX;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const int other = __shfl_xor(mine, o);
-            mine = other < mine ? other : mine;
-        }
-        __syncthreads(); // readers of the previous chunk (and of sh_next) are done
-        if (threadIdx.x == 0) sh_next = INT_MAX;
-        __syncthreads();
-        if ((threadIdx.x & 63) == 0 && mine != INT_MAX) atomicMin(&sh_next, mine);
-        __syncthreads();
-        return sh_next;
-    };
-    const SRC *src = source + k0 * S;
-    double normsum = 0.0;
-    if (METHOD == XR_GEOMETRIC_MEAN) {
-        for (int c0 = seg0; c0 < seg1; c0 += CH) {
-            c0 = next_chunk(c0);
-            if (c0 >= seg1) break;
-            for (int j = c0 + threadIdx.x; j < c0 + CH && j < seg1; j += AP_BLOCK) sh_w[j - c0] = data[j];
-            __syncthreads();
-            const int a = s > c0 ? s : c0, b = e < c0 + CH ? e : c0 + CH;
-            for (int j = a; j < b; j++) normsum += sh_w[j - c0];
-        }
-    }
-    Red<METHOD> red[KTILE];
-    for (int c0 = seg0; c0 < seg1; c0 += CH) {
-        c0 = next_chunk(c0);
-        if (c0 >= seg1) break;
-        {
-            constexpr int PER = CH / AP_BLOCK;
-            int col[PER];
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int j = c0 + u * AP_BLOCK + threadIdx.x;
-                col[u] = j < seg1 ? indices[j] : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < PER; u++) {
-                const int j = c0 + u * AP_BLOCK + threadIdx.x;
-                if (col[u] >= 0) {
-                    sh_w[j - c0] = data[j];
-#pragma unroll
-                    for (int kk = 0; kk < KTILE; kk++)
-                        if (kk < kn) sh_v[kk][j - c0] = ld_src(src, (int64_t)kk * S + col[u]);
-                }
-            }
-        }
-        __syncthreads();
-        const int a = s > c0 ? s : c0, b = e < c0 + CH ? e : c0 + CH;
-        for (int j = a; j < b; j++) {
-            const double w = sh_w[j - c0];
-#pragma unroll
-            for (int kk = 0; kk < KTILE; kk++)
-                if (kk < kn) red[kk].add(sh_v[kk][j - c0], w, normsum);
-        }
-    }
-    if (t < T && !is_long) {
-        const int64_t t_out = row_order ? (int64_t)row_order[t] : t;
-#pragma unroll
-        for (int kk = 0; kk < KTILE; kk++) {
-            if (kk < kn) {
-                double r = NAN; // regridder.py:44,62: rows without entries stay NaN
-                if (e > s) {
-                    r = red[kk].fin();
-                    if (METHOD == XR_GEOMETRIC_MEAN && normsum == 0) r = NAN;
-                }
-                out[(k0 + kk) * T + t_out] = r;
-            }
-        }
-    }
-}
-
 // Many source variables (K >= 2): one thread per row keeps KTILE reducer states in registers and
 // walks its row once per k-tile; no LDS, so occupancy is limited by registers only and every
 // thread has KTILE independent gathers in flight per entry.  Rows are visited in stored (spatial)
@@ -719,7 +606,6 @@ k_apply_direct(const int32_t *__restrict__ indptr, const int32_t *__restrict__ i
 static constexpr int PLAN_LMAX = 4096; // entries of a block the builder can sort in LDS
 static constexpr int PLAN_UMAX = 512;  // distinct columns per block kept in the plan
 static constexpr int PLAN_KT = 8;      // source variables per pipeline stage (LDS: PLAN_KT * PLAN_UMAX doubles)
-static constexpr int PLAN_SUBS_DEFAULT = 1; // row blocks per workgroup of k_apply_plan
 
 __global__ void __launch_bounds__(AP_BLOCK)
 k_plan_build(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, int64_t T,
@@ -951,7 +837,17 @@ k_plan_build_group(const int32_t *__restrict__ indptr, const int32_t *__restrict
 // neighbours use the rest: as separate workgroups they drift apart and every one of them fetches the line on its own -- the L1
 // of a CU holds 256 lines, the L2 of an XCD four microseconds of traffic --, in lockstep on ONE CU the requests for a line meet
 // in that CU's L1.
-template <int METHOD, typename SRC, int KTILE, int SUBS, bool MERGE = false>
+// FAST (round 6; opt-in for `mean` / `first_order_conservative`: option "apply_contract"): on NaN-free tiles the
+// products are CONTRACTED into the running sums (one fused multiply-add per entry and variable instead of a multiplication and
+// an addition) and the mean is the sum times ONE reciprocal of the row's weight sum (computed once per row, outside the loop
+// over the variable tiles) instead of an IEEE division per variable -- the reduction was the kernel's floor (0.71-0.81 ms of
+// vector work per K = 256 apply against 0.52 ms of memory time).  The results then differ from the reference's sequential
+// loop (regridder.py:41-67) by the roundings of at most n products (n = entries of the row, 4 on average) and one
+// multiplication: <= (n + 2) ulp of sum |w v| / sum w -- measured at full size 8e-16 of the field's range, but 1e-9 RELATIVE where a
+// mean of mixed-sign data cancels to ~1e-7 of that range.  What it buys (profiles/r06_apply_fast_ab.txt): K = 256 on the
+// lattice-numbered pair 1.01 -> 0.92 ms (50 -> 56 % of HBM), on the qhull-numbered benchmark matrix 1.57 -> 1.53 ms (that one is
+// bound by its line fills, not by the reduction).  The default stays the reference's operation order, bit for bit.
+template <int METHOD, typename SRC, int KTILE, int SUBS, bool MERGE = false, bool FAST = false>
 __global__ void __launch_bounds__(AP_BLOCK * SUBS)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
              const int32_t *__restrict__ ucol, const int32_t *__restrict__ nuniq, const uint16_t *__restrict__ loc,
@@ -1035,6 +931,7 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     double wsum_row = 0.0; // sum of the row's weights in entry order (= Red::b when no value is NaN)
     if (!is_long)
         for (int j = s; j < e; j++) wsum_row += sh_w[j - seg0];
+    const double inv_wsum = FAST ? 1.0 / wsum_row : 0.0; // (FAST: one division per row for all K variables)
     // prologue: request tile 0
     double stage[UPT][KTILE];
     {
@@ -1091,10 +988,15 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                     for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * UMAX + l];
 #pragma unroll
                     for (int kk = 0; kk < KTILE; kk++) {
-                        if (METHOD == XR_MEAN) acc[kk] += w * v[kk];
-                        else if (METHOD == XR_SUM) acc[kk] += v[kk];
+                        if (METHOD == XR_SUM) acc[kk] += v[kk];
+                        else if (FAST) acc[kk] = fma(w, v[kk], acc[kk]);
+                        else if (METHOD == XR_MEAN) acc[kk] += w * v[kk];
                         else acc[kk] += v[kk] * w;
                     }
+                }
+                if (FAST && METHOD == XR_MEAN) {
+#pragma unroll
+                    for (int kk = 0; kk < KTILE; kk++) acc[kk] *= inv_wsum;
                 }
                 const bool defined = e > s && wsum_row != 0;
                 double *o = out + k0 * T + t_out;
@@ -1107,14 +1009,14 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                     // (1M x 1M, K = 256: 1.52 -> 1.44 ms qhull-numbered, 1.04 -> 0.99 ms lattice-numbered; XR_PLAN_DBG=4: plain stores)
 #pragma unroll
                     for (int kk = 0; kk < KTILE; kk++)
-                        __builtin_nontemporal_store(defined ? (METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk]) : NAN, &o[kk * T]);
+                        __builtin_nontemporal_store(defined ? (METHOD == XR_MEAN && !FAST ? acc[kk] / wsum_row : acc[kk]) : NAN, &o[kk * T]);
                 } else if (kn == KTILE) {
 #pragma unroll
-                    for (int kk = 0; kk < KTILE; kk++) o[kk * T] = defined ? (METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk]) : NAN;
+                    for (int kk = 0; kk < KTILE; kk++) o[kk * T] = defined ? (METHOD == XR_MEAN && !FAST ? acc[kk] / wsum_row : acc[kk]) : NAN;
                 } else {
 #pragma unroll
                     for (int kk = 0; kk < KTILE; kk++)
-                        if (kk < kn) o[kk * T] = defined ? (METHOD == XR_MEAN ? acc[kk] / wsum_row : acc[kk]) : NAN;
+                        if (kk < kn) o[kk * T] = defined ? (METHOD == XR_MEAN && !FAST ? acc[kk] / wsum_row : acc[kk]) : NAN;
                 }
             }
         } else if (t < T && !is_long) {
@@ -1200,8 +1102,6 @@ __global__ void k_tile_rows(const int32_t *__restrict__ indptr, const int32_t *_
 static void ensure_tiled(const xr_csr *ccsr) {
     xr_csr *csr = const_cast<xr_csr *>(ccsr); // like the plan: a cache-friendly re-layout of the same matrix
     if (!csr->has_tile_key) return;
-    static const bool no_tile = getenv("XR_APPLY_NO_TILING") != nullptr; // measurement switch
-    if (no_tile) return;
     // (a re-layout of the matrix: only under the exclusive scope -- the apply entry points call prepare_for_apply first,
     // so that the concurrent, shared part of an apply finds this done)
     XR_REQUIRE(exclusive_held(), XR_ERR_INVALID, "internal: row tiling requested outside the exclusive scope");
@@ -1243,13 +1143,13 @@ static void ensure_tiled(const xr_csr *ccsr) {
     csr->tile_key.release();
 }
 
-// XR_PLAN_MERGE: 1 / 0 force a merged / per-block plan; unset: merged when the blocks use less than PLAN_MERGE_UTIL of the 16
+// option "plan_merge": 1 / 0 force a merged / per-block plan; -1 (default): merged when the blocks use less than PLAN_MERGE_UTIL of the 16
 // values of the source lines they touch (measured by the per-block builder: ~4 on a qhull-numbered mesh, ~12 on a
 // lattice-numbered one -- there the lockstep of a group costs 2 % and saves nothing)
 static constexpr double PLAN_MERGE_UTIL = 6.0;
 static int plan_merge_mode() { // (read when a matrix' plan is built, once per matrix: a test can switch between matrices)
-    const char *e = getenv("XR_PLAN_MERGE");
-    return e ? (atoi(e) == 1 ? 1 : 0) : -1;
+    const int64_t e = option(OPT_PLAN_MERGE);
+    return e < 0 ? -1 : (e == 1 ? 1 : 0);
 }
 
 static void ensure_plan(const xr_csr *ccsr) {
@@ -1266,7 +1166,7 @@ static void ensure_plan(const xr_csr *ccsr) {
     // of 4096 entries among thousands of 1000 (a Delaunay hull) costs every block a third of the occupancy (K = 256 on
     // the benchmark matrix: 1.76 -> 1.2 ms).  Blocks beyond 2048 entries (twice the typical triangle-mesh block) go to
     // the direct kernel instead.
-    static const int plan_cap = getenv("XR_PLAN_CAP") ? std::min(PLAN_LMAX, std::max(256, atoi(getenv("XR_PLAN_CAP")))) : 2048;
+    constexpr int plan_cap = 2048;
     if (nb > 0) {
         DevBuf<int32_t> max_entries(4); // [0] largest planned block, [1] number of unplanned blocks, [2] distinct columns, [3] distinct lines (sums over the planned blocks)
         csr->plan_unplanned.alloc((size_t)nb);
@@ -1296,7 +1196,7 @@ static void ensure_plan(const xr_csr *ccsr) {
         const int m = h[0];
         csr->plan_n_unplanned = h[1];
         csr->plan_lmax = std::min(PLAN_LMAX, std::max(256, (m + 255) / 256 * 256));
-        if (getenv("XR_DEBUG_PLAN")) {
+        if (option(OPT_DEBUG) & 2) {
             std::vector<int32_t> nu((size_t)n_lists);
             d2h(nu.data(), csr->plan_nuniq.get(), sizeof(int32_t) * (size_t)n_lists);
             double sum = 0; int cnt = 0, mx = 0;
@@ -2081,7 +1981,7 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                   csr->n, csr->m, src, K, out);
     };
     const bool long_on_side = csr->has_long && K >= PLAN_KT;
-    const bool use_plan = K > 1 && K >= PLAN_KT && getenv("XR_APPLY_NO_PLAN") == nullptr; // (measurement / test switch, read per call)
+    const bool use_plan = K > 1 && K >= PLAN_KT && option(OPT_APPLY_PLAN) != 0; // (measurement / test switch)
     if (use_plan) { // (built once per matrix, on the main stream, in front of the fork)
         ensure_tiled(csr);
         ensure_plan(csr);
@@ -2105,8 +2005,7 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         launch_long_rows(false);
         if (use_plan) launch_unplanned();
     }
-    static const bool k1_block_kernel = getenv("XR_APPLY_K1") && !strcmp(getenv("XR_APPLY_K1"), "block"); // A/B switch
-    if (K == 1 && !k1_block_kernel) {
+    if (K == 1) {
         // one launch: long-row blocks in front, then one wave per 64 stored rows
         const int n_long_blocks = csr->has_long ? engine().num_cu / 2 : 0;
         const bool any_huge = csr->has_long && !(csr->max_row_len >= 0 && csr->max_row_len <= APPLY_WAVE);
@@ -2114,12 +2013,6 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
         XR_LAUNCH("apply_rows1", (k_apply_rows1<METHOD, SRC>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(), csr->indices.get(),
                   csr->data.get(), row_order_of(csr), csr->long_rows.get(), csr->n_long.get(), n_long_blocks, any_huge,
                   csr->n, csr->m, src, out, csr->apply_gated ? csr->n_long.get() + 1 : (const int32_t *)nullptr);
-    } else if (K == 1) {
-        dim3 grid(div_up(csr->n, AP_BLOCK), 1);
-        XR_LAUNCH("apply_stream", (k_apply_stream<METHOD, SRC, 1, 2048>), grid, dim3(AP_BLOCK), 0, csr->indptr.get(),
-                  csr->indices.get(), csr->data.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out,
-                  csr->has_long ? huge.get() : (int32_t *)nullptr);
-        if (csr->has_long) launch_long_rows(true);
     } else {
         if (use_plan) {
             // many variables: rows regrouped into 2-D tiles, then a blocked CSR with per-block distinct-column
@@ -2128,15 +2021,15 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
             // for the largest planned block, so typical matrices run three blocks per CU instead of two
             // (tuning hooks: row blocks per workgroup, variables per tile, the L2-blocked order of k_apply_plan: super tiles of
             // `super_blocks` workgroups x items of `item_tiles` variable tiles)
-            static const int plan_subs_env = getenv("XR_PLAN_SUBS") ? (atoi(getenv("XR_PLAN_SUBS")) == 4 ? 4 : atoi(getenv("XR_PLAN_SUBS")) == 2 ? 2 : 1) : PLAN_SUBS_DEFAULT;
             const bool merged = csr->plan_merged;
-            const int plan_subs = merged ? PLAN_GROUP : plan_subs_env;
+            const int plan_subs = merged ? PLAN_GROUP : 1;
+            // contracted products + one reciprocal per row (k_apply_plan, FAST): opt-in
+            constexpr bool FAST_OK = METHOD == XR_MEAN || METHOD == XR_FIRST_ORDER_CONSERVATIVE;
+            const bool fast = FAST_OK && option(OPT_APPLY_CONTRACT) != 0;
             // default: items of 64 variables, super tile = the XCD's whole range of row blocks -- every XCD sweeps its row blocks
             // once per 64 variables (the source planes in flight: 0.5 GB instead of all K of them; what the host-side split
             // into groups of 128 variables did until round 4, without its extra launches, forks and joins)
-            static const int super_env = getenv("XR_APPLY_SUPER") ? std::max(0, atoi(getenv("XR_APPLY_SUPER"))) : -1;
-            static const int item_env = getenv("XR_APPLY_ITEM") ? std::max(1, atoi(getenv("XR_APPLY_ITEM"))) : 0;
-            const int plan_dbg = getenv("XR_PLAN_DBG") ? atoi(getenv("XR_PLAN_DBG")) : 0; // measurement: 1 no gathers, 2 no stores, 4 non-temporal stores
+            const int plan_dbg = (int)option(OPT_PLAN_DBG); // measurement: 1 no gathers, 2 no stores, 4 plain instead of non-temporal stores
             // LDS per row block: a tile of distinct source values + the block's entries (weight + 16-bit local column), sized for
             // the largest planned block of the matrix.  4 row blocks per workgroup: tiles of 4 variables (4 x 34 KB)
             const int plan_kt = plan_subs > 1 ? 4 : PLAN_KT;
@@ -2156,33 +2049,29 @@ static void launch_stream(const xr_csr *csr, const SRC *src, int64_t K, double *
                 XR_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
                 granted = shmem;
             };
-            static size_t granted1 = 0, granted2 = 0, granted4 = 0, granted_m = 0;
-            if (merged) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, PLAN_GROUP, true>), granted_m);
-            else if (plan_subs == 4) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 4>), granted4);
-            else if (plan_subs == 2) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, 2>), granted2);
+            static size_t granted1 = 0, granted_m = 0, granted1f = 0, granted_mf = 0;
+            if (merged && fast) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, PLAN_GROUP, true, FAST_OK>), granted_mf);
+            else if (merged) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, 4, PLAN_GROUP, true>), granted_m);
+            else if (fast) allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT, 1, false, FAST_OK>), granted1f);
             else allow_lds(reinterpret_cast<const void *>(&k_apply_plan<METHOD, SRC, PLAN_KT, 1>), granted1);
             const int64_t n_groups = div_up(div_up(csr->n, AP_BLOCK), plan_subs);
-            const int item_tiles = item_env > 0 ? item_env : 64 / plan_kt;
-            const int super_blocks = super_env >= 0 ? super_env : (K > (int64_t)plan_kt * item_tiles ? (int)std::min<int64_t>((n_groups + 7) / 8, 1 << 30) : 0);
+            const int item_tiles = 64 / plan_kt;
+            const int super_blocks = K > (int64_t)plan_kt * item_tiles ? (int)std::min<int64_t>((n_groups + 7) / 8, 1 << 30) : 0;
             int64_t plan_grid = (n_groups + 7) / 8 * 8;
             if (super_blocks > 0) {
                 const int64_t per_xcd = (n_groups + 7) / 8;
                 const int64_t n_items = div_up(K, (int64_t)plan_kt * item_tiles);
                 plan_grid = 8 * div_up(per_xcd, super_blocks) * super_blocks * n_items;
             }
-#define XR_PLAN_LAUNCH(KT, SUBS)                                                                                                     \
-    XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, KT, SUBS>), dim3((unsigned)plan_grid), dim3(AP_BLOCK * SUBS), shmem,            \
-              csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),                   \
+#define XR_PLAN_LAUNCH(KT, SUBS, MERGED, FASTF)                                                                                      \
+    XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, KT, SUBS, MERGED, FASTF>), dim3((unsigned)plan_grid), dim3(AP_BLOCK * SUBS),   \
+              shmem, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),            \
               csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out, csr->plan_lmax, super_blocks,      \
               item_tiles, plan_dbg)
-            if (merged)
-                XR_LAUNCH("apply_plan", (k_apply_plan<METHOD, SRC, 4, PLAN_GROUP, true>), dim3((unsigned)plan_grid), dim3(AP_BLOCK * PLAN_GROUP), shmem,
-                          csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->plan_ucol.get(), csr->plan_nuniq.get(),
-                          csr->plan_loc.get(), row_order_of(csr), csr->has_long, csr->n, csr->m, src, K, out, csr->plan_lmax, super_blocks,
-                          item_tiles, plan_dbg);
-            else if (plan_subs == 4) XR_PLAN_LAUNCH(4, 4);
-            else if (plan_subs == 2) XR_PLAN_LAUNCH(4, 2);
-            else XR_PLAN_LAUNCH(PLAN_KT, 1);
+            if (merged && fast) XR_PLAN_LAUNCH(4, PLAN_GROUP, true, FAST_OK);
+            else if (merged) XR_PLAN_LAUNCH(4, PLAN_GROUP, true, false);
+            else if (fast) XR_PLAN_LAUNCH(PLAN_KT, 1, false, FAST_OK);
+            else XR_PLAN_LAUNCH(PLAN_KT, 1, false, false);
 #undef XR_PLAN_LAUNCH
             if (side_late) {
                 SideScope side(true);
@@ -2231,21 +2120,8 @@ static void launch_workspace(const xr_csr *csr, const SRC *src, int64_t K, doubl
 template <typename SRC>
 static void apply_dispatch(const xr_csr *csr, int method, double p, const SRC *src, int64_t K, double *out) {
     if (csr->n == 0 || K == 0) return;
-    // Many variables are walked in groups of 128: the blocks in flight then gather from 1 GB of source planes at a
-    // time instead of from all K of them.  Measured at K = 256 on the 1M x 1M benchmark matrix: 2.21 -> 2.07 ms with
-    // qhull-numbered (scattered) columns, 1.10 -> 1.13 ms with lattice-numbered ones; smaller groups lose more on
-    // re-staging the entries than they gain.
-    // (Round 5: the many-variable kernel orders its own work by groups of 64 variables -- k_apply_plan, L2-blocked order -- so the
-    // host-side split is off by default; XR_APPLY_KGROUP=128 restores it.)
-    static const int64_t kgroup = getenv("XR_APPLY_KGROUP") ? atoll(getenv("XR_APPLY_KGROUP")) : 0; // tuning hook
-    if (kgroup > 0 && K > kgroup + kgroup / 2) {
-        for (int64_t k0 = 0; k0 < K; k0 += kgroup) {
-            const int64_t kc = (K - k0) < kgroup + kgroup / 2 ? (K - k0) : kgroup; // (no short tail group)
-            apply_dispatch<SRC>(csr, method, p, src + k0 * csr->m, kc, out + k0 * csr->n);
-            if (kc != kgroup) break;
-        }
-        return;
-    }
+    // (Until round 4 many variables were walked in host-side groups of 128; since round 5 the many-variable kernel orders its
+    // own work by groups of 64 variables -- k_apply_plan, L2-blocked order.)
     switch (method) {
     case XR_MEAN: launch_stream<XR_MEAN, SRC>(csr, src, K, out); break;
     case XR_HARMONIC_MEAN: launch_stream<XR_HARMONIC_MEAN, SRC>(csr, src, K, out); break;
@@ -2455,8 +2331,7 @@ k_apply_outer(const int32_t *__restrict__ ipy, const int32_t *__restrict__ sy, c
 
 template <int METHOD, typename SRC, int KT, int CX>
 static void launch_outer_kt(const xr_outer *o, const SRC *src, int64_t K, double *out) {
-    static const int rpb_env = getenv("XR_OUTER_ROWS") ? atoi(getenv("XR_OUTER_ROWS")) : 0; // tuning hook
-    const int rpb = (int)std::max<int64_t>(rpb_env > 0 ? rpb_env : 4, div_up(o->nty, 65535));
+    const int rpb = (int)std::max<int64_t>(4, div_up(o->nty, 65535));
     const dim3 grid((unsigned)div_up(o->ntx, AP_BLOCK), (unsigned)div_up(o->nty, rpb), (unsigned)div_up(K, KT));
     XR_LAUNCH("apply_outer", (k_apply_outer<METHOD, SRC, KT, CX>), grid, dim3(AP_BLOCK), 0, o->ipy.get(), o->sy.get(),
               o->wy.get(), o->ipx.get(), o->sx.get(), o->wx.get(), o->nty, o->ntx, o->nsx, o->nsy * o->nsx, rpb, src, K,
@@ -2633,13 +2508,13 @@ static xr_csr *outer_materialise(const xr_outer *o) {
 // cooperative long-row kernels is the faster engine (and the only one for mode / percentiles, which need a row's
 // values side by side).  Products too large to store (>= 2^31 entries) stay matrix-free.
 static bool outer_matrix_free(const xr_outer *o, int method) {
-    const char *force = getenv("XR_OUTER_APPLY"); // test hook: "free" | "csr"
+    const int64_t force = option(OPT_OUTER_APPLY); // test hook: 1 "free" | 2 "csr"
     const bool reducible = method != XR_MODE && method != XR_PERCENTILE;
     const bool fits = o->Py == 0 || o->Px < (((int64_t)1 << 31) - 1) / o->Py;
     if (!reducible) return false;
     if (!fits) return true;
-    if (force && !strcmp(force, "free")) return true;
-    if (force && !strcmp(force, "csr")) return false;
+    if (force == 1) return true;
+    if (force == 2) return false;
     return o->max_cx <= 4;
 }
 
@@ -2876,8 +2751,8 @@ int xr_apply_outer(xr_outer *o, int method, double percentile, const void *sourc
     const size_t esz = source_dtype == XR_F64 ? 8 : 4;
     const int64_t n = o->nty * o->ntx, m = o->nsy * o->nsx;
     const size_t per_k = (size_t)m * esz + (size_t)n * sizeof(double);
-    const char *chunk_env = getenv("XR_APPLY_CHUNK_BYTES"); // test hook
-    const size_t budget = chunk_env ? (size_t)atoll(chunk_env) : ((size_t)4 << 30);
+    const int64_t chunk_opt = option(OPT_APPLY_CHUNK_BYTES); // test hook
+    const size_t budget = chunk_opt > 0 ? (size_t)chunk_opt : ((size_t)4 << 30);
     int64_t kchunk = per_k > 0 ? (int64_t)(budget / per_k) : K;
     if (kchunk < 1) kchunk = 1;
     if (kchunk > K) kchunk = K;
@@ -3028,7 +2903,7 @@ int xr_csr_destroy(xr_csr *csr) {
 // scope; the apply proper then only reads the matrix and runs under the shared scope next to other threads' applies.
 static int prepare_for_apply(const xr_csr *csr, int64_t K) {
     XR_API_BEGIN
-    if (csr && csr->n > 0 && K >= PLAN_KT && !getenv("XR_APPLY_NO_PLAN") && (csr->has_tile_key || !csr->plan_ready)) {
+    if (csr && csr->n > 0 && K >= PLAN_KT && option(OPT_APPLY_PLAN) != 0 && (csr->has_tile_key || !csr->plan_ready)) {
         ensure_tiled(csr);
         ensure_plan(csr);
         stream_sync();
@@ -3067,8 +2942,8 @@ int xr_apply_csr(const xr_csr *csr, int method, double percentile, const void *s
     // The stacked variables go through the device in chunks of at most ~4 GiB of staging (source + result), so any
     // K works whatever the size of HBM; every variable is independent, results do not depend on the chunking.
     const size_t per_k = (size_t)csr->m * esz + (size_t)csr->n * sizeof(double);
-    const char *chunk_env = getenv("XR_APPLY_CHUNK_BYTES"); // test hook
-    const size_t budget = chunk_env ? (size_t)atoll(chunk_env) : ((size_t)4 << 30);
+    const int64_t chunk_opt = option(OPT_APPLY_CHUNK_BYTES); // test hook
+    const size_t budget = chunk_opt > 0 ? (size_t)chunk_opt : ((size_t)4 << 30);
     int64_t kchunk = per_k > 0 ? (int64_t)(budget / per_k) : K;
     if (kchunk < 1) kchunk = 1;
     if (kchunk > K) kchunk = K;
@@ -3140,7 +3015,7 @@ void xr::csr_partial_dev(const xr_csr *csr, int method, const void *source_dev, 
         source_dev = stored_source(csr, source_dev, source_dtype, K, permuted);
         constexpr int PKT = 8;
         bool long_done = false; // (the long rows went with the short ones)
-        static const bool one_var = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
+        constexpr bool one_var = false; // (the one-variable-per-thread kernels serve K < 8 only)
         if (K >= PKT && !one_var && rows_layout != 0) {
             dim3 grid(div_up(csr->n, 128), (unsigned)div_up(K, PKT));
             const size_t rows_shmem = sizeof(double) * 128 * (size_t)(partial_components(method) * PKT + 1);
@@ -3260,7 +3135,7 @@ int xr_reduce_partial_rows_dev(int method, const double *rows_dev, const int64_t
     XR_REQUIRE(n_targets >= 0 && K >= 0, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: negative size");
     if (n_targets * K > 0) {
         XR_REQUIRE(indptr_dev && out_dev, XR_ERR_INVALID, "xr_reduce_partial_rows_dev: NULL argument");
-        static const bool plain = getenv("XR_PARTIAL_KT") && atoi(getenv("XR_PARTIAL_KT")) == 1; // A/B switch
+        constexpr bool plain = false;
         if (K == 1 && !plain && (reinterpret_cast<uintptr_t>(rows_dev) & 15) == 0) {
 #define XR_REDUCE_K1(M)                                                                                                             \
     case M:                                                                                                                         \

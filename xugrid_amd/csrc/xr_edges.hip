@@ -683,13 +683,13 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     // and the count kernel of what has arrived runs on the side stream while the next pieces are on their way: XR_EDGE_PIPE=0
     // restores the single upload + single launch (A/B switch).
     const size_t edge_bytes = sizeof(double) * 4 * (size_t)n_edge;
-    static const bool pipe_off = getenv("XR_EDGE_PIPE") && atoi(getenv("XR_EDGE_PIPE")) == 0;
+    constexpr bool pipe_off = false;
     const GridParams &g = tree->grid;
     const int big_grid = engine().num_cu * 8;
-    const int big_cells = getenv("XR_EDGE_BIG") ? atoi(getenv("XR_EDGE_BIG")) : EDGE_BIG_CELLS; // tuning hook
-    const bool major = getenv("XR_EDGE_WALK") ? !strcmp(getenv("XR_EDGE_WALK"), "major") : false; // tuning hook
-    const bool deal = !major && !(getenv("XR_EDGE_KERNEL") && !strcmp(getenv("XR_EDGE_KERNEL"), "old")); // (A/B switch)
-    const int deal_slots = getenv("XR_EDGE_DEAL") ? atoi(getenv("XR_EDGE_DEAL")) : 48; // tuning hook: parking slots per edge (24 / 32 / 40 / 48)
+    const int big_cells = option(OPT_EDGE_BIG) > 0 ? (int)option(OPT_EDGE_BIG) : EDGE_BIG_CELLS; // test / tuning hook
+    const bool major = option(OPT_EDGE_WALK) != 0; // test / tuning hook
+    const bool deal = !major && option(OPT_EDGE_KERNEL) == 0; // (test / A/B switch)
+    const int deal_slots = (int)option(OPT_EDGE_DEAL); // test / tuning hook: parking slots per edge (24 / 32 / 40 / 48)
     // count pass of the edges [e0, e0 + ne) with the thread-per-edge kernel
     auto deal_count = [&](int64_t e0, int64_t ne) {
 #define XR_DEAL_COUNT(P)                                                                                                              \
@@ -704,7 +704,7 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
         else XR_DEAL_COUNT(48);
 #undef XR_DEAL_COUNT
     };
-    static const size_t pipe_bytes = (size_t)(getenv("XR_EDGE_PIPE_MB") ? std::max(4, atoi(getenv("XR_EDGE_PIPE_MB"))) : 16) << 20; // tuning hook
+    constexpr size_t pipe_bytes = (size_t)16 << 20; // (launches of 16 MB: smaller ones lose to their tails what the overlap gains)
     const bool piped = deal && !pipe_off && edge_bytes >= pipe_bytes + ((size_t)4 << 20) && !current_lane() && !stream_override();
     if (piped) {
         // fill(pinned, off, n) is called for piece k BEFORE its DMA is enqueued, i.e. right after the DMA of piece k - 1 was: the
@@ -746,7 +746,7 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     // the wave-per-edge count pass keeps its hits in a pool (16 B each; 4 per edge of the network, at least 1M): the fill pass
     // replays them instead of walking the long edges again (XR_EDGE_POOL=0: both passes walk, as before)
     // (XR_EDGE_POOL = n > 0: a pool of n hits -- test hook for the refusal path)
-    const int pool_env = getenv("XR_EDGE_POOL") ? atoi(getenv("XR_EDGE_POOL")) : -1;
+    const int pool_env = (int)option(OPT_EDGE_POOL);
     const bool pooled = pool_env != 0;
     const int pool_cap = !pooled ? 1 : pool_env > 0 ? pool_env : (int)std::min<int64_t>(std::max<int64_t>(4 * n_edge, (int64_t)1 << 20), (int64_t)1 << 28);
     DevBuf<EdgeHit> pool((size_t)pool_cap);

@@ -48,6 +48,52 @@ hipStream_t stream_override() { return t_stream_override; }
 StreamOverride::StreamOverride(hipStream_t s) : prev(t_stream_override) { t_stream_override = s; }
 StreamOverride::~StreamOverride() { t_stream_override = prev; }
 
+// ---- run-time options (xr_internal.h: enum Option) --------------------------------------------------------------------------
+namespace {
+struct OptionDef {
+    const char *name;
+    int64_t def;
+};
+const OptionDef k_option_defs[OPT_COUNT] = {
+    {"overlap_fused", 1}, {"queue_margin", 0}, {"clip_quad", 1}, {"dust", 1}, {"no_side", 0}, {"side_fork", 1}, {"debug", 0},
+    {"host_stamps", 0}, {"apply_plan", 1}, {"apply_contract", 0}, {"plan_merge", -1}, {"plan_dbg", 0}, {"apply_chunk_bytes", 0},
+    {"outer_apply", 0}, {"edge_big", 0}, {"edge_deal", 48}, {"edge_kernel", 0}, {"edge_walk", 0}, {"edge_pool", -1}, {"mail_poll", 1},
+    {"points_defer", 1}, {"ingest_device", 0}, {"stats_sample", 1}, {"force_query_sort", 0}, {"early_apply", 1},
+};
+std::atomic<int64_t> g_options[OPT_COUNT];
+std::once_flag g_options_once;
+// words some options accepted as environment values before they were numbers
+int64_t option_word(const char *v) {
+    static const struct { const char *word; int64_t value; } words[] = {{"old", 1}, {"major", 1}, {"free", 1}, {"csr", 2}, {"device", 1}};
+    for (const auto &w : words)
+        if (!strcmp(v, w.word)) return w.value;
+    char *end = nullptr;
+    const long long n = strtoll(v, &end, 10);
+    return end && end != v ? (int64_t)n : 0;
+}
+void options_init() {
+    std::call_once(g_options_once, [] {
+        for (int i = 0; i < OPT_COUNT; i++) {
+            char env[64] = "XR_";
+            size_t k = 3;
+            for (const char *c = k_option_defs[i].name; *c && k + 1 < sizeof(env); c++) env[k++] = (char)toupper((unsigned char)*c);
+            env[k] = 0;
+            const char *v = getenv(env); // (the library's only look at the environment besides XUGRID_AMD_LIB on the Python side)
+            g_options[i].store(v ? option_word(v) : k_option_defs[i].def, std::memory_order_relaxed);
+        }
+    });
+}
+int option_index(const char *name) {
+    for (int i = 0; i < OPT_COUNT; i++)
+        if (!strcmp(name, k_option_defs[i].name)) return i;
+    return -1;
+}
+} // namespace
+int64_t option(Option o) {
+    options_init();
+    return g_options[o].load(std::memory_order_relaxed);
+}
+
 ExclusiveScope::ExclusiveScope() {
     if (t_exclusive_depth++ == 0) {
         engine_mutex().lock();
@@ -150,16 +196,15 @@ void engine_init(int device) {
         // the side stream carries short latency-bound kernels next to a long one on the main stream: highest priority
         int lo = 0, hi = 0;
         XR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        const char *pr = getenv("XR_SIDE_PRIORITY"); // (measurement switch: lo / normal instead of the highest)
-        const int prio = pr && !strcmp(pr, "lo") ? lo : pr && !strcmp(pr, "normal") ? (lo + hi) / 2 : hi;
-        XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, prio));
-        XR_HIP(hipStreamCreateWithPriority(&g_engine.side2, hipStreamNonBlocking, prio));
+        // (lowest / normal / highest measured in round 5 on config 3: 1.81-1.86 / 1.83-1.88 / 1.89-1.91 ms under one script's clock, but
+        // the big faces' chain of xr_overlap needs the highest)
+        XR_HIP(hipStreamCreateWithPriority(&g_engine.side, hipStreamNonBlocking, hi));
+        XR_HIP(hipStreamCreateWithPriority(&g_engine.side2, hipStreamNonBlocking, hi));
     }
     // fork / join between two streams of the one device: a device-scope release is all the waiting stream needs (the default,
     // a system-scope release, writes the caches back to host visibility at every record: ~7 us between two dependent kernels
-    // on the main stream, rocprofv3 timeline of round 4).  XR_EVENT_SCOPE=system restores the default (A/B switch).
-    const bool dev_scope = !(getenv("XR_EVENT_SCOPE") && !strcmp(getenv("XR_EVENT_SCOPE"), "system"));
-    const unsigned ev_flags = hipEventDisableTiming | (dev_scope ? hipEventReleaseToDevice : 0u);
+    // on the main stream, rocprofv3 timeline of round 4).
+    const unsigned ev_flags = hipEventDisableTiming | hipEventReleaseToDevice;
     XR_HIP(hipEventCreateWithFlags(&g_engine.fork_event, ev_flags));
     XR_HIP(hipEventCreateWithFlags(&g_engine.join_event, ev_flags));
     XR_HIP(hipEventCreateWithFlags(&g_engine.aux_event, ev_flags));
@@ -674,10 +719,7 @@ void mailbox_wait() {
     pool_release_deferred();
 }
 
-static bool mail_poll_enabled() {
-    static const bool on = !(getenv("XR_MAIL_POLL") && atoi(getenv("XR_MAIL_POLL")) == 0);
-    return on;
-}
+static bool mail_poll_enabled() { return option(OPT_MAIL_POLL) != 0; }
 
 static inline void cpu_relax() {
 #if defined(__x86_64__) || defined(__i386__)
@@ -728,7 +770,7 @@ bool poll_pinned_f64(const volatile double *word, double expected) {
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct HostStamps {
-    bool on = getenv("XR_HOST_STAMPS") && atoi(getenv("XR_HOST_STAMPS")) != 0;
+    bool on = option(OPT_HOST_STAMPS) != 0;
     std::chrono::steady_clock::time_point last[16];
     bool seen[16] = {};
     double sum_us[16][16] = {}; // [from][to] accumulated interval from the latest stamp of `from` to a stamp of `to`
@@ -800,10 +842,7 @@ ProfScope::~ProfScope() {
 }
 
 // XR_NO_SIDE=1 (measurement hook): the "side" work runs in line on the main stream -- every kernel alone on the device
-static bool side_disabled() {
-    const char *v = getenv("XR_NO_SIDE");
-    return v && atoi(v) != 0;
-}
+static bool side_disabled() { return option(OPT_NO_SIDE) != 0; }
 
 static bool lane_side_ready(Lane *l) {
     if (l->side) return true;
@@ -862,8 +901,7 @@ SideScope::~SideScope() {
 }
 SideForkScope::SideForkScope() {
     Engine &e = engine();
-    static const bool off = getenv("XR_SIDE_FORK") && atoi(getenv("XR_SIDE_FORK")) == 0; // (A/B switch: the tails one behind the other)
-    if (off || current_lane() || !e.on_side || t_stream_override || !e.side2) return;
+    if (option(OPT_SIDE_FORK) == 0 || current_lane() || !e.on_side || t_stream_override || !e.side2) return;
     XR_HIP(hipEventRecord(e.fork2_event, e.side));
     XR_HIP(hipStreamWaitEvent(e.side2, e.fork2_event, 0));
     prev = t_stream_override;
@@ -971,6 +1009,25 @@ int xr_host_interleave2(const double *x, int64_t x_stride, const double *y, int6
     } catch (const Failure &f) {
         return f.code;
     }
+}
+
+int xr_set_option(const char *name, int64_t value) {
+    XR_API_BEGIN
+    XR_REQUIRE(name, XR_ERR_INVALID, "xr_set_option: NULL name");
+    const int i = option_index(name);
+    XR_REQUIRE(i >= 0, XR_ERR_INVALID, "xr_set_option: unknown option '%s'", name);
+    options_init();
+    g_options[i].store(value, std::memory_order_relaxed);
+    XR_API_END
+}
+
+int xr_get_option(const char *name, int64_t *value) {
+    XR_API_BEGIN
+    XR_REQUIRE(name && value, XR_ERR_INVALID, "xr_get_option: NULL argument");
+    const int i = option_index(name);
+    XR_REQUIRE(i >= 0, XR_ERR_INVALID, "xr_get_option: unknown option '%s'", name);
+    *value = option((Option)i);
+    XR_API_END
 }
 
 int xr_set_async(int on) {

@@ -91,36 +91,6 @@ __device__ __forceinline__ float box_gap(float4 b, float qx0, float qx1, float q
     return fmaxf(fmaxf(qx0 - b.y, b.x - qx1), fmaxf(qy0 - b.w, b.z - qy1));
 }
 
-// The same test as a LANE MASK (bit i = lane i's record overlaps lane i's query box strictly): four compares whose masks are
-// combined on the scalar unit -- 4 vector instructions where box_gap needs 7 and a compare.  (Written with ballots on purpose:
-// as `a && b && c && d` the compiler packs the four bits into a byte per lane with select / shift / bit-op chains.)
-// a - b < 0 <=> a < b exactly (gradual underflow), so both forms give the same answer.
-__device__ __forceinline__ unsigned long long box_hit_mask(float4 b, float qx0, float qx1, float qy0, float qy1) {
-    return __builtin_amdgcn_ballot_w64(qx0 < b.y) & __builtin_amdgcn_ballot_w64(b.x < qx1) & __builtin_amdgcn_ballot_w64(qy0 < b.w) &
-           __builtin_amdgcn_ballot_w64(b.z < qy1);
-}
-// ... and as one float again, from packed adds: with q = (q0, q1) and b = (bmin, bmax) of one axis as register pairs,
-// v_pk_add_f32 with per-half operand selection and negation gives (q0 - bmax, bmin - q1) in ONE instruction; two v_max3 fold the
-// four gaps and `guard` (a float >= 0 masks the record, -inf keeps it).  5 vector instructions, none on the scalar unit.
-typedef float float2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float box_gap_packed(float4 b, float2v qx, float2v qy, float guard) {
-    float2v gx, gy;
-    const float2v bxp = {b.x, b.y}, byp = {b.z, b.w};
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(gx) : "v"(qx), "v"(bxp));
-    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,0]" : "=v"(gy) : "v"(qy), "v"(byp));
-    float g;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(g) : "v"(gx.x), "v"(gx.y), "v"(gy.x));
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(g) : "v"(g), "v"(gy.y), "v"(guard));
-    return g;
-}
-// count + (lane's bit of mask): the mask goes in as the carry of ONE add
-__device__ __forceinline__ int add_lane_mask(int count, unsigned long long mask) {
-    int out;
-    unsigned long long carry_out;
-    asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(out), "=s"(carry_out) : "v"(count), "s"(mask));
-    return out;
-}
-
 // conservative float bounds: strictly below / above the double value
 __device__ __forceinline__ float f32_below(double v) {
     return nextafterf(__double2float_rd(v), -INFINITY);

@@ -274,6 +274,42 @@ struct SideForkScope {
 void side_join();
 bool side_mark(); // record the fork point now; false: no side stream here (SideScope(true) would run in line, i.e. BEHIND what follows)
 
+// ---------------------------------------------------------------------------------------------
+// Run-time options: every switch a test or a measurement script flips.  The table (name, default, meaning) is in
+// xr_engine.hip; values are read ONCE from the environment (XR_<NAME IN CAPITALS>) when the library is first used -- the one
+// getenv call site of the library, no getenv on any call path or worker thread -- and changed afterwards only through
+// xr_set_option.  None of them changes a result.
+// ---------------------------------------------------------------------------------------------
+enum Option : int {
+    OPT_OVERLAP_FUSED,     // 1: dense meshes of <= 4 nodes per face take the one-round-trip pipeline; 0: the general kernel chain
+    OPT_QUEUE_MARGIN,      // > 0: capacity of the big faces' pair queue (tests force the regrow path with a tiny one)
+    OPT_CLIP_QUAD,         // 1: quadrilateral targets x triangle source through k_clip_quad_tri (general chain); 0: k_clip_small
+    OPT_DUST,              // 1: rounding dust confirmed by the reference's pre-clip tests; 0: the round-3 behaviour
+    OPT_NO_SIDE,           // 1: side-stream work in line on the main stream (every kernel alone on the device)
+    OPT_SIDE_FORK,         // 1: the big faces' bitmap rows on a second side stream beside the light ones
+    OPT_DEBUG,             // bits: 1 one line per weight build, 2 apply-plan statistics, 4 Voronoi sizes (stderr)
+    OPT_HOST_STAMPS,       // 1: wall-clock stamps along the host path of a weight build, averages at exit
+    OPT_APPLY_PLAN,        // 1: K >= 8 variables through the planned kernels; 0: the direct kernel
+    OPT_APPLY_CONTRACT,    // 1: fused multiply-adds + one reciprocal per row in the planned kernel (NOT bit-identical; <= (n + 2) ulp)
+    OPT_PLAN_MERGE,        // -1: per matrix from the blocks' use of the source lines; 0 / 1: force the per-block / the merged plan
+    OPT_PLAN_DBG,          // measurement bits of k_apply_plan: 1 no gathers, 2 no stores, 4 plain instead of non-temporal stores
+    OPT_APPLY_CHUNK_BYTES, // > 0: staging budget of the host <-> device chunks of xr_apply_csr (tests force many chunks)
+    OPT_OUTER_APPLY,       // 0: auto; 1: matrix-free apply of factored raster weights; 2: through the materialised CSR
+    OPT_EDGE_BIG,          // > 0: cells of an edge's box from which on it goes to the wave-per-edge kernels
+    OPT_EDGE_DEAL,         // parking slots per edge of the dealt edge kernels (24 / 32 / 40 / 48)
+    OPT_EDGE_KERNEL,       // 0: dealt kernels; 1 ("old"): thread-per-edge count / replay / redo
+    OPT_EDGE_WALK,         // 1 ("major"): every edge walks along its major axis
+    OPT_EDGE_POOL,         // >= 0: size of the hit pool of the dealt kernels (tests force its overflow path)
+    OPT_MAIL_POLL,         // 1: the host polls the mailbox's sequence word, small copies without a stream synchronisation
+    OPT_POINTS_DEFER,      // 1: xr_locate_flags_begin defers its kernels to the next call that has the device to spare
+    OPT_INGEST_DEVICE,     // 1 ("device"): connectivity validated and narrowed on the device instead of while it is staged
+    OPT_STATS_SAMPLE,      // 1: tree statistics from a sample of the faces (exact on demand); 0: always exact
+    OPT_FORCE_QUERY_SORT,  // 1: Morton query order even for coherent numberings
+    OPT_EARLY_APPLY,       // 1: the apply of xr_overlap_apply_dev enqueued in front of the size read-back
+    OPT_COUNT
+};
+int64_t option(Option o);
+
 inline unsigned div_up(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------------------

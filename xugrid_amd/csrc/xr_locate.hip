@@ -606,6 +606,16 @@ void flush_pending_points() {
     }
     list.clear();
 }
+// A mesh is about to lose its derived arrays (xr_mesh_invalidate) or to go away (xr_mesh_destroy): the deferred kernels of
+// every pending handle that reads it -- the source's index, the query's centroids -- are launched NOW, while the arrays are
+// still there (the pool parks blocks freed while the side stream is in flight; xr_mesh_destroy synchronises).
+void flush_pending_points_of(const xr_mesh *mesh) {
+    for (xr_points *h : pending_points())
+        if (h->deferred && (h->source == mesh || h->query == mesh)) {
+            flush_pending_points();
+            return;
+        }
+}
 static void forget_pending_points(xr_points *h) {
     auto &list = pending_points();
     for (size_t i = 0; i < list.size(); i++)
@@ -884,7 +894,7 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
             h->inside.alloc((size_t)n);
             h->query = query;
             if (!query) h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
-            static const bool defer = !(getenv("XR_POINTS_DEFER") && atoi(getenv("XR_POINTS_DEFER")) == 0); // (A/B switch)
+            const bool defer = option(OPT_POINTS_DEFER) != 0; // (A/B switch)
             if (defer) {
                 h->deferred = true; // launched by flush_pending_points
                 pending_points().push_back(h);

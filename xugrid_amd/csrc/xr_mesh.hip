@@ -478,13 +478,13 @@ static StatsTail stats_tail_for(xr_mesh *mesh, double *partials, int64_t nb) {
         memset(mesh->stats_host, 0, sizeof(double) * 16);
         XR_HIP(hipEventCreateWithFlags(&mesh->stats_event, hipEventDisableTiming | hipEventReleaseToSystem));
     }
-    // XR_STATS_TAIL: 0 = never (a separate reduction kernel, as until round 3), 1 = always, default = grids of up to
-    // STATS_TAIL_MAX_BLOCKS blocks.  Every block pays ~3 us at its end for the hand-off (agent-scope stores, their
+    // The statistics leave through the kernel's last block for grids of up to STATS_TAIL_MAX_BLOCKS blocks (beyond that a separate
+    // reduction kernel, as until round 3; "never" / "always" were measured behind a switch in round 4).  Every block pays ~3 us at its end for the hand-off (agent-scope stores, their
     // acknowledgement, a returning atomic): nothing for the 490 blocks of sample_stats, whose result the host is waiting
     // for (16 instead of 12 + 10 + 20 us until the tree's statistics are there), but +15 us for the 3900 blocks of
     // prepare_faces, whose statistics are only read after the index build -- those keep the one-block kernel on the side
     // stream (measured, 1M x 1M step: never 0.507, always 0.520, default see DESIGN section 5).
-    static const int tail_mode = getenv("XR_STATS_TAIL") ? atoi(getenv("XR_STATS_TAIL")) : 2;
+    constexpr int tail_mode = 2;
     mesh->stats_seq += 1.0;
     mesh->stats_polled = true; // (both forms end with the sequence word)
     // (the in-kernel form is for the engine's own main stream)
@@ -504,7 +504,7 @@ void mesh_prepare(xr_mesh *mesh, bool want_fxy, bool stats_on_side, bool allow_s
     if (mesh->prepared && (mesh->has_attrs || !want_fxy) && (!mesh->stats_sampled || allow_sampled)) return;
     const int64_t F = mesh->n_face;
     const int m = mesh->m;
-    static const bool sampling_off = getenv("XR_STATS_SAMPLE") && atoi(getenv("XR_STATS_SAMPLE")) == 0; // measurement switch
+    const bool sampling_off = option(OPT_STATS_SAMPLE) == 0; // measurement switch
     // Polygon (ragged) meshes always keep len / bbox: the index build then reads one coalesced 32-byte box per face instead
     // of gathering the face's 6-20 vertices again in both of its passes (Voronoi tessellation of 1M triangles:
     // index_count 0.134 -> see DESIGN, index_scatter 0.067 ms).
@@ -860,7 +860,7 @@ void mesh_query_order(xr_mesh *mesh) {
     const int m = mesh->m;
     // coherent numbering (consecutive faces are, on average, within a few face extents of each
     // other -- typical for mesh generators, not for qhull output): keep the caller's order
-    static const bool force_sort = getenv("XR_FORCE_QUERY_SORT") != nullptr;
+    const bool force_sort = option(OPT_FORCE_QUERY_SORT) != 0;
     const double mean_ext = F > 0 ? mesh->h_stats[4] / (double)F : 0.0;
     const double mean_jump = F > 0 ? mesh->h_stats[7] / ((double)F * 63.0 / 64.0) : 0.0;
     mesh->query_identity = !force_sort && (F == 0 || mean_jump <= 4.0 * mean_ext);
@@ -912,7 +912,7 @@ void mesh_build_index(xr_mesh *mesh) {
     // 1.0 -> 0.155, 1.25 -> 0.137, 1.5 -> 0.134, 2.0 -> 0.144; round 5's, interleaved on one box: 1.25 -> 0.0924,
     // 1.4 -> 0.0898, 1.5 -> 0.0976, 1.6 -> 0.111 -- at 1.5 the second level still holds more than 1/64 of the records, so every
     // face walks it, yet it is too empty to pay for its cell bounds; XR_H0_FACTOR is the A/B switch)
-    static const double h0_factor = getenv("XR_H0_FACTOR") ? std::min(8.0, std::max(0.25, atof(getenv("XR_H0_FACTOR")))) : 1.4; // (tuning hook)
+    constexpr double h0_factor = 1.4; // (measured optimum, round 5: 1.25 -> 0.0924, 1.4 -> 0.0898, 1.5 -> 0.0976 ms of search)
     double h0 = F > 0 ? h0_factor * sum_ext / (double)F : 1.0;
     if (!(h0 > 0)) h0 = std::max(W, H);
     // bound the level-0 cell count by ~4 cells per face
@@ -1093,7 +1093,7 @@ int xr_mesh_create(const double *node_xy, int64_t n_node, const void *faces, int
     const size_t cnt = (size_t)n_face * (size_t)n_max_node;
     // (Meshes of less than 1 MB take the device-side ingest: two plain copies and a kernel, no pinned staging buffers --
     // those are 2 x 64 MiB of pinned host memory, allocated on first use.)
-    static const bool device_ingest_env = getenv("XR_INGEST") && !strcmp(getenv("XR_INGEST"), "device");
+    const bool device_ingest_env = option(OPT_INGEST_DEVICE) != 0;
     const bool device_ingest =
         device_ingest_env || cnt * (size_t)faces_itemsize + sizeof(double) * 2 * (size_t)n_node < ((size_t)1 << 20);
     xr_mesh *mesh = new xr_mesh();
@@ -1233,6 +1233,7 @@ int xr_mesh_create_dev(const double *node_xy_dev, int64_t n_node, const void *fa
 int xr_mesh_destroy(xr_mesh *mesh) {
     XR_API_BEGIN
     if (mesh) {
+        flush_pending_points_of(mesh); // (an xr_points handle made from this mesh whose kernels have not been launched yet)
         release_point();
         delete mesh;
     }
@@ -1281,6 +1282,7 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     XR_REQUIRE(mesh, XR_ERR_INVALID, "xr_mesh_invalidate: NULL mesh");
     // (the blocks go back to the pool, which hands them out again in stream order on the one main stream: in asynchronous
     // mode nothing has to wait here)
+    flush_pending_points_of(mesh); // (an xr_points handle made from this mesh whose kernels have not been launched yet)
     release_point();
     mesh->prepared = false;
     mesh->has_attrs = false;

@@ -162,6 +162,7 @@ void mesh_face_coords(xr_mesh *mesh); // make sure the caller-order vertex block
 void mesh_query_order(xr_mesh *mesh);
 void mesh_build_index(xr_mesh *mesh);
 void flush_pending_points(); // launch the deferred source-side kernels of pending xr_points handles (xr_locate.hip)
+void flush_pending_points_of(const xr_mesh *mesh); // ... if one of them reads `mesh`, before its arrays are released
 void mesh_read_stats(xr_mesh *mesh, bool need_exact = false); // need_exact: statistics over ALL faces (sampled ones are redone)
 // the apply of a finished (or, K = 1, of a just-enqueued) matrix on the calling thread's launch stream (xr_apply.hip)
 void csr_apply_dev(const xr_csr *csr, int method, double percentile, const void *src_dev, int dtype, int64_t K, double *out_dev);

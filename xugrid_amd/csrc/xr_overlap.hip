@@ -50,7 +50,6 @@ __device__ __forceinline__ bool rec_hit(float4 b, float qx0, float qx1, float qy
 static constexpr int SLOTS = 16;
 static constexpr int QCUR_STRIDE = 32; // words between the cursors of the regular queue's eight regions: a 128-byte line each
 static constexpr int QCUR_BASE = 32;   // first of them in the control words of overlap_tri
-static constexpr int SEARCH_HIT_DEFAULT = 0; // form of the walk's box test (see k_search)
 static constexpr int TILE_RUN = 16; // rows per run in the tiling hint (128-byte output stores per variable).  Measured, K = 256 on
                                     // the benchmark matrix: runs of 64 rows / tiles of 24 extents 2.10 ms, 16 / 12: 1.72 ms (a qhull-numbered
                                     // target: long runs of consecutive ids are not compact); a lattice-numbered pair 0.99 ms either way
@@ -76,11 +75,10 @@ static constexpr int BIGREC_BLOCK = 64;  // ... of which at most this many may t
 // PACK: the owning thread of a parked candidate rides in the top 8 bits of the record id (trees of at most 2^24 faces) instead
 // of a byte array of its own: 19.5 instead of 23.5 KB of LDS per block = 8 instead of 6 resident blocks per CU for a
 // kernel that is a chain of dependent loads.
-// HIT: the form of the f32 box test in the walk's step (all three give the same answer; XR_SEARCH_HIT is the A/B switch):
-//   0  one float through subtract / max (box_gap), range guard folded into the max: 62 vector instructions per step of four
-//   1  five compares, lane masks combined on the scalar unit, count += carry: 37 vector + ~28 scalar instructions
-//   2  the two gaps of an axis from ONE packed add (v_pk_add_f32 with per-half operand selection and negation), two v_max3: 47 + 10
-template <bool PACK, int HIT = 0>
+// (The f32 box test of a step through subtract / max, 62 vector instructions per step of four records.  Two cheaper forms --
+// compares combined on the scalar unit: 37 + 28 scalar; packed adds: 47 + 10 -- were measured in round 5 and changed nothing:
+// the kernel waits on memory.  They are gone.)
+template <bool PACK>
 __global__ void __launch_bounds__(256)
 k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64_t n_tree,
          const int32_t *__restrict__ cell_start,
@@ -223,7 +221,6 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
         const int c_x0 = cell_coord(bb.x, g.x0, g.inv_h0, g.nx[0]), c_x1 = cell_coord(bb.y, g.x0, g.inv_h0, g.nx[0]);
         const int c_y0 = cell_coord(bb.z, g.y0, g.inv_h0, g.ny[0]), c_y1 = cell_coord(bb.w, g.y0, g.inv_h0, g.ny[0]);
         constexpr int WALK_LOADS = 4;
-        const float2v qxp = {qx0, qx1}, qyp = {qy0, qy1};
         int visited = 0, n_rows = 0;
         for (int l = 0; l < l_coop; l++)
             n_rows += (c_y1 >> (l * LEVEL_SHIFT)) - max((c_y0 >> (l * LEVEL_SHIFT)) - 1, 0) + 1;
@@ -264,15 +261,7 @@ k_search(const double *__restrict__ q_bbox, int64_t n_query, GridParams g, int64
 #pragma unroll
                             for (int u = 0; u < WALK_LOADS; u++) {
                                 sh_slots[count < SLOTS ? count : SLOTS][threadIdx.x] = r + u;
-                                if (HIT == 1) {
-                                    unsigned long long h = box_hit_mask(bx[u], qx0, qx1, qy0, qy1);
-                                    if (u > 0) h &= __builtin_amdgcn_ballot_w64(r + u <= last);
-                                    count = add_lane_mask(count, h);
-                                } else if (HIT == 2) {
-                                    count += box_gap_packed(bx[u], qxp, qyp, u > 0 ? (r + u <= last ? -INFINITY : 1.0f) : -INFINITY) < 0.0f ? 1 : 0;
-                                } else {
-                                    count += fmaxf(box_gap(bx[u], qx0, qx1, qy0, qy1), r + u <= last ? -INFINITY : 1.0f) < 0.0f ? 1 : 0;
-                                }
+                                count += fmaxf(box_gap(bx[u], qx0, qx1, qy0, qy1), r + u <= last ? -INFINITY : 1.0f) < 0.0f ? 1 : 0;
                             }
                         }
                     }
@@ -387,15 +376,8 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int lane) {
 // not fit the queue as currently allocated are listed and filled by a second launch (FUSED = false) after the host
 // regrew it.  (The two-walk version -- count, reserve, fill -- took twice as long per face, and a big face is a
 // chain of dependent phases: the kernel's duration is the slowest face's.)
-static constexpr int BIG_STAGE = 5120; // default size of the stage (dynamic LDS; XR_BIG_STAGE overrides: tuning hook)
-static int big_stage_entries() {
-    static const int n = [] {
-        const char *e = getenv("XR_BIG_STAGE");
-        const int v = e ? atoi(e) : BIG_STAGE;
-        return v < 64 ? 64 : (v > 12288 ? 12288 : v);
-    }();
-    return n;
-}
+static constexpr int BIG_STAGE = 5120; // size of the stage (dynamic LDS; 3072 / 2048 / 1024 / 512 measured in round 5: no gain)
+static int big_stage_entries() { return BIG_STAGE; }
 static constexpr int BIG_RANK_MAX = 1 << 16; // big faces ranked by id (all-pairs, inside k_search_big); longer lists keep their order
 
 template <bool FUSED>
@@ -1389,19 +1371,14 @@ k_row_fill_long(const int32_t *__restrict__ cand_off, const int32_t *__restrict_
 
 } // namespace xr
 #include "xr_overlap_fused.h"
-#include "xr_overlap_stream.h"
 namespace xr {
 
-static bool debug_fused() {
-    static const bool on = getenv("XR_DEBUG_FUSED") != nullptr;
-    return on;
-}
+static bool debug_fused() { return (option(OPT_DEBUG) & 1) != 0; }
 static int xcd_remap_mask() {
-    // bit 0 clip, bit 1 search, bit 2 row_fill.  Default: clip + search -- 15 % fewer HBM bytes fetched by both
-    // (PMC: clip 161 -> 130 MB, search 56 -> 48 MB per launch) at an unchanged clip time and a 5 % shorter search;
+    // bit 0 clip, bit 1 search, bit 2 row_fill: the XCD-aware block order for clip + search -- 15 % fewer HBM bytes fetched by
+    // both (PMC: clip 161 -> 130 MB, search 56 -> 48 MB per launch) at an unchanged clip time and a 5 % shorter search;
     // row_fill loses more on the then interleaved queue than it gains.
-    static const int mask = getenv("XR_XCD_REMAP") ? atoi(getenv("XR_XCD_REMAP")) : 3;
-    return mask;
+    return 3;
 }
 static unsigned xcd_grid(int64_t n_blocks, bool remap) { return (unsigned)(remap ? (n_blocks + 7) / 8 * 8 : n_blocks); }
 
@@ -1419,8 +1396,7 @@ static double overlap_dust_threshold(const xr_mesh *tree, const xr_mesh *query) 
         mag = std::max(mag, std::max(std::max(fabs(h[0]), fabs(h[1])), std::max(fabs(h[2]), fabs(h[3]))));
         ext = std::min(ext, m->stats_sampled ? std::max(h[1] - h[0], h[3] - h[2]) : h[5]);
     }
-    static const bool off = getenv("XR_DUST") && atoi(getenv("XR_DUST")) == 0; // (measurement switch: no confirmation)
-    return off ? 0.0 : 5.7e-14 * mag * ext;
+    return option(OPT_DUST) == 0 ? 0.0 : 5.7e-14 * mag * ext; // (option "dust" = 0: measurement switch, no confirmation)
 }
 
 template <int MAXV, int BLOCK>
@@ -1450,18 +1426,11 @@ static void launch_clip_for(const xr_mesh *tree, const xr_mesh *query, const int
         // triangle x triangle: the clipped polygon never has more than 6 vertices
         constexpr int MAXV = 6, BLOCK = 256;
         const size_t shmem = (size_t)(MAXV + 1) * BLOCK * sizeof(double2); // + one trash row for clamped pushes
-        static const bool old_clip = getenv("XR_CLIP_OLD") != nullptr; // measurement switch: the slot-loop kernel
-        if (old_clip)
-            XR_LAUNCH("clip_small", (k_clip_small<MAXV, BLOCK, true>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK),
-                      shmem, query->qo_fxy(), query->qo_len(), query->qo_off(), query->m, query->qo_perm(), tree->rec_fxy.get(),
-                      tree->rec_len.get(), tree->record_off(), tree->m, cand_tgt, cand_src, C, cand_area, tree->rec_face.get(), cand_sid,
-                      overflow_count, nnz_row, remap, dust);
-        else
-            XR_LAUNCH("clip_tri", (k_clip_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
+        XR_LAUNCH("clip_tri", (k_clip_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
                       query->qo_fxy(), query->m, tree->rec_fxy.get(), tree->m, cand_tgt, cand_src, C, cand_area,
                       tree->rec_face.get(), cand_sid, overflow_count, nnz_row, remap, dust);
-    } else if (query->m == 4 && tree->m == 3 && !(getenv("XR_CLIP_QUAD") && atoi(getenv("XR_CLIP_QUAD")) == 0)) {
-        // quadrilateral targets (a raster) x triangle source (XR_CLIP_QUAD=0: the slot-loop kernel, A/B switch)
+    } else if (query->m == 4 && tree->m == 3 && option(OPT_CLIP_QUAD) != 0) {
+        // quadrilateral targets (a raster) x triangle source (option "clip_quad" = 0: the slot-loop kernel, test switch)
         constexpr int BLOCK = 256;
         const size_t shmem = (size_t)(QUAD_MAXV + 2) * BLOCK * sizeof(double2);
         XR_LAUNCH("clip_quad_tri", (k_clip_quad_tri<BLOCK>), dim3(xcd_grid(div_up(C, BLOCK), remap)), dim3(BLOCK), shmem,
@@ -1499,8 +1468,8 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     const int64_t n_blocks = div_up(T, FB);
     const bool remap = xcd_remap_mask() & 2;
     const unsigned grid = xcd_grid(n_blocks, remap);
-    const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
-    int64_t big_capacity = margin_env ? std::max<int64_t>((int64_t)atoll(margin_env), 1) : ((int64_t)4 << 20);
+    const int64_t margin_opt = option(OPT_QUEUE_MARGIN); // test hook: a tiny margin forces the regrow path
+    int64_t big_capacity = margin_opt > 0 ? margin_opt : ((int64_t)4 << 20);
     // the regular pair queue: eight regions (one per XCD) of region_cap pairs each -- every block of 256 faces parks at most
     // 256 x SLOTS pairs and an XCD takes ceil(n_blocks / 8) blocks
     const int64_t region_cap = div_up(div_up(T, FB), 8) * FB * SLOTS;
@@ -1509,35 +1478,27 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     int32_t *mail = const_cast<int32_t *>(engine().mailbox);
     static_assert(sizeof(FusedCounters) == 32, "FusedCounters layout");
     // ctl: [0] regular queue cursor, [1] big queue cursor, [2] big faces, [3] big faces that did not fit, [4] clip
-    // overflows among the big pairs | FusedCounters | look-back status words
+    // overflows among the big pairs | FusedCounters
     // | per block of 256 target faces: survivors (clip), regular faces (search)
     // The 16 counter words come from the engine's zero-at-rest scratch (k_publish_all clears them again after copying them
     // to the mailbox) and k_search clears its block's survivor count: no memset in front of the search.
     constexpr size_t CTL_HEAD = QCUR_BASE + 8 * QCUR_STRIDE; // (the eight region cursors of the regular queue behind the 16 counters: a line each)
-    DevBuf<int32_t> ctl_tail(4 * (size_t)grid), ctl_own;
-    unsigned long long *status = reinterpret_cast<unsigned long long *>(ctl_tail.get());
-    int32_t *blk_surv = ctl_tail.get() + 2 * (size_t)grid, *blk_rows = blk_surv + grid;
+    DevBuf<int32_t> ctl_tail(2 * (size_t)grid), ctl_own;
+    int32_t *blk_surv = ctl_tail.get(), *blk_rows = blk_surv + grid;
     DevBuf<int32_t> blk_base(2 * (size_t)grid); // first stored row / CSR base of every hardware block (k_assemble_scan)
-    // XR_ASSEMBLE_SCAN=0: the assembly finds its bases by the decoupled look-back instead (measurement / fallback switch)
-    // (default 2: every assembly block sums the counts of the blocks in front of it itself; 1: a one-block scan kernel
-    // between clip and assembly, as until round 3)
-    // The own prefix reads b words in block b -- O(blocks^2) L2 reads in total: fine for a few thousand blocks (1M faces: 62 MB),
-    // 6 GB for the 39k blocks of a 10M-face target (measured: 10M -> 10M 4.39 -> 4.89 ms): from 8192 blocks on the scan kernel.
-    const char *scan_env = getenv("XR_ASSEMBLE_SCAN");
-    const int scan_mode = scan_env ? atoi(scan_env) : (grid <= 8192 ? 2 : 1);
-    const bool scan_bases = scan_mode != 0;
+    // Row bases of the assembly: every assembly block sums the counts of the blocks in front of it itself (scan_mode 2) -- it reads
+    // b words in block b, O(blocks^2) L2 reads in total: fine for a few thousand blocks (1M faces: 62 MB), 6 GB for the 39k blocks
+    // of a 10M-face target (measured: 10M -> 10M 4.39 -> 4.89 ms) -- so from 8192 blocks on a one-block scan kernel between clip and
+    // assembly provides them (scan_mode 1, as until round 3).  (Until round 5 a decoupled look-back inside k_assemble was a third
+    // form, behind a switch; it lost in round 3 and is gone.)
+    const int scan_mode = grid <= 8192 ? 2 : 1;
     DevBuf<int32_t> cand_count((size_t)T), cand_off((size_t)T + 1), big_list((size_t)T), pending((size_t)T), nnz_row((size_t)T),
         slot_face((size_t)T), big_indptr((size_t)T + 1);
     DevBuf<uint8_t> is_big((size_t)T);
     DevBuf<int2> block_seg((size_t)n_blocks);
-    // XR_CLIP_COMPACT=1: the clip writes only its survivors, compacted in place over the queue (16 B per survivor at the
-    // front of every 64-pair stretch), and k_assemble_packed reads only those.  Measured on the 1M x 1M benchmark (round 3,
-    // A/B on one box): the HBM bytes drop as intended, but the assembly becomes three passes of dependent loads (stretch
-    // count -> survivors) with returning LDS atomics -- 0.066 -> 0.087 ms -- and the clip pays 2 us for the ranking:
-    // step 0.582 -> 0.603 ms.  Kept as a switch, off by default.
-    const bool compact = scan_bases && tree->m == 3 && query->m == 3 && getenv("XR_CLIP_COMPACT") && atoi(getenv("XR_CLIP_COMPACT")) == 1;
-    DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)(compact ? 1 : reg_capacity));
-    DevBuf<int32_t> wave_surv((size_t)(compact ? reg_capacity / 64 + 1 : 1));
+    // (measured and removed: the clip writing only its survivors, compacted in place over the queue -- the HBM bytes drop, but the
+    // assembly becomes three passes of dependent loads, 0.066 -> 0.087 ms, DESIGN_HISTORY.md round 3)
+    DevBuf<int32_t> cand_tgt((size_t)reg_capacity), cand_src((size_t)reg_capacity), cand_sid((size_t)reg_capacity);
     DevBuf<double> cand_area((size_t)reg_capacity);
     csr->n_long.alloc(2); // [0] rows of more than XR_APPLY_LONG_ROW entries, [1] gate of an apply enqueued behind the build
     csr->row_order.alloc((size_t)T);
@@ -1574,18 +1535,14 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
             XR_HIP(hipMemsetAsync(ctl_head, 0, CTL_HEAD * sizeof(int32_t), st));
         }
         FusedCounters *fc = reinterpret_cast<FusedCounters *>(ctl_head + 8);
-        if (!scan_bases) XR_HIP(hipMemsetAsync(status, 0, sizeof(unsigned long long) * (size_t)grid, st)); // (look-back words: XR_ASSEMBLE_SCAN=0 only)
-        static const bool pack_ok = !(getenv("XR_SEARCH_PACK") && atoi(getenv("XR_SEARCH_PACK")) == 0); // (A/B switch)
-        static const int hit_form = getenv("XR_SEARCH_HIT") ? atoi(getenv("XR_SEARCH_HIT")) : SEARCH_HIT_DEFAULT; // (A/B switch)
-#define XR_SEARCH_LAUNCH(PACKED, FORM)                                                                                              \
-    XR_LAUNCH("search", (k_search<PACKED, FORM>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face,                      \
+#define XR_SEARCH_LAUNCH(PACKED)                                                                                                    \
+    XR_LAUNCH("search", (k_search<PACKED>), dim3(grid), dim3(256), 0, query->qo_bbox(), T, g, tree->n_face,                            \
               tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(), cand_src.get(),          \
               ctl_head + QCUR_BASE, block_seg.get(), is_big.get(), big_list.get(), ctl_head + 2, tile, (int32_t *)nullptr, nnz_row.get(),   \
-              remap, scan_bases ? blk_rows : (int32_t *)nullptr, scan_bases ? blk_surv : (int32_t *)nullptr, (int)region_cap)
-        if (!(pack_ok && tree->n_face <= ((int64_t)1 << 24))) XR_SEARCH_LAUNCH(false, SEARCH_HIT_DEFAULT);
-        else if (hit_form == 1) XR_SEARCH_LAUNCH(true, 1);
-        else if (hit_form == 2) XR_SEARCH_LAUNCH(true, 2);
-        else XR_SEARCH_LAUNCH(true, 0);
+              remap, blk_rows, blk_surv, (int)region_cap)
+        // (the owner byte rides in the record id's top byte where the tree has at most 2^24 faces)
+        if (tree->n_face <= ((int64_t)1 << 24)) XR_SEARCH_LAUNCH(true);
+        else XR_SEARCH_LAUNCH(false);
 #undef XR_SEARCH_LAUNCH
         {
             // ---- side stream: everything about the big faces except their final placement
@@ -1600,91 +1557,57 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
                 XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
                           query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
                           big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3, (int32_t *)nullptr,
-                          (int32_t *)nullptr, dust);
+                          dust);
             else
                 XR_LAUNCH("clip_big", (k_clip_tri_queue<CLIP_BLOCK, 2, false, 1>), dim3(engine().num_cu), dim3(CLIP_BLOCK), clip_shmem,
                           query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), big_tgt.get(), big_src.get(), ctl_head + 1,
                           big_capacity, big_area.get(), big_sid.get(), &fc->error, nnz_row.get(), ctl_head + 3, (int32_t *)nullptr,
-                          (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
+                          dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
             // (rows in face order: ranked inside search_big; their offsets: scanned inside row_fill_long -- two launches less
             // in what is the critical path of the whole weight build)
             // Two launches: the rows of at most ROW_BLOCK candidates (all but a handful) with 16 KB of LDS per block -- a block
             // per row, resident beside the clip and the assembly -- and the few longer ones with the bitmap (150 KB, a CU per
             // block).  As ONE launch every block needed a whole CU: it could not start before the clip's blocks had left and
             // then walked ~5 rows in turn -- 54-64 us, ending after the assembly (round-4 timeline).  XR_ROWFILL_SPLIT=0: one launch.
-            static const bool fill_split = !(getenv("XR_ROWFILL_SPLIT") && atoi(getenv("XR_ROWFILL_SPLIT")) == 0);
-            if (fill_split) {
-                // (round 6: the two launches are independent -- each scans the row lengths itself and fills only its own class of
-                // rows -- so the bitmap rows go to a SECOND side stream and run beside the light ones: the big faces' chain
-                // behind the clip is one launch shorter where it is the step's critical path, 0.506 -> 0.500 ms in an A/B)
-                SideForkScope fork;
-                XR_LAUNCH("row_fill_huge", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
-                          cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
-                          tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
-                          nnz_row.get(), big_indptr.get(), &fc->p_big, 2);
-                fork.end_launches();
-                XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu * 6), dim3(256), ROW_FILL_LIGHT_LDS, cand_off.get(),
-                          cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
-                          tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
-                          nnz_row.get(), big_indptr.get(), &fc->p_big, 1);
-            } else {
-                XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
-                          cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
-                          tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
-                          nnz_row.get(), big_indptr.get(), &fc->p_big);
-            }
+            // (round 6: the two launches are independent -- each scans the row lengths itself and fills only its own class of
+            // rows -- so the bitmap rows go to a SECOND side stream and run beside the light ones: the big faces' chain
+            // behind the clip is one launch shorter where it is the step's critical path, 0.506 -> 0.500 ms in an A/B)
+            SideForkScope fork;
+            XR_LAUNCH("row_fill_huge", k_row_fill_long, dim3(engine().num_cu), dim3(256), fill_shmem, cand_off.get(),
+                      cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
+                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
+                      nnz_row.get(), big_indptr.get(), &fc->p_big, 2);
+            fork.end_launches();
+            XR_LAUNCH("row_fill_long", k_row_fill_long, dim3(engine().num_cu * 6), dim3(256), ROW_FILL_LIGHT_LDS, cand_off.get(),
+                      cand_count.get(), big_sid.get(), big_area.get(), big_indptr.get(), tree_area, relative,
+                      tree->n_face, big_indices.get(), big_data.get(), slot_face.get(), ctl_head + 2, (int64_t)0, ctl_head + 3,
+                      nnz_row.get(), big_indptr.get(), &fc->p_big, 1);
         }
         // Persistent blocks per CU: five fill the LDS and the register files (best for the clip alone).  The big faces' chain
         // on the side stream then gets few wave slots while the clip runs; with its kernels at raised wave priority and only
         // three launches long (search_big -> clip -> row_fill_long) it still ends about when k_assemble does: 3, 4 and 5
         // blocks per CU all give the same step (0.635 ms) -- measured after the chain lost two launches; before, 3 was
-        // 4 % faster because the chain was the critical path.  XR_CLIP_BPC overrides (tuning hook).
-        static const int clip_bpc = getenv("XR_CLIP_BPC") ? atoi(getenv("XR_CLIP_BPC")) : 5;
-        static const bool clip_soa = getenv("XR_CLIP_SOA") && atoi(getenv("XR_CLIP_SOA")) == 1; // A/B switch: slot-major LDS columns
-        if (!tri_pair) {
+        // 4 % faster because the chain was the critical path.
+        // (slot-major LDS columns -- k_clip_tri_queue's SOA form -- were measured in round 3 and lost; the template parameter is all
+        // that is left of them)
+        if (!tri_pair)
             // (k_clip_small's LDS columns: 36 KB per block, four persistent blocks per CU)
-            const int bpc = std::min(clip_bpc, 4);
-            if (scan_bases)
-                XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 1, false, 1>), dim3(engine().num_cu * bpc), dim3(CLIP_BLOCK), clip_shmem,
-                          query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                          ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                          (const int32_t *)nullptr, blk_surv, (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
-            else
-                XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 0, false, 1>), dim3(engine().num_cu * bpc), dim3(CLIP_BLOCK), clip_shmem,
-                          query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                          ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                          (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
-        } else if (scan_bases && clip_soa)
-            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, true>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
+            XR_LAUNCH("clip_small", (k_clip_tri_queue<CLIP_BLOCK, 1, false, 1>), dim3(engine().num_cu * 4), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr, dust);
-        else if (scan_bases)
-            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, false>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
-                      query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
-                      ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, blk_surv, compact ? wave_surv.get() : (int32_t *)nullptr, dust);
+                      (const int32_t *)nullptr, blk_surv, dust, query->qo_len(), tree->rec_len.get(), query->m, tree->m);
         else
-            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 0>), dim3(engine().num_cu * clip_bpc), dim3(CLIP_BLOCK), clip_shmem,
+            XR_LAUNCH("clip_tri", (k_clip_tri_queue<CLIP_BLOCK, 1, false>), dim3(engine().num_cu * 5), dim3(CLIP_BLOCK), clip_shmem,
                       query->qo_fxy(), tree->rec_fxy.get(), tree->rec_face.get(), cand_tgt.get(), cand_src.get(),
                       ctl_head + QCUR_BASE, -region_cap, cand_area.get(), cand_sid.get(), &fc->error, (int32_t *)nullptr,
-                      (const int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, dust);
+                      (const int32_t *)nullptr, blk_surv, dust);
         if (scan_mode == 1)
             XR_LAUNCH("assemble_scan", k_assemble_scan, dim3(1), dim3(1024), 0, blk_rows, blk_surv, (int64_t)n_blocks, (int)grid,
                       remap, blk_base.get(), blk_base.get() + grid, fc, csr->indptr.get());
-        if (compact)
-            XR_LAUNCH("assemble", k_assemble_packed, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
-                      cand_src.get(), cand_area.get(), wave_surv.get(), block_seg.get(), is_big.get(), tree_area, relative, tile,
-                      csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc, status, csr->indptr.get(),
-                      csr->indices.get(), csr->data.get(), csr->row_order.get(), csr->long_rows.get(), cap, remap,
-                      scan_mode == 1 ? blk_base.get() : (const int32_t *)nullptr,
-                      scan_mode == 1 ? blk_base.get() + grid : (const int32_t *)nullptr,
-                      scan_mode == 2 ? blk_rows : (const int32_t *)nullptr, scan_mode == 2 ? blk_surv : (const int32_t *)nullptr);
-        else
         XR_LAUNCH("assemble", k_assemble, dim3(grid), dim3(FB), 0, query->qo_bbox(), query->qo_perm(), T, cand_tgt.get(),
                   cand_off.get(), cand_count.get(), block_seg.get(), is_big.get(), cand_area.get(), cand_sid.get(),
                   tree_area, relative, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, fc,
-                  status, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
+                  csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
                   csr->long_rows.get(), cap, remap, scan_mode == 1 ? blk_base.get() : (const int32_t *)nullptr,
                   scan_mode == 1 ? blk_base.get() + grid : (const int32_t *)nullptr,
                   scan_mode == 2 ? blk_rows : (const int32_t *)nullptr, scan_mode == 2 ? blk_surv : (const int32_t *)nullptr);
@@ -1713,12 +1636,12 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
         const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], n_pending = mail[3], big_overflow = mail[4];
         const int32_t err = mail[5], rows_regular = mail[6], p_regular = mail[8], p_big = mail[9];
         XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
-        if (getenv("XR_DEBUG_FUSED"))
+        if (debug_fused())
             fprintf(stderr, "[tri] T=%lld C=%d big: %d faces %d pairs (%d pending) p_regular=%d p_big=%d err=%d rows=%d long=%d regions %d %d %d %d %d %d %d %d of %lld\n",
                     (long long)T, C_reg, n_big, C_big, n_pending, p_regular, p_big, err, rows_regular, mail[7], mail[11], mail[12], mail[13],
                     mail[14], mail[15], mail[16], mail[17], mail[18], (long long)region_cap);
         (void)big_overflow;
-        if (err & (1 | 8)) return false;
+        if (err & 1) return false;
         if (n_pending > 0 || C_big > big_capacity) { // some big faces needed more room than the margin
             big_capacity = (int64_t)C_big + 1024;
             continue;
@@ -1737,116 +1660,13 @@ static bool overlap_tri(xr_mesh *tree, xr_mesh *query, const double *tree_area, 
     }
 }
 
-// Triangle x triangle pairs as ONE streamed kernel (xr_overlap_stream.h): a workgroup takes 256 target faces from the grid
-// walk to their finished CSR rows, big faces are listed and claimed by whichever block has finished its own rows.  One launch
-// + the publication; ONE host round trip.  -> false if the matrix has to go through the kernel chain (overlap_tri) after
-// all: a big face with more candidates than a block's stage, or a clip that needs more than 6 vertices.
-static bool overlap_stream(xr_mesh *tree, xr_mesh *query, const double *tree_area, bool relative, xr_csr *csr,
-                           const MortonParams &tile, EarlyApply *early) {
-    const int64_t T = query->n_face;
-    const GridParams &g = tree->grid;
-    hipStream_t st = launch_stream();
-    const int64_t n_blocks = div_up(T, FB);
-    const bool remap = xcd_remap_mask() & 2;
-    const unsigned grid = xcd_grid(n_blocks, remap);
-    int64_t per_face = 8; // CSR entries reserved per target face; regrown if the matrix is denser
-    int32_t *mail = const_cast<int32_t *>(engine().mailbox);
-    // the blocks' scratch stretches: pair words, (source id | dead), area -- SB_STRETCH per block, touched as far as the block's
-    // pairs go (1700 of 4096 on the benchmark) and read back by the block that wrote them
-    DevBuf<int32_t> sc_pair((size_t)grid * SB_STRETCH), sc_sid((size_t)grid * SB_STRETCH), ctl_own;
-    DevBuf<double> sc_area((size_t)grid * SB_STRETCH);
-    csr->n_long.alloc(2); // [0] rows of more than XR_APPLY_LONG_ROW entries, [1] gate of an apply enqueued behind the build
-    csr->row_order.alloc((size_t)T);
-    csr->has_row_order = true;
-    const size_t clip_shmem = (size_t)(TRI_MAXV + 1) * FB * sizeof(double2);
-    static_assert((size_t)(TRI_MAXV + 1) * FB * sizeof(double2) >= sizeof(int32_t) * (SLOTS + 1) * FB + (sizeof(float4) + sizeof(int32_t)) * BIGREC_BLOCK &&
-                      (size_t)(TRI_MAXV + 1) * FB * sizeof(double2) >= sizeof(int32_t) * SB_STRETCH,
-                  "the clip's columns are the largest of the three lives of the block's LDS region");
-    const double dust = overlap_dust_threshold(tree, query);
-    for (int attempt = 0;; attempt++) {
-        XR_REQUIRE(attempt < 8, XR_ERR_LIMIT, "xr_overlap: the weight matrix does not fit the device buffers");
-        const int64_t cap = per_face * T + ((int64_t)1 << 20);
-        XR_REQUIRE(cap < ((int64_t)1 << 31), XR_ERR_LIMIT, "nnz exceeds the int32 range");
-        csr->indices.alloc((size_t)cap);
-        csr->data.alloc((size_t)cap);
-        csr->long_rows.alloc((size_t)(cap / XR_APPLY_LONG_ROW + 1));
-        // control words + the list of big faces: zero at rest (k_publish_stream clears the words, a claimed list entry is cleared
-        // by the block that claimed it)
-        const size_t ctl_words = SC_HEAD + (size_t)T;
-        int32_t *ctl = zero_scratch(1, ctl_words);
-        const bool ctl_cached = ctl != nullptr;
-        if (!ctl_cached) {
-            ctl_own.alloc(ctl_words);
-            ctl = ctl_own.get();
-            XR_HIP(hipMemsetAsync(ctl, 0, ctl_words * sizeof(int32_t), st));
-        }
-        static const bool stream_debug = getenv("XR_STREAM_DEBUG") != nullptr; // phase clocks of the streamed kernel (measurement)
-        DevBuf<unsigned long long> dbg;
-        if (stream_debug) {
-            dbg.alloc(16);
-            XR_HIP(hipMemsetAsync(dbg.get(), 0, 16 * sizeof(unsigned long long), st));
-            XR_HIP(hipMemsetAsync(dbg.get() + 7, 0xff, sizeof(unsigned long long), st));
-        }
-        XR_LAUNCH("overlap_block", k_overlap_block, dim3(grid), dim3(FB), clip_shmem, query->qo_bbox(), query->qo_fxy(), query->qo_perm(), T,
-                  g, tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_face.get(), sc_pair.get(),
-                  sc_sid.get(), sc_area.get(), ctl, ctl + SC_HEAD, tile, csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr,
-                  tree_area, relative, dust, csr->indptr.get(), csr->indices.get(), csr->data.get(), csr->row_order.get(),
-                  csr->long_rows.get(), cap, remap, dbg.get());
-        host_stamp(5);
-        const int32_t seq = mailbox_next_seq();
-        XR_LAUNCH("publish", k_publish_stream, dim3(1), dim3(64), 0, ctl, csr->indptr.get(), T, csr->n_long.get(), mail, seq, cap);
-        if (ctl_cached) zero_scratch_done(1); // (words and list are zero again behind the two kernels)
-        if (early) {
-            // sizes unknown on the host yet: pessimistic flags (long rows possible, of any length) -- they only add blocks that
-            // look at the device-side list of long rows and find it short or empty; results do not depend on them
-            csr->nnz = 0;
-            csr->has_long = true;
-            csr->max_row_len = -1;
-            csr->apply_gated = true; // (the kernel looks at the gate k_publish_stream has just set: a failed attempt is skipped)
-            early->fn(csr);
-            csr->apply_gated = false;
-        }
-        host_stamp(6);
-        mailbox_wait_seq(seq);
-        host_stamp(7);
-        const int32_t C_reg = mail[0], C_big = mail[1], n_big = mail[2], err = mail[3], rows = mail[4], entries = mail[5];
-        XR_REQUIRE(C_reg >= 0 && C_big >= 0, XR_ERR_LIMIT, "candidate pair count exceeds the int32 range");
-        if (debug_fused())
-            fprintf(stderr, "[stream] T=%lld C=%d big: %d faces %d pairs rows=%d entries=%d err=%d long=%d max_row=%d\n", (long long)T, C_reg,
-                    n_big, C_big, rows, entries, err, mail[6], mail[7]);
-        if (stream_debug) {
-            unsigned long long h[16];
-            d2h(h, dbg.get(), sizeof(h));
-            const double us = 0.01; // 100 MHz
-            fprintf(stderr, "[stream clocks] per block (mean us): walk %.1f clip %.1f rows %.1f | big faces: %llu handled, mean %.1f us, longest %.1f us, most per block %llu | "
-                            "kernel span %.1f us, last block start %.1f us, longest block %.1f us\n",
-                    h[0] * us / n_blocks, h[1] * us / n_blocks, h[2] * us / n_blocks, h[4], h[4] ? h[3] * us / h[4] : 0.0, h[5] * us, h[6],
-                    (h[8] - h[7]) * us, (h[10] - h[7]) * us, h[9] * us);
-        }
-        XR_REQUIRE(!(err & 8), XR_ERR_INVALID, "xr_overlap: internal error (a listed face was never published)");
-        if (err & (1 | 2)) return false;
-        if ((err & 4) || entries < 0 || (int64_t)entries > cap) {
-            per_face *= 2;
-            continue;
-        }
-        XR_REQUIRE(rows == T, XR_ERR_INVALID, "xr_overlap: internal row count mismatch");
-        tree->last_candidates = (int64_t)C_reg + C_big;
-        csr->nnz = entries;
-        csr->has_long = mail[6] > 0; // rows of more than XR_APPLY_LONG_ROW entries (none: the apply skips their kernels)
-        csr->max_row_len = mail[6] > 0 ? mail[7] : XR_APPLY_LONG_ROW;
-        if (early) early->done = true; // (the apply enqueued in THIS attempt saw the final matrix)
-        return true;
-    }
-}
-
 static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, EarlyApply *early = nullptr) {
     // (the query side on the side stream next to the tree side was measured: the prepare kernels are bandwidth bound and
     // just slow each other down, 0.684 -> 0.706 ms per step)
     // the tree side only needs its records (built from the raw mesh).  Its statistics go to the host through a one-block
     // kernel that ends with writes to pinned memory (~20 us): on the side stream as well, beside the preparation of the
-    // query mesh, which is what the host waits behind anyway (XR_STATS_INLINE=1: in line, measurement hook)
-    static const bool stats_inline = getenv("XR_STATS_INLINE") && atoi(getenv("XR_STATS_INLINE")) != 0;
-    mesh_prepare(tree, false, /*stats_on_side=*/!stats_inline, /*allow_sampled=*/true); // (bounds exact, mean extent sampled)
+    // query mesh, which is what the host waits behind anyway
+    mesh_prepare(tree, false, /*stats_on_side=*/true, /*allow_sampled=*/true); // (bounds exact, mean extent sampled)
     host_stamp(1);
     mesh_prepare(query, true, /*stats_on_side=*/true); // (its statistics are first read by mesh_query_order below)
     host_stamp(2);
@@ -1879,31 +1699,21 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
         double span = std::max(hs[1] - hs[0], hs[3] - hs[2]);
         if (!(span > 0)) span = 1.0;
         // tile edge <= 12 mean extents (the side count is a power of two): about one block of 256 triangles per tile
-        static const double tile_ext = getenv("XR_TILE_EXT") ? atof(getenv("XR_TILE_EXT")) : 12.0; // tuning hook
-        double h = tile_ext * hs[4] / (double)T;
+        double h = 12.0 * hs[4] / (double)T;
         if (!(h > 0)) h = span;
         int bits = 0;
         while (bits < 12 && ldexp(h, bits) < span) bits++;
         tile = MortonParams{hs[0], hs[2], (double)(1 << bits) / (span * (1.0 + 1e-9)), 1 << bits};
-        static const int tile_run = getenv("XR_TILE_RUN") ? atoi(getenv("XR_TILE_RUN")) : TILE_RUN; // tuning hook (power of two)
-        tile.n_run = tile_run;
+        tile.n_run = TILE_RUN;
         csr->tile_key.alloc((size_t)T);
         csr->tile_key_range = (int64_t)1 << (2 * bits);
         csr->has_tile_key = bits > 0;
     }
     {
-        // triangle x triangle: the single-round-trip pipeline of xr_overlap_fused.h (XR_OVERLAP_FUSED=0, read per call:
-        // measurement / test switch back to the general kernel chain)
-        const char *fused_env = getenv("XR_OVERLAP_FUSED");
-        const bool fused_on = !(fused_env && atoi(fused_env) == 0);
+        // triangle x triangle: the single-round-trip pipeline of xr_overlap_fused.h (option "overlap_fused" = 0: test /
+        // measurement switch back to the general kernel chain)
+        const bool fused_on = option(OPT_OVERLAP_FUSED) != 0;
         if (fused_on && tree->m <= DENSE_MAX_NODES && query->m <= DENSE_MAX_NODES && (T + 8 * FB) * SLOTS < ((int64_t)1 << 31)) {
-            // triangle x triangle on a tree of at most 2^24 faces (the pair word's record field): the streamed kernel;
-            // XR_OVERLAP_STREAM=0 (read per call: test / measurement switch) keeps the kernel chain
-            const char *stream_env = getenv("XR_OVERLAP_STREAM");
-            const bool stream_on = stream_env && atoi(stream_env) == 1; // (experiment: slower than the chain as ONE kernel, see DESIGN)
-            if (stream_on && tree->m == 3 && query->m == 3 && tree->n_face <= ((int64_t)1 << 24) &&
-                overlap_stream(tree, query, tree_area, relative, csr, tile, early))
-                return;
             if (overlap_tri(tree, query, tree_area, relative, csr, tile, early)) return;
             csr->has_row_order = false; // (the general pipeline below stores the rows in query order)
         }
@@ -1920,18 +1730,18 @@ static void overlap(xr_mesh *tree, xr_mesh *query, bool relative, xr_csr *csr, E
     const int big_grid = engine().num_cu * 8;
     const int64_t n_blocks = div_up(T, 256);
     DevBuf<int2> block_seg((size_t)n_blocks);
-    const char *margin_env = getenv("XR_QUEUE_MARGIN"); // test hook: a tiny margin forces the regrow path
-    int64_t capacity = T * SLOTS + (margin_env ? (int64_t)atoll(margin_env) : ((int64_t)4 << 20));
+    const int64_t margin_opt = option(OPT_QUEUE_MARGIN); // test hook: a tiny margin forces the regrow path
+    int64_t capacity = T * SLOTS + (margin_opt > 0 ? margin_opt : ((int64_t)4 << 20));
     XR_REQUIRE(capacity < ((int64_t)1 << 31), XR_ERR_LIMIT, "candidate pair queue exceeds the int32 range");
     DevBuf<int32_t> cand_tgt((size_t)capacity), cand_src((size_t)capacity), nnz_row((size_t)T);
     const bool remap_search = xcd_remap_mask() & 2, remap_rows = xcd_remap_mask() & 4;
     if (tree->n_face <= ((int64_t)1 << 24))
-        XR_LAUNCH("search", (k_search<true, SEARCH_HIT_DEFAULT>), dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
+        XR_LAUNCH("search", (k_search<true>), dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
                   tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
                   cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
     else
-        XR_LAUNCH("search", (k_search<false, SEARCH_HIT_DEFAULT>), dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
+        XR_LAUNCH("search", (k_search<false>), dim3(xcd_grid(div_up(T, 256), remap_search)), dim3(256), 0, query->qo_bbox(), T, g,
                   tree->n_face, tree->cell_start.get(), tree->rec_bb.get(), cand_count.get(), cand_off.get(), cand_tgt.get(),
                   cand_src.get(), counters.get() + 3, block_seg.get(), is_big.get(), big_list.get(), counters.get() + 2, tile,
                   csr->has_tile_key ? csr->tile_key.get() : (int32_t *)nullptr, nnz_row.get(), remap_search);
@@ -2060,9 +1870,7 @@ int xr_overlap_apply_dev(xr_mesh *tree, xr_mesh *query, int relative, int method
         EarlyApply early;
         early.fn = [&](const xr_csr *c) { csr_apply_dev(c, method, percentile, source_dev, source_dtype, K, out_dev); };
         // one variable and a streaming reducer: the apply is one launch that needs no size on the host
-        static const bool early_off = getenv("XR_EARLY_APPLY") && atoi(getenv("XR_EARLY_APPLY")) == 0; // A/B switch
-        const bool can_early = !early_off && K == 1 && method != XR_MODE && method != XR_PERCENTILE &&
-                               !(getenv("XR_APPLY_K1") && !strcmp(getenv("XR_APPLY_K1"), "block"));
+        const bool can_early = option(OPT_EARLY_APPLY) != 0 && K == 1 && method != XR_MODE && method != XR_PERCENTILE;
         overlap(tree, query, relative != 0, csr, can_early ? &early : nullptr);
         host_stamp(8);
         if (!early.done && K > 0) csr_apply_dev(csr, method, percentile, source_dev, source_dtype, K, out_dev);
@@ -2083,12 +1891,15 @@ int xr_overlap_partial_dev(xr_mesh *tree, xr_mesh *query, int relative, int meth
     XR_REQUIRE(tree && query && out, XR_ERR_INVALID, "xr_overlap_partial_dev: NULL argument");
     XR_REQUIRE(K >= 0 && (source_dev || tree->n_face == 0 || K == 0) && (out_dev || query->n_face == 0 || K == 0), XR_ERR_INVALID,
                "xr_overlap_partial_dev: NULL data argument");
+    // (checked BEFORE the weight build: inside it they would fire in the early apply's callback, half-way through the build)
+    XR_REQUIRE(xr_partial_components(method) > 0, XR_ERR_INVALID, "xr_overlap_partial_dev: method %d has no partial state", method);
+    XR_REQUIRE(source_dtype == XR_F32 || source_dtype == XR_F64, XR_ERR_INVALID, "xr_overlap_partial_dev: source_dtype must be XR_F32 or XR_F64");
+    XR_REQUIRE(K < 65536, XR_ERR_LIMIT, "xr_overlap_partial_dev: at most 65535 variables per call");
     xr_csr *csr = new xr_csr();
     try {
         EarlyApply early;
         early.fn = [&](const xr_csr *c) { csr_partial_dev(c, method, source_dev, source_dtype, K, out_dev, rows_layout); };
-        static const bool early_off = getenv("XR_EARLY_APPLY") && atoi(getenv("XR_EARLY_APPLY")) == 0; // A/B switch
-        const bool can_early = !early_off && K == 1; // (one variable: the wave-window kernel needs no size on the host)
+        const bool can_early = option(OPT_EARLY_APPLY) != 0 && K == 1; // (one variable: the wave-window kernel needs no size on the host)
         overlap(tree, query, relative != 0, csr, can_early ? &early : nullptr);
         if (!early.done && K > 0) csr_partial_dev(csr, method, source_dev, source_dtype, K, out_dev, rows_layout);
         dev_call_done();

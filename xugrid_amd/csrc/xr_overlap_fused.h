@@ -12,8 +12,8 @@
 //                             thousand (rows, entries) pairs into every block's first stored row and CSR base
 //   k_assemble                the block that owns 256 consecutive target faces counts its survivors per row in LDS, ranks
 //                             every survivor among its row and writes the final CSR at its base.  No row counters in
-//                             HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)  XR_ASSEMBLE_SCAN=0: the
-//                             bases come from a decoupled look-back inside k_assemble instead (bounded spins, abort bit)
+//                             HBM.  (xr_csr::row_order maps stored rows to the caller's faces.)  Up to 8192 blocks every
+//                             block sums the counts of the blocks in front of it itself instead of k_assemble_scan
 //   big faces (hull slivers, > SLOTS hits; 0.1 % of the faces, but their block-per-face kernels are chains of dependent
 //   phases: 15 % of the step when run in line) on a SIDE STREAM, forked behind k_search: k_search_big -> k_clip_tri_queue on
 //   their own pair queue -> k_row_fill_long (rows in face order as ranked by k_search_big; scans their lengths itself) into a small
@@ -35,7 +35,7 @@ static constexpr int FWAVES = FB / 64;
 
 struct FusedCounters {                    // device words, zeroed before the launch
     int32_t n_apply_long;                 // rows with more than XR_APPLY_LONG_ROW entries
-    int32_t error;                        // bit 0: clip buffer overflow, bit 2: CSR capacity, bit 3: look-back aborted
+    int32_t error;                        // bit 0: clip buffer overflow, bit 2: CSR capacity
     int32_t p_regular;                    // entries of all regular rows (k_assemble)
     int32_t rows_regular;                 // regular rows
     int32_t p_big;                        // entries of the big faces' rows (k_big_order)
@@ -46,74 +46,6 @@ struct FusedCounters {                    // device words, zeroed before the lau
 static_assert(offsetof(FusedCounters, error) == 4 && offsetof(FusedCounters, p_regular) == 8 && offsetof(FusedCounters, rows_regular) == 12 &&
                   offsetof(FusedCounters, p_big) == 16 && offsetof(FusedCounters, max_row) == 24,
               "k_publish_all addresses the fields by word");
-
-// Decoupled look-back: one 64-bit status word per block -- nothing yet / the block's own aggregate / its inclusive prefix.
-// Value: rows in bits 31..61, entries in bits 0..30 (both totals stay below 2^31, so sums never carry across).  Blocks
-// are chained in blockIdx order (the dispatcher starts blocks in that order, so a predecessor is running or done; no
-// ticket counter: 4000 returning atomics on one address cost 30-40 us by themselves).  HIP does not PROMISE that order,
-// so every spin is bounded: a block that waits longer than LB_SPIN_LIMIT polls raises the abort bit and the host
-// falls back to the scan-based pipeline.
-static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_VALUE = (1ull << 62) - 1;
-static constexpr int LB_SPIN_LIMIT = 1 << 16; // polls (~20 ms): far beyond any real wait
-static constexpr int LB_WIN = 8;              // status words per lane and poll: a look-back window of 512 blocks
-
-// exclusive prefix of this block's aggregate over all earlier blocks (called by the 64 lanes of wave 0); -1 = aborted
-__device__ __forceinline__ long long lookback_exclusive(unsigned long long *status, int b, long long aggregate, int lane,
-                                                        int32_t *error_bits) {
-    if (b == 0) {
-        if (lane == 0) __hip_atomic_store(&status[0], LB_PREFIX | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (lane == 0) __hip_atomic_store(&status[b], LB_AGG | (unsigned long long)aggregate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // Every round trip fetches the status words of LB_WIN * 64 predecessors (LB_WIN loads per lane, in flight together):
-    // all resident blocks start at about the same time, so the nearest PUBLISHED prefix is up to ~2000 blocks back and a
-    // 64-wide window needed ~30 dependent round trips per block (a third of the kernel's time, measured with clock64).
-    long long exclusive = 0;
-    int look = b - 1, spins = 0;
-    while (true) {
-        unsigned long long word[LB_WIN];
-#pragma unroll
-        for (int k = 0; k < LB_WIN; k++) {
-            const int idx = look - lane - 64 * k;
-            word[k] = LB_PREFIX; // (virtual block -1: prefix 0)
-            if (idx >= 0) word[k] = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        bool done = false, wait = false;
-        int advanced = 0;
-#pragma unroll
-        for (int k = 0; k < LB_WIN; k++) {
-            if (done || wait) continue; // (uniform)
-            const unsigned long long flag = word[k] >> 62;
-            const unsigned long long not_ready = __ballot(flag == 0), has_prefix = __ballot(flag == 2);
-            const int first_prefix = has_prefix ? __ffsll((long long)has_prefix) - 1 : 64;
-            const int first_wait = not_ready ? __ffsll((long long)not_ready) - 1 : 64;
-            if (first_wait < first_prefix) { // a predecessor in this window has published nothing yet
-                wait = true;
-                continue;
-            }
-            long long v = lane <= first_prefix ? (long long)(word[k] & LB_VALUE) : 0;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-            exclusive += v;
-            advanced = k + 1;
-            if (first_prefix < 64) done = true;
-        }
-        if (done) break;
-        look -= 64 * advanced; // (windows summed so far held aggregates only: they are final)
-        if (wait) {
-            if (++spins > LB_SPIN_LIMIT || (__hip_atomic_load(error_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 8)) {
-                if (lane == 0) atomicOr(error_bits, 8);
-                exclusive = -1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    // (after an abort the prefix is garbage, but it is published all the same so that nobody else spins)
-    if (lane == 0)
-        __hip_atomic_store(&status[b], LB_PREFIX | (unsigned long long)((exclusive < 0 ? 0 : exclusive) + aggregate), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return exclusive;
-}
 
 // block-wide exclusive scan of one int per thread (FB threads); returns the exclusive value, total in *total
 __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/, int *total) {
@@ -154,15 +86,12 @@ __device__ __forceinline__ int block_excl_scan(int v, int *sh_wave /*[FWAVES]*/,
 template <int BLOCK, int COUNT, bool SOA = false, int KIND = 0>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(KIND == 0 ? 5 : 4)))
 k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ rec_fxy,
-                 const int32_t *__restrict__ rec_face, const int32_t *cand_tgt /* (rewritten in place when compacting) */,
+                 const int32_t *__restrict__ rec_face, const int32_t *cand_tgt,
                  const int32_t *cand_src, const int32_t *__restrict__ n_cand_dev, int64_t capacity,
                  double *__restrict__ cand_area, int32_t *__restrict__ cand_sid, int32_t *__restrict__ error_bits,
                  int32_t *__restrict__ nnz_row /* optional: survivors per target face, counted by atomics */,
                  const int32_t *__restrict__ skip_if /* optional: nothing is done when this device word is > 0 */,
                  int32_t *__restrict__ blk_surv = nullptr /* optional: survivors per BLOCK of 256 target faces (k_assemble_scan) */,
-                 int32_t *__restrict__ wave_surv = nullptr /* COUNT == 1: survivors per 64-pair stretch; the output is then
-                 COMPACTED: the survivors of stretch w are written to the front of the stretch, IN PLACE over the queue --
-                 (target face, caller's source id, area) in cand_tgt / cand_src / cand_area at w * 64 + rank */,
                  double dust = 0.0 /* areas up to this are confirmed by the reference's pre-clip tests (xr_overlap.hip: confirm_dust) */,
                  const uint8_t *__restrict__ q_len = nullptr, const uint8_t *__restrict__ s_len = nullptr, int q_m = 3, int s_m = 3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -270,22 +199,7 @@ k_clip_tri_queue(const double *__restrict__ q_fxy, const double *__restrict__ re
             }
         }
         const int tq_now = active ? cur_tq : -1;
-        if (COUNT == 1 && wave_surv) {
-            // Only the pairs that survive (60 % on the benchmark) are written, packed at the front of the wave's own
-            // 64-pair stretch of the queue: 16 bytes per survivor into lines the wave has just read, no holes for the
-            // assembly to fetch.  (All 64 inputs of the stretch were loaded an iteration ago: overwriting is safe.)
-            overflow = overflow || (active && area == TRI_AREA_OVERFLOW);
-            const bool keep = active && area > 0;
-            const unsigned long long surv = __ballot(keep);
-            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(surv >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)surv, 0));
-            const int64_t w0 = c & ~(int64_t)63;
-            if (keep) {
-                cand_area[w0 + rank] = area;
-                const_cast<int32_t *>(cand_tgt)[w0 + rank] = cur_tq;
-                const_cast<int32_t *>(cand_src)[w0 + rank] = sid;
-            }
-            if ((tid & 63) == 0 && w0 < c_end) wave_surv[w0 >> 6] = __popcll(surv);
-        } else if (active) {
+        if (active) {
             overflow = overflow || area == TRI_AREA_OVERFLOW;
             cand_area[c] = area;
             cand_sid[c] = area > 0 ? sid : 0x7fffffff;
@@ -392,7 +306,7 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
            const int32_t *__restrict__ cand_count, const int2 *__restrict__ block_seg,
            const uint8_t *__restrict__ is_big, const double *__restrict__ cand_area,
            const int32_t *__restrict__ cand_sid, const double *__restrict__ src_area, bool relative, MortonParams tile,
-           int32_t *__restrict__ tile_key, FusedCounters *__restrict__ counters, unsigned long long *__restrict__ status,
+           int32_t *__restrict__ tile_key, FusedCounters *__restrict__ counters,
            int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data, int32_t *__restrict__ row_order,
            int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap,
            const int32_t *__restrict__ base_rows = nullptr, const int32_t *__restrict__ base_nnz = nullptr,
@@ -474,16 +388,12 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
             for (int w = 0; w < FWAVES; w++) tot += sh_part[w];
             sh_base = tot;
         }
-    } else if (base_nnz) { // scanned beforehand (k_assemble_scan)
+    } else { // scanned beforehand (k_assemble_scan)
         if (tid == 0) sh_base = ((long long)base_rows[b] << 31) | (long long)base_nnz[b];
-    } else if (tid < 64) {
-        const long long packed = lookback_exclusive(status, b, ((long long)block_rows << 31) | (long long)block_nnz, tid, &counters->error);
-        if (tid == 0) sh_base = packed;
     }
     __syncthreads();
-    if (sh_base < 0) return; // aborted (the host falls back)
     const long long base = sh_base & 0x7fffffffll, row_base = sh_base >> 31;
-    if (!base_nnz && b == n_chain - 1 && tid == 0) { // (look-back or own prefix: the last block of the chain knows the totals)
+    if (!base_nnz && b == n_chain - 1 && tid == 0) { // (own prefix: the last block of the chain knows the totals)
         const long long entries = base + block_nnz, rows = row_base + block_rows;
         counters->p_regular = (int32_t)entries; // entries of all regular rows
         counters->rows_regular = (int32_t)rows;
@@ -526,169 +436,6 @@ k_assemble(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm
             if (pos < csr_capacity) {
                 indices[pos] = s;
                 data[pos] = relative ? area[u] / src_area[s] : area[u];
-            } else {
-                overflow_cap = true;
-            }
-        }
-    }
-    if (overflow_cap) atomicOr(&counters->error, 4);
-}
-
-// The same assembly on the COMPACTED clip output (k_clip_tri_queue with wave_surv): the block's stretch of the queue is a
-// run of 64-pair wave stretches, each holding its survivors -- (target face, source id, area) -- packed at its front.  The
-// block's four waves take the wave stretches in turn, 64 lanes on (up to) 64 survivors: nothing of the 40 % of the pairs
-// that clipped to nothing is fetched.  Three passes over the survivors (the second and third hit L2): count per row ->
-// [scan of the rows, base of the block] -> source ids into per-row lists in LDS (order of arrival) -> rank of every
-// survivor among its row's list = its position in the row, ascending in the source id; written with its area.
-// (A wave stretch at either end of the block's stretch is shared with the neighbouring block: each takes its own rows.)
-__global__ void __launch_bounds__(FB, 2)
-k_assemble_packed(const double *__restrict__ q_bbox, const int32_t *__restrict__ q_perm, int64_t n_query,
-                  const int32_t *__restrict__ surv_tgt, const int32_t *__restrict__ surv_sid,
-                  const double *__restrict__ surv_area, const int32_t *__restrict__ wave_surv,
-                  const int2 *__restrict__ block_seg, const uint8_t *__restrict__ is_big,
-                  const double *__restrict__ src_area, bool relative, MortonParams tile, int32_t *__restrict__ tile_key,
-                  FusedCounters *__restrict__ counters, unsigned long long *__restrict__ status,
-                  int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
-                  int32_t *__restrict__ row_order, int32_t *__restrict__ apply_long_rows, int64_t csr_capacity, bool remap,
-                  const int32_t *__restrict__ base_rows, const int32_t *__restrict__ base_nnz,
-                  const int32_t *__restrict__ blk_rows, const int32_t *__restrict__ blk_surv) {
-    __shared__ int32_t sh_list[SLOTS * FB]; // source ids, row by row (a row's list: [sh_rowoff[row], + sh_nnz[row]))
-    __shared__ int32_t sh_nnz[FB];          // survivors of the face
-    __shared__ int32_t sh_cur[FB];          // fill cursor of the face's list
-    __shared__ uint16_t sh_rowoff[FB];      // offset of the face's row inside the block
-    __shared__ int32_t sh_wave[FWAVES];
-    __shared__ long long sh_part[FWAVES];
-    __shared__ long long sh_base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t n_blocks = (n_query + FB - 1) / FB;
-    const int64_t lb = xcd_block(n_blocks, remap); // (blocks beyond n_blocks carry no faces but stay in the chain)
-    const bool valid_block = lb < n_blocks;
-    sh_nnz[tid] = 0;
-    sh_cur[tid] = 0;
-    const int64_t t0 = lb * FB;
-    const int64_t t = t0 + tid;
-    const bool in_range = valid_block && t < n_query;
-    const int2 seg = valid_block ? block_seg[lb] : make_int2(0, 0);
-    const int total = seg.y;
-    const bool regular = in_range && !is_big[t];
-    // wave stretches that overlap the block's stretch of the queue
-    const int wc0 = seg.x >> 6, wc1 = total > 0 ? (seg.x + total - 1) >> 6 : wc0 - 1;
-    __syncthreads();
-    // ---- pass 1: survivors per row (four wave stretches in flight per wave)
-    for (int wc = wc0 + wave; wc <= wc1; wc += 4 * FWAVES) {
-        int n[4], row[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int w = wc + u * FWAVES;
-            n[u] = w <= wc1 ? wave_surv[w] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int w = wc + u * FWAVES;
-            row[u] = lane < n[u] ? surv_tgt[(int64_t)w * 64 + lane] - (int)t0 : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (row[u] >= 0 && row[u] < FB) atomicAdd(&sh_nnz[row[u]], 1);
-    }
-    __syncthreads();
-    const int my_nnz = regular ? sh_nnz[tid] : 0;
-    int block_nnz = 0, block_rows = 0;
-    const int rowoff = block_excl_scan(my_nnz, sh_wave, &block_nnz);
-    const int rowidx = block_excl_scan(regular ? 1 : 0, sh_wave, &block_rows);
-    sh_rowoff[tid] = (uint16_t)rowoff;
-    const int b = (int)blockIdx.x, n_chain = (int)gridDim.x;
-    if (blk_surv) { // own prefix over the blocks in front (see k_assemble)
-        const int64_t per_xcd = (n_blocks + 7) >> 3;
-        long long acc = 0;
-        for (int hb = tid; hb < b; hb += FB) {
-            const int64_t plb = remap ? (int64_t)(hb & 7) * per_xcd + (hb >> 3) : hb;
-            if (plb < n_blocks) acc += ((long long)blk_rows[plb] << 31) | (long long)blk_surv[plb];
-        }
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
-        if (lane == 0) sh_part[wave] = acc;
-        __syncthreads();
-        if (tid == 0) {
-            long long tot = 0;
-#pragma unroll
-            for (int w = 0; w < FWAVES; w++) tot += sh_part[w];
-            sh_base = tot;
-        }
-    } else if (base_nnz) {
-        if (tid == 0) sh_base = ((long long)base_rows[b] << 31) | (long long)base_nnz[b];
-    } else if (tid < 64) {
-        const long long packed = lookback_exclusive(status, b, ((long long)block_rows << 31) | (long long)block_nnz, tid, &counters->error);
-        if (tid == 0) sh_base = packed;
-    }
-    __syncthreads();
-    if (sh_base < 0) return; // aborted (the host falls back)
-    const long long base = sh_base & 0x7fffffffll, row_base = sh_base >> 31;
-    if (!base_nnz && b == n_chain - 1 && tid == 0) {
-        const long long entries = base + block_nnz, rows = row_base + block_rows;
-        counters->p_regular = (int32_t)entries; // entries of all regular rows
-        counters->rows_regular = (int32_t)rows;
-        indptr[rows] = (int32_t)entries;        // (= indptr[T] when there are no big faces)
-    }
-    if (regular) {
-        const long long r = row_base + rowidx; // stored row of the face
-        indptr[r] = (int32_t)(base + rowoff);
-        row_order[r] = q_perm ? q_perm[t] : (int32_t)t;
-        if (tile_key) {
-            const int64_t mid = (t & ~(int64_t)(tile.n_run - 1)) + tile.n_run / 2;
-            tile_key[r] = morton_key(tile, reinterpret_cast<const double4 *>(q_bbox)[mid < n_query ? mid : n_query - 1]);
-        }
-        if (my_nnz > XR_APPLY_LONG_ROW) {
-            apply_long_rows[atomicAdd(&counters->n_apply_long, 1)] = (int32_t)r;
-            atomicMax(&counters->max_row, my_nnz); // (long rows only: the apply asks whether any row exceeds its wave kernel)
-        }
-    }
-    // ---- pass 2: the rows' source ids into their lists (order of arrival)
-    for (int wc = wc0 + wave; wc <= wc1; wc += 4 * FWAVES) {
-        int n[4], row[4], sid[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int w = wc + u * FWAVES;
-            n[u] = w <= wc1 ? wave_surv[w] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t i = (int64_t)(wc + u * FWAVES) * 64 + lane;
-            row[u] = lane < n[u] ? surv_tgt[i] - (int)t0 : -1;
-            sid[u] = lane < n[u] ? surv_sid[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (row[u] >= 0 && row[u] < FB) sh_list[sh_rowoff[row[u]] + atomicAdd(&sh_cur[row[u]], 1)] = sid[u];
-    }
-    __syncthreads();
-    // ---- pass 3: rank within the row, final position
-    bool overflow_cap = false;
-    for (int wc = wc0 + wave; wc <= wc1; wc += 4 * FWAVES) {
-        int n[4], row[4], sid[4];
-        double area[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int w = wc + u * FWAVES;
-            n[u] = w <= wc1 ? wave_surv[w] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t i = (int64_t)(wc + u * FWAVES) * 64 + lane;
-            row[u] = lane < n[u] ? surv_tgt[i] - (int)t0 : -1;
-            sid[u] = lane < n[u] ? surv_sid[i] : 0;
-            area[u] = lane < n[u] ? surv_area[i] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (row[u] < 0 || row[u] >= FB) continue;
-            const int a0 = sh_rowoff[row[u]], a1 = a0 + sh_nnz[row[u]];
-            int rank = 0;
-            for (int j = a0; j < a1; j++) rank += sh_list[j] < sid[u] ? 1 : 0;
-            const long long pos = base + a0 + rank;
-            if (pos < csr_capacity) {
-                indices[pos] = sid[u];
-                data[pos] = relative ? area[u] / src_area[sid[u]] : area[u];
             } else {
                 overflow_cap = true;
             }

@@ -40,8 +40,9 @@ struct Bounds { // [0..3] min x, min y, max x, max y as keys
     unsigned long long k[4];
 };
 // centroid + box of face f of a dense (F, m) int64 connectivity with -1 fill
-__device__ __forceinline__ void face_geometry(const double *__restrict__ xy, const int64_t *__restrict__ faces, int64_t f, int m,
-                                              double &cx, double &cy, double &x0, double &y0, double &x1, double &y1) {
+// -> number of valid nodes (a face without any: centroid (0, 0), an empty box -- it takes no part in the bounds)
+__device__ __forceinline__ int face_geometry(const double *__restrict__ xy, const int64_t *__restrict__ faces, int64_t f, int m,
+                                             double &cx, double &cy, double &x0, double &y0, double &x1, double &y1) {
     double sx = 0.0, sy = 0.0;
     int n = 0;
     x0 = y0 = INFINITY;
@@ -58,6 +59,7 @@ __device__ __forceinline__ void face_geometry(const double *__restrict__ xy, con
     }
     cx = sx / (double)(n > 0 ? n : 1);
     cy = sy / (double)(n > 0 ? n : 1);
+    return n;
 }
 
 // Bounds of a set of boxes, two stages: every block reduces its boxes (waves by shuffles, the block through LDS) and writes ONE
@@ -122,13 +124,15 @@ k_shard_centroids(const double *__restrict__ sxy, const int64_t *__restrict__ sf
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool is_src = i < S, valid = i < S + T;
     double cx = 0, cy = 0, x0, y0, x1, y1;
-    if (is_src) face_geometry(sxy, sf, i, ms, cx, cy, x0, y0, x1, y1);
-    else if (valid) face_geometry(txy, tf, i - S, mt, cx, cy, x0, y0, x1, y1);
+    int n_nodes = 0;
+    if (is_src) n_nodes = face_geometry(sxy, sf, i, ms, cx, cy, x0, y0, x1, y1);
+    else if (valid) n_nodes = face_geometry(txy, tf, i - S, mt, cx, cy, x0, y0, x1, y1);
     if (is_src) scen[i] = make_double2(cx, cy);
     else if (valid) tcen[i - S] = make_double2(cx, cy);
-    // (a block holds faces of one mesh except the one straddling S: the two reductions are masked per mesh)
-    bounds_block_partial(partial, is_src, cx, cy, cx, cy);
-    bounds_block_partial(partial + gridDim.x, valid && !is_src, cx, cy, cx, cy);
+    // (a block holds faces of one mesh except the one straddling S: the two reductions are masked per mesh; a face without a
+    // valid node has no centroid -- its (0, 0) must not stretch the bounds the Morton cells are cut from)
+    bounds_block_partial(partial, is_src && n_nodes > 0, cx, cy, cx, cy);
+    bounds_block_partial(partial + gridDim.x, valid && !is_src && n_nodes > 0, cx, cy, cx, cy);
 }
 
 __device__ __forceinline__ int raster_cell(double v, double lo, double f, int n) {
@@ -180,7 +184,9 @@ k_shard_work(const double2 *__restrict__ scen, int64_t S, const Bounds *__restri
         const int cell = raster_cell(c.y, loy, fy, n_grid) * n_grid + raster_cell(c.x, lox, fx, n_grid);
         const int ns = n_src[cell] > 0 ? n_src[cell] : 1;
         const double cost = (1.0 + 4.0 * (double)n_tgt[cell] / (double)ns) * 4096.0;
-        const double r = rint(cost);
+        // (clamped to 2^20 per face -- 63 target faces per source face of the cell --: with S < 2^31 faces the total stays below
+        // 2^51 and `before * world` in k_shard_owner below 2^63 for world <= 4096, which xr_shard_plan_dev requires)
+        const double r = fmin(rint(cost), 1048576.0);
         w = r >= 1.0 ? (unsigned long long)r : 1ull;
     }
     atomicAdd(&cell_work[mc], w);
@@ -250,7 +256,7 @@ k_shard_owner(int64_t S, const int32_t *__restrict__ mcell, const unsigned long 
         o = (int)(i % world);
     } else {
         const unsigned long long t = *total > 0 ? *total : 1ull;
-        const unsigned long long q = before[mcell[i]] * (unsigned long long)world / t; // (work < 2^40, world < 2^16: no overflow)
+        const unsigned long long q = before[mcell[i]] * (unsigned long long)world / t; // (work < 2^51 by the clamp above, world <= 2^12: no overflow)
         o = q < (unsigned long long)world ? (int)q : world - 1;
     }
     flag[i] = o == rank ? 1 : 0;
@@ -368,7 +374,7 @@ int xr_shard_plan_dev(const double *src_xy_dev, const int64_t *src_faces_dev, in
     XR_API_BEGIN
     const int64_t S = n_src_face, T = n_tgt_face;
     XR_REQUIRE(S >= 0 && T >= 0 && src_m >= 1 && tgt_m >= 1, XR_ERR_INVALID, "xr_shard_plan_dev: bad sizes");
-    XR_REQUIRE(world >= 1 && world < 65536 && rank >= 0 && rank < world, XR_ERR_INVALID, "xr_shard_plan_dev: rank %d of %d", rank, world);
+    XR_REQUIRE(world >= 1 && world <= 4096 && rank >= 0 && rank < world, XR_ERR_INVALID, "xr_shard_plan_dev: rank %d of %d (at most 4096 ranks)", rank, world);
     XR_REQUIRE(mode >= 0 && mode <= 2, XR_ERR_INVALID, "xr_shard_plan_dev: mode %d (0 hash, 1 morton, 2 balanced)", mode);
     XR_REQUIRE(n_local_faces && n_local_targets, XR_ERR_INVALID, "xr_shard_plan_dev: NULL argument");
     XR_REQUIRE((S == 0 || (src_xy_dev && src_faces_dev && local_faces_dev)) && (T == 0 || (tgt_xy_dev && tgt_faces_dev && local_targets_dev)),

@@ -656,7 +656,7 @@ static void voronoi_boundary_cells(xr_voronoi *v) {
                 }
     }
     const auto tk3 = std::chrono::steady_clock::now();
-    if (getenv("XR_DEBUG_VORONOI"))
+    if (option(OPT_DEBUG) & 4)
         fprintf(stderr, "[voronoi] records %lld: set-up %.3f, sort %.3f, cells + convexity %.3f ms\n", (long long)n_rec,
                 std::chrono::duration<double, std::milli>(tk1 - tk0).count(), std::chrono::duration<double, std::milli>(tk2 - tk1).count(),
                 std::chrono::duration<double, std::milli>(tk3 - tk2).count());
@@ -900,7 +900,7 @@ int xr_voronoi_mesh(const xr_voronoi *v, const double *extra_xy, int64_t n_extra
 int xr_voronoi_mesh_auto(xr_voronoi *v, xr_mesh **out, int64_t *n_tail, int64_t *n_map) {
     XR_API_BEGIN
     XR_REQUIRE(v && out && n_tail && n_map, XR_ERR_INVALID, "xr_voronoi_mesh_auto: NULL argument");
-    const bool dbg = getenv("XR_DEBUG_VORONOI") != nullptr;
+    const bool dbg = (option(OPT_DEBUG) & 4) != 0;
     const auto t0 = std::chrono::steady_clock::now();
     voronoi_boundary(v);
     const auto t1 = std::chrono::steady_clock::now();

@@ -402,17 +402,27 @@ def _method(method):
     return table[method], method in RELATIVE_OVERLAP_METHODS
 
 
-def shard_lists(full, world, rank, partition="balanced", backend=None):
+def shard_lists(full, world, rank, partition="balanced", backend=None, rule="auto"):
     """(sxy, sfa, txy, tfa) tensors of the replicated meshes -> (global ids of rank's source faces, global ids of the
     target faces it can give weight to), both ascending, on the tensors' device.  Every rank computes the same owner
     array (exact integer arithmetic), so the shards are disjoint and complete without communication.
 
-    A backend with ``shard_plan`` (the HIP backend: ``xr_shard_plan_dev``, a dozen O(S + T) kernels) evaluates ITS rule --
-    Morton cells instead of a sort of the faces, see include/xugrid_amd.h -- on the device; the torch rule below serves the
-    other backends (CPU tests).  The two cut the curve at slightly different faces; within one job every rank uses the same."""
+    TWO rules implement ``partition``, and they cut the Morton curve at slightly different faces:
+      "engine"  ``backend.shard_plan`` (the HIP backend: ``xr_shard_plan_dev``, a dozen O(S + T) kernels) -- Morton CELLS of
+                the source centroids' bounding square (all faces of a cell share an owner), 128 x 128 occupancy filter;
+      "torch"   the rule below -- a cut per FACE along the sorted curve -- for backends without the engine (CPU tests).
+    ``rule="auto"`` takes the engine's where the backend has it.  The lists a regridder WORKS with are the ones it
+    publishes (``ShardedOverlapRegridder.local_faces`` / ``.local_targets`` / ``.partition_rule``): code that needs a
+    rank's ids -- to slice ``local_source``, to write shard files -- must take them from there, or call this function
+    with the same backend AND the rule the regridder reports; recomputing them with another backend gives another cut."""
     import torch
 
-    if backend is not None and hasattr(backend, "shard_plan") and partition in ("hash", "morton", "balanced"):
+    has_engine_rule = backend is not None and hasattr(backend, "shard_plan") and partition in ("hash", "morton", "balanced")
+    if rule not in ("auto", "engine", "torch"):
+        raise ValueError(f"unknown partition rule {rule!r}")
+    if rule == "engine" and not has_engine_rule:
+        raise ValueError("rule='engine' needs a backend with shard_plan (the HIP backend)")
+    if has_engine_rule and rule != "torch":
         return backend.shard_plan(full, world, rank, partition)
     sxy, sfa, txy, tfa = full
     cen = _centroids_t(sxy, sfa)
@@ -485,6 +495,8 @@ class ShardedOverlapRegridder:
 
         sxy, sfa, txy, tfa = self._full
         local_faces, local_targets = shard_lists(self._full, self.world, self.rank, self.partition, self.backend)
+        # which of shard_lists' two rules produced the lists (anyone recomputing them must ask for the same one)
+        self.partition_rule = "engine" if hasattr(self.backend, "shard_plan") and self.partition in ("hash", "morton", "balanced") else "torch"
         sfa_local = sfa[local_faces]
         self._local_faces_t, self._local_targets_t = local_faces, local_targets
         self._local_np = [None, None]

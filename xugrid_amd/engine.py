@@ -58,6 +58,35 @@ def set_async(on=True):
     check(_lib.load().xr_set_async(1 if on else 0))
 
 
+def set_option(name, value):
+    """A run-time option of the library (include/xugrid_amd.h: xr_set_option; the table is DESIGN.md section 8).  Options start
+    from the environment (``XR_<NAME>``, read once); tests and measurement scripts change them here.  -> the previous value."""
+    previous = get_option(name)
+    check(_lib.load().xr_set_option(name.encode(), int(value)))
+    return previous
+
+
+def get_option(name):
+    value = ctypes.c_int64()
+    check(_lib.load().xr_get_option(name.encode(), ctypes.byref(value)))
+    return int(value.value)
+
+
+class option:
+    """``with engine.option("overlap_fused", 0): ...`` -- an option changed for the block, restored behind it."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.previous = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.previous)
+        return False
+
+
 def _as_xy(vertices):
     xy = np.ascontiguousarray(vertices, dtype=np.float64)
     if xy.ndim != 2 or xy.shape[1] != 2:
@@ -416,7 +445,9 @@ def replace_interpolated_weights(vertices, faces, face_index, weights, node_to_n
 
 class DevicePoints:
     """Query points of a barycentric construction and their "inside the source grid" flags, in HBM
-    (include/xugrid_amd.h: xr_locate_flags_begin).  Creating one ENQUEUES the source-side kernels and returns at once."""
+    (include/xugrid_amd.h: xr_locate_flags_begin).  The source-side kernels are deferred: the engine enqueues them when the
+    Voronoi pre-step or the construction that consumes the handle next has the device to spare.  The handle keeps BOTH
+    meshes alive until then."""
 
     def __init__(self, source: DeviceMesh, query: DeviceMesh = None, points=None):
         if (query is None) == (points is None):
@@ -430,7 +461,8 @@ class DevicePoints:
             check(_lib.load().xr_locate_flags_begin(source._h, query._h, None, 0, ctypes.byref(handle)))
             self.n = query.n_face
         self._h = handle
-        self._source = source  # (keeps the mesh alive as long as its flags)
+        self._source = source  # (the deferred kernels read both meshes: they live as long as the handle)
+        self._query = query
 
     def __del__(self):
         h = getattr(self, "_h", None)

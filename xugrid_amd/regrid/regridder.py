@@ -128,7 +128,11 @@ class BaseRegridder(abc.ABC):
         if self._method is None:
             w = self._ensure_host_weights()
             if isinstance(w, MatrixCOO):
-                w = w.to_csr()
+                # (converted once per weight matrix, not per call)
+                cached = getattr(self, "_custom_csr", None)
+                if cached is None or cached[0] is not w:
+                    cached = self._custom_csr = (w, w.to_csr())
+                w = cached[1]
             if w.n != size:
                 raise ValueError(f"the weights have {w.n} rows, the target grid {size} cells")
             return self._custom(np.asarray(source, dtype=np.float64), w, size)

@@ -85,7 +85,9 @@ class Ugrid2d:
         return self._node_y
 
     # plain attributes in the reference (ugrid2d.py:86-87): assigning new coordinates is legal there.  Here the interleaved
-    # buffer is what the device sees, so an assignment rebuilds it and drops everything derived from the old coordinates.
+    # buffer is what the device sees, so an assignment rebuilds it and drops everything derived from the old coordinates
+    # that THIS grid holds.  Regridders and UnstructuredGrid2d wrappers already built from the grid keep the weights they
+    # computed from the old coordinates, as in the reference: build new ones.
     @node_x.setter
     def node_x(self, value):
         self._set_node_axis(0, value)
@@ -132,12 +134,11 @@ class Ugrid2d:
 
     @property
     def node_coordinates(self):
-        """(n_node, 2).  The reference returns a fresh ``column_stack`` per call (ugridbase.py:576-579); here it is a READ-ONLY
-        view of the grid's own buffer (the one the device mesh is uploaded from): an in-place modification raises instead of
-        silently leaving the device copy and the cached ``node_x`` / ``node_y`` stale.  Copy it to get a writable array."""
-        view = self._node_xy.view()
-        view.flags.writeable = False
-        return view
+        """(n_node, 2), a FRESH array per call as in the reference (``column_stack``, ugridbase.py:576-579): writing into it
+        changes neither the grid nor its device copy -- assign ``node_x`` / ``node_y`` for that (the setters drop what was
+        derived from the old coordinates).  Until round 5 this was a read-only view of the grid's own buffer; reference-style
+        code that edits the returned array in place raised on it."""
+        return self._node_xy.copy()
 
     @property
     def bounds(self):
@@ -336,6 +337,7 @@ class RectilinearUgrid2d(Ugrid2d):
     node_x = property(lambda self: self._materialise().node_x)
     node_y = property(lambda self: self._materialise().node_y)
     node_coordinates = property(lambda self: self._materialise().node_coordinates)
+    _node_xy = property(lambda self: self._materialise()._node_xy)
     face_node_connectivity = property(lambda self: self._materialise().face_node_connectivity)
 
     @property
