@@ -318,6 +318,40 @@ def run_single(args):
                 split.setdefault(k, []).append(1e3 * v)
         return t[-1] - t[0], (src_g, tgt_g, rg, res)
 
+    # ... and the same classes on arrays that already live in HBM (round 6): Ugrid2d.from_device_arrays x 2 + OverlapRegridder +
+    # regrid(device array) -> device array.  Nothing crosses PCIe; the regridder's weights are built by its first regrid in one
+    # engine call with the apply (xr_overlap_apply_dev, the entry point of the timed step); mesh validation + int64 -> int32
+    # narrowing of both connectivities and the result's allocation are inside.
+    def api_device_once(dev_arrays, split=None):
+        d_sxy, d_sf, d_txy, d_tf, d_data = dev_arrays
+        t = [time.perf_counter()]
+        src_g = xa.Ugrid2d.from_device_arrays(d_sxy, d_sf)
+        tgt_g = xa.Ugrid2d.from_device_arrays(d_txy, d_tf)
+        t.append(time.perf_counter())
+        rg = xa.OverlapRegridder(src_g, tgt_g, method="mean")
+        t.append(time.perf_counter())
+        res = rg.regrid(d_data)  # (returns with the result complete)
+        t.append(time.perf_counter())
+        if split is not None:
+            for k, v in zip(("device_grids", "constructor", "regrid_weights_and_apply"), np.diff(t)):
+                split.setdefault(k, []).append(1e3 * v)
+        return t[-1] - t[0], (src_g, tgt_g, rg, res)
+
+    api_device_ms, api_device_phases, api_device_equal = None, {}, None
+    if not args.step_only:
+        dev_arrays = tuple(E.DeviceArray.from_host(a) for a in (sxy, sf, txy, tf, data))
+        times, split, keep_d = [], {}, None
+        for i in range(9):
+            del keep_d
+            E.dev_sync()
+            dt, keep_d = api_device_once(dev_arrays, split if i >= 6 else None)
+            if i < 6:
+                times.append(dt)
+        api_device_ms = 1e3 * float(np.median(times[1:]))
+        api_device_phases = {k: round(float(np.median(v)), 4) for k, v in split.items()}
+        api_device_result = keep_d[3].download()
+        del keep_d, dev_arrays
+
     api_times, keep = [], None
     for _ in range(0 if args.step_only else 6):
         del keep
@@ -330,6 +364,9 @@ def run_single(args):
         del keep
         E.dev_sync()
         _, keep = api_once(api_split)
+    if keep is not None and api_device_ms is not None:
+        api_device_equal = bool(np.array_equal(api_device_result, keep[3], equal_nan=True))
+        del api_device_result
     del keep
     api_phases = {k: round(float(np.median(v)), 4) for k, v in api_split.items()}
 
@@ -490,6 +527,11 @@ def run_single(args):
             "copied into the pinned staging buffers) + weights + apply + download of the result vector over PCIe, median of 5; "
             "not part of `value`",
             "api_ms": api_ms,
+            "api_device_ms": api_device_ms,
+            "api_device_phases_ms": api_device_phases,
+            "api_device_note": "the same classes on HBM-resident arrays: Ugrid2d.from_device_arrays x 2 + OverlapRegridder + regrid(device "
+                               "array) -> device array; weights + apply in one engine call; equal to the host-array result: "
+                               + str(api_device_equal),
             "api_phases_ms": api_phases,
             "api_note": "xa.OverlapRegridder(xa.Ugrid2d(x, y, -1, faces), xa.Ugrid2d(...), method='mean').regrid(data): host arrays "
             "in, host result out, through the reference-shaped Python classes; median of 5 after a warm-up.  api_phases_ms "

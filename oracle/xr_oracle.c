@@ -782,7 +782,7 @@ static int sat_intersect(const P2 *a, int na, const P2 *b, int nb) {
 
 /* ---- Sutherland-Hodgman clip of `subject` (query polygon) by convex CCW `clipper` (tree
  * polygon) followed by the fan area of the clipped polygon.  THE reference arithmetic for
- * the HIP kernel (xugrid_amd/csrc/xr_clip.hip.h mirrors it operation for operation). ---- */
+ * the HIP kernels (xugrid_amd/csrc/xr_clip_tri.h and the clip kernels of xr_overlap.hip mirror it operation for operation). ---- */
 static inline int sh_inside(P2 p, P2 r, P2 U) { return U.x * (p.y - r.y) > U.y * (p.x - r.x); }
 
 static inline int sh_intersection(P2 a, P2 V, P2 r, P2 N, P2 *out) {

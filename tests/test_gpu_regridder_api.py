@@ -283,6 +283,81 @@ def test_barycentric_device_pipeline(hip, oracle, kind):
     assert np.array_equal(d2, data) and np.array_equal(i2, indices) and np.array_equal(p2, indptr)
 
 
+def test_device_arrays_in_and_out_equal_the_host_path(hip, oracle):
+    """Round 6: the reference-shaped classes reach data that already lives in HBM.  ``Ugrid2d.from_device_arrays`` + ``regrid`` of
+    a device array (here the engine's own ``DeviceArray`` through ``__cuda_array_interface__``; torch tensors: the next test)
+    give bit for bit what host arrays give (regridder.py:102-113, :212-262); the weights of a regridder between two device
+    grids are built by its first ``regrid`` in one engine call with the apply (xr_overlap_apply_dev); the result stays on the
+    device."""
+    from xugrid_amd import engine
+
+    sxy, sf = meshgen.triangle_mesh(6000, 51)
+    txy, tf = meshgen.triangle_mesh(5000, 52, 30.0, 0.8)
+    src_h = xa.Ugrid2d(sxy[:, 0], sxy[:, 1], -1, sf)
+    tgt_h = xa.Ugrid2d(txy[:, 0], txy[:, 1], -1, tf)
+    rng = np.random.default_rng(1)
+    data = rng.normal(size=(3, sf.shape[0]))
+    data[1, ::11] = np.nan
+    t = engine.DeviceArray.from_host
+    src_d = xa.Ugrid2d.from_device_arrays(t(sxy), t(sf))
+    tgt_d = xa.Ugrid2d.from_device_arrays(t(txy), t(tf.astype(np.int32)))  # (int32 connectivity is taken as it is)
+    assert (src_d.n_node, src_d.n_face, src_d.n_max_node_per_face) == (sxy.shape[0], sf.shape[0], 3)
+    for cls, kwargs in ((xa.OverlapRegridder, {"method": "mean"}), (xa.OverlapRegridder, {"method": "maximum"}),
+                        (xa.OverlapRegridder, {"method": "median"}), (xa.RelativeOverlapRegridder, {}),
+                        (xa.CentroidLocatorRegridder, {}), (xa.BarycentricInterpolator, {})):
+        expected = cls(src_h, tgt_h, **kwargs).regrid(data)
+        rg = cls(src_d, tgt_d, **kwargs)
+        if cls in (xa.OverlapRegridder, xa.RelativeOverlapRegridder):
+            assert rg._device_weights is None and rg._deferred is not None  # built by the first regrid
+        got = rg.regrid(t(data))
+        assert isinstance(got, engine.DeviceArray) and got.dtype == np.float64 and got.shape == expected.shape
+        assert same_or_nan(got.download(), expected).all(), cls.__name__
+        assert rg._device_weights is not None
+        # again (cached weights now), one variable, float32, host data on device grids
+        one = rg.regrid(t(data[0]))
+        assert one.shape == (tf.shape[0],) and same_or_nan(one.download(), expected[0]).all()
+        d32 = data.astype(np.float32)
+        assert same_or_nan(rg.regrid(t(d32)).download(), cls(src_h, tgt_h, **kwargs).regrid(d32)).all()
+        assert same_or_nan(rg.regrid(data), expected).all()
+        # extra leading dims are flattened and restored (regridder.py:145-163, :193-195)
+        stacked = rg.regrid(t(np.stack([data, data[::-1]])))
+        assert stacked.shape == (2, 3, tf.shape[0]) and same_or_nan(stacked.download()[1], expected[::-1]).all()
+    # a deferred regridder asked for its weights first builds them on its own
+    rg = xa.OverlapRegridder(src_d, tgt_d)
+    w = rg._ensure_host_weights()
+    wh = xa.OverlapRegridder(src_h, tgt_h)._ensure_host_weights()
+    assert np.array_equal(w.data, wh.data) and np.array_equal(w.indices, wh.indices) and np.array_equal(w.indptr, wh.indptr)
+    # the host view of a device grid is a download
+    assert np.array_equal(src_d.node_coordinates, sxy) and np.array_equal(src_d.face_node_connectivity, sf)
+    # a device grid paired with a host grid or a raster (no deferral then)
+    mixed = xa.OverlapRegridder(src_d, tgt_h).regrid(t(data))
+    assert same_or_nan(mixed.download(), xa.OverlapRegridder(src_h, tgt_h).regrid(data)).all()
+    raster = xa.Raster(x=np.linspace(0.2, 0.8, 30), y=np.linspace(0.8, 0.2, 25))
+    assert same_or_nan(xa.OverlapRegridder(src_d, raster).regrid(t(data)).download(), xa.OverlapRegridder(src_h, raster).regrid(data)).all()
+    # errors of the host path, on device data
+    with pytest.raises(ValueError):
+        rg.regrid(t(data[:, :-1].copy()))
+    with pytest.raises(TypeError):
+        rg.regrid(t(np.arange(sf.shape[0])))
+    with pytest.raises(ValueError):
+        xa.Ugrid2d.from_device_arrays(t(sxy.astype(np.float32)), t(sf))
+    with pytest.raises(TypeError):
+        xa.Ugrid2d.from_device_arrays(sxy, sf)
+
+
+def test_torch_tensors_in_and_out(tmp_path):
+    """... and with torch tensors on the GPU: tensors in, a tensor out, equal to the numpy path.  torch has to initialise its HIP
+    runtime BEFORE the engine binds the device, so this runs in a process of its own (tests/device_api_worker_gpu.py)."""
+    import os
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "device_api_worker_gpu.py")
+    res = subprocess.run([sys.executable, worker], capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    assert "TORCH_DEVICE_API_OK" in res.stdout
+
+
 def test_deferred_points_survive_invalidate_and_release_of_their_meshes(hip):
     """xr_locate_flags_begin defers its kernels (round 5); the handle keeps raw mesh pointers.  A source mesh INVALIDATED and a
     query mesh released between the handle's creation and its use must not change the result: xr_mesh_invalidate /

@@ -87,6 +87,119 @@ class option:
         return False
 
 
+# ---- arrays that already live in HBM -----------------------------------------------------------------------------------------
+_DEV_TYPESTR = {"<f8": np.float64, "<f4": np.float32, "<i8": np.int64, "<i4": np.int32}
+
+
+def device_array_info(obj):
+    """-> (device pointer, shape, numpy dtype) if ``obj`` is a C-contiguous array in device memory -- a torch tensor on the GPU,
+    or anything with ``__cuda_array_interface__`` (cupy, numba, ``DeviceArray``; on ROCm the interface carries HIP pointers) --
+    else None.  Device arrays that are not contiguous, or of another dtype than float64 / float32 / int64 / int32, raise."""
+    if isinstance(obj, np.ndarray):
+        return None
+    if (type(obj).__module__ or "").startswith("torch"):
+        if not getattr(obj, "is_cuda", False):
+            return None
+        if not obj.is_contiguous():
+            raise ValueError("device arrays must be C-contiguous")
+        name = str(obj.dtype).replace("torch.", "")
+        table = {"float64": np.float64, "float32": np.float32, "int64": np.int64, "int32": np.int32}
+        if name not in table:
+            raise TypeError(f"unsupported device dtype {obj.dtype}")
+        return int(obj.data_ptr()), tuple(int(n) for n in obj.shape), np.dtype(table[name])
+    try:
+        cai = getattr(obj, "__cuda_array_interface__", None)
+    except Exception:  # noqa: BLE001  (objects that raise for host data)
+        cai = None
+    if not isinstance(cai, dict):
+        return None
+    shape = tuple(int(n) for n in cai["shape"])
+    typestr = cai["typestr"].replace("=", "<")
+    if typestr not in _DEV_TYPESTR:
+        raise TypeError(f"unsupported device dtype {cai['typestr']}")
+    dtype = np.dtype(_DEV_TYPESTR[typestr])
+    strides = cai.get("strides")
+    if strides is not None:
+        expect, acc = [], dtype.itemsize
+        for n in reversed(shape):
+            expect.append(acc)
+            acc *= max(n, 1)
+        if tuple(strides) != tuple(reversed(expect)):
+            raise ValueError("device arrays must be C-contiguous")
+    return int(cai["data"][0]), shape, dtype
+
+
+class DeviceArray:
+    """An array in the engine's HBM (xr_dev_alloc): what ``Regridder.regrid`` returns for device input that is not a torch
+    tensor, and a way to put host arrays there once.  Exposes ``__cuda_array_interface__`` (version 3), so torch / cupy can wrap
+    it without a copy; ``download()`` -> numpy."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self.shape = tuple(int(n) for n in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        handle = ctypes.c_void_p()
+        check(_lib.load().xr_dev_alloc(max(self.nbytes, 1), ctypes.byref(handle)))
+        self._h = handle
+        self.ptr = int(handle.value or 0)
+
+    @classmethod
+    def from_host(cls, array):
+        a = np.ascontiguousarray(array)
+        out = cls(a.shape, a.dtype)
+        if a.nbytes:
+            check(_lib.load().xr_dev_upload(out._h, a.ctypes.data_as(ctypes.c_void_p), a.nbytes))
+        return out
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 3, "strides": None}
+
+    def reshape(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if int(np.prod(shape, dtype=np.int64)) * self.dtype.itemsize != self.nbytes:
+            raise ValueError("cannot reshape a device array to another size")
+        view = object.__new__(DeviceArray)
+        view.shape, view.dtype, view.nbytes, view.ptr, view._h, view._base = tuple(int(n) for n in shape), self.dtype, self.nbytes, self.ptr, None, self
+        return view
+
+    def download(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(_lib.load().xr_dev_download(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                _lib.load().xr_dev_free(h)
+            except Exception:  # noqa: BLE001
+                pass
+            self._h = None
+
+
+def empty_like_device(like, shape, dtype=np.float64):
+    """A fresh device array of ``shape`` of the same KIND as ``like``: a torch tensor on ``like``'s device for a torch tensor,
+    a ``DeviceArray`` otherwise.  -> (array, device pointer)"""
+    if (type(like).__module__ or "").startswith("torch"):
+        import torch
+
+        out = torch.empty(tuple(shape), dtype=getattr(torch, np.dtype(dtype).name), device=like.device)
+        return out, int(out.data_ptr())
+    out = DeviceArray(shape, dtype)
+    return out, out.ptr
+
+
+def sync_producer(obj):
+    """Device input handed over by another library was written on ITS stream; the engine reads it on its own.  For torch
+    tensors the current torch stream is drained first (a no-op when the engine runs on that very stream, xr_set_stream)."""
+    if (type(obj).__module__ or "").startswith("torch"):
+        import torch
+
+        torch.cuda.current_stream(obj.device).synchronize()
+
+
 def _as_xy(vertices):
     xy = np.ascontiguousarray(vertices, dtype=np.float64)
     if xy.ndim != 2 or xy.shape[1] != 2:

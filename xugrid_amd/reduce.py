@@ -5,7 +5,9 @@ the reducer ids of the HIP apply kernels (include/xugrid_amd.h, xugrid_amd/csrc/
 The reference hands Python functions ``f(values, weights, workspace)`` to numba; here a method
 is a small descriptor ``Method(name, method_id, percentile)`` that selects a kernel
 specialisation.  Arbitrary Python callables (a numba feature, examples/overlap_regridder.py:105-169)
-cannot run on the device and are rejected with a TypeError -- there is no CPU fallback.
+cannot run on the device: they are the caller's own host code and run on the host over the engine's
+weights, in the loop of make_regrid (regrid/regridder.py: _make_host_regrid).  No BUILT-IN reducer has a
+host path -- there is no CPU fallback.
 """
 from typing import NamedTuple
 

@@ -22,7 +22,7 @@ import numpy as np
 from .. import engine
 from ..reduce import ABSOLUTE_OVERLAP_METHODS, RELATIVE_OVERLAP_METHODS, Method, create_percentile_method
 from ..sparse import MatrixCOO, MatrixCSR
-from ..ugrid2d import Ugrid2d
+from ..ugrid2d import DeviceUgrid2d, Ugrid2d
 from . import persist
 from .structured import Raster, StructuredGrid2d
 from .unstructured import UnstructuredGrid2d
@@ -159,16 +159,62 @@ class BaseRegridder(abc.ABC):
         out = self._regrid(source, size)
         return out.reshape(first_dims_shape + self._target.shape)
 
+    def _regrid_device(self, data, info):
+        """``_regrid_array`` for data that already lives in HBM (a torch tensor on the GPU, anything with
+        ``__cuda_array_interface__``): same layout contract (regridder.py:143-195 -- the spatial dims last, the leading ones
+        flattened to K), device pointers straight into the apply kernels, and a result of the same kind on the device: nothing
+        crosses PCIe.  The first call of a regridder whose weights are still deferred (device grids, see ``_compute_overlap``)
+        builds them in the same engine call (xr_overlap_apply_dev)."""
+        ptr, shape, dtype = info
+        if getattr(self, "_method", True) is None:
+            raise TypeError("a custom Python reduction runs on the host: pass host arrays")
+        if dtype not in (np.dtype(np.float64), np.dtype(np.float32)):
+            raise TypeError(f"device data must be float64 or float32, received {dtype}")
+        source_grid = self._source
+        nd = source_grid.ndim
+        if len(shape) < nd or tuple(shape[len(shape) - nd:]) != tuple(source_grid.shape):
+            raise ValueError(
+                f"data does not contain regridder source dimensions: trailing shape {source_grid.shape} expected, "
+                f"received {tuple(shape)}"
+            )
+        first_dims_shape = tuple(shape[: len(shape) - nd])
+        K = int(np.prod(first_dims_shape, dtype=np.int64)) if first_dims_shape else 1
+        out, out_ptr = engine.empty_like_device(data, first_dims_shape + tuple(self._target.shape), np.float64)
+        engine.sync_producer(data)
+        dtype_id = engine.XR_F64 if dtype == np.dtype(np.float64) else engine.XR_F32
+        method_id, percentile = self._apply_method()
+        deferred = getattr(self, "_deferred", None)
+        if self._device_weights is None and deferred is not None:
+            source, target, relative = deferred
+            self._device_weights = source.ugrid_topology.device_mesh.overlap_apply_dev(
+                target.ugrid_topology.device_mesh, ptr, dtype_id, K, out_ptr, method_id, percentile, relative=relative)
+            self._deferred = None
+        else:
+            weights = self._ensure_device_weights()
+            rows = getattr(weights, "n", self._target.size)
+            if rows != self._target.size:
+                raise ValueError(f"the weights have {rows} rows, the target grid {self._target.size} cells")
+            weights.apply_dev(ptr, dtype_id, K, out_ptr, method_id, percentile)
+        engine.dev_sync()  # (the result is complete when the call returns, whatever stream its consumer uses)
+        return out
+
+    def _apply_method(self):
+        return self._method.method_id, self._method.percentile
+
     def regrid(self, data):
         """
         Regrid ``data`` from the source topology to the target topology; additional leading
         dimensions (time, layer ...) are regridded in one batched device call.
 
-        data: np.ndarray ``(..., n_face)`` / ``(..., ny, nx)``, or an object exposing ``.values``
-        (e.g. an xarray.DataArray, whose dims must end with the source dims).
+        data: np.ndarray ``(..., n_face)`` / ``(..., ny, nx)``, an object exposing ``.values``
+        (e.g. an xarray.DataArray, whose dims must end with the source dims), or an array that already lives on the
+        device (torch tensor on the GPU / ``__cuda_array_interface__``): the result then stays there too.
         """
         if isinstance(data, np.ndarray):
             return self._regrid_array(data)
+        info = engine.device_array_info(data)
+        if info is not None:
+            return self._regrid_device(data, info)
         if hasattr(data, "values") and hasattr(data, "dims"):
             values = np.asarray(data.values)
             dims = tuple(data.dims)
@@ -203,8 +249,16 @@ class BaseRegridder(abc.ABC):
         return (dims[-1],) if dims else ()
 
     # ---- weights access / persistence (regridder.py:264-361)
+    def _build_deferred(self):
+        deferred = getattr(self, "_deferred", None)
+        if self._device_weights is None and deferred is not None:
+            source, target, relative = deferred
+            self._device_weights = source.overlap_device(target, relative=relative)
+            self._deferred = None
+
     def _ensure_host_weights(self):
         if self._weights is None:
+            self._build_deferred()
             if self._device_weights is None:
                 raise ValueError("Weights have not been computed yet.")
             data, indices, indptr = self._device_weights.download()
@@ -213,6 +267,7 @@ class BaseRegridder(abc.ABC):
         return self._weights
 
     def _ensure_device_weights(self):
+        self._build_deferred()
         if self._device_weights is None:
             w = self._weights
             if w is None:
@@ -393,6 +448,9 @@ class CentroidLocatorRegridder(BaseRegridder):
         self._device_weights = source.locate_centroids_device(target, tolerance)
         self._weights = None
 
+    def _apply_method(self):
+        return engine.METHOD_IDS["select"], 0.0
+
     def _regrid(self, source, size):
         A = self._weights
         if self._device_weights is None and A is not None and A.row.size and (np.diff(A.row) < 0).any():
@@ -433,8 +491,17 @@ class CentroidLocatorRegridder(BaseRegridder):
 class BaseOverlapRegridder(BaseRegridder, abc.ABC):
     def _compute_overlap(self, source, target, relative: bool) -> None:
         source, target = convert_to_match(source, target)
-        self._device_weights = source.overlap_device(target, relative=relative)
         self._weights = None
+        if isinstance(source.ugrid_topology, DeviceUgrid2d) and isinstance(target.ugrid_topology, DeviceUgrid2d):
+            # Both grids were made from device arrays: a pipeline that keeps its data in HBM.  The weights are built by the
+            # first call that needs them -- ``regrid`` of device data does it in ONE engine call with the apply
+            # (xr_overlap_apply_dev: the apply rides on the construction, the step bench.py times); ``weights``,
+            # ``to_dataset`` or host data build them on their own.  (The reference builds in the constructor,
+            # regridder.py:428-436; what is computed is the same.)
+            self._device_weights = None
+            self._deferred = (source, target, relative)
+            return
+        self._device_weights = source.overlap_device(target, relative=relative)
 
     @classmethod
     def _weights_from_dataset(cls, dataset) -> MatrixCSR:

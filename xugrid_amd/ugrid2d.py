@@ -295,6 +295,16 @@ class Ugrid2d:
         }
 
     @staticmethod
+    def from_device_arrays(node_coordinates, face_node_connectivity, fill_value=FILL_VALUE, name="mesh2d"):
+        """A grid whose arrays ALREADY live in HBM: ``node_coordinates`` float64 ``(n_node, 2)`` and ``face_node_connectivity``
+        int64 / int32 ``(n_face, n_max_node_per_face)`` as torch tensors on the GPU or anything with ``__cuda_array_interface__``
+        (cupy, numba, ``engine.DeviceArray``).  Nothing crosses PCIe: the device mesh is made from the pointers
+        (xr_mesh_create_dev validates and copies), the host arrays of the base class are downloaded only if somebody reads
+        them.  (The reference has host grids only, ugrid2d.py:72-110; this is how its classes reach data a GPU pipeline
+        already holds.)"""
+        return DeviceUgrid2d(node_coordinates, face_node_connectivity, fill_value, name)
+
+    @staticmethod
     def from_dataset(dataset, name):
         return Ugrid2d(
             np.asarray(dataset[f"{name}_node_x"]),
@@ -368,3 +378,64 @@ class RectilinearUgrid2d(Ugrid2d):
 
             self._celltree = CellTree2d.from_device_mesh(DeviceMesh.from_rectilinear(self._xv, self._yv))
         return self._celltree
+
+
+class DeviceUgrid2d(Ugrid2d):
+    """``Ugrid2d.from_device_arrays``: the mesh exists on the device; host copies are made lazily (see RectilinearUgrid2d)."""
+
+    def __init__(self, node_coordinates, face_node_connectivity, fill_value=FILL_VALUE, name="mesh2d"):
+        from . import engine
+
+        xy = engine.device_array_info(node_coordinates)
+        faces = engine.device_array_info(face_node_connectivity)
+        if xy is None or faces is None:
+            raise TypeError("from_device_arrays expects device arrays (torch tensors on the GPU or __cuda_array_interface__)")
+        (xy_ptr, xy_shape, xy_dtype), (f_ptr, f_shape, f_dtype) = xy, faces
+        if len(xy_shape) != 2 or xy_shape[1] != 2 or xy_dtype != np.float64:
+            raise ValueError("node_coordinates must be a float64 (n_node, 2) device array")
+        if len(f_shape) != 2 or f_dtype not in (np.dtype(np.int64), np.dtype(np.int32)):
+            raise ValueError("face_node_connectivity must be an int64 / int32 (n_face, n_max_node_per_face) device array")
+        engine.sync_producer(node_coordinates)
+        engine.sync_producer(face_node_connectivity)
+        mesh = engine.DeviceMesh.from_device(xy_ptr, xy_shape[0], f_ptr, f_dtype.itemsize, f_shape[0], f_shape[1], fill_value)
+        self._n_node, self._n_face, self._m = xy_shape[0], f_shape[0], f_shape[1]
+        self._host = None
+        self.fill_value = FILL_VALUE
+        self.start_index = 0
+        self.name = name
+        self._celltree = CellTree2d.from_device_mesh(mesh)
+        self._voronoi_device_cache = None
+        self._area = None
+        self._centroids = None
+        self._edge_node_connectivity = None
+        self._face_edge_connectivity = None
+        self._edge_face_connectivity = None
+        self._node_face_connectivity = None
+
+    def _materialise(self):
+        if self._host is None:
+            xy, faces = self._celltree.device_mesh.download()
+            self._host = Ugrid2d(xy[:, 0], xy[:, 1], FILL_VALUE, faces, name=self.name)
+        return self._host
+
+    node_x = property(lambda self: self._materialise().node_x)
+    node_y = property(lambda self: self._materialise().node_y)
+    node_coordinates = property(lambda self: self._materialise().node_coordinates)
+    _node_xy = property(lambda self: self._materialise()._node_xy)
+    face_node_connectivity = property(lambda self: self._materialise().face_node_connectivity)
+    n_node = property(lambda self: self._n_node)
+    n_face = property(lambda self: self._n_face)
+    n_max_node_per_face = property(lambda self: self._m)
+    bounds = property(lambda self: self._materialise().bounds)
+
+    def node_coordinates_of(self, nodes):
+        return self._materialise().node_coordinates_of(nodes)
+
+    @property
+    def celltree(self) -> CellTree2d:
+        return self._celltree
+
+    def drop_device_caches(self):
+        # (the device mesh IS this grid: its derived arrays and index go, the raw arrays stay)
+        self._voronoi_device_cache = None
+        self._celltree.device_mesh.invalidate()
