@@ -348,6 +348,9 @@ int xr_outer_destroy(xr_outer *outer);
  * xr_apply_csr like any other weights (source variables live on the EDGES).  `relative` lengths are not offered:
  * the reference never requests them (gridder.py:49) and its formula indexes the edge lengths by face id (:213-214). */
 int xr_edge_length_csr(xr_mesh *tree, const double *edge_xy, int64_t n_edge, xr_csr **out);
+/* ... with the end points already in HBM (edge_xy_dev: float64 [n_edge][2][2], a device pointer): no upload -- the device part
+ * of the call above on its own (a third of which is the PCIe transfer of 32 bytes per edge). */
+int xr_edge_length_csr_dev(xr_mesh *tree, const double *edge_xy_dev, int64_t n_edge, xr_csr **out);
 /* The third return value of intersect_edges for the entries of such a matrix: intersections float64[nnz, 2, 2]
  * (begin and end point of every piece, along the direction of its edge), in the entry order of the CSR. */
 int xr_edge_pieces(xr_mesh *tree, const xr_csr *csr, const double *edge_xy, int64_t n_edge,

@@ -185,6 +185,13 @@ def test_network_gridder_pipelined_upload(hip, oracle):
     edges = random_network(rng, 700_000, lo.min() - 0.02 * span, hi.max() + 0.02 * span, 0.006 * span)
     assert edges.nbytes >= (20 << 20)
     device_vs_oracle(oracle, nodes, faces, edges)
+    # ... and with the end points already in HBM (xr_edge_length_csr_dev, round 6): no upload, one count launch, the same matrix
+    from xugrid_amd import engine
+
+    mesh = engine.DeviceMesh(nodes, faces, -1)
+    host = engine.edge_length_csr(mesh, edges).download()
+    dev = engine.edge_length_csr(mesh, engine.DeviceArray.from_host(edges)).download()
+    assert all(np.array_equal(a, b) for a, b in zip(host, dev))
 
 
 def test_celltree_intersect_edges_adapter(hip, oracle):

@@ -101,6 +101,7 @@ SIGNATURES = {
     "xr_apply_outer": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
     "xr_apply_outer_dev": (c_int, [vp, c_int, c_f64, vp, c_int, c_i64, vp]),
     "xr_edge_length_csr": (c_int, [vp, vp, c_i64, p_vp]),
+    "xr_edge_length_csr_dev": (c_int, [vp, vp, c_i64, p_vp]),
     "xr_edge_pieces": (c_int, [vp, vp, vp, c_i64, vp]),
     "xr_csr_set_row_keys": (c_int, [vp, vp, c_i64]),
     "xr_csr_set_col_keys": (c_int, [vp, vp, c_i64]),

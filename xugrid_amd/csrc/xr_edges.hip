@@ -657,7 +657,8 @@ k_edge_pieces(const int32_t *__restrict__ indptr, const int32_t *__restrict__ in
     }
 }
 
-static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n_edge, xr_csr *csr) {
+// edge_xy_dev != nullptr: the end points already live in HBM (xr_edge_length_csr_dev): no upload, one count launch
+static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n_edge, xr_csr *csr, const double *edge_xy_dev = nullptr) {
     const int64_t F = tree->n_face;
     csr->n = F;
     csr->m = n_edge;
@@ -672,7 +673,8 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     }
     mesh_prepare(tree, false);
     mesh_build_index(tree);
-    DevBuf<double> edge_xy((size_t)n_edge * 4);
+    DevBuf<double> edge_xy_own((size_t)(edge_xy_dev ? 1 : n_edge * 4));
+    struct { const double *p; const double *get() const { return p; } } edge_xy{edge_xy_dev ? edge_xy_dev : edge_xy_own.get()};
     DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters(8); // [0] big, [1] rows to sort, [2] redo, [4] pool cursor, [5] its refusal mark, [6] big edges that walk again
     DevBuf<int32_t> edge_hits((size_t)n_edge), side_face((size_t)n_edge * EDGE_SLOTS), redo_list((size_t)n_edge);
     DevBuf<double> side_len((size_t)n_edge * EDGE_SLOTS);
@@ -705,7 +707,7 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
 #undef XR_DEAL_COUNT
     };
     constexpr size_t pipe_bytes = (size_t)16 << 20; // (launches of 16 MB: smaller ones lose to their tails what the overlap gains)
-    const bool piped = deal && !pipe_off && edge_bytes >= pipe_bytes + ((size_t)4 << 20) && !current_lane() && !stream_override();
+    const bool piped = !edge_xy_dev && deal && !pipe_off && edge_bytes >= pipe_bytes + ((size_t)4 << 20) && !current_lane() && !stream_override();
     if (piped) {
         // fill(pinned, off, n) is called for piece k BEFORE its DMA is enqueued, i.e. right after the DMA of piece k - 1 was: the
         // count kernel of piece k - 1 is forked behind that DMA (SideScope) and runs beside the DMA of piece k
@@ -720,14 +722,14 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
             deal_count((int64_t)(done / 32), (int64_t)((upto - done) / 32));
             done = upto;
         };
-        h2d_staged(edge_xy.get(), edge_bytes, [&](char *pinned, size_t off, size_t n) {
+        h2d_staged(edge_xy_own.get(), edge_bytes, [&](char *pinned, size_t off, size_t n) {
             count_upto(off);
             parallel_ranges(n, 64, [=](size_t b, size_t e) { memcpy(pinned + b, src_bytes + off + b, e - b); });
         });
         count_upto(edge_bytes, true);
         side_join();
-    } else {
-        h2d(edge_xy.get(), edge_xy_host, edge_bytes);
+    } else if (!edge_xy_dev) {
+        h2d(edge_xy_own.get(), edge_xy_host, edge_bytes);
     }
     if (piped) {
     } else if (deal) {
@@ -839,6 +841,22 @@ int xr_edge_length_csr(xr_mesh *tree, const double *edge_xy, int64_t n_edge, xr_
     xr_csr *csr = new xr_csr();
     try {
         edge_length_csr(tree, edge_xy, n_edge, csr);
+        stream_sync();
+    } catch (...) {
+        delete csr;
+        throw;
+    }
+    *out = csr;
+    XR_API_END
+}
+
+int xr_edge_length_csr_dev(xr_mesh *tree, const double *edge_xy_dev, int64_t n_edge, xr_csr **out) {
+    XR_API_BEGIN
+    XR_REQUIRE(tree && out && (edge_xy_dev || n_edge == 0), XR_ERR_INVALID, "xr_edge_length_csr_dev: NULL argument");
+    XR_REQUIRE(n_edge >= 0 && n_edge < ((int64_t)1 << 30), XR_ERR_LIMIT, "xr_edge_length_csr_dev: too many edges");
+    xr_csr *csr = new xr_csr();
+    try {
+        edge_length_csr(tree, nullptr, n_edge, csr, edge_xy_dev);
         stream_sync();
     } catch (...) {
         delete csr;

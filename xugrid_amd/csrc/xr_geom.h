@@ -91,6 +91,28 @@ __device__ __forceinline__ float box_gap(float4 b, float qx0, float qx1, float q
     return fmaxf(fmaxf(qx0 - b.y, b.x - qx1), fmaxf(qy0 - b.w, b.z - qy1));
 }
 
+// ---------------------------------------------------------------------------------------------
+// polygon_length (a minimal polygon is a triangle; stop at the first fill value) and
+// counter_clockwise (the first non-collinear vertex triple decides) of one face
+template <int MA>
+__device__ __forceinline__ void face_shape(const double *__restrict__ node_xy, const int (&face)[MA], int m, int &n,
+                                           bool &flip) {
+    n = m;
+#pragma unroll
+    for (int i = MA - 1; i >= 3; i--)
+        if (i < m && face[i] < 0) n = i;
+    flip = false;
+    for (int i = 0; i < n; i++) {
+        const int ia = face[(i + n - 2) % n], ib = face[(i + n - 1) % n], ic = face[i];
+        const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib), c = load_p2(node_xy, ic);
+        const double ux = b.x - a.x, uy = b.y - a.y, vx = c.x - a.x, vy = c.y - a.y;
+        const double prod = ux * vy - uy * vx;
+        if (prod == 0) continue;
+        flip = prod < 0;
+        break;
+    }
+}
+
 // conservative float bounds: strictly below / above the double value
 __device__ __forceinline__ float f32_below(double v) {
     return nextafterf(__double2float_rd(v), -INFINITY);

@@ -306,6 +306,8 @@ enum Option : int {
     OPT_STATS_SAMPLE,      // 1: tree statistics from a sample of the faces (exact on demand); 0: always exact
     OPT_FORCE_QUERY_SORT,  // 1: Morton query order even for coherent numberings
     OPT_EARLY_APPLY,       // 1: the apply of xr_overlap_apply_dev enqueued in front of the size read-back
+    OPT_STAR_FLAG,         // 1: "inside the source grid" of a barycentric construction from the faces around the located Voronoi
+                           //    cell (k_star_flag), the grid walk only for the points they leave open; 0: the grid walk for all
     OPT_COUNT
 };
 int64_t option(Option o);

@@ -34,6 +34,9 @@ struct xr_points {
     // locate pass only shared the vector ALUs with the pre-step's kernels, and the first of those that needs LDS waited for
     // it to drain), or the construction that consumes the handle (a cached tessellation: no pre-step in between)
     bool deferred = false;
+    // round 6: the flags are not computed here at all but by the construction that consumes the handle, from the faces around
+    // each point's Voronoi cell (k_star_flag); the handle then only carries the points
+    bool flags_pending = false;
 };
 
 
@@ -407,6 +410,9 @@ k_bary_cell_flag(const int32_t *__restrict__ faces_raw, int64_t n_cell, int m, i
     flag[c] = any;
 }
 
+// OPEN_ONLY: only the points whose flag is STAR_OPEN (left open by k_star_flag) are located; a block without one leaves at once
+static constexpr uint8_t STAR_OPEN = 2;
+template <bool OPEN_ONLY>
 __global__ void __launch_bounds__(256)
 k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m, GridParams g,
               const int32_t *__restrict__ cell_start, const float *__restrict__ rec_bb,
@@ -414,11 +420,84 @@ k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
               uint8_t *__restrict__ inside) {
     __shared__ LocateBig sh_big;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = i < n;
+    bool valid = i < n;
+    if (OPEN_ONLY) {
+        valid = valid && inside[i] == STAR_OPEN;
+        if (!__syncthreads_or(valid)) return;
+    }
     const P2 p = valid ? load_p2(pts, (int)i) : P2{0.0, 0.0};
     const int l_split = locate_prepare(sh_big, g, cell_start, rec_bb, n_tree, p, valid, tol);
     const int r = locate_point(rec_fxy, rec_len, rec_off, m, g, cell_start, rec_bb, rec_face, p, valid, tol, sh_big, l_split);
     if (valid) inside[i] = r >= 0;
+}
+
+// "Inside the source grid" (unstructured.py:188-190: grid.locate_points(points) == -1 with the default tolerance) WITHOUT a walk
+// through the source grid's index (round 6).  The vertices of the Voronoi cell that holds the point are the centroids of the source
+// faces around the cell's node (vertex id < n_identity: the face itself; behind that: vertex_face) -- the faces whose union the
+// cell lies in.  The point is tested against exactly those faces with the locate kernels' own test (xr_point_in_face.h, on the
+// face's counter-clockwise-normalised vertices as the tree holds them: the same directed edges, the same roundings): a hit means
+// locate_points finds A face, i.e. != -1, which is all the reference asks (:189).  No hit (a point in a concave exterior cell beyond
+// the hull, a degenerate star) leaves the flag OPEN and k_locate_flag<true> walks the grid for those points alone.  Per point ~6
+// triangle tests instead of a grid walk + ~18 box tests + the exact tests of the parked records: 1M faces / 4M points,
+// locate_flag 284 us (175 us of vector instructions, PMC) -> see DESIGN.
+// The faces' vertices come from the source mesh's own face-major block (fxy: counter-clockwise-normalised, caller's face order --
+// what the tree's records hold, so the test sees the same directed edges and roundings), FOUR faces per round with all their loads
+// in flight together: as a chain cell row -> connectivity -> nodes per face the kernel took 295 us for 4M points.
+template <int MS> // nodes per face of a dense source mesh (3, 4); 0: any mesh, one face at a time
+__global__ void __launch_bounds__(256)
+k_star_flag(const int64_t *__restrict__ cell_of_point, const int32_t *__restrict__ cells, int mv, int64_t n_identity,
+            const int64_t *__restrict__ vertex_face, int64_t n_real /* vertices below it have a source face */,
+            const double *__restrict__ src_fxy, const uint8_t *__restrict__ src_len, const int32_t *__restrict__ src_off, int ms,
+            const double *__restrict__ pts, int64_t n, double tol, uint8_t *__restrict__ inside) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t cell = cell_of_point[i];
+    if (cell < 0) { // (no weights either way)
+        inside[i] = 0;
+        return;
+    }
+    const P2 p = load_p2(pts, (int)i);
+    const int32_t *row = cells + cell * mv;
+    uint8_t flag = STAR_OPEN;
+    constexpr int B = 4;
+    bool open = true; // (the row's fill has not been met)
+    for (int j0 = 0; j0 < mv && open && flag == STAR_OPEN; j0 += B) {
+        int64_t f[B];
+#pragma unroll
+        for (int u = 0; u < B; u++) {
+            const int64_t v = j0 + u < mv ? row[j0 + u] : -1;
+            open = open && v >= 0;
+            f[u] = (!open || v >= n_real) ? -1 : v; // (a substitute vertex has no face of its own)
+        }
+#pragma unroll
+        for (int u = 0; u < B; u++)
+            if (f[u] >= n_identity) f[u] = vertex_face[f[u]];
+        if constexpr (MS > 0) {
+            const double2 *fx = reinterpret_cast<const double2 *>(src_fxy);
+            double2 vtx[B][MS];
+            int len[B];
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+                const int64_t ff = f[u] < 0 ? 0 : f[u];
+                len[u] = f[u] < 0 ? 0 : src_len[ff];
+#pragma unroll
+                for (int k = 0; k < MS; k++) vtx[u][k] = fx[ff * MS + k];
+            }
+#pragma unroll
+            for (int u = 0; u < B; u++) {
+                if (flag != STAR_OPEN || len[u] < 3) continue;
+                const bool hit = point_in_face_regs<MS>(vtx[u], len[u], p, tol);
+                if (hit) flag = 1;
+            }
+        } else {
+            for (int u = 0; u < B; u++) {
+                if (flag != STAR_OPEN || f[u] < 0) continue;
+                const double *poly = src_fxy + 2 * face_vertex_base(src_off, f[u], ms);
+                if (point_in_face(poly, src_len[f[u]], p, tol)) flag = 1;
+            }
+        }
+    }
+    inside[i] = flag;
 }
 
 // replace_interpolated_weights (xugrid/regrid/unstructured.py:17-57) on the point's own row, then the
@@ -583,8 +662,9 @@ static void launch_points(xr_points *h) {
         XR_HIP(hipEventRecord(engine().aux_event, engine().side));
         h->pts_marked = true;
     }
+    if (h->flags_pending) return; // (the consumer fills `inside`: k_star_flag)
     xr_mesh *source = h->source;
-    XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(h->n, 256)), dim3(256), 0, source->rec_fxy.get(),
+    XR_LAUNCH("locate_flag", k_locate_flag<false>, dim3(div_up(h->n, 256)), dim3(256), 0, source->rec_fxy.get(),
               source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
               source->rec_face.get(), source->n_face, h->pts.get(), h->n, h->tol_source, h->inside.get());
 }
@@ -718,7 +798,7 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 // the source-side part of UnstructuredGrid2d.barycentric (unstructured.py:147, 188-190) -- the query points and
 // `grid.locate_points(points) == -1` -- enqueued WITHOUT a final wait: it needs nothing of the Voronoi tessellation
 static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, DevBuf<double> &pts,
-                         DevBuf<uint8_t> &inside) {
+                         DevBuf<uint8_t> &inside, bool points_only = false) {
     mesh_prepare(source, false);
     mesh_build_index(source);
     const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
@@ -726,7 +806,8 @@ static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, 
     inside.alloc((size_t)n);
     if (query) mesh_centroids_dev(query, pts.get());
     else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
-    XR_LAUNCH("locate_flag", k_locate_flag, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
+    if (points_only) return; // (the flags come from k_star_flag)
+    XR_LAUNCH("locate_flag", k_locate_flag<false>, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
               source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
               source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
 }
@@ -775,7 +856,10 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             const double tol = resolve_tolerance(voronoi, tolerance);
             DevBuf<double> own_pts, w((size_t)n * m);
             DevBuf<uint8_t> own_inside;
-            if (!pre) locate_flags(source, query, points, n, own_pts, own_inside);
+            // the flags from the faces around each point's cell (k_star_flag, behind the barycentric kernel) unless the handle
+            // brings them (option "star_flag" = 0, or a handle made while it was)
+            const bool star = pre ? pre->flags_pending : option(OPT_STAR_FLAG) != 0;
+            if (!pre) locate_flags(source, query, points, n, own_pts, own_inside, star);
             bool join_later = false;
             if (pre && pre->on_side) { // (filled on the side stream)
                 if (pre->pts_marked) { // the points now, the flags in front of bary_fix_count
@@ -829,6 +913,24 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
             if (join_later) {
                 side_join();
                 pre->on_side = false;
+            }
+            if (star) {
+                const double tol_source = pre ? pre->tol_source : resolve_tolerance(source, -1.0);
+                const int64_t *vface_tab = voronoi->bary_ids.get();
+                mesh_face_coords(source); // (its face-major vertex block in the caller's order: built once per mesh)
+                mesh_prepare(source, false); // (the index for the points the star leaves open: still there unless the mesh was
+                mesh_build_index(source);    // invalidated since the handle was made)
+#define XR_STAR(MSV)                                                                                                                 \
+    XR_LAUNCH("star_flag", k_star_flag<MSV>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), voronoi->faces_raw.get(), m, n_identity,  \
+              vface_tab, nv - n_extra, source->fxy.get(), source->len.get(), source->caller_off(), source->m, pts.get(), n,           \
+              tol_source, inside.get())
+                if (source->m == 3 && !source->ragged()) XR_STAR(3);
+                else if (source->m == 4 && !source->ragged()) XR_STAR(4);
+                else XR_STAR(0);
+#undef XR_STAR
+                XR_LAUNCH("locate_flag", k_locate_flag<true>, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
+                          source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(),
+                          source->rec_bb.get(), source->rec_face.get(), source->n_face, pts.get(), n, tol_source, inside.get());
             }
             if (reference_order)
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
@@ -894,6 +996,7 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
             h->inside.alloc((size_t)n);
             h->query = query;
             if (!query) h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            h->flags_pending = option(OPT_STAR_FLAG) != 0;
             const bool defer = option(OPT_POINTS_DEFER) != 0; // (A/B switch)
             if (defer) {
                 h->deferred = true; // launched by flush_pending_points

@@ -41,28 +41,6 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // ---------------------------------------------------------------------------------------------
 // per-face preparation.  MC > 0: compile-time vertices per face; MC == 0: runtime m <= 32.
-// ---------------------------------------------------------------------------------------------
-// polygon_length (a minimal polygon is a triangle; stop at the first fill value) and
-// counter_clockwise (the first non-collinear vertex triple decides) of one face
-template <int MA>
-__device__ __forceinline__ void face_shape(const double *__restrict__ node_xy, const int (&face)[MA], int m, int &n,
-                                           bool &flip) {
-    n = m;
-#pragma unroll
-    for (int i = MA - 1; i >= 3; i--)
-        if (i < m && face[i] < 0) n = i;
-    flip = false;
-    for (int i = 0; i < n; i++) {
-        const int ia = face[(i + n - 2) % n], ib = face[(i + n - 1) % n], ic = face[i];
-        const P2 a = load_p2(node_xy, ia), b = load_p2(node_xy, ib), c = load_p2(node_xy, ic);
-        const double ux = b.x - a.x, uy = b.y - a.y, vx = c.x - a.x, vy = c.y - a.y;
-        const double prod = ux * vy - uy * vx;
-        if (prod == 0) continue;
-        flip = prod < 0;
-        break;
-    }
-}
-
 // connectivity.area on the caller's order (connectivity.py:372-382, 615-633): fill slots and the closing slot
 // repeat node 0; everything relative to node 0.  Only `relative` overlap weights and xr_mesh_area read it, so it
 // is computed on demand (mesh_area) and not by the preparation pass.

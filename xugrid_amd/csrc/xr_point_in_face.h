@@ -67,4 +67,38 @@ template <typename Load> __device__ __forceinline__ bool point_in_face_impl(Load
     return c;
 }
 
+// the same test on MS vertices held in REGISTERS (n <= MS of them valid): the loop is unrolled with constant indices, so the
+// vertex array never needs dynamic addressing (which would put it into scratch memory)
+template <int MS, typename V> __device__ __forceinline__ bool point_in_face_regs(const V (&vtx)[MS], int n, P2 p, double tol) {
+    bool c = false, on_edge = false;
+    P2 v0{vtx[0].x, vtx[0].y};
+#pragma unroll
+    for (int k = 1; k < MS; k++)
+        if (k == n - 1) v0 = P2{vtx[k].x, vtx[k].y};
+#pragma unroll
+    for (int i = 0; i < MS; i++) {
+        if (i < n) {
+            const P2 v1{vtx[i].x, vtx[i].y};
+            const double wx = v1.x - v0.x, wy = v1.y - v0.y;
+            const double len2 = wx * wx + wy * wy;
+            if (len2 > 0) {
+                const double ux = p.x - v0.x, uy = p.y - v0.y;
+                const double twice_area = fabs(wx * uy - wy * ux);
+                if (!edge_certainly_far(twice_area, len2, tol)) {
+                    const double len = sqrt(len2);
+                    if (twice_area < tol * len) {
+                        const double tpar = ux * wx + uy * wy;
+                        if (tpar >= 0 && tpar <= len2) on_edge = true;
+                    }
+                }
+                if ((v0.y > p.y) != (v1.y > p.y)) {
+                    if (left_of_crossing(p.x, wx * (p.y - v0.y), wy, v0.x)) c = !c;
+                }
+            }
+            v0 = v1;
+        }
+    }
+    return on_edge || c; // (point_in_face_impl returns at the first edge the point lies on: the same boolean)
+}
+
 } // namespace xr

@@ -506,10 +506,18 @@ def morton_row_keys(xy, faces_per_tile=144):
 def edge_length_csr(tree: DeviceMesh, edge_node_coordinates) -> "DeviceCSR":
     """NetworkGridder weights: (n_edge, 2, 2) end points -> CSR rows = faces of ``tree``, columns = edges, data =
     length of the edge inside the face (include/xugrid_amd.h: xr_edge_length_csr)."""
+    handle = ctypes.c_void_p()
+    info = device_array_info(edge_node_coordinates)
+    if info is not None:  # the end points already live in HBM (xr_edge_length_csr_dev): no upload
+        ptr, shape, dtype = info
+        if len(shape) != 3 or tuple(shape[1:]) != (2, 2) or dtype != np.dtype(np.float64):
+            raise ValueError("edge_node_coordinates must be a float64 (n_edge, 2, 2) array")
+        sync_producer(edge_node_coordinates)
+        check(_lib.load().xr_edge_length_csr_dev(tree._h, ctypes.c_void_p(ptr), shape[0], ctypes.byref(handle)))
+        return DeviceCSR(handle)
     xy = np.ascontiguousarray(edge_node_coordinates, dtype=np.float64)
     if xy.ndim != 3 or xy.shape[1:] != (2, 2):
         raise ValueError("edge_node_coordinates must have shape (n_edge, 2, 2)")
-    handle = ctypes.c_void_p()
     check(_lib.load().xr_edge_length_csr(tree._h, _ptr(xy), xy.shape[0], ctypes.byref(handle)))
     return DeviceCSR(handle)
 

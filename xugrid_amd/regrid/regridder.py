@@ -492,7 +492,8 @@ class BaseOverlapRegridder(BaseRegridder, abc.ABC):
     def _compute_overlap(self, source, target, relative: bool) -> None:
         source, target = convert_to_match(source, target)
         self._weights = None
-        if isinstance(source.ugrid_topology, DeviceUgrid2d) and isinstance(target.ugrid_topology, DeviceUgrid2d):
+        if (isinstance(source, UnstructuredGrid2d) and isinstance(source.ugrid_topology, DeviceUgrid2d)
+                and isinstance(target.ugrid_topology, DeviceUgrid2d)):
             # Both grids were made from device arrays: a pipeline that keeps its data in HBM.  The weights are built by the
             # first call that needs them -- ``regrid`` of device data does it in ONE engine call with the apply
             # (xr_overlap_apply_dev: the apply rides on the construction, the step bench.py times); ``weights``,
