@@ -847,6 +847,16 @@ k_plan_build_group(const int32_t *__restrict__ indptr, const int32_t *__restrict
 // mean of mixed-sign data cancels to ~1e-7 of that range.  What it buys (profiles/r06_apply_fast_ab.txt): K = 256 on the
 // lattice-numbered pair 1.01 -> 0.92 ms (50 -> 56 % of HBM), on the qhull-numbered benchmark matrix 1.57 -> 1.53 ms (that one is
 // bound by its line fills, not by the reduction).  The default stays the reference's operation order, bit for bit.
+// The staged tile of distinct source values in LDS is VARIABLE-minor (round 6): the KTILE values of a column in KTILE / 2 consecutive
+// 16-byte slots, read with ds_read_b128 (which reaches its rate from one wave per SIMD; ds_read_b64 needs ~4 and the kernel has 3) --
+// the slot of a pair XOR-swizzled with the column so that, for a fixed pair, the columns spread over all 16 slot positions of a
+// 256-byte LDS row.  Until round 5 it was variable-MAJOR (vals[kk][u]: a ds_read_b64 at a random column per variable).  Same values,
+// same arithmetic; measured with gathers and stores off (option plan_dbg = 3, the reduction's floor): merged plan 0.785 -> 0.685 ms,
+// per-block plan 0.588 -> 0.502 ms per K = 256 apply; whole kernel - 1.5 ... 2 % (profiles/r06_experiments/apply_lds_layout_ab.txt).
+template <int KTILE> __device__ __forceinline__ int plan_slot(int u, int k2) {
+    static_assert(KTILE == 8 || KTILE == 4, "tiles of 4 or 8 variables");
+    return KTILE == 8 ? u * 4 + (k2 ^ ((u >> 2) & 3)) : u * 2 + (k2 ^ ((u >> 3) & 1));
+}
 template <int METHOD, typename SRC, int KTILE, int SUBS, bool MERGE = false, bool FAST = false>
 __global__ void __launch_bounds__(AP_BLOCK * SUBS)
 k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices, const double *__restrict__ data,
@@ -862,7 +872,7 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
     const size_t stage_bytes = ((sizeof(double) * (size_t)lmax + sizeof(uint16_t) * (size_t)lmax) + 15) / 16 * 16;
     char *smem = MERGE ? smem_all
                        : smem_all + (size_t)sub * (((sizeof(double) * (KTILE * PLAN_UMAX + lmax) + sizeof(uint16_t) * lmax) + 15) / 16 * 16);
-    double *vals = reinterpret_cast<double *>(smem);                      // [KTILE][UMAX]
+    double *vals = reinterpret_cast<double *>(smem);                      // [UMAX][KTILE / 2] 16-byte slots, swizzled (plan_slot)
     double *sh_w = MERGE ? reinterpret_cast<double *>(smem_all + sizeof(double) * KTILE * UMAX + (size_t)sub * stage_bytes)
                          : vals + KTILE * PLAN_UMAX;                      // [lmax] = entries of the largest planned block
     uint16_t *sh_loc = reinterpret_cast<uint16_t *>(sh_w + lmax);         // [lmax]
@@ -952,10 +962,10 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
             const int u = q * GATHERERS + gtid;
             if (u < nu) {
 #pragma unroll
-                for (int kk = 0; kk < KTILE; kk++) {
-                    vals[kk * UMAX + u] = stage[q][kk];
-                    my_nan |= (stage[q][kk] != stage[q][kk]) ? 1 : 0;
-                }
+                for (int kk = 0; kk < KTILE; kk++) my_nan |= (stage[q][kk] != stage[q][kk]) ? 1 : 0;
+#pragma unroll
+                for (int k2 = 0; k2 < KTILE / 2; k2++)
+                    reinterpret_cast<double2 *>(vals)[plan_slot<KTILE>(u, k2)] = make_double2(stage[q][2 * k2], stage[q][2 * k2 + 1]);
             }
         }
         // block-uniform: does this tile hold any NaN?  (NaN-free tiles take the short path below)
@@ -985,7 +995,11 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                     const double w = sh_w[j];
                     double v[KTILE];
 #pragma unroll
-                    for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * UMAX + l];
+                    for (int k2 = 0; k2 < KTILE / 2; k2++) {
+                        const double2 t2 = reinterpret_cast<const double2 *>(vals)[plan_slot<KTILE>(l, k2)];
+                        v[2 * k2] = t2.x;
+                        v[2 * k2 + 1] = t2.y;
+                    }
 #pragma unroll
                     for (int kk = 0; kk < KTILE; kk++) {
                         if (METHOD == XR_SUM) acc[kk] += v[kk];
@@ -1026,7 +1040,11 @@ k_apply_plan(const int32_t *__restrict__ indptr, const int32_t *__restrict__ ind
                 const double w = sh_w[j];
                 double v[KTILE];
 #pragma unroll
-                for (int kk = 0; kk < KTILE; kk++) v[kk] = vals[kk * UMAX + l];
+                for (int k2 = 0; k2 < KTILE / 2; k2++) {
+                    const double2 t2 = reinterpret_cast<const double2 *>(vals)[plan_slot<KTILE>(l, k2)];
+                    v[2 * k2] = t2.x;
+                    v[2 * k2 + 1] = t2.y;
+                }
 #pragma unroll
                 for (int kk = 0; kk < KTILE; kk++)
                     if (kk < kn) red[kk].add(v[kk], w, normsum);
