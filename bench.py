@@ -591,7 +591,21 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
             "0.99 ms = 4.2 TB/s)",
             "ms": 1e3 * dt, "cell_variables_per_s": K * T / dt, "algorithmic_GBps": nbytes / dt / 1e9,
             "frac_of_hbm_peak": nbytes / dt / 1e9 / HBM_PEAK_GBS,
+            "frac_of_achievable_6p3TBps": nbytes / dt / 1e9 / 6300.0,
         }
+        # ... and with option apply_contract (fused multiply-adds + one reciprocal per row: NOT bit-identical, within (n + 2) ulp;
+        # off by default -- DESIGN section 4)
+        E.set_option("apply_contract", 1)
+        for _ in range(2):
+            csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+        E.dev_sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            csr.apply_dev(d_src.value, E.XR_F64, K, d_out.value, 0)
+        E.dev_sync()
+        dtc = (time.perf_counter() - t0) / n
+        E.set_option("apply_contract", 0)
+        out["config5_apply_K256"]["contracted_opt_in"] = {"ms": 1e3 * dtc, "frac_of_hbm_peak": nbytes / dtc / 1e9 / HBM_PEAK_GBS}
         # the same with the source cells renumbered along a Morton curve (xr_csr_set_col_keys): once with the caller's
         # block (a gather pass per apply puts it in the stored order), once with a block that already is in that order
         keys, key_range = E.morton_row_keys(mesh.centroids(), faces_per_tile=8)  # (fine keys: 1.70 -> 1.58 ms against tiles of 64)

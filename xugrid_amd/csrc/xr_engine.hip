@@ -319,8 +319,10 @@ static void lane_release_blocks(Lane *lane) {
 // called after the main stream has been synchronised with the host
 static void pool_release_deferred(bool may_block = true) {
     if (!g_side_active || t_lane) return;
-    if (may_block) (void)hipStreamSynchronize(g_engine.side);
-    else if (hipStreamQuery(g_engine.side) != hipSuccess) { // (still busy: the blocks stay parked until a later host sync)
+    if (may_block) {
+        (void)hipStreamSynchronize(g_engine.side);
+        (void)hipStreamSynchronize(g_engine.side2);
+    } else if (hipStreamQuery(g_engine.side) != hipSuccess || hipStreamQuery(g_engine.side2) != hipSuccess) { // (still busy: the blocks stay parked until a later host sync)
         (void)hipGetLastError();
         return;
     }
@@ -899,6 +901,7 @@ SideScope::~SideScope() {
         (void)hipEventRecord(g_engine.join_event, g_engine.side);
     }
 }
+static bool g_fork2_pending = false; // (exclusive path only) the second side stream holds work the next side_join must wait for
 SideForkScope::SideForkScope() {
     Engine &e = engine();
     if (option(OPT_SIDE_FORK) == 0 || current_lane() || !e.on_side || t_stream_override || !e.side2) return;
@@ -917,7 +920,9 @@ void SideForkScope::end_launches() {
 SideForkScope::~SideForkScope() {
     if (!active) return;
     end_launches();
-    (void)hipStreamWaitEvent(g_engine.side, g_engine.join2_event, 0);
+    // (the MAIN stream waits for the second stream's event itself, in side_join: made to wait for it here, the side stream put a
+    // second event hop -- ~10 us -- between the second stream's last kernel and the main stream's next one)
+    g_fork2_pending = true;
 }
 void side_join() {
     if (side_disabled()) return;
@@ -934,6 +939,10 @@ void side_join() {
     if (t_exclusive_depth == 0) return;
     Engine &e = engine();
     XR_HIP(hipStreamWaitEvent(e.stream, e.join_event, 0));
+    if (g_fork2_pending) {
+        XR_HIP(hipStreamWaitEvent(e.stream, e.join2_event, 0));
+        g_fork2_pending = false;
+    }
 }
 
 void prof_flush() {
