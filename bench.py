@@ -1033,7 +1033,7 @@ def multi_workload(args, backend, strong, K, steps, warmup, both_exchanges, setu
             rg = TargetPartitionedRegridder(sxy, sf, txy, tf, backend, method="mean")
         else:
             rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=exchange,
-                                         k_tile=args.k_tile)
+                                         k_tile=args.k_tile, ownership=(args.ownership if exchange == "sparse" else None))
         dsync()
         setup_s = time.perf_counter() - t0
         local = local_block(rg)
@@ -1213,7 +1213,8 @@ class ProjectionDist:
     """Stand-in for the few torch.distributed calls of ShardedOverlapRegridder, for ONE "rank" at a time on ONE GPU
     (`bench.py --project-shards W`): the exchange LISTS are the real ones (computed from all W shards beforehand), the
     data path of a collective is a device copy of the right shape -- its time is measured and taken out of the
-    projection, which prices the exchange from the bytes and the xGMI link rate instead."""
+    projection, which prices the exchange from the bytes and the xGMI link rate instead.  The set-up collectives are
+    answered in the order ShardedOverlapRegridder issues them (`tables["setup"]`: one precomputed answer per call)."""
 
     class _Done:
         def wait(self):
@@ -1222,8 +1223,9 @@ class ProjectionDist:
     class ReduceOp:
         SUM, MAX = "sum", "max"
 
-    def __init__(self, rank, world, counts, ids_to):
-        self.rank, self.world, self.counts, self.ids_to = rank, world, counts, ids_to
+    def __init__(self, rank, world, tables):
+        self.rank, self.world = rank, world
+        self._answers = list(tables["setup"][rank])
         self._cycle = {}
 
     def get_rank(self, group=None):
@@ -1238,14 +1240,16 @@ class ProjectionDist:
     def barrier(self, group=None):
         pass
 
+    def _next(self, kind):
+        got_kind, value = self._answers.pop(0)
+        assert got_kind == kind, f"projection stand-in: expected a {got_kind} call, ShardedOverlapRegridder issued {kind}"
+        return value
+
     def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None, group=None, async_op=False):
         import torch
 
-        if input.dtype == torch.int64 and input_split_sizes is None:      # set-up: how many rows every sender has for me
-            output.copy_(torch.as_tensor(self.counts[:, self.rank], device=output.device))
-        elif input.dtype == torch.int64:                                   # set-up: which of my targets they are
-            parts = [self.ids_to[s][self.rank] for s in range(self.world)]
-            output.copy_(torch.cat(parts) if parts else input[:0])
+        if input.dtype == torch.int64:                                     # set-up: counts, claims, owners, row ids
+            output.copy_(self._next("a2a").to(output.device))
         else:                                                              # a step: rows of partial states (values: my own, cycled)
             n_out, n_in = output.shape[0], input.shape[0]
             if n_out and n_in:
@@ -1262,6 +1266,12 @@ class ProjectionDist:
         return self._Done() if async_op else None
 
     def all_gather(self, tensor_list, tensor, group=None):
+        import torch
+
+        if tensor.dtype == torch.int64 and self._answers:                  # set-up: every rank's owned rows
+            for dst, src in zip(tensor_list, self._next("gather")):
+                dst.copy_(src.to(dst.device))
+            return
         for dst in tensor_list:
             dst.copy_(tensor)
 
@@ -1297,28 +1307,57 @@ def run_projection(args):
     data = meshgen.smooth_field(sxy[sf].mean(axis=1), 0)
     steps, warmup = max(1, min(args.steps, 20)), max(1, min(args.warmup, 5))
 
-    def shard_tables(world):
-        """the real exchange lists of all `world` shards: counts[s, o] rows of sender s for owner o, and the ids"""
+    def shard_tables(world, ownership):
+        """The real exchange lists of all `world` shards, as the set-up collectives of ShardedOverlapRegridder would deliver
+        them: per rank the answers in call order, and counts[s, o] = rows of sender s for owner o."""
         full = (_t(sxy, dev), _t(sf.astype(np.int64), dev), _t(txy, dev), _t(tf.astype(np.int64), dev))
         t_chunk = -(-T // world)
-        counts = np.zeros((world, world), dtype=np.int64)
-        ids_to = []
-        for r in range(world):
-            _, lt = shard_lists(full, world, r, args.partition, backend)
-            owner = torch.div(lt, t_chunk, rounding_mode="floor")
-            counts[r] = torch.bincount(owner, minlength=world).cpu().numpy()
-            local = lt - owner * t_chunk
-            ids_to.append(list(torch.split(local, [int(c) for c in counts[r]])))
+        lts = [shard_lists(full, world, r, args.partition, backend)[1] for r in range(world)]
         del full
-        return counts, ids_to
+        auth = [torch.div(lt, t_chunk, rounding_mode="floor") for lt in lts]
+        claim_counts = torch.stack([torch.bincount(a, minlength=world) for a in auth]).cpu()  # [sender, authority]
+        setup = [[] for _ in range(world)]
+        if ownership == "partition":
+            lowest = torch.full((T,), world, dtype=torch.int64, device=dev)
+            for r in reversed(range(world)):
+                lowest[lts[r]] = r
+            claims_to = [list(torch.split(lt - a * t_chunk, [int(c) for c in claim_counts[r]])) for r, (lt, a) in enumerate(zip(lts, auth))]
+            rows, owners = [], []
+            for r in range(world):
+                own = lowest[lts[r]]
+                order = torch.argsort(own, stable=True)
+                rows.append(lts[r][order])
+                owners.append(own[order])
+            owned = [rows[r][owners[r] == r] for r in range(world)]
+            counts = torch.stack([torch.bincount(o, minlength=world) for o in owners]).cpu()    # [sender, owner]
+            rows_to = [list(torch.split(rows[r], [int(c) for c in counts[r]])) for r in range(world)]
+            pad = max(max(int(o.numel()) for o in owned), 1)
+            padded = []
+            for o in owned:
+                p = torch.full((pad,), -1, dtype=torch.int64, device=dev)
+                p[: o.numel()] = o
+                padded.append(p)
+            for r in range(world):
+                setup[r] = [("a2a", claim_counts[:, r].clone()), ("a2a", torch.cat([claims_to[s][r] for s in range(world)])),
+                            ("a2a", lowest[lts[r]]), ("a2a", counts[:, r].clone()),
+                            ("a2a", torch.cat([rows_to[s][r] for s in range(world)])),
+                            ("gather", [torch.tensor([int(o.numel())]) for o in owned]), ("gather", padded)]
+            counts = counts.numpy()
+        else:
+            counts = claim_counts.numpy()
+            ids_to = [list(torch.split(lt - a * t_chunk, [int(c) for c in claim_counts[r]])) for r, (lt, a) in enumerate(zip(lts, auth))]
+            for r in range(world):
+                setup[r] = [("a2a", claim_counts[:, r].clone()), ("a2a", torch.cat([ids_to[s][r] for s in range(world)]))]
+        return counts, {"setup": setup}
 
     def run_shards(world):
-        counts, ids_to = shard_tables(world)
+        ownership = args.ownership or ("partition" if args.exchange == "sparse" and args.partition != "hash" else "chunk")
+        counts, tables = shard_tables(world, ownership)
         rows = []
         for r in range(world):
-            pd = ProjectionDist(r, world, counts, ids_to)
+            pd = ProjectionDist(r, world, tables)
             rg = ShardedOverlapRegridder(sxy, sf, txy, tf, backend, partition=args.partition, exchange=args.exchange,
-                                         k_tile=args.k_tile, dist=pd)
+                                         k_tile=args.k_tile, dist=pd, ownership=ownership)
             local = rg.local_source(data)
 
             def step():
@@ -1384,6 +1423,7 @@ def run_projection(args):
                 "ShardedOverlapRegridder + HipBackend per shard, collectives looped back); projected step = max over shards of "
                 "the measured compute time + modelled exchange",
         "workload": mesh_kind, "shards": W, "partition": args.partition, "exchange": args.exchange,
+        "ownership": args.ownership or ("partition" if args.exchange == "sparse" and args.partition != "hash" else "chunk"),
         "source_faces": S, "target_faces": T, "steps": steps, "warmup": warmup,
         "per_shard": rows,
         "imbalance_max_over_mean": float(comp.max() / comp.mean()),
@@ -1416,6 +1456,9 @@ def main():
                     help="source shards: Morton blocks of equal estimated work (default) / equal face counts, or id mod N")
     ap.add_argument("--exchange", default="sparse", choices=["sparse", "dense"],
                     help="sparse all-to-all of the touched targets (default) or dense reduce-scatter")
+    ap.add_argument("--ownership", default=None, choices=["partition", "chunk"],
+                    help="sparse exchange: who finalises a target row -- the lowest rank whose shard touches it (default for the "
+                    "spatial partitions: only the boundary layer leaves a GPU) or its id chunk")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path even with one rank")
     ap.add_argument("--strong", action="store_true",
                     help="multi-GPU: strong scaling on BASELINE config 4 (a fixed 10M -> 10M pair sharded over the ranks)")

@@ -200,6 +200,31 @@ def test_sharded_regridder_world3_and_8_loopback(oracle):
             for exchange in ("sparse", "dense"):
                 for o in per_rank:
                     np.testing.assert_allclose(o[method, exchange], expected, rtol=1e-12, atol=1e-14, equal_nan=True)
+    # ownership of the rows (round 6): "partition" -- the lowest rank whose shard touches the row -- against id chunks.  Same
+    # results; every touched row has exactly one owner, who touches it; and only the boundary layer leaves a rank
+    def owners(dist, rank):
+        res = {}
+        for ownership in ("partition", "chunk"):
+            rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), partition="morton", k_tile=3, dist=dist, ownership=ownership)
+            res[ownership] = (rg.regrid(data), rg.exchange_bytes(), rg.local_targets.copy(),
+                              rg.owned_targets.numpy().copy() if ownership == "partition" else None, rg.regrid(data, gather=False).shape)
+        return res
+
+    per_rank, _ = run_ranks(4, owners)
+    expected = oracle.regrid_csr("mean", data, a, s_, indptr, T)
+    for o in per_rank:
+        for ownership in ("partition", "chunk"):
+            np.testing.assert_allclose(o[ownership][0], expected, rtol=1e-12, atol=1e-14, equal_nan=True)
+    owned = [o["partition"][3] for o in per_rank]
+    touched = np.unique(np.concatenate([o["partition"][2] for o in per_rank]))
+    assert np.array_equal(np.sort(np.concatenate(owned)), touched)  # disjoint and complete over the touched rows
+    for o, mine in zip(per_rank, owned):
+        assert np.isin(mine, o["partition"][2]).all() and (np.diff(mine) > 0).all()
+        assert o["partition"][4] == (data.shape[0], mine.size)
+    off_partition = sum(o["partition"][1]["sent_off_gpu"] for o in per_rank)
+    off_chunk = sum(o["chunk"][1]["sent_off_gpu"] for o in per_rank)
+    assert off_partition < 0.35 * off_chunk, (off_partition, off_chunk)  # (a 1400-face target: the boundary layer is thick)
+
     # relative and absolute weights are not interchangeable; whole-row reducers are refused
     def refuse(dist, rank):
         rg = ShardedOverlapRegridder(sxy, sf, txy, tf, OracleBackend(), dist=dist)

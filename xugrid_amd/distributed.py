@@ -448,10 +448,17 @@ class ShardedOverlapRegridder:
     partition: "balanced" (default; Morton blocks of equal estimated work, ``work_weights``), "morton" (Morton
     blocks of equal source-face counts) or "hash" (face id mod world size).
     k_tile: stacked variables exchanged per collective (tiles are pipelined).
+    ownership (sparse exchange): who combines and finalises a target row.  "partition" (default for the spatial partitions, round 6): the LOWEST RANK AMONG
+    THE RANKS WHOSE SHARD CAN GIVE THE ROW WEIGHT -- with spatially compact shards that is the one rank that touches the row
+    for all but the boundary layer between shards (~3-4 % of the rows at eight shards), so only those rows leave a GPU;
+    the ranks agree on it once, at set-up, through the id-chunk authorities (two small collectives), and rank r's slice of
+    the result is its OWNED rows (``owned_targets``, ascending ids) instead of an id chunk.  "chunk": row t belongs to rank
+    ``t // t_chunk`` -- the north star's reduce-scatter slices, what the dense exchange always uses; 7/8 of a rank's state rows
+    then leave the GPU whatever the partition.
     """
 
     def __init__(self, source_xy, source_faces, target_xy, target_faces, backend, partition="balanced", group=None,
-                 exchange="sparse", method="mean", k_tile=32, dist=None, always_exchange=False):
+                 exchange="sparse", method="mean", k_tile=32, dist=None, always_exchange=False, ownership=None):
         import torch
 
         if dist is None:  # (tests inject a loop-back implementation of the four collectives used here)
@@ -463,6 +470,13 @@ class ShardedOverlapRegridder:
             raise ValueError(f"{self.method.name!r} needs whole rows: use TargetPartitionedRegridder "
                              f"(source-sharded reducers: {', '.join(SHARD_METHODS)})")
         self.exchange = exchange
+        if ownership is None:
+            # (with the hash partition every rank touches nearly every row: "the lowest rank that touches it" would make rank 0
+            # the owner of everything -- id chunks are the balanced choice there)
+            ownership = "partition" if exchange == "sparse" and partition != "hash" else "chunk"
+        if ownership not in ("partition", "chunk") or (ownership == "partition" and exchange != "sparse"):
+            raise ValueError(f"ownership {ownership!r} is not available with the {exchange} exchange")
+        self.ownership = ownership
         self.k_tile = max(1, int(k_tile))
         # a group of ONE rank needs no collective: every state already is where it is combined.  always_exchange=True makes
         # the calls all the same (tests of the RCCL plumbing on a one-GPU box)
@@ -498,6 +512,11 @@ class ShardedOverlapRegridder:
         # which of shard_lists' two rules produced the lists (anyone recomputing them must ask for the same one)
         self.partition_rule = "engine" if hasattr(self.backend, "shard_plan") and self.partition in ("hash", "morton", "balanced") else "torch"
         sfa_local = sfa[local_faces]
+        self._row_owner = None
+        if self.ownership == "partition":
+            # the rows of the shard's matrix grouped by the rank that will combine them (ascending ids inside a group): the
+            # partial states then leave the kernel in the order the exchange sends them
+            local_targets, self._row_owner = self._order_by_owner(local_targets)
         self._local_faces_t, self._local_targets_t = local_faces, local_targets
         self._local_np = [None, None]
         if hasattr(self.backend, "build_weights_t"):  # device tensors in, nothing crosses PCIe
@@ -518,34 +537,83 @@ class ShardedOverlapRegridder:
 
     @property
     def local_targets(self):
-        """global ids of the target faces this rank can give weight to (ascending), host array"""
+        """global ids of the target faces this rank can give weight to, in the row order of its matrix (ascending; with
+        ``ownership="partition"`` ascending inside each owner's group), host array"""
         if self._local_np[1] is None:
             self._local_np[1] = self._local_targets_t.cpu().numpy()
         return self._local_np[1]
+
+    def _a2a(self, send, send_counts, recv_counts):
+        """all_to_all_single of an int64 id list with split sizes (gloo: through the host)"""
+        import torch
+
+        recv = torch.empty(sum(recv_counts), dtype=send.dtype, device=send.device)
+        self.dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                    group=self.group)
+        return recv
+
+    def _a2a_counts(self, cnt_in):
+        import torch
+
+        cnt_out = torch.empty(self.world, dtype=torch.int64, device=cnt_in.device)
+        if self.dist.get_backend(self.group) != "nccl":
+            cnt_in, cnt_out = cnt_in.cpu(), cnt_out.cpu()
+        self.dist.all_to_all_single(cnt_out, cnt_in, group=self.group)
+        return [int(c) for c in cnt_in.cpu()], [int(c) for c in cnt_out.cpu()]
+
+    def _order_by_owner(self, lt):
+        """ascending local target ids -> (the ids grouped by owner rank, the owner of every row).  The owner of a target is the
+        lowest rank whose near-shard filter kept it; the ranks learn it from the target's id-chunk authority (claims in, owners
+        back: two small collectives, once per set-up)."""
+        import torch
+
+        W = self.world
+        auth = torch.div(lt, self.t_chunk, rounding_mode="floor")  # (ascending ids: grouped by authority already)
+        send_counts, recv_counts = self._a2a_counts(torch.bincount(auth, minlength=W))
+        claims = self._a2a(lt - auth * self.t_chunk, send_counts, recv_counts)  # chunk-local ids, grouped by sender
+        sender = torch.repeat_interleave(torch.arange(W, device=lt.device), torch.as_tensor(recv_counts, device=lt.device))
+        lowest = torch.full((self.t_chunk,), W, dtype=torch.int64, device=lt.device)
+        lowest.scatter_reduce_(0, claims, sender, reduce="amin")
+        owner = self._a2a(lowest[claims], recv_counts, send_counts)  # back to the claimants, in the order they asked
+        order = torch.argsort(owner, stable=True)
+        return lt[order], owner[order]
 
     def _setup_sparse_exchange(self):
         """Who gets which of my partial rows: exchanged once (the weights are fixed)."""
         import torch
 
-        dist, W = self.dist, self.world
+        W = self.world
         lt = self._local_targets_dev
         dev = lt.device
-        owner = torch.div(lt, self.t_chunk, rounding_mode="floor")  # local targets are ascending -> grouped by owner
-        cnt_in = torch.bincount(owner, minlength=W)
-        cnt_out = torch.empty(W, dtype=torch.int64, device=dev)
-        if dist.get_backend(self.group) != "nccl":
-            cnt_in, cnt_out = cnt_in.cpu(), cnt_out.cpu()
-        dist.all_to_all_single(cnt_out, cnt_in, group=self.group)
-        self._send_counts = [int(c) for c in cnt_in.cpu()]
-        self._recv_counts = [int(c) for c in cnt_out.cpu()]
-        ids_in = lt - owner * self.t_chunk
-        ids_out = torch.empty(sum(self._recv_counts), dtype=torch.int64, device=dev)
-        dist.all_to_all_single(ids_out, ids_in, output_split_sizes=self._recv_counts,
-                               input_split_sizes=self._send_counts, group=self.group)
-        # per owned target: the received rows that belong to it, in sender order (stable sort of the positions)
+        if self.exchange != "sparse":
+            self.n_out = self.t_chunk
+            return
+        if self.ownership == "partition":
+            owner = self._row_owner
+            self.owned_targets = lt[owner == self.rank]  # ascending global ids: the rows this rank finalises
+            self.n_out = int(self.owned_targets.numel())
+            self._send_counts, self._recv_counts = self._a2a_counts(torch.bincount(owner, minlength=W))
+            ids_out = torch.searchsorted(self.owned_targets, self._a2a(lt, self._send_counts, self._recv_counts))
+            # every rank's owned list, for gathers of the result (regrid(gather=True))
+            counts = torch.empty(W, dtype=torch.int64, device=dev if self.dist.get_backend(self.group) == "nccl" else "cpu")
+            parts = [torch.empty(1, dtype=torch.int64, device=counts.device) for _ in range(W)]
+            self.dist.all_gather(parts, torch.tensor([self.n_out], dtype=torch.int64, device=counts.device), group=self.group)
+            self._out_counts = [int(p[0]) for p in parts]
+            pad = max(max(self._out_counts), 1)
+            mine = torch.full((pad,), -1, dtype=torch.int64, device=dev)
+            mine[: self.n_out] = self.owned_targets
+            lists = [torch.empty_like(mine) for _ in range(W)]
+            self.dist.all_gather(lists, mine, group=self.group)
+            self._all_owned = [l[:c] for l, c in zip(lists, self._out_counts)]
+        else:
+            owner = torch.div(lt, self.t_chunk, rounding_mode="floor")  # local targets are ascending -> grouped by owner
+            self.n_out = self.t_chunk
+            self._send_counts, self._recv_counts = self._a2a_counts(torch.bincount(owner, minlength=W))
+            ids_out = self._a2a(lt - owner * self.t_chunk, self._send_counts, self._recv_counts)
+        # per finalised target: the received rows that belong to it, in sender order (stable sort of the positions)
         order = torch.argsort(ids_out, stable=True)
-        counts = torch.bincount(ids_out, minlength=self.t_chunk)
-        indptr = torch.zeros(self.t_chunk + 1, dtype=torch.int64, device=dev)
+        counts = torch.bincount(ids_out, minlength=self.n_out)
+        indptr = torch.zeros(self.n_out + 1, dtype=torch.int64, device=dev)
         indptr[1:] = torch.cumsum(counts, 0)
         self._recv_order = order
         self._recv_indptr = indptr
@@ -577,7 +645,8 @@ class ShardedOverlapRegridder:
             path, __regrid_data=data, __regrid_indices=indices, __regrid_indptr=indptr, __regrid_n=n, __regrid_m=m,
             __regrid_nnz=data.size, __shard_source_faces=self.local_faces, __shard_target_faces=self.local_targets,
             __shard_rank=self.rank, __shard_world=self.world, __n_source=self.n_source, __n_target=self.n_target,
-            __shard_exchange=self.exchange, __shard_method=self.method.name,
+            __shard_exchange=self.exchange, __shard_method=self.method.name, __shard_ownership=self.ownership,
+            __shard_row_owner=(self._row_owner.cpu().numpy() if self._row_owner is not None else np.zeros(0, dtype=np.int64)),
         )
         return path
 
@@ -603,6 +672,8 @@ class ShardedOverlapRegridder:
                 raise ValueError("relative and absolute overlap weights are not interchangeable")
             self.n_source, self.n_target = int(f["__n_source"]), int(f["__n_target"])
             self._local_np = [f["__shard_source_faces"].astype(np.int64), f["__shard_target_faces"].astype(np.int64)]
+            self.ownership = str(f["__shard_ownership"]) if "__shard_ownership" in f.files else "chunk"
+            row_owner = f["__shard_row_owner"].astype(np.int64) if self.ownership == "partition" else None
             n, m = int(f["__regrid_n"]), int(f["__regrid_m"])
             if n != self.local_targets.size or m != self.local_faces.size:
                 raise ValueError("shard id lists do not match the stored matrix")
@@ -614,6 +685,10 @@ class ShardedOverlapRegridder:
         self.t_chunk = -(-self.n_target // self.world)
         self._local_faces_t = backend.to_device(self.local_faces)
         self._local_targets_t = self._local_targets_dev = backend.to_device(self.local_targets)
+        if self.exchange != "sparse":
+            # (the dense exchange scatters the local rows by their global ids -- any row order -- and owns by id chunk)
+            self.ownership, row_owner = "chunk", None
+        self._row_owner = backend.to_device(row_owner) if row_owner is not None else None
         self._setup_sparse_exchange()
         return self
 
@@ -712,20 +787,22 @@ class ShardedOverlapRegridder:
             self._timing.append((t_begin, self._mark()))
         be, mid = self.backend, self.method.method_id
         if kind == "sparse":
-            return be.reduce_rows(mid, buf, self._recv_indptr, self._recv_order, self.t_chunk, kt)
+            return be.reduce_rows(mid, buf, self._recv_indptr, self._recv_order, self.n_out, kt)
         if aux[0] is not None:  # gloo: all_reduce of the whole buffer, own slice
             buf = aux[0][self.dist.get_rank(self.group)]
         return be.finalize(mid, buf)  # (C, kt, chunk) -> (kt, chunk)
 
     def regrid_local(self, local_source):
-        """local (K, S_local) device tensor -> this rank's (K, t_chunk) slice of the result.  The variables go
-        through the exchange in tiles of ``k_tile``: the collective of a tile overlaps the kernel of the next."""
+        """local (K, S_local) device tensor -> this rank's slice of the result: (K, t_chunk) for id-chunk ownership, (K, n_out) in
+        the order of ``owned_targets`` for ``ownership="partition"``.  The variables go through the exchange in tiles of
+        ``k_tile``: the collective of a tile overlaps the kernel of the next."""
         import torch
 
         K = local_source.shape[0]
         if K <= self.k_tile:
             return self._finish_tile(self._start_tile(local_source))
-        out = torch.empty((K, self.t_chunk), dtype=torch.float64, device=local_source.device)
+        out = torch.empty((K, self.n_out if self.exchange == "sparse" else self.t_chunk), dtype=torch.float64,
+                          device=local_source.device)
         pending, k_prev = None, 0
         for k0 in range(0, K, self.k_tile):
             k1 = min(k0 + self.k_tile, K)
@@ -741,9 +818,22 @@ class ShardedOverlapRegridder:
         import torch
 
         squeeze = np.asarray(data).ndim == 1
-        local = self.regrid_local(self.local_source(data))  # (K, chunk)
+        local = self.regrid_local(self.local_source(data))  # (K, chunk) / (K, owned rows)
         if not gather:
             return local
+        if self.ownership == "partition" and self.exchange == "sparse":
+            # slices of different lengths: padded for the gather, scattered to the rows they belong to; a row nobody can give
+            # weight to has no owner and stays NaN (regridder.py:44: the output starts as NaN)
+            K, pad = local.shape[0], max(max(self._out_counts), 1)
+            padded = torch.full((K, pad), float("nan"), dtype=local.dtype, device=local.device)
+            padded[:, : self.n_out] = local
+            parts = [torch.empty_like(padded) for _ in range(self.world)]
+            self.dist.all_gather(parts, padded, group=self.group)
+            out = torch.full((K, self.n_target), float("nan"), dtype=local.dtype, device=local.device)
+            for part, ids, c in zip(parts, self._all_owned, self._out_counts):
+                out[:, ids] = part[:, :c]
+            out = out.cpu().numpy()
+            return out[0] if squeeze else out
         parts = [torch.empty_like(local) for _ in range(self.world)]
         self.dist.all_gather(parts, local, group=self.group)
         out = torch.cat(parts, dim=1)[:, : self.n_target].cpu().numpy()
