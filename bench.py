@@ -337,6 +337,13 @@ def run_single(args):
                 split.setdefault(k, []).append(1e3 * v)
         return t[-1] - t[0], (src_g, tgt_g, rg, res)
 
+    api_times, keep = [], None
+    for _ in range(0 if args.step_only else 6):
+        del keep
+        E.dev_sync()
+        dt, keep = api_once()
+        api_times.append(dt)
+    api_ms = 1e3 * float(np.median(api_times[1:])) if api_times else None
     api_device_ms, api_device_phases, api_device_equal = None, {}, None
     if not args.step_only:
         dev_arrays = tuple(E.DeviceArray.from_host(a) for a in (sxy, sf, txy, tf, data))
@@ -352,13 +359,6 @@ def run_single(args):
         api_device_result = keep_d[3].download()
         del keep_d, dev_arrays
 
-    api_times, keep = [], None
-    for _ in range(0 if args.step_only else 6):
-        del keep
-        E.dev_sync()
-        dt, keep = api_once()
-        api_times.append(dt)
-    api_ms = 1e3 * float(np.median(api_times[1:])) if api_times else None
     api_split = {}
     for _ in range(0 if args.step_only else 3):
         del keep
@@ -536,7 +536,9 @@ def run_single(args):
             "api_note": "xa.OverlapRegridder(xa.Ugrid2d(x, y, -1, faces), xa.Ugrid2d(...), method='mean').regrid(data): host arrays "
             "in, host result out, through the reference-shaped Python classes; median of 5 after a warm-up.  api_phases_ms "
             "(further passes with a synchronisation between the phases): grid wrappers / uploads / constructor = weights / "
-            "regrid = apply + download",
+            "regrid = apply + download.  (3.0-3.7 ms by run: the passes allocate ~150 MB of fresh numpy arrays "
+            "whose first-touch page faults depend on the state of the process heap; a mallopt() that keeps released memory did not "
+            "settle it)",
         },
         "roofline": roofline,
         "cpu_baseline": cpu,
