@@ -57,10 +57,10 @@ def oracle():
 def xr_option():
     """``xr_option(name, value)`` sets a run-time option of the library (include/xugrid_amd.h: xr_set_option) for the rest of the
     test; ``value=None`` puts back what the option held when the test first touched it; everything is restored at teardown.
-    Strings are the words the environment variables of rounds 1-5 took ("old", "major", "free", "csr") or numerals."""
+    Strings are the words the environment variables of rounds 1-5 took ("free", "csr", "device") or numerals."""
     from xugrid_amd import engine
 
-    words = {"old": 1, "major": 1, "free": 1, "csr": 2, "device": 1}
+    words = {"free": 1, "csr": 2, "device": 1}
     initial = {}
 
     def set_option(name, value):

@@ -93,10 +93,11 @@ def test_many_edges_through_few_faces(hip, oracle):
 
 
 def test_every_edge_kernel_path_equals_oracle(hip, oracle, xr_option):
-    """The thread-per-edge passes deal the exact clips out over the wave (default: 48 parking slots per edge); edges with
-    more candidate faces than slots go to the wave-per-edge kernels.  Shallow parking (24) sends many edges there, a tiny
-    big-box threshold nearly all of them, option edge_kernel = 1 ("old") runs the previous kernels: the CSR is the oracle's each time.
-    Edge lengths from far below a cell to a third of the mesh, so that the candidate lists range from 1 to hundreds."""
+    """The walk emits (edge, record) candidates into a flat queue -- a wave's 64 edges share an LDS stage of 1024 entries --
+    and one thread per candidate clips.  A small stage sends the edges of the waves it does not hold to the wave-per-edge
+    kernel, a tiny big-box threshold nearly all edges, a huge one none (a long edge then fills its wave's stage); a queue far
+    too short is regrown from what the cursors counted; with and without the tile sort of the edges: the CSR is the oracle's each time.  Edge lengths from far below a cell
+    to a third of the mesh, so that the candidate lists range from 1 to hundreds."""
     rng = np.random.default_rng(31)
     nodes, faces = meshgen.triangle_mesh(4000, 4)
     lo, hi = nodes.min(), nodes.max()
@@ -104,13 +105,11 @@ def test_every_edge_kernel_path_equals_oracle(hip, oracle, xr_option):
     edges = np.concatenate([random_network(rng, 3000, lo, hi, 0.01 * span), random_network(rng, 2000, lo, hi, 0.06 * span),
                             random_network(rng, 400, lo, hi, 0.3 * span)])
     edges = edges[rng.permutation(edges.shape[0])]
-    # (the wave-per-edge count pass keeps its hits in a pool that the fill pass replays: off, and with a pool far too small --
-    # the edges that are refused, or have more hits than a wave's stage, walk again)
-    settings = [{}, {"edge_deal": 24}, {"edge_deal": 32, "edge_big": 8}, {"edge_deal": 40, "edge_big": 100000},
-                {"edge_kernel": "old"}, {"edge_walk": "major"}, {"edge_pool": 0, "edge_big": 8},
-                {"edge_pool": 700, "edge_big": 8}, {"edge_pool": 1, "edge_deal": 24}]
+    settings = [{}, {"edge_stage": 64}, {"edge_stage": 300, "edge_big": 8}, {"edge_big": 100000}, {"edge_big": 8},
+                {"edge_queue": 1000}, {"edge_queue": 20000, "edge_stage": 128}, {"edge_stage": 1}, {"edge_sort": 0},
+                {"edge_sort": 0, "edge_stage": 100}]
     for options in settings:
-        for k in ("edge_deal", "edge_big", "edge_kernel", "edge_walk", "edge_pool"):
+        for k in ("edge_stage", "edge_big", "edge_queue", "edge_sort"):
             xr_option(k, None)
         for k, v in options.items():
             xr_option(k, v)

@@ -19,9 +19,7 @@
 namespace xr {
 
 static constexpr int EDGE_BIG_CELLS = 64;  // edges whose box covers more grid cells (all levels) get a wave of their own
-static constexpr int EDGE_SLOTS = 6;       // hits per edge the count pass keeps for the fill pass (slot-major side buffer)
-static constexpr int ROW_SORT_SMALL = 16;  // rows up to this length are insertion-sorted by one thread (in global memory: every step waits for the
-                                           // store before it -- at 48 the few rows of 30-48 entries WERE the kernel, 0.23 ms; 16: 0.10)
+static constexpr int ROW_SORT_SMALL = 16;  // rows up to this length are insertion-sorted by one thread (k_edge_rows_sort)
 static constexpr int ROW_SORT_LDS = 4096;  // rows up to this length are sorted in LDS by one block
 
 // a + t (b - a), t in [0, 1], against every half-plane of the CCW polygon.  -> length of the clipped piece, or -1;
@@ -95,30 +93,14 @@ __device__ __forceinline__ int64_t edge_cells(const EdgeBox &q, const GridParams
     return total;
 }
 
-// the records of one grid cell against the edge's f32 box: CAND(record) for every record that passes.  The exact clip
-// (edge_test) is NOT run from here by the thread-per-edge kernels: they park the candidates in LDS and clip them
-// afterwards in a loop all lanes of a wave step through together (a clip is ~150 instructions with a division per face
-// side; run from inside the walk, every lane that found a candidate made the whole wave execute it).
+// the records [r0, r1) of a run of grid cells against the edge's f32 box: CAND(record) for every record that passes
 template <typename Cand>
-__device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, const float4 *__restrict__ rbb,
-                                          const double *__restrict__, const uint8_t *__restrict__, const int32_t *__restrict__,
-                                          int, const int32_t *__restrict__, Cand &&cand) {
+__device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, const float4 *__restrict__ rbb, Cand &&cand) {
     for (int r = r0; r < r1; r++) {
         const float4 bb = rbb[r];
         if (box_gap(bb, q.qx0, q.qx1, q.qy0, q.qy1) <= 0.0f) cand(r);
     }
 }
-
-// exact clip of the edge against record r; HIT(face id, length) for a piece of positive length
-template <typename Hit>
-__device__ __forceinline__ void edge_test(const EdgeBox &q, int r, const double *__restrict__ rec_fxy,
-                                          const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
-                                          const int32_t *__restrict__ rec_face, Hit &&hit) {
-    const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, r, m), rec_len[r], q.a, q.b);
-    if (len > 0.0) hit(rec_face[r], len); // (a degenerate piece of zero length is no intersection)
-}
-
-static constexpr int EDGE_PARK = 16; // candidates parked per edge; further ones are clipped on the spot
 
 // The walk along an edge.  Per level the cells along the edge's MAJOR axis are visited; for each of them the piece
 // of the segment inside the slab of that cell's records ([origin, origin + 2 h): a record starts in its cell and is
@@ -173,71 +155,53 @@ __device__ __forceinline__ void edge_minor_range(const EdgeWalk &w, int cm, doub
     if (kb > o1) kb = o1;
 }
 
-// one thread walks the whole edge (BLOCK = false), or the 64 lanes of a wave share it (BLOCK = true)
-template <bool BLOCK, typename Hit>
-__device__ __forceinline__ void edge_walk(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
-                                          const float4 *__restrict__ rbb, const double *__restrict__ rec_fxy,
-                                          const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
-                                          const int32_t *__restrict__ rec_face, Hit &&hit) {
+// the 64 lanes of a wave share one (long) edge: lane i takes items i, i + 64, ... of every level's (major cell, minor
+// residue) list.  SYNC() is called by all lanes together after every round of 64 items (the wave flushes its stage there).
+template <typename Cand, typename Sync>
+__device__ __forceinline__ void edge_walk_wave(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
+                                               const float4 *__restrict__ rbb, Cand &&cand, Sync &&sync) {
     constexpr int MINOR_W = 6;
     const EdgeWalk w = edge_walk_setup(q, g);
+    const int lane = threadIdx.x & 63;
     for (int l = 0; l < g.n_levels; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], ny = g.ny[l], base = g.base[l];
+        if (cell_start[base] == cell_start[base + nx * ny]) continue; // (a level without records; uniform)
         const int n_maj = w.xmajor ? nx : ny, n_min = w.xmajor ? ny : nx;
         const int c0 = cell_coord(w.lo_maj - h, w.org_maj, inv_h, n_maj), c1 = cell_coord(w.hi_maj, w.org_maj, inv_h, n_maj);
         const int o0 = cell_coord(w.lo_min - h, w.org_min, inv_h, n_min), o1 = cell_coord(w.hi_min, w.org_min, inv_h, n_min);
-        if (BLOCK) {
-            const int64_t work = (int64_t)(c1 - c0 + 1) * MINOR_W;
-            for (int64_t c = threadIdx.x & 63; c < work; c += 64) {
+        const int64_t work = (int64_t)(c1 - c0 + 1) * MINOR_W;
+        for (int64_t c_first = 0; c_first < work; c_first += 64) { // (wave-uniform)
+            const int64_t c = c_first + lane;
+            if (c < work) {
                 const int cm = c0 + (int)(c / MINOR_W), k = (int)(c % MINOR_W);
                 int ka, kb;
                 edge_minor_range(w, cm, h, inv_h, n_maj, n_min, o0, o1, ka, kb);
                 for (int cn = ka + k; cn <= kb; cn += MINOR_W) {
                     const int cx = w.xmajor ? cm : cn, cy = w.xmajor ? cn : cm;
                     const int r0 = cell_start[base + cy * nx + cx], r1 = cell_start[base + cy * nx + cx + 1];
-                    if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
+                    if (r0 != r1) edge_cell(q, r0, r1, rbb, cand);
                 }
             }
-        } else {
-            for (int cm = c0; cm <= c1; cm++) {
-                int ka, kb;
-                edge_minor_range(w, cm, h, inv_h, n_maj, n_min, o0, o1, ka, kb);
-                if (ka > kb) continue;
-                if (w.xmajor) { // the minor cells of one major cell are cy = ka..kb at fixed cx: separate runs
-                    for (int cy = ka; cy <= kb; cy++) {
-                        const int r0 = cell_start[base + cy * nx + cm], r1 = cell_start[base + cy * nx + cm + 1];
-                        if (r0 != r1) edge_cell(q, r0, r1, rbb, rec_fxy, rec_len, rec_off, m, rec_face, hit);
-                    }
-                } else { // cells cx = ka..kb of row cm are one contiguous record run
-                    edge_cell(q, cell_start[base + cm * nx + ka], cell_start[base + cm * nx + kb + 1], rbb, rec_fxy, rec_len, rec_off,
-                              m, rec_face, hit);
-                }
-            }
+            sync();
         }
     }
 }
 
 // all grid cells of the edge's box, level by level (short edges: a handful of cells, no per-cell arithmetic)
-template <typename Hit>
+template <typename Cand>
 __device__ __forceinline__ void edge_walk_box(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
-                                              const float4 *__restrict__ rbb, const double *__restrict__ rec_fxy,
-                                              const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off, int m,
-                                              const int32_t *__restrict__ rec_face, Hit &&hit) {
+                                              const float4 *__restrict__ rbb, Cand &&cand) {
     for (int l = 0; l < g.n_levels; l++) {
         const double h = level_h(g, l), inv_h = level_inv_h(g, l);
         const int nx = g.nx[l], base = g.base[l];
         const int cx0 = cell_coord(q.xmin - h, g.x0, inv_h, nx), cx1 = cell_coord(q.xmax, g.x0, inv_h, nx);
         const int cy0 = cell_coord(q.ymin - h, g.y0, inv_h, g.ny[l]), cy1 = cell_coord(q.ymax, g.y0, inv_h, g.ny[l]);
         for (int cy = cy0; cy <= cy1; cy++)
-            edge_cell(q, cell_start[base + cy * nx + cx0], cell_start[base + cy * nx + cx1 + 1], rbb, rec_fxy, rec_len, rec_off, m,
-                      rec_face, hit);
+            edge_cell(q, cell_start[base + cy * nx + cx0], cell_start[base + cy * nx + cx1 + 1], rbb, cand);
     }
 }
 
-// pass 1, one thread per edge: count the hits per face; the first EDGE_SLOTS hits of every edge are kept in a
-// slot-major side buffer so that the fill pass need not walk the grid again.  Edges with more hits are queued for
-// a second walk (redo_list), edges whose box spans many cells for the block-per-edge kernels (big_list).
 // append `item` to a list for the lanes with `flag`: one returning atomic per wave instead of one per lane
 // (every lane of the wave that is still active must call this together)
 __device__ __forceinline__ void wave_append(bool flag, int32_t item, int32_t *__restrict__ list,
@@ -252,334 +216,272 @@ __device__ __forceinline__ void wave_append(bool flag, int32_t item, int32_t *__
     if (flag) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = item;
 }
 
-template <bool MAJOR_WALK>
+
+// ---- the pipeline: walk -> flat candidate queue -> clip -> scan -> fill -> row sort -------------------------------------
+// Until round 5 the thread-per-edge pass walked the grid, parked up to 48 candidates per edge in LDS (50 KB a block: three
+// blocks per CU for a kernel that is a chain of dependent loads), dealt the Cyrus-Beck clips of a wave's 64 edges out over its
+// lanes, kept six hits per edge in a side buffer and sent edges with more hits through the whole walk a second time; long edges
+// had a wave each that walked AND clipped.  Round 6: the walk only EMITS (edge, record) candidates into a flat queue -- a wave's
+// 64 edges share one LDS stage of 1024 entries (20 KB a block), so an edge may have hundreds of candidates as long as its wave
+// stays under the stage -- and one thread per CANDIDATE clips: perfectly balanced, no slots, no second walk, no hit pool.  The
+// clip leaves (edge, face, length) in the queue entry itself; after the scan of the row counts the fill pass runs over the queue
+// once more.  1M edges of exponentially distributed length over 1M triangles: device part 1.56 -> see DESIGN ms.
+static constexpr int EDGE_STAGE = 1024;     // candidates a wave of 64 edges may stage (16 per edge on average)
+static constexpr int EDGE_BIG_STAGE = 2048; // candidates one long edge stages between two flushes
+static constexpr int EQ_STRIDE = 32;        // words between the eight region cursors: a 128-byte line each
+// counters: [0] wave-per-edge list length, [1] rows to sort (k_edge_rows_sort), [2] bit 0: a queue region overflowed,
+// [8 + x * EQ_STRIDE] cursor of queue region x
+static constexpr int EQ_CURSORS = 8;
+static constexpr int EQ_WORDS = EQ_CURSORS + 8 * EQ_STRIDE;
+
+// reserve n entries of region x; -> first entry, or -1 (overflow: the flag is set, the host regrows the queue and starts over)
+__device__ __forceinline__ int64_t queue_reserve(int32_t *__restrict__ counters, int x, int n, int64_t region_cap) {
+    const int32_t b = atomicAdd(&counters[EQ_CURSORS + x * EQ_STRIDE], n);
+    if (b < 0 || (int64_t)b + n > region_cap) {
+        atomicOr(&counters[2], 1);
+        return -1;
+    }
+    return (int64_t)x * region_cap + b;
+}
+
+// pass 0: the edges in a spatially coherent order.  A network's edges come in any order (the benchmark's are random): the 64
+// edges of a wave then walk 64 different neighbourhoods of the grid, the clips of a wave gather 64 unrelated faces and the
+// fill scatters into 64 unrelated rows.  Counting sort by the tile (EDGE_TILE x EDGE_TILE level-0 cells) of the edge's
+// midpoint: histogram, scan, scatter of the edge ids -- the walk then takes edge perm[i].  The order inside a tile is whatever
+// the atomics make it; no result depends on it (rows are ordered by edge id at the end).
+static constexpr int EDGE_TILE = 4;
+__device__ __forceinline__ int edge_tile(const double *__restrict__ edge_xy, int64_t e, const GridParams &g, int ntx) {
+    const P2 a = load_p2(edge_xy, (int)(2 * e)), b = load_p2(edge_xy, (int)(2 * e + 1));
+    const int cx = cell_coord(0.5 * (a.x + b.x), g.x0, g.inv_h0, g.nx[0]), cy = cell_coord(0.5 * (a.y + b.y), g.y0, g.inv_h0, g.ny[0]);
+    return (cy / EDGE_TILE) * ntx + cx / EDGE_TILE; // (NaN coordinates: cell 0)
+}
 __global__ void __launch_bounds__(256)
-k_edges_count(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const int32_t *__restrict__ cell_start,
-              const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
-              int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
-              int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
-              int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
-              double *__restrict__ side_len, int big_cells) {
-    __shared__ int32_t sh_park[EDGE_PARK][256];
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const bool live = e < n_edge;
-    EdgeBox q{};
-    bool walk = false, big = false;
+k_edge_tile_count(const double *__restrict__ edge_xy, int64_t n_edge, int64_t e_base, GridParams g, int ntx,
+                  int32_t *__restrict__ tile_of, int32_t *__restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_edge) return;
+    const int t = edge_tile(edge_xy, e_base + i, g, ntx);
+    // (the returning atomic gives the edge its rank inside the tile: the scatter needs no second one)
+    reinterpret_cast<int2 *>(tile_of)[i] = make_int2(t, atomicAdd(hist + t, 1));
+}
+__global__ void __launch_bounds__(256)
+k_edge_tile_scatter(const int32_t *__restrict__ tile_of, int64_t n_edge, int64_t e_base, const int32_t *__restrict__ start,
+                    int32_t *__restrict__ perm) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_edge) return;
+    const int2 tr = reinterpret_cast<const int2 *>(tile_of)[i];
+    perm[start[tr.x] + tr.y] = (int32_t)(e_base + i);
+}
+
+// pass 1, one thread per edge: walk the boxes of all levels, stage the candidates of the wave's 64 edges in LDS, then write
+// the block's candidates as one stretch of the queue (ONE reservation per block).  Edges whose box spans many cells, and the
+// edges of a wave whose stage ran full, are listed for the wave-per-edge kernel (their staged candidates are dropped: edge -1).
+__global__ void __launch_bounds__(256)
+k_edge_walk(const double *__restrict__ edge_xy, int64_t n_edge, int64_t e_base, GridParams g, const int32_t *__restrict__ cell_start,
+            const float *__restrict__ rec_bb, int2 *__restrict__ queue, int64_t region_cap, int32_t *__restrict__ counters,
+            int32_t *__restrict__ big_list, int big_cells, int stage_cap /* <= EDGE_STAGE (test hook: a tiny stage) */,
+            const int32_t *__restrict__ perm /* optional: item i is edge perm[i] (k_edge_tile_scatter) instead of e_base + i */) {
+    __shared__ int32_t sh_rec[4][EDGE_STAGE];
+    __shared__ uint8_t sh_own[4][EDGE_STAGE];
+    __shared__ int32_t sh_edge[256];
+    __shared__ int32_t sh_n[4];
+    __shared__ long long sh_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 256 + tid;
+    const bool live = i < n_edge;
+    const int64_t e = !live ? 0 : perm ? (int64_t)perm[i] : e_base + i;
+    sh_edge[tid] = (int32_t)e;
+    if (lane == 0) sh_n[wv] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    bool big = false, over = false;
     if (live) {
-        q = load_edge(edge_xy, e, g);
+        const EdgeBox q = load_edge(edge_xy, e, g);
         const bool finite = q.xmin == q.xmin && q.ymin == q.ymin && q.xmax == q.xmax && q.ymax == q.ymax; // no NaN
         big = finite && edge_cells(q, g) > big_cells;
-        walk = finite && !big;
-    }
-    int nh = 0;
-    if (walk) {
-        auto hit = [&](int face, double len) {
-            atomicAdd(row_count + face, 1);
-            if (nh < EDGE_SLOTS) {
-                side_face[(int64_t)nh * n_edge + e] = face;
-                side_len[(int64_t)nh * n_edge + e] = len;
-            }
-            nh++;
-        };
-        const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-        int np = 0;
-        auto park = [&](int r) {
-            if (np < EDGE_PARK) sh_park[np][threadIdx.x] = r;
-            else edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit);
-            np++;
-        };
-        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
-        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
-        const int parked = np < EDGE_PARK ? np : EDGE_PARK;
-        for (int k = 0; k < parked; k++) edge_test(q, sh_park[k][threadIdx.x], rec_fxy, rec_len, rec_off, m, rec_face, hit);
-    }
-    const bool redo = nh > EDGE_SLOTS;
-    wave_append(big, (int32_t)e, big_list, n_big);
-    wave_append(redo, (int32_t)e, redo_list, n_redo);
-    if (live) edge_hits[e] = redo ? 0 : nh;
-}
-
-// ---- thread-per-edge passes with the exact clips dealt out over the wave ------------------------------------------
-// Diagnosis (1M edges of exponentially distributed length over 1M triangles, variants of k_edges_count): the walk alone
-// takes 0.35 of the count pass's 0.98 ms; the rest are the Cyrus-Beck clips (~135 vector instructions each).  An edge has
-// ~10 candidate faces on average but the longest of a wave 30-40, and a loop "clip my candidates" -- worse, the clips
-// made on the spot once an edge's 16 parking slots were full -- makes the whole wave step through the longest lists one
-// after the other.  Here the walk only PARKS (EDGE_DEAL slots per edge); the wave then treats the parked candidates of its
-// 64 edges as ONE list and lane i clips items i, i + 64, ... (owner lane by a binary search over the wave's running
-// counts, its edge by a cross-lane read; a hit takes the owner's next slot by an LDS atomic).  Edges with more candidates
-// than slots go to the wave-per-edge kernels (big_list), which deal an edge's candidates over the lanes by construction.
-// FILL = false: count pass; FILL = true: the listed (redo) edges write their rows.  EDGE_DEAL: parking slots per edge.
-template <bool FILL, int EDGE_DEAL>
-__global__ void __launch_bounds__(256)
-k_edges_deal(const double *__restrict__ edge_xy, int64_t n_edge, GridParams g, const int32_t *__restrict__ cell_start,
-             const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
-             const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
-             int32_t *__restrict__ big_list, int32_t *__restrict__ n_big, int32_t *__restrict__ redo_list,
-             int32_t *__restrict__ n_redo, int32_t *__restrict__ edge_hits, int32_t *__restrict__ side_face,
-             double *__restrict__ side_len, int big_cells, const int32_t *__restrict__ indptr, int32_t *__restrict__ indices,
-             double *__restrict__ data, const int32_t *__restrict__ todo_list, const int32_t *__restrict__ n_todo,
-             int64_t e_base = 0 /* count pass over a PIECE of the edges: item i is edge e_base + i (n_edge = the piece's length; edge_xy
-                                  and every per-edge output stay indexed by the edge's own id) */,
-             int64_t n_edge_all = 0 /* ... and the number of ALL edges, the stride of the slot-major side buffers (0: n_edge) */) {
-    __shared__ int32_t sh_park[EDGE_DEAL][256];
-    __shared__ int32_t sh_hits[256];
-    const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-    const int tid = threadIdx.x, lane = tid & 63, wbase = tid & ~63;
-    const int64_t n_items = FILL ? (int64_t)*n_todo : n_edge;
-    const int64_t side_stride = n_edge_all > 0 ? n_edge_all : n_edge;
-    const int64_t n_rounded = (n_items + 255) / 256 * 256; // (every lane of a wave takes part in the cross-lane reads)
-    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n_rounded; i += (int64_t)gridDim.x * 256) {
-        const bool live = i < n_items;
-        const int64_t e = live ? (FILL ? (int64_t)todo_list[i] : e_base + i) : 0;
-        EdgeBox q{};
-        bool walk = false, big = false;
-        if (live) {
-            q = load_edge(edge_xy, e, g);
-            const bool finite = q.xmin == q.xmin && q.ymin == q.ymin && q.xmax == q.xmax && q.ymax == q.ymax; // no NaN
-            big = !FILL && finite && edge_cells(q, g) > big_cells;
-            walk = finite && !big;
-        }
-        sh_hits[tid] = 0;
-        int np = 0;
-        if (walk) {
-            auto park = [&](int r) {
-                sh_park[np < EDGE_DEAL ? np : EDGE_DEAL - 1][tid] = r;
-                np++;
-            };
-            edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
-        }
-        // (FILL: the listed edges had at most EDGE_DEAL candidates in the count pass -- the same walk)
-        if (np > EDGE_DEAL) {
-            big = !FILL;
-            np = 0;
-        }
-        int incl = np;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int v = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += v;
-        }
-        const int total = __shfl(incl, 63, 64);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int first = 0; first < total; first += 64) { // (wave-uniform)
-            const int item = first + lane;
-            const bool has = item < total;
-            int lo = 0, hi = 63; // owner = first lane whose running count exceeds the item
-#pragma unroll
-            for (int step = 0; step < 6; step++) {
-                const int mid = (lo + hi) >> 1;
-                const int v = __shfl(incl, mid, 64);
-                if (v > item) hi = mid;
-                else lo = mid + 1;
-            }
-            const int ol = has ? lo : 0;
-            const int slot = item - (__shfl(incl, ol, 64) - __shfl(np, ol, 64));
-            const P2 a{__shfl(q.a.x, ol, 64), __shfl(q.a.y, ol, 64)}, b{__shfl(q.b.x, ol, 64), __shfl(q.b.y, ol, 64)};
-            const long long e_owner = __shfl((long long)e, ol, 64);
-            if (has) {
-                const int rr = sh_park[slot][wbase + ol];
-                const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, rr, m), rec_len[rr], a, b);
-                if (len > 0.0) { // (a degenerate piece of zero length is no intersection)
-                    const int face = rec_face[rr];
-                    const int k_row = atomicAdd(row_count + face, 1);
-                    if (FILL) {
-                        indices[indptr[face] + k_row] = (int32_t)e_owner;
-                        data[indptr[face] + k_row] = len;
-                    } else {
-                        const int k_edge = atomicAdd(&sh_hits[wbase + ol], 1);
-                        if (k_edge < EDGE_SLOTS) {
-                            side_face[(int64_t)k_edge * side_stride + e_owner] = face;
-                            side_len[(int64_t)k_edge * side_stride + e_owner] = len;
-                        }
-                    }
+        if (finite && !big) {
+            auto cand = [&](int r) {
+                const int k = atomicAdd(&sh_n[wv], 1);
+                if (k < stage_cap) {
+                    sh_rec[wv][k] = r;
+                    sh_own[wv][k] = (uint8_t)lane;
+                } else {
+                    over = true;
                 }
-            }
+            };
+            edge_walk_box(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), cand);
         }
+    }
+    // (an edge that met a full stage may have candidates missing: it walks again in the wave kernel)
+    const unsigned long long dropped = __ballot(over);
+    wave_append(live && (big || over), (int32_t)e, big_list, counters);
+    __syncthreads();
+    int n_w[4], total = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        n_w[w] = sh_n[w] < stage_cap ? sh_n[w] : stage_cap;
+        total += n_w[w];
+    }
+    if (tid == 0) sh_base = total > 0 ? (long long)queue_reserve(counters, blockIdx.x & 7, total, region_cap) : -1;
+    __syncthreads();
+    const long long base = sh_base;
+    if (base < 0) return;
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) woff += w < wv ? n_w[w] : 0;
+    for (int k = lane; k < n_w[wv]; k += 64) {
+        const int owner = sh_own[wv][k];
+        queue[base + woff + k] = make_int2(((dropped >> owner) & 1ull) ? -1 : sh_edge[wv * 64 + owner], sh_rec[wv][k]);
+    }
+}
+
+// pass 1b, long edges (and the edges of the waves whose stage ran full): one wave per edge walks the cells along the segment's
+// major axis and stages the candidates; the stage is flushed -- one reservation -- whenever it is half full at the end of a
+// round of 64 cells, and at the edge's end.  A candidate that meets a full stage in the middle of a round reserves its own entry.
+__global__ void __launch_bounds__(256)
+k_edge_walk_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
+                const float *__restrict__ rec_bb, int2 *__restrict__ queue, int64_t region_cap, int32_t *__restrict__ counters,
+                const int32_t *__restrict__ big_list) {
+    __shared__ int32_t sh_rec[4][EDGE_BIG_STAGE];
+    __shared__ int32_t sh_n[4];
+    const int nb = counters[0], wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int x = blockIdx.x & 7;
+    auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (!FILL) {
-            const int nh = sh_hits[tid];
-            const bool redo = nh > EDGE_SLOTS;
-            wave_append(big, (int32_t)e, big_list, n_big);
-            wave_append(redo, (int32_t)e, redo_list, n_redo);
-            if (live) edge_hits[e] = redo ? 0 : nh;
-        }
-    }
-}
-
-// pass 2a: the kept hits go to their rows (arbitrary order within a row)
-__global__ void __launch_bounds__(256)
-k_edges_replay(int64_t n_edge, const int32_t *__restrict__ edge_hits, const int32_t *__restrict__ side_face,
-               const double *__restrict__ side_len, int32_t *__restrict__ row_count,
-               const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_edge) return;
-    const int nh = edge_hits[e];
-    for (int k = 0; k < nh; k++) {
-        const int face = side_face[(int64_t)k * n_edge + e];
-        const int pos = indptr[face] + atomicAdd(row_count + face, 1);
-        indices[pos] = (int32_t)e;
-        data[pos] = side_len[(int64_t)k * n_edge + e];
-    }
-}
-
-// pass 2b: the edges with more than EDGE_SLOTS hits walk the grid once more
-template <bool MAJOR_WALK>
-__global__ void __launch_bounds__(256)
-k_edges_redo(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
-             const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
-             int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
-             const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
-             const int32_t *__restrict__ redo_list, const int32_t *__restrict__ n_redo) {
-    __shared__ int32_t sh_park[EDGE_PARK][256];
-    const int n = *n_redo;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int64_t e = redo_list[i];
-        const EdgeBox q = load_edge(edge_xy, e, g);
-        auto hit = [&](int face, double len) {
-            const int pos = indptr[face] + atomicAdd(row_count + face, 1);
-            indices[pos] = (int32_t)e;
-            data[pos] = len;
-        };
-        const float4 *__restrict__ rbb = reinterpret_cast<const float4 *>(rec_bb);
-        int np = 0;
-        auto park = [&](int r) {
-            if (np < EDGE_PARK) sh_park[np][threadIdx.x] = r;
-            else edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit);
-            np++;
-        };
-        if (MAJOR_WALK) edge_walk<false>(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
-        else edge_walk_box(q, g, cell_start, rbb, rec_fxy, rec_len, rec_off, m, rec_face, park);
-        const int parked = np < EDGE_PARK ? np : EDGE_PARK;
-        for (int k = 0; k < parked; k++) edge_test(q, sh_park[k][threadIdx.x], rec_fxy, rec_len, rec_off, m, rec_face, hit);
-    }
-}
-
-// long edges: one wave per edge
-template <bool FILL>
-__global__ void __launch_bounds__(256)
-k_edges_big(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
-            const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len, const int32_t *__restrict__ rec_off,
-            int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
-            const int32_t *__restrict__ indptr, int32_t *__restrict__ indices, double *__restrict__ data,
-            const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big) {
-    const int nb = *n_big;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nb; i += gridDim.x * 4) {
-        const int64_t e = big_list[i];
-        const EdgeBox q = load_edge(edge_xy, e, g);
-        auto hit = [&](int face, double len) {
-            const int k = atomicAdd(row_count + face, 1);
-            if (FILL) {
-                indices[indptr[face] + k] = (int32_t)e;
-                data[indptr[face] + k] = len;
-            }
-        };
-        auto cand = [&](int r) { edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit); };
-        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, rec_off, m, rec_face, cand);
-    }
-}
-
-// Count pass of the wave-per-edge kernels that KEEPS its hits: the lanes append (face, length) to a stage of their wave in
-// LDS; when the edge is done the wave reserves a stretch of the hit pool with one atomic and copies the stage out.  The
-// fill pass is then a replay of the pool (one thread per hit) instead of a second walk over the long edges.  Edges with
-// more hits than the stage holds, or that find the pool full, are listed for the walking fill pass (k_edges_big<true>).
-static constexpr int BIG_STAGE_HITS = 256;
-struct EdgeHit {
-    int32_t edge, face;
-    double len;
-};
-
-__global__ void __launch_bounds__(256)
-k_edges_big_pool(const double *__restrict__ edge_xy, GridParams g, const int32_t *__restrict__ cell_start,
-                 const float *__restrict__ rec_bb, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
-                 const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int32_t *__restrict__ row_count,
-                 const int32_t *__restrict__ big_list, const int32_t *__restrict__ n_big, EdgeHit *__restrict__ pool,
-                 int32_t *__restrict__ pool_cursor /* [0] cursor, [1] capacity - first refused base (0: none refused) */, int pool_cap,
-                 int32_t *__restrict__ walk_list, int32_t *__restrict__ n_walk) {
-    __shared__ int32_t sh_face[4][BIG_STAGE_HITS];
-    __shared__ double sh_len[4][BIG_STAGE_HITS];
-    __shared__ int32_t sh_n[4];
-    const int nb = *n_big, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    };
     for (int i = blockIdx.x * 4 + wv; i < nb; i += gridDim.x * 4) { // (wave-uniform)
-        const int64_t e = big_list[i];
+        const int32_t e = big_list[i];
         const EdgeBox q = load_edge(edge_xy, e, g);
         if (lane == 0) sh_n[wv] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        auto hit = [&](int face, double len) {
-            atomicAdd(row_count + face, 1);
+        wave_sync();
+        auto flush = [&](int at_least) {
+            wave_sync();
+            const int n = sh_n[wv] < EDGE_BIG_STAGE ? sh_n[wv] : EDGE_BIG_STAGE;
+            if (n < at_least) return; // (uniform)
+            long long base = -1;
+            if (lane == 0) base = queue_reserve(counters, x, n, region_cap);
+            base = __shfl(base, 0, 64);
+            if (base >= 0)
+                for (int k = lane; k < n; k += 64) queue[base + k] = make_int2(e, sh_rec[wv][k]);
+            wave_sync();
+            if (lane == 0) sh_n[wv] = 0;
+            wave_sync();
+        };
+        auto cand = [&](int r) {
             const int k = atomicAdd(&sh_n[wv], 1);
-            if (k < BIG_STAGE_HITS) {
-                sh_face[wv][k] = face;
-                sh_len[wv][k] = len;
+            if (k < EDGE_BIG_STAGE) {
+                sh_rec[wv][k] = r;
+            } else {
+                const int64_t pos = queue_reserve(counters, x, 1, region_cap);
+                if (pos >= 0) queue[pos] = make_int2(e, r);
             }
         };
-        auto cand = [&](int r) { edge_test(q, r, rec_fxy, rec_len, rec_off, m, rec_face, hit); };
-        edge_walk<true>(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), rec_fxy, rec_len, rec_off, m, rec_face, cand);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int n = sh_n[wv];
-        int base = -1;
-        if (lane == 0) {
-            if (n <= BIG_STAGE_HITS && n > 0) {
-                const int b = atomicAdd(pool_cursor, n);
-                if (b >= 0 && b <= pool_cap - n) base = b;
-                else if (b >= 0 && b < pool_cap) atomicMax(pool_cursor + 1, pool_cap - b); // (the cursor only grows: every later stretch is refused too)
-            }
-            if (n > 0 && base < 0) walk_list[atomicAdd(n_walk, 1)] = (int32_t)e;
-        }
-        base = __shfl(base, 0, 64);
-        if (base >= 0)
-            for (int k = lane; k < n; k += 64) pool[base + k] = EdgeHit{(int32_t)e, sh_face[wv][k], sh_len[wv][k]};
+        edge_walk_wave(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), cand, [&]() { flush(EDGE_BIG_STAGE / 2); });
+        flush(1);
     }
 }
 
-// fill pass of the pooled hits: the granted stretches are exactly [0, end), end = the base of the first refused stretch
-// (the cursor only grows, so nothing behind a refused stretch is granted) or the cursor itself
+// pass 2, one thread per candidate (persistent grid over the eight queue regions): the exact clip.  A piece of positive length
+// turns the entry into (edge, face) + its length and counts for the face's row; everything else becomes edge -1.
 __global__ void __launch_bounds__(256)
-k_edges_pool_replay(const EdgeHit *__restrict__ pool, const int32_t *__restrict__ pool_cursor, int pool_cap,
-                    int32_t *__restrict__ row_count, const int32_t *__restrict__ indptr, int32_t *__restrict__ indices,
-                    double *__restrict__ data) {
-    const int end = pool_cap - (pool_cursor[1] > 0 ? pool_cursor[1] : 0);
-    const int cur = pool_cursor[0] < 0 ? 0 : pool_cursor[0]; // (a wrapped cursor: nothing was granted after the wrap)
-    const int n = cur < end ? cur : end;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const EdgeHit h = pool[i];
-        const int pos = indptr[h.face] + atomicAdd(row_count + h.face, 1);
-        indices[pos] = h.edge;
-        data[pos] = h.len;
+k_edge_clip(const double *__restrict__ edge_xy, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
+            const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int2 *__restrict__ queue,
+            double *__restrict__ queue_len, int64_t region_cap, const int32_t *__restrict__ counters, int32_t *__restrict__ row_count) {
+    if (counters[2] & 1) return; // (a region overflowed: the host starts over with a longer queue)
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int x = 0; x < 8; x++) {
+        const int64_t n = counters[EQ_CURSORS + x * EQ_STRIDE];
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const int64_t c = (int64_t)x * region_cap + i;
+            const int2 pr = queue[c];
+            if (pr.x < 0) continue;
+            const P2 a = load_p2(edge_xy, 2 * pr.x), b = load_p2(edge_xy, 2 * pr.x + 1);
+            const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, pr.y, m), rec_len[pr.y], a, b);
+            if (len > 0.0) { // (a degenerate piece of zero length is no intersection)
+                const int face = rec_face[pr.y];
+                atomicAdd(row_count + face, 1);
+                queue[c] = make_int2(pr.x, face);
+                queue_len[c] = len;
+            } else {
+                queue[c] = make_int2(-1, 0);
+            }
+        }
     }
 }
 
-// rows ordered by edge id: short rows by one thread each, the others are queued
+// pass 3: the kept entries go to their rows (arbitrary order within a row; k_edge_rows_sort orders them by edge id)
+__global__ void __launch_bounds__(256)
+k_edge_fill(const int2 *__restrict__ queue, const double *__restrict__ queue_len, int64_t region_cap,
+            const int32_t *__restrict__ counters, int32_t *__restrict__ row_fill, const int32_t *__restrict__ indptr,
+            int32_t *__restrict__ indices, double *__restrict__ data) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int x = 0; x < 8; x++) {
+        const int64_t n = counters[EQ_CURSORS + x * EQ_STRIDE];
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const int64_t c = (int64_t)x * region_cap + i;
+            const int2 pr = queue[c];
+            if (pr.x < 0) continue;
+            const int pos = indptr[pr.y] + atomicAdd(row_fill + pr.y, 1);
+            indices[pos] = pr.x;
+            data[pos] = queue_len[c];
+        }
+    }
+}
+
+// rows ordered by edge id: short rows by one thread each, the others are queued.  The rows of a block's 256 faces are one
+// stretch of the CSR: it is staged in LDS (coalesced), every thread insertion-sorts its row there, and the stretch goes back as
+// whole lines.  (Until round 5 the insertion sort ran in global memory, every step waiting for the store before it: 0.097 ms for
+// the 1M rows of the benchmark network; bitonic networks in registers -- 4 / 8 / 16 slots by row length -- took 0.178 ms: nearly
+// every wave holds a row of more than eight entries and runs all three.)
+static constexpr int ROWS_STAGE = 3072; // entries a block stages (36 KB); a denser block sorts in global memory
+template <typename K, typename V>
+__device__ __forceinline__ void row_insertion_sort(K *__restrict__ k, V *__restrict__ v, int n) {
+    for (int i = 1; i < n; i++) {
+        const int32_t key = k[i];
+        const double val = v[i];
+        int j = i - 1;
+        while (j >= 0 && k[j] > key) {
+            k[j + 1] = k[j];
+            v[j + 1] = v[j];
+            j--;
+        }
+        k[j + 1] = key;
+        v[j + 1] = val;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_edge_rows_sort(const int32_t *__restrict__ indptr, int64_t n_face, int32_t *__restrict__ indices,
                  double *__restrict__ data, int32_t *__restrict__ sort_list, int32_t *__restrict__ n_sort,
                  int32_t *__restrict__ long_rows, int32_t *__restrict__ n_long) {
-    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (f >= n_face) return;
-    const int s = indptr[f], e = indptr[f + 1];
-    if (e - s > XR_APPLY_LONG_ROW) long_rows[atomicAdd(n_long, 1)] = (int32_t)f;
-    if (e - s > ROW_SORT_SMALL) {
-        sort_list[atomicAdd(n_sort, 1)] = (int32_t)f;
-        return;
-    }
-    for (int i = s + 1; i < e; i++) {
-        const int key = indices[i];
-        const double val = data[i];
-        int j = i - 1;
-        while (j >= s && indices[j] > key) {
-            indices[j + 1] = indices[j];
-            data[j + 1] = data[j];
-            j--;
+    __shared__ int32_t sh_k[ROWS_STAGE];
+    __shared__ double sh_v[ROWS_STAGE];
+    const int64_t f0 = (int64_t)blockIdx.x * 256, f = f0 + threadIdx.x;
+    const int64_t f1 = f0 + 256 < n_face ? f0 + 256 : n_face;
+    const int s0 = indptr[f0], total = indptr[f1] - s0;
+    const bool staged = total <= ROWS_STAGE; // (uniform)
+    if (staged) {
+        for (int i = threadIdx.x; i < total; i += 256) {
+            sh_k[i] = indices[s0 + i];
+            sh_v[i] = data[s0 + i];
         }
-        indices[j + 1] = key;
-        data[j + 1] = val;
+        __syncthreads();
+    }
+    if (f < n_face) {
+        const int s = indptr[f], n = indptr[f + 1] - s;
+        if (n > XR_APPLY_LONG_ROW) long_rows[atomicAdd(n_long, 1)] = (int32_t)f;
+        if (n > ROW_SORT_SMALL) sort_list[atomicAdd(n_sort, 1)] = (int32_t)f; // (k_edge_rows_sort_big, behind this kernel)
+        else if (staged) row_insertion_sort(sh_k + (s - s0), sh_v + (s - s0), n);
+        else row_insertion_sort(indices + s, data + s, n);
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += 256) {
+        indices[s0 + i] = sh_k[i];
+        data[s0 + i] = sh_v[i];
     }
 }
 
@@ -657,7 +559,7 @@ k_edge_pieces(const int32_t *__restrict__ indptr, const int32_t *__restrict__ in
     }
 }
 
-// edge_xy_dev != nullptr: the end points already live in HBM (xr_edge_length_csr_dev): no upload, one count launch
+// edge_xy_dev != nullptr: the end points already live in HBM (xr_edge_length_csr_dev): no upload, one walk launch
 static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n_edge, xr_csr *csr, const double *edge_xy_dev = nullptr) {
     const int64_t F = tree->n_face;
     csr->n = F;
@@ -674,140 +576,103 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     mesh_prepare(tree, false);
     mesh_build_index(tree);
     DevBuf<double> edge_xy_own((size_t)(edge_xy_dev ? 1 : n_edge * 4));
-    struct { const double *p; const double *get() const { return p; } } edge_xy{edge_xy_dev ? edge_xy_dev : edge_xy_own.get()};
-    DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters(8); // [0] big, [1] rows to sort, [2] redo, [4] pool cursor, [5] its refusal mark, [6] big edges that walk again
-    DevBuf<int32_t> edge_hits((size_t)n_edge), side_face((size_t)n_edge * EDGE_SLOTS), redo_list((size_t)n_edge);
-    DevBuf<double> side_len((size_t)n_edge * EDGE_SLOTS);
-    XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
-    XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * 8, st));
-    // The edge coordinates come from the host (32 bytes per edge: 0.86 ms of PCIe for 1M edges, a third of the whole call).  With the
-    // thread-per-edge count pass -- independent per edge -- the upload goes in the staging pipeline's pieces (4 MiB = 131072 edges)
-    // and the count kernel of what has arrived runs on the side stream while the next pieces are on their way: XR_EDGE_PIPE=0
-    // restores the single upload + single launch (A/B switch).
+    const double *edge_xy = edge_xy_dev ? edge_xy_dev : edge_xy_own.get();
+    DevBuf<int32_t> row_count((size_t)F), big_list((size_t)n_edge), counters((size_t)EQ_WORDS);
     const size_t edge_bytes = sizeof(double) * 4 * (size_t)n_edge;
-    constexpr bool pipe_off = false;
     const GridParams &g = tree->grid;
-    const int big_grid = engine().num_cu * 8;
-    const int big_cells = option(OPT_EDGE_BIG) > 0 ? (int)option(OPT_EDGE_BIG) : EDGE_BIG_CELLS; // test / tuning hook
-    const bool major = option(OPT_EDGE_WALK) != 0; // test / tuning hook
-    const bool deal = !major && option(OPT_EDGE_KERNEL) == 0; // (test / A/B switch)
-    const int deal_slots = (int)option(OPT_EDGE_DEAL); // test / tuning hook: parking slots per edge (24 / 32 / 40 / 48)
-    // count pass of the edges [e0, e0 + ne) with the thread-per-edge kernel
-    auto deal_count = [&](int64_t e0, int64_t ne) {
-#define XR_DEAL_COUNT(P)                                                                                                              \
-    XR_LAUNCH("edges_count", (k_edges_deal<false, P>), dim3(div_up(ne, 256)), dim3(256), 0, edge_xy.get(), ne, g,                      \
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,      \
-              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,             \
-              edge_hits.get(), side_face.get(), side_len.get(), big_cells, (const int32_t *)nullptr, (int32_t *)nullptr,              \
-              (double *)nullptr, (const int32_t *)nullptr, (const int32_t *)nullptr, e0, n_edge)
-        if (deal_slots <= 24) XR_DEAL_COUNT(24);
-        else if (deal_slots <= 32) XR_DEAL_COUNT(32);
-        else if (deal_slots <= 40) XR_DEAL_COUNT(40);
-        else XR_DEAL_COUNT(48);
-#undef XR_DEAL_COUNT
+    const int grid_persistent = engine().num_cu * 8;
+    const int big_cells = option(OPT_EDGE_BIG) > 0 ? (int)option(OPT_EDGE_BIG) : EDGE_BIG_CELLS;                          // test / tuning hook
+    const int stage_cap = option(OPT_EDGE_STAGE) > 0 ? (int)std::min<int64_t>(option(OPT_EDGE_STAGE), EDGE_STAGE) : EDGE_STAGE; // test hook
+    // candidates the queue holds: 16 per edge (the benchmark network has 10) and at least a million; a region that runs full
+    // sets a flag, the clip and the fill do nothing, and everything is redone with a queue as long as the cursors say
+    int64_t queue_pairs = option(OPT_EDGE_QUEUE) > 0 ? option(OPT_EDGE_QUEUE) : std::max<int64_t>(16 * n_edge, (int64_t)1 << 20);
+    // (edges [e0, e0 + ne): tile sort -- histogram, scan, scatter -- then the walk in that order; option edge_sort = 0: as they come)
+    const int ntx = (int)div_up(g.nx[0], EDGE_TILE), n_tiles = ntx * (int)div_up(g.ny[0], EDGE_TILE);
+    const bool sorted = option(OPT_EDGE_SORT) != 0 && n_edge >= 4096;
+    DevBuf<int32_t> tile_of((size_t)(sorted ? 2 * n_edge : 2)), perm((size_t)(sorted ? n_edge : 1)), tile_hist((size_t)(sorted ? n_tiles : 1)),
+        tile_start((size_t)(sorted ? n_tiles + 1 : 1));
+    auto walk = [&](int64_t e0, int64_t ne, int2 *queue, int64_t region_cap) {
+        if (sorted) {
+            XR_HIP(hipMemsetAsync(tile_hist.get(), 0, sizeof(int32_t) * (size_t)n_tiles, launch_stream()));
+            XR_LAUNCH("edges_tile_count", k_edge_tile_count, dim3(div_up(ne, 256)), dim3(256), 0, edge_xy, ne, e0, g, ntx,
+                      tile_of.get() + 2 * e0, tile_hist.get());
+            exclusive_scan_i32(tile_hist.get(), tile_start.get(), n_tiles);
+            XR_LAUNCH("edges_tile_scatter", k_edge_tile_scatter, dim3(div_up(ne, 256)), dim3(256), 0, tile_of.get() + 2 * e0, ne, e0,
+                      tile_start.get(), perm.get() + e0);
+        }
+        XR_LAUNCH("edges_walk", k_edge_walk, dim3(div_up(ne, 256)), dim3(256), 0, edge_xy, ne, e0, g, tree->cell_start.get(),
+                  tree->rec_bb.get(), queue, region_cap, counters.get(), big_list.get(), big_cells, stage_cap,
+                  sorted ? perm.get() + e0 : (const int32_t *)nullptr);
     };
-    constexpr size_t pipe_bytes = (size_t)16 << 20; // (launches of 16 MB: smaller ones lose to their tails what the overlap gains)
-    const bool piped = !edge_xy_dev && deal && !pipe_off && edge_bytes >= pipe_bytes + ((size_t)4 << 20) && !current_lane() && !stream_override();
-    if (piped) {
-        // fill(pinned, off, n) is called for piece k BEFORE its DMA is enqueued, i.e. right after the DMA of piece k - 1 was: the
-        // count kernel of piece k - 1 is forked behind that DMA (SideScope) and runs beside the DMA of piece k
-        const char *src_bytes = reinterpret_cast<const char *>(edge_xy_host);
-        size_t done = 0; // bytes whose DMA has been enqueued
-        auto count_upto = [&](size_t upto, bool last = false) {
-            // (launches of pipe_bytes of coordinates: a launch ends with its slowest waves and at three 50 KB blocks per CU a small
-            // grid is a round and a third -- 131072 edges per launch took 142 us each against 95 us for an eighth of the single
-            // launch, 262144 took 265 us: what the overlap gained the tails lost.  Half a million edges per launch by default.)
-            if (upto <= done || (!last && upto - done < pipe_bytes)) return;
-            SideScope side;
-            deal_count((int64_t)(done / 32), (int64_t)((upto - done) / 32));
-            done = upto;
-        };
-        h2d_staged(edge_xy_own.get(), edge_bytes, [&](char *pinned, size_t off, size_t n) {
-            count_upto(off);
-            parallel_ranges(n, 64, [=](size_t b, size_t e) { memcpy(pinned + b, src_bytes + off + b, e - b); });
-        });
-        count_upto(edge_bytes, true);
-        side_join();
-    } else if (!edge_xy_dev) {
-        h2d(edge_xy_own.get(), edge_xy_host, edge_bytes);
+    bool uploaded = edge_xy_dev != nullptr;
+    for (int attempt = 0;; attempt++) {
+        XR_REQUIRE(attempt < 6, XR_ERR_LIMIT, "xr_edge_length_csr: the candidate queue does not fit");
+        const int64_t region_cap = (div_up(queue_pairs, 8) + 63) / 64 * 64;
+        XR_REQUIRE(region_cap < ((int64_t)1 << 30), XR_ERR_LIMIT, "xr_edge_length_csr: too many candidate pairs");
+        DevBuf<int2> queue((size_t)(8 * region_cap));
+        DevBuf<double> queue_len((size_t)(8 * region_cap));
+        XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
+        XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * (size_t)EQ_WORDS, st));
+        // The edge coordinates come from the host (32 bytes per edge: 0.86 ms of PCIe for 1M edges).  The walk is independent per
+        // edge, so the upload goes in the staging pipeline's pieces and the walk of what has arrived runs on the side stream while
+        // the next pieces are on their way (launches of 16 MB of coordinates: smaller ones lose to their tails what the overlap gains).
+        constexpr size_t pipe_bytes = (size_t)16 << 20;
+        const bool piped = !uploaded && edge_bytes >= pipe_bytes + ((size_t)4 << 20) && !current_lane() && !stream_override();
+        if (piped) {
+            // fill(pinned, off, n) is called for piece k BEFORE its DMA is enqueued, i.e. right after the DMA of piece k - 1 was: the
+            // walk of piece k - 1 is forked behind that DMA (SideScope) and runs beside the DMA of piece k
+            const char *src_bytes = reinterpret_cast<const char *>(edge_xy_host);
+            size_t done = 0; // bytes whose walk has been enqueued
+            auto walk_upto = [&](size_t upto, bool last = false) {
+                if (upto <= done || (!last && upto - done < pipe_bytes)) return;
+                SideScope side;
+                walk((int64_t)(done / 32), (int64_t)((upto - done) / 32), queue.get(), region_cap);
+                done = upto;
+            };
+            h2d_staged(edge_xy_own.get(), edge_bytes, [&](char *pinned, size_t off, size_t n) {
+                walk_upto(off);
+                parallel_ranges(n, 64, [=](size_t b, size_t e) { memcpy(pinned + b, src_bytes + off + b, e - b); });
+            });
+            walk_upto(edge_bytes, true);
+            side_join();
+        } else {
+            if (!uploaded) h2d(edge_xy_own.get(), edge_xy_host, edge_bytes);
+            walk(0, n_edge, queue.get(), region_cap);
+        }
+        uploaded = true;
+        XR_LAUNCH("edges_walk_big", k_edge_walk_big, dim3(grid_persistent), dim3(256), 0, edge_xy, g, tree->cell_start.get(),
+                  tree->rec_bb.get(), queue.get(), region_cap, counters.get(), big_list.get());
+        XR_LAUNCH("edges_clip", k_edge_clip, dim3(grid_persistent), dim3(256), 0, edge_xy, tree->rec_fxy.get(), tree->rec_len.get(),
+                  tree->record_off(), tree->m, tree->rec_face.get(), queue.get(), queue_len.get(), region_cap, counters.get(),
+                  row_count.get());
+        exclusive_scan_i32(row_count.get(), csr->indptr.get(), F);
+        int32_t c[EQ_WORDS];
+        d2h(c, counters.get(), sizeof(c));
+        int64_t longest = 0, pairs = 0;
+        for (int x = 0; x < 8; x++) {
+            const int64_t n = c[EQ_CURSORS + x * EQ_STRIDE] < 0 ? ((int64_t)1 << 31) : c[EQ_CURSORS + x * EQ_STRIDE];
+            longest = std::max(longest, n);
+            pairs += n;
+        }
+        if (c[2] & 1) { // (the cursors kept counting: they say what the regions need)
+            queue_pairs = std::max(2 * queue_pairs, 8 * (longest + longest / 8 + 1024));
+            continue;
+        }
+        const int32_t P = read_scalar(csr->indptr.get() + F);
+        XR_REQUIRE(P >= 0, XR_ERR_LIMIT, "nnz exceeds the int32 range");
+        if (option(OPT_DEBUG) & 8)
+            fprintf(stderr, "[edges] %lld edges: %d with a wave of their own, %lld candidate pairs (queue %lld), nnz %d\n",
+                    (long long)n_edge, c[0], (long long)pairs, (long long)(8 * region_cap), P);
+        csr->nnz = P;
+        csr->indices.alloc((size_t)P);
+        csr->data.alloc((size_t)P);
+        if (P == 0) return;
+        XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
+        XR_LAUNCH("edges_fill", k_edge_fill, dim3(grid_persistent), dim3(256), 0, queue.get(), queue_len.get(), region_cap,
+                  counters.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
+        break;
     }
-    if (piped) {
-    } else if (deal) {
-        deal_count(0, n_edge);
-    }
-    else if (major)
-    XR_LAUNCH("edges_count", k_edges_count<true>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
-              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
-              edge_hits.get(), side_face.get(), side_len.get(), big_cells);
-    else
-    XR_LAUNCH("edges_count", k_edges_count<false>, dim3(div_up(n_edge, 256)), dim3(256), 0, edge_xy.get(), n_edge, g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
-              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), redo_list.get(), counters.get() + 2,
-              edge_hits.get(), side_face.get(), side_len.get(), big_cells);
-    // the wave-per-edge count pass keeps its hits in a pool (16 B each; 4 per edge of the network, at least 1M): the fill pass
-    // replays them instead of walking the long edges again (XR_EDGE_POOL=0: both passes walk, as before)
-    // (XR_EDGE_POOL = n > 0: a pool of n hits -- test hook for the refusal path)
-    const int pool_env = (int)option(OPT_EDGE_POOL);
-    const bool pooled = pool_env != 0;
-    const int pool_cap = !pooled ? 1 : pool_env > 0 ? pool_env : (int)std::min<int64_t>(std::max<int64_t>(4 * n_edge, (int64_t)1 << 20), (int64_t)1 << 28);
-    DevBuf<EdgeHit> pool((size_t)pool_cap);
-    DevBuf<int32_t> walk_list((size_t)(pooled ? n_edge : 1));
-    if (pooled)
-    XR_LAUNCH("edges_big_count", k_edges_big_pool, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
-              tree->rec_face.get(), row_count.get(), big_list.get(), counters.get(), pool.get(), counters.get() + 4, pool_cap,
-              walk_list.get(), counters.get() + 6);
-    else
-    XR_LAUNCH("edges_big_count", k_edges_big<false>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
-              tree->rec_face.get(), row_count.get(), (const int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,
-              big_list.get(), counters.get());
-    exclusive_scan_i32(row_count.get(), csr->indptr.get(), F);
-    const int32_t P = read_scalar(csr->indptr.get() + F);
-    XR_REQUIRE(P >= 0, XR_ERR_LIMIT, "nnz exceeds the int32 range");
-    csr->nnz = P;
-    csr->indices.alloc((size_t)P);
-    csr->data.alloc((size_t)P);
-    if (P == 0) return;
-    XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
-    XR_LAUNCH("edges_replay", k_edges_replay, dim3(div_up(n_edge, 256)), dim3(256), 0, n_edge, edge_hits.get(),
-              side_face.get(), side_len.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
-#define XR_DEAL_FILL(P)                                                                                                               \
-    XR_LAUNCH("edges_redo", (k_edges_deal<true, P>), dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),     \
-              dim3(256), 0, edge_xy.get(), n_edge, g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),                \
-              tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), (int32_t *)nullptr,            \
-              (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (int32_t *)nullptr, (double *)nullptr,  \
-              big_cells, csr->indptr.get(), csr->indices.get(), csr->data.get(), redo_list.get(), counters.get() + 2)
-    if (deal) {
-        if (deal_slots <= 24) XR_DEAL_FILL(24);
-        else if (deal_slots <= 32) XR_DEAL_FILL(32);
-        else if (deal_slots <= 40) XR_DEAL_FILL(40);
-        else XR_DEAL_FILL(48);
-    }
-#undef XR_DEAL_FILL
-    else if (major)
-    XR_LAUNCH("edges_redo", k_edges_redo<true>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
-              dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
-              tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
-              csr->data.get(), redo_list.get(), counters.get() + 2);
-    else
-    XR_LAUNCH("edges_redo", k_edges_redo<false>, dim3((unsigned)std::min<int64_t>(div_up(n_edge, 256), engine().num_cu * 8)),
-              dim3(256), 0, edge_xy.get(), g, tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(),
-              tree->rec_len.get(), tree->record_off(), tree->m, tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(),
-              csr->data.get(), redo_list.get(), counters.get() + 2);
-    if (pooled) {
-        XR_LAUNCH("edges_pool_replay", k_edges_pool_replay, dim3(engine().num_cu * 8), dim3(256), 0, pool.get(), counters.get() + 4,
-                  pool_cap, row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
-        XR_LAUNCH("edges_big_fill", k_edges_big<true>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
-                  tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
-                  tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
-                  walk_list.get(), counters.get() + 6);
-    } else
-    XR_LAUNCH("edges_big_fill", k_edges_big<true>, dim3(big_grid), dim3(256), 0, edge_xy.get(), g,
-              tree->cell_start.get(), tree->rec_bb.get(), tree->rec_fxy.get(), tree->rec_len.get(), tree->record_off(), tree->m,
-              tree->rec_face.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(),
-              big_list.get(), counters.get());
+    const int32_t P = (int32_t)csr->nnz;
     DevBuf<int32_t> sort_list((size_t)(P / ROW_SORT_SMALL + 1));
     csr->long_rows.alloc((size_t)(P / XR_APPLY_LONG_ROW + 1));
     csr->n_long.alloc(1);

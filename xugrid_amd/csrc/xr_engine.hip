@@ -57,14 +57,14 @@ struct OptionDef {
 const OptionDef k_option_defs[OPT_COUNT] = {
     {"overlap_fused", 1}, {"queue_margin", 0}, {"clip_quad", 1}, {"dust", 1}, {"no_side", 0}, {"side_fork", 1}, {"debug", 0},
     {"host_stamps", 0}, {"apply_plan", 1}, {"apply_contract", 0}, {"plan_merge", -1}, {"plan_dbg", 0}, {"apply_chunk_bytes", 0},
-    {"outer_apply", 0}, {"edge_big", 0}, {"edge_deal", 48}, {"edge_kernel", 0}, {"edge_walk", 0}, {"edge_pool", -1}, {"mail_poll", 1},
+    {"outer_apply", 0}, {"edge_big", 0}, {"edge_stage", 0}, {"edge_queue", 0}, {"edge_sort", 1}, {"mail_poll", 1},
     {"points_defer", 1}, {"ingest_device", 0}, {"stats_sample", 1}, {"force_query_sort", 0}, {"early_apply", 1}, {"star_flag", 1},
 };
 std::atomic<int64_t> g_options[OPT_COUNT];
 std::once_flag g_options_once;
 // words some options accepted as environment values before they were numbers
 int64_t option_word(const char *v) {
-    static const struct { const char *word; int64_t value; } words[] = {{"old", 1}, {"major", 1}, {"free", 1}, {"csr", 2}, {"device", 1}};
+    static const struct { const char *word; int64_t value; } words[] = {{"free", 1}, {"csr", 2}, {"device", 1}};
     for (const auto &w : words)
         if (!strcmp(v, w.word)) return w.value;
     char *end = nullptr;

@@ -296,10 +296,9 @@ enum Option : int {
     OPT_APPLY_CHUNK_BYTES, // > 0: staging budget of the host <-> device chunks of xr_apply_csr (tests force many chunks)
     OPT_OUTER_APPLY,       // 0: auto; 1: matrix-free apply of factored raster weights; 2: through the materialised CSR
     OPT_EDGE_BIG,          // > 0: cells of an edge's box from which on it goes to the wave-per-edge kernels
-    OPT_EDGE_DEAL,         // parking slots per edge of the dealt edge kernels (24 / 32 / 40 / 48)
-    OPT_EDGE_KERNEL,       // 0: dealt kernels; 1 ("old"): thread-per-edge count / replay / redo
-    OPT_EDGE_WALK,         // 1 ("major"): every edge walks along its major axis
-    OPT_EDGE_POOL,         // >= 0: size of the hit pool of the dealt kernels (tests force its overflow path)
+    OPT_EDGE_STAGE,        // > 0: candidates a wave of 64 edges may stage (<= 1024; tests force the overflow into the wave-per-edge kernel)
+    OPT_EDGE_QUEUE,        // > 0: candidate pairs the edge queue holds at first (tests force the regrow path with a tiny one)
+    OPT_EDGE_SORT,         // 1: the edges are walked in the order of the grid tiles of their midpoints; 0: as they come
     OPT_MAIL_POLL,         // 1: the host polls the mailbox's sequence word, small copies without a stream synchronisation
     OPT_POINTS_DEFER,      // 1: xr_locate_flags_begin defers its kernels to the next call that has the device to spare
     OPT_INGEST_DEVICE,     // 1 ("device"): connectivity validated and narrowed on the device instead of while it is staged
