@@ -18,6 +18,7 @@
 
 namespace xr {
 
+static constexpr int EDGE_WALK_PAD = 8;    // records of padding behind rec_bb (xr_mesh.hip allocates them; WALK_PAD of the face search)
 static constexpr int EDGE_BIG_CELLS = 64;  // edges whose box covers more grid cells (all levels) get a wave of their own
 static constexpr int ROW_SORT_SMALL = 16;  // rows up to this length are insertion-sorted by one thread (k_edge_rows_sort)
 static constexpr int ROW_SORT_LDS = 4096;  // rows up to this length are sorted in LDS by one block
@@ -60,6 +61,44 @@ __device__ __forceinline__ double cyrus_beck_length(const double *__restrict__ p
     return sqrt(ex * ex + ey * ey);
 }
 
+// the same clip on a polygon held in registers (MP slots, n <= MP corners; static indices): every operation of
+// cyrus_beck_length in the same order -- only the vertex loads have moved in front of the loop
+template <int MP>
+__device__ __forceinline__ double cyrus_beck_length_regs(const P2 (&v)[MP], int n, P2 a, P2 b) {
+    const double sx = b.x - a.x, sy = b.y - a.y;
+    double t0 = 0.0, t1 = 1.0;
+    bool outside = false;
+    P2 v0 = v[0];
+#pragma unroll
+    for (int i = 0; i < MP; i++) {
+        if (i < n) {
+            const P2 v1 = (i + 1 < MP && i + 1 < n) ? v[i + 1 < MP ? i + 1 : 0] : v[0];
+            const double wx = v1.x - v0.x, wy = v1.y - v0.y;
+            if (wx != 0.0 || wy != 0.0) {
+                const double nx = -wy, ny = wx; // inward normal of a CCW polygon
+                const double den = nx * sx + ny * sy;
+                const double num = nx * (v0.x - a.x) + ny * (v0.y - a.y);
+                if (den == 0.0) {
+                    if (num > 0.0) outside = true; // parallel and outside
+                } else {
+                    const double t = num / den;
+                    if (den > 0.0) {
+                        if (t > t0) t0 = t;
+                    } else {
+                        if (t < t1) t1 = t;
+                    }
+                }
+            }
+            v0 = v1;
+        }
+    }
+    if (outside || !(t0 < t1)) return -1.0;
+    const double cx = a.x + t0 * sx, cy = a.y + t0 * sy;
+    const double dx = a.x + t1 * sx, dy = a.y + t1 * sy;
+    const double ex = dx - cx, ey = dy - cy;
+    return sqrt(ex * ex + ey * ey);
+}
+
 struct EdgeBox {
     P2 a, b;
     double xmin, xmax, ymin, ymax;
@@ -81,13 +120,29 @@ __device__ __forceinline__ EdgeBox load_edge(const double *__restrict__ edge_xy,
     return q;
 }
 
+// Level-0 cells of the box corners, once: the level-l cell of x is (level-0 cell) >> l exactly (cell sizes are power-of-two
+// multiples and the clamped ranges nest), and a record that can overlap starts at most one cell below the box's lower corner --
+// the face search's rule (xr_overlap.hip: k_search), no per-level floating-point cell arithmetic.
+struct EdgeCells {
+    int x0, x1, y0, y1;
+};
+__device__ __forceinline__ EdgeCells edge_cells0(const EdgeBox &q, const GridParams &g) {
+    return EdgeCells{cell_coord(q.xmin, g.x0, g.inv_h0, g.nx[0]), cell_coord(q.xmax, g.x0, g.inv_h0, g.nx[0]),
+                     cell_coord(q.ymin, g.y0, g.inv_h0, g.ny[0]), cell_coord(q.ymax, g.y0, g.inv_h0, g.ny[0])};
+}
+__device__ __forceinline__ void edge_level_range(const EdgeCells &c, int l, int &cx0, int &cx1, int &cy0, int &cy1) {
+    const int sh = l * LEVEL_SHIFT;
+    cx0 = max((c.x0 >> sh) - 1, 0);
+    cx1 = c.x1 >> sh;
+    cy0 = max((c.y0 >> sh) - 1, 0);
+    cy1 = c.y1 >> sh;
+}
 // number of grid cells (all levels) under the edge's box
-__device__ __forceinline__ int64_t edge_cells(const EdgeBox &q, const GridParams &g) {
+__device__ __forceinline__ int64_t edge_cells(const EdgeCells &c, const GridParams &g) {
     int64_t total = 0;
     for (int l = 0; l < g.n_levels; l++) {
-        const double h = level_h(g, l), inv_h = level_inv_h(g, l);
-        const int cx0 = cell_coord(q.xmin - h, g.x0, inv_h, g.nx[l]), cx1 = cell_coord(q.xmax, g.x0, inv_h, g.nx[l]);
-        const int cy0 = cell_coord(q.ymin - h, g.y0, inv_h, g.ny[l]), cy1 = cell_coord(q.ymax, g.y0, inv_h, g.ny[l]);
+        int cx0, cx1, cy0, cy1;
+        edge_level_range(c, l, cx0, cx1, cy0, cy1);
         total += (int64_t)(cx1 - cx0 + 1) * (cy1 - cy0 + 1);
     }
     return total;
@@ -96,9 +151,17 @@ __device__ __forceinline__ int64_t edge_cells(const EdgeBox &q, const GridParams
 // the records [r0, r1) of a run of grid cells against the edge's f32 box: CAND(record) for every record that passes
 template <typename Cand>
 __device__ __forceinline__ void edge_cell(const EdgeBox &q, int r0, int r1, const float4 *__restrict__ rbb, Cand &&cand) {
-    for (int r = r0; r < r1; r++) {
-        const float4 bb = rbb[r];
-        if (box_gap(bb, q.qx0, q.qx1, q.qy0, q.qy1) <= 0.0f) cand(r);
+    // four independent loads in flight per step (one at a time, a run of n records was n dependent round trips: the walk kernel
+    // waited 79 % of its wave cycles); a load beyond the run reads the next run or rec_bb's padding and is masked
+    constexpr int LOADS = 4;
+    static_assert(LOADS - 1 <= EDGE_WALK_PAD, "rec_bb padding");
+    for (int r = r0; r < r1; r += LOADS) {
+        float4 bb[LOADS];
+#pragma unroll
+        for (int u = 0; u < LOADS; u++) bb[u] = rbb[r + u];
+#pragma unroll
+        for (int u = 0; u < LOADS; u++)
+            if (r + u < r1 && box_gap(bb[u], q.qx0, q.qx1, q.qy0, q.qy1) <= 0.0f) cand(r + u);
     }
 }
 
@@ -188,17 +251,45 @@ __device__ __forceinline__ void edge_walk_wave(const EdgeBox &q, const GridParam
     }
 }
 
-// all grid cells of the edge's box, level by level (short edges: a handful of cells, no per-cell arithmetic)
+// all grid cells of the edge's box, level by level (short edges: a handful of cells, no per-cell arithmetic).  The record runs
+// of FOUR levels (up to four grid rows each) are fetched together before any of them is walked: three round trips for the ten
+// levels of the benchmark mesh -- eight of them all but empty -- instead of one per level and row.
 template <typename Cand>
-__device__ __forceinline__ void edge_walk_box(const EdgeBox &q, const GridParams &g, const int32_t *__restrict__ cell_start,
-                                              const float4 *__restrict__ rbb, Cand &&cand) {
-    for (int l = 0; l < g.n_levels; l++) {
-        const double h = level_h(g, l), inv_h = level_inv_h(g, l);
-        const int nx = g.nx[l], base = g.base[l];
-        const int cx0 = cell_coord(q.xmin - h, g.x0, inv_h, nx), cx1 = cell_coord(q.xmax, g.x0, inv_h, nx);
-        const int cy0 = cell_coord(q.ymin - h, g.y0, inv_h, g.ny[l]), cy1 = cell_coord(q.ymax, g.y0, inv_h, g.ny[l]);
-        for (int cy = cy0; cy <= cy1; cy++)
-            edge_cell(q, cell_start[base + cy * nx + cx0], cell_start[base + cy * nx + cx1 + 1], rbb, cand);
+__device__ __forceinline__ void edge_walk_box(const EdgeBox &q, const EdgeCells &c, const GridParams &g,
+                                              const int32_t *__restrict__ cell_start, const float4 *__restrict__ rbb, Cand &&cand) {
+    constexpr int LCH = 4, RCH = 4;
+    for (int l0 = 0; l0 < g.n_levels; l0 += LCH) { // (uniform)
+        int r0[LCH][RCH], r1[LCH][RCH];
+#pragma unroll
+        for (int j = 0; j < LCH; j++) {
+            const int l = l0 + j < g.n_levels ? l0 + j : g.n_levels - 1;
+            const int nx = g.nx[l], base = g.base[l];
+            int cx0, cx1, cy0, cy1;
+            edge_level_range(c, l, cx0, cx1, cy0, cy1);
+#pragma unroll
+            for (int k = 0; k < RCH; k++) {
+                const bool has = l0 + j < g.n_levels && cy0 + k <= cy1;
+                const int cy = has ? cy0 + k : cy0;
+                r0[j][k] = cell_start[base + cy * nx + cx0];
+                r1[j][k] = has ? cell_start[base + cy * nx + cx1 + 1] : r0[j][k];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < LCH; j++) {
+#pragma unroll
+            for (int k = 0; k < RCH; k++) edge_cell(q, r0[j][k], r1[j][k], rbb, cand);
+        }
+        // (rows beyond the four fetched ones: a tall box on a fine level)
+#pragma unroll
+        for (int j = 0; j < LCH; j++) {
+            if (l0 + j < g.n_levels) {
+                const int l = l0 + j, nx = g.nx[l], base = g.base[l];
+                int cx0, cx1, cy0, cy1;
+                edge_level_range(c, l, cx0, cx1, cy0, cy1);
+                for (int cy = cy0 + RCH; cy <= cy1; cy++)
+                    edge_cell(q, cell_start[base + cy * nx + cx0], cell_start[base + cy * nx + cx1 + 1], rbb, cand);
+            }
+        }
     }
 }
 
@@ -282,8 +373,9 @@ k_edge_walk(const double *__restrict__ edge_xy, int64_t n_edge, int64_t e_base, 
             int32_t *__restrict__ big_list, int big_cells, int stage_cap /* <= EDGE_STAGE (test hook: a tiny stage) */,
             const int32_t *__restrict__ perm /* optional: item i is edge perm[i] (k_edge_tile_scatter) instead of e_base + i */) {
     __shared__ int32_t sh_rec[4][EDGE_STAGE];
-    __shared__ uint8_t sh_own[4][EDGE_STAGE];
+    __shared__ uint16_t sh_tag[4][EDGE_STAGE]; // owner lane | the candidate's number among its owner's << 6
     __shared__ int32_t sh_edge[256];
+    __shared__ int32_t sh_first[256];          // first queue slot (inside the wave's stretch) of every lane's candidates
     __shared__ int32_t sh_n[4];
     __shared__ long long sh_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -296,26 +388,42 @@ k_edge_walk(const double *__restrict__ edge_xy, int64_t n_edge, int64_t e_base, 
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     bool big = false, over = false;
+    int stored = 0;
     if (live) {
         const EdgeBox q = load_edge(edge_xy, e, g);
         const bool finite = q.xmin == q.xmin && q.ymin == q.ymin && q.xmax == q.xmax && q.ymax == q.ymax; // no NaN
-        big = finite && edge_cells(q, g) > big_cells;
+        const EdgeCells cells = edge_cells0(q, g);
+        big = finite && edge_cells(cells, g) > big_cells;
         if (finite && !big) {
             auto cand = [&](int r) {
                 const int k = atomicAdd(&sh_n[wv], 1);
                 if (k < stage_cap) {
                     sh_rec[wv][k] = r;
-                    sh_own[wv][k] = (uint8_t)lane;
+                    sh_tag[wv][k] = (uint16_t)(lane | (stored << 6));
+                    stored++;
                 } else {
                     over = true;
                 }
             };
-            edge_walk_box(q, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), cand);
+            edge_walk_box(q, cells, g, cell_start, reinterpret_cast<const float4 *>(rec_bb), cand);
         }
     }
     // (an edge that met a full stage may have candidates missing: it walks again in the wave kernel)
     const unsigned long long dropped = __ballot(over);
     wave_append(live && (big || over), (int32_t)e, big_list, counters);
+    // The stage holds the wave's candidates in the order the lanes' appends happened to interleave.  They leave it GROUPED BY
+    // EDGE, in walk order (lane l's candidates behind those of the lanes below it): the clip's 64 lanes then read the same two
+    // end points and neighbouring records -- a few lines per load instead of 64 (the clip is bound by the address rate of
+    // its gathers, not by arithmetic: 7 loads x 64 lines per round).
+    {
+        int incl = stored;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += u;
+        }
+        sh_first[tid] = incl - stored;
+    }
     __syncthreads();
     int n_w[4], total = 0;
 #pragma unroll
@@ -331,8 +439,9 @@ k_edge_walk(const double *__restrict__ edge_xy, int64_t n_edge, int64_t e_base, 
 #pragma unroll
     for (int w = 0; w < 4; w++) woff += w < wv ? n_w[w] : 0;
     for (int k = lane; k < n_w[wv]; k += 64) {
-        const int owner = sh_own[wv][k];
-        queue[base + woff + k] = make_int2(((dropped >> owner) & 1ull) ? -1 : sh_edge[wv * 64 + owner], sh_rec[wv][k]);
+        const int tag = sh_tag[wv][k], owner = tag & 63;
+        queue[base + woff + sh_first[wv * 64 + owner] + (tag >> 6)] =
+            make_int2(((dropped >> owner) & 1ull) ? -1 : sh_edge[wv * 64 + owner], sh_rec[wv][k]);
     }
 }
 
@@ -385,48 +494,128 @@ k_edge_walk_big(const double *__restrict__ edge_xy, GridParams g, const int32_t 
 }
 
 // pass 2, one thread per candidate (persistent grid over the eight queue regions): the exact clip.  A piece of positive length
-// turns the entry into (edge, face) + its length and counts for the face's row; everything else becomes edge -1.
+// turns the entry into (edge, face) + its length + its RANK in the face's row (the returning atomic that counts the row:
+// the fill pass needs no second one); everything else becomes edge -1.
+// MC = 3 / 4: dense meshes -- the corners, the end points and the length byte are fetched together, in front of the arithmetic
+// (as a loop over the polygon in memory a candidate was five dependent round trips: 0.22 ms for 8.5M candidates, all latency);
+// MC = 0: any mesh, from memory.
+template <int MC>
 __global__ void __launch_bounds__(256)
 k_edge_clip(const double *__restrict__ edge_xy, const double *__restrict__ rec_fxy, const uint8_t *__restrict__ rec_len,
             const int32_t *__restrict__ rec_off, int m, const int32_t *__restrict__ rec_face, int2 *__restrict__ queue,
-            double *__restrict__ queue_len, int64_t region_cap, const int32_t *__restrict__ counters, int32_t *__restrict__ row_count) {
+            double *__restrict__ queue_len, int32_t *__restrict__ queue_rank, int64_t region_cap,
+            const int32_t *__restrict__ counters, int32_t *__restrict__ row_count) {
     if (counters[2] & 1) return; // (a region overflowed: the host starts over with a longer queue)
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int x = 0; x < 8; x++) {
-        const int64_t n = counters[EQ_CURSORS + x * EQ_STRIDE];
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-            const int64_t c = (int64_t)x * region_cap + i;
-            const int2 pr = queue[c];
-            if (pr.x < 0) continue;
-            const P2 a = load_p2(edge_xy, 2 * pr.x), b = load_p2(edge_xy, 2 * pr.x + 1);
-            const double len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, pr.y, m), rec_len[pr.y], a, b);
-            if (len > 0.0) { // (a degenerate piece of zero length is no intersection)
-                const int face = rec_face[pr.y];
-                atomicAdd(row_count + face, 1);
-                queue[c] = make_int2(pr.x, face);
-                queue_len[c] = len;
+    // One returning atomic per DISTINCT face of the block's 256 candidates (the edges come tile by tile, so these hit a few dozen
+    // faces) instead of one per hit: device-scope atomics run at the memory side of the fabric at ~20 G/s -- 4M of them were
+    // most of this kernel.  The block's rounds are software-pipelined: the entry, corners, end points and face id of round k + 1
+    // are in flight while round k is clipped and counted (as a chain entry -> gathers -> face id -> atomic -> stores a round was
+    // five dependent round trips with three barriers in between: 69 % of the wave cycles waited, PMC).
+    __shared__ KeyTable sh_tab;
+    constexpr int MV = MC > 0 ? MC : 1;
+    const double2 *__restrict__ fx = reinterpret_cast<const double2 *>(rec_fxy);
+    const double2 *__restrict__ ex = reinterpret_cast<const double2 *>(edge_xy);
+    // the chunks of 256 entries of all eight regions as one list (uniform arithmetic on eight scalars)
+    int64_t first_chunk[9];
+    first_chunk[0] = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) first_chunk[x + 1] = first_chunk[x] + ((int64_t)counters[EQ_CURSORS + x * EQ_STRIDE] + 255) / 256;
+    const int64_t n_chunks = first_chunk[8];
+    struct Round {
+        int64_t c;   // queue index of this thread's entry (-1: none)
+        int2 pr;
+        double2 vv[MV], pa, pb;
+        int nl, face;
+    };
+    auto fetch = [&](int64_t chunk, Round &r) {
+        r.c = -1;
+        r.pr = make_int2(-1, 0);
+        r.nl = 0;
+        r.face = 0;
+        if (chunk >= n_chunks) return;
+        int x = 0;
+#pragma unroll
+        for (int k = 1; k < 8; k++) x += chunk >= first_chunk[k] ? 1 : 0;
+        const int64_t i = (chunk - first_chunk[x]) * 256 + threadIdx.x;
+        if (i >= counters[EQ_CURSORS + x * EQ_STRIDE]) return;
+        r.c = (int64_t)x * region_cap + i;
+        r.pr = queue[r.c];
+        if (r.pr.x < 0) return;
+        if constexpr (MC > 0) {
+#pragma unroll
+            for (int k = 0; k < MC; k++) r.vv[k] = fx[(int64_t)r.pr.y * MC + k];
+            r.nl = rec_len[r.pr.y];
+        }
+        r.pa = ex[2 * (int64_t)r.pr.x];
+        r.pb = ex[2 * (int64_t)r.pr.x + 1];
+        r.face = rec_face[r.pr.y];
+    };
+    Round cur, nxt;
+    fetch(blockIdx.x, cur);
+    for (int64_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) { // (block-uniform)
+        agg_clear(sh_tab);
+        fetch(chunk + gridDim.x, nxt);
+        double len = -1.0;
+        if (cur.pr.x >= 0) {
+            const P2 a{cur.pa.x, cur.pa.y}, b{cur.pb.x, cur.pb.y};
+            if constexpr (MC > 0) {
+                P2 v[MC];
+#pragma unroll
+                for (int k = 0; k < MC; k++) v[k] = P2{cur.vv[k].x, cur.vv[k].y};
+                len = cyrus_beck_length_regs<MC>(v, cur.nl, a, b);
             } else {
-                queue[c] = make_int2(-1, 0);
+                len = cyrus_beck_length(rec_fxy + 2 * face_vertex_base(rec_off, cur.pr.y, m), rec_len[cur.pr.y], a, b);
             }
         }
+        const bool hit = len > 0.0; // (a degenerate piece of zero length is no intersection)
+        __syncthreads();
+        int slot = 0, rank = 0;
+        if (hit) slot = agg_insert(sh_tab, cur.face, rank);
+        __syncthreads();
+        for (int s = threadIdx.x; s < AGG_SLOTS; s += 256)
+            if (sh_tab.key[s] >= 0) sh_tab.base[s] = atomicAdd(row_count + sh_tab.key[s], sh_tab.cnt[s]);
+        __syncthreads();
+        if (hit) {
+            queue_rank[cur.c] = sh_tab.base[slot] + rank;
+            queue[cur.c] = make_int2(cur.pr.x, cur.face);
+            queue_len[cur.c] = len;
+        } else if (cur.pr.x >= 0) {
+            queue[cur.c] = make_int2(-1, 0);
+        }
+        __syncthreads(); // (the table is cleared at the top of the next round)
+        cur = nxt;
     }
 }
 
-// pass 3: the kept entries go to their rows (arbitrary order within a row; k_edge_rows_sort orders them by edge id)
+// pass 3: the kept entries go to their rows at the rank the clip's atomic gave them (arbitrary order within a row;
+// k_edge_rows_sort orders the rows by edge id)
 __global__ void __launch_bounds__(256)
-k_edge_fill(const int2 *__restrict__ queue, const double *__restrict__ queue_len, int64_t region_cap,
-            const int32_t *__restrict__ counters, int32_t *__restrict__ row_fill, const int32_t *__restrict__ indptr,
+k_edge_fill(const int2 *__restrict__ queue, const double *__restrict__ queue_len, const int32_t *__restrict__ queue_rank,
+            int64_t region_cap, const int32_t *__restrict__ counters, const int32_t *__restrict__ indptr,
             int32_t *__restrict__ indices, double *__restrict__ data) {
+    constexpr int U = 4; // entries per thread and round, their loads in flight together
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int x = 0; x < 8; x++) {
         const int64_t n = counters[EQ_CURSORS + x * EQ_STRIDE];
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-            const int64_t c = (int64_t)x * region_cap + i;
-            const int2 pr = queue[c];
-            if (pr.x < 0) continue;
-            const int pos = indptr[pr.y] + atomicAdd(row_fill + pr.y, 1);
-            indices[pos] = pr.x;
-            data[pos] = queue_len[c];
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += U * stride) {
+            int2 pr[U];
+            int pos[U];
+            double len[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) pr[u] = i + u * stride < n ? queue[(int64_t)x * region_cap + i + u * stride] : make_int2(-1, 0);
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int64_t c = (int64_t)x * region_cap + i + u * stride;
+                pos[u] = pr[u].x >= 0 ? indptr[pr[u].y] + queue_rank[c] : 0;
+                len[u] = pr[u].x >= 0 ? queue_len[c] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (pr[u].x >= 0) {
+                    indices[pos[u]] = pr[u].x;
+                    data[pos[u]] = len[u];
+                }
+            }
         }
     }
 }
@@ -611,6 +800,7 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
         XR_REQUIRE(region_cap < ((int64_t)1 << 30), XR_ERR_LIMIT, "xr_edge_length_csr: too many candidate pairs");
         DevBuf<int2> queue((size_t)(8 * region_cap));
         DevBuf<double> queue_len((size_t)(8 * region_cap));
+        DevBuf<int32_t> queue_rank((size_t)(8 * region_cap));
         XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
         XR_HIP(hipMemsetAsync(counters.get(), 0, sizeof(int32_t) * (size_t)EQ_WORDS, st));
         // The edge coordinates come from the host (32 bytes per edge: 0.86 ms of PCIe for 1M edges).  The walk is independent per
@@ -642,9 +832,15 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
         uploaded = true;
         XR_LAUNCH("edges_walk_big", k_edge_walk_big, dim3(grid_persistent), dim3(256), 0, edge_xy, g, tree->cell_start.get(),
                   tree->rec_bb.get(), queue.get(), region_cap, counters.get(), big_list.get());
-        XR_LAUNCH("edges_clip", k_edge_clip, dim3(grid_persistent), dim3(256), 0, edge_xy, tree->rec_fxy.get(), tree->rec_len.get(),
-                  tree->record_off(), tree->m, tree->rec_face.get(), queue.get(), queue_len.get(), region_cap, counters.get(),
-                  row_count.get());
+        // (a persistent grid of what is resident: 92-96 registers with the next round's operands in flight, five waves per SIMD)
+#define XR_EDGE_CLIP(MC)                                                                                                           \
+    XR_LAUNCH("edges_clip", k_edge_clip<MC>, dim3(engine().num_cu * (MC > 0 ? 5 : 7)), dim3(256), 0, edge_xy, tree->rec_fxy.get(), tree->rec_len.get(), \
+              tree->record_off(), tree->m, tree->rec_face.get(), queue.get(), queue_len.get(), queue_rank.get(), region_cap,        \
+              counters.get(), row_count.get())
+        if (tree->record_off() == nullptr && tree->m == 3) XR_EDGE_CLIP(3);
+        else if (tree->record_off() == nullptr && tree->m == 4) XR_EDGE_CLIP(4);
+        else XR_EDGE_CLIP(0);
+#undef XR_EDGE_CLIP
         exclusive_scan_i32(row_count.get(), csr->indptr.get(), F);
         int32_t c[EQ_WORDS];
         d2h(c, counters.get(), sizeof(c));
@@ -667,9 +863,8 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
         csr->indices.alloc((size_t)P);
         csr->data.alloc((size_t)P);
         if (P == 0) return;
-        XR_HIP(hipMemsetAsync(row_count.get(), 0, sizeof(int32_t) * (size_t)F, st));
-        XR_LAUNCH("edges_fill", k_edge_fill, dim3(grid_persistent), dim3(256), 0, queue.get(), queue_len.get(), region_cap,
-                  counters.get(), row_count.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
+        XR_LAUNCH("edges_fill", k_edge_fill, dim3(grid_persistent), dim3(256), 0, queue.get(), queue_len.get(), queue_rank.get(),
+                  region_cap, counters.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
         break;
     }
     const int32_t P = (int32_t)csr->nnz;
