@@ -799,9 +799,11 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
                          "frac_of_hbm_peak": b_edges / t_dev / 1e9 / HBM_PEAK_GBS,
                          "whole_call_GBps": b_edges / min(times) / 1e9,
                          "note": "achieved / frac: the DEVICE part (end points in HBM, xr_edge_length_csr_dev: index of the mesh "
-                                 "cached, count pass + scan + replay / redo + row sort, one host read-back of nnz); whole_call: "
-                                 "incl. the 32 MB host -> device copy of the edge coordinates (PCIe).  The device part is a grid "
-                                 "walk per edge, latency / instruction bound like the face search"},
+                                 "cached; tile sort of the edges, walk -> flat candidate queue, one thread per candidate clips, "
+                                 "scan, fill, row sort; one host read-back of the queue cursors and nnz); whole_call: incl. the "
+                                 "32 MB host -> device copy of the edge coordinates (PCIe).  The device part gathers by position "
+                                 "(8.5M candidates) and counts rows with device-scope atomics: not bandwidth-bound (round 5: "
+                                 "1.57 ms)"},
             "note": "1M random segments (exponential lengths, mean ~2 cell sizes) over the ~1M-triangle source mesh; "
             "weights_ms includes the 32 MB upload of the edge coordinates, device_ms does not",
         }
