@@ -40,7 +40,7 @@ def run(seed0, n_iter):
                                np.column_stack([q[:k, 0], q[:k, 2], q[:k, 3], np.full(k, -1)]), q[k:]])
             lo, hi = xy.min(), xy.max()
             span = hi - lo
-            ne = int(10 ** rng.uniform(0.5, 3.7))
+            ne = int(10 ** rng.uniform(0.5, 4.3))
             edges = random_network(rng, ne, lo - 0.1 * span, hi + 0.1 * span, 10 ** rng.uniform(-2.5, -0.2) * span)
             nn = min(ne, 200)
             if nn:  # edges between mesh nodes (through corners, along sides) and axis-aligned edges
@@ -51,10 +51,18 @@ def run(seed0, n_iter):
             tree = O.CellTree2d(xy, f)
             e, fc, pts = tree.intersect_edges(edges)
             w, cols, indptr = csr_from_pairs(e, fc, pts, f.shape[0])
+            # (the network kernels' tuning hooks at random: a small stage sends whole waves of edges to the wave-per-edge kernel, a
+            # short queue is regrown, the edges in tile order or as they come -- the CSR must not notice; the sort needs >= 4096 edges)
+            opts = {"edge_stage": int(rng.choice([0, 0, 1, 40, 300])), "edge_big": int(rng.choice([0, 0, 8, 100000])),
+                    "edge_queue": int(rng.choice([0, 0, 500, 20000])), "edge_sort": int(rng.integers(2))}
+            for k, v in opts.items():
+                E.set_option(k, v)
             csr = E.edge_length_csr(E.DeviceMesh(xy, f), edges)
+            for k, v in (("edge_stage", 0), ("edge_big", 0), ("edge_queue", 0), ("edge_sort", 1)):
+                E.set_option(k, v)
             dd, di, dp = csr.download()
             if not (np.array_equal(dp, indptr) and np.array_equal(di, cols) and np.array_equal(dd, w)):
-                msg = f"network (faces={f.shape[0]} edges={ne} nnz={e.size} vs {csr.nnz})"
+                msg = f"network (faces={f.shape[0]} edges={ne} nnz={e.size} vs {csr.nnz}; {opts})"
             if not msg:
                 ks, kt = random_raster(rng, 150), random_raster(rng, 150)
                 s, t = StructuredGrid2d(Raster(**ks)), StructuredGrid2d(Raster(**kt))

@@ -94,8 +94,10 @@ int64_t option(Option o) {
     return g_options[o].load(std::memory_order_relaxed);
 }
 
+static thread_local bool t_mark_open = false; // (side_mark() .. SideScope(at_mark): see side_mark)
 ExclusiveScope::ExclusiveScope() {
     if (t_exclusive_depth++ == 0) {
+        t_mark_open = false; // (a call that failed between a mark and its scope leaves nothing behind)
         engine_mutex().lock();
         engine_rw().lock();
     }
@@ -111,6 +113,7 @@ static void lane_release_blocks(Lane *lane);
 
 SharedScope::SharedScope() {
     if (t_exclusive_depth > 0 || t_lane) return; // nested inside another entry point: that one's context is used
+    t_mark_open = false;
     engine_rw().lock_shared();
     leased = true;
     Engine &e = engine();
@@ -434,8 +437,10 @@ static void fast_copy_init() {
     g_fast.ring = static_cast<char *>(p);
 }
 
+void assert_no_open_mark(const char *what);
 void h2d(void *dst, const void *src, size_t bytes) {
     if (!bytes) return;
+    assert_no_open_mark("h2d");
     if (bytes >= BIG_COPY_BYTES) {
         h2d_big(dst, src, bytes);
         return;
@@ -645,6 +650,7 @@ static inline size_t up_piece(size_t bytes) { // small pieces start the pipeline
 }
 void h2d_staged(void *dst, size_t bytes, const std::function<void(char *, size_t, size_t)> &fill) {
     if (!bytes) return;
+    assert_no_open_mark("h2d_staged");
     Lane &sl = stage_init();
     hipStream_t st = launch_stream();
     // the two 64 MiB staging buffers as a ring of pieces
@@ -861,18 +867,28 @@ static bool lane_side_ready(Lane *l) {
     l->join_event = b;
     return true;
 }
+// Invariant of the host -> device copies (h2d, h2d_staged): they are ordered on the MAIN stream only.  Work started with
+// SideScope(at_mark = true) depends on what the main stream held at the last side_mark(), so an upload issued between the two
+// would not be visible to it: t_mark_open is set by side_mark(), cleared by the SideScope that consumes the mark, and every
+// upload checks it.  (The one at_mark user is the early apply of xr_overlap_apply_dev, which uploads nothing.)
+void assert_no_open_mark(const char *what) {
+    XR_REQUIRE(!t_mark_open, XR_ERR_INVALID, "internal: %s between side_mark() and SideScope(at_mark): the side work would not see it", what);
+}
 bool side_mark() {
     if (side_disabled()) return false;
     if (Lane *l = current_lane()) {
         if (!lane_side_ready(l)) return false;
         XR_HIP(hipEventRecord(l->fork_event, l->stream));
+        t_mark_open = true;
         return true;
     }
     if (t_exclusive_depth == 0) return false;
     XR_HIP(hipEventRecord(engine().fork_event, engine().stream));
+    t_mark_open = true;
     return true;
 }
 SideScope::SideScope(bool at_mark) {
+    if (at_mark) t_mark_open = false;
     if (side_disabled()) return;
     if (Lane *l = current_lane()) {
         if (!lane_side_ready(l)) return;
