@@ -15,6 +15,7 @@
 #include <cstring>
 
 #include "xr_objects.h"
+#include "xr_agg.h"
 
 namespace xr {
 

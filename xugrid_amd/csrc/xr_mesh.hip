@@ -18,6 +18,7 @@
 #include <atomic>
 
 #include "xr_objects.h"
+#include "xr_agg.h"
 
 namespace xr {
 
@@ -606,7 +607,7 @@ void mesh_read_stats(xr_mesh *mesh, bool need_exact) {
 // so that final results do not depend on it.
 // ---------------------------------------------------------------------------------------------
 
-// (KeyTable / agg_insert -- one global atomic per DISTINCT key of a block -- live in xr_geom.h: the edge kernels use them too)
+// (KeyTable / agg_insert -- one global atomic per DISTINCT key of a block -- live in xr_agg.h: the edge kernels use them too)
 
 // (`lv` = the per-level grid sizes in LDS, [0..L) nx, [L..2L) ny, [2L..3L) base: the level differs from lane to lane, and
 // indexing the kernel ARGUMENT g.nx[l] with it compiles to three dependent global loads per face)
