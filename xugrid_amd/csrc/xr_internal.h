@@ -1,6 +1,7 @@
 // xr_internal.h -- shared internals of libxugrid_amd.so (engine context, HBM block pool,
 // launch/profiling helpers, device scan).  gfx950 / wave64 only.
 #pragma once
+#include <memory>
 
 #include <hip/hip_runtime.h>
 
@@ -161,6 +162,23 @@ template <typename T> struct DevBuf {
     }
     T *get() const { return p; }
     size_t bytes() const { return n * sizeof(T); }
+};
+
+// A buffer of points that is either the holder's own or SHARED with the mesh whose face centroids it holds (xr_mesh::centroids_dev:
+// the reference caches `Ugrid2d.centroids` on the grid, ugrid2d.py; here the device copy is kept until the mesh is invalidated or
+// destroyed -- a handle that shares it keeps it alive beyond that).
+struct PointsBuf {
+    DevBuf<double> own;
+    std::shared_ptr<DevBuf<double>> shared;
+    void alloc(size_t count) {
+        shared.reset();
+        own.alloc(count);
+    }
+    void share(std::shared_ptr<DevBuf<double>> s) {
+        own.release();
+        shared = std::move(s);
+    }
+    double *get() const { return shared ? shared->get() : own.get(); }
 };
 
 // "Zero at rest" scratch words: int32 arrays the engine keeps between calls and that are ALL ZERO whenever no call is

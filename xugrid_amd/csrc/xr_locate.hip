@@ -15,7 +15,7 @@
 struct xr_points {
     int64_t n = 0;
     xr_mesh *source = nullptr;
-    xr::DevBuf<double> pts;
+    xr::PointsBuf pts; // (the query mesh's centroids are shared with the mesh, not copied)
     xr::DevBuf<uint8_t> inside;
     // The kernels that fill the two buffers (centroids of the query, point location in the source grid) go to the engine's
     // SIDE stream -- the high-priority stream the big faces of xr_overlap use, known to run beside the main one -- as soon as
@@ -654,7 +654,7 @@ static double resolve_tolerance(xr_mesh *mesh, double tolerance) {
 }
 
 static void launch_points(xr_points *h) {
-    if (h->query) mesh_centroids_dev(h->query, h->pts.get());
+    if (h->query) h->pts.share(mesh_centroids_shared(h->query));
     if (engine().on_side && !current_lane()) {
         // the consumer needs the points long before it needs the flags: it waits for this mark first and joins the side
         // stream only in front of the kernel that reads `inside` (on a cached tessellation locate_flag then runs BESIDE the
@@ -797,15 +797,18 @@ int xr_barycentric(xr_mesh *mesh, const double *points, int64_t n, double tolera
 
 // the source-side part of UnstructuredGrid2d.barycentric (unstructured.py:147, 188-190) -- the query points and
 // `grid.locate_points(points) == -1` -- enqueued WITHOUT a final wait: it needs nothing of the Voronoi tessellation
-static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, DevBuf<double> &pts,
+static void locate_flags(xr_mesh *source, xr_mesh *query, const double *points, int64_t n, PointsBuf &pts,
                          DevBuf<uint8_t> &inside, bool points_only = false) {
     mesh_prepare(source, false);
     mesh_build_index(source);
     const double tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
-    pts.alloc((size_t)n * 2);
     inside.alloc((size_t)n);
-    if (query) mesh_centroids_dev(query, pts.get());
-    else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+    if (query) {
+        pts.share(mesh_centroids_shared(query));
+    } else {
+        pts.alloc((size_t)n * 2);
+        h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+    }
     if (points_only) return; // (the flags come from k_star_flag)
     XR_LAUNCH("locate_flag", k_locate_flag<false>, dim3(div_up(n, 256)), dim3(256), 0, source->rec_fxy.get(),
               source->rec_len.get(), source->record_off(), source->m, source->grid, source->cell_start.get(), source->rec_bb.get(),
@@ -854,7 +857,8 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
         } else {
             mesh_prepare(voronoi, false); mesh_build_index(voronoi);
             const double tol = resolve_tolerance(voronoi, tolerance);
-            DevBuf<double> own_pts, w((size_t)n * m);
+            PointsBuf own_pts;
+            DevBuf<double> w((size_t)n * m);
             DevBuf<uint8_t> own_inside;
             // the flags from the faces around each point's cell (k_star_flag, behind the barycentric kernel) unless the handle
             // brings them (option "star_flag" = 0, or a handle made while it was)
@@ -870,7 +874,7 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                     pre->on_side = false;
                 }
             }
-            DevBuf<double> &pts = pre ? pre->pts : own_pts;
+            PointsBuf &pts = pre ? pre->pts : own_pts;
             DevBuf<uint8_t> &inside = pre ? pre->inside : own_inside;
             // the vertex table the weight slots are paired with: the caller's order as the reference does
             // (unstructured.py:175,193) = the mesh's own int32 connectivity, read as it is; or -- tree_order -- the tree's
@@ -992,10 +996,12 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
             mesh_prepare(source, false);
             mesh_build_index(source);
             h->tol_source = resolve_tolerance(source, -1.0); // unstructured.py:189: default tolerance
-            h->pts.alloc((size_t)n * 2);
             h->inside.alloc((size_t)n);
             h->query = query;
-            if (!query) h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            if (!query) { // (a query mesh: its centroids, shared with the mesh, when the kernels are launched -- launch_points)
+                h->pts.alloc((size_t)n * 2);
+                h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            }
             h->flags_pending = option(OPT_STAR_FLAG) != 0;
             const bool defer = option(OPT_POINTS_DEFER) != 0; // (A/B switch)
             if (defer) {
@@ -1010,11 +1016,14 @@ int xr_locate_flags_begin(xr_mesh *source, xr_mesh *query, const double *points,
             }
         }
         else if (n > 0) { // (no source faces: every point is outside)
-            h->pts.alloc((size_t)n * 2);
             h->inside.alloc((size_t)n);
             XR_HIP(hipMemsetAsync(h->inside.get(), 0, (size_t)n, launch_stream()));
-            if (query) mesh_centroids_dev(query, h->pts.get());
-            else h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            if (query) {
+                h->pts.share(mesh_centroids_shared(query));
+            } else {
+                h->pts.alloc((size_t)n * 2);
+                h2d(h->pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            }
         }
     } catch (...) {
         delete h;
@@ -1106,9 +1115,13 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
             mesh_prepare(tree, false);
             mesh_build_index(tree);
             const double tol = resolve_tolerance(tree, tolerance);
-            DevBuf<double> pts((size_t)n * 2);
-            if (query) mesh_centroids_dev(query, pts.get());
-            else h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            PointsBuf pts;
+            if (query) {
+                pts.share(mesh_centroids_shared(query));
+            } else {
+                pts.alloc((size_t)n * 2);
+                h2d(pts.get(), points, sizeof(double) * 2 * (size_t)n);
+            }
             DevBuf<int32_t> col((size_t)n), found((size_t)n);
             XR_LAUNCH("locate_col", k_locate_col, dim3(div_up(n, 256)), dim3(256), 0, tree->rec_fxy.get(),
                       tree->rec_len.get(), tree->record_off(), tree->m, tree->grid, tree->cell_start.get(), tree->rec_bb.get(),

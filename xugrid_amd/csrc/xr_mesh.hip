@@ -951,6 +951,22 @@ void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev) {
                   mesh->faces_raw.get(), mesh->n_face, mesh->m, cxy_dev);
 }
 
+std::shared_ptr<DevBuf<double>> mesh_centroids_shared(xr_mesh *mesh) {
+    hipStream_t st = launch_stream();
+    if (!mesh->centroids_dev) {
+        auto c = std::make_shared<DevBuf<double>>((size_t)std::max<int64_t>(mesh->n_face, 1) * 2);
+        mesh_centroids_dev(mesh, c->get());
+        if (!mesh->centroids_event) XR_HIP(hipEventCreateWithFlags(&mesh->centroids_event, hipEventDisableTiming));
+        XR_HIP(hipEventRecord(mesh->centroids_event, st));
+        mesh->centroids_stream = st;
+        mesh->centroids_dev = std::move(c);
+    } else if (st != mesh->centroids_stream) {
+        // (filled on another stream -- a points handle launches on the side stream --: this stream's work comes behind it)
+        XR_HIP(hipStreamWaitEvent(st, mesh->centroids_event, 0));
+    }
+    return mesh->centroids_dev;
+}
+
 void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order) {
     if (mesh->n_face > 0)
         XR_LAUNCH("faces_ccw", k_faces_ccw, dim3(div_up(mesh->n_face, 256)), dim3(256), 0, mesh->node_xy.get(),
@@ -1206,7 +1222,7 @@ int xr_mesh_info(const xr_mesh *mesh, int64_t *n_node, int64_t *n_face, int64_t 
 int xr_mesh_device_bytes(const xr_mesh *mesh, int64_t *bytes) {
     XR_API_BEGIN
     XR_REQUIRE(mesh && bytes, XR_ERR_INVALID, "xr_mesh_device_bytes: NULL argument");
-    size_t b = mesh->node_xy.bytes() + mesh->faces_raw.bytes() + mesh->fxy.bytes() + mesh->fxy_off.bytes() +
+    size_t b = (mesh->centroids_dev ? mesh->centroids_dev->bytes() : 0) + mesh->node_xy.bytes() + mesh->faces_raw.bytes() + mesh->fxy.bytes() + mesh->fxy_off.bytes() +
                mesh->len.bytes() + mesh->bbox.bytes() + mesh->area.bytes() + mesh->stats.bytes() + mesh->q_perm.bytes() +
                mesh->q_fxy.bytes() + mesh->q_off.bytes() + mesh->q_len.bytes() + mesh->q_bbox.bytes() +
                mesh->cell_start.bytes() + mesh->rec_bb.bytes() + mesh->rec_face.bytes() + mesh->rec_fxy.bytes() +
@@ -1247,6 +1263,7 @@ int xr_mesh_invalidate(xr_mesh *mesh) {
     mesh->indexed = false;
     mesh->stats_valid = false;
     mesh->fxy.release(); mesh->len.release(); mesh->bbox.release(); mesh->area.release(); mesh->stats.release();
+    mesh->centroids_dev.reset(); // (a handle that shares them keeps them)
     mesh->q_perm.release(); mesh->q_fxy.release(); mesh->q_len.release(); mesh->q_bbox.release(); mesh->q_off.release();
     mesh->fxy_off.release(); mesh->rec_off.release();
     mesh->cell_start.release(); mesh->rec_bb.release(); mesh->rec_face.release(); mesh->rec_fxy.release();
@@ -1270,10 +1287,8 @@ int xr_mesh_centroids(xr_mesh *mesh, double *centroids_out) {
     XR_REQUIRE(mesh && centroids_out, XR_ERR_INVALID, "xr_mesh_centroids: NULL argument");
     const int64_t F = mesh->n_face;
     if (F > 0) {
-        DevBuf<double> c((size_t)F * 2);
-        XR_LAUNCH("centroids", k_centroids, dim3(div_up(F, 256)), dim3(256), 0, mesh->node_xy.get(),
-                  mesh->faces_raw.get(), F, mesh->m, c.get());
-        d2h(centroids_out, c.get(), sizeof(double) * 2 * (size_t)F);
+        const auto c = mesh_centroids_shared(mesh);
+        d2h(centroids_out, c->get(), sizeof(double) * 2 * (size_t)F);
         stream_sync();
     }
     XR_API_END

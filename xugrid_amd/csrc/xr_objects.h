@@ -1,5 +1,6 @@
 // xr_objects.h -- the two device-resident handle types behind the C ABI.
 #pragma once
+#include <memory>
 #include <vector>
 
 #include "xr_geom.h"
@@ -30,6 +31,10 @@ struct xr_mesh {
     xr::DevBuf<uint8_t> len;  // [n_face]
     xr::DevBuf<double> bbox;  // [n_face*4] xmin,xmax,ymin,ymax
     xr::DevBuf<double> area;  // [n_face]   connectivity.area on the caller's vertex order (mesh_area, on demand)
+    hipEvent_t centroids_event = nullptr;   // recorded behind the kernel that filled centroids_dev, on centroids_stream: a user on
+    hipStream_t centroids_stream = nullptr; // another stream (the handles' kernels run on the side stream) waits for it
+    std::shared_ptr<xr::DevBuf<double>> centroids_dev; // [n_face*2] connectivity.centroids, on demand (mesh_centroids_shared); kept like
+                                                       // the reference's cached Ugrid2d.centroids until the mesh is invalidated
     xr::DevBuf<double> stats; // [8] xmin,xmax,ymin,ymax,sum_extent,max_extent,max_diagonal,sum_jump (device)
     bool stats_valid = false;
     bool stats_sampled = false; // h_stats[4..6] come from a sample of the faces ([7] = faces sampled): enough to size a grid, NOT for the default tolerance
@@ -47,6 +52,7 @@ struct xr_mesh {
     xr_mesh &operator=(const xr_mesh &) = delete;
     ~xr_mesh() {
         if (stats_host) (void)hipHostFree(stats_host);
+        if (centroids_event) (void)hipEventDestroy(centroids_event);
         if (stats_event) (void)hipEventDestroy(stats_event);
     }
 
@@ -168,5 +174,6 @@ void mesh_read_stats(xr_mesh *mesh, bool need_exact = false); // need_exact: sta
 void csr_apply_dev(const xr_csr *csr, int method, double percentile, const void *src_dev, int dtype, int64_t K, double *out_dev);
 void csr_partial_dev(const xr_csr *csr, int method, const void *src_dev, int dtype, int64_t K, double *out_dev, int rows_layout);
 void mesh_centroids_dev(xr_mesh *mesh, double *cxy_dev);    // connectivity.centroids into device memory [n_face*2]
+std::shared_ptr<xr::DevBuf<double>> mesh_centroids_shared(xr_mesh *mesh); // ... computed once per mesh, shared with the callers
 void mesh_faces_ccw_dev(xr_mesh *mesh, int64_t *faces_dev, bool caller_order = false); // CCW-normalised (or the caller's) connectivity [n_face*m]
 } // namespace xr
