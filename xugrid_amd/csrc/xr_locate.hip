@@ -559,11 +559,13 @@ __global__ void __launch_bounds__(256)
 k_bary_fill(const int64_t *__restrict__ face_of_point, const double *__restrict__ weights, int m,
             const FI *__restrict__ faces_ccw, const int64_t *__restrict__ vertex_face,
             const int32_t *__restrict__ indptr, int64_t n, int32_t *__restrict__ indices,
-            double *__restrict__ data, int64_t n_identity = 0 /* vertices below it ARE their face (the centroids): no table gather */) {
+            double *__restrict__ data, int64_t n_identity /* vertices below it ARE their face (the centroids): no table gather */,
+            int64_t capacity /* entries the two arrays hold: a block whose rows end beyond it writes nothing (the host redoes the fill) */) {
     __shared__ int32_t sh_idx[FILL_STAGE];
     __shared__ double sh_val[FILL_STAGE];
     const int64_t i0 = (int64_t)blockIdx.x * 256, i = i0 + threadIdx.x;
     const int64_t i1 = i0 + 256 < n ? i0 + 256 : n;
+    if ((int64_t)indptr[i1] > capacity) return; // (uniform)
     const int base = indptr[i0], total = indptr[i1] - base;
     const bool staged = total <= FILL_STAGE;
     if (i < n) {
@@ -943,16 +945,26 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                 XR_LAUNCH("bary_fix_count", k_bary_fix_count<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
                           faces_ccw.get(), voronoi->node_xy.get(), n2n, nv - n_extra, inside.get(), n, count.get(), n_pos.get());
             exclusive_scan_i32(count.get(), csr->indptr.get(), n);
+            // The fill needs the row pointers, not the host: it is launched into arrays sized by a guess -- seven entries per point
+            // (a Delaunay source gives six) -- BEFORE the host reads the number of entries, so that read-back, the two allocations and
+            // the launch no longer sit between the scan and the fill (55 us of an idle device per construction, timeline).  A
+            // matrix that does not fit is filled again into arrays of its real size.
+            auto fill = [&](int64_t capacity) {
+                csr->indices.alloc((size_t)capacity);
+                csr->data.alloc((size_t)capacity);
+                if (reference_order)
+                    XR_LAUNCH("bary_fill", k_bary_fill<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                              voronoi->faces_raw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity,
+                              capacity);
+                else
+                    XR_LAUNCH("bary_fill", k_bary_fill<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
+                              faces_ccw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity, capacity);
+            };
+            const int64_t guess = std::min<int64_t>(n * (int64_t)m, 7 * n + ((int64_t)1 << 16));
+            fill(guess);
             const int64_t nnz = read_scalar(csr->indptr.get() + n);
             csr->nnz = nnz;
-            csr->indices.alloc((size_t)nnz);
-            csr->data.alloc((size_t)nnz);
-            if (nnz > 0 && reference_order)
-                XR_LAUNCH("bary_fill", k_bary_fill<int32_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          voronoi->faces_raw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity);
-            else if (nnz > 0)
-                XR_LAUNCH("bary_fill", k_bary_fill<int64_t>, dim3(div_up(n, 256)), dim3(256), 0, face.get(), w.get(), m,
-                          faces_ccw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity);
+            if (nnz > guess) fill(nnz);
             stream_sync();
         }
     } catch (...) {
@@ -1127,12 +1139,12 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
                       tree->rec_len.get(), tree->record_off(), tree->m, tree->grid, tree->cell_start.get(), tree->rec_bb.get(),
                       tree->rec_face.get(), tree->n_face, pts.get(), n, tol, col.get(), found.get());
             exclusive_scan_i32(found.get(), csr->indptr.get(), n);
+            // (a point has at most one entry: the arrays hold n, and the fill is enqueued in front of the read-back of nnz)
+            csr->indices.alloc((size_t)n);
+            csr->data.alloc((size_t)n);
+            XR_LAUNCH("locate_fill", k_locate_fill, dim3(div_up(n, 256)), dim3(256), 0, col.get(), csr->indptr.get(), n,
+                      csr->indices.get(), csr->data.get());
             csr->nnz = read_scalar(csr->indptr.get() + n);
-            csr->indices.alloc((size_t)csr->nnz);
-            csr->data.alloc((size_t)csr->nnz);
-            if (csr->nnz > 0)
-                XR_LAUNCH("locate_fill", k_locate_fill, dim3(div_up(n, 256)), dim3(256), 0, col.get(), csr->indptr.get(), n,
-                          csr->indices.get(), csr->data.get());
             stream_sync();
         }
     } catch (...) {
