@@ -720,7 +720,9 @@ def other_configs(E, lib, _lib, csr, S, T, mesh, mesh_xy, src_faces=None, delaun
             "note": "source and target meshes resident; construct_ms = median of 5 constructions on a source whose Voronoi "
             "tessellation is not cached (device pre-step + native O(boundary) part + xr_barycentric_csr); "
             "construct_ms_voronoi_cached = a further interpolator on the same source (the tessellation, its prepared "
-            "arrays and its index are kept on the Ugrid2d, like its celltree)",
+            "arrays and its index are kept on the Ugrid2d, like its celltree).  In both figures the target's face centroids come "
+            "from its mesh, where the untimed first construction left them (round 6; the reference caches Ugrid2d.centroids on the "
+            "grid the same way): a target that has never been one pays 0.08 ms more",
         }
         del rg, src_g, tgt_g
     except Exception as e:  # noqa: BLE001
