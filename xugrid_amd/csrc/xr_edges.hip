@@ -593,7 +593,9 @@ k_edge_clip(const double *__restrict__ edge_xy, const double *__restrict__ rec_f
 __global__ void __launch_bounds__(256)
 k_edge_fill(const int2 *__restrict__ queue, const double *__restrict__ queue_len, const int32_t *__restrict__ queue_rank,
             int64_t region_cap, const int32_t *__restrict__ counters, const int32_t *__restrict__ indptr,
-            int32_t *__restrict__ indices, double *__restrict__ data) {
+            int32_t *__restrict__ indices, double *__restrict__ data,
+            int64_t capacity /* entries the two arrays hold: the launch may precede the host's read of nnz */) {
+    if (counters[2] & 1) return; // (a region overflowed: nothing was clipped)
     constexpr int U = 4; // entries per thread and round, their loads in flight together
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int x = 0; x < 8; x++) {
@@ -612,7 +614,7 @@ k_edge_fill(const int2 *__restrict__ queue, const double *__restrict__ queue_len
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                if (pr[u].x >= 0) {
+                if (pr[u].x >= 0 && pos[u] < capacity) {
                     indices[pos[u]] = pr[u].x;
                     data[pos[u]] = len[u];
                 }
@@ -843,29 +845,45 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
         else XR_EDGE_CLIP(0);
 #undef XR_EDGE_CLIP
         exclusive_scan_i32(row_count.get(), csr->indptr.get(), F);
-        int32_t c[EQ_WORDS];
-        d2h(c, counters.get(), sizeof(c));
-        int64_t longest = 0, pairs = 0;
-        for (int x = 0; x < 8; x++) {
-            const int64_t n = c[EQ_CURSORS + x * EQ_STRIDE] < 0 ? ((int64_t)1 << 31) : c[EQ_CURSORS + x * EQ_STRIDE];
-            longest = std::max(longest, n);
-            pairs += n;
-        }
-        if (c[2] & 1) { // (the cursors kept counting: they say what the regions need)
-            queue_pairs = std::max(2 * queue_pairs, 8 * (longest + longest / 8 + 1024));
-            continue;
-        }
-        const int32_t P = read_scalar(csr->indptr.get() + F);
+        // The fill needs the row pointers, not the host: it goes into arrays sized by a guess (five pieces per edge; the benchmark
+        // network has four) BEFORE the host reads the cursors and nnz -- the two read-backs, two allocations and the launch no
+        // longer sit between the scan and the fill with the device idle.  A matrix that does not fit is filled again.
+        auto fill = [&](int64_t capacity) {
+            csr->indices.alloc((size_t)capacity);
+            csr->data.alloc((size_t)capacity);
+            XR_LAUNCH("edges_fill", k_edge_fill, dim3(grid_persistent), dim3(256), 0, queue.get(), queue_len.get(), queue_rank.get(),
+                      region_cap, counters.get(), csr->indptr.get(), csr->indices.get(), csr->data.get(), capacity);
+        };
+        const int64_t guess = std::min<int64_t>(8 * region_cap, 5 * n_edge + ((int64_t)1 << 16));
+        // (ONE read-back on the way: nnz, with the fill enqueued behind the copy -- it runs while the value travels and the host
+        // sizes the row sort.  A queue region that overflowed left the clip and the fill idle and every row empty: nnz = 0 then,
+        // and only then -- or for the debug line -- the cursors are read as well.)
+        const int32_t P = read_scalar(csr->indptr.get() + F, [&] { fill(guess); });
         XR_REQUIRE(P >= 0, XR_ERR_LIMIT, "nnz exceeds the int32 range");
-        if (option(OPT_DEBUG) & 8)
-            fprintf(stderr, "[edges] %lld edges: %d with a wave of their own, %lld candidate pairs (queue %lld), nnz %d\n",
-                    (long long)n_edge, c[0], (long long)pairs, (long long)(8 * region_cap), P);
+        if (P == 0 || (option(OPT_DEBUG) & 8)) {
+            int32_t c[EQ_WORDS];
+            d2h(c, counters.get(), sizeof(c));
+            int64_t longest = 0, pairs = 0;
+            for (int x = 0; x < 8; x++) {
+                const int64_t n = c[EQ_CURSORS + x * EQ_STRIDE] < 0 ? ((int64_t)1 << 31) : c[EQ_CURSORS + x * EQ_STRIDE];
+                longest = std::max(longest, n);
+                pairs += n;
+            }
+            if (c[2] & 1) { // (the cursors kept counting: they say what the regions need)
+                queue_pairs = std::max(2 * queue_pairs, 8 * (longest + longest / 8 + 1024));
+                continue;
+            }
+            if (option(OPT_DEBUG) & 8)
+                fprintf(stderr, "[edges] %lld edges: %d with a wave of their own, %lld candidate pairs (queue %lld), nnz %d\n",
+                        (long long)n_edge, c[0], (long long)pairs, (long long)(8 * region_cap), P);
+        }
         csr->nnz = P;
-        csr->indices.alloc((size_t)P);
-        csr->data.alloc((size_t)P);
-        if (P == 0) return;
-        XR_LAUNCH("edges_fill", k_edge_fill, dim3(grid_persistent), dim3(256), 0, queue.get(), queue_len.get(), queue_rank.get(),
-                  region_cap, counters.get(), csr->indptr.get(), csr->indices.get(), csr->data.get());
+        if (P > guess) fill(P);
+        if (P == 0) {
+            csr->indices.alloc(0);
+            csr->data.alloc(0);
+            return;
+        }
         break;
     }
     const int32_t P = (int32_t)csr->nnz;
@@ -876,17 +894,14 @@ static void edge_length_csr(xr_mesh *tree, const double *edge_xy_host, int64_t n
     XR_LAUNCH("edge_rows_sort", k_edge_rows_sort, dim3(div_up(F, 256)), dim3(256), 0, csr->indptr.get(), F,
               csr->indices.get(), csr->data.get(), sort_list.get(), counters.get() + 1, csr->long_rows.get(),
               csr->n_long.get());
-    int32_t h[2];
-    d2h(h, counters.get(), sizeof(h));
+    // (the queued rows' kernel reads their number on the device: it is launched without the host knowing it -- one read-back at
+    // the end, of the long-row count the apply wants, instead of two in front of this launch)
+    DevBuf<int32_t> tmp_idx((size_t)P);
+    DevBuf<double> tmp_val((size_t)P);
+    XR_LAUNCH("edge_rows_sort_big", k_edge_rows_sort_big, dim3(engine().num_cu * 4), dim3(256), 0, csr->indptr.get(),
+              csr->indices.get(), csr->data.get(), sort_list.get(), counters.get() + 1, tmp_idx.get(), tmp_val.get());
     csr->has_long = read_scalar(csr->n_long.get()) > 0;
-    if (h[1] > 0) {
-        DevBuf<int32_t> tmp_idx((size_t)P);
-        DevBuf<double> tmp_val((size_t)P);
-        XR_LAUNCH("edge_rows_sort_big", k_edge_rows_sort_big, dim3(std::min<int>(h[1], engine().num_cu * 4)), dim3(256),
-                  0, csr->indptr.get(), csr->indices.get(), csr->data.get(), sort_list.get(), counters.get() + 1,
-                  tmp_idx.get(), tmp_val.get());
-        stream_sync();
-    }
+    stream_sync();
 }
 
 } // namespace xr

@@ -461,8 +461,14 @@ void h2d(void *dst, const void *src, size_t bytes) {
     XR_HIP(hipStreamSynchronize(launch_stream()));
 }
 
-void d2h(void *dst, const void *src, size_t bytes) {
-    if (!bytes) return;
+static void d2h_impl(void *dst, const void *src, size_t bytes, const std::function<void()> *behind);
+void d2h(void *dst, const void *src, size_t bytes) { d2h_impl(dst, src, bytes, nullptr); }
+void d2h(void *dst, const void *src, size_t bytes, const std::function<void()> &behind) { d2h_impl(dst, src, bytes, &behind); }
+static void d2h_impl(void *dst, const void *src, size_t bytes, const std::function<void()> *behind) {
+    if (!bytes) {
+        if (behind) (*behind)();
+        return;
+    }
     if (bytes <= FAST_D2H_MAX && (reinterpret_cast<uintptr_t>(src) & 3) == 0 && fast_copy_allowed()) {
         fast_copy_init();
         Engine &e = engine();
@@ -475,6 +481,7 @@ void d2h(void *dst, const void *src, size_t bytes) {
                            reinterpret_cast<uint32_t *>(g_fast.page), n_words, static_cast<const uint8_t *>(src) + 4 * n_words,
                            reinterpret_cast<uint8_t *>(g_fast.page) + 4 * n_words, n_tail, g_fast.done, seq_word, g_fast.seq);
         XR_HIP(hipGetLastError());
+        if (behind) (*behind)(); // (enqueued behind the copy: it runs while the host waits for the words and works on them)
         const auto t0 = std::chrono::steady_clock::now();
         bool seen = true;
         for (uint64_t spins = 0; *seq_word != g_fast.seq; spins++) {
@@ -488,10 +495,15 @@ void d2h(void *dst, const void *src, size_t bytes) {
         XR_REQUIRE(seen, XR_ERR_HIP, "read-back sequence word missing after synchronisation");
         std::atomic_thread_fence(std::memory_order_acquire);
         memcpy(dst, g_fast.page, bytes);
+        if (behind) return; // (work was enqueued behind the copy: the stream is not drained)
         // (everything in front of the copy kernel has executed: the stream is drained as far as pool blocks are concerned)
         e.main_busy = false;
         pool_release_deferred(/*may_block=*/false);
         return;
+    }
+    if (behind) { // (no mailbox here -- a caller's stream, a lane --: the plain order, the work first)
+        (*behind)();
+        behind = nullptr;
     }
     if (bytes <= 4096) {
         // scalar read-backs go through the pinned page: no pageable staging, one sync

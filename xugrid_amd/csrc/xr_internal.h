@@ -195,6 +195,9 @@ void zero_scratch_done(int slot);
 
 void h2d(void *dst, const void *src, size_t bytes);       // synchronous w.r.t. the host
 void d2h(void *dst, const void *src, size_t bytes);       // stream-ordered, then synchronised
+// ... with work for the device to do meanwhile: `behind` is called once the copy has been enqueued and before the host waits for it
+// -- what it launches runs while the value travels (a kernel that needs the device-side result but not the host's knowledge of it).
+void d2h(void *dst, const void *src, size_t bytes, const std::function<void()> &behind);
 void stream_sync();
 // XR_HOST_STAMPS=1: wall-clock stamps at a few points of the host path, averaged per point and printed at exit (where the
 // host's time goes between the mailbox of one weight build and the first kernel of the next -- profiles/r04_host_stamps.txt)
@@ -215,6 +218,11 @@ void d2h_big(void *dst, const void *src, size_t bytes);
 template <typename T> T read_scalar(const T *dev) {
     T v;
     d2h(&v, dev, sizeof(T));
+    return v;
+}
+template <typename T> T read_scalar(const T *dev, const std::function<void()> &behind) {
+    T v;
+    d2h(&v, dev, sizeof(T), behind);
     return v;
 }
 

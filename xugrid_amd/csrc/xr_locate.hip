@@ -961,8 +961,7 @@ static void barycentric_csr(xr_mesh *voronoi, xr_mesh *source, xr_mesh *query, c
                               faces_ccw.get(), vface, csr->indptr.get(), n, csr->indices.get(), csr->data.get(), n_identity, capacity);
             };
             const int64_t guess = std::min<int64_t>(n * (int64_t)m, 7 * n + ((int64_t)1 << 16));
-            fill(guess);
-            const int64_t nnz = read_scalar(csr->indptr.get() + n);
+            const int64_t nnz = read_scalar(csr->indptr.get() + n, [&] { fill(guess); }); // (the fill behind the copy: it runs while nnz travels)
             csr->nnz = nnz;
             if (nnz > guess) fill(nnz);
             stream_sync();
@@ -1142,9 +1141,10 @@ int xr_locate_csr(xr_mesh *tree, xr_mesh *query, const double *points, int64_t n
             // (a point has at most one entry: the arrays hold n, and the fill is enqueued in front of the read-back of nnz)
             csr->indices.alloc((size_t)n);
             csr->data.alloc((size_t)n);
-            XR_LAUNCH("locate_fill", k_locate_fill, dim3(div_up(n, 256)), dim3(256), 0, col.get(), csr->indptr.get(), n,
-                      csr->indices.get(), csr->data.get());
-            csr->nnz = read_scalar(csr->indptr.get() + n);
+            csr->nnz = read_scalar(csr->indptr.get() + n, [&] {
+                XR_LAUNCH("locate_fill", k_locate_fill, dim3(div_up(n, 256)), dim3(256), 0, col.get(), csr->indptr.get(), n,
+                          csr->indices.get(), csr->data.get());
+            });
             stream_sync();
         }
     } catch (...) {
