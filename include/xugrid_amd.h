@@ -148,7 +148,8 @@ int xr_mesh_device_bytes(const xr_mesh *mesh, int64_t *bytes);
 int xr_mesh_prepare(xr_mesh *mesh);
 /* Spatial index over the faces of this mesh (the "tree" side): hierarchical uniform grid. */
 int xr_mesh_build_index(xr_mesh *mesh);
-/* Drop all derived state (prepare + index); used by benchmarks to time the whole path. */
+/* Drop all derived state (prepare + index + the face centroids a locate / barycentric call left on the mesh -- the
+ * reference caches Ugrid2d.centroids on the grid the same way); used by benchmarks to time the whole path. */
 int xr_mesh_invalidate(xr_mesh *mesh);
 /* Face areas, connectivity.area (xugrid/ugrid/connectivity.py:615-633) -> float64[n_face]. */
 int xr_mesh_area(xr_mesh *mesh, double *area_out);
