@@ -441,7 +441,7 @@ k_locate_flag(const double *__restrict__ rec_fxy, const uint8_t *__restrict__ re
 // triangle tests instead of a grid walk + ~18 box tests + the exact tests of the parked records: 1M faces / 4M points,
 // locate_flag 284 us (175 us of vector instructions, PMC) -> see DESIGN.
 // The faces' vertices come from the source mesh's own face-major block (fxy: counter-clockwise-normalised, caller's face order --
-// what the tree's records hold, so the test sees the same directed edges and roundings), FOUR faces per round with all their loads
+// what the tree's records hold, so the test sees the same directed edges and roundings), TWO faces per round with all their loads
 // in flight together: as a chain cell row -> connectivity -> nodes per face the kernel took 295 us for 4M points.
 template <int MS> // nodes per face of a dense source mesh (3, 4); 0: any mesh, one face at a time
 __global__ void __launch_bounds__(256)
@@ -459,7 +459,7 @@ k_star_flag(const int64_t *__restrict__ cell_of_point, const int32_t *__restrict
     const P2 p = load_p2(pts, (int)i);
     const int32_t *row = cells + cell * mv;
     uint8_t flag = STAR_OPEN;
-    constexpr int B = 4;
+    constexpr int B = 2; // faces per round (4M points, 1M-face Delaunay source: 1 face 0.234 ms, 2: 0.132, 3: 0.150, 4: 0.158, 6: 0.201 -- registers against rounds)
     bool open = true; // (the row's fill has not been met)
     for (int j0 = 0; j0 < mv && open && flag == STAR_OPEN; j0 += B) {
         int64_t f[B];
