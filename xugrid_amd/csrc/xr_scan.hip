@@ -37,6 +37,36 @@ __device__ __forceinline__ int block_excl_scan(int v, int *total, int *lds /* >=
     return woff + incl - v;
 }
 
+// a thread's SCAN_ITEMS consecutive elements as two 16-byte accesses (the tile base and every thread's offset are multiples of
+// eight elements, the arrays come from the pool: 32-byte aligned); element by element only in the one tile that holds the end
+__device__ __forceinline__ void load_items(const int32_t *__restrict__ in, int64_t base, int64_t n, int (&v)[SCAN_ITEMS]) {
+    static_assert(SCAN_ITEMS == 8, "two int4 per thread");
+    if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        const int4 a = *reinterpret_cast<const int4 *>(in + base), b = *reinterpret_cast<const int4 *>(in + base + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) v[i] = base + i < n ? in[base + i] : 0;
+    }
+}
+__device__ __forceinline__ void store_scanned(int32_t *__restrict__ out, int64_t base, int64_t n, const int (&v)[SCAN_ITEMS], int ex) {
+    int o[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        o[i] = ex;
+        ex += v[i];
+    }
+    if (base + SCAN_ITEMS <= n && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+        *reinterpret_cast<int4 *>(out + base) = make_int4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<int4 *>(out + base + 4) = make_int4(o[4], o[5], o[6], o[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++)
+            if (base + i < n) out[base + i] = o[i];
+    }
+}
+
 __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_reduce(const int32_t *__restrict__ in,
                                                             int32_t *__restrict__ block_sums, int64_t n) {
     __shared__ int lds[4];
@@ -78,21 +108,13 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply(const int32_t *__rest
     // thread owns SCAN_ITEMS consecutive elements so the scan order is the array order
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
+    load_items(in, base, n, v);
     int s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        int64_t j = base + i;
-        v[i] = j < n ? in[j] : 0;
-        s += v[i];
-    }
+    for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
     int tot;
-    int ex = block_excl_scan(s, &tot, lds) + block_off[blockIdx.x];
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        int64_t j = base + i;
-        if (j < n) out[j] = ex;
-        ex += v[i];
-    }
+    const int ex = block_excl_scan(s, &tot, lds) + block_off[blockIdx.x];
+    store_scanned(out, base, n, v, ex);
 }
 
 __global__ void k_fill_i32(int32_t *p, int32_t v, int64_t n) {
@@ -123,20 +145,12 @@ __global__ void __launch_bounds__(SCAN_BLOCK) k_scan_apply_fused(const int32_t *
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
+    load_items(in, base, n, v);
     int s = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const int64_t j = base + i;
-        v[i] = j < n ? in[j] : 0;
-        s += v[i];
-    }
-    int ex = block_excl_scan(s, &tot, lds) + sh_base;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const int64_t j = base + i;
-        if (j < n) out[j] = ex;
-        ex += v[i];
-    }
+    for (int i = 0; i < SCAN_ITEMS; i++) s += v[i];
+    const int ex = block_excl_scan(s, &tot, lds) + sh_base;
+    store_scanned(out, base, n, v, ex);
     if (blockIdx.x == nb - 1 && threadIdx.x == 0) {
         out[n] = sh_base + tot; // grand total
         if (host_total) *host_total = sh_base + tot;
