@@ -116,6 +116,16 @@ def test_every_edge_kernel_path_equals_oracle(hip, oracle, xr_option):
         device_vs_oracle(oracle, nodes, faces, edges)
 
 
+def test_more_pieces_than_the_fill_guessed(hip, oracle):
+    """The CSR fill is enqueued into arrays sized by a guess (five pieces per edge) before the host knows nnz; a matrix that does
+    not fit is filled again into arrays of its real size: 12 000 edges across half of an 80 x 80 raster, ~50 pieces each."""
+    nodes, faces = raster_quads(np.linspace(0.0, 1.0, 81), np.linspace(0.0, 1.0, 81))
+    rng = np.random.default_rng(5)
+    edges = random_network(rng, 12_000, 0.0, 1.0, 0.5)
+    csr, (w, cols, indptr) = device_vs_oracle(oracle, nodes, faces, edges)
+    assert csr.nnz > 5 * edges.shape[0] + (1 << 16), "the case no longer exceeds the guess"
+
+
 def _sample(grid_values, shape, x_loc, y_loc, y_descending):
     ny, nx = shape
     i = np.floor(x_loc).astype(int)

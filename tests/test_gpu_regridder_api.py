@@ -890,3 +890,35 @@ def test_config1_as_survey_words_it(hip, oracle, golden):
     t = int(np.argmax(np.diff(w.indptr)))
     sl = slice(w.indptr[t], w.indptr[t + 1])
     np.testing.assert_allclose(out.ravel()[t], (w.data[sl] * elev[w.indices[sl]].astype(np.float64)).sum() / w.data[sl].sum(), rtol=1e-12)
+
+
+def test_barycentric_rows_longer_than_the_guess(hip, oracle):
+    """The barycentric CSR is filled into arrays sized by a guess (seven entries per point) before the host knows nnz; a matrix
+    that does not fit is filled again into arrays of its real size.  A fan of 16 triangles around one node: the node's Voronoi
+    cell has 16 corners, and 30 000 points inside it carry 16 weights each -- more than twice the guess.  Device == oracle."""
+    from xugrid_amd import engine
+
+    n_sector = 16
+    ang = 2 * np.pi * np.arange(n_sector) / n_sector
+    ring1 = np.column_stack([np.cos(ang), np.sin(ang)])
+    ring2 = 2.0 * np.column_stack([np.cos(ang + 0.1), np.sin(ang + 0.1)])
+    xy = np.vstack([[0.0, 0.0], ring1, ring2])
+    faces = []
+    for i in range(n_sector):
+        j = (i + 1) % n_sector
+        faces.append([0, 1 + i, 1 + j])
+        faces.append([1 + i, 1 + n_sector + i, 1 + n_sector + j])
+        faces.append([1 + i, 1 + n_sector + j, 1 + j])
+    faces = np.array(faces, dtype=np.int64)
+    src = xa.Ugrid2d(xy[:, 0], xy[:, 1], -1, faces)
+    rng = np.random.default_rng(3)
+    r, a = 0.3 * np.sqrt(rng.random(30_000)), rng.uniform(0, 2 * np.pi, 30_000)
+    pts = np.ascontiguousarray(np.column_stack([r * np.cos(a), r * np.sin(a)]))
+    us = xa.regrid.UnstructuredGrid2d(src)
+    voronoi_mesh, face_index_tail, n2n = us._voronoi_device()
+    c = engine.barycentric_csr(voronoi_mesh, src.device_mesh, face_index_tail, n2n, points=pts, n_identity=src.n_face)
+    data, indices, indptr = c.download()
+    assert c.nnz > 7 * pts.shape[0] + (1 << 16), "the case no longer exceeds the guess"
+    os_, ot, ow = oracle_barycentric_triplets(oracle, src, pts)
+    rows = np.repeat(np.arange(c.n), np.diff(indptr))
+    assert np.array_equal(indices, os_) and np.array_equal(rows, ot) and np.array_equal(data, ow)
